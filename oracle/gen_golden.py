@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python oracle/gen_golden.py
+
+  * sample_proc_<case>.npz : inputs + outputs of the reference's own
+    MetaSampleProcessor / LinearFeatureBaseline / utils (imported from /root/reference, which is
+    importable after stubbing the absent ``pyprind`` progress-bar package -- SURVEY.md 8c).
+  * promp_autograd_<case>.npz : inputs + loss / KLs / exact meta-gradient of the ProMP
+    meta-objective computed by torch.autograd (float64, double backward) on a direct
+    transcription of the TF graph's forward arithmetic.  TensorFlow is absent, so this is the
+    independent autodiff that pins oracle/promp.py's hand-derived gradient + HVP.
+
+Only data (inputs and expected outputs) is written; no reference source is copied.
+/root/reference does not exist on the GPU box: nothing imports this module at test time.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+from promp_amd import synthetic  # noqa: E402
+
+
+def _import_reference():
+    sys.path.insert(0, '/root/reference')
+    shim = types.ModuleType('pyprind')
+
+    class ProgBar:
+        def __init__(self, *a, **k): pass
+        def update(self, *a, **k): pass
+        def stop(self, *a, **k): pass
+    shim.ProgBar = ProgBar
+    sys.modules['pyprind'] = shim
+    from meta_policy_search.samplers.meta_sample_processor import MetaSampleProcessor
+    from meta_policy_search.baselines.linear_baseline import LinearFeatureBaseline, LinearTimeBaseline
+    from meta_policy_search.baselines.zero_baseline import ZeroBaseline
+    from meta_policy_search.utils import utils
+    return MetaSampleProcessor, dict(zero=ZeroBaseline, linear_feature=LinearFeatureBaseline,
+                                     linear_time=LinearTimeBaseline), utils
+
+
+SAMPLE_PROC_CASES = {
+    # name: (seed, dims, processor kwargs, baseline, extras)
+    'default':      (11, dict(M=3, P=4, T=40, O=5, A=2), dict(discount=0.99, gae_lambda=1.0, normalize_adv=True), 'linear_feature', {}),
+    'gae095':       (12, dict(M=3, P=4, T=40, O=5, A=2), dict(discount=0.99, gae_lambda=0.95, normalize_adv=False), 'linear_feature', {}),
+    'undiscounted': (13, dict(M=2, P=5, T=30, O=3, A=2), dict(discount=1.0, gae_lambda=1.0, normalize_adv=False), 'linear_feature', {}),
+    'positive':     (14, dict(M=3, P=4, T=40, O=5, A=2), dict(discount=0.99, gae_lambda=1.0, normalize_adv=True, positive_adv=True), 'linear_feature', {}),
+    'ragged':       (15, dict(M=4, P=5, T=50, O=6, A=3), dict(discount=0.99, gae_lambda=0.97, normalize_adv=True), 'linear_feature', dict(ragged=True)),
+    'clipped_obs':  (16, dict(M=3, P=4, T=40, O=5, A=2), dict(discount=0.99, gae_lambda=1.0, normalize_adv=True), 'linear_feature', dict(obs_scale=4.0)),
+    'float64_obs':  (17, dict(M=2, P=4, T=40, O=5, A=2), dict(discount=0.99, gae_lambda=1.0, normalize_adv=True), 'linear_feature', dict(obs_dtype='float64')),
+    'zero_base':    (18, dict(M=3, P=4, T=25, O=2, A=2), dict(discount=1.0, gae_lambda=1.0, normalize_adv=False), 'zero', {}),
+    'time_base':    (19, dict(M=3, P=4, T=40, O=5, A=2), dict(discount=0.99, gae_lambda=1.0, normalize_adv=True), 'linear_time', {}),
+    'halfcheetah':  (20, dict(M=2, P=3, T=200, O=20, A=6), dict(discount=0.99, gae_lambda=1.0, normalize_adv=True), 'linear_feature', {}),
+}
+
+
+def make_sample_proc_inputs(seed, dims, extras):
+    rng = np.random.RandomState(seed)
+    hidden = (8, 8)
+    theta = synthetic.init_theta(rng, dims['O'], hidden, dims['A'])
+    paths = synthetic.make_paths(rng, theta, dims['M'], dims['P'], dims['T'], dims['O'], dims['A'], hidden,
+                                 ragged=extras.get('ragged', False),
+                                 obs_dtype=np.dtype(extras.get('obs_dtype', 'float32')))
+    if 'obs_scale' in extras:
+        for plist in paths.values():
+            for p in plist:
+                p['observations'] = (p['observations'] * extras['obs_scale']).astype(p['observations'].dtype)
+    return paths
+
+
+def gen_sample_proc():
+    MetaSampleProcessor, baselines, utils = _import_reference()
+    # reference logger is only touched when log != False
+    for name, (seed, dims, kw, bname, extras) in SAMPLE_PROC_CASES.items():
+        paths = make_sample_proc_inputs(seed, dims, extras)
+        lens = np.array([[len(p['rewards']) for p in plist] for plist in paths.values()], dtype=np.int32)
+        obs = np.concatenate([p['observations'] for plist in paths.values() for p in plist])
+        act = np.concatenate([p['actions'] for plist in paths.values() for p in plist])
+        rew = np.concatenate([p['rewards'] for plist in paths.values() for p in plist])
+        base = baselines[bname]()
+        proc = MetaSampleProcessor(baseline=base, **kw)
+        coeffs = []
+        # run task by task through the reference's own per-task routine to capture the coefficients
+        # (the shared baseline object is re-fit per task, linear_baseline.py:70), then the full method.
+        import copy
+        for plist in copy.deepcopy(paths).values():
+            proc._compute_samples_data(plist)
+            c = base.get_param_values() if bname != 'zero' else None
+            coeffs.append(np.zeros(0) if c is None else np.array(c, dtype=np.float64))
+        out = proc.process_samples(paths, log=False)
+        all_paths = [p for plist in paths.values() for p in plist]
+        stats = dict(AverageDiscountedReturn=float(np.mean([p['returns'][0] for p in all_paths])),
+                     AverageReturn=float(np.mean([sum(p['rewards']) for p in all_paths])),
+                     StdReturn=float(np.std([sum(p['rewards']) for p in all_paths])),
+                     MaxReturn=float(np.max([sum(p['rewards']) for p in all_paths])),
+                     MinReturn=float(np.min([sum(p['rewards']) for p in all_paths])),
+                     NumTrajs=len(all_paths))
+        np.savez_compressed(
+            os.path.join(GOLDEN, 'sample_proc_%s.npz' % name),
+            meta=json.dumps(dict(seed=seed, dims=dims, kwargs=kw, baseline=bname, extras=extras, stats=stats,
+                                 keys=sorted(out[0].keys()))),
+            path_lengths=lens, observations=obs, actions=act, rewards=rew,
+            returns=np.concatenate([sd['returns'] for sd in out]),
+            advantages=np.concatenate([sd['advantages'] for sd in out]),
+            adj_avg_rewards=np.concatenate([sd['adj_avg_rewards'] for sd in out]),
+            coeffs=np.stack(coeffs),
+            # utils.discount_cumsum on the first path, pinned separately
+            dc_first=utils.discount_cumsum(all_paths[0]['rewards'], kw['discount']),
+        )
+        print('wrote sample_proc_%s.npz  N=%d' % (name, len(rew)))
+
+
+# --------------------------------------------------------------------------------------------------
+PROMP_CASES = {
+    'k1_small': dict(seed=101, M=3, P=2, T=12, O=5, A=3, hidden=(8, 8), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1),
+    'k1_hc':    dict(seed=102, M=2, P=2, T=20, O=20, A=6, hidden=(64, 64), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1),
+    'k1_stdclip': dict(seed=103, M=2, P=2, T=12, O=4, A=3, hidden=(8, 8), K=1, clip_eps=0.2, eta=[1e-2], alpha=0.1,
+                       low_log_std=True),
+    'k2_small': dict(seed=104, M=2, P=2, T=10, O=4, A=2, hidden=(8, 8), K=2, clip_eps=0.3, eta=[5e-4, 1e-3], alpha=0.05),
+}
+
+
+def make_promp_inputs(c):
+    """Slabs for steps 0..K with real advantages spread and ratio != 1 at the outer step."""
+    rng = np.random.RandomState(c['seed'])
+    O, A, hidden, M = c['O'], c['A'], c['hidden'], c['M']
+    theta = synthetic.init_theta(rng, O, hidden, A)
+    theta = (theta + 0.05 * rng.randn(theta.size)).astype(np.float32)
+    if c.get('low_log_std'):
+        theta[-A:] = np.log(1e-6) + np.array([-0.5, 0.5, -1.0][:A])   # straddles the min_std clip
+    all_slabs = []
+    for k in range(c['K'] + 1):
+        # "old" policy differs slightly from theta so that ratio != 1 and the clip is active on some rows
+        theta_old = (theta + 0.1 * rng.randn(M, theta.size)).astype(np.float32)
+        if c.get('low_log_std'):
+            # sigma ~ 1e-6: keep the old means equal to the new ones so that z stays O(1)
+            theta_old = np.tile(theta, (M, 1))
+        paths = synthetic.make_paths(rng, theta_old, M, c['P'], c['T'], O, A, hidden)
+        slabs = []
+        for plist in paths.values():
+            cat = lambda key: np.concatenate([p[key] for p in plist])
+            n = len(cat('rewards'))
+            slabs.append(dict(observations=cat('observations'), actions=cat('actions'),
+                              advantages=rng.randn(n).astype(np.float32),
+                              agent_infos=dict(mean=np.concatenate([p['agent_infos']['mean'] for p in plist]),
+                                               log_std=np.concatenate([p['agent_infos']['log_std'] for p in plist]))))
+        all_slabs.append(slabs)
+    return theta, all_slabs
+
+
+def torch_meta_objective(theta, all_slabs, c, min_log_std=float(np.log(1e-6))):
+    """Direct transcription of the TF forward graph (pro_mp.py:88-155) in torch float64;
+    gradients come from torch.autograd (create_graph through the inner step)."""
+    import torch
+    O, A, hidden = c['O'], c['A'], c['hidden']
+    sizes = (O,) + tuple(hidden) + (A,)
+    th = torch.tensor(np.asarray(theta, dtype=np.float64), requires_grad=True)
+    alpha = c['alpha']
+
+    def split(t):
+        parts, off = [], 0
+        for i in range(len(sizes) - 1):
+            n = sizes[i] * sizes[i + 1]
+            parts.append(t[off:off + n].reshape(sizes[i], sizes[i + 1])); off += n
+            parts.append(t[off:off + sizes[i + 1]]); off += sizes[i + 1]
+        parts.append(t[off:off + A])
+        return parts
+
+    def dist(t, obs, clip):
+        p = split(t)
+        x = obs
+        for i in range(len(sizes) - 1):
+            x = x @ p[2 * i] + p[2 * i + 1]
+            if i < len(sizes) - 2:
+                x = torch.tanh(x)
+        s = p[-1]
+        if clip:
+            s = torch.maximum(s, torch.tensor(min_log_std, dtype=torch.float64))
+        return x, s
+
+    def logli(a, mu, s):
+        z = (a - mu) / torch.exp(s)
+        return -(s * torch.ones_like(mu)).sum(-1) - 0.5 * (z ** 2).sum(-1) - 0.5 * A * np.log(2 * np.pi)
+
+    def kl(om, ols, mu, s):
+        num = (om - mu) ** 2 + torch.exp(ols) ** 2 - torch.exp(s) ** 2
+        den = 2 * torch.exp(s) ** 2 + 1e-8
+        return (num / den + s - ols).sum(-1)
+
+    T = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+    K, M = c['K'], c['M']
+    surr, okls = [], []
+    ikls = [[] for _ in range(K)]
+    for i in range(M):
+        cur, clip = th, True
+        for k in range(K):
+            sl = all_slabs[k][i]
+            mu, s = dist(cur, T(sl['observations']), clip)
+            om, ols = T(sl['agent_infos']['mean']), T(sl['agent_infos']['log_std'])
+            ratio = torch.exp(logli(T(sl['actions']), mu, s) - logli(T(sl['actions']), om, ols))
+            inner = -(ratio * T(sl['advantages'])).mean()
+            ikls[k].append(kl(om, ols, mu, s).mean())
+            g, = torch.autograd.grad(inner, cur, create_graph=True)
+            cur, clip = cur - alpha * g, False
+        sl = all_slabs[K][i]
+        mu, s = dist(cur, T(sl['observations']), False)
+        om, ols = T(sl['agent_infos']['mean']), T(sl['agent_infos']['log_std'])
+        ratio = torch.exp(logli(T(sl['actions']), mu, s) - logli(T(sl['actions']), om, ols))
+        adv = T(sl['advantages'])
+        clipped = torch.minimum(ratio * adv, torch.clamp(ratio, 1 - c['clip_eps'], 1 + c['clip_eps']) * adv)
+        surr.append(-clipped.mean())
+        okls.append(kl(om, ols, mu, s).mean())
+    mean_ikl = torch.stack([torch.stack(x).mean() for x in ikls])
+    loss = torch.stack(surr).mean() + (torch.tensor(c['eta'], dtype=torch.float64) * mean_ikl).mean()
+    grad, = torch.autograd.grad(loss, th)
+    return float(loss.detach()), mean_ikl.detach().numpy(), float(torch.stack(okls).mean().detach()), grad.numpy()
+
+
+def gen_promp():
+    for name, c in PROMP_CASES.items():
+        theta, all_slabs = make_promp_inputs(c)
+        loss, ikl, okl, grad = torch_meta_objective(theta, all_slabs, c)
+        flat = {}
+        for k, slabs in enumerate(all_slabs):
+            for key in ('observations', 'actions', 'advantages'):
+                flat['step%d_%s' % (k, key)] = np.stack([s[key] for s in slabs])
+            flat['step%d_mean' % k] = np.stack([s['agent_infos']['mean'] for s in slabs])
+            flat['step%d_log_std' % k] = np.stack([s['agent_infos']['log_std'] for s in slabs])
+        np.savez_compressed(os.path.join(GOLDEN, 'promp_autograd_%s.npz' % name),
+                            meta=json.dumps(c), theta=theta, loss=loss, inner_kl=ikl, outer_kl=okl, grad=grad, **flat)
+        print('wrote promp_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
+
+
+if __name__ == '__main__':
+    os.makedirs(GOLDEN, exist_ok=True)
+    gen_sample_proc()
+    gen_promp()

@@ -1,0 +1,132 @@
+"""Pins oracle/policy.py + oracle/promp.py (reference rows a8-a13).
+
+TensorFlow is absent, and the reference's tests hold only properties for these rows, so the oracle's
+hand-derived gradient / Hessian-vector product is checked against
+  (1) torch.autograd double-backward goldens (tests/golden/promp_autograd_*.npz, oracle/gen_golden.py),
+  (2) central finite differences,
+  (3) the reference's properties: ratio == 1 at unchanged params (reference tests/test_integration.py:128-175),
+      Adam convergence of the optimizer wrapper (reference tests/test_optimizers.py:42-115).
+"""
+import numpy as np
+import pytest
+
+from oracle import policy as op
+from oracle import promp as pm
+from tests import helpers
+
+
+def _spec(c):
+    return op.PolicySpec(c['O'], c['A'], c['hidden'])
+
+
+@pytest.mark.parametrize('name', helpers.promp_cases())
+def test_meta_gradient_matches_torch_autograd(name):
+    c, theta, all_slabs, g = helpers.load_promp(name)
+    spec = _spec(c)
+    r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), all_slabs, np.full(spec.n_params, c['alpha']),
+                                   np.array(c['eta']), c['clip_eps'])
+    assert r['loss'] == pytest.approx(float(g['loss']), rel=1e-10, abs=1e-12)
+    np.testing.assert_allclose(r['inner_kl'], g['inner_kl'], rtol=1e-10)
+    assert r['outer_kl'] == pytest.approx(float(g['outer_kl']), rel=1e-10)
+    scale = np.max(np.abs(g['grad']))
+    np.testing.assert_allclose(r['grad'], g['grad'], rtol=1e-7, atol=1e-9 * scale)
+
+
+def test_hvp_matches_finite_differences():
+    c, theta, all_slabs, _ = helpers.load_promp('k1_small')
+    spec = _spec(c)
+    theta = theta.astype(np.float64)
+    rng = np.random.RandomState(3)
+    v = rng.randn(spec.n_params)
+    slab = all_slabs[0][0]
+    for kind in (pm.INNER_RATIO, pm.INNER_LOGLIK):
+        hv = pm.hvp(spec, theta, slab, v, kind, clip_log_std=True)
+        eps = 1e-5
+        gp = pm.loss_and_grad(spec, theta + eps * v, slab, kind, True)['grad']
+        gm = pm.loss_and_grad(spec, theta - eps * v, slab, kind, True)['grad']
+        np.testing.assert_allclose(hv, (gp - gm) / (2 * eps), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('kind', ['ratio', 'clip', 'loglik'])
+def test_gradients_match_finite_differences(kind):
+    c, theta, all_slabs, _ = helpers.load_promp('k1_small')
+    spec = _spec(c)
+    theta = theta.astype(np.float64)
+    slab = all_slabs[1][1]
+    r = pm.loss_and_grad(spec, theta, slab, kind, clip_log_std=False, clip_eps=0.3)
+    rng = np.random.RandomState(4)
+    for _ in range(5):
+        d = rng.randn(spec.n_params)
+        eps = 1e-6
+        f = lambda t: pm.loss_and_grad(spec, t, slab, kind, False, clip_eps=0.3, want_grad=False)
+        fd = (f(theta + eps * d)['loss'] - f(theta - eps * d)['loss']) / (2 * eps)
+        assert np.dot(r['grad'], d) == pytest.approx(fd, rel=1e-5, abs=1e-8)
+        fdk = (f(theta + eps * d)['kl'] - f(theta - eps * d)['kl']) / (2 * eps)
+        assert np.dot(r['grad_kl'], d) == pytest.approx(fdk, rel=1e-5, abs=1e-8)
+
+
+def test_likelihood_ratio_is_one_at_unchanged_params():
+    # reference tests/test_integration.py:128-175
+    rng = np.random.RandomState(5)
+    spec = op.PolicySpec(4, 3, (8, 8))
+    theta = spec.init_params(rng)
+    obs = rng.randn(50, 4)
+    mu, s, _ = op.forward(spec, theta, obs, clip_log_std=True)
+    act = mu + np.exp(s) * rng.randn(50, 3)
+    rho = op.likelihood_ratio(act, mu, np.tile(s, (50, 1)), mu, s)
+    np.testing.assert_array_equal(rho, np.ones(50))
+    slab = dict(observations=obs, actions=act, advantages=rng.randn(50),
+                agent_infos=dict(mean=mu, log_std=np.tile(s, (50, 1))))
+    r = pm.loss_and_grad(spec, theta, slab, 'ratio', True)
+    assert r['kl'] == pytest.approx(0.0, abs=1e-12)
+    assert r['loss'] == pytest.approx(-np.mean(slab['advantages']))
+
+
+def test_param_dict_roundtrip_and_names():
+    # reference tests/test_policies.py:85-120 (get/set params round trip) + key order of policies/base.py:271-277
+    spec = op.PolicySpec(20, 6, (64, 64))
+    assert spec.n_params == 5900            # Theta at config 3
+    assert spec.names == ['mean_network/hidden_0/kernel', 'mean_network/hidden_0/bias',
+                          'mean_network/hidden_1/kernel', 'mean_network/hidden_1/bias',
+                          'mean_network/output/kernel', 'mean_network/output/bias',
+                          'log_std_network/log_std_var']
+    theta = spec.init_params(np.random.RandomState(0))
+    d = spec.to_ordered_dict(theta)
+    assert d['log_std_network/log_std_var'].shape == (1, 6)
+    np.testing.assert_array_equal(spec.from_ordered_dict(d), theta)
+
+
+def test_adam_fits_sine():
+    # reference tests/test_optimizers.py:42-76: Adam drives a small MLP regression below MSE 0.02
+    rng = np.random.RandomState(6)
+    spec = op.PolicySpec(1, 1, (16, 16))
+    theta = spec.init_params(rng)
+    x = rng.uniform(-3, 3, size=(400, 1)); y = np.sin(x)
+    st = pm.AdamState(spec.n_params)
+
+    def loss_grad(th):
+        mu, s, cache = op.forward(spec, th, x, False)
+        d = (mu - y)
+        return float(np.mean(d ** 2)), pm._backprop(spec, cache, 2 * d / len(x), np.zeros(1))
+
+    for _ in range(3000):
+        l, g = loss_grad(theta)
+        theta = pm.adam_step(theta, g, st, 1e-2)
+    assert loss_grad(theta)[0] < 0.02
+
+
+def test_kl_coeff_rule():
+    # meta_algos/pro_mp.py:201-214
+    out = pm.adapt_kl_coeff(np.array([1.0, 1.0, 1.0]), [0.001, 0.01, 0.02], 0.01)
+    np.testing.assert_array_equal(out, [0.5, 1.0, 2.0])
+
+
+def test_sharded_partial_sums_add_up():
+    c, theta, all_slabs, _ = helpers.load_promp('k1_small')
+    spec = _spec(c)
+    a = np.full(spec.n_params, c['alpha']); eta = np.array(c['eta'])
+    full = pm.meta_objective_and_grad(spec, theta, all_slabs, a, eta, c['clip_eps'])
+    p0 = pm.meta_objective_and_grad(spec, theta, all_slabs, a, eta, c['clip_eps'], tasks=[0, 2], n_tasks_total=3)
+    p1 = pm.meta_objective_and_grad(spec, theta, all_slabs, a, eta, c['clip_eps'], tasks=[1], n_tasks_total=3)
+    np.testing.assert_allclose(p0['grad'] + p1['grad'], full['grad'], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(p0['inner_kl'] + p1['inner_kl'], full['inner_kl'], rtol=1e-12)
