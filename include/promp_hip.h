@@ -1,0 +1,172 @@
+/*
+ * promp_hip.h -- C ABI of libpromp_hip.so, the MI355X (gfx950) implementation of the ProMP
+ * meta-RL training hot path:
+ *
+ *     MetaSampleProcessor.process_samples -> MAMLAlgo._adapt -> ProMP.optimize_policy
+ *
+ * The reference (jonasrothfuss/ProMP) is pure Python/TF1 and has no FFI; this header is the
+ * boundary a maintainer would bind with ctypes from the reference's plugin classes (see
+ * INTEGRATION.md).  Each entry point cites the reference code it replaces, paths relative to
+ * meta_policy_search/ in the reference tree.
+ *
+ * Conventions
+ *   - return 0 on success, negative on failure; promp_last_error() has the message
+ *     (thread-local, valid until the next call on the thread).
+ *   - the caller owns every host buffer (C-contiguous); the library owns device memory in ctx.
+ *   - float32 unless noted; parameters cross the boundary as ONE flat vector [Theta] in the
+ *     reference's OrderedDict order (policies/base.py:271-277): hidden_0/kernel [O,H1] row-major
+ *     (x @ W convention, policies/networks/mlp.py:101), hidden_0/bias, hidden_1/kernel,
+ *     hidden_1/bias, output/kernel [H2,A], output/bias, log_std_var [A].
+ *   - work is enqueued on the context's HIP stream; calls that hand data back to the host
+ *     synchronise before returning, the others return once the work is enqueued.
+ *   - one ctx per GPU per process; not thread-safe (the reference's host is single-threaded).
+ *   - there is NO CPU fallback: with no usable HIP device promp_ctx_create fails.
+ */
+#ifndef PROMP_HIP_H
+#define PROMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct promp_ctx promp_ctx;
+
+typedef struct promp_dims {
+    int32_t n_tasks;            /* meta-tasks resident on this GPU (M_local)                       */
+    int32_t n_tasks_global;     /* meta_batch_size over all ranks: the task-mean divides by this   */
+    int32_t obs_dim;            /* O                                                               */
+    int32_t act_dim;            /* A  (<= 8)                                                       */
+    int32_t hidden1, hidden2;   /* hidden_sizes, each 32 or 64 in this build                       */
+    int32_t num_inner_steps;    /* K = num_inner_grad_steps (>= 1)                                 */
+    int32_t max_rows;           /* capacity: rows (env steps) per sampling step over local tasks   */
+    int32_t max_paths;          /* capacity: paths per sampling step over local tasks              */
+} promp_dims;
+
+enum { PROMP_BASELINE_ZERO = 0, PROMP_BASELINE_LINEAR_FEATURE = 1, PROMP_BASELINE_LINEAR_TIME = 2 };
+enum { PROMP_INNER_RATIO = 0,   /* -mean(ratio*adv)   meta_algos/pro_mp.py:59-65   */
+       PROMP_INNER_LOGLIK = 1   /* -mean(logpi*adv)   meta_algos/trpo_maml.py:58-62 */ };
+enum { PROMP_OUTER_CLIP = 0,    /* PPO clipped surrogate, meta_algos/pro_mp.py:141-145 */
+       PROMP_OUTER_RATIO = 1    /* unclipped,            meta_algos/trpo_maml.py:135    */ };
+
+/* SampleProcessor.__init__ arguments (samplers/base.py:48-65) + baseline choice */
+typedef struct promp_proc_opts {
+    double discount;
+    double gae_lambda;
+    double reg_coeff;          /* LinearBaseline reg_coeff, baselines/linear_baseline.py:12,68 */
+    int32_t normalize_adv;
+    int32_t positive_adv;
+    int32_t baseline_kind;     /* PROMP_BASELINE_* */
+    int32_t reserved;
+} promp_proc_opts;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims);
+void promp_ctx_destroy(promp_ctx* ctx);
+const char* promp_last_error(void);
+int promp_abi_version(void);
+/* Theta = O*H1+H1 + H1*H2+H2 + H2*A+A + A */
+int promp_param_count(const promp_dims* dims);
+/* LinearFeatureBaseline: 2*O+4 (baselines/linear_baseline.py:101-106); LinearTime: 4; Zero: 0 */
+int promp_feature_dim(const promp_dims* dims, int baseline_kind);
+int promp_sync(promp_ctx* ctx);
+
+/* ---- trajectories ---------------------------------------------------------------------------
+ * Upload one sampling step's paths (what MetaSampler.obtain_samples returns,
+ * samplers/meta_sampler.py:59-137), flattened task-major, path-major, time-major:
+ *   task_path_offsets [n_tasks+1] : paths of task i are [tpo[i], tpo[i+1])
+ *   path_row_offsets  [n_paths+1] : rows of path p are  [pro[p], pro[p+1])   (ragged allowed)
+ *   obs [rows,O], act [rows,A], rew [rows], old_mean [rows,A]  (agent_infos['mean'])
+ *   old_log_std: [rows,A] when log_std_per_row != 0 (the reference's layout,
+ *                policies/meta_gaussian_mlp_policy.py:135-136), else [n_tasks,A].
+ * act / old_mean / old_log_std may be NULL when only process_samples is needed. */
+int promp_upload_step(promp_ctx* ctx, int step, int n_paths,
+                      const int32_t* task_path_offsets, const int32_t* path_row_offsets,
+                      const float* obs, const float* act, const float* rew,
+                      const float* old_mean, const float* old_log_std, int log_std_per_row);
+
+/* ---- rows a1-a7: MetaSampleProcessor.process_samples (samplers/meta_sample_processor.py:8-49,
+ * samplers/base.py:99-173, utils/utils.py:59-81, baselines/linear_baseline.py:17-106).
+ * Computes on the device, per task: returns -> baseline fit -> GAE -> normalise; results stay
+ * resident for promp_inner_adapt / promp_optimize.  Asynchronous. */
+int promp_process_samples(promp_ctx* ctx, int step, const promp_proc_opts* opts);
+
+/* Copy results of promp_process_samples to the host (any pointer may be NULL):
+ *   returns [rows], advantages [rows] float32;  coeffs [n_tasks, feature_dim] float64
+ *   (LinearBaseline._coeffs per task);  path_returns0 [n_paths] = returns[0] of each path,
+ *   path_undiscounted [n_paths] = sum(rewards), path_reward_sumsq [n_paths] = sum(rewards^2)
+ *   (float64; inputs of _log_path_stats, samplers/base.py:135-149, and of the adj_avg_rewards
+ *   moments, samplers/meta_sample_processor.py:40-44). */
+int promp_download_processed(promp_ctx* ctx, int step, float* returns, float* advantages, double* coeffs,
+                             double* path_returns0, double* path_undiscounted, double* path_reward_sumsq);
+
+/* Use caller-provided advantages for a step instead of promp_process_samples' (float32 [rows]). */
+int promp_set_advantages(promp_ctx* ctx, int step, const float* advantages);
+
+/* ---- parameters (rows a14: policies/base.py:173-203, 234-240, 262-286) ---------------------- */
+int promp_set_theta(promp_ctx* ctx, const float* theta);                 /* [Theta] meta-parameters     */
+int promp_get_theta(promp_ctx* ctx, float* theta);
+int promp_set_step_sizes(promp_ctx* ctx, const float* step_sizes);       /* [Theta], base.py:303-313     */
+int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
+int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);
+/* MetaPolicy.switch_to_pre_update: replicate theta into every task's parameter slot */
+int promp_switch_to_pre_update(promp_ctx* ctx);
+/* MetaPolicy.update_task_parameters / policies_params_vals: per-task parameters [n_tasks,Theta] */
+int promp_set_task_thetas(promp_ctx* ctx, const float* theta_tasks);
+int promp_get_task_thetas(promp_ctx* ctx, float* theta_tasks);
+
+/* ---- rows a8-a10: MAMLAlgo._adapt (meta_algos/base.py:217-242): for every local task
+ *   theta_i <- theta_i - step_sizes * grad_theta L_i(theta_i)   on step `step`'s data,
+ * explicit per-task parameters => raw log_std (policies/gaussian_mlp_policy.py:182).  Asynchronous. */
+int promp_inner_adapt(promp_ctx* ctx, int step, int inner_kind);
+
+/* ---- rows a11-a13 ---------------------------------------------------------------------------
+ * One evaluation of the ProMP meta-objective (meta_algos/pro_mp.py:67-163) and of its exact
+ * gradient (what tf.gradients yields through meta_algos/base.py:206, i.e. including the
+ * second-order MAML term), over steps 0..K of resident data, reduced over local tasks and, when a
+ * communicator is attached, all-reduced over ranks; leaves the task-MEAN gradient on the device.
+ *   stats_out [K+2] = { loss, inner_kl[0..K-1], outer_kl };  grad_out [Theta] (may be NULL). */
+int promp_meta_grad(promp_ctx* ctx, float clip_eps, const float* inner_kl_coeff, int inner_kind, int outer_kind,
+                    float* grad_out, float* stats_out);
+/* tf.train.AdamOptimizer step on theta with the gradient left by promp_meta_grad
+ * (optimizers/maml_first_order_optimizer.py:24,64; b1=.9 b2=.999 eps=1e-8, bias-corrected lr). */
+int promp_adam_step(promp_ctx* ctx, float learning_rate);
+/* ProMP.optimize_policy's numerical core (meta_algos/pro_mp.py:165-199 +
+ * optimizers/maml_first_order_optimizer.py:82-115,146-163): num_epochs x (meta_grad, Adam), then
+ * compute_stats.  loss_before = loss of the first epoch; stats_after [K+2] as in promp_meta_grad.
+ * Everything is enqueued back-to-back; one synchronisation at the end. */
+int promp_optimize(promp_ctx* ctx, int num_epochs, float learning_rate, float clip_eps,
+                   const float* inner_kl_coeff, int inner_kind, int outer_kind,
+                   float* loss_before, float* stats_after);
+
+/* ---- multi-GPU: task-sharded data parallelism, one process per GPU, RCCL over xGMI.
+ * The only exchange on the path is the task-mean of the meta-objective / its gradient
+ * (meta_algos/pro_mp.py:122,151,155): ONE all-reduce of [Theta+K+2] floats per epoch. */
+int promp_comm_unique_id(void* id_out, size_t id_bytes);                  /* rank 0; 128 bytes  */
+int promp_comm_init(promp_ctx* ctx, int rank, int nranks, const void* id, size_t id_bytes);
+int promp_allreduce_f64(promp_ctx* ctx, double* host_buf, int n, int op /*0 sum, 1 max*/);
+
+/* ---- evaluation hooks used by the parity tests and by alternative optimizers (TRPO-MAML's
+ * conjugate-gradient loop calls these per evaluation): per-task objective, mean-KL and their
+ * gradient at the CURRENT per-task parameters on step `step`'s data.
+ *   kind: 0 ratio surrogate, 1 clipped surrogate, 2 log-likelihood
+ *   grads_out [n_tasks,Theta], loss_out [n_tasks], kl_out [n_tasks] (any may be NULL). */
+int promp_eval_loss_grad(promp_ctx* ctx, int step, int kind, float clip_eps, int clip_log_std,
+                         float* grads_out, float* loss_out, float* kl_out);
+/* per task: out_i = -H_i v_i + kl_weight * grad KL_i, H_i = Hessian of the inner objective at the
+ * current per-task parameters on step `step`'s data; v [n_tasks,Theta]; out [n_tasks,Theta]. */
+int promp_eval_hvp(promp_ctx* ctx, int step, int inner_kind, int clip_log_std, float kl_weight,
+                   const float* v, float* out);
+
+/* ---- measurement: HIP-event timing of the pass kernels on the context's stream ------------- */
+enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PROMP_KERNEL_COUNT = 3 };
+int promp_prof_enable(promp_ctx* ctx, int on);
+int promp_prof_read(promp_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches, int64_t* rows);
+int promp_device_info(promp_ctx* ctx, char* name_out, size_t name_bytes, int32_t* n_cus, int32_t* clock_mhz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROMP_HIP_H */

@@ -1,0 +1,338 @@
+"""ctypes binding of libpromp_hip.so (include/promp_hip.h).
+
+The product binds exactly one library: ``promp_amd/libpromp_hip.so`` built in-tree by
+``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU fallback: if the library is missing or no
+HIP device is usable, loading / context creation raises.
+
+``Library(path)`` with an explicit path exists for the test-suite, which also runs the same C ABI
+compiled against the SIMT interpreter in tests/emu (kernel-source verification in a GPU-less container).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, 'libpromp_hip.so')
+
+BASELINE_ZERO, BASELINE_LINEAR_FEATURE, BASELINE_LINEAR_TIME = 0, 1, 2
+INNER_RATIO, INNER_LOGLIK = 0, 1
+OUTER_CLIP, OUTER_RATIO = 0, 1
+LOSS_RATIO, LOSS_CLIP, LOSS_LOGLIK = 0, 1, 2
+KERNEL_FWD_BWD, KERNEL_HVP, KERNEL_GRAM = 0, 1, 2
+
+
+class PrompError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [('n_tasks', C.c_int32), ('n_tasks_global', C.c_int32), ('obs_dim', C.c_int32), ('act_dim', C.c_int32),
+                ('hidden1', C.c_int32), ('hidden2', C.c_int32), ('num_inner_steps', C.c_int32),
+                ('max_rows', C.c_int32), ('max_paths', C.c_int32)]
+
+
+class ProcOpts(C.Structure):
+    _fields_ = [('discount', C.c_double), ('gae_lambda', C.c_double), ('reg_coeff', C.c_double),
+                ('normalize_adv', C.c_int32), ('positive_adv', C.c_int32), ('baseline_kind', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+_F = C.POINTER(C.c_float)
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int32)
+_P = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/promp_hip.h
+SIGNATURES = {
+    'promp_ctx_create': (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(Dims)]),
+    'promp_ctx_destroy': (None, [_P]),
+    'promp_last_error': (C.c_char_p, []),
+    'promp_abi_version': (C.c_int, []),
+    'promp_param_count': (C.c_int, [C.POINTER(Dims)]),
+    'promp_feature_dim': (C.c_int, [C.POINTER(Dims), C.c_int]),
+    'promp_sync': (C.c_int, [_P]),
+    'promp_upload_step': (C.c_int, [_P, C.c_int, C.c_int, _I, _I, _F, _F, _F, _F, _F, C.c_int]),
+    'promp_process_samples': (C.c_int, [_P, C.c_int, C.POINTER(ProcOpts)]),
+    'promp_download_processed': (C.c_int, [_P, C.c_int, _F, _F, _D, _D, _D, _D]),
+    'promp_set_advantages': (C.c_int, [_P, C.c_int, _F]),
+    'promp_set_theta': (C.c_int, [_P, _F]),
+    'promp_get_theta': (C.c_int, [_P, _F]),
+    'promp_set_step_sizes': (C.c_int, [_P, _F]),
+    'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
+    'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
+    'promp_switch_to_pre_update': (C.c_int, [_P]),
+    'promp_set_task_thetas': (C.c_int, [_P, _F]),
+    'promp_get_task_thetas': (C.c_int, [_P, _F]),
+    'promp_inner_adapt': (C.c_int, [_P, C.c_int, C.c_int]),
+    'promp_meta_grad': (C.c_int, [_P, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
+    'promp_adam_step': (C.c_int, [_P, C.c_float]),
+    'promp_optimize': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
+    'promp_comm_unique_id': (C.c_int, [_P, C.c_size_t]),
+    'promp_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
+    'promp_allreduce_f64': (C.c_int, [_P, _D, C.c_int, C.c_int]),
+    'promp_eval_loss_grad': (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_int, _F, _F, _F]),
+    'promp_eval_hvp': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F]),
+    'promp_prof_enable': (C.c_int, [_P, C.c_int]),
+    'promp_prof_read': (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'promp_device_info': (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+}
+
+
+class Library:
+    def __init__(self, path=None):
+        self.path = path or DEFAULT_LIBRARY
+        if not os.path.exists(self.path):
+            raise PrompError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                             '(hipcc --offload-arch=gfx950).  promp_amd has no CPU fallback.' % self.path)
+        self.cdll = C.CDLL(self.path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)   # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, rc):
+        if rc < 0:
+            raise PrompError(self.cdll.promp_last_error().decode())
+        return rc
+
+
+_default = None
+
+
+def get_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def set_library_for_testing(lib):
+    """Test hook: make ``lib`` (a ``Library``) the one new contexts bind.  Used by tests/ to run the plugin
+    classes against tests/emu/libpromp_emu.so; never called by the package itself."""
+    global _default
+    _default = lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Context:
+    """One promp_ctx (one GPU).  Thin, NumPy-in / NumPy-out."""
+
+    def __init__(self, n_tasks, obs_dim, act_dim, hidden_sizes, num_inner_steps=1, max_rows=0, max_paths=0,
+                 n_tasks_global=None, device_id=0, lib=None):
+        self.lib = lib or get_library()
+        hs = tuple(int(h) for h in hidden_sizes)
+        if len(hs) != 2:
+            raise PrompError('hidden_sizes %r unsupported: this build implements two hidden layers' % (hidden_sizes,))
+        self.dims = Dims(int(n_tasks), int(n_tasks_global or n_tasks), int(obs_dim), int(act_dim), hs[0], hs[1],
+                         int(num_inner_steps), int(max_rows), int(max_paths))
+        self._h = _P()
+        self.lib.check(self.lib.cdll.promp_ctx_create(C.byref(self._h), int(device_id), C.byref(self.dims)))
+        self.n_params = self.lib.cdll.promp_param_count(C.byref(self.dims))
+        self.n_tasks, self.K = int(n_tasks), int(num_inner_steps)
+        self.step_rows = {}
+        self.step_paths = {}
+
+    def close(self):
+        if self._h:
+            self.lib.cdll.promp_ctx_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, name, *args):
+        return self.lib.check(getattr(self.lib.cdll, name)(self._h, *args))
+
+    # ---- trajectories ----
+    def upload_step(self, step, task_path_offsets, path_row_offsets, obs, rew, act=None, old_mean=None,
+                    old_log_std=None):
+        tpo = np.ascontiguousarray(task_path_offsets, dtype=np.int32)
+        pro = np.ascontiguousarray(path_row_offsets, dtype=np.int32)
+        obs, rew = _f32(obs), _f32(rew)
+        per_row = 0
+        if act is not None:
+            act, old_mean, old_log_std = _f32(act), _f32(old_mean), _f32(old_log_std)
+            old_log_std = old_log_std.reshape(-1, act.shape[1])
+            if old_log_std.shape[0] == obs.shape[0]:
+                per_row = 1          # the reference's layout: agent_infos['log_std'] is [rows, A]
+            elif old_log_std.shape[0] == self.n_tasks:
+                per_row = 0          # compact: one row per task
+            else:
+                raise PrompError('old_log_std must be [rows, A] or [n_tasks, A]')
+        n_paths = len(pro) - 1
+        self._call('promp_upload_step', int(step), int(n_paths), _ptr(tpo, C.c_int32), _ptr(pro, C.c_int32),
+                   _ptr(obs, C.c_float), _ptr(act, C.c_float), _ptr(rew, C.c_float), _ptr(old_mean, C.c_float),
+                   _ptr(old_log_std, C.c_float), per_row)
+        self.step_rows[step] = int(pro[-1])
+        self.step_paths[step] = int(n_paths)
+
+    def process_samples(self, step, discount=0.99, gae_lambda=1.0, normalize_adv=False, positive_adv=False,
+                        baseline_kind=BASELINE_LINEAR_FEATURE, reg_coeff=1e-5):
+        o = ProcOpts(float(discount), float(gae_lambda), float(reg_coeff), int(bool(normalize_adv)),
+                     int(bool(positive_adv)), int(baseline_kind), 0)
+        self._call('promp_process_samples', int(step), C.byref(o))
+        self._last_kind = int(baseline_kind)
+
+    def download_processed(self, step, baseline_kind=None):
+        R, P = self.step_rows[step], self.step_paths[step]
+        kind = self._last_kind if baseline_kind is None else baseline_kind
+        D = self.lib.cdll.promp_feature_dim(C.byref(self.dims), int(kind))
+        out = dict(returns=np.empty(R, np.float32), advantages=np.empty(R, np.float32),
+                   coeffs=np.zeros((self.n_tasks, D), np.float64), path_returns0=np.empty(P, np.float64),
+                   path_undiscounted=np.empty(P, np.float64), path_reward_sumsq=np.empty(P, np.float64))
+        self._call('promp_download_processed', int(step), _ptr(out['returns'], C.c_float),
+                   _ptr(out['advantages'], C.c_float), _ptr(out['coeffs'], C.c_double) if D else None,
+                   _ptr(out['path_returns0'], C.c_double), _ptr(out['path_undiscounted'], C.c_double),
+                   _ptr(out['path_reward_sumsq'], C.c_double))
+        return out
+
+    def set_advantages(self, step, adv):
+        adv = _f32(adv)
+        assert adv.shape == (self.step_rows[step],)
+        self._call('promp_set_advantages', int(step), _ptr(adv, C.c_float))
+
+    # ---- parameters ----
+    def set_theta(self, theta):
+        theta = _f32(theta)
+        assert theta.shape == (self.n_params,)
+        self._call('promp_set_theta', _ptr(theta, C.c_float))
+
+    def get_theta(self):
+        out = np.empty(self.n_params, np.float32)
+        self._call('promp_get_theta', _ptr(out, C.c_float))
+        return out
+
+    def set_step_sizes(self, s):
+        s = _f32(np.broadcast_to(np.asarray(s, dtype=np.float32), (self.n_params,)))
+        self._call('promp_set_step_sizes', _ptr(s, C.c_float))
+
+    def set_adam_state(self, m, v, t):
+        m, v = _f32(m), _f32(v)
+        self._call('promp_set_adam_state', _ptr(m, C.c_float), _ptr(v, C.c_float), int(t))
+
+    def get_adam_state(self):
+        m, v, t = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32), C.c_int64(0)
+        self._call('promp_get_adam_state', _ptr(m, C.c_float), _ptr(v, C.c_float), C.byref(t))
+        return m, v, int(t.value)
+
+    def switch_to_pre_update(self):
+        self._call('promp_switch_to_pre_update')
+
+    def set_task_thetas(self, th):
+        th = _f32(th)
+        assert th.shape == (self.n_tasks, self.n_params)
+        self._call('promp_set_task_thetas', _ptr(th, C.c_float))
+
+    def get_task_thetas(self):
+        out = np.empty((self.n_tasks, self.n_params), np.float32)
+        self._call('promp_get_task_thetas', _ptr(out, C.c_float))
+        return out
+
+    # ---- algorithm ----
+    def inner_adapt(self, step, inner_kind=INNER_RATIO):
+        self._call('promp_inner_adapt', int(step), int(inner_kind))
+
+    def meta_grad(self, clip_eps, inner_kl_coeff, inner_kind=INNER_RATIO, outer_kind=OUTER_CLIP):
+        eta = _f32(inner_kl_coeff)
+        assert eta.shape == (self.K,)
+        grad, stats = np.empty(self.n_params, np.float32), np.empty(self.K + 2, np.float32)
+        self._call('promp_meta_grad', float(clip_eps), _ptr(eta, C.c_float), int(inner_kind), int(outer_kind),
+                   _ptr(grad, C.c_float), _ptr(stats, C.c_float))
+        return grad, dict(loss=float(stats[0]), inner_kl=stats[1:1 + self.K].copy(), outer_kl=float(stats[1 + self.K]))
+
+    def adam_step(self, lr):
+        self._call('promp_adam_step', float(lr))
+
+    def optimize(self, num_epochs, lr, clip_eps, inner_kl_coeff, inner_kind=INNER_RATIO, outer_kind=OUTER_CLIP):
+        eta = _f32(inner_kl_coeff)
+        assert eta.shape == (self.K,)
+        lb, stats = C.c_float(0), np.empty(self.K + 2, np.float32)
+        self._call('promp_optimize', int(num_epochs), float(lr), float(clip_eps), _ptr(eta, C.c_float), int(inner_kind),
+                   int(outer_kind), C.byref(lb), _ptr(stats, C.c_float))
+        return dict(loss_before=float(lb.value), loss_after=float(stats[0]), inner_kl=stats[1:1 + self.K].copy(),
+                    outer_kl=float(stats[1 + self.K]))
+
+    def eval_loss_grad(self, step, kind, clip_eps=0.0, clip_log_std=False):
+        g = np.empty((self.n_tasks, self.n_params), np.float32)
+        l, k = np.empty(self.n_tasks, np.float32), np.empty(self.n_tasks, np.float32)
+        self._call('promp_eval_loss_grad', int(step), int(kind), float(clip_eps), int(bool(clip_log_std)),
+                   _ptr(g, C.c_float), _ptr(l, C.c_float), _ptr(k, C.c_float))
+        return g, l, k
+
+    def eval_hvp(self, step, v, inner_kind=INNER_RATIO, clip_log_std=False, kl_weight=0.0):
+        v = _f32(v)
+        assert v.shape == (self.n_tasks, self.n_params)
+        out = np.empty_like(v)
+        self._call('promp_eval_hvp', int(step), int(inner_kind), int(bool(clip_log_std)), float(kl_weight),
+                   _ptr(v, C.c_float), _ptr(out, C.c_float))
+        return out
+
+    # ---- multi-GPU / measurement ----
+    def comm_init(self, rank, nranks, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._call('promp_comm_init', int(rank), int(nranks), C.cast(buf, _P), 128)
+
+    def allreduce_f64(self, values, op='sum'):
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._call('promp_allreduce_f64', _ptr(a, C.c_double), int(a.size), 1 if op == 'max' else 0)
+        return a
+
+    def sync(self):
+        self._call('promp_sync')
+
+    def prof_enable(self, on=True):
+        self._call('promp_prof_enable', int(bool(on)))
+
+    def prof_read(self, kernel_id):
+        ms, n, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        self._call('promp_prof_read', int(kernel_id), C.byref(ms), C.byref(n), C.byref(rows))
+        return dict(total_ms=ms.value, launches=n.value, rows=rows.value)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mhz = C.c_int32(0), C.c_int32(0)
+        self._call('promp_device_info', name, 256, C.byref(cus), C.byref(mhz))
+        return dict(name=name.value.decode(), n_cus=cus.value, clock_mhz=mhz.value)
+
+
+def comm_unique_id(lib=None):
+    lib = lib or get_library()
+    buf = C.create_string_buffer(128)
+    lib.check(lib.cdll.promp_comm_unique_id(C.cast(buf, _P), 128))
+    return bytes(buf.raw)
+
+
+def flatten_paths(paths_meta_batch):
+    """OrderedDict{task -> [path dicts]} (MetaSampler.obtain_samples' return value) -> flat arrays + CSR offsets."""
+    tpo, pro = [0], [0]
+    obs, act, rew, mean, ls = [], [], [], [], []
+    has_policy = True
+    for _, plist in paths_meta_batch.items():
+        for p in plist:
+            n = len(p['rewards'])
+            pro.append(pro[-1] + n)
+            obs.append(np.asarray(p['observations'], dtype=np.float32).reshape(n, -1))
+            rew.append(np.asarray(p['rewards'], dtype=np.float32).reshape(n))
+            if 'actions' in p and 'agent_infos' in p and p['agent_infos'] and 'mean' in p['agent_infos']:
+                act.append(np.asarray(p['actions'], dtype=np.float32).reshape(n, -1))
+                mean.append(np.asarray(p['agent_infos']['mean'], dtype=np.float32).reshape(n, -1))
+                ls.append(np.asarray(p['agent_infos']['log_std'], dtype=np.float32).reshape(n, -1))
+            else:
+                has_policy = False
+        tpo.append(len(pro) - 1)
+    out = dict(task_path_offsets=np.array(tpo, np.int32), path_row_offsets=np.array(pro, np.int32),
+               obs=np.concatenate(obs), rew=np.concatenate(rew), act=None, old_mean=None, old_log_std=None)
+    if has_policy:
+        out.update(act=np.concatenate(act), old_mean=np.concatenate(mean), old_log_std=np.concatenate(ls))
+    return out

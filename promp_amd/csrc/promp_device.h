@@ -1,0 +1,104 @@
+// promp_device.h -- device-side vocabulary shared by every kernel of libpromp_hip.
+//
+// gfx950 / CDNA4 only: 64-lane wavefronts, exact-FP32 MFMA (v_mfma_f32_32x32x2_f32,
+// v_mfma_f32_16x16x4_f32) and FP64 MFMA (v_mfma_f64_16x16x4_f64).  There is no other backend.
+//
+// When PROMP_EMU is defined the same kernel sources are compiled by g++ against tests/emu/hip_emu.h,
+// a SIMT interpreter (one host thread per lane, MFMA fragment layouts restated from
+// cdna_hip_programming.md section 3).  That build exists only so that tests can check kernel indexing
+// in a container without a GPU; it is never built into or loaded by the product.
+#pragma once
+
+#ifdef PROMP_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+
+#define PROMP_DEV __device__ __forceinline__
+#define PROMP_HD __host__ __device__ inline
+#define PROMP_SMEM_DECL extern __shared__ __attribute__((aligned(16))) unsigned char promp_smem_raw[]
+#define PROMP_SMEM_PTR promp_smem_raw
+#define PROMP_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, dim3(block), smem, stream, __VA_ARGS__)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// D[32x32] += A[32x2] * B[2x32].  lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for register r in [0,16).
+PROMP_DEV f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// D[16x16] += A[16x4] * B[4x16].  lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// D: col = l&15, row = 4*(l>>4) + r for r in [0,4).
+PROMP_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// FP64: same A/B lane map as mfma16; D: col = l&15, row = (l>>4) + 4*r.
+PROMP_DEV f64x4 mfma16d(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+PROMP_DEV float shfl_xor_f32(float v, int m) { return __shfl_xor(v, m, 64); }
+PROMP_DEV double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
+PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }
+PROMP_DEV double shfl_idx_f64(double v, int l) { return __shfl(v, l, 64); }
+PROMP_DEV float fast_exp(float x) { return __expf(x); }
+PROMP_DEV float fast_rcp(float x) { return __frcp_rn(x); }
+#endif
+
+PROMP_DEV f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+PROMP_DEV f32x4 zero4() {
+    f32x4 z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = 0.f;
+    return z;
+}
+PROMP_DEV f64x4 zero4d() {
+    f64x4 z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = 0.0;
+    return z;
+}
+
+PROMP_DEV float wave_sum_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f32(v, m);
+    return v;
+}
+PROMP_DEV double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
+PROMP_DEV double wave_min_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        double o = shfl_xor_f64(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7, saturates correctly at +-1.
+PROMP_DEV float fast_tanh(float x) { return 1.f - 2.f * fast_rcp(fast_exp(2.f * x) + 1.f); }
+
+// row of accumulator register r of a 32x32 MFMA tile for lane-half lh = lane>>5
+PROMP_DEV int row32(int r, int lh) { return (r & 3) + ((r >> 2) << 3) + (lh << 2); }
+
+// One MFMA operand stream: the value this lane feeds at k-step k is p[k*ks].
+struct Opnd {
+    const float* p;
+    int ks;
+};
+
+// acc[32x32] += sgn * A * B over K (even) with 32x32x2 MFMAs
+PROMP_DEV void gemm32(f32x16& acc, Opnd a, Opnd b, int K, float sgn) {
+#pragma unroll 4
+    for (int k = 0; k < K; k += 2) acc = mfma32(sgn * a.p[k * a.ks], b.p[k * b.ks], acc);
+}
+// acc[16x16] += sgn * A * B over K (multiple of 4) with 16x16x4 MFMAs
+PROMP_DEV void gemm16(f32x4& acc, Opnd a, Opnd b, int K, float sgn) {
+#pragma unroll 4
+    for (int k = 0; k < K; k += 4) acc = mfma16(sgn * a.p[k * a.ks], b.p[k * b.ks], acc);
+}

@@ -1,0 +1,751 @@
+// promp_hip.hip -- host side of libpromp_hip.so: context, device memory, launch sequences, C ABI.
+// See include/promp_hip.h for the contract.  gfx950 only; built by __graft_entry__.build():
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC promp_hip.hip -lrccl -o libpromp_hip.so
+#include "promp_kernels_policy.h"
+#include "promp_kernels_sample.h"
+#include "../../include/promp_hip.h"
+
+#ifndef PROMP_EMU
+#include <rccl/rccl.h>
+#endif
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                            \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct StepData {
+    int n_paths = 0, n_rows = 0, n_work = 0;
+    bool has_policy = false, processed = false, has_adv = false;
+    int ls_per_row = 0;
+    int feat_dim = 0;
+    float *obs = nullptr, *act = nullptr, *rew = nullptr, *old_mean = nullptr, *old_ls = nullptr;
+    float *ret32 = nullptr, *adv32 = nullptr;
+    double *ret64 = nullptr, *adv64 = nullptr;
+    int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
+    int *task_row_offsets = nullptr, *task_path_offsets = nullptr, *task_wg_offsets = nullptr;
+    double *path_ret0 = nullptr, *path_undisc = nullptr, *path_rsq = nullptr, *path_mom = nullptr;
+    double* coeffs = nullptr;
+    WorkItem* work = nullptr;
+};
+
+struct ProfSlot {
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    size_t used = 0;
+    double total_ms = 0.0;
+    long long launches = 0, rows = 0;
+};
+
+}  // namespace
+
+struct promp_ctx {
+    promp_dims d;
+    int device = 0, n_cus = 256, clock_mhz = 0;
+    char dev_name[256];
+    int NP = 0, Dmax = 0, coeff_stride = 0, max_work = 0, partial_stride = 0, gram_stride = 0;
+    hipStream_t stream = nullptr;
+    std::vector<StepData> steps;
+    float *theta = nullptr, *step_sizes = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    long long adam_t = 0;
+    float *theta_tasks = nullptr, *chain = nullptr, *lam = nullptr, *vbuf = nullptr, *vw2t = nullptr;
+    float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
+    float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
+    double *gram_partials = nullptr, *red64 = nullptr;
+    size_t smem_fwd = 0, smem_hvp = 0;
+#ifndef PROMP_EMU
+    ncclComm_t comm = nullptr;
+#endif
+    int rank = 0, nranks = 1;
+    bool prof = false;
+    ProfSlot prof_slots[PROMP_KERNEL_COUNT];
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, size_t n) {
+    HIPCHECK(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+    HIPCHECK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
+    return 0;
+}
+
+int check_dims(const promp_dims* d) {
+    if (!d) return fail(-1, "dims is NULL");
+    if (d->n_tasks < 1 || d->n_tasks_global < d->n_tasks) return fail(-1, "bad task counts (%d local, %d global)", d->n_tasks, d->n_tasks_global);
+    if (d->obs_dim < 1 || d->obs_dim > 32)
+        return fail(-1, "obs_dim %d unsupported: this build tiles the first layer for obs_dim <= 32 (Ant, O=111, is a later round)", d->obs_dim);
+    if (d->act_dim < 1 || d->act_dim > 8) return fail(-1, "act_dim %d unsupported (1..8)", d->act_dim);
+    if (!((d->hidden1 == 32 || d->hidden1 == 64) && d->hidden1 == d->hidden2))
+        return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates (32,32) and (64,64)", d->hidden1, d->hidden2);
+    if (d->num_inner_steps < 1) return fail(-1, "num_inner_steps must be >= 1");
+    if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
+    return 0;
+}
+
+int param_count(const promp_dims* d) {
+    return d->obs_dim * d->hidden1 + d->hidden1 + d->hidden1 * d->hidden2 + d->hidden2 + d->hidden2 * d->act_dim +
+           d->act_dim + d->act_dim;
+}
+
+int feature_dim(const promp_dims* d, int kind) {
+    if (kind == PROMP_BASELINE_LINEAR_FEATURE) return 2 * d->obs_dim + 4;
+    if (kind == PROMP_BASELINE_LINEAR_TIME) return 4;
+    return 0;
+}
+
+// ---- profiling helpers -------------------------------------------------------------------------
+int prof_begin(promp_ctx* c, int id, long long rows) {
+    if (!c->prof) return 0;
+    ProfSlot& s = c->prof_slots[id];
+    if (s.used + 2 > s.ev.size()) {
+        hipEvent_t a, b;
+        HIPCHECK(hipEventCreate(&a));
+        HIPCHECK(hipEventCreate(&b));
+        s.ev.push_back(a);
+        s.ev.push_back(b);
+    }
+    HIPCHECK(hipEventRecord(s.ev[s.used], c->stream));
+    s.rows += rows;
+    return 0;
+}
+int prof_end(promp_ctx* c, int id) {
+    if (!c->prof) return 0;
+    ProfSlot& s = c->prof_slots[id];
+    HIPCHECK(hipEventRecord(s.ev[s.used + 1], c->stream));
+    s.used += 2;
+    s.launches += 1;
+    return 0;
+}
+int prof_collect(promp_ctx* c) {
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int id = 0; id < PROMP_KERNEL_COUNT; ++id) {
+        ProfSlot& s = c->prof_slots[id];
+        for (size_t i = 0; i + 1 < s.used; i += 2) {
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]));
+            s.total_ms += ms;
+        }
+        s.used = 0;
+    }
+    return 0;
+}
+
+// ---- launches ----------------------------------------------------------------------------------
+int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long long theta_stride, int loss_kind,
+                float clip_eps, int clip_ls, float klw) {
+    if (!S.has_policy) return fail(-3, "step has no actions / agent_infos uploaded");
+    if (!S.has_adv) return fail(-3, "step has no advantages: call promp_process_samples or promp_set_advantages first");
+    PassArgs a;
+    a.obs = S.obs; a.act = S.act; a.adv = S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
+    a.ls_per_row = S.ls_per_row;
+    a.task_row_offsets = S.task_row_offsets;
+    a.work = S.work;
+    a.theta = theta; a.theta_task_stride = theta_stride;
+    a.vdir = c->vbuf; a.vw2t = c->vw2t;
+    a.partials = c->partials; a.partial_stride = c->partial_stride;
+    a.O = c->d.obs_dim; a.A = c->d.act_dim;
+    a.loss_kind = loss_kind; a.clip_eps = clip_eps; a.clip_log_std = clip_ls;
+    a.min_log_std = logf(1e-6f);   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
+    a.kl_weight = klw;
+    const int id = hvp ? PROMP_KERNEL_HVP : PROMP_KERNEL_FWD_BWD;
+    if (prof_begin(c, id, S.n_rows)) return -2;
+    const bool h64 = c->d.hidden1 == 64;
+    if (!hvp) {
+        if (h64) { auto k = k_fwd_bwd<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_fwd, c->stream, a); }
+        else     { auto k = k_fwd_bwd<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_fwd, c->stream, a); }
+    } else {
+        if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_hvp, c->stream, a); }
+        else     { auto k = k_hvp<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_hvp, c->stream, a); }
+    }
+    HIPCHECK(hipGetLastError());
+    return prof_end(c, id);
+}
+
+int launch_reduce(promp_ctx* c, StepData& S, int mode, const float* cur, long long cur_stride, float* next, float* scal) {
+    ReduceArgs r;
+    r.partials = c->partials; r.partial_stride = c->partial_stride;
+    r.task_wg_offsets = S.task_wg_offsets;
+    r.NP = c->NP; r.H1 = c->d.hidden1; r.H2 = c->d.hidden2;
+    r.oW2 = c->d.obs_dim * c->d.hidden1 + c->d.hidden1;
+    r.step_sizes = c->step_sizes; r.mode = mode;
+    r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
+    r.lam = c->lam; r.v = c->vbuf; r.vw2t = c->vw2t; r.scal = scal;
+    PROMP_LAUNCH(k_reduce_task, dim3((c->NP + 2 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, r);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+int loss_kind_inner(int inner_kind) { return inner_kind == PROMP_INNER_LOGLIK ? LOSS_LOGLIK : LOSS_RATIO; }
+int loss_kind_outer(int outer_kind) { return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : LOSS_CLIP; }
+
+// One evaluation of the meta-objective (+ gradient, + Adam) enqueued on the stream.
+int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_kind, int outer_kind, bool want_grad,
+                 bool do_adam, float lr) {
+    const int K = c->d.num_inner_steps, M = c->d.n_tasks, NP = c->NP;
+    const size_t MNP = (size_t)M * NP;
+    for (int k = 0; k <= K; ++k)
+        if (c->steps[k].n_rows == 0) return fail(-3, "step %d has no data", k);
+    for (int k = 0; k < K; ++k) {
+        const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
+        const long long st = (k == 0) ? 0 : NP;
+        if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f)) return -2;
+        if (launch_reduce(c, c->steps[k], 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+    }
+    if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f)) return -2;
+    if (launch_reduce(c, c->steps[K], want_grad ? 1 : 3, nullptr, 0, nullptr, c->scal_outer)) return -2;
+    if (want_grad) {
+        for (int k = K - 1; k >= 0; --k) {
+            const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
+            const long long st = (k == 0) ? 0 : NP;
+            if (launch_pass(c, c->steps[k], true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, eta_host[k] / (float)K)) return -2;
+            if (launch_reduce(c, c->steps[k], 2, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+        }
+    }
+    FinalArgs f;
+    f.lam = c->lam; f.NP = NP; f.K = K; f.n_tasks = M;
+    f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = want_grad ? 1 : 0;
+    PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 255) / 256), 256, 0, c->stream, f);
+    HIPCHECK(hipGetLastError());
+#ifndef PROMP_EMU
+    if (c->nranks > 1) {
+        ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)(NP + K + 2), ncclFloat, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    }
+#endif
+    AdamArgs ad;
+    ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
+    ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = NP; ad.K = K;
+    ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
+    ad.do_update = do_adam ? 1 : 0;
+    ad.lr_t = 0.f;
+    if (do_adam) {
+        c->adam_t += 1;
+        const double t = (double)c->adam_t;
+        ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
+    }
+    PROMP_LAUNCH(k_mean_adam, dim3((NP + 1 + 255) / 256), 256, 0, c->stream, ad);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+int upload_eta(promp_ctx* c, const float* eta) {
+    HIPCHECK(hipMemcpyAsync(c->eta_dev, eta, sizeof(float) * c->d.num_inner_steps, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void free_step(StepData& S) {
+    void* ptrs[] = {S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
+                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets, S.path_ret0,
+                    S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* promp_last_error(void) { return g_err.c_str(); }
+int promp_abi_version(void) { return 1; }
+
+int promp_param_count(const promp_dims* d) {
+    if (!d) return fail(-1, "dims is NULL");
+    return param_count(d);
+}
+int promp_feature_dim(const promp_dims* d, int kind) {
+    if (!d) return fail(-1, "dims is NULL");
+    return feature_dim(d, kind);
+}
+
+int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
+    if (!out) return fail(-1, "out is NULL");
+    *out = nullptr;
+    if (check_dims(dims)) return -1;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(-2, "no HIP device available (%s): libpromp_hip has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+    if (device_id < 0 || device_id >= ndev) return fail(-1, "device_id %d out of range (%d devices)", device_id, ndev);
+    HIPCHECK(hipSetDevice(device_id));
+    promp_ctx* c = new promp_ctx();
+    c->d = *dims;
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, device_id));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->clock_mhz = prop.clockRate / 1000;
+    snprintf(c->dev_name, sizeof c->dev_name, "%s", prop.name);
+    HIPCHECK(hipStreamCreate(&c->stream));
+    const int K = dims->num_inner_steps, M = dims->n_tasks;
+    c->NP = param_count(dims);
+    c->Dmax = 2 * dims->obs_dim + 4;
+    c->coeff_stride = c->Dmax;
+    c->max_work = c->n_cus + M;
+    c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
+    const int nblk_max = (c->Dmax + 1 + 15) / 16;
+    c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
+    const int Opad = (dims->obs_dim + 1) & ~1;
+    c->smem_fwd = sizeof(float) * (size_t)make_layout(Opad, dims->hidden1, dims->hidden2, 0).total;
+    c->smem_hvp = sizeof(float) * (size_t)make_layout(Opad, dims->hidden1, dims->hidden2, 1).total;
+    if (c->smem_hvp > 160 * 1024) {
+        const size_t need = c->smem_hvp;
+        promp_ctx_destroy(c);
+        return fail(-1, "LDS budget exceeded (%zu bytes)", need);
+    }
+    {
+        auto k0 = k_fwd_bwd<2, 2>; auto k1 = k_fwd_bwd<1, 1>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
+        HIPCHECK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        auto g1 = k_gram<1>; auto g2 = k_gram<2>; auto g3 = k_gram<3>; auto g4 = k_gram<4>; auto g5 = k_gram<5>;
+        HIPCHECK(hipFuncSetAttribute((const void*)g1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)g2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)g3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)g4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)g5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const size_t NP = c->NP, MNP = (size_t)M * NP;
+    int rc = 0;
+    rc |= dev_alloc(&c->theta, NP); rc |= dev_alloc(&c->step_sizes, NP);
+    rc |= dev_alloc(&c->adam_m, NP); rc |= dev_alloc(&c->adam_v, NP);
+    rc |= dev_alloc(&c->theta_tasks, MNP); rc |= dev_alloc(&c->chain, (size_t)(K + 1) * MNP);
+    rc |= dev_alloc(&c->lam, MNP); rc |= dev_alloc(&c->vbuf, MNP);
+    rc |= dev_alloc(&c->vw2t, (size_t)M * dims->hidden1 * dims->hidden2);
+    rc |= dev_alloc(&c->partials, (size_t)c->max_work * c->partial_stride);
+    rc |= dev_alloc(&c->scal_inner, (size_t)K * M * 2); rc |= dev_alloc(&c->scal_outer, (size_t)M * 2);
+    rc |= dev_alloc(&c->scal_tmp, (size_t)M * 2);
+    rc |= dev_alloc(&c->red, NP + K + 2); rc |= dev_alloc(&c->grad_mean, NP);
+    rc |= dev_alloc(&c->stats, (size_t)K + 2); rc |= dev_alloc(&c->eta_dev, (size_t)K);
+    rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
+    rc |= dev_alloc(&c->red64, 64);
+    c->steps.resize(K + 1);
+    for (int s = 0; s <= K && !rc; ++s) {
+        StepData& S = c->steps[s];
+        const size_t R = dims->max_rows, P = dims->max_paths, A = dims->act_dim, O = dims->obs_dim;
+        rc |= dev_alloc(&S.obs, R * O); rc |= dev_alloc(&S.act, R * A); rc |= dev_alloc(&S.rew, R);
+        rc |= dev_alloc(&S.old_mean, R * A); rc |= dev_alloc(&S.old_ls, R * A);
+        rc |= dev_alloc(&S.ret32, R); rc |= dev_alloc(&S.adv32, R); rc |= dev_alloc(&S.ret64, R); rc |= dev_alloc(&S.adv64, R);
+        rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
+        rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
+        rc |= dev_alloc(&S.task_wg_offsets, (size_t)M + 1);
+        rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
+        rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
+        rc |= dev_alloc(&S.work, (size_t)c->max_work);
+    }
+    if (rc) { promp_ctx_destroy(c); return -2; }
+    *out = c;
+    return 0;
+}
+
+void promp_ctx_destroy(promp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifndef PROMP_EMU
+    if (c->comm) ncclCommDestroy(c->comm);
+#endif
+    for (auto& S : c->steps) free_step(S);
+    void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf, c->vw2t,
+                    c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
+                    c->gram_partials, c->red64};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& s : c->prof_slots)
+        for (auto ev : s.ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int promp_sync(promp_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro, const float* obs,
+                      const float* act, const float* rew, const float* old_mean, const float* old_ls, int ls_per_row) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (!tpo || !pro || !obs || !rew) return fail(-1, "offsets, obs and rew are required");
+    const int M = c->d.n_tasks;
+    if (n_paths < 1 || n_paths > c->d.max_paths) return fail(-1, "n_paths %d outside [1, max_paths=%d]", n_paths, c->d.max_paths);
+    if (tpo[0] != 0 || tpo[M] != n_paths) return fail(-1, "task_path_offsets must start at 0 and end at n_paths");
+    if (pro[0] != 0) return fail(-1, "path_row_offsets must start at 0");
+    const int R = pro[n_paths];
+    if (R < 1 || R > c->d.max_rows) return fail(-1, "rows %d outside [1, max_rows=%d]", R, c->d.max_rows);
+    std::vector<int> path_task(n_paths), row_t(R), tro(M + 1);
+    for (int i = 0; i < M; ++i) {
+        if (tpo[i + 1] <= tpo[i]) return fail(-1, "task %d has no paths", i);
+        tro[i] = pro[tpo[i]];
+        for (int p = tpo[i]; p < tpo[i + 1]; ++p) {
+            if (pro[p + 1] < pro[p]) return fail(-1, "path_row_offsets must be non-decreasing");
+            path_task[p] = i;
+            for (int r = pro[p]; r < pro[p + 1]; ++r) row_t[r] = r - pro[p];
+        }
+        if (pro[tpo[i + 1]] == tro[i]) return fail(-1, "task %d has no rows", i);
+    }
+    tro[M] = R;
+    // work table: contiguous 64-row-tile ranges, workgroups shared out over tasks in proportion to their tiles
+    std::vector<int> tiles(M), nwg(M), two(M + 1);
+    long long total_tiles = 0;
+    for (int i = 0; i < M; ++i) { tiles[i] = (tro[i + 1] - tro[i] + PROMP_TILE - 1) / PROMP_TILE; total_tiles += tiles[i]; }
+    const int target = c->n_cus;
+    std::vector<WorkItem> work;
+    two[0] = 0;
+    for (int i = 0; i < M; ++i) {
+        long long w = (tiles[i] * (long long)target + total_tiles / 2) / total_tiles;
+        if (w < 1) w = 1;
+        if (w > tiles[i]) w = tiles[i];
+        nwg[i] = (int)w;
+        for (int g = 0; g < nwg[i]; ++g) {
+            const int t0 = (int)((long long)tiles[i] * g / nwg[i]), t1 = (int)((long long)tiles[i] * (g + 1) / nwg[i]);
+            WorkItem it;
+            it.task = i;
+            it.row_begin = tro[i] + t0 * PROMP_TILE;
+            it.row_end = tro[i] + t1 * PROMP_TILE;
+            if (it.row_end > tro[i + 1]) it.row_end = tro[i + 1];
+            it.pad = 0;
+            work.push_back(it);
+        }
+        two[i + 1] = (int)work.size();
+    }
+    if ((int)work.size() > c->max_work) return fail(-5, "internal: work table overflow (%zu > %d)", work.size(), c->max_work);
+    StepData& S = c->steps[step];
+    S.n_paths = n_paths; S.n_rows = R; S.n_work = (int)work.size();
+    S.processed = false; S.has_adv = false;
+    const size_t O = c->d.obs_dim, A = c->d.act_dim;
+    hipStream_t st = c->stream;
+    HIPCHECK(hipMemcpyAsync(S.obs, obs, sizeof(float) * R * O, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * R, hipMemcpyHostToDevice, st));
+    S.has_policy = act && old_mean && old_ls;
+    if (S.has_policy) {
+        S.ls_per_row = ls_per_row ? 1 : 0;
+        HIPCHECK(hipMemcpyAsync(S.act, act, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.old_mean, old_mean, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.old_ls, old_ls, sizeof(float) * (ls_per_row ? (size_t)R : (size_t)M) * A, hipMemcpyHostToDevice, st));
+    }
+    HIPCHECK(hipMemcpyAsync(S.path_row_offsets, pro, sizeof(int) * (n_paths + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_path_offsets, tpo, sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.path_task, path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.row_t, row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_row_offsets, tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_wg_offsets, two.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.work, work.data(), sizeof(WorkItem) * work.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));  // host staging vectors go out of scope
+    return 0;
+}
+
+int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
+    if (!c || !o) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    if (!(o->discount >= 0 && o->discount <= 1)) return fail(-1, "discount factor must be in [0,1]");      // samplers/base.py:57
+    if (!(o->gae_lambda >= 0 && o->gae_lambda <= 1)) return fail(-1, "gae_lambda must be in [0,1]");       // samplers/base.py:58
+    if (o->baseline_kind < 0 || o->baseline_kind > 2) return fail(-1, "unknown baseline kind %d", o->baseline_kind);
+    SampleArgs a;
+    a.obs = S.obs; a.rew = S.rew; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
+    a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets; a.work = S.work;
+    a.task_wg_offsets = S.task_wg_offsets;
+    a.O = c->d.obs_dim; a.kind = o->baseline_kind; a.D = feature_dim(&c->d, o->baseline_kind);
+    a.gamma = o->discount; a.lam = o->gae_lambda; a.reg = o->reg_coeff;
+    a.normalize = o->normalize_adv; a.positive = o->positive_adv;
+    a.ret64 = S.ret64; a.ret32 = S.ret32; a.adv64 = S.adv64; a.adv32 = S.adv32;
+    a.path_ret0 = S.path_ret0; a.path_undisc = S.path_undisc; a.path_rsq = S.path_rsq; a.path_mom = S.path_mom;
+    a.gram_partials = c->gram_partials; a.coeffs = S.coeffs; a.coeff_stride = c->coeff_stride;
+    S.feat_dim = a.D;
+    hipStream_t st = c->stream;
+    PROMP_LAUNCH(k_returns, dim3(S.n_paths), 64, 0, st, a);
+    HIPCHECK(hipGetLastError());
+    if (a.kind != BASE_ZERO) {
+        const int nblk = (a.D + 1 + 15) / 16;
+        if (prof_begin(c, PROMP_KERNEL_GRAM, S.n_rows)) return -2;
+        switch (nblk) {
+            case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<1>::SMEM_BYTES, st, a); } break;
+            case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<2>::SMEM_BYTES, st, a); } break;
+            case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<3>::SMEM_BYTES, st, a); } break;
+            case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<4>::SMEM_BYTES, st, a); } break;
+            case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<5>::SMEM_BYTES, st, a); } break;
+            default: return fail(-1, "feature dim %d unsupported in this build", a.D);
+        }
+        HIPCHECK(hipGetLastError());
+        if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
+        const int DA = a.D + 1;
+        const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 2 * DA + 2);
+        PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
+        HIPCHECK(hipGetLastError());
+    }
+    PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), st, a);
+    HIPCHECK(hipGetLastError());
+    PROMP_LAUNCH(k_normalize, dim3(S.n_work), 256, 0, st, a);
+    HIPCHECK(hipGetLastError());
+    S.processed = true;
+    S.has_adv = true;
+    return 0;
+}
+
+int promp_download_processed(promp_ctx* c, int step, float* returns, float* adv, double* coeffs, double* ret0,
+                             double* undisc, double* rsq) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (!S.processed) return fail(-3, "step %d has not been processed", step);
+    hipStream_t st = c->stream;
+    if (returns) HIPCHECK(hipMemcpyAsync(returns, S.ret32, sizeof(float) * S.n_rows, hipMemcpyDeviceToHost, st));
+    if (adv) HIPCHECK(hipMemcpyAsync(adv, S.adv32, sizeof(float) * S.n_rows, hipMemcpyDeviceToHost, st));
+    if (ret0) HIPCHECK(hipMemcpyAsync(ret0, S.path_ret0, sizeof(double) * S.n_paths, hipMemcpyDeviceToHost, st));
+    if (undisc) HIPCHECK(hipMemcpyAsync(undisc, S.path_undisc, sizeof(double) * S.n_paths, hipMemcpyDeviceToHost, st));
+    if (rsq) HIPCHECK(hipMemcpyAsync(rsq, S.path_rsq, sizeof(double) * S.n_paths, hipMemcpyDeviceToHost, st));
+    if (coeffs && S.feat_dim > 0) {
+        std::vector<double> tmp((size_t)c->d.n_tasks * c->coeff_stride);
+        HIPCHECK(hipMemcpyAsync(tmp.data(), S.coeffs, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < c->d.n_tasks; ++i)
+            memcpy(coeffs + (size_t)i * S.feat_dim, tmp.data() + (size_t)i * c->coeff_stride, sizeof(double) * S.feat_dim);
+    }
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int promp_set_advantages(promp_ctx* c, int step, const float* adv) {
+    if (!c || !adv) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    HIPCHECK(hipMemcpyAsync(S.adv32, adv, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    S.has_adv = true;
+    return 0;
+}
+
+static int copy_in(promp_ctx* c, float* dst, const float* src, size_t n) {
+    if (!c || !src) return fail(-1, "NULL argument");
+    HIPCHECK(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int copy_out(promp_ctx* c, float* dst, const float* src, size_t n) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    HIPCHECK(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int promp_set_theta(promp_ctx* c, const float* th) { return c ? copy_in(c, c->theta, th, c->NP) : fail(-1, "ctx is NULL"); }
+int promp_get_theta(promp_ctx* c, float* th) { return c ? copy_out(c, th, c->theta, c->NP) : fail(-1, "ctx is NULL"); }
+int promp_set_step_sizes(promp_ctx* c, const float* s) { return c ? copy_in(c, c->step_sizes, s, c->NP) : fail(-1, "ctx is NULL"); }
+int promp_set_task_thetas(promp_ctx* c, const float* t) { return c ? copy_in(c, c->theta_tasks, t, (size_t)c->d.n_tasks * c->NP) : fail(-1, "ctx is NULL"); }
+int promp_get_task_thetas(promp_ctx* c, float* t) { return c ? copy_out(c, t, c->theta_tasks, (size_t)c->d.n_tasks * c->NP) : fail(-1, "ctx is NULL"); }
+
+int promp_set_adam_state(promp_ctx* c, const float* m, const float* v, int64_t t) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (copy_in(c, c->adam_m, m, c->NP) || copy_in(c, c->adam_v, v, c->NP)) return -2;
+    c->adam_t = t;
+    return 0;
+}
+int promp_get_adam_state(promp_ctx* c, float* m, float* v, int64_t* t) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (m && copy_out(c, m, c->adam_m, c->NP)) return -2;
+    if (v && copy_out(c, v, c->adam_v, c->NP)) return -2;
+    if (t) *t = c->adam_t;
+    return 0;
+}
+
+int promp_switch_to_pre_update(promp_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    PROMP_LAUNCH(k_replicate, dim3((c->NP + 255) / 256), 256, 0, c->stream, c->theta_tasks, (const float*)c->theta, c->NP, c->d.n_tasks);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    if (launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f)) return -2;
+    return launch_reduce(c, S, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
+}
+
+int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_kind, int outer_kind, float* grad_out,
+                    float* stats_out) {
+    if (!c || !eta) return fail(-1, "NULL argument");
+    if (upload_eta(c, eta)) return -2;
+    if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, true, false, 0.f)) return -2;
+    if (grad_out && copy_out(c, grad_out, c->grad_mean, c->NP)) return -2;
+    if (stats_out && copy_out(c, stats_out, c->stats, c->d.num_inner_steps + 2)) return -2;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int promp_adam_step(promp_ctx* c, float lr) {
+    if (!c) return fail(-1, "ctx is NULL");
+    // red still holds the (all-reduced) sums of the last promp_meta_grad
+    AdamArgs ad;
+    ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
+    ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = c->NP; ad.K = c->d.num_inner_steps;
+    ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
+    ad.do_update = 1;
+    c->adam_t += 1;
+    const double t = (double)c->adam_t;
+    ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
+    PROMP_LAUNCH(k_mean_adam, dim3((c->NP + 1 + 255) / 256), 256, 0, c->stream, ad);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+int promp_optimize(promp_ctx* c, int num_epochs, float lr, float clip_eps, const float* eta, int inner_kind, int outer_kind,
+                   float* loss_before, float* stats_after) {
+    if (!c || !eta) return fail(-1, "NULL argument");
+    if (num_epochs < 0) return fail(-1, "num_epochs must be >= 0");
+    if (upload_eta(c, eta)) return -2;
+    const int K = c->d.num_inner_steps;
+    for (int e = 0; e < num_epochs; ++e) {
+        if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, true, true, lr)) return -2;
+        if (e == 0 && loss_before)  // the loss evaluated by the first epoch, before its update
+            HIPCHECK(hipMemcpyAsync(loss_before, c->stats, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, false, false, 0.f)) return -2;   // compute_stats
+    if (stats_after) HIPCHECK(hipMemcpyAsync(stats_after, c->stats, sizeof(float) * (K + 2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int clip_ls, float* grads_out, float* loss_out,
+                         float* kl_out) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (kind < 0 || kind > 2) return fail(-1, "unknown objective kind %d", kind);
+    StepData& S = c->steps[step];
+    const int M = c->d.n_tasks;
+    if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f)) return -2;
+    if (launch_reduce(c, S, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
+    std::vector<float> sc((size_t)M * 2);
+    if (copy_out(c, sc.data(), c->scal_tmp, sc.size())) return -2;
+    for (int i = 0; i < M; ++i) {
+        if (loss_out) loss_out[i] = sc[2 * i];
+        if (kl_out) kl_out[i] = sc[2 * i + 1];
+    }
+    return 0;
+}
+
+int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float klw, const float* v, float* out) {
+    if (!c || !v || !out) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    const int M = c->d.n_tasks, NP = c->NP, H1 = c->d.hidden1, H2 = c->d.hidden2;
+    const int oW2 = c->d.obs_dim * H1 + H1;
+    std::vector<float> vt((size_t)M * H1 * H2);
+    for (int i = 0; i < M; ++i)
+        for (int k1 = 0; k1 < H1; ++k1)
+            for (int j2 = 0; j2 < H2; ++j2) vt[(size_t)i * H1 * H2 + (size_t)j2 * H1 + k1] = v[(size_t)i * NP + oW2 + k1 * H2 + j2];
+    if (copy_in(c, c->vbuf, v, (size_t)M * NP) || copy_in(c, c->vw2t, vt.data(), vt.size())) return -2;
+    HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
+    if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw)) return -2;
+    if (launch_reduce(c, S, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    return copy_out(c, out, c->lam, (size_t)M * NP);
+}
+
+int promp_comm_unique_id(void* id_out, size_t id_bytes) {
+#ifndef PROMP_EMU
+    if (!id_out || id_bytes < sizeof(ncclUniqueId)) return fail(-1, "id buffer must hold %zu bytes", sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(-4, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+    memset(id_out, 0, id_bytes);
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+#else
+    (void)id_out; (void)id_bytes;
+    return fail(-4, "no communicator in the kernel-emulation build");
+#endif
+}
+
+int promp_comm_init(promp_ctx* c, int rank, int nranks, const void* id, size_t id_bytes) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "bad rank %d / nranks %d", rank, nranks);
+#ifndef PROMP_EMU
+    if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(-1, "id buffer must hold %zu bytes", sizeof(ncclUniqueId));
+    HIPCHECK(hipSetDevice(c->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, uid, rank);
+    if (r != ncclSuccess) return fail(-4, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    c->rank = rank;
+    c->nranks = nranks;
+    return 0;
+#else
+    (void)id; (void)id_bytes;
+    if (nranks != 1) return fail(-4, "no communicator in the kernel-emulation build");
+    return 0;
+#endif
+}
+
+int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {
+    if (!c || !buf) return fail(-1, "NULL argument");
+    if (n < 1 || n > 64) return fail(-1, "n must be in [1,64]");
+    if (c->nranks == 1) return 0;
+#ifndef PROMP_EMU
+    HIPCHECK(hipMemcpyAsync(c->red64, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    ncclResult_t r = ncclAllReduce(c->red64, c->red64, (size_t)n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    HIPCHECK(hipMemcpyAsync(buf, c->red64, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+#endif
+    return 0;
+}
+
+int promp_prof_enable(promp_ctx* c, int on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (prof_collect(c)) return -2;
+    c->prof = on != 0;
+    if (on)
+        for (auto& s : c->prof_slots) { s.total_ms = 0.0; s.launches = 0; s.rows = 0; }
+    return 0;
+}
+
+int promp_prof_read(promp_ctx* c, int id, double* total_ms, int64_t* launches, int64_t* rows) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (id < 0 || id >= PROMP_KERNEL_COUNT) return fail(-1, "kernel id %d out of range", id);
+    if (prof_collect(c)) return -2;
+    if (total_ms) *total_ms = c->prof_slots[id].total_ms;
+    if (launches) *launches = c->prof_slots[id].launches;
+    if (rows) *rows = c->prof_slots[id].rows;
+    return 0;
+}
+
+int promp_device_info(promp_ctx* c, char* name_out, size_t name_bytes, int32_t* n_cus, int32_t* clock_mhz) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (name_out && name_bytes) snprintf(name_out, name_bytes, "%s", c->dev_name);
+    if (n_cus) *n_cus = c->n_cus;
+    if (clock_mhz) *clock_mhz = c->clock_mhz;
+    return 0;
+}
+
+}  // extern "C"

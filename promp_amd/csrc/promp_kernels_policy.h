@@ -1,0 +1,824 @@
+// promp_kernels_policy.h -- per-task Gaussian-MLP policy passes (reference rows a8-a13).
+//
+//   k_fwd_bwd : objective + mean KL + gradient of one task on one slab            (K8-K11)
+//   k_hvp     : out = -H v + kl_weight * grad KL, H = Hessian of the inner objective (K12, K13)
+//   k_reduce_*: fixed-order reduction of per-workgroup partials, inner SGD step, task mean (K10, K14)
+//   k_adam    : tf.train.AdamOptimizer step                                         (K14)
+//
+// Arithmetic follows oracle/promp.py (which restates meta_algos/pro_mp.py:59-155,
+// meta_algos/base.py:192-215, policies/networks/mlp.py:65-119,
+// policies/distributions/diagonal_gaussian.py:16-109 of the reference).
+//
+// Work decomposition.  A workgroup (256 threads = 4 wavefronts, one per SIMD) owns a contiguous
+// row range of ONE task and walks it in tiles of 64 rows.  Per tile every GEMM of the pass runs
+// on the matrix cores in exact FP32 (32x32x2 tiles; 16x16x4 for the thin A<=8 output layer), with
+// operands read from LDS: activations live in LDS as [row][unit] (stride = units+1, an odd stride
+// is bank-conflict-free for both the row-major A reads and the transposed weight-gradient reads),
+// the task's parameters as [in][out(+1)].  Weight-gradient tiles stay in accumulator registers
+// across all tiles of the workgroup and are written once, as one partial per workgroup;
+// a second tiny kernel adds the partials of a task in fixed order (bitwise reproducible).
+#pragma once
+#include "promp_device.h"
+
+#define PROMP_TILE 64
+#define PROMP_MS 17          // row stride of the [64][16] mean / d-mean staging tiles
+#define PROMP_PARTIAL_EXTRA 4  // loss, kl, 2 spare
+
+struct WorkItem {
+    int task, row_begin, row_end, pad;
+};
+
+enum { LOSS_RATIO = 0, LOSS_CLIP = 1, LOSS_LOGLIK = 2 };
+
+struct PassArgs {
+    const float* obs;           // [rows][O]
+    const float* act;           // [rows][A]
+    const float* adv;           // [rows]
+    const float* old_mean;      // [rows][A]
+    const float* old_log_std;   // [rows][A] or [tasks][A]
+    int ls_per_row;
+    const int* task_row_offsets;  // [tasks+1]
+    const WorkItem* work;         // [grid]
+    const float* theta;           // [Theta] or [tasks][Theta]
+    long long theta_task_stride;  // 0 => shared
+    const float* vdir;            // hvp: [tasks][Theta]
+    const float* vw2t;            // hvp: [tasks][H2*H1] transposed copy of v's hidden_1 kernel
+    float* partials;              // [grid][partial_stride]
+    int partial_stride;
+    int O, A;
+    int loss_kind;
+    float clip_eps;
+    int clip_log_std;
+    float min_log_std;
+    float kl_weight;
+};
+
+struct LdsLayout {
+    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, vls, zero;
+    int xs, h1, h2, ds, ms, rh1, rh2, qs, ms2;
+    int total;  // floats
+    int XS, HS;
+};
+
+PROMP_HD LdsLayout make_layout(int Opad, int H1, int H2, int hvp) {
+    LdsLayout L;
+    int o = 0;
+#define PROMP_TAKE(field, n) \
+    L.field = o;             \
+    o += ((n) + 3) & ~3
+    PROMP_TAKE(w1, Opad * H1);
+    PROMP_TAKE(b1, H1);
+    PROMP_TAKE(w2, H1 * (H2 + 1));
+    PROMP_TAKE(b2, H2);
+    PROMP_TAKE(w3, H2 * 16);
+    PROMP_TAKE(w3t, 8 * H2);
+    PROMP_TAKE(b3, 16);
+    PROMP_TAKE(ls, 16);
+    PROMP_TAKE(lmask, 16);
+    PROMP_TAKE(vls, 16);
+    PROMP_TAKE(zero, 4);
+    L.XS = ((Opad > 32 ? Opad : 32) + 1) | 1;
+    L.HS = (H1 > H2 ? H1 : H2) + 1;
+    PROMP_TAKE(xs, PROMP_TILE * L.XS);
+    PROMP_TAKE(h1, PROMP_TILE * L.HS);
+    PROMP_TAKE(h2, PROMP_TILE * L.HS);
+    PROMP_TAKE(ds, PROMP_TILE * L.HS);
+    PROMP_TAKE(ms, PROMP_TILE * PROMP_MS);
+    L.rh1 = L.rh2 = L.qs = L.ms2 = 0;
+    if (hvp) {
+        PROMP_TAKE(rh1, PROMP_TILE * L.HS);
+        PROMP_TAKE(rh2, PROMP_TILE * L.HS);
+        PROMP_TAKE(qs, PROMP_TILE * L.HS);
+        PROMP_TAKE(ms2, PROMP_TILE * PROMP_MS);
+    }
+#undef PROMP_TAKE
+    L.total = o;
+    return L;
+}
+
+// Stage one task's parameters in LDS.  th is the flat [Theta] vector.
+template <int H1, int H2>
+PROMP_DEV void stage_params(float* sm, const LdsLayout& L, const float* th, int O, int A, int Opad, int tid,
+                            int clip_log_std, float min_log_std) {
+    const int oW1 = 0, ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A,
+              oS = ob3 + A;
+    float* W1s = sm + L.w1;
+    for (int e = tid; e < Opad * H1; e += 256) W1s[e] = (e < O * H1) ? th[oW1 + e] : 0.f;
+    float* W2s = sm + L.w2;
+    for (int e = tid; e < H1 * H2; e += 256) {
+        const int k = e / H2, j = e - k * H2;
+        W2s[k * (H2 + 1) + j] = th[oW2 + e];
+    }
+    float* W3s = sm + L.w3;
+    for (int e = tid; e < H2 * 16; e += 256) {
+        const int k = e >> 4, j = e & 15;
+        W3s[e] = (j < A) ? th[oW3 + k * A + j] : 0.f;
+    }
+    float* W3Ts = sm + L.w3t;
+    for (int e = tid; e < 8 * H2; e += 256) {
+        const int aa = e / H2, k = e - aa * H2;
+        W3Ts[e] = (aa < A) ? th[oW3 + k * A + aa] : 0.f;
+    }
+    if (tid < H1) sm[L.b1 + tid] = th[ob1 + tid];
+    if (tid < H2) sm[L.b2 + tid] = th[ob2 + tid];
+    if (tid < 16) {
+        sm[L.b3 + tid] = (tid < A) ? th[ob3 + tid] : 0.f;
+        const float sr = (tid < A) ? th[oS + tid] : 0.f;
+        // tf.maximum(log_std_var, min_log_std): gradient flows to the variable iff var >= min
+        const bool clipped = clip_log_std && (sr < min_log_std);
+        sm[L.ls + tid] = clipped ? min_log_std : sr;
+        sm[L.lmask + tid] = clipped ? 0.f : 1.f;
+    }
+    if (tid < 4) sm[L.zero + tid] = 0.f;
+    float* Xs = sm + L.xs;
+    for (int e = tid; e < PROMP_TILE * L.XS; e += 256) Xs[e] = 0.f;
+}
+
+PROMP_DEV void load_obs_tile(float* Xs, int XS, const float* obs, long long base, int nrows, int O, int tid) {
+    for (int e = tid; e < PROMP_TILE * O; e += 256) {
+        const int r = e / O, c = e - r * O;
+        Xs[r * XS + c] = (r < nrows) ? obs[base * O + e] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fwd_bwd
+// ---------------------------------------------------------------------------------------------
+template <int NB1, int NB2>
+__global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, MS = PROMP_MS;
+    PROMP_SMEM_DECL;
+    float* sm = (float*)PROMP_SMEM_PTR;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5, i16 = lane & 15, kk = lane >> 4;
+    const WorkItem wk = a.work[blockIdx.x];
+    const int task = wk.task;
+    const int O = a.O, A = a.A, Opad = (O + 1) & ~1;
+    const LdsLayout L = make_layout(Opad, H1, H2, 0);
+    const int XS = L.XS, HS = L.HS;
+    float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
+          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask;
+    float *Xs = sm + L.xs, *H1s = sm + L.h1, *H2s = sm + L.h2, *Ds = sm + L.ds, *Ms = sm + L.ms;
+    const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
+    const float invN = 1.0f / (float)ntask;
+    const float* th = a.theta + (long long)task * a.theta_task_stride;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
+              NP = oS + A;
+
+    stage_params<H1, H2>(sm, L, th, O, A, Opad, tid, a.clip_log_std, a.min_log_std);
+    __syncthreads();
+
+    // persistent accumulators (weight-gradient tiles owned by this wave)
+    f32x16 acc_w2 = zero16(), acc_w1 = zero16();
+    f32x4 acc_w3 = zero4();
+    float loss = 0.f, klsum = 0.f, gb1 = 0.f, gb2 = 0.f;
+    float gs[8], gb3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gs[i] = gb3[i] = 0.f;
+
+    constexpr int NRB3 = H2 / 16;                       // 16-row blocks of the output-kernel gradient
+    constexpr int P3 = (NRB3 >= 4) ? 1 : 4 / NRB3;      // sample-split of those blocks over 4 waves
+    constexpr int KS3 = PROMP_TILE / P3;
+    constexpr int P1 = 4 / NB1;                         // sample-split of the first-layer gradient
+    constexpr int KS1 = PROMP_TILE / P1;
+    const int rbk3 = w % NRB3, part3 = (w / NRB3) % P3;
+    const int cb1 = w % NB1, part1 = w / NB1;
+
+    for (int base = wk.row_begin; base < wk.row_end; base += PROMP_TILE) {
+        const int nrows = (wk.row_end - base) < PROMP_TILE ? (wk.row_end - base) : PROMP_TILE;
+        load_obs_tile(Xs, XS, a.obs, base, nrows, O, tid);
+        __syncthreads();
+        // ---- layer 1: H1 = tanh(X W1 + b1)
+        if (w < 2 * NB1) {
+            const int rb = w / NB1, cb = w % NB1;
+            f32x16 acc = zero16();
+            gemm32(acc, Opnd{Xs + (rb * 32 + li) * XS + lh, 1}, Opnd{W1s + lh * H1 + cb * 32 + li, H1}, Opad, 1.f);
+            const int col = cb * 32 + li;
+            const float bb = b1s[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H1s[(rb * 32 + row32(r, lh)) * HS + col] = fast_tanh(acc[r] + bb);
+        }
+        __syncthreads();
+        // ---- layer 2: H2 = tanh(H1 W2 + b2)
+        if (w < 2 * NB2) {
+            const int rb = w / NB2, cb = w % NB2;
+            f32x16 acc = zero16();
+            gemm32(acc, Opnd{H1s + (rb * 32 + li) * HS + lh, 1}, Opnd{W2s + lh * (H2 + 1) + cb * 32 + li, H2 + 1}, H1,
+                   1.f);
+            const int col = cb * 32 + li;
+            const float bb = b2s[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H2s[(rb * 32 + row32(r, lh)) * HS + col] = fast_tanh(acc[r] + bb);
+        }
+        __syncthreads();
+        // ---- output layer: mean = H2 W3 + b3 (16 rows per wave, columns padded to 16)
+        {
+            f32x4 acc = zero4();
+            gemm16(acc, Opnd{H2s + (16 * w + i16) * HS + kk, 1}, Opnd{W3s + kk * 16 + i16, 16}, H2, 1.f);
+            const float bb = b3s[i16];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ms[(16 * w + 4 * kk + r) * MS + i16] = acc[r] + bb;
+        }
+        __syncthreads();
+        // ---- distribution + objective epilogue, one thread per row
+        if (tid < PROMP_TILE) {
+            float dmu[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dmu[i] = 0.f;
+            if (tid < nrows) {
+                const long long n = (long long)base + tid;
+                const float advn = a.adv[n];
+                const float* ols = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+                float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
+                float z[8], e[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    z[i] = 0.f;
+                    e[i] = 0.f;
+                    if (i < A) {
+                        const float s = lss[i], so = ols[i];
+                        const float mu = Ms[tid * MS + i], mo = a.old_mean[n * A + i], ac = a.act[n * A + i];
+                        e[i] = expf(-s);
+                        z[i] = (ac - mu) * e[i];
+                        const float zo = (ac - mo) * expf(-so);
+                        dlp += (so - s) - 0.5f * (z[i] * z[i] - zo * zo);
+                        sumz2 += z[i] * z[i];
+                        sums += s;
+                        const float so2 = expf(2.f * so), sn2 = expf(2.f * s);
+                        const float num = (mo - mu) * (mo - mu) + so2 - sn2;
+                        kl += num / (2.f * sn2 + 1e-8f) + s - so;
+                    }
+                }
+                const float rho = expf(dlp);
+                float c;
+                if (a.loss_kind == LOSS_RATIO) {
+                    loss += -rho * advn * invN;
+                    c = -advn * rho * invN;
+                } else if (a.loss_kind == LOSS_CLIP) {
+                    const float x = rho * advn;
+                    const float rc = fminf(fmaxf(rho, 1.f - a.clip_eps), 1.f + a.clip_eps);
+                    const float y = rc * advn;
+                    loss += -fminf(x, y) * invN;
+                    c = (x <= y) ? -advn * rho * invN : 0.f;
+                } else {
+                    const float lp = -sums - 0.5f * sumz2 - 0.5f * (float)A * 1.8378770664093453f;
+                    loss += -lp * advn * invN;
+                    c = -advn * invN;
+                }
+                klsum += kl * invN;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < A) {
+                        dmu[i] = c * z[i] * e[i];
+                        gs[i] += c * (z[i] * z[i] - 1.f);
+                        gb3[i] += dmu[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Ms[tid * MS + i] = (i < 8) ? dmu[i] : 0.f;
+        }
+        __syncthreads();
+        // ---- output-kernel gradient (+=) and back-propagation to layer 2
+        gemm16(acc_w3, Opnd{H2s + (part3 * KS3 + kk) * HS + 16 * rbk3 + i16, HS},
+               Opnd{Ms + (part3 * KS3 + kk) * MS + i16, MS}, KS3, 1.f);
+        if (w < 2 * NB2) {
+            const int rb = w / NB2, cb = w % NB2;
+            f32x16 acc = zero16();
+            gemm32(acc, Opnd{Ms + (rb * 32 + li) * MS + lh, 1}, Opnd{W3Ts + lh * H2 + cb * 32 + li, H2}, 8, 1.f);
+            const int col = cb * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + row32(r, lh);
+                const float h = H2s[row * HS + col];
+                Ds[row * HS + col] = acc[r] * (1.f - h * h);
+            }
+        }
+        __syncthreads();
+        // ---- hidden_1 gradient (+=), its bias, and back-propagation to layer 1 (dZ1 overwrites H2s)
+        if (w < NB1 * NB2) {
+            const int kb = w / NB2, jb = w % NB2;
+            gemm32(acc_w2, Opnd{H1s + lh * HS + kb * 32 + li, HS}, Opnd{Ds + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
+                   1.f);
+        }
+        if (tid >= 128 && tid < 128 + H2) {
+            float s = 0.f;
+            for (int r = 0; r < PROMP_TILE; ++r) s += Ds[r * HS + tid - 128];
+            gb2 += s;
+        }
+        if (w < 2 * NB1) {
+            const int rb = w / NB1, cb = w % NB1;
+            f32x16 acc = zero16();
+            gemm32(acc, Opnd{Ds + (rb * 32 + li) * HS + lh, 1}, Opnd{W2s + (cb * 32 + li) * (H2 + 1) + lh, 1}, H2, 1.f);
+            const int col = cb * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + row32(r, lh);
+                const float h = H1s[row * HS + col];
+                H2s[row * HS + col] = acc[r] * (1.f - h * h);
+            }
+        }
+        __syncthreads();
+        // ---- hidden_0 gradient (+=) and its bias
+        gemm32(acc_w1, Opnd{Xs + (part1 * KS1 + lh) * XS + li, XS}, Opnd{H2s + (part1 * KS1 + lh) * HS + cb1 * 32 + li, HS},
+               KS1, 1.f);
+        if (tid >= 192 && tid < 192 + H1) {
+            float s = 0.f;
+            for (int r = 0; r < PROMP_TILE; ++r) s += H2s[r * HS + tid - 192];
+            gb1 += s;
+        }
+        __syncthreads();
+    }
+
+    // ---- one partial per workgroup, in the flat parameter order
+    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    if (w < NB1 * NB2) {
+        const int kb = w / NB2, jb = w % NB2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[oW2 + (kb * 32 + row32(r, lh)) * H2 + jb * 32 + li] = acc_w2[r];
+    }
+    float* S1 = H1s;  // [part][cb][32][32]
+    float* S3 = Ds;   // [part][H2][16]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S1[((part1 * NB1 + cb1) * 32 + row32(r, lh)) * 32 + li] = acc_w1[r];
+    if (w < NRB3 * P3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S3[(part3 * H2 + 16 * rbk3 + 4 * kk + r) * 16 + i16] = acc_w3[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < O * H1; e += 256) {
+        const int row = e / H1, col = e - row * H1;
+        float s = 0.f;
+        for (int p = 0; p < P1; ++p) s += S1[((p * NB1 + (col >> 5)) * 32 + row) * 32 + (col & 31)];
+        P[e] = s;
+    }
+    for (int e = tid; e < H2 * A; e += 256) {
+        const int hid = e / A, aa = e - hid * A;
+        float s = 0.f;
+        for (int p = 0; p < P3; ++p) s += S3[(p * H2 + hid) * 16 + aa];
+        P[oW3 + e] = s;
+    }
+    if (tid >= 192 && tid < 192 + H1) P[ob1 + tid - 192] = gb1;
+    if (tid >= 128 && tid < 128 + H2) P[ob2 + tid - 128] = gb2;
+    if (w == 0) {
+        loss = wave_sum_f32(loss);
+        klsum = wave_sum_f32(klsum);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gb3[i] = wave_sum_f32(gb3[i]);
+            gs[i] = wave_sum_f32(gs[i]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < A) {
+                    P[ob3 + i] = gb3[i];
+                    P[oS + i] = gs[i] * lmask[i];
+                }
+            }
+            P[NP] = loss;
+            P[NP + 1] = klsum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_hvp:  out = -(d^2 L/d theta^2) v + kl_weight * grad KL   (R-operator, see oracle/promp.py:hvp)
+// "q" quantities are (-R{.} + kl_weight * dKL{.}) of the reverse pass.
+// theta in LDS; the direction v is read from global memory (L1/L2 resident, 23.6 KB per task).
+// ---------------------------------------------------------------------------------------------
+template <int NB1, int NB2>
+__global__ void __launch_bounds__(256) k_hvp(PassArgs a) {
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, MS = PROMP_MS;
+    PROMP_SMEM_DECL;
+    float* sm = (float*)PROMP_SMEM_PTR;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5, i16 = lane & 15, kk = lane >> 4;
+    const WorkItem wk = a.work[blockIdx.x];
+    const int task = wk.task;
+    const int O = a.O, A = a.A, Opad = (O + 1) & ~1;
+    const LdsLayout L = make_layout(Opad, H1, H2, 1);
+    const int XS = L.XS, HS = L.HS;
+    float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
+          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *vls = sm + L.vls,
+          *zero = sm + L.zero;
+    float *Xs = sm + L.xs, *H1s = sm + L.h1, *H2s = sm + L.h2, *Ds = sm + L.ds, *Ms = sm + L.ms;
+    float *RH1s = sm + L.rh1, *RH2s = sm + L.rh2, *Qs = sm + L.qs, *Ms2 = sm + L.ms2;
+    const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
+    const float invN = 1.0f / (float)ntask;
+    const float* th = a.theta + (long long)task * a.theta_task_stride;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
+              NP = oS + A;
+    const float* v = a.vdir + (long long)task * NP;
+    const float* vW2T = a.vw2t + (long long)task * (H1 * H2);
+
+    stage_params<H1, H2>(sm, L, th, O, A, Opad, tid, a.clip_log_std, a.min_log_std);
+    __syncthreads();
+    if (tid < 16) vls[tid] = (tid < A) ? v[oS + tid] * lmask[tid] : 0.f;  // R{s} = mask * v_s
+    __syncthreads();
+
+    f32x16 acc_w2 = zero16(), acc_w1 = zero16();
+    f32x4 acc_w3 = zero4();
+    float klsum = 0.f, ob1acc = 0.f, ob2acc = 0.f;
+    float outs[8], outb3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) outs[i] = outb3[i] = 0.f;
+
+    constexpr int NRB3 = H2 / 16;
+    constexpr int P3 = (NRB3 >= 4) ? 1 : 4 / NRB3;
+    constexpr int KS3 = PROMP_TILE / P3;
+    constexpr int P1 = 4 / NB1;
+    constexpr int KS1 = PROMP_TILE / P1;
+    const int rbk3 = w % NRB3, part3 = (w / NRB3) % P3;
+    const int cb1 = w % NB1, part1 = w / NB1;
+    const float klw = a.kl_weight;
+
+    for (int base = wk.row_begin; base < wk.row_end; base += PROMP_TILE) {
+        const int nrows = (wk.row_end - base) < PROMP_TILE ? (wk.row_end - base) : PROMP_TILE;
+        load_obs_tile(Xs, XS, a.obs, base, nrows, O, tid);
+        __syncthreads();
+        // ---- layer 1 and its tangent:  Rz1 = X vW1 + vb1
+        if (w < 2 * NB1) {
+            const int rb = w / NB1, cb = w % NB1;
+            f32x16 az = zero16(), ar = zero16();
+            const Opnd xa{Xs + (rb * 32 + li) * XS + lh, 1};
+            gemm32(az, xa, Opnd{W1s + lh * H1 + cb * 32 + li, H1}, Opad, 1.f);
+            // rows k >= O of v's first kernel do not exist: X's pad column is zero, clamp the row index
+            {
+#pragma unroll 4
+                for (int k = 0; k < Opad; k += 2) {
+                    const int kr = (k + lh < O) ? (k + lh) : (O - 1);
+                    ar = mfma32(xa.p[k], v[kr * H1 + cb * 32 + li], ar);
+                }
+            }
+            const int col = cb * 32 + li;
+            const float bb = b1s[col], vb = v[ob1 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + row32(r, lh);
+                const float h = fast_tanh(az[r] + bb);
+                H1s[row * HS + col] = h;
+                RH1s[row * HS + col] = (1.f - h * h) * (ar[r] + vb);
+            }
+        }
+        __syncthreads();
+        // ---- layer 2 and its tangent:  Rz2 = H1 vW2 + RH1 W2 + vb2
+        if (w < 2 * NB2) {
+            const int rb = w / NB2, cb = w % NB2;
+            f32x16 az = zero16(), ar = zero16();
+            const Opnd ha{H1s + (rb * 32 + li) * HS + lh, 1};
+            const Opnd wb{W2s + lh * (H2 + 1) + cb * 32 + li, H2 + 1};
+            gemm32(az, ha, wb, H1, 1.f);
+            gemm32(ar, ha, Opnd{v + oW2 + lh * H2 + cb * 32 + li, H2}, H1, 1.f);
+            gemm32(ar, Opnd{RH1s + (rb * 32 + li) * HS + lh, 1}, wb, H1, 1.f);
+            const int col = cb * 32 + li;
+            const float bb = b2s[col], vb = v[ob2 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + row32(r, lh);
+                const float h = fast_tanh(az[r] + bb);
+                H2s[row * HS + col] = h;
+                RH2s[row * HS + col] = (1.f - h * h) * (ar[r] + vb);
+            }
+        }
+        __syncthreads();
+        // ---- output layer and its tangent:  Rmu = H2 vW3 + RH2 W3 + vb3
+        {
+            f32x4 am = zero4(), ar = zero4();
+            const Opnd ha{H2s + (16 * w + i16) * HS + kk, 1};
+            const Opnd wb{W3s + kk * 16 + i16, 16};
+            gemm16(am, ha, wb, H2, 1.f);
+            gemm16(ar, Opnd{RH2s + (16 * w + i16) * HS + kk, 1}, wb, H2, 1.f);
+            {   // + H2 vW3 ; columns >= A do not exist (MFMA must stay wave-uniform: mask the value)
+                const int jc = (i16 < A) ? i16 : 0;
+                const float jm = (i16 < A) ? 1.f : 0.f;
+#pragma unroll 4
+                for (int k = 0; k < H2; k += 4) ar = mfma16(ha.p[k], jm * v[oW3 + (k + kk) * A + jc], ar);
+            }
+            const float bb = b3s[i16], vb = (i16 < A) ? v[ob3 + i16] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Ms[(16 * w + 4 * kk + r) * MS + i16] = am[r] + bb;
+                Ms2[(16 * w + 4 * kk + r) * MS + i16] = ar[r] + vb;
+            }
+        }
+        __syncthreads();
+        // ---- loss-level R-operator, one thread per row
+        if (tid < PROMP_TILE) {
+            float dmu[8], qmu[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dmu[i] = qmu[i] = 0.f;
+            if (tid < nrows) {
+                const long long n = (long long)base + tid;
+                const float advn = a.adv[n];
+                const float* ols = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+                float dlp = 0.f, Rlp = 0.f, kl = 0.f;
+                float z[8], e[8], Rmu[8], dklm[8], dkls[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    z[i] = e[i] = Rmu[i] = dklm[i] = dkls[i] = 0.f;
+                    if (i < A) {
+                        const float s = lss[i], so = ols[i];
+                        const float mu = Ms[tid * MS + i], mo = a.old_mean[n * A + i], ac = a.act[n * A + i];
+                        Rmu[i] = Ms2[tid * MS + i];
+                        e[i] = expf(-s);
+                        z[i] = (ac - mu) * e[i];
+                        const float zo = (ac - mo) * expf(-so);
+                        dlp += (so - s) - 0.5f * (z[i] * z[i] - zo * zo);
+                        Rlp += z[i] * e[i] * Rmu[i] + (z[i] * z[i] - 1.f) * vls[i];
+                        const float so2 = expf(2.f * so), sn2 = expf(2.f * s);
+                        const float num = (mo - mu) * (mo - mu) + so2 - sn2;
+                        const float den = 2.f * sn2 + 1e-8f;
+                        kl += num / den + s - so;
+                        dklm[i] = -2.f * (mo - mu) / den * invN;
+                        dkls[i] = ((-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f) * invN;
+                    }
+                }
+                float c, Rc;
+                if (a.loss_kind == LOSS_RATIO) {
+                    c = -advn * expf(dlp) * invN;
+                    Rc = c * Rlp;
+                } else {
+                    c = -advn * invN;
+                    Rc = 0.f;
+                }
+                klsum += kl * invN;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i < A) {
+                        const float Rs = vls[i];
+                        const float Rz = -Rmu[i] * e[i] - z[i] * Rs;
+                        dmu[i] = c * z[i] * e[i];
+                        const float Rdmu = Rc * z[i] * e[i] + c * (Rz * e[i] - z[i] * e[i] * Rs);
+                        const float Rds = Rc * (z[i] * z[i] - 1.f) + 2.f * c * z[i] * Rz;
+                        qmu[i] = -Rdmu + klw * dklm[i];
+                        outs[i] += -Rds + klw * dkls[i];
+                        outb3[i] += qmu[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                Ms[tid * MS + i] = (i < 8) ? dmu[i] : 0.f;
+                Ms2[tid * MS + i] = (i < 8) ? qmu[i] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- out_W3 += -RH2^T dmu + H2^T qmu ; dZ2, qZ2
+        {
+            const int r0 = part3 * KS3 + kk;
+            gemm16(acc_w3, Opnd{RH2s + r0 * HS + 16 * rbk3 + i16, HS}, Opnd{Ms + r0 * MS + i16, MS}, KS3, -1.f);
+            gemm16(acc_w3, Opnd{H2s + r0 * HS + 16 * rbk3 + i16, HS}, Opnd{Ms2 + r0 * MS + i16, MS}, KS3, 1.f);
+        }
+        if (w < 2 * NB2) {
+            const int rb = w / NB2, cb = w % NB2;
+            f32x16 ad = zero16(), aq = zero16();
+            const Opnd da{Ms + (rb * 32 + li) * MS + lh, 1};
+            const Opnd wb{W3Ts + lh * H2 + cb * 32 + li, H2};
+            gemm32(ad, da, wb, 8, 1.f);
+            gemm32(aq, Opnd{Ms2 + (rb * 32 + li) * MS + lh, 1}, wb, 8, 1.f);
+            {   // aq -= dmu vW3^T : B[k=a][j=hidden] = vW3[hidden][a], zero for a >= A
+                const int hid = cb * 32 + li;
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const int aa = k + lh;
+                    const float bv = (aa < A) ? v[oW3 + hid * A + aa] : 0.f;
+                    aq = mfma32(-da.p[k], bv, aq);
+                }
+            }
+            const int col = cb * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + row32(r, lh);
+                const float h = H2s[row * HS + col], rh = RH2s[row * HS + col];
+                const float d1 = 1.f - h * h;
+                Ds[row * HS + col] = ad[r] * d1;
+                Qs[row * HS + col] = aq[r] * d1 + 2.f * ad[r] * h * rh;
+            }
+        }
+        __syncthreads();
+        // ---- out_W2 += -RH1^T dZ2 + H1^T qZ2 ; out_b2 ; qZ1 (overwrites H2s)
+        if (w < NB1 * NB2) {
+            const int kb = w / NB2, jb = w % NB2;
+            gemm32(acc_w2, Opnd{RH1s + lh * HS + kb * 32 + li, HS}, Opnd{Ds + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
+                   -1.f);
+            gemm32(acc_w2, Opnd{H1s + lh * HS + kb * 32 + li, HS}, Opnd{Qs + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
+                   1.f);
+        }
+        if (tid >= 128 && tid < 128 + H2) {
+            float s = 0.f;
+            for (int r = 0; r < PROMP_TILE; ++r) s += Qs[r * HS + tid - 128];
+            ob2acc += s;
+        }
+        if (w < 2 * NB1) {
+            const int rb = w / NB1, cb = w % NB1;
+            f32x16 ad = zero16(), aq = zero16();
+            const Opnd da{Ds + (rb * 32 + li) * HS + lh, 1};
+            const Opnd wt{W2s + (cb * 32 + li) * (H2 + 1) + lh, 1};
+            gemm32(ad, da, wt, H2, 1.f);
+            gemm32(aq, Opnd{Qs + (rb * 32 + li) * HS + lh, 1}, wt, H2, 1.f);
+            // aq -= dZ2 vW2^T : B[k=j2][j=k1] = vW2[k1][j2] = vW2T[j2][k1]
+            gemm32(aq, da, Opnd{vW2T + lh * H1 + cb * 32 + li, H1}, H2, -1.f);
+            const int col = cb * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + row32(r, lh);
+                const float h = H1s[row * HS + col], rh = RH1s[row * HS + col];
+                H2s[row * HS + col] = aq[r] * (1.f - h * h) + 2.f * ad[r] * h * rh;
+            }
+        }
+        __syncthreads();
+        // ---- out_W1 += X^T qZ1 ; out_b1
+        gemm32(acc_w1, Opnd{Xs + (part1 * KS1 + lh) * XS + li, XS}, Opnd{H2s + (part1 * KS1 + lh) * HS + cb1 * 32 + li, HS},
+               KS1, 1.f);
+        if (tid >= 192 && tid < 192 + H1) {
+            float s = 0.f;
+            for (int r = 0; r < PROMP_TILE; ++r) s += H2s[r * HS + tid - 192];
+            ob1acc += s;
+        }
+        __syncthreads();
+    }
+
+    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    if (w < NB1 * NB2) {
+        const int kb = w / NB2, jb = w % NB2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[oW2 + (kb * 32 + row32(r, lh)) * H2 + jb * 32 + li] = acc_w2[r];
+    }
+    float* S1 = H1s;
+    float* S3 = Ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S1[((part1 * NB1 + cb1) * 32 + row32(r, lh)) * 32 + li] = acc_w1[r];
+    if (w < NRB3 * P3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S3[(part3 * H2 + 16 * rbk3 + 4 * kk + r) * 16 + i16] = acc_w3[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < O * H1; e += 256) {
+        const int row = e / H1, col = e - row * H1;
+        float s = 0.f;
+        for (int p = 0; p < P1; ++p) s += S1[((p * NB1 + (col >> 5)) * 32 + row) * 32 + (col & 31)];
+        P[e] = s;
+    }
+    for (int e = tid; e < H2 * A; e += 256) {
+        const int hid = e / A, aa = e - hid * A;
+        float s = 0.f;
+        for (int p = 0; p < P3; ++p) s += S3[(p * H2 + hid) * 16 + aa];
+        P[oW3 + e] = s;
+    }
+    if (tid >= 192 && tid < 192 + H1) P[ob1 + tid - 192] = ob1acc;
+    if (tid >= 128 && tid < 128 + H2) P[ob2 + tid - 128] = ob2acc;
+    if (w == 0) {
+        klsum = wave_sum_f32(klsum);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            outb3[i] = wave_sum_f32(outb3[i]);
+            outs[i] = wave_sum_f32(outs[i]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < A) {
+                    P[ob3 + i] = outb3[i];
+                    P[oS + i] = outs[i] * lmask[i];
+                }
+            }
+            P[NP] = 0.f;
+            P[NP + 1] = klsum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reductions over the per-workgroup partials of each task (fixed order => reproducible).
+// grid = (ceil((NP+EXTRA)/256), n_tasks)
+// ---------------------------------------------------------------------------------------------
+struct ReduceArgs {
+    const float* partials;
+    int partial_stride;
+    const int* task_wg_offsets;  // [tasks+1]: workgroups of task i are [o[i], o[i+1])
+    int NP;                      // Theta
+    int H1, H2, oW2;
+    const float* step_sizes;     // [Theta]
+    // mode 0 (inner step): next[i] = cur[i] - alpha * g ; scal[i] = {loss, kl}
+    // mode 1 (outer)     : lam[i] = g ; v[i] = alpha * g ; vw2t ; scal[i] = {loss, kl}
+    // mode 2 (hvp)       : lam[i] += g ; v[i] = alpha * lam[i] ; vw2t ; scal[i] = {-, kl}
+    // mode 3 (plain)     : lam[i] = g ; scal
+    int mode;
+    const float* cur;            // [Theta] or [tasks][Theta]
+    long long cur_task_stride;
+    float* next;                 // [tasks][Theta]
+    float* lam;                  // [tasks][Theta]
+    float* v;                    // [tasks][Theta]
+    float* vw2t;                 // [tasks][H2*H1]
+    float* scal;                 // [tasks][2]
+};
+
+__global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int task = blockIdx.y;
+    if (j >= a.NP + 2) return;
+    float g = 0.f;
+    for (int wg = a.task_wg_offsets[task]; wg < a.task_wg_offsets[task + 1]; ++wg)
+        g += a.partials[(long long)wg * a.partial_stride + j];
+    if (j >= a.NP) {
+        a.scal[task * 2 + (j - a.NP)] = g;
+        return;
+    }
+    const long long tj = (long long)task * a.NP + j;
+    if (a.mode == 0) {
+        a.next[tj] = a.cur[(long long)task * a.cur_task_stride + j] - a.step_sizes[j] * g;
+        return;
+    }
+    float lam = g;
+    if (a.mode == 2) lam += a.lam[tj];
+    a.lam[tj] = lam;
+    if (a.mode == 3) return;
+    const float vv = a.step_sizes[j] * lam;
+    a.v[tj] = vv;
+    const int q = j - a.oW2;
+    if (q >= 0 && q < a.H1 * a.H2) {
+        const int k1 = q / a.H2, j2 = q - k1 * a.H2;
+        a.vw2t[(long long)task * a.H1 * a.H2 + j2 * a.H1 + k1] = vv;
+    }
+}
+
+// Task sum of lam (gradient) and of the per-task scalars -> red[NP + K + 2]
+//   red[0..NP)      = sum_i lam[i][j]
+//   red[NP]         = sum_i J_i                     (outer surrogate)
+//   red[NP+1+k]     = sum_i KL^k_i
+//   red[NP+1+K]     = sum_i outer KL_i
+// grid = ceil((NP+K+2)/256)
+struct FinalArgs {
+    const float* lam;
+    int NP, K, n_tasks;
+    const float* scal_inner;  // [K][tasks][2]
+    const float* scal_outer;  // [tasks][2]
+    float* red;
+    int want_grad;
+};
+
+__global__ void __launch_bounds__(256) k_reduce_final(FinalArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.NP + a.K + 2) return;
+    float s = 0.f;
+    if (j < a.NP) {
+        if (a.want_grad)
+            for (int i = 0; i < a.n_tasks; ++i) s += a.lam[(long long)i * a.NP + j];
+    } else if (j == a.NP) {
+        for (int i = 0; i < a.n_tasks; ++i) s += a.scal_outer[i * 2 + 0];
+    } else if (j <= a.NP + a.K) {
+        const int k = j - a.NP - 1;
+        for (int i = 0; i < a.n_tasks; ++i) s += a.scal_inner[((long long)k * a.n_tasks + i) * 2 + 1];
+    } else {
+        for (int i = 0; i < a.n_tasks; ++i) s += a.scal_outer[i * 2 + 1];
+    }
+    a.red[j] = s;
+}
+
+// Mean over the global meta-batch + Adam.  red holds SUMS over all tasks (after the all-reduce).
+// stats[0] = loss = mean_i J_i + mean_k(eta_k * mean_i KL^k_i); stats[1+k] = inner_kl[k]; stats[1+K] = outer_kl
+struct AdamArgs {
+    float* theta;
+    float* m;
+    float* v;
+    const float* red;
+    float* grad_mean;  // [NP] task-mean gradient (kept for promp_meta_grad's output)
+    float* stats;      // [K+2]
+    const float* eta;  // [K]
+    int NP, K;
+    float inv_tasks;
+    float lr_t;        // lr * sqrt(1-b2^t)/(1-b1^t); 0 => no parameter update (stats / grad only)
+    int do_update;
+};
+
+__global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < a.NP) {
+        const float g = a.red[j] * a.inv_tasks;
+        a.grad_mean[j] = g;
+        if (a.do_update) {
+            const float m = 0.9f * a.m[j] + 0.1f * g;
+            const float v = 0.999f * a.v[j] + 0.001f * g * g;
+            a.m[j] = m;
+            a.v[j] = v;
+            a.theta[j] -= a.lr_t * m / (sqrtf(v) + 1e-8f);
+        }
+    } else if (j == a.NP) {
+        float pen = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            const float ikl = a.red[a.NP + 1 + k] * a.inv_tasks;
+            a.stats[1 + k] = ikl;
+            pen += a.eta[k] * ikl;
+        }
+        a.stats[0] = a.red[a.NP] * a.inv_tasks + pen / (float)a.K;
+        a.stats[1 + a.K] = a.red[a.NP + 1 + a.K] * a.inv_tasks;
+    }
+}
+
+// dst[i][:] = src[:] for i < n_tasks   (MetaPolicy.switch_to_pre_update)
+__global__ void __launch_bounds__(256) k_replicate(float* dst, const float* src, int NP, int n_tasks) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < NP)
+        for (int i = 0; i < n_tasks; ++i) dst[(long long)i * NP + j] = src[j];
+}

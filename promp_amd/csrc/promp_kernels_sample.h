@@ -1,0 +1,324 @@
+// promp_kernels_sample.h -- sample processing on the device (reference rows a1-a7), FP64 like the
+// reference (SciPy lfilter / NumPy lstsq compute in float64).
+//
+//   k_returns   : per path  R[t] = r[t] + g R[t+1]             utils/utils.py:74-81, samplers/base.py:103-104
+//   k_gram      : per task  [Phi R]^T [Phi R] (normal equations) baselines/linear_baseline.py:66-67,101-106
+//   k_fit       : per task  (G + reg I) w = Phi^T R, NaN retry   baselines/linear_baseline.py:68-77
+//   k_gae       : per path  b = Phi w ; delta ; GAE scan          baselines/linear_baseline.py:17-33, samplers/base.py:151-162
+//   k_normalize : per task  (adv-mean)/(std+1e-8) [, shift >0]    utils/utils.py:59-71
+//
+// One wavefront owns one path in the scans: the linear recurrence y[t] = x[t] + c*y[t+1] is a
+// 6-step wave-level suffix scan over 64 time steps (weights c, c^2, c^4, ...), chained across
+// 64-step chunks from the end of the path with a carry, so ragged path lengths need no padding.
+// The Gram matrix runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): the target is appended
+// to the features as one more column so that Phi^T R falls out of the same product.
+#pragma once
+#include "promp_device.h"
+#include "promp_kernels_policy.h"  // WorkItem
+
+enum { BASE_ZERO = 0, BASE_LINFEAT = 1, BASE_LINTIME = 2 };
+
+struct SampleArgs {
+    const float* obs;              // [rows][O]
+    const float* rew;              // [rows]
+    const int* path_row_offsets;   // [paths+1]
+    const int* path_task;          // [paths]
+    const int* row_t;              // [rows] time index inside the path
+    const int* task_row_offsets;   // [tasks+1]
+    const int* task_path_offsets;  // [tasks+1]
+    const WorkItem* work;          // row ranges (multiples of 64 from the task start)
+    const int* task_wg_offsets;    // [tasks+1]
+    int O, D, kind;
+    double gamma, lam, reg;
+    int normalize, positive;
+    double* ret64;
+    float* ret32;
+    double* adv64;
+    float* adv32;
+    double* path_ret0;
+    double* path_undisc;
+    double* path_rsq;
+    double* path_mom;       // [paths][3] sum adv, sum adv^2, min adv
+    double* gram_partials;  // [grid][NPAIR*256]
+    double* coeffs;         // [tasks][coeff_stride]
+    int coeff_stride;
+};
+
+PROMP_DEV double feature_at(const SampleArgs& a, long long row, int c) {
+    const int O = a.O;
+    if (c == a.D) return a.ret64[row];  // appended target column
+    if (c > a.D) return 0.0;
+    int q = c;
+    if (a.kind == BASE_LINFEAT) {
+        if (c < 2 * O) {
+            const float o = a.obs[row * O + (c < O ? c : c - O)];
+            const float oc = fminf(fmaxf(o, -10.f), 10.f);
+            // the reference squares in the observations' own dtype (float32), then promotes
+            return (c < O) ? (double)oc : (double)(oc * oc);
+        }
+        q = c - 2 * O;
+    }
+    const double tau = (double)a.row_t[row] / 100.0;
+    if (q == 0) return tau;
+    if (q == 1) return tau * tau;
+    if (q == 2) return tau * tau * tau;
+    return 1.0;
+}
+
+// grid = paths, block = 64
+__global__ void __launch_bounds__(64) k_returns(SampleArgs a) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int row0 = a.path_row_offsets[p], T = a.path_row_offsets[p + 1] - row0;
+    const double g = a.gamma;
+    const double f = pow(g, (double)(64 - lane));
+    double carry = 0.0, usum = 0.0, rsq = 0.0, y0 = 0.0;
+    for (int end = T; end > 0; end -= 64) {
+        const int t = end - 64 + lane;
+        const double x = (t >= 0) ? (double)a.rew[row0 + t] : 0.0;
+        double y = x, gg = g;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double up = shfl_down_f64(y, d);
+            if (lane + d < 64) y += gg * up;
+            gg *= gg;
+        }
+        y += f * carry;
+        if (t >= 0) {
+            a.ret64[row0 + t] = y;
+            a.ret32[row0 + t] = (float)y;
+        }
+        if (t == 0) y0 = y;
+        carry = shfl_idx_f64(y, 0);
+        usum += x;
+        rsq += x * x;
+    }
+    usum = wave_sum_f64(usum);
+    rsq = wave_sum_f64(rsq);
+    y0 = wave_sum_f64(y0);
+    if (lane == 0) {
+        a.path_ret0[p] = y0;
+        a.path_undisc[p] = usum;
+        a.path_rsq[p] = rsq;
+    }
+}
+
+template <int NBLK>
+struct GramCfg {
+    static constexpr int FS = (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16;  // row stride (doubles)
+    static constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
+    static constexpr int SMEM_BYTES = (32 * FS + NPAIR * 256) * 8;
+};
+
+// grid = work items, block = 256.  Partial Gram of [Phi R] over the item's rows.
+template <int NBLK>
+__global__ void __launch_bounds__(256) k_gram(SampleArgs a) {
+    constexpr int FS = GramCfg<NBLK>::FS, NPAIR = GramCfg<NBLK>::NPAIR, NC = 16 * NBLK;
+    PROMP_SMEM_DECL;
+    double* Phi = (double*)PROMP_SMEM_PTR;
+    double* Red = Phi + 32 * FS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    const WorkItem wk = a.work[blockIdx.x];
+    f64x4 acc[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) acc[p] = zero4d();
+    for (int base = wk.row_begin; base < wk.row_end; base += 32) {
+        const int nrows = (wk.row_end - base) < 32 ? (wk.row_end - base) : 32;
+        for (int e = tid; e < 32 * NC; e += 256) {
+            const int r = e / NC, c = e - r * NC;
+            Phi[r * FS + c] = (r < nrows) ? feature_at(a, (long long)base + r, c) : 0.0;
+        }
+        __syncthreads();
+        for (int s = w; s < 8; s += 4) {
+            double av[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) av[b] = Phi[(4 * s + kk) * FS + 16 * b + i16];
+            int p = 0;
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+                for (int bj = bi; bj < NBLK; ++bj) {
+                    acc[p] = mfma16d(av[bi], av[bj], acc[p]);
+                    ++p;
+                }
+        }
+        __syncthreads();
+    }
+    for (int ww = 0; ww < 4; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = p * 256 + (kk + 4 * r) * 16 + i16;
+                    Red[idx] = (ww == 0 ? 0.0 : Red[idx]) + acc[p][r];
+                }
+        }
+        __syncthreads();
+    }
+    double* out = a.gram_partials + (long long)blockIdx.x * (NPAIR * 256);
+    for (int e = tid; e < NPAIR * 256; e += 256) out[e] = Red[e];
+}
+
+// grid = tasks, block = 256.  smem: G[(D+1)^2] + Wm[(D+1)^2] + yv[D+1] + wv[D+1] + flag   (doubles)
+__global__ void __launch_bounds__(256) k_fit(SampleArgs a, int NBLK) {
+    PROMP_SMEM_DECL;
+    const int D = a.D, DA = D + 1;
+    double* G = (double*)PROMP_SMEM_PTR;
+    double* Wm = G + DA * DA;
+    double* yv = Wm + DA * DA;
+    double* wv = yv + DA;
+    int* flag = (int*)(wv + DA);
+    const int tid = threadIdx.x, task = blockIdx.x;
+    const int NPAIR = NBLK * (NBLK + 1) / 2;
+    // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
+    for (int e = tid; e < NPAIR * 256; e += 256) {
+        double s = 0.0;
+        for (int wg = a.task_wg_offsets[task]; wg < a.task_wg_offsets[task + 1]; ++wg)
+            s += a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+        int p = e >> 8, bi = 0, rem = p;
+        while (rem >= NBLK - bi) {
+            rem -= NBLK - bi;
+            ++bi;
+        }
+        const int bj = bi + rem;
+        const int row = 16 * bi + ((e & 255) >> 4), col = 16 * bj + (e & 15);
+        if (row < DA && col < DA) {
+            G[row * DA + col] = s;
+            if (bi != bj) G[col * DA + row] = s;
+        }
+    }
+    __syncthreads();
+    // 2. Cholesky of (G[:D,:D] + reg I) carrying the right-hand-side row D along (forward solve for free),
+    //    then back substitution; NaN => reg *= 10, at most 5 tries (linear_baseline.py:68-77)
+    double reg = a.reg;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        for (int e = tid; e < DA * DA; e += 256) {
+            const int i = e / DA, j = e - i * DA;
+            Wm[e] = G[e] + ((i == j && i < D) ? reg : 0.0);
+        }
+        __syncthreads();
+        for (int j = 0; j < D; ++j) {
+            if (tid == 0) Wm[j * DA + j] = sqrt(Wm[j * DA + j]);
+            __syncthreads();
+            if (tid > j && tid <= D) Wm[tid * DA + j] /= Wm[j * DA + j];
+            __syncthreads();
+            const int nr = D - j, nc = D - j - 1;  // rows j+1..D, cols j+1..D-1
+            for (int e = tid; e < nr * nc; e += 256) {
+                const int i = j + 1 + e / nc, k = j + 1 + e % nc;
+                if (k <= i) Wm[i * DA + k] -= Wm[i * DA + j] * Wm[k * DA + j];
+            }
+            __syncthreads();
+        }
+        if (tid < D) yv[tid] = Wm[D * DA + tid];
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int j = D - 1; j >= 0; --j) {
+            if (tid == 0) wv[j] = yv[j] / Wm[j * DA + j];
+            __syncthreads();
+            if (tid < j) yv[tid] -= Wm[j * DA + tid] * wv[j];
+            __syncthreads();
+        }
+        if (tid < D && wv[tid] != wv[tid]) *flag = 1;
+        __syncthreads();
+        const int bad = *flag;
+        __syncthreads();
+        if (!bad) break;
+        reg *= 10.0;
+    }
+    if (tid < D) a.coeffs[(long long)task * a.coeff_stride + tid] = wv[tid];
+}
+
+// grid = paths, block = 64.  smem: D doubles (the task's coefficients)
+__global__ void __launch_bounds__(64) k_gae(SampleArgs a) {
+    PROMP_SMEM_DECL;
+    double* wc = (double*)PROMP_SMEM_PTR;
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int row0 = a.path_row_offsets[p], T = a.path_row_offsets[p + 1] - row0;
+    const int task = a.path_task[p];
+    const int O = a.O, D = a.D;
+    if (a.kind != BASE_ZERO)
+        for (int i = lane; i < D; i += 64) wc[i] = a.coeffs[(long long)task * a.coeff_stride + i];
+    __syncthreads();
+    const double g = a.gamma, gl = a.gamma * a.lam;
+    const double f = pow(gl, (double)(64 - lane));
+    double carry = 0.0, bcarry = 0.0, s1 = 0.0, s2 = 0.0, mn = 1e300;
+    for (int end = T; end > 0; end -= 64) {
+        const int t = end - 64 + lane;
+        const bool valid = t >= 0;
+        const long long row = (long long)row0 + t;
+        double b = 0.0;
+        if (valid && a.kind != BASE_ZERO) {
+            int q = 0;
+            if (a.kind == BASE_LINFEAT) {
+                for (int c = 0; c < O; ++c) {
+                    const float o = a.obs[row * O + c];
+                    const float oc = fminf(fmaxf(o, -10.f), 10.f);
+                    b += wc[c] * (double)oc + wc[O + c] * (double)(oc * oc);
+                }
+                q = 2 * O;
+            }
+            const double tau = (double)t / 100.0;
+            b += wc[q] * tau + wc[q + 1] * (tau * tau) + wc[q + 2] * (tau * tau * tau) + wc[q + 3];
+        }
+        double bn = shfl_down_f64(b, 1);
+        if (lane == 63) bn = bcarry;
+        const double x = valid ? ((double)a.rew[valid ? row : 0] + g * bn - b) : 0.0;
+        double y = x, gg = gl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double up = shfl_down_f64(y, d);
+            if (lane + d < 64) y += gg * up;
+            gg *= gg;
+        }
+        y += f * carry;
+        if (valid) {
+            a.adv64[row] = y;
+            s1 += y;
+            s2 += y * y;
+            mn = y < mn ? y : mn;
+        }
+        carry = shfl_idx_f64(y, 0);
+        bcarry = shfl_idx_f64(b, 0);
+    }
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
+    mn = wave_min_f64(mn);
+    if (lane == 0) {
+        a.path_mom[3 * p + 0] = s1;
+        a.path_mom[3 * p + 1] = s2;
+        a.path_mom[3 * p + 2] = mn;
+    }
+}
+
+// grid = work items, block = 256
+__global__ void __launch_bounds__(256) k_normalize(SampleArgs a) {
+    __shared__ double st[3];
+    const int tid = threadIdx.x;
+    const WorkItem wk = a.work[blockIdx.x];
+    const int task = wk.task;
+    if (tid == 0) {
+        double s1 = 0.0, s2 = 0.0, mn = 1e300;
+        for (int p = a.task_path_offsets[task]; p < a.task_path_offsets[task + 1]; ++p) {
+            s1 += a.path_mom[3 * p];
+            s2 += a.path_mom[3 * p + 1];
+            mn = a.path_mom[3 * p + 2] < mn ? a.path_mom[3 * p + 2] : mn;
+        }
+        const double n = (double)(a.task_row_offsets[task + 1] - a.task_row_offsets[task]);
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        st[0] = mean;
+        st[1] = sqrt(var);
+        st[2] = mn;
+    }
+    __syncthreads();
+    const double mean = st[0], sd = st[1];
+    double mn = st[2];
+    if (a.normalize) mn = (mn - mean) / (sd + 1e-8);
+    for (int row = wk.row_begin + tid; row < wk.row_end; row += 256) {
+        double x = a.adv64[row];
+        if (a.normalize) x = (x - mean) / (sd + 1e-8);
+        if (a.positive) x = (x - mn) + 1e-8;
+        a.adv32[row] = (float)x;
+    }
+}

@@ -1,0 +1,27 @@
+"""Build tests/emu/libpromp_emu.so: the kernel sources of promp_amd/csrc compiled by g++ against the
+SIMT interpreter in hip_emu.h.  TEST INFRASTRUCTURE ONLY -- never loaded by the promp_amd package."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC = os.path.join(ROOT, 'promp_amd', 'csrc', 'promp_hip.hip')
+OUT = os.path.join(HERE, 'libpromp_emu.so')
+
+
+def build(force=False):
+    deps = [SRC, os.path.join(HERE, 'hip_emu.h')] + [os.path.join(ROOT, 'promp_amd', 'csrc', f)
+                                                      for f in os.listdir(os.path.join(ROOT, 'promp_amd', 'csrc'))]
+    deps.append(os.path.join(ROOT, 'include', 'promp_hip.h'))
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    cmd = ['g++', '-std=c++20', '-O1', '-g', '-DPROMP_EMU', '-fPIC', '-shared', '-x', 'c++', SRC,
+           '-I', HERE, '-I', os.path.join(ROOT, 'promp_amd', 'csrc'), '-o', OUT, '-lpthread',
+           '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-variable', '-Wno-unused-but-set-variable']
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,204 @@
+// hip_emu.h -- TEST INFRASTRUCTURE ONLY.  A SIMT interpreter just big enough to execute the kernels of
+// promp_amd/csrc on the host: one OS thread per lane, 64-lane wavefronts, workgroup barriers, wave
+// shuffles and the MFMA fragment layouts of gfx950 (restated from cdna_hip_programming.md section 3:
+//   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+//   16x16x4 f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15, row=4*(l>>4)+r
+//   16x16x4 f64 : same A/B,                               D col=l&15, row=(l>>4)+4*r
+// each product accumulated as a k-ordered fma chain).
+// It exists so that kernel indexing / host sequencing can be checked in a container without a GPU.
+// It is built only by tests/emu/build_emu.py into tests/emu/libpromp_emu.so and is never loaded by
+// promp_amd (the product binds libpromp_hip.so only and has no CPU path).
+#pragma once
+#include <algorithm>
+#include <barrier>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define PROMP_DEV inline
+#define PROMP_HD inline
+#define __global__
+#define __device__
+#define __host__
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef double f64x4 __attribute__((vector_size(32)));
+
+namespace emu {
+
+struct Wave {
+    std::barrier<> bar;
+    float fa[64], fb[64];
+    double da[64], db[64];
+    explicit Wave(int n) : bar(n) {}
+};
+
+struct Block {
+    std::barrier<> bar;
+    std::vector<std::unique_ptr<Wave>> waves;
+    unsigned char* smem;
+    Block(int nthreads, size_t smem_bytes) : bar(nthreads) {
+        for (int w = 0; w * 64 < nthreads; ++w) waves.emplace_back(new Wave(std::min(64, nthreads - w * 64)));
+        smem = (unsigned char*)aligned_alloc(64, (smem_bytes + 1024 + 63) / 64 * 64);
+        memset(smem, 0xFF, (smem_bytes + 1024 + 63) / 64 * 64);   // poison: uninitialised LDS reads show up as NaN
+    }
+    ~Block() { free(smem); }
+};
+
+struct TL {
+    dim3 tidx, bidx, bdim, gdim;
+    Block* blk = nullptr;
+};
+inline thread_local TL tl;
+
+inline Wave& wave() { return *tl.blk->waves[tl.tidx.x >> 6]; }
+inline int lane() { return tl.tidx.x & 63; }
+
+template <class F>
+void launch(dim3 grid, int block, size_t smem, F body) {
+    for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned bx = 0; bx < grid.x; ++bx) {
+            Block blk(block, smem);
+            std::vector<std::thread> th;
+            th.reserve(block);
+            for (int t = 0; t < block; ++t)
+                th.emplace_back([&, t]() {
+                    tl.tidx = dim3(t);
+                    tl.bidx = dim3(bx, by);
+                    tl.bdim = dim3(block);
+                    tl.gdim = grid;
+                    tl.blk = &blk;
+                    body();
+                });
+            for (auto& x : th) x.join();
+        }
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::tl.tidx)
+#define blockIdx (emu::tl.bidx)
+#define blockDim (emu::tl.bdim)
+#define gridDim (emu::tl.gdim)
+#define PROMP_SMEM_DECL (void)0
+#define PROMP_SMEM_PTR (emu::tl.blk->smem)
+#define PROMP_LAUNCH(kern, grid, block, smem, stream, ...) emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
+
+inline void __syncthreads() { emu::tl.blk->bar.arrive_and_wait(); }
+
+inline f32x16 mfma32(float a, float b, f32x16 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 31, h = l >> 5;
+    W.fa[l] = a;
+    W.fb[l] = b;
+    W.bar.arrive_and_wait();
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        acc = fmaf(W.fa[i], W.fb[j], acc);
+        acc = fmaf(W.fa[i + 32], W.fb[j + 32], acc);
+        d[r] = acc;
+    }
+    W.bar.arrive_and_wait();
+    return d;
+}
+inline f32x4 mfma16(float a, float b, f32x4 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 15, g = l >> 4;
+    W.fa[l] = a;
+    W.fb[l] = b;
+    W.bar.arrive_and_wait();
+    f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(W.fa[i + 16 * k], W.fb[j + 16 * k], acc);
+        d[r] = acc;
+    }
+    W.bar.arrive_and_wait();
+    return d;
+}
+inline f64x4 mfma16d(double a, double b, f64x4 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 15, g = l >> 4;
+    W.da[l] = a;
+    W.db[l] = b;
+    W.bar.arrive_and_wait();
+    f64x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int i = g + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fma(W.da[i + 16 * k], W.db[j + 16 * k], acc);
+        d[r] = acc;
+    }
+    W.bar.arrive_and_wait();
+    return d;
+}
+
+inline double emu_shfl_f64(double v, int src) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane();
+    W.da[l] = v;
+    W.bar.arrive_and_wait();
+    const double r = (src >= 0 && src < 64) ? W.da[src] : v;
+    W.bar.arrive_and_wait();
+    return r;
+}
+inline float shfl_xor_f32(float v, int m) { return (float)emu_shfl_f64((double)v, emu::lane() ^ m); }
+inline double shfl_xor_f64(double v, int m) { return emu_shfl_f64(v, emu::lane() ^ m); }
+inline double shfl_down_f64(double v, int d) { return emu_shfl_f64(v, emu::lane() + d); }
+inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
+inline float fast_exp(float x) { return expf(x); }
+inline float fast_rcp(float x) { return 1.0f / x; }
+
+// ---- host runtime shims -------------------------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+inline const char* hipGetErrorString(hipError_t) { return "emulated-hip-error"; }
+typedef void* hipStream_t;
+struct EmuEvent { std::chrono::steady_clock::time_point t; };
+typedef EmuEvent* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; int clockRate; };
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    snprintf(p->name, sizeof p->name, "kernel-emulator (tests only)");
+    const char* e = getenv("PROMP_EMU_CUS");
+    p->multiProcessorCount = e ? atoi(e) : 4;
+    p->clockRate = 1000;
+    return 0;
+}
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(64, (n + 63) / 64 * 64); return *p ? 0 : 1; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent(); return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return 0;
+}

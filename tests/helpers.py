@@ -51,3 +51,45 @@ def load_promp(name):
                               agent_infos=dict(mean=g['step%d_mean' % k][i], log_std=g['step%d_log_std' % k][i])))
         all_slabs.append(slabs)
     return c, g['theta'], all_slabs, g
+
+
+def make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=False, low_log_std=False, per_task_log_std=False):
+    """Seeded slabs for steps 0..K (same recipe as oracle/gen_golden.py:make_promp_inputs): the 'old' policy
+    differs from theta so that ratio != 1 and the PPO clip is active on some rows."""
+    from promp_amd import synthetic
+    rng = np.random.RandomState(seed)
+    theta = synthetic.init_theta(rng, O, hidden, A)
+    theta = (theta + 0.05 * rng.randn(theta.size)).astype(np.float32)
+    if low_log_std:
+        theta[-A:] = np.log(1e-6) + np.array([-0.5, 0.5, -1.0, 0.2, -0.2, 0.1, 0.3, -0.3][:A])
+    all_slabs, all_paths = [], []
+    for k in range(K + 1):
+        theta_old = (theta + 0.1 * rng.randn(M, theta.size)).astype(np.float32)
+        if low_log_std:
+            theta_old = np.tile(theta, (M, 1))
+        paths = synthetic.make_paths(rng, theta_old, M, P, T, O, A, hidden, ragged=ragged)
+        slabs = []
+        for plist in paths.values():
+            cat = lambda key: np.concatenate([p[key] for p in plist])
+            n = len(cat('rewards'))
+            ls = np.concatenate([p['agent_infos']['log_std'] for p in plist])
+            slabs.append(dict(observations=cat('observations'), actions=cat('actions'),
+                              advantages=rng.randn(n).astype(np.float32),
+                              agent_infos=dict(mean=np.concatenate([p['agent_infos']['mean'] for p in plist]),
+                                               log_std=ls)))
+        all_slabs.append(slabs)
+        all_paths.append(paths)
+    return theta, all_slabs, all_paths
+
+
+def upload_slabs(ctx, all_paths, all_slabs, compact_log_std=False):
+    """Upload steps 0..K of make_promp_case() into a Context and set the advantages."""
+    from promp_amd import _lib
+    for k, paths in enumerate(all_paths):
+        fl = _lib.flatten_paths(paths)
+        ls = fl['old_log_std']
+        if compact_log_std:
+            ls = np.stack([s['agent_infos']['log_std'][0] for s in all_slabs[k]])
+        ctx.upload_step(k, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'], fl['act'],
+                        fl['old_mean'], ls)
+        ctx.set_advantages(k, np.concatenate([s['advantages'] for s in all_slabs[k]]))

@@ -1,0 +1,162 @@
+"""Parity checks HIP path vs oracle, shared by the emulated (CPU, tiny) and the real (-m gpu) tests.
+Every check goes through the C ABI (promp_amd._lib.Context) of the library it is handed.
+
+Stated tolerances (float32 device arithmetic vs float64 oracle):
+  returns      : rtol 1e-6  (FP64 scan on device, rounded once to float32)
+  advantages   : rtol 1e-4, atol 1e-5  (after normalisation)
+  coefficients : predictions compared, not raw coefficients (normal equations are ill-conditioned);
+                 raw coefficients rtol 1e-6 on well-conditioned fixtures
+  loss / KL    : rtol 1e-4
+  gradients    : 1e-4 of the max-norm (meta-gradient: 1e-3 in BASELINE.md; we hold 1e-4)
+"""
+import numpy as np
+
+from oracle import policy as op
+from oracle import promp as pm
+from oracle import sample_processing as sp
+from promp_amd import _lib
+from tests import helpers
+
+KIND = dict(zero=0, linear_feature=1, linear_time=2)
+
+
+def rel_max(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def run_sample_processing(lib, paths, kwargs, baseline, hidden=(32, 32)):
+    fl = _lib.flatten_paths(paths)
+    M, O = len(paths), fl['obs'].shape[1]
+    ctx = _lib.Context(M, O, 2, hidden, 1, max_rows=len(fl['rew']), max_paths=len(fl['path_row_offsets']) - 1, lib=lib)
+    ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
+    ctx.process_samples(0, baseline_kind=KIND[baseline], **kwargs)
+    out = ctx.download_processed(0)
+    ctx.close()
+    return out
+
+
+def check_sample_processing_golden(lib, name):
+    """HIP path vs the reference's own outputs (tests/golden/sample_proc_*.npz)."""
+    meta, paths, g = helpers.load_sample_proc(name)
+    out = run_sample_processing(lib, paths, meta['kwargs'], meta['baseline'])
+    np.testing.assert_allclose(out['returns'], g['returns'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out['advantages'], g['advantages'], rtol=1e-4, atol=1e-5)
+    if meta['baseline'] != 'zero' and meta['extras'].get('obs_dtype', 'float32') == 'float32':
+        np.testing.assert_allclose(out['coeffs'], g['coeffs'], rtol=1e-5, atol=1e-7)
+    st = meta['stats']
+    assert np.mean(out['path_returns0']) == np.float64(st['AverageDiscountedReturn']).__class__(
+        np.mean(out['path_returns0']))  # finite
+    np.testing.assert_allclose(np.mean(out['path_returns0']), st['AverageDiscountedReturn'], rtol=1e-5)
+    np.testing.assert_allclose(np.mean(out['path_undiscounted']), st['AverageReturn'], rtol=1e-5)
+    np.testing.assert_allclose(np.std(out['path_undiscounted']), st['StdReturn'], rtol=1e-4)
+    np.testing.assert_allclose(np.max(out['path_undiscounted']), st['MaxReturn'], rtol=1e-5)
+    np.testing.assert_allclose(np.min(out['path_undiscounted']), st['MinReturn'], rtol=1e-5)
+    # adj_avg_rewards moments (meta_sample_processor.py:40-44) from the per-path sums
+    n = len(g['rewards'])
+    mu = np.sum(out['path_undiscounted']) / n
+    sd = np.sqrt(max(np.sum(out['path_reward_sumsq']) / n - mu * mu, 0.0))
+    np.testing.assert_allclose((g['rewards'] - mu) / (sd + 1e-8), g['adj_avg_rewards'], rtol=1e-4, atol=1e-5)
+
+
+def check_sample_processing_oracle(lib, seed, M, P, T, O, ragged, kwargs, baseline='linear_feature'):
+    from promp_amd import synthetic
+    rng = np.random.RandomState(seed)
+    theta = synthetic.init_theta(rng, O, (8, 8), 2)
+    paths = synthetic.make_paths(rng, theta, M, P, T, O, 2, (8, 8), ragged=ragged)
+    out = run_sample_processing(lib, paths, kwargs, baseline)
+    ref, coeffs, stats = sp.process_samples_meta(paths, baseline_kind=KIND[baseline], **kwargs)
+    np.testing.assert_allclose(out['returns'], np.concatenate([r['returns'] for r in ref]), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out['advantages'], np.concatenate([r['advantages'] for r in ref]), rtol=1e-4, atol=1e-5)
+    return out
+
+
+def make_ctx(lib, M, O, A, hidden, K, all_paths, n_tasks_global=None):
+    R = max(sum(len(p['rewards']) for pl in paths.values() for p in pl) for paths in all_paths)
+    NPaths = max(sum(len(pl) for pl in paths.values()) for paths in all_paths)
+    return _lib.Context(M, O, A, hidden, K, max_rows=R, max_paths=NPaths, lib=lib, n_tasks_global=n_tasks_global)
+
+
+def check_loss_grad(lib, seed, M, P, T, O, A, hidden, ragged=False, compact_log_std=False, low_log_std=False):
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=ragged,
+                                                          low_log_std=low_log_std)
+    spec = op.PolicySpec(O, A, hidden)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs, compact_log_std=compact_log_std)
+    rng = np.random.RandomState(seed + 1)
+    th = (theta + (0.0 if low_log_std else 0.02) * rng.randn(M, theta.size)).astype(np.float32)
+    ctx.set_task_thetas(th)
+    for kind, name in ((0, 'ratio'), (1, 'clip'), (2, 'loglik')):
+        for clip_ls in ((True,) if low_log_std else (False, True)):
+            g, l, k = ctx.eval_loss_grad(1, kind, clip_eps=0.3, clip_log_std=clip_ls)
+            for i in range(M):
+                r = pm.loss_and_grad(spec, th[i].astype(np.float64), all_slabs[1][i], name, clip_ls, clip_eps=0.3)
+                if not low_log_std:
+                    np.testing.assert_allclose(l[i], r['loss'], rtol=1e-4, atol=1e-6)
+                    np.testing.assert_allclose(k[i], r['kl'], rtol=1e-4, atol=1e-6)
+                    assert rel_max(g[i], r['grad']) < 1e-4, (name, i)
+                else:
+                    # sigma = 1e-6 makes z = (a-mu)/sigma amplify the float32 rounding of mu by 1e6, so values
+                    # are not comparable in float32 (the oracle's mask arithmetic is pinned in float64 by
+                    # tests/test_oracle_policy.py::k1_stdclip); here: finite results and an exact-zero mask
+                    assert np.isfinite(l[i]) and np.isfinite(k[i]) and np.all(np.isfinite(g[i]))
+                if low_log_std:   # gradient does not flow into clipped log_std entries
+                    mask = th[i][-A:] < np.log(1e-6)
+                    assert mask.any() and np.all(g[i][-A:][mask] == 0.0)
+    ctx.close()
+
+
+def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False):
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=ragged)
+    spec = op.PolicySpec(O, A, hidden)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    rng = np.random.RandomState(seed + 2)
+    th = (theta + 0.02 * rng.randn(M, theta.size)).astype(np.float32)
+    ctx.set_task_thetas(th)
+    v = rng.randn(M, theta.size).astype(np.float32)
+    for kind, name in ((0, 'ratio'), (1, 'loglik')):
+        out = ctx.eval_hvp(0, v, inner_kind=kind, clip_log_std=True, kl_weight=0.37)
+        for i in range(M):
+            t64 = th[i].astype(np.float64)
+            ref = -pm.hvp(spec, t64, all_slabs[0][i], v[i].astype(np.float64), name, True) + \
+                0.37 * pm.loss_and_grad(spec, t64, all_slabs[0][i], name, True)['grad_kl']
+            assert rel_max(out[i], ref) < 1e-4, (name, i)
+    ctx.close()
+
+
+def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, compact_log_std=False):
+    """meta-objective + exact gradient, _adapt, and E Adam epochs + compute_stats."""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=ragged)
+    spec = op.PolicySpec(O, A, hidden)
+    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs, compact_log_std=compact_log_std)
+    alpha = np.full(spec.n_params, 0.1, np.float32)
+    eta = np.array([5e-4, 1e-3, 2e-3][:K], np.float32)
+    a64, e64, t64 = alpha.astype(np.float64), eta.astype(np.float64), theta.astype(np.float64)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(alpha)
+    g, st = ctx.meta_grad(0.3, eta)
+    r = pm.meta_objective_and_grad(spec, t64, all_slabs, a64, e64, 0.3)
+    np.testing.assert_allclose(st['loss'], r['loss'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st['inner_kl'], r['inner_kl'], rtol=1e-4)
+    np.testing.assert_allclose(st['outer_kl'], r['outer_kl'], rtol=1e-4)
+    assert rel_max(g, r['grad']) < 1e-4
+    # MAMLAlgo._adapt
+    ctx.switch_to_pre_update()
+    ctx.inner_adapt(0)
+    ad = pm.adapt(spec, [t64] * M, all_slabs[0], a64)
+    assert rel_max(ctx.get_task_thetas() - theta, np.stack(ad) - t64) < 1e-4
+    # ProMP.optimize_policy core
+    res = ctx.optimize(epochs, 1e-3, 0.3, eta)
+    th_ref, ref = pm.optimize_policy(spec, t64, all_slabs, a64, e64, 0.3, pm.AdamState(spec.n_params), 1e-3, epochs)
+    np.testing.assert_allclose(res['loss_before'], ref['loss_before'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res['loss_after'], ref['loss_after'], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(res['inner_kl'], ref['inner_kl'], rtol=2e-4)
+    np.testing.assert_allclose(res['outer_kl'], ref['outer_kl'], rtol=2e-4)
+    # Adam normalises the step to ~lr per element; elements with |g| ~ 0 can flip sign between f32 and f64
+    d_dev, d_ref = ctx.get_theta() - theta, th_ref - t64
+    assert np.mean(np.abs(d_dev - d_ref)) < 0.02 * np.mean(np.abs(d_ref))
+    m, v, t = ctx.get_adam_state()
+    assert t == epochs
+    ctx.close()
+    return res
