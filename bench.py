@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s through GAE + inner adapt + outer ProMP update (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic meta-batch already resident in HBM:
+    process_samples(step 0) -> _adapt -> process_samples(step 1) -> optimize_policy (E=5 Adam epochs + stats)
+i.e. Trainer.train()'s timed stages Time-SampleProc + Time-InnerStep + Time-OuterStep (meta_trainer.py:96-142)
+on BASELINE config 3: 40-task HalfCheetahRandVel shapes (obs 20, act 6, 2x64 tanh MLP, H=200, P=20, K=1).
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU is STRONG scaling of the named config: the 40 tasks are sharded i -> GPU (i mod N); the only
+exchange is one RCCL all-reduce of [Theta+K+2] floats per Adam epoch (+1 for the stats pass).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from promp_amd import _lib, comm, synthetic  # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_row(O, H1, H2, A):
+    """matmul FLOPs, 2/MAC.  FWD = 2(O*H1+H1*H2+H2*A); BWD = 2*FWD - 2*O*H1; HVP = 2*(FWD+BWD)."""
+    fwd = 2 * (O * H1 + H1 * H2 + H2 * A)
+    bwd = 2 * fwd - 2 * O * H1
+    return dict(fwd=fwd, bwd=bwd, fwd_bwd=fwd + bwd, hvp=2 * (fwd + bwd))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3])
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
+                    help='strong: the named config sharded over N GPUs (default); weak: the named config per GPU')
+    ap.add_argument('--epochs', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local_rank = comm.env_world()
+    if world != args.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d; for N>1 launch with python -m torch.distributed.run '
+              '--nproc-per-node N bench.py --gpus N' % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    cfg = synthetic.CONFIGS[args.config]
+    P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
+    M_global = cfg['M'] * (world if args.scaling == 'weak' else 1)
+    task_ids = [i for i in range(M_global) if i % world == rank]
+    M = len(task_ids)
+    K, E = 1, args.epochs
+    N = P * T
+
+    ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
+    info = ctx.device_info()
+    if world > 1:
+        uid = comm.exchange_unique_id(rank, world, lambda: _lib.comm_unique_id())
+        ctx.comm_init(rank, world, uid)
+
+    # ---- synthetic, seeded, resident in HBM before timing ----
+    seed = 1000 * args.config
+    theta0 = synthetic.init_theta(np.random.RandomState(seed), O, hidden, A)
+    alpha = np.full(ctx.n_params, 0.1, np.float32)
+    eta = np.array([5e-4], np.float32)
+    opts = dict(discount=0.99, gae_lambda=1.0, normalize_adv=True)
+    ctx.set_theta(theta0)
+    ctx.set_step_sizes(alpha)
+    p0 = synthetic.make_paths_for_tasks(seed, task_ids, theta0, P, T, O, A, hidden)
+    f0 = _lib.flatten_paths(p0)
+    ctx.upload_step(0, f0['task_path_offsets'], f0['path_row_offsets'], f0['obs'], f0['rew'], f0['act'], f0['old_mean'],
+                    np.tile(theta0[-A:], (M, 1)))
+    ctx.switch_to_pre_update()
+    ctx.process_samples(0, **opts)
+    ctx.inner_adapt(0)
+    th1 = ctx.get_task_thetas()           # post-update policies "sample" step 1 (ratio == 1 at the first epoch)
+    p1 = synthetic.make_paths_for_tasks(seed + 1, task_ids, th1, P, T, O, A, hidden)
+    f1 = _lib.flatten_paths(p1)
+    ctx.upload_step(1, f1['task_path_offsets'], f1['path_row_offsets'], f1['obs'], f1['rew'], f1['act'], f1['old_mean'],
+                    th1[:, -A:].copy())
+
+    def iteration():
+        ctx.switch_to_pre_update()                       # meta_trainer.py:85
+        ctx.process_samples(0, **opts)                   # :105  (step 0)
+        ctx.inner_adapt(0)                               # :116
+        ctx.process_samples(1, **opts)                   # :105  (step 1)
+        return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
+
+    def barrier():
+        ctx.sync()
+        ctx.allreduce_f64([0.0])
+        ctx.sync()
+
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            res = iteration()
+        ctx.sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        return float(ctx.allreduce_f64([dt], op='max')[0]), res
+
+    for _ in range(args.warmup):
+        iteration()
+    elapsed, res = timed(args.steps)
+    if not np.isfinite(res['loss_after']):
+        raise SystemExit('bench: non-finite loss')
+    env_steps = M_global * N * (K + 1) * args.steps
+    value = env_steps / elapsed
+
+    out = {
+        'metric': 'env-steps/sec through GAE+inner+outer update', 'value': value, 'unit': 'env-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE config %d: %d-task HalfCheetahRandVel shapes (obs=%d, act=%d, 2x%d tanh MLP, H=%d, '
+                               'P=%d paths/task, K=1 inner step, E=%d ProMP epochs + stats); process_samples x2 + _adapt + '
+                               'optimize_policy per step' % (args.config, M_global, O, A, hidden[0], T, P, E),
+                   'meta_batch_size': M_global, 'tasks_per_gpu': M, 'rows_per_task_per_step': N,
+                   'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
+                   'device': info['name']},
+    }
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, on the stream it runs on ----
+    if not args.no_roofline:
+        ctx.prof_enable(True)
+        n_prof = max(3, min(args.steps, 10))
+        for _ in range(n_prof):
+            iteration()
+        fl = flops_per_row(O, hidden[0], hidden[1], A)
+        kern = {}
+        for name, kid, f in (('k_fwd_bwd', _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), ('k_hvp', _lib.KERNEL_HVP, fl['hvp'])):
+            pr = ctx.prof_read(kid)
+            avg_ms = pr['total_ms'] / max(pr['launches'], 1)
+            rows = pr['rows'] / max(pr['launches'], 1)
+            kern[name] = dict(avg_ms=avg_ms, launches_per_step=pr['launches'] / n_prof, rows_per_launch=rows,
+                              flop_per_row=f, tflops=f * rows / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                              ms_per_step=pr['total_ms'] / n_prof)
+        pg = ctx.prof_read(_lib.KERNEL_GRAM)
+        kern['k_gram'] = dict(avg_ms=pg['total_ms'] / max(pg['launches'], 1), launches_per_step=pg['launches'] / n_prof,
+                              ms_per_step=pg['total_ms'] / n_prof)
+        ctx.prof_enable(False)
+        dom = max(('k_fwd_bwd', 'k_hvp'), key=lambda k: kern[k]['ms_per_step'])
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'], 'peak': FP32_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS, 'traffic': None,
+                           'avg_launch_ms': kern[dom]['avg_ms'], 'kernels': kern,
+                           'end_to_end_tflops_per_gpu': value * ((fl['fwd_bwd'] + E * (2 * fl['fwd'] + 3 * fl['bwd'] + fl['hvp'])
+                                                                           + 2 * fl['fwd'] + fl['bwd']) / 2.0) / 1e12 / world}
+
+    # ---- CPU baseline: the float64 NumPy oracle ("port") on the host cores, rank 0, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg, theta0, alpha, eta, opts, E)
+
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+
+
+def cpu_baseline(cfg, theta0, alpha, eta, opts, E, sample_tasks=20):
+    """Time the oracle (CPU restatement of the reference; the reference's TF graph cannot run here) on a bounded
+    sample: the same per-task shapes, `sample_tasks` tasks instead of 40, ONE full step."""
+    from oracle import policy as op, promp as pm, sample_processing as sp
+    P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
+    Ms = min(sample_tasks, cfg['M'])
+    spec = op.PolicySpec(O, A, hidden)
+    rng = np.random.RandomState(99)
+    p0 = synthetic.make_paths(rng, theta0, Ms, P, T, O, A, hidden)
+    t64, a64, e64 = theta0.astype(np.float64), alpha.astype(np.float64), eta.astype(np.float64)
+    t0 = time.perf_counter()
+    s0, _, _ = sp.process_samples_meta(p0, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **opts)
+    ad = pm.adapt(spec, [t64] * Ms, s0, a64)
+    t_a = time.perf_counter()
+    p1 = synthetic.make_paths(rng, np.stack(ad).astype(np.float32), Ms, P, T, O, A, hidden)   # not timed
+    t_b = time.perf_counter()
+    s1, _, _ = sp.process_samples_meta(p1, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **opts)
+    pm.optimize_policy(spec, t64, [s0, s1], a64, e64, 0.3, pm.AdamState(spec.n_params), 1e-3, E)
+    dt = (t_a - t0) + (time.perf_counter() - t_b)
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {'value': Ms * P * T * 2 / dt, 'unit': 'env-steps/s', 'cores': int(threads), 'kind': 'port',
+            'sample': 'float64 NumPy oracle (BLAS threads=%d of %d host cores), one full step on %d of the %d tasks '
+                      '(same per-task shapes), %.1f s' % (threads, os.cpu_count() or 1, Ms, cfg['M'], dt)}
+
+
+if __name__ == '__main__':
+    main()

@@ -72,3 +72,15 @@ def make_paths(rng, theta_tasks, M, P, T, O, A, hidden, ragged=False, obs_dtype=
                               agent_infos=dict(mean=mean, log_std=np.tile(log_std, (Tp, 1)).astype(np.float32))))
         out[i] = paths
     return out
+
+
+def make_paths_for_tasks(base_seed, task_ids, theta_tasks, P, T, O, A, hidden):
+    """Like make_paths but every task draws from its own RandomState(base_seed*100003 + task_id), so a
+    rank holding tasks {i : i % world == rank} generates exactly its shard of the single-GPU batch."""
+    theta_tasks = np.asarray(theta_tasks, dtype=np.float32)
+    out = OrderedDict()
+    for slot, i in enumerate(task_ids):
+        rng = np.random.RandomState((base_seed * 100003 + int(i)) % (2 ** 31 - 1))
+        th = theta_tasks if theta_tasks.ndim == 1 else theta_tasks[slot]
+        out[slot] = make_paths(rng, th, 1, P, T, O, A, hidden)[0]
+    return out

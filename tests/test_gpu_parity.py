@@ -1,0 +1,175 @@
+"""Parity tests proper: the hipcc-built libpromp_hip.so on a real MI355X, through the C ABI, against
+  * the reference's own outputs (tests/golden/sample_proc_*.npz),
+  * torch.autograd goldens of the TF graph's arithmetic (tests/golden/promp_autograd_*.npz),
+  * the float64 oracle on seeded inputs (sizes the oracle finishes in seconds),
+  * size-independent properties at BASELINE.json's full config-3 size.
+Tolerances are stated in tests/parity_checks.py."""
+import numpy as np
+import pytest
+
+from oracle import policy as op
+from oracle import promp as pm
+from promp_amd import _lib, synthetic
+from tests import devlib, helpers, parity_checks as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    return devlib.gpu_library()
+
+
+@pytest.mark.parametrize('name', helpers.sample_proc_cases())
+def test_sample_processing_vs_reference_outputs(lib, name):
+    pc.check_sample_processing_golden(lib, name)
+
+
+def test_sample_processing_config3_vs_oracle(lib):
+    out = pc.check_sample_processing_oracle(lib, 21, M=40, P=20, T=200, O=20, ragged=False,
+                                            kwargs=dict(discount=0.99, gae_lambda=1.0, normalize_adv=True))
+    adv = out['advantages'].reshape(40, -1)
+    np.testing.assert_allclose(adv.mean(axis=1), 0.0, atol=1e-5)      # per-task normalisation
+    np.testing.assert_allclose(adv.std(axis=1), 1.0, rtol=1e-5)
+
+
+def test_sample_processing_ragged_long_paths(lib):
+    pc.check_sample_processing_oracle(lib, 22, M=8, P=7, T=333, O=17, ragged=True,
+                                      kwargs=dict(discount=0.97, gae_lambda=0.9, normalize_adv=True, positive_adv=True))
+
+
+def test_sample_processing_point_env_shape(lib):
+    pc.check_sample_processing_oracle(lib, 23, M=4, P=20, T=100, O=2, ragged=False,
+                                      kwargs=dict(discount=0.99, gae_lambda=1.0, normalize_adv=True))
+
+
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 17, 6), ((32, 32), 31, 8)])
+def test_loss_grad(lib, hidden, O, A):
+    pc.check_loss_grad(lib, 31, M=5, P=6, T=150, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_loss_grad(lib, 32, M=3, P=4, T=100, O=O, A=A, hidden=hidden, compact_log_std=True)
+
+
+def test_loss_grad_clipped_log_std(lib):
+    pc.check_loss_grad(lib, 33, M=2, P=2, T=50, O=4, A=3, hidden=(32, 32), low_log_std=True)
+
+
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 5, 3)])
+def test_hvp(lib, hidden, O, A):
+    pc.check_hvp(lib, 41, M=4, P=5, T=130, O=O, A=A, hidden=hidden, ragged=True)
+
+
+@pytest.mark.parametrize('hidden,O,A,K', [((64, 64), 20, 6, 1), ((32, 32), 2, 2, 1), ((64, 64), 20, 6, 2), ((32, 32), 7, 3, 3)])
+def test_meta_objective_adapt_optimize(lib, hidden, O, A, K):
+    pc.check_meta(lib, 51, M=6, P=5, T=120, O=O, A=A, hidden=hidden, K=K, ragged=True, epochs=5)
+
+
+@pytest.mark.parametrize('name', ['k1_hc'])
+def test_meta_gradient_vs_torch_autograd_golden(lib, name):
+    c, theta, all_slabs, g = helpers.load_promp(name)
+    M, O, A, hidden, K = c['M'], c['O'], c['A'], tuple(c['hidden']), c['K']
+    N = all_slabs[0][0]['observations'].shape[0]
+    ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M, lib=lib)
+    for k in range(K + 1):
+        cat = lambda f: np.concatenate([f(s) for s in all_slabs[k]])
+        ctx.upload_step(k, np.arange(M + 1), np.arange(M + 1) * N, cat(lambda s: s['observations']), np.zeros(M * N),
+                        cat(lambda s: s['actions']), cat(lambda s: s['agent_infos']['mean']),
+                        cat(lambda s: s['agent_infos']['log_std']))
+        ctx.set_advantages(k, cat(lambda s: s['advantages']))
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(np.full(ctx.n_params, c['alpha'], np.float32))
+    grad, st = ctx.meta_grad(c['clip_eps'], np.array(c['eta'], np.float32))
+    np.testing.assert_allclose(st['loss'], float(g['loss']), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st['inner_kl'], g['inner_kl'], rtol=1e-4)
+    np.testing.assert_allclose(st['outer_kl'], float(g['outer_kl']), rtol=1e-4)
+    assert pc.rel_max(grad, g['grad']) < 1e-4
+    ctx.close()
+
+
+# ---- full BASELINE config 3 (M=40, P=20, T=200, O=20, A=6, 2x64): properties + one oracle comparison ----
+@pytest.fixture(scope='module')
+def config3(lib):
+    M, P, T, O, A, hidden = 40, 20, 200, 20, 6, (64, 64)
+    rng = np.random.RandomState(3)
+    theta = synthetic.init_theta(rng, O, hidden, A)
+    ctx = _lib.Context(M, O, A, hidden, 1, max_rows=M * P * T, max_paths=M * P, lib=lib)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(np.full(ctx.n_params, 0.1, np.float32))
+    opts = dict(discount=0.99, gae_lambda=1.0, normalize_adv=True)
+    p0 = synthetic.make_paths(rng, theta, M, P, T, O, A, hidden)
+    f0 = _lib.flatten_paths(p0)
+    ctx.upload_step(0, f0['task_path_offsets'], f0['path_row_offsets'], f0['obs'], f0['rew'], f0['act'], f0['old_mean'], f0['old_log_std'])
+    ctx.process_samples(0, **opts)
+    ctx.switch_to_pre_update()
+    ctx.inner_adapt(0)
+    th1 = ctx.get_task_thetas()
+    p1 = synthetic.make_paths(rng, th1, M, P, T, O, A, hidden)
+    f1 = _lib.flatten_paths(p1)
+    ctx.upload_step(1, f1['task_path_offsets'], f1['path_row_offsets'], f1['obs'], f1['rew'], f1['act'], f1['old_mean'], f1['old_log_std'])
+    ctx.process_samples(1, **opts)
+    yield dict(ctx=ctx, theta=theta, th1=th1, p0=p0, p1=p1, opts=opts, dims=(M, P, T, O, A, hidden))
+    ctx.close()
+
+
+def test_config3_ratio_is_one_at_unchanged_params(config3):
+    # reference tests/test_integration.py:128-175: likelihood ratio == 1 when params are unchanged
+    ctx, M = config3['ctx'], config3['dims'][0]
+    adv0 = ctx.download_processed(0)['advantages'].reshape(M, -1)
+    ctx.switch_to_pre_update()
+    g, l, k = ctx.eval_loss_grad(0, 0, clip_log_std=True)
+    np.testing.assert_allclose(l, -adv0.mean(axis=1), atol=2e-6)      # -mean(1 * adv)
+    np.testing.assert_allclose(k, 0.0, atol=1e-6)                      # KL(old || same) == 0
+    # post-update policy on its own samples
+    ctx.set_task_thetas(config3['th1'])
+    g, l, k = ctx.eval_loss_grad(1, 1, clip_eps=0.3)
+    np.testing.assert_allclose(k, 0.0, atol=1e-6)
+
+
+def test_config3_hvp_is_linear_and_deterministic(config3):
+    ctx = config3['ctx']
+    M = config3['dims'][0]
+    rng = np.random.RandomState(5)
+    ctx.switch_to_pre_update()
+    v1 = rng.randn(M, ctx.n_params).astype(np.float32)
+    v2 = rng.randn(M, ctx.n_params).astype(np.float32)
+    h1, h2 = ctx.eval_hvp(0, v1, clip_log_std=True), ctx.eval_hvp(0, v2, clip_log_std=True)
+    h12 = ctx.eval_hvp(0, v1 + v2, clip_log_std=True)
+    assert pc.rel_max(h12, (h1 + h2).astype(np.float64)) < 1e-4
+    np.testing.assert_array_equal(h1, ctx.eval_hvp(0, v1, clip_log_std=True))    # fixed-order reductions: bitwise
+
+
+def test_config3_meta_gradient_vs_oracle_and_determinism(config3):
+    from oracle import sample_processing as sp
+    ctx, theta = config3['ctx'], config3['theta']
+    M, P, T, O, A, hidden = config3['dims']
+    spec = op.PolicySpec(O, A, hidden)
+    eta = np.array([5e-4], np.float32)
+    ctx.set_theta(theta)
+    g1, st1 = ctx.meta_grad(0.3, eta)
+    g2, st2 = ctx.meta_grad(0.3, eta)
+    np.testing.assert_array_equal(g1, g2)
+    s0, _, _ = sp.process_samples_meta(config3['p0'], baseline_kind=sp.BASELINE_LINEAR_FEATURE, **config3['opts'])
+    s1, _, _ = sp.process_samples_meta(config3['p1'], baseline_kind=sp.BASELINE_LINEAR_FEATURE, **config3['opts'])
+    r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), [s0, s1], np.full(spec.n_params, 0.1), eta.astype(np.float64), 0.3)
+    np.testing.assert_allclose(st1['loss'], r['loss'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st1['inner_kl'], r['inner_kl'], rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(st1['outer_kl'], r['outer_kl'], rtol=1e-3, atol=1e-9)
+    assert pc.rel_max(g1, r['grad']) < 1e-3      # meta-gradient 1e-3 of its max-norm
+
+
+def test_config3_zero_advantages_give_zero_surrogate_gradient(config3):
+    ctx = config3['ctx']
+    M, P, T = config3['dims'][:3]
+    adv = ctx.download_processed(1)['advantages']
+    ctx.set_advantages(1, np.zeros(M * P * T, np.float32))
+    ctx.set_task_thetas(config3['th1'])
+    g, l, k = ctx.eval_loss_grad(1, 1, clip_eps=0.3)
+    assert np.all(g == 0.0) and np.all(l == 0.0)
+    ctx.set_advantages(1, adv)
+
+
+def test_single_rank_communicator(lib):
+    # nranks == 1 goes through ncclCommInitRank and the data path skips the all-reduce
+    ctx = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)
+    ctx.comm_init(0, 1, _lib.comm_unique_id(lib))
+    np.testing.assert_array_equal(ctx.allreduce_f64([1.0, 2.0]), [1.0, 2.0])
+    ctx.close()
