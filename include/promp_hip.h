@@ -102,6 +102,10 @@ int promp_process_samples(promp_ctx* ctx, int step, const promp_proc_opts* opts)
 int promp_download_processed(promp_ctx* ctx, int step, float* returns, float* advantages, double* coeffs,
                              double* path_returns0, double* path_undiscounted, double* path_reward_sumsq);
 
+/* float64 views of the same step: returns [rows] and the RAW (pre-normalisation) GAE advantages [rows], i.e. what the
+ * reference stores back into every path dict (samplers/base.py:104,159).  Either pointer may be NULL. */
+int promp_download_raw(promp_ctx* ctx, int step, double* returns64, double* raw_advantages64);
+
 /* Use caller-provided advantages for a step instead of promp_process_samples' (float32 [rows]). */
 int promp_set_advantages(promp_ctx* ctx, int step, const float* advantages);
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     'promp_upload_step': (C.c_int, [_P, C.c_int, C.c_int, _I, _I, _F, _F, _F, _F, _F, C.c_int]),
     'promp_process_samples': (C.c_int, [_P, C.c_int, C.POINTER(ProcOpts)]),
     'promp_download_processed': (C.c_int, [_P, C.c_int, _F, _F, _D, _D, _D, _D]),
+    'promp_download_raw': (C.c_int, [_P, C.c_int, _D, _D]),
     'promp_set_advantages': (C.c_int, [_P, C.c_int, _F]),
     'promp_set_theta': (C.c_int, [_P, _F]),
     'promp_get_theta': (C.c_int, [_P, _F]),
@@ -196,6 +197,12 @@ class Context:
                    _ptr(out['path_returns0'], C.c_double), _ptr(out['path_undiscounted'], C.c_double),
                    _ptr(out['path_reward_sumsq'], C.c_double))
         return out
+
+    def download_raw(self, step):
+        R = self.step_rows[step]
+        ret, adv = np.empty(R, np.float64), np.empty(R, np.float64)
+        self._call('promp_download_raw', int(step), _ptr(ret, C.c_double), _ptr(adv, C.c_double))
+        return ret, adv
 
     def set_advantages(self, step, adv):
         adv = _f32(adv)

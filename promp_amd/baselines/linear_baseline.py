@@ -1,0 +1,65 @@
+"""LinearFeatureBaseline / LinearTimeBaseline (reference: meta_policy_search/baselines/linear_baseline.py).
+
+The objects carry the configuration (feature kind, reg_coeff) and the coefficient vector; the arithmetic
+(features, normal equations, solve, prediction) is fused into the device sample-processing pipeline that
+MetaSampleProcessor drives (k_gram / k_fit / k_gae in promp_amd/csrc/promp_kernels_sample.h).  After
+process_samples, ``_coeffs`` holds the fit of the last task, as in the reference where one shared baseline
+object is re-fit task by task (linear_baseline.py:70)."""
+import numpy as np
+
+from .. import _lib
+from .base import Baseline
+
+
+class LinearBaseline(Baseline):
+    kind = None
+
+    def __init__(self, reg_coeff=1e-5):
+        self._coeffs = None
+        self._reg_coeff = reg_coeff
+
+    def get_param_values(self, **tags):
+        return self._coeffs
+
+    def set_params(self, value, **tags):
+        self._coeffs = value
+
+    def fit(self, paths, target_key='returns'):
+        """Standalone fit: targets are taken from path[target_key].  The device pipeline regresses on the returns
+        it computes itself, so an arbitrary target is expressed as rewards whose undiscounted return IS the
+        target: r[t] = y[t] - y[t+1] (discount 1)."""
+        assert all(target_key in p for p in paths)
+        from collections import OrderedDict
+        shadow = []
+        for p in paths:
+            y = np.asarray(p[target_key], dtype=np.float64)
+            r = y - np.append(y[1:], 0.0)
+            shadow.append(dict(observations=p['observations'], rewards=r))
+        fl = _lib.flatten_paths(OrderedDict([(0, shadow)]))
+        ctx = _lib.Context(1, fl['obs'].shape[1], 1, (32, 32), 1, max_rows=len(fl['rew']), max_paths=len(paths))
+        ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
+        ctx.process_samples(0, discount=1.0, gae_lambda=1.0, baseline_kind=self.kind, reg_coeff=self._reg_coeff)
+        self._coeffs = ctx.download_processed(0)['coeffs'][0]
+        ctx.close()
+
+    def predict(self, path):
+        """Phi . w through the device: with rewards 0 and discount 1, lambda 1 the GAE recursion gives
+        adv[t] = -b[t], hence b = -adv (zeros when unfit, linear_baseline.py:31-32)."""
+        n = len(path['observations'])
+        if self._coeffs is None:
+            return np.zeros(n)
+        raise NotImplementedError('standalone predict() with externally set coefficients is not on the device path; '
+                                  'MetaSampleProcessor fuses fit+predict (see promp_amd/samplers)')
+
+    def log_diagnostics(self, paths, prefix):
+        pass
+
+
+class LinearFeatureBaseline(LinearBaseline):
+    """b(o,t) = w . [clip(o,+-10), clip(o)^2, t/100, (t/100)^2, (t/100)^3, 1]  (linear_baseline.py:101-106)"""
+    kind = _lib.BASELINE_LINEAR_FEATURE
+
+
+class LinearTimeBaseline(LinearBaseline):
+    """b(t) = w . [t/100, (t/100)^2, (t/100)^3, 1]  (linear_baseline.py:122-126)"""
+    kind = _lib.BASELINE_LINEAR_TIME

@@ -16,6 +16,12 @@
 #include <string>
 #include <vector>
 
+#ifdef PROMP_EMU
+#define PROMP_ARCH_NAME(prop) "emulator"
+#else
+#define PROMP_ARCH_NAME(prop) (prop).gcnArchName
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -297,7 +303,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     HIPCHECK(hipGetDeviceProperties(&prop, device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->clock_mhz = prop.clockRate / 1000;
-    snprintf(c->dev_name, sizeof c->dev_name, "%s", prop.name);
+    snprintf(c->dev_name, sizeof c->dev_name, "%s", prop.name[0] ? prop.name : PROMP_ARCH_NAME(prop));
     HIPCHECK(hipStreamCreate(&c->stream));
     const int K = dims->num_inner_steps, M = dims->n_tasks;
     c->NP = param_count(dims);
@@ -529,6 +535,17 @@ int promp_download_processed(promp_ctx* c, int step, float* returns, float* adv,
             memcpy(coeffs + (size_t)i * S.feat_dim, tmp.data() + (size_t)i * c->coeff_stride, sizeof(double) * S.feat_dim);
     }
     HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int promp_download_raw(promp_ctx* c, int step, double* ret64, double* adv64) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (!S.processed) return fail(-3, "step %d has not been processed", step);
+    if (ret64) HIPCHECK(hipMemcpyAsync(ret64, S.ret64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
+    if (adv64) HIPCHECK(hipMemcpyAsync(adv64, S.adv64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -1,0 +1,69 @@
+"""ProMP (reference: meta_policy_search/meta_algos/pro_mp.py:9-214 + optimizers/maml_first_order_optimizer.py)."""
+import numpy as np
+
+from .. import _lib
+from ..utils import logger
+from .base import MAMLAlgo
+
+
+class ProMP(MAMLAlgo):
+    """
+    Args (pro_mp.py:30-57): policy, name, learning_rate, num_ppo_steps, num_minibatches (unused, as in the
+    reference: maml_first_order_optimizer.py:41,97-99), clip_eps, target_inner_step, init_inner_kl_penalty,
+    adaptive_inner_kl_penalty, anneal_factor (unused in the reference too: clip_eps is fed un-annealed,
+    pro_mp.py:182), inner_lr, meta_batch_size, num_inner_grad_steps, trainable_inner_step_size
+    """
+    inner_kind = _lib.INNER_RATIO
+    outer_kind = _lib.OUTER_CLIP
+
+    def __init__(self, *args, name='ppo_maml', learning_rate=1e-3, num_ppo_steps=5, num_minibatches=1, clip_eps=0.2,
+                 target_inner_step=0.01, init_inner_kl_penalty=1e-2, adaptive_inner_kl_penalty=True, anneal_factor=1.0,
+                 **kwargs):
+        super(ProMP, self).__init__(*args, **kwargs)
+        self.learning_rate = learning_rate
+        self.num_ppo_steps = num_ppo_steps
+        self.num_minibatches = num_minibatches
+        self.clip_eps = clip_eps
+        self.target_inner_step = target_inner_step
+        self.adaptive_inner_kl_penalty = adaptive_inner_kl_penalty
+        self.inner_kl_coeff = init_inner_kl_penalty * np.ones(self.num_inner_grad_steps)
+        self.anneal_coeff = 1
+        self.anneal_factor = anneal_factor
+        self._optimization_keys = ['observations', 'actions', 'advantages', 'agent_infos']
+        self.name = name
+
+    def optimize_policy(self, all_samples_data, log=True):
+        """MAML outer step: E Adam epochs on the meta-objective, then stats (pro_mp.py:165-199)"""
+        assert len(all_samples_data) == self.num_inner_grad_steps + 1
+        slots = [self._slot_of(sd, k) for k, sd in enumerate(all_samples_data)]
+        assert slots == list(range(self.num_inner_grad_steps + 1)), \
+            'samples of sampling step k must be resident in slot k (got %r)' % (slots,)
+        if log: logger.log('Optimizing')
+        res = self.session.ctx.optimize(self.num_ppo_steps, self.learning_rate, self.clip_eps, self.inner_kl_coeff,
+                                        self.inner_kind, self.outer_kind)
+        if log: logger.log('Computing statistics')
+        loss_before, loss_after, inner_kls = res['loss_before'], res['loss_after'], res['inner_kl']
+        if self.adaptive_inner_kl_penalty:
+            if log: logger.log('Updating inner KL loss coefficients')
+            self.inner_kl_coeff = self.adapt_kl_coeff(self.inner_kl_coeff, inner_kls, self.target_inner_step)
+        if log:
+            logger.logkv('LossBefore', loss_before)
+            logger.logkv('LossAfter', loss_after)
+            logger.logkv('KLInner', np.mean(inner_kls))
+            logger.logkv('KLCoeffInner', np.mean(self.inner_kl_coeff))
+        self.last_stats = res
+
+    def adapt_kl_coeff(self, kl_coeff, kl_values, kl_target):
+        if hasattr(kl_values, '__iter__'):
+            assert len(kl_coeff) == len(kl_values)
+            return np.array([_adapt_kl_coeff(kl_coeff[i], kl, kl_target) for i, kl in enumerate(kl_values)])
+        return _adapt_kl_coeff(kl_coeff, kl_values, kl_target)
+
+
+def _adapt_kl_coeff(kl_coeff, kl, kl_target):
+    """pro_mp.py:208-214"""
+    if kl < kl_target / 1.5:
+        kl_coeff /= 2
+    elif kl > kl_target * 1.5:
+        kl_coeff *= 2
+    return kl_coeff

@@ -1,0 +1,152 @@
+"""MetaGaussianMLPPolicy: the parameter container the algorithm reads and writes
+(reference: policies/meta_gaussian_mlp_policy.py:9-157, policies/gaussian_mlp_policy.py:31-123,
+policies/base.py:25-34,173-286).
+
+Parameters live on the GPU as one flat float32 vector in the reference's OrderedDict order; get_param_values /
+set_params / policies_params_vals / update_task_parameters expose them under the reference's names
+('mean_network/hidden_0/kernel', ..., 'log_std_network/log_std_var').
+
+get_actions (rollout-side inference, SURVEY.md 8f "next" row 1) is evaluated on the host here: it belongs to the
+sampling stage that precedes the timed hot path and will move to the device with the sampler.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import session as session_mod
+from ..utils import logger
+from .distributions.diagonal_gaussian import DiagonalGaussian
+
+
+class MetaGaussianMLPPolicy(object):
+    def __init__(self, meta_batch_size, obs_dim, action_dim, name='policy', hidden_sizes=(32, 32), learn_std=True,
+                 hidden_nonlinearity='tanh', output_nonlinearity=None, init_std=1., min_std=1e-6, **kwargs):
+        assert output_nonlinearity is None, 'only a linear output layer is implemented'
+        assert hidden_nonlinearity in ('tanh', None) or getattr(hidden_nonlinearity, '__name__', '') == 'tanh', \
+            'only tanh hidden units are implemented (the reference default, policies/base.py:31)'
+        assert abs(min_std - 1e-6) < 1e-12, 'min_std is fixed at the reference default 1e-6 in the kernels'
+        self.meta_batch_size = int(meta_batch_size)
+        self.obs_dim, self.action_dim = int(np.prod(obs_dim)), int(np.prod(action_dim))
+        self.name = name
+        self.hidden_sizes = tuple(hidden_sizes)
+        self.learn_std = learn_std
+        self.min_log_std, self.init_log_std = np.log(min_std), np.log(init_std)
+        self._dist = DiagonalGaussian(self.action_dim)
+        sizes = (self.obs_dim,) + self.hidden_sizes + (self.action_dim,)
+        self._shapes = OrderedDict()
+        for i in range(len(sizes) - 1):
+            lname = 'output' if i == len(sizes) - 2 else 'hidden_%d' % i
+            self._shapes['mean_network/%s/kernel' % lname] = (sizes[i], sizes[i + 1])
+            self._shapes['mean_network/%s/bias' % lname] = (sizes[i + 1],)
+        self._shapes['log_std_network/log_std_var'] = (1, self.action_dim)
+        self.policy_params_keys = list(self._shapes.keys())
+        # xavier-uniform kernels, zero biases, log_std = log(init_std)   (mlp.py:12-13, gaussian_mlp_policy.py:63-69)
+        parts = []
+        for k, shp in self._shapes.items():
+            if k.endswith('kernel'):
+                lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+                parts.append(np.random.uniform(-lim, lim, size=shp))
+            elif k.endswith('bias'):
+                parts.append(np.zeros(shp))
+            else:
+                parts.append(np.full(shp, self.init_log_std))
+        self.session = session_mod.DeviceSession(self.meta_batch_size, self.obs_dim, self.action_dim, self.hidden_sizes)
+        self.session.set_theta(self._flatten(parts))
+        self._pre_update_mode = True
+        self.switch_to_pre_update()
+
+    # ---- flat <-> named ----
+    def _flatten(self, parts):
+        return np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1) for p in parts])
+
+    def _unflatten(self, theta):
+        out, off = OrderedDict(), 0
+        for k, shp in self._shapes.items():
+            n = int(np.prod(shp))
+            out[k] = theta[off:off + n].reshape(shp).copy()
+            off += n
+        return out
+
+    @property
+    def distribution(self):
+        return self._dist
+
+    # ---- reference API: parameters ----
+    def get_params(self):
+        return self.get_param_values()
+
+    def get_param_values(self):
+        return self._unflatten(self.session.get_theta())
+
+    def set_params(self, policy_params):
+        assert all(k1 == k2 for k1, k2 in zip(self.policy_params_keys, policy_params.keys())), \
+            'parameter keys must match with variable'
+        self.session.set_theta(self._flatten(list(policy_params.values())))
+
+    def switch_to_pre_update(self):
+        """policies/base.py:234-240: get_action uses the pre-update policy; per-task params = theta replicated"""
+        self._pre_update_mode = True
+        s = self.session
+        s.step_cursor = 0
+        if s.ctx is not None:
+            s.ctx.switch_to_pre_update()
+            s.task_thetas = None
+        else:
+            s.task_thetas = np.tile(s.theta, (self.meta_batch_size, 1))
+
+    def _task_thetas(self):
+        s = self.session
+        return s.ctx.get_task_thetas() if s.ctx is not None else s.task_thetas
+
+    @property
+    def policies_params_vals(self):
+        return [self._unflatten(t) for t in self._task_thetas()]
+
+    def update_task_parameters(self, updated_policies_parameters):
+        """policies/base.py:262-269"""
+        th = np.stack([self._flatten(list(d.values())) for d in updated_policies_parameters])
+        s = self.session
+        s.task_thetas = th
+        if s.ctx is not None:
+            s.ctx.set_task_thetas(th)
+        self._pre_update_mode = False
+
+    # ---- reference API: acting (host side, see module docstring) ----
+    def _mean(self, theta, obs):
+        x, off = np.asarray(obs, dtype=np.float32), 0
+        sizes = (self.obs_dim,) + self.hidden_sizes + (self.action_dim,)
+        for i in range(len(sizes) - 1):
+            W = theta[off:off + sizes[i] * sizes[i + 1]].reshape(sizes[i], sizes[i + 1]); off += W.size
+            b = theta[off:off + sizes[i + 1]]; off += b.size
+            x = x @ W + b
+            if i < len(sizes) - 2:
+                x = np.tanh(x)
+        return x
+
+    def get_actions(self, observations):
+        """observations: list[M] of [B,O] -> (list[M] of [B,A], list[M] of list[B] of {mean, log_std})
+        (meta_gaussian_mlp_policy.py:99-157)"""
+        assert len(observations) == self.meta_batch_size
+        thetas = self._task_thetas()
+        actions, agent_infos = [], []
+        for i, obs in enumerate(observations):
+            th = thetas[i]
+            mean = self._mean(th, obs)
+            raw = th[-self.action_dim:]
+            log_std = np.maximum(raw, self.min_log_std) if self._pre_update_mode else raw   # gaussian_mlp_policy.py:71 vs :182
+            actions.append(mean + np.random.normal(size=mean.shape) * np.exp(raw))            # noise uses the raw variable (:74)
+            agent_infos.append([dict(mean=m, log_std=log_std) for m in mean])
+        return actions, agent_infos
+
+    def get_action(self, observation, task=0):
+        obs = [np.expand_dims(observation, 0)] * self.meta_batch_size
+        a, infos = self.get_actions(obs)
+        return a[task][0], infos[task][0]
+
+    def reset(self, dones=None):
+        pass
+
+    def log_diagnostics(self, paths, prefix=''):
+        """gaussian_mlp_policy.py:118-123"""
+        log_stds = np.vstack([p['agent_infos']['log_std'] for p in paths])
+        logger.logkv(prefix + 'AveragePolicyStd', np.mean(np.exp(log_stds)))

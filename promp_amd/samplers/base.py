@@ -1,0 +1,117 @@
+"""SampleProcessor (reference: meta_policy_search/samplers/base.py:33-173), single-task flavour.
+The arithmetic runs on the device; see MetaSampleProcessor for the meta-batch version the Trainer uses."""
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import _lib, session as session_mod
+from ..utils import logger
+
+
+def _concat_tensor_dict_list(dict_list):
+    """utils/utils.py:104-122"""
+    if not dict_list or not dict_list[0]:
+        return {}
+    out = {}
+    for k in dict_list[0].keys():
+        ex = dict_list[0][k]
+        out[k] = _concat_tensor_dict_list([d[k] for d in dict_list]) if isinstance(ex, dict) \
+            else np.concatenate([d[k] for d in dict_list])
+    return out
+
+
+class SampleProcessor(object):
+    """
+    - fits a reward baseline, - performs GAE, - stacks the path data, - logs path statistics
+
+    Args (samplers/base.py:48-65): baseline, discount=0.99, gae_lambda=1, normalize_adv=False, positive_adv=False
+    """
+
+    def __init__(self, baseline, discount=0.99, gae_lambda=1, normalize_adv=False, positive_adv=False):
+        assert 0 <= discount <= 1.0, 'discount factor must be in [0,1]'
+        assert 0 <= gae_lambda <= 1.0, 'gae_lambda must be in [0,1]'
+        assert hasattr(baseline, 'fit') and hasattr(baseline, 'predict')
+        self.baseline = baseline
+        self.discount = discount
+        self.gae_lambda = gae_lambda
+        self.normalize_adv = normalize_adv
+        self.positive_adv = positive_adv
+        self._private_session = None
+
+    # -- device plumbing -------------------------------------------------------------------------
+    def _session_for(self, M, O, A):
+        s = session_mod.current()
+        if s is not None and (s.M, s.O, s.A) == (M, O, A):
+            return s
+        p = self._private_session
+        if p is None or (p.M, p.O, p.A) != (M, O, A):
+            keep = session_mod.current()
+            p = session_mod.DeviceSession(M, O, A, (32, 32), 1)   # private: sample processing only
+            session_mod._current = keep
+            self._private_session = p
+        return p
+
+    def _process_on_device(self, paths_meta_batch):
+        """-> (list[M] of SamplesData, per-path float64 stats) ; mutates the path dicts like the reference."""
+        M = len(paths_meta_batch)
+        fl = _lib.flatten_paths(paths_meta_batch)
+        O = fl['obs'].shape[1]
+        first = next(iter(paths_meta_batch.values()))[0]
+        A = int(np.asarray(first['actions']).reshape(len(first['rewards']), -1).shape[1]) if 'actions' in first else 1
+        sess = self._session_for(M, O, A)
+        slot = sess.next_slot()
+        upload = sess.upload_flat(slot, fl)
+        ctx = sess.ctx
+        kind = getattr(self.baseline, 'kind', _lib.BASELINE_ZERO)
+        ctx.process_samples(slot, discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=self.normalize_adv,
+                            positive_adv=self.positive_adv, baseline_kind=kind,
+                            reg_coeff=getattr(self.baseline, '_reg_coeff', 1e-5))
+        out = ctx.download_processed(slot, kind)
+        ret64, raw_adv64 = ctx.download_raw(slot)
+        if kind != _lib.BASELINE_ZERO:
+            self.baseline._coeffs = out['coeffs'][-1].copy()      # the shared baseline ends on the last task's fit
+        pro, tpo = fl['path_row_offsets'], fl['task_path_offsets']
+        result = []
+        for i, (_, plist) in enumerate(paths_meta_batch.items()):
+            r0, r1 = pro[tpo[i]], pro[tpo[i + 1]]
+            for j, p in enumerate(plist):                        # side effect of samplers/base.py:104,159
+                a, b = pro[tpo[i] + j], pro[tpo[i] + j + 1]
+                p['returns'] = ret64[a:b]
+                p['advantages'] = raw_adv64[a:b]
+            sd = session_mod.SamplesData(
+                observations=np.concatenate([p['observations'] for p in plist]),
+                actions=np.concatenate([p['actions'] for p in plist]),
+                rewards=np.concatenate([p['rewards'] for p in plist]),
+                returns=ret64[r0:r1],
+                advantages=out['advantages'][r0:r1],
+                env_infos=_concat_tensor_dict_list([p.get('env_infos', {}) for p in plist]),
+                agent_infos=_concat_tensor_dict_list([p.get('agent_infos', {}) for p in plist]),
+            )
+            sd.device_ref = (sess.serial, upload, slot, i)
+            result.append(sd)
+        return result, out
+
+    # -- reference API ---------------------------------------------------------------------------
+    def process_samples(self, paths, log=False, log_prefix=''):
+        """single task: list of paths -> dict with 7 keys (samplers/base.py:67-95)"""
+        assert type(paths) == list, 'paths must be a list'
+        assert paths[0].keys() >= {'observations', 'actions', 'rewards'}
+        assert self.baseline, 'baseline must be specified - use self.build_sample_processor(baseline_obj)'
+        result, out = self._process_on_device(OrderedDict([(0, paths)]))
+        self._log_path_stats(out, log=log, log_prefix='')      # the reference drops log_prefix here (base.py:92)
+        sd = dict(result[0])
+        assert sd.keys() >= {'observations', 'actions', 'rewards', 'advantages', 'returns'}
+        return sd
+
+    def _log_path_stats(self, out, log=False, log_prefix=''):
+        """samplers/base.py:135-149, from the per-path sums the device produced"""
+        und = out['path_undiscounted']
+        if log == 'reward':
+            logger.logkv(log_prefix + 'AverageReturn', np.mean(und))
+        elif log == 'all' or log is True:
+            logger.logkv(log_prefix + 'AverageDiscountedReturn', np.mean(out['path_returns0']))
+            logger.logkv(log_prefix + 'AverageReturn', np.mean(und))
+            logger.logkv(log_prefix + 'NumTrajs', len(und))
+            logger.logkv(log_prefix + 'StdReturn', np.std(und))
+            logger.logkv(log_prefix + 'MaxReturn', np.max(und))
+            logger.logkv(log_prefix + 'MinReturn', np.min(und))

@@ -1,0 +1,149 @@
+"""The drop-in boundary: the reference's plugin classes re-created over the HIP library.
+CPU: runs against the kernel emulator at tiny shapes.  The same scenarios run on the GPU in test_gpu_plugin_api.py."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+from oracle import sample_processing as sp
+from promp_amd import _lib, session
+from tests import devlib, helpers
+
+
+@pytest.fixture()
+def emu():
+    lib = devlib.emu_library()
+    _lib.set_library_for_testing(lib)
+    yield lib
+    _lib.set_library_for_testing(None)
+    session._current = None
+
+
+def run_processor_scenario():
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    meta, paths, g = helpers.load_sample_proc('ragged')
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), **meta['kwargs'])
+    with pytest.raises(AssertionError):
+        proc.process_samples(list(paths.values()))            # "paths must be a dict" (meta_sample_processor.py:25)
+    out = proc.process_samples(paths, log=False)
+    assert isinstance(out, list) and len(out) == len(paths)
+    # reference tests/test_samplers.py:172-189: 8 keys, advantages.size == N
+    assert set(out[0].keys()) == {'observations', 'actions', 'rewards', 'returns', 'advantages', 'env_infos',
+                                  'agent_infos', 'adj_avg_rewards'}
+    assert out[0]['advantages'].size == out[0]['rewards'].size
+    cat = lambda k: np.concatenate([sd[k] for sd in out])
+    np.testing.assert_allclose(cat('returns'), g['returns'], rtol=1e-12)          # float64, as the reference
+    np.testing.assert_allclose(cat('advantages'), g['advantages'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cat('adj_avg_rewards'), g['adj_avg_rewards'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(proc.baseline.get_param_values(), g['coeffs'][-1], rtol=1e-5, atol=1e-7)
+    # side effect on the path dicts (samplers/base.py:104,159): raw (un-normalised) GAE advantages
+    ref_paths = helpers.load_sample_proc('ragged')[1]
+    sp.process_samples_meta(ref_paths, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **meta['kwargs'])
+    np.testing.assert_allclose(paths[1][2]['advantages'], ref_paths[1][2]['advantages'], rtol=1e-7, atol=1e-9)
+
+
+def run_algo_scenario(M=2, P=2, T=30, O=5, A=3, hidden=(32, 32), K=1, epochs=2):
+    """policy + sample processor + ProMP wired like run_scripts/pro-mp_run_mujoco.py:21-77, on synthetic paths."""
+    from oracle import policy as op, promp as pm
+    from promp_amd import synthetic
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.meta_algos.pro_mp import ProMP
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    np.random.seed(3)
+    policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
+    algo = ProMP(policy=policy, inner_lr=0.1, meta_batch_size=M, num_inner_grad_steps=K, learning_rate=1e-3,
+                 num_ppo_steps=epochs, clip_eps=0.3, target_inner_step=0.01, init_inner_kl_penalty=5e-4,
+                 adaptive_inner_kl_penalty=False)
+    params0 = policy.get_param_values()
+    assert list(params0.keys())[0] == 'mean_network/hidden_0/kernel' and params0['log_std_network/log_std_var'].shape == (1, A)
+    theta0 = np.concatenate([v.reshape(-1) for v in params0.values()])
+    spec = op.PolicySpec(O, A, hidden)
+    rng = np.random.RandomState(5)
+    policy.switch_to_pre_update()
+    all_samples, all_paths = [], []
+    for step in range(K + 1):
+        th = np.stack([np.concatenate([v.reshape(-1) for v in d.values()]) for d in policy.policies_params_vals])
+        paths = synthetic.make_paths(rng, th, M, P, T, O, A, hidden)
+        all_paths.append(paths)
+        sd = proc.process_samples(paths, log=False)
+        all_samples.append(sd)
+        if step < K:
+            algo._adapt(sd)
+    # oracle on the same inputs
+    kw = dict(baseline_kind=sp.BASELINE_LINEAR_FEATURE, discount=0.99, gae_lambda=1, normalize_adv=True)
+    ref_samples = [sp.process_samples_meta(p, **kw)[0] for p in all_paths]
+    ad = pm.adapt(spec, [theta0.astype(np.float64)] * M, ref_samples[0], np.full(spec.n_params, 0.1))
+    th1 = np.stack([np.concatenate([v.reshape(-1) for v in d.values()]) for d in policy.policies_params_vals])
+    if K == 1:
+        assert np.max(np.abs(th1 - np.stack(ad))) < 1e-5
+    algo.optimize_policy(all_samples, log=False)
+    th_ref, ref = pm.optimize_policy(spec, theta0.astype(np.float64), ref_samples, np.full(spec.n_params, 0.1),
+                                     np.full(K, 5e-4), 0.3, pm.AdamState(spec.n_params), 1e-3, epochs)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], ref['loss_before'], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(algo.last_stats['loss_after'], ref['loss_after'], rtol=1e-3, atol=1e-5)
+    th_new = np.concatenate([v.reshape(-1) for v in policy.get_param_values().values()])
+    assert np.mean(np.abs((th_new - theta0) - (th_ref - theta0))) < 0.05 * np.mean(np.abs(th_ref - theta0))
+    # samples that did NOT come from our processor (plain dicts) are uploaded on the fly
+    plain = [[dict(sd) for sd in step] for step in all_samples]
+    policy.set_params(params0)
+    algo2_stats_before = algo.last_stats['loss_before']
+    algo.session.ctx.set_adam_state(np.zeros(spec.n_params), np.zeros(spec.n_params), 0)
+    algo.optimize_policy(plain, log=False)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], algo2_stats_before, rtol=1e-5, atol=1e-6)
+
+
+def run_trainer_scenario(n_itr=2):
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.envs.point_env import MetaPointEnv
+    from promp_amd.meta_algos.pro_mp import ProMP
+    from promp_amd.meta_trainer import Trainer
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    from promp_amd.samplers.meta_sampler import MetaSampler
+    from promp_amd.utils import logger
+    logger.configure(quiet=True)
+    np.random.seed(1)
+    M, P, T = 2, 3, 12
+    env = MetaPointEnv()
+    policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=(32, 32))
+    sampler = MetaSampler(env=env, policy=policy, rollouts_per_meta_task=P, meta_batch_size=M, max_path_length=T, parallel=False)
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
+    algo = ProMP(policy=policy, inner_lr=0.1, meta_batch_size=M, num_inner_grad_steps=1, learning_rate=1e-3, num_ppo_steps=2,
+                 clip_eps=0.3, init_inner_kl_penalty=5e-4, adaptive_inner_kl_penalty=False)
+    trainer = Trainer(algo=algo, policy=policy, env=env, sampler=sampler, sample_processor=proc, n_itr=n_itr, num_inner_grad_steps=1)
+    before = policy.get_param_values()
+    seen = {}
+    orig = logger.dumpkvs
+
+    def grab():
+        seen.update(logger.getkvs())
+        return orig()
+    logger.dumpkvs = grab
+    try:
+        trainer.train()
+    finally:
+        logger.dumpkvs = orig
+    # the reference's logging keys (meta_trainer.py:131-142, samplers/base.py:143-149, pro_mp.py:195-199)
+    for k in ['Itr', 'n_timesteps', 'Time-OuterStep', 'Time-TotalInner', 'Time-InnerStep', 'Time-SampleProc', 'Time-Sampling',
+              'Time', 'ItrTime', 'Time-MAMLSteps', 'Step_0-AverageReturn', 'Step_1-AverageDiscountedReturn', 'Step_0-NumTrajs',
+              'Step_1-StdReturn', 'Step_0-MaxReturn', 'Step_0-MinReturn', 'Step_0-AveragePolicyStd', 'LossBefore', 'LossAfter',
+              'KLInner', 'KLCoeffInner']:
+        assert k in seen, k
+    assert seen['n_timesteps'] == n_itr * 2 * M * P * T
+    after = policy.get_param_values()
+    assert any(np.any(before[k] != after[k]) for k in before) and all(np.all(np.isfinite(v)) for v in after.values())
+
+
+def test_meta_sample_processor_api(emu):
+    run_processor_scenario()
+
+
+def test_policy_algo_api(emu):
+    run_algo_scenario()
+
+
+def test_trainer_end_to_end(emu):
+    run_trainer_scenario(n_itr=1)
