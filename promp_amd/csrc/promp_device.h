@@ -39,7 +39,7 @@ PROMP_DEV double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }
 PROMP_DEV double shfl_idx_f64(double v, int l) { return __shfl(v, l, 64); }
 PROMP_DEV float fast_exp(float x) { return __expf(x); }
-PROMP_DEV float fast_rcp(float x) { return __frcp_rn(x); }
+PROMP_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 #endif
 
 PROMP_DEV f32x16 zero16() {
@@ -92,13 +92,28 @@ struct Opnd {
     int ks;
 };
 
-// acc[32x32] += sgn * A * B over K (even) with 32x32x2 MFMAs
+// acc[32x32] += sgn * A * B over K (even, >= 2) with 32x32x2 MFMAs.  Operands of step k+1 are requested
+// from LDS before the MFMA of step k issues, so the ~64-cycle MFMA covers the LDS latency.
 PROMP_DEV void gemm32(f32x16& acc, Opnd a, Opnd b, int K, float sgn) {
+    float a0 = a.p[0], b0 = b.p[0];
 #pragma unroll 4
-    for (int k = 0; k < K; k += 2) acc = mfma32(sgn * a.p[k * a.ks], b.p[k * b.ks], acc);
+    for (int k = 2; k < K; k += 2) {
+        const float a1 = a.p[k * a.ks], b1 = b.p[k * b.ks];
+        acc = mfma32(sgn * a0, b0, acc);
+        a0 = a1;
+        b0 = b1;
+    }
+    acc = mfma32(sgn * a0, b0, acc);
 }
-// acc[16x16] += sgn * A * B over K (multiple of 4) with 16x16x4 MFMAs
+// acc[16x16] += sgn * A * B over K (multiple of 4, >= 4) with 16x16x4 MFMAs
 PROMP_DEV void gemm16(f32x4& acc, Opnd a, Opnd b, int K, float sgn) {
+    float a0 = a.p[0], b0 = b.p[0];
 #pragma unroll 4
-    for (int k = 0; k < K; k += 4) acc = mfma16(sgn * a.p[k * a.ks], b.p[k * b.ks], acc);
+    for (int k = 4; k < K; k += 4) {
+        const float a1 = a.p[k * a.ks], b1 = b.p[k * b.ks];
+        acc = mfma16(sgn * a0, b0, acc);
+        a0 = a1;
+        b0 = b1;
+    }
+    acc = mfma16(sgn * a0, b0, acc);
 }

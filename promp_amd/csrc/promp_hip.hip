@@ -43,7 +43,8 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 struct StepData {
-    int n_paths = 0, n_rows = 0, n_work = 0;
+    int n_paths = 0, n_rows = 0;
+    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (k_hvp), [1]: two per CU (k_fwd_bwd, sample kernels)
     bool has_policy = false, processed = false, has_adv = false;
     int ls_per_row = 0;
     int feat_dim = 0;
@@ -51,10 +52,11 @@ struct StepData {
     float *ret32 = nullptr, *adv32 = nullptr;
     double *ret64 = nullptr, *adv64 = nullptr;
     int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
-    int *task_row_offsets = nullptr, *task_path_offsets = nullptr, *task_wg_offsets = nullptr;
+    int *task_row_offsets = nullptr, *task_path_offsets = nullptr;
+    int* task_wg_offsets[2] = {nullptr, nullptr};
     double *path_ret0 = nullptr, *path_undisc = nullptr, *path_rsq = nullptr, *path_mom = nullptr;
     double* coeffs = nullptr;
-    WorkItem* work = nullptr;
+    WorkItem* work[2] = {nullptr, nullptr};
 };
 
 struct ProfSlot {
@@ -167,7 +169,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.obs = S.obs; a.act = S.act; a.adv = S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
-    a.work = S.work;
+    a.work = S.work[hvp ? 0 : 1];
     a.theta = theta; a.theta_task_stride = theta_stride;
     a.vdir = c->vbuf; a.vw2t = c->vw2t;
     a.partials = c->partials; a.partial_stride = c->partial_stride;
@@ -179,20 +181,20 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     if (prof_begin(c, id, S.n_rows)) return -2;
     const bool h64 = c->d.hidden1 == 64;
     if (!hvp) {
-        if (h64) { auto k = k_fwd_bwd<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_fwd, c->stream, a); }
-        else     { auto k = k_fwd_bwd<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_fwd, c->stream, a); }
+        if (h64) { auto k = k_fwd_bwd<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, c->smem_fwd, c->stream, a); }
+        else     { auto k = k_fwd_bwd<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, c->smem_fwd, c->stream, a); }
     } else {
-        if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_hvp, c->stream, a); }
-        else     { auto k = k_hvp<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work), 256, c->smem_hvp, c->stream, a); }
+        if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
+        else     { auto k = k_hvp<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
     }
     HIPCHECK(hipGetLastError());
     return prof_end(c, id);
 }
 
-int launch_reduce(promp_ctx* c, StepData& S, int mode, const float* cur, long long cur_stride, float* next, float* scal) {
+int launch_reduce(promp_ctx* c, StepData& S, int table, int mode, const float* cur, long long cur_stride, float* next, float* scal) {
     ReduceArgs r;
     r.partials = c->partials; r.partial_stride = c->partial_stride;
-    r.task_wg_offsets = S.task_wg_offsets;
+    r.task_wg_offsets = S.task_wg_offsets[table];
     r.NP = c->NP; r.H1 = c->d.hidden1; r.H2 = c->d.hidden2;
     r.oW2 = c->d.obs_dim * c->d.hidden1 + c->d.hidden1;
     r.step_sizes = c->step_sizes; r.mode = mode;
@@ -217,16 +219,16 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
         if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f)) return -2;
-        if (launch_reduce(c, c->steps[k], 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+        if (launch_reduce(c, c->steps[k], 1, 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
     }
     if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f)) return -2;
-    if (launch_reduce(c, c->steps[K], want_grad ? 1 : 3, nullptr, 0, nullptr, c->scal_outer)) return -2;
+    if (launch_reduce(c, c->steps[K], 1, want_grad ? 1 : 3, nullptr, 0, nullptr, c->scal_outer)) return -2;
     if (want_grad) {
         for (int k = K - 1; k >= 0; --k) {
             const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
             const long long st = (k == 0) ? 0 : NP;
             if (launch_pass(c, c->steps[k], true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, eta_host[k] / (float)K)) return -2;
-            if (launch_reduce(c, c->steps[k], 2, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+            if (launch_reduce(c, c->steps[k], 0, 2, nullptr, 0, nullptr, c->scal_tmp)) return -2;
         }
     }
     FinalArgs f;
@@ -264,8 +266,8 @@ int upload_eta(promp_ctx* c, const float* eta) {
 
 void free_step(StepData& S) {
     void* ptrs[] = {S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
-                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets, S.path_ret0,
-                    S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work};
+                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.path_ret0,
+                    S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -309,12 +311,12 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->NP = param_count(dims);
     c->Dmax = 2 * dims->obs_dim + 4;
     c->coeff_stride = c->Dmax;
-    c->max_work = c->n_cus + M;
+    c->max_work = 2 * c->n_cus + M;
     c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     const int Opad = (dims->obs_dim + 1) & ~1;
-    c->smem_fwd = sizeof(float) * (size_t)make_layout(Opad, dims->hidden1, dims->hidden2, 0).total;
+    c->smem_fwd = sizeof(float) * (size_t)make_layout_fwd(dims->obs_dim, Opad, dims->hidden1, dims->hidden2).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout(Opad, dims->hidden1, dims->hidden2, 1).total;
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;
@@ -358,10 +360,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         rc |= dev_alloc(&S.ret32, R); rc |= dev_alloc(&S.adv32, R); rc |= dev_alloc(&S.ret64, R); rc |= dev_alloc(&S.adv64, R);
         rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
         rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
-        rc |= dev_alloc(&S.task_wg_offsets, (size_t)M + 1);
+        rc |= dev_alloc(&S.task_wg_offsets[0], (size_t)M + 1); rc |= dev_alloc(&S.task_wg_offsets[1], (size_t)M + 1);
         rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
         rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
-        rc |= dev_alloc(&S.work, (size_t)c->max_work);
+        rc |= dev_alloc(&S.work[0], (size_t)c->max_work); rc |= dev_alloc(&S.work[1], (size_t)c->max_work);
     }
     if (rc) { promp_ctx_destroy(c); return -2; }
     *out = c;
@@ -416,33 +418,35 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         if (pro[tpo[i + 1]] == tro[i]) return fail(-1, "task %d has no rows", i);
     }
     tro[M] = R;
-    // work table: contiguous 64-row-tile ranges, workgroups shared out over tasks in proportion to their tiles
-    std::vector<int> tiles(M), nwg(M), two(M + 1);
+    // work tables: contiguous 64-row-tile ranges, workgroups shared out over tasks in proportion to their tiles
+    std::vector<int> tiles(M);
     long long total_tiles = 0;
     for (int i = 0; i < M; ++i) { tiles[i] = (tro[i + 1] - tro[i] + PROMP_TILE - 1) / PROMP_TILE; total_tiles += tiles[i]; }
-    const int target = c->n_cus;
-    std::vector<WorkItem> work;
-    two[0] = 0;
-    for (int i = 0; i < M; ++i) {
-        long long w = (tiles[i] * (long long)target + total_tiles / 2) / total_tiles;
-        if (w < 1) w = 1;
-        if (w > tiles[i]) w = tiles[i];
-        nwg[i] = (int)w;
-        for (int g = 0; g < nwg[i]; ++g) {
-            const int t0 = (int)((long long)tiles[i] * g / nwg[i]), t1 = (int)((long long)tiles[i] * (g + 1) / nwg[i]);
-            WorkItem it;
-            it.task = i;
-            it.row_begin = tro[i] + t0 * PROMP_TILE;
-            it.row_end = tro[i] + t1 * PROMP_TILE;
-            if (it.row_end > tro[i + 1]) it.row_end = tro[i + 1];
-            it.pad = 0;
-            work.push_back(it);
+    std::vector<WorkItem> work[2];
+    std::vector<int> two[2];
+    for (int t = 0; t < 2; ++t) {
+        const int target = (t + 1) * c->n_cus;
+        two[t].assign(M + 1, 0);
+        for (int i = 0; i < M; ++i) {
+            long long w = (tiles[i] * (long long)target + total_tiles / 2) / total_tiles;
+            if (w < 1) w = 1;
+            if (w > tiles[i]) w = tiles[i];
+            for (int g = 0; g < (int)w; ++g) {
+                const int t0 = (int)((long long)tiles[i] * g / w), t1 = (int)((long long)tiles[i] * (g + 1) / w);
+                WorkItem it;
+                it.task = i;
+                it.row_begin = tro[i] + t0 * PROMP_TILE;
+                it.row_end = tro[i] + t1 * PROMP_TILE;
+                if (it.row_end > tro[i + 1]) it.row_end = tro[i + 1];
+                it.pad = 0;
+                work[t].push_back(it);
+            }
+            two[t][i + 1] = (int)work[t].size();
         }
-        two[i + 1] = (int)work.size();
+        if ((int)work[t].size() > c->max_work) return fail(-5, "internal: work table overflow (%zu > %d)", work[t].size(), c->max_work);
     }
-    if ((int)work.size() > c->max_work) return fail(-5, "internal: work table overflow (%zu > %d)", work.size(), c->max_work);
     StepData& S = c->steps[step];
-    S.n_paths = n_paths; S.n_rows = R; S.n_work = (int)work.size();
+    S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false;
     const size_t O = c->d.obs_dim, A = c->d.act_dim;
     hipStream_t st = c->stream;
@@ -460,8 +464,10 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
     HIPCHECK(hipMemcpyAsync(S.path_task, path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.row_t, row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.task_row_offsets, tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.task_wg_offsets, two.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.work, work.data(), sizeof(WorkItem) * work.size(), hipMemcpyHostToDevice, st));
+    for (int t = 0; t < 2; ++t) {
+        HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[t], two[t].data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.work[t], work[t].data(), sizeof(WorkItem) * work[t].size(), hipMemcpyHostToDevice, st));
+    }
     HIPCHECK(hipStreamSynchronize(st));  // host staging vectors go out of scope
     return 0;
 }
@@ -476,8 +482,8 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (o->baseline_kind < 0 || o->baseline_kind > 2) return fail(-1, "unknown baseline kind %d", o->baseline_kind);
     SampleArgs a;
     a.obs = S.obs; a.rew = S.rew; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
-    a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets; a.work = S.work;
-    a.task_wg_offsets = S.task_wg_offsets;
+    a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets; a.work = S.work[1];
+    a.task_wg_offsets = S.task_wg_offsets[1];
     a.O = c->d.obs_dim; a.kind = o->baseline_kind; a.D = feature_dim(&c->d, o->baseline_kind);
     a.gamma = o->discount; a.lam = o->gae_lambda; a.reg = o->reg_coeff;
     a.normalize = o->normalize_adv; a.positive = o->positive_adv;
@@ -492,11 +498,11 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         const int nblk = (a.D + 1 + 15) / 16;
         if (prof_begin(c, PROMP_KERNEL_GRAM, S.n_rows)) return -2;
         switch (nblk) {
-            case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<1>::SMEM_BYTES, st, a); } break;
-            case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<2>::SMEM_BYTES, st, a); } break;
-            case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<3>::SMEM_BYTES, st, a); } break;
-            case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<4>::SMEM_BYTES, st, a); } break;
-            case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work), 256, GramCfg<5>::SMEM_BYTES, st, a); } break;
+            case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<1>::SMEM_BYTES, st, a); } break;
+            case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<2>::SMEM_BYTES, st, a); } break;
+            case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<3>::SMEM_BYTES, st, a); } break;
+            case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<4>::SMEM_BYTES, st, a); } break;
+            case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<5>::SMEM_BYTES, st, a); } break;
             default: return fail(-1, "feature dim %d unsupported in this build", a.D);
         }
         HIPCHECK(hipGetLastError());
@@ -508,7 +514,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     }
     PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), st, a);
     HIPCHECK(hipGetLastError());
-    PROMP_LAUNCH(k_normalize, dim3(S.n_work), 256, 0, st, a);
+    PROMP_LAUNCH(k_normalize, dim3(S.n_work[1]), 256, 0, st, a);
     HIPCHECK(hipGetLastError());
     S.processed = true;
     S.has_adv = true;
@@ -606,7 +612,7 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     StepData& S = c->steps[step];
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f)) return -2;
-    return launch_reduce(c, S, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
+    return launch_reduce(c, S, 1, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
 }
 
 int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_kind, int outer_kind, float* grad_out,
@@ -661,7 +667,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     StepData& S = c->steps[step];
     const int M = c->d.n_tasks;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f)) return -2;
-    if (launch_reduce(c, S, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (launch_reduce(c, S, 1, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
     std::vector<float> sc((size_t)M * 2);
     if (copy_out(c, sc.data(), c->scal_tmp, sc.size())) return -2;
@@ -685,7 +691,7 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     if (copy_in(c, c->vbuf, v, (size_t)M * NP) || copy_in(c, c->vw2t, vt.data(), vt.size())) return -2;
     HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
     if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw)) return -2;
-    if (launch_reduce(c, S, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (launch_reduce(c, S, 0, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     return copy_out(c, out, c->lam, (size_t)M * NP);
 }
 

@@ -143,9 +143,47 @@ PROMP_DEV void load_obs_tile(float* Xs, int XS, const float* obs, long long base
 
 // ---------------------------------------------------------------------------------------------
 // k_fwd_bwd
+//
+// LDS budget <= 80 KB so that TWO workgroups are resident per CU (8 waves, 2 per SIMD): while one
+// workgroup is in a serial segment (tile load, per-row epilogue, barrier) the other one feeds the matrix
+// pipe.  To get there the cotangent tiles dZ2 / dZ1 overwrite H2 / H1 in place (each element is read and
+// rewritten by the one lane that owns it in the MFMA accumulator layout), the observation tile is a flat
+// copy of the 64 contiguous rows, and the next tile's rows are prefetched into registers.
 // ---------------------------------------------------------------------------------------------
+struct LdsFwd {
+    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2, xs, h1, h2, ms, red, total, HS;
+};
+
+PROMP_HD LdsFwd make_layout_fwd(int O, int Opad, int H1, int H2) {
+    LdsFwd L;
+    int o = 0;
+#define PROMP_TAKE(field, n) \
+    L.field = o;             \
+    o += ((n) + 3) & ~3
+    PROMP_TAKE(w1, Opad * H1);
+    PROMP_TAKE(b1, H1);
+    PROMP_TAKE(w2, H1 * (H2 + 1));
+    PROMP_TAKE(b2, H2);
+    PROMP_TAKE(w3, H2 * 16);
+    PROMP_TAKE(w3t, 8 * H2);
+    PROMP_TAKE(b3, 16);
+    PROMP_TAKE(ls, 16);
+    PROMP_TAKE(lmask, 16);
+    PROMP_TAKE(es, 16);
+    PROMP_TAKE(sn2, 16);
+    L.HS = (H1 > H2 ? H1 : H2) + 1;
+    PROMP_TAKE(xs, PROMP_TILE * O + 64);   // flat [64][O] (+ zeroed slack read by the padded operand lanes)
+    PROMP_TAKE(h1, PROMP_TILE * L.HS);
+    PROMP_TAKE(h2, PROMP_TILE * L.HS);
+    PROMP_TAKE(ms, PROMP_TILE * PROMP_MS);
+    PROMP_TAKE(red, 2 * H1 + 2 * H2 + 96);   // end-of-kernel bias / epilogue partials
+#undef PROMP_TAKE
+    L.total = o;
+    return L;
+}
+
 template <int NB1, int NB2>
-__global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
+__global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
     constexpr int H1 = 32 * NB1, H2 = 32 * NB2, MS = PROMP_MS;
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -154,52 +192,113 @@ __global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
     const WorkItem wk = a.work[blockIdx.x];
     const int task = wk.task;
     const int O = a.O, A = a.A, Opad = (O + 1) & ~1;
-    const LdsLayout L = make_layout(Opad, H1, H2, 0);
-    const int XS = L.XS, HS = L.HS;
+    const LdsFwd L = make_layout_fwd(O, Opad, H1, H2);
+    const int HS = L.HS;
     float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
-          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask;
-    float *Xs = sm + L.xs, *H1s = sm + L.h1, *H2s = sm + L.h2, *Ds = sm + L.ds, *Ms = sm + L.ms;
+          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
+          *sn2s = sm + L.sn2;
+    float *Xs = sm + L.xs, *H1s = sm + L.h1, *H2s = sm + L.h2, *Ms = sm + L.ms;
     const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
     const float invN = 1.0f / (float)ntask;
     const float* th = a.theta + (long long)task * a.theta_task_stride;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
               NP = oS + A;
 
-    stage_params<H1, H2>(sm, L, th, O, A, Opad, tid, a.clip_log_std, a.min_log_std);
-    __syncthreads();
+    // ---- stage this task's parameters ----
+    for (int e = tid; e < Opad * H1; e += 256) W1s[e] = (e < O * H1) ? th[e] : 0.f;
+    for (int e = tid; e < H1 * H2; e += 256) {
+        const int k = e / H2, j = e - k * H2;
+        W2s[k * (H2 + 1) + j] = th[oW2 + e];
+    }
+    for (int e = tid; e < H2 * 16; e += 256) {
+        const int k = e >> 4, j = e & 15;
+        W3s[e] = (j < A) ? th[oW3 + k * A + j] : 0.f;
+    }
+    for (int e = tid; e < 8 * H2; e += 256) {
+        const int aa = e / H2, k = e - aa * H2;
+        W3Ts[e] = (aa < A) ? th[oW3 + k * A + aa] : 0.f;
+    }
+    if (tid < H1) b1s[tid] = th[ob1 + tid];
+    if (tid < H2) b2s[tid] = th[ob2 + tid];
+    if (tid < 16) {
+        b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
+        const float sr = (tid < A) ? th[oS + tid] : 0.f;
+        const bool clipped = a.clip_log_std && (sr < a.min_log_std);   // tf.maximum: gradient iff var >= min
+        const float s = clipped ? a.min_log_std : sr;
+        lss[tid] = s;
+        lmask[tid] = clipped ? 0.f : 1.f;
+        ess[tid] = expf(-s);
+        sn2s[tid] = expf(2.f * s);
+    }
+    for (int e = tid; e < 64; e += 256) Xs[PROMP_TILE * O + e] = 0.f;
 
-    // persistent accumulators (weight-gradient tiles owned by this wave)
+    // ---- persistent accumulators ----
     f32x16 acc_w2 = zero16(), acc_w1 = zero16();
     f32x4 acc_w3 = zero4();
     float loss = 0.f, klsum = 0.f, gb1 = 0.f, gb2 = 0.f;
-    float gs[8], gb3[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) gs[i] = gb3[i] = 0.f;
+    float gs0 = 0.f, gs1 = 0.f, gb30 = 0.f, gb31 = 0.f;
 
-    constexpr int NRB3 = H2 / 16;                       // 16-row blocks of the output-kernel gradient
-    constexpr int P3 = (NRB3 >= 4) ? 1 : 4 / NRB3;      // sample-split of those blocks over 4 waves
+    constexpr int NRB3 = H2 / 16;
+    constexpr int P3 = (NRB3 >= 4) ? 1 : 4 / NRB3;
     constexpr int KS3 = PROMP_TILE / P3;
-    constexpr int P1 = 4 / NB1;                         // sample-split of the first-layer gradient
+    constexpr int P1 = 4 / NB1;
     constexpr int KS1 = PROMP_TILE / P1;
     const int rbk3 = w % NRB3, part3 = (w / NRB3) % P3;
     const int cb1 = w % NB1, part1 = w / NB1;
+    // epilogue role: 4 threads per row, actions {q, q+4}
+    const int erow = tid >> 2, q = tid & 3;
+    const bool own0 = q < A, own1 = (q + 4) < A;
+    const int XE = PROMP_TILE * O;
+
+    // prefetch the first tile's observations
+    float xr[8];
+    {
+        const int nrows = (wk.row_end - wk.row_begin) < PROMP_TILE ? (wk.row_end - wk.row_begin) : PROMP_TILE;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            xr[u] = (e < nrows * O) ? a.obs[(long long)wk.row_begin * O + e] : 0.f;
+        }
+    }
+    __syncthreads();
 
     for (int base = wk.row_begin; base < wk.row_end; base += PROMP_TILE) {
         const int nrows = (wk.row_end - base) < PROMP_TILE ? (wk.row_end - base) : PROMP_TILE;
-        load_obs_tile(Xs, XS, a.obs, base, nrows, O, tid);
+        // ---- tile rows -> LDS; request the next tile and this tile's per-row epilogue inputs
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 256 * u;
+            if (e < XE) Xs[e] = xr[u];
+        }
+        {
+            const int nb = base + PROMP_TILE;
+            const int nn = (wk.row_end - nb) < PROMP_TILE ? (wk.row_end - nb) : PROMP_TILE;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * u;
+                xr[u] = (nb < wk.row_end && e < nn * O) ? a.obs[(long long)nb * O + e] : 0.f;
+            }
+        }
+        const bool rvalid = erow < nrows;
+        const long long n = (long long)base + (rvalid ? erow : 0);
+        const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+        const float advn = rvalid ? a.adv[n] : 0.f;
+        const float ac0 = (rvalid && own0) ? a.act[n * A + q] : 0.f, ac1 = (rvalid && own1) ? a.act[n * A + q + 4] : 0.f;
+        const float mo0 = (rvalid && own0) ? a.old_mean[n * A + q] : 0.f, mo1 = (rvalid && own1) ? a.old_mean[n * A + q + 4] : 0.f;
+        const float so0 = (rvalid && own0) ? olsp[q] : 0.f, so1 = (rvalid && own1) ? olsp[q + 4] : 0.f;
         __syncthreads();
-        // ---- layer 1: H1 = tanh(X W1 + b1)
+        // ---- layer 1
         if (w < 2 * NB1) {
             const int rb = w / NB1, cb = w % NB1;
             f32x16 acc = zero16();
-            gemm32(acc, Opnd{Xs + (rb * 32 + li) * XS + lh, 1}, Opnd{W1s + lh * H1 + cb * 32 + li, H1}, Opad, 1.f);
+            gemm32(acc, Opnd{Xs + (rb * 32 + li) * O + lh, 1}, Opnd{W1s + lh * H1 + cb * 32 + li, H1}, Opad, 1.f);
             const int col = cb * 32 + li;
             const float bb = b1s[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) H1s[(rb * 32 + row32(r, lh)) * HS + col] = fast_tanh(acc[r] + bb);
         }
         __syncthreads();
-        // ---- layer 2: H2 = tanh(H1 W2 + b2)
+        // ---- layer 2
         if (w < 2 * NB2) {
             const int rb = w / NB2, cb = w % NB2;
             f32x16 acc = zero16();
@@ -211,7 +310,7 @@ __global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
             for (int r = 0; r < 16; ++r) H2s[(rb * 32 + row32(r, lh)) * HS + col] = fast_tanh(acc[r] + bb);
         }
         __syncthreads();
-        // ---- output layer: mean = H2 W3 + b3 (16 rows per wave, columns padded to 16)
+        // ---- output layer (16 rows per wave, 16 padded columns)
         {
             f32x4 acc = zero4();
             gemm16(acc, Opnd{H2s + (16 * w + i16) * HS + kk, 1}, Opnd{W3s + kk * 16 + i16, 16}, H2, 1.f);
@@ -220,113 +319,125 @@ __global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
             for (int r = 0; r < 4; ++r) Ms[(16 * w + 4 * kk + r) * MS + i16] = acc[r] + bb;
         }
         __syncthreads();
-        // ---- distribution + objective epilogue, one thread per row
-        if (tid < PROMP_TILE) {
-            float dmu[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dmu[i] = 0.f;
-            if (tid < nrows) {
-                const long long n = (long long)base + tid;
-                const float advn = a.adv[n];
-                const float* ols = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
-                float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
-                float z[8], e[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    z[i] = 0.f;
-                    e[i] = 0.f;
-                    if (i < A) {
-                        const float s = lss[i], so = ols[i];
-                        const float mu = Ms[tid * MS + i], mo = a.old_mean[n * A + i], ac = a.act[n * A + i];
-                        e[i] = expf(-s);
-                        z[i] = (ac - mu) * e[i];
-                        const float zo = (ac - mo) * expf(-so);
-                        dlp += (so - s) - 0.5f * (z[i] * z[i] - zo * zo);
-                        sumz2 += z[i] * z[i];
-                        sums += s;
-                        const float so2 = expf(2.f * so), sn2 = expf(2.f * s);
-                        const float num = (mo - mu) * (mo - mu) + so2 - sn2;
-                        kl += num / (2.f * sn2 + 1e-8f) + s - so;
-                    }
-                }
+        // ---- distribution + objective epilogue: 4 threads per row, each owns actions {q, q+4}
+        {
+            float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
+            float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f;
+            if (own0) {
+                const float s = lss[q], mu = Ms[erow * MS + q];
+                e0 = ess[q];
+                z0 = (ac0 - mu) * e0;
+                const float zo = (ac0 - mo0) * fast_exp(-so0);
+                dlp += (so0 - s) - 0.5f * (z0 * z0 - zo * zo);
+                sumz2 += z0 * z0;
+                sums += s;
+                const float sn2 = sn2s[q];
+                kl += ((mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2) / (2.f * sn2 + 1e-8f) + s - so0;
+            }
+            if (own1) {
+                const float s = lss[q + 4], mu = Ms[erow * MS + q + 4];
+                e1 = ess[q + 4];
+                z1 = (ac1 - mu) * e1;
+                const float zo = (ac1 - mo1) * fast_exp(-so1);
+                dlp += (so1 - s) - 0.5f * (z1 * z1 - zo * zo);
+                sumz2 += z1 * z1;
+                sums += s;
+                const float sn2 = sn2s[q + 4];
+                kl += ((mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2) / (2.f * sn2 + 1e-8f) + s - so1;
+            }
+            // reduce over the 4 threads of the row (adjacent lanes)
+            dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
+            sumz2 += shfl_xor_f32(sumz2, 1);  sumz2 += shfl_xor_f32(sumz2, 2);
+            sums += shfl_xor_f32(sums, 1);  sums += shfl_xor_f32(sums, 2);
+            kl += shfl_xor_f32(kl, 1);  kl += shfl_xor_f32(kl, 2);
+            float c = 0.f, lrow = 0.f;
+            if (rvalid) {
                 const float rho = expf(dlp);
-                float c;
                 if (a.loss_kind == LOSS_RATIO) {
-                    loss += -rho * advn * invN;
+                    lrow = -rho * advn * invN;
                     c = -advn * rho * invN;
                 } else if (a.loss_kind == LOSS_CLIP) {
                     const float x = rho * advn;
-                    const float rc = fminf(fmaxf(rho, 1.f - a.clip_eps), 1.f + a.clip_eps);
-                    const float y = rc * advn;
-                    loss += -fminf(x, y) * invN;
+                    const float y = fminf(fmaxf(rho, 1.f - a.clip_eps), 1.f + a.clip_eps) * advn;
+                    lrow = -fminf(x, y) * invN;
                     c = (x <= y) ? -advn * rho * invN : 0.f;
                 } else {
                     const float lp = -sums - 0.5f * sumz2 - 0.5f * (float)A * 1.8378770664093453f;
-                    loss += -lp * advn * invN;
+                    lrow = -lp * advn * invN;
                     c = -advn * invN;
                 }
-                klsum += kl * invN;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i < A) {
-                        dmu[i] = c * z[i] * e[i];
-                        gs[i] += c * (z[i] * z[i] - 1.f);
-                        gb3[i] += dmu[i];
-                    }
+                if (q == 0) {
+                    loss += lrow;
+                    klsum += kl * invN;
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Ms[tid * MS + i] = (i < 8) ? dmu[i] : 0.f;
+            if (own0) {
+                const float d = c * z0 * e0;
+                Ms[erow * MS + q] = d;
+                gs0 += c * (z0 * z0 - 1.f);
+                gb30 += d;
+            }
+            if (own1) {
+                const float d = c * z1 * e1;
+                Ms[erow * MS + q + 4] = d;
+                gs1 += c * (z1 * z1 - 1.f);
+                gb31 += d;
+            }
+            // columns >= A of Ms already hold exact zeros (zero-padded W3s / b3s)
         }
         __syncthreads();
-        // ---- output-kernel gradient (+=) and back-propagation to layer 2
+        // ---- output-kernel gradient (+=) and dH2 = dmu W3^T (kept in registers until H2 is free)
         gemm16(acc_w3, Opnd{H2s + (part3 * KS3 + kk) * HS + 16 * rbk3 + i16, HS},
                Opnd{Ms + (part3 * KS3 + kk) * MS + i16, MS}, KS3, 1.f);
+        f32x16 accd = zero16();
         if (w < 2 * NB2) {
             const int rb = w / NB2, cb = w % NB2;
-            f32x16 acc = zero16();
-            gemm32(acc, Opnd{Ms + (rb * 32 + li) * MS + lh, 1}, Opnd{W3Ts + lh * H2 + cb * 32 + li, H2}, 8, 1.f);
-            const int col = cb * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + row32(r, lh);
-                const float h = H2s[row * HS + col];
-                Ds[row * HS + col] = acc[r] * (1.f - h * h);
-            }
+            gemm32(accd, Opnd{Ms + (rb * 32 + li) * MS + lh, 1}, Opnd{W3Ts + lh * H2 + cb * 32 + li, H2}, 8, 1.f);
         }
         __syncthreads();
-        // ---- hidden_1 gradient (+=), its bias, and back-propagation to layer 1 (dZ1 overwrites H2s)
+        if (w < 2 * NB2) {   // dZ2 = dH2 * (1 - H2^2), in place over H2 ; its column sums are d/d(b2)
+            const int rb = w / NB2, cb = w % NB2, col = cb * 32 + li;
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int idx = (rb * 32 + row32(r, lh)) * HS + col;
+                const float h = H2s[idx];
+                const float d = accd[r] * (1.f - h * h);
+                H2s[idx] = d;
+                cs += d;
+            }
+            gb2 += cs + shfl_xor_f32(cs, 32);
+        }
+        __syncthreads();
+        // ---- hidden_1 kernel gradient (+=) and dH1 = dZ2 W2^T
         if (w < NB1 * NB2) {
             const int kb = w / NB2, jb = w % NB2;
-            gemm32(acc_w2, Opnd{H1s + lh * HS + kb * 32 + li, HS}, Opnd{Ds + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
+            gemm32(acc_w2, Opnd{H1s + lh * HS + kb * 32 + li, HS}, Opnd{H2s + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
                    1.f);
         }
-        if (tid >= 128 && tid < 128 + H2) {
-            float s = 0.f;
-            for (int r = 0; r < PROMP_TILE; ++r) s += Ds[r * HS + tid - 128];
-            gb2 += s;
-        }
+        accd = zero16();
         if (w < 2 * NB1) {
             const int rb = w / NB1, cb = w % NB1;
-            f32x16 acc = zero16();
-            gemm32(acc, Opnd{Ds + (rb * 32 + li) * HS + lh, 1}, Opnd{W2s + (cb * 32 + li) * (H2 + 1) + lh, 1}, H2, 1.f);
-            const int col = cb * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + row32(r, lh);
-                const float h = H1s[row * HS + col];
-                H2s[row * HS + col] = acc[r] * (1.f - h * h);
-            }
+            gemm32(accd, Opnd{H2s + (rb * 32 + li) * HS + lh, 1}, Opnd{W2s + (cb * 32 + li) * (H2 + 1) + lh, 1}, H2, 1.f);
         }
         __syncthreads();
-        // ---- hidden_0 gradient (+=) and its bias
-        gemm32(acc_w1, Opnd{Xs + (part1 * KS1 + lh) * XS + li, XS}, Opnd{H2s + (part1 * KS1 + lh) * HS + cb1 * 32 + li, HS},
-               KS1, 1.f);
-        if (tid >= 192 && tid < 192 + H1) {
-            float s = 0.f;
-            for (int r = 0; r < PROMP_TILE; ++r) s += H2s[r * HS + tid - 192];
-            gb1 += s;
+        if (w < 2 * NB1) {   // dZ1 in place over H1
+            const int rb = w / NB1, cb = w % NB1, col = cb * 32 + li;
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int idx = (rb * 32 + row32(r, lh)) * HS + col;
+                const float h = H1s[idx];
+                const float d = accd[r] * (1.f - h * h);
+                H1s[idx] = d;
+                cs += d;
+            }
+            gb1 += cs + shfl_xor_f32(cs, 32);
         }
+        __syncthreads();
+        // ---- hidden_0 kernel gradient (+=)
+        gemm32(acc_w1, Opnd{Xs + (part1 * KS1 + lh) * O + li, O}, Opnd{H1s + (part1 * KS1 + lh) * HS + cb1 * 32 + li, HS},
+               KS1, 1.f);
         __syncthreads();
     }
 
@@ -337,13 +448,28 @@ __global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) P[oW2 + (kb * 32 + row32(r, lh)) * H2 + jb * 32 + li] = acc_w2[r];
     }
-    float* S1 = H1s;  // [part][cb][32][32]
-    float* S3 = Ds;   // [part][H2][16]
+    // scratch (tile buffers are dead): S1 [P1][NB1][32][32] over H1s..H2s (contiguous), S3 [P3][H2][16] over Ms
+    float* S1 = H1s;
+    float* S3 = Ms;
+    float* SB = sm + L.red;                  // [2][H1] + [2][H2] bias partials of the two row blocks
+    float* SE = SB + 2 * H1 + 2 * H2;        // [4 waves][4 q][6] epilogue partials
 #pragma unroll
     for (int r = 0; r < 16; ++r) S1[((part1 * NB1 + cb1) * 32 + row32(r, lh)) * 32 + li] = acc_w1[r];
-    if (w < NRB3 * P3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S3[(part3 * H2 + 16 * rbk3 + 4 * kk + r) * 16 + i16] = acc_w3[r];
+    for (int r = 0; r < 4; ++r) S3[(part3 * H2 + 16 * rbk3 + 4 * kk + r) * 16 + i16] = acc_w3[r];
+    if (w < 2 * NB1 && lh == 0) SB[(w / NB1) * H1 + (w % NB1) * 32 + li] = gb1;
+    if (w < 2 * NB2 && lh == 0) SB[2 * H1 + (w / NB2) * H2 + (w % NB2) * 32 + li] = gb2;
+    {   // per-action sums over the rows of this wave: lanes with equal q differ in bits 2..5
+        float v0 = gs0, v1 = gs1, v2 = gb30, v3 = gb31, v4 = loss, v5 = klsum;
+#pragma unroll
+        for (int m = 4; m <= 32; m <<= 1) {
+            v0 += shfl_xor_f32(v0, m);  v1 += shfl_xor_f32(v1, m);  v2 += shfl_xor_f32(v2, m);
+            v3 += shfl_xor_f32(v3, m);  v4 += shfl_xor_f32(v4, m);  v5 += shfl_xor_f32(v5, m);
+        }
+        if (lane < 4) {   // lane == q
+            float* se = SE + w * 24 + lane * 6;
+            se[0] = v0; se[1] = v1; se[2] = v2; se[3] = v3; se[4] = v4; se[5] = v5;
+        }
     }
     __syncthreads();
     for (int e = tid; e < O * H1; e += 256) {
@@ -358,27 +484,26 @@ __global__ void __launch_bounds__(256) k_fwd_bwd(PassArgs a) {
         for (int p = 0; p < P3; ++p) s += S3[(p * H2 + hid) * 16 + aa];
         P[oW3 + e] = s;
     }
-    if (tid >= 192 && tid < 192 + H1) P[ob1 + tid - 192] = gb1;
-    if (tid >= 128 && tid < 128 + H2) P[ob2 + tid - 128] = gb2;
-    if (w == 0) {
-        loss = wave_sum_f32(loss);
-        klsum = wave_sum_f32(klsum);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            gb3[i] = wave_sum_f32(gb3[i]);
-            gs[i] = wave_sum_f32(gs[i]);
+    if (tid < H1) P[ob1 + tid] = SB[tid] + SB[H1 + tid];
+    if (tid < H2) P[ob2 + tid] = SB[2 * H1 + tid] + SB[2 * H1 + H2 + tid];
+    if (tid < 8 && tid < A) {
+        const int qq = tid & 3, hi = tid >> 2;   // action tid = qq + 4*hi
+        float g = 0.f, b = 0.f;
+        for (int ww = 0; ww < 4; ++ww) {
+            g += SE[ww * 24 + qq * 6 + hi];
+            b += SE[ww * 24 + qq * 6 + 2 + hi];
         }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i < A) {
-                    P[ob3 + i] = gb3[i];
-                    P[oS + i] = gs[i] * lmask[i];
-                }
-            }
-            P[NP] = loss;
-            P[NP + 1] = klsum;
+        P[ob3 + tid] = b;
+        P[oS + tid] = g * lmask[tid];
+    }
+    if (tid == 0) {
+        float l = 0.f, k = 0.f;
+        for (int ww = 0; ww < 4; ++ww) {
+            l += SE[ww * 24 + 4];
+            k += SE[ww * 24 + 5];
         }
+        P[NP] = l;
+        P[NP + 1] = k;
     }
 }
 

@@ -44,27 +44,6 @@ struct SampleArgs {
     int coeff_stride;
 };
 
-PROMP_DEV double feature_at(const SampleArgs& a, long long row, int c) {
-    const int O = a.O;
-    if (c == a.D) return a.ret64[row];  // appended target column
-    if (c > a.D) return 0.0;
-    int q = c;
-    if (a.kind == BASE_LINFEAT) {
-        if (c < 2 * O) {
-            const float o = a.obs[row * O + (c < O ? c : c - O)];
-            const float oc = fminf(fmaxf(o, -10.f), 10.f);
-            // the reference squares in the observations' own dtype (float32), then promotes
-            return (c < O) ? (double)oc : (double)(oc * oc);
-        }
-        q = c - 2 * O;
-    }
-    const double tau = (double)a.row_t[row] / 100.0;
-    if (q == 0) return tau;
-    if (q == 1) return tau * tau;
-    if (q == 2) return tau * tau * tau;
-    return 1.0;
-}
-
 // grid = paths, block = 64
 __global__ void __launch_bounds__(64) k_returns(SampleArgs a) {
     const int p = blockIdx.x, lane = threadIdx.x;
@@ -106,7 +85,8 @@ template <int NBLK>
 struct GramCfg {
     static constexpr int FS = (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16;  // row stride (doubles)
     static constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
-    static constexpr int SMEM_BYTES = (32 * FS + NPAIR * 256) * 8;
+    // Phi [32][FS] f64 | Red [NPAIR][256] f64 | raw obs [32][32] f32 | targets [32] f64 | tau [32] f64
+    static constexpr int SMEM_BYTES = (32 * FS + NPAIR * 256 + 32 + 32) * 8 + 32 * 32 * 4;
 };
 
 // grid = work items, block = 256.  Partial Gram of [Phi R] over the item's rows.
@@ -116,16 +96,52 @@ __global__ void __launch_bounds__(256) k_gram(SampleArgs a) {
     PROMP_SMEM_DECL;
     double* Phi = (double*)PROMP_SMEM_PTR;
     double* Red = Phi + 32 * FS;
+    double* Tg = Red + NPAIR * 256;
+    double* Tau = Tg + 32;
+    float* Ob = (float*)(Tau + 32);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
     const WorkItem wk = a.work[blockIdx.x];
+    const int O = a.O, D = a.D;
     f64x4 acc[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = zero4d();
     for (int base = wk.row_begin; base < wk.row_end; base += 32) {
         const int nrows = (wk.row_end - base) < 32 ? (wk.row_end - base) : 32;
+        // stage the raw rows with unconditional coalesced loads, then build the features out of LDS
+        if (a.kind == BASE_LINFEAT)
+            for (int e = tid; e < 32 * O; e += 256) Ob[e] = (e < nrows * O) ? a.obs[(long long)base * O + e] : 0.f;
+        if (tid < 32) {
+            Tg[tid] = (tid < nrows) ? a.ret64[base + tid] : 0.0;
+            Tau[tid] = (tid < nrows) ? (double)a.row_t[base + tid] / 100.0 : 0.0;
+        }
+        __syncthreads();
         for (int e = tid; e < 32 * NC; e += 256) {
             const int r = e / NC, c = e - r * NC;
-            Phi[r * FS + c] = (r < nrows) ? feature_at(a, (long long)base + r, c) : 0.0;
+            double f = 0.0;
+            if (r < nrows) {
+                int q = c;
+                bool done = false;
+                if (c == D) {
+                    f = Tg[r];
+                    done = true;
+                } else if (c > D) {
+                    done = true;
+                } else if (a.kind == BASE_LINFEAT) {
+                    if (c < 2 * O) {
+                        const float o = Ob[r * O + (c < O ? c : c - O)];
+                        const float oc = fminf(fmaxf(o, -10.f), 10.f);
+                        // the reference squares in the observations' own dtype (float32), then promotes
+                        f = (c < O) ? (double)oc : (double)(oc * oc);
+                        done = true;
+                    }
+                    q = c - 2 * O;
+                }
+                if (!done) {
+                    const double tau = Tau[r];
+                    f = (q == 0) ? tau : (q == 1) ? tau * tau : (q == 2) ? tau * tau * tau : 1.0;
+                }
+            }
+            Phi[r * FS + c] = f;
         }
         __syncthreads();
         for (int s = w; s < 8; s += 4) {
