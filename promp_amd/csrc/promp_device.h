@@ -38,6 +38,16 @@ PROMP_DEV float shfl_xor_f32(float v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }
 PROMP_DEV double shfl_idx_f64(double v, int l) { return __shfl(v, l, 64); }
+// Orders this wave's LDS traffic between producer and consumer lanes of the SAME wave (no s_barrier):
+// LDS executes one wave's instructions in order, so it is enough to (a) stop the compiler from moving memory
+// accesses across this point and (b) have the data written.  Deliberately NOT a fence: a fence would also wait
+// for the global prefetch loads in flight (vmcnt) and serialise them with the tile pipeline.
+PROMP_DEV void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+PROMP_DEV unsigned long long promp_clock() { return (unsigned long long)clock64(); }
+PROMP_DEV unsigned long long promp_wall_clock() { return (unsigned long long)wall_clock64(); }   // constant 100 MHz
 PROMP_DEV float fast_exp(float x) { return __expf(x); }
 PROMP_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 #endif
@@ -116,4 +126,38 @@ PROMP_DEV void gemm16(f32x4& acc, Opnd a, Opnd b, int K, float sgn) {
         b0 = b1;
     }
     acc = mfma16(sgn * a0, b0, acc);
+}
+
+// acc[ia][ib] (16x16 tiles) += sgn * A_ia * B_ib over K (multiple of 4) with 16x16x4 MFMAs.
+// Operand streams: A block ia feeds a[k*a_ks + ia*a_bs], B block ib feeds b[k*b_ks + ib*b_bs] (pointers already
+// offset for this lane).  NA*NB independent accumulators hide the 40-cycle dependent latency; the operands of
+// step k+4 are requested before the MFMAs of step k issue.
+template <int NA, int NB>
+PROMP_DEV void outer16(f32x4 (&acc)[NA][NB], const float* a, int a_ks, int a_bs, const float* b, int b_ks, int b_bs, int K,
+                       float sgn) {
+    float a0[NA], b0[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a0[i] = a[i * a_bs];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b0[j] = b[j * b_bs];
+#pragma unroll 2
+    for (int k = 4; k < K; k += 4) {
+        float a1[NA], b1[NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a1[i] = a[k * a_ks + i * a_bs];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b1[j] = b[k * b_ks + j * b_bs];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = mfma16(sgn * a0[i], b0[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a0[i] = a1[i];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b0[j] = b1[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = mfma16(sgn * a0[i], b0[j], acc[i][j]);
 }

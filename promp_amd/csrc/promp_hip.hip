@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 
 struct StepData {
     int n_paths = 0, n_rows = 0;
-    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (k_hvp), [1]: two per CU (k_fwd_bwd, sample kernels)
+    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (policy passes), [1]: two per CU (sample kernels)
     bool has_policy = false, processed = false, has_adv = false;
     int ls_per_row = 0;
     int feat_dim = 0;
@@ -88,6 +89,8 @@ struct promp_ctx {
     int rank = 0, nranks = 1;
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
+    unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
+    bool dbg_enabled = false;
 };
 
 namespace {
@@ -169,7 +172,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.obs = S.obs; a.act = S.act; a.adv = S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
-    a.work = S.work[hvp ? 0 : 1];
+    a.work = S.work[0];
     a.theta = theta; a.theta_task_stride = theta_stride;
     a.vdir = c->vbuf; a.vw2t = c->vw2t;
     a.partials = c->partials; a.partial_stride = c->partial_stride;
@@ -177,12 +180,13 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.loss_kind = loss_kind; a.clip_eps = clip_eps; a.clip_log_std = clip_ls;
     a.min_log_std = logf(1e-6f);   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
     a.kl_weight = klw;
+    a.dbg = c->dbg_enabled ? c->dbg : nullptr;
     const int id = hvp ? PROMP_KERNEL_HVP : PROMP_KERNEL_FWD_BWD;
     if (prof_begin(c, id, S.n_rows)) return -2;
     const bool h64 = c->d.hidden1 == 64;
     if (!hvp) {
-        if (h64) { auto k = k_fwd_bwd<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, c->smem_fwd, c->stream, a); }
-        else     { auto k = k_fwd_bwd<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, c->smem_fwd, c->stream, a); }
+        if (h64) { auto k = k_fwd_bwd<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
+        else     { auto k = k_fwd_bwd<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
     } else {
         if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
         else     { auto k = k_hvp<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
@@ -219,10 +223,10 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
         if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f)) return -2;
-        if (launch_reduce(c, c->steps[k], 1, 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+        if (launch_reduce(c, c->steps[k], 0, 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
     }
     if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f)) return -2;
-    if (launch_reduce(c, c->steps[K], 1, want_grad ? 1 : 3, nullptr, 0, nullptr, c->scal_outer)) return -2;
+    if (launch_reduce(c, c->steps[K], 0, want_grad ? 1 : 3, nullptr, 0, nullptr, c->scal_outer)) return -2;
     if (want_grad) {
         for (int k = K - 1; k >= 0; --k) {
             const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
@@ -316,7 +320,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     const int Opad = (dims->obs_dim + 1) & ~1;
-    c->smem_fwd = sizeof(float) * (size_t)make_layout_fwd(dims->obs_dim, Opad, dims->hidden1, dims->hidden2).total;
+    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
+    if (const char* e = getenv("PROMP_DEV_FWD_LDS_PAD")) c->smem_fwd += (size_t)atoi(e);   // developer experiment: force 1 WG/CU
     c->smem_hvp = sizeof(float) * (size_t)make_layout(Opad, dims->hidden1, dims->hidden2, 1).total;
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;
@@ -351,6 +356,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->stats, (size_t)K + 2); rc |= dev_alloc(&c->eta_dev, (size_t)K);
     rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
     rc |= dev_alloc(&c->red64, 64);
+    rc |= dev_alloc(&c->dbg, 256);
     c->steps.resize(K + 1);
     for (int s = 0; s <= K && !rc; ++s) {
         StepData& S = c->steps[s];
@@ -425,7 +431,10 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
     std::vector<WorkItem> work[2];
     std::vector<int> two[2];
     for (int t = 0; t < 2; ++t) {
-        const int target = (t + 1) * c->n_cus;
+        // table 0: k_hvp and k_fwd_bwd (one workgroup per CU: measured faster than two shorter ones, the parameter
+        // staging and the end-of-kernel reduction amortise over twice the tiles); table 1: the sample-processing kernels
+        int target = (t + 1) * c->n_cus;
+        if (const char* e = getenv(t == 0 ? "PROMP_DEV_TARGET0" : "PROMP_DEV_TARGET1")) target = atoi(e);   // developer experiment
         two[t].assign(M + 1, 0);
         for (int i = 0; i < M; ++i) {
             long long w = (tiles[i] * (long long)target + total_tiles / 2) / total_tiles;
@@ -612,7 +621,7 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     StepData& S = c->steps[step];
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f)) return -2;
-    return launch_reduce(c, S, 1, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
+    return launch_reduce(c, S, 0, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
 }
 
 int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_kind, int outer_kind, float* grad_out,
@@ -667,7 +676,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     StepData& S = c->steps[step];
     const int M = c->d.n_tasks;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f)) return -2;
-    if (launch_reduce(c, S, 1, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (launch_reduce(c, S, 0, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
     std::vector<float> sc((size_t)M * 2);
     if (copy_out(c, sc.data(), c->scal_tmp, sc.size())) return -2;
@@ -741,6 +750,21 @@ int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {
     HIPCHECK(hipMemcpyAsync(buf, c->red64, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
 #endif
+    return 0;
+}
+
+// Developer tooling (not part of include/promp_hip.h): run one k_fwd_bwd / k_hvp launch on the current per-task
+// parameters with cycle stamps of workgroup 0 enabled, and return the 256 raw stamps.
+int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long* out) {
+    if (!c || !out) return fail(-1, "NULL argument");
+    StepData& S = c->steps[step];
+    HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * 256, c->stream));
+    c->dbg_enabled = true;
+    const int rc = launch_pass(c, S, hvp != 0, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f);
+    c->dbg_enabled = false;
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(out, c->dbg, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -51,6 +51,7 @@ struct PassArgs {
     int clip_log_std;
     float min_log_std;
     float kl_weight;
+    unsigned long long* dbg;      // optional cycle stamps of block 0 / lane 0 (tools/phase_timing.py), else NULL
 };
 
 struct LdsLayout {
@@ -142,27 +143,39 @@ PROMP_DEV void load_obs_tile(float* Xs, int XS, const float* obs, long long base
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fwd_bwd
+// k_fwd_bwd -- wave-private pipelines.
 //
-// LDS budget <= 80 KB so that TWO workgroups are resident per CU (8 waves, 2 per SIMD): while one
-// workgroup is in a serial segment (tile load, per-row epilogue, barrier) the other one feeds the matrix
-// pipe.  To get there the cotangent tiles dZ2 / dZ1 overwrite H2 / H1 in place (each element is read and
-// rewritten by the one lane that owns it in the MFMA accumulator layout), the observation tile is a flat
-// copy of the 64 contiguous rows, and the next tile's rows are prefetched into registers.
+// The workgroup (4 waves, TWO workgroups resident per CU => 2 waves per SIMD) shares one task's parameters
+// in LDS; every wave walks its own 16-row tiles through the whole forward/backward chain with its own LDS
+// buffers, so there is NO workgroup barrier inside the tile loop: waves drift apart and one wave's VALU /
+// LDS segments overlap the MFMA segments of the other wave on the same SIMD.  All GEMMs are
+// v_mfma_f32_16x16x4_f32 (exact FP32, same FLOP rate as 32x32x2) with up to 16 independent accumulators per
+// GEMM, which also covers the 40-cycle dependent-accumulator latency.  The cotangent tiles dZ2 / dZ1
+// overwrite H2 / H1 in place.  Weight-gradient tiles live in registers across all tiles of the wave; the
+// four waves' tiles are added in a fixed order through LDS at the end (bitwise reproducible).
 // ---------------------------------------------------------------------------------------------
-struct LdsFwd {
-    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2, xs, h1, h2, ms, red, total, HS;
+// developer tooling: cycle stamps of workgroup 0 / thread 0, kept in LDS and dumped when the kernel ends
+#define PROMP_STAMP(i) do { if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0) dbgs[(i)] = promp_clock(); } while (0)
+#define PROMP_WROWS 16
+#define PROMP_XS 33
+
+struct LdsWave {
+    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2;
+    int wave0, wave_stride, x, h1, h2, ms;   // per-wave region: offsets of the private buffers inside it
+    int total, HS, WS, Opad4, dbg;
 };
 
-PROMP_HD LdsFwd make_layout_fwd(int O, int Opad, int H1, int H2) {
-    LdsFwd L;
+PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
+    LdsWave L;
     int o = 0;
 #define PROMP_TAKE(field, n) \
     L.field = o;             \
     o += ((n) + 3) & ~3
-    PROMP_TAKE(w1, Opad * H1);
+    L.Opad4 = (O + 3) & ~3;
+    L.WS = H2 + 1;
+    PROMP_TAKE(w1, L.Opad4 * H1);
     PROMP_TAKE(b1, H1);
-    PROMP_TAKE(w2, H1 * (H2 + 1));
+    PROMP_TAKE(w2, H1 * L.WS);
     PROMP_TAKE(b2, H2);
     PROMP_TAKE(w3, H2 * 16);
     PROMP_TAKE(w3t, 8 * H2);
@@ -172,11 +185,18 @@ PROMP_HD LdsFwd make_layout_fwd(int O, int Opad, int H1, int H2) {
     PROMP_TAKE(es, 16);
     PROMP_TAKE(sn2, 16);
     L.HS = (H1 > H2 ? H1 : H2) + 1;
-    PROMP_TAKE(xs, PROMP_TILE * O + 64);   // flat [64][O] (+ zeroed slack read by the padded operand lanes)
-    PROMP_TAKE(h1, PROMP_TILE * L.HS);
-    PROMP_TAKE(h2, PROMP_TILE * L.HS);
-    PROMP_TAKE(ms, PROMP_TILE * PROMP_MS);
-    PROMP_TAKE(red, 2 * H1 + 2 * H2 + 96);   // end-of-kernel bias / epilogue partials
+    L.wave0 = o;
+    int q = 0;
+    L.x = q;  q += (PROMP_WROWS * PROMP_XS + 3) & ~3;
+    L.h1 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
+    L.h2 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
+    L.ms = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
+    L.wave_stride = q;
+    o += nwaves * q;
+    // the end-of-kernel reduction buffer [NP + 2] aliases the per-wave regions
+    if (o - L.wave0 < NP + 8) o = L.wave0 + NP + 8;
+    L.dbg = o;
+    o += 256;   // 128 cycle stamps (developer tooling)
 #undef PROMP_TAKE
     L.total = o;
     return L;
@@ -184,31 +204,35 @@ PROMP_HD LdsFwd make_layout_fwd(int O, int Opad, int H1, int H2) {
 
 template <int NB1, int NB2>
 __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
-    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, MS = PROMP_MS;
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, XS = PROMP_XS;
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5, i16 = lane & 15, kk = lane >> 4;
+    const int i16 = lane & 15, kk = lane >> 4;
     const WorkItem wk = a.work[blockIdx.x];
     const int task = wk.task;
-    const int O = a.O, A = a.A, Opad = (O + 1) & ~1;
-    const LdsFwd L = make_layout_fwd(O, Opad, H1, H2);
-    const int HS = L.HS;
+    const int O = a.O, A = a.A;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
+              NP = oS + A;
+    const LdsWave L = make_layout_wave(O, H1, H2, 4, NP);
+    const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4;
     float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
           *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
           *sn2s = sm + L.sn2;
-    float *Xs = sm + L.xs, *H1s = sm + L.h1, *H2s = sm + L.h2, *Ms = sm + L.ms;
+    unsigned long long* dbgs = (unsigned long long*)(sm + L.dbg);
+    if (a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
+    float* wreg = sm + L.wave0 + w * L.wave_stride;
+    float *Xw = wreg + L.x, *H1w = wreg + L.h1, *H2w = wreg + L.h2, *Msw = wreg + L.ms;
     const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
     const float invN = 1.0f / (float)ntask;
     const float* th = a.theta + (long long)task * a.theta_task_stride;
-    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
-              NP = oS + A;
+    PROMP_STAMP(0);
 
-    // ---- stage this task's parameters ----
-    for (int e = tid; e < Opad * H1; e += 256) W1s[e] = (e < O * H1) ? th[e] : 0.f;
+    // ---- stage this task's parameters (shared by the 4 waves) ----
+    for (int e = tid; e < Opad4 * H1; e += 256) W1s[e] = (e < O * H1) ? th[e] : 0.f;
     for (int e = tid; e < H1 * H2; e += 256) {
         const int k = e / H2, j = e - k * H2;
-        W2s[k * (H2 + 1) + j] = th[oW2 + e];
+        W2s[k * WS + j] = th[oW2 + e];
     }
     for (int e = tid; e < H2 * 16; e += 256) {
         const int k = e >> 4, j = e & 15;
@@ -230,52 +254,64 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
         ess[tid] = expf(-s);
         sn2s[tid] = expf(2.f * s);
     }
-    for (int e = tid; e < 64; e += 256) Xs[PROMP_TILE * O + e] = 0.f;
+    for (int e = lane; e < PROMP_WROWS * XS; e += 64) Xw[e] = 0.f;   // pad columns stay zero
+    __syncthreads();
+    PROMP_STAMP(1);
 
-    // ---- persistent accumulators ----
-    f32x16 acc_w2 = zero16(), acc_w1 = zero16();
-    f32x4 acc_w3 = zero4();
-    float loss = 0.f, klsum = 0.f, gb1 = 0.f, gb2 = 0.f;
-    float gs0 = 0.f, gs1 = 0.f, gb30 = 0.f, gb31 = 0.f;
+    // ---- persistent accumulators of this wave ----
+    f32x4 aw2[NC1][NC2], aw1[2][NC1], aw3[NC2][1];
+#pragma unroll
+    for (int i = 0; i < NC1; ++i)
+#pragma unroll
+        for (int j = 0; j < NC2; ++j) aw2[i][j] = zero4();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NC1; ++j) aw1[i][j] = zero4();
+#pragma unroll
+    for (int j = 0; j < NC2; ++j) aw3[j][0] = zero4();
+    float gb1[NC1], gb2[NC2];
+#pragma unroll
+    for (int j = 0; j < NC1; ++j) gb1[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC2; ++j) gb2[j] = 0.f;
+    float loss = 0.f, klsum = 0.f, gs0 = 0.f, gs1 = 0.f, gb30 = 0.f, gb31 = 0.f;
 
-    constexpr int NRB3 = H2 / 16;
-    constexpr int P3 = (NRB3 >= 4) ? 1 : 4 / NRB3;
-    constexpr int KS3 = PROMP_TILE / P3;
-    constexpr int P1 = 4 / NB1;
-    constexpr int KS1 = PROMP_TILE / P1;
-    const int rbk3 = w % NRB3, part3 = (w / NRB3) % P3;
-    const int cb1 = w % NB1, part1 = w / NB1;
-    // epilogue role: 4 threads per row, actions {q, q+4}
-    const int erow = tid >> 2, q = tid & 3;
+    // epilogue role: 4 lanes per row, actions {q, q+4}
+    const int erow = lane >> 2, q = lane & 3;
     const bool own0 = q < A, own1 = (q + 4) < A;
-    const int XE = PROMP_TILE * O;
-
-    // prefetch the first tile's observations
+    // where this lane's share of a [16][O] tile lands in the padded LDS tile
+    int xoff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = lane + 64 * u;
+        xoff[u] = (e < PROMP_WROWS * O) ? (e / O) * XS + (e % O) : -1;
+    }
+    const int first = wk.row_begin + PROMP_WROWS * w;
     float xr[8];
     {
-        const int nrows = (wk.row_end - wk.row_begin) < PROMP_TILE ? (wk.row_end - wk.row_begin) : PROMP_TILE;
+        const int nr = (wk.row_end - first) < PROMP_WROWS ? (wk.row_end - first) : PROMP_WROWS;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int e = tid + 256 * u;
-            xr[u] = (e < nrows * O) ? a.obs[(long long)wk.row_begin * O + e] : 0.f;
+            const int e = lane + 64 * u;
+            xr[u] = (first < wk.row_end && e < nr * O) ? a.obs[(long long)first * O + e] : 0.f;
         }
     }
-    __syncthreads();
 
-    for (int base = wk.row_begin; base < wk.row_end; base += PROMP_TILE) {
-        const int nrows = (wk.row_end - base) < PROMP_TILE ? (wk.row_end - base) : PROMP_TILE;
-        // ---- tile rows -> LDS; request the next tile and this tile's per-row epilogue inputs
+    int tix = 0;
+    for (int base = first; base < wk.row_end; base += 4 * PROMP_WROWS, ++tix) {
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 0);
+        const int nrows = (wk.row_end - base) < PROMP_WROWS ? (wk.row_end - base) : PROMP_WROWS;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + 256 * u;
-            if (e < XE) Xs[e] = xr[u];
-        }
+        for (int u = 0; u < 8; ++u)
+            if (xoff[u] >= 0) Xw[xoff[u]] = xr[u];
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 9);
         {
-            const int nb = base + PROMP_TILE;
-            const int nn = (wk.row_end - nb) < PROMP_TILE ? (wk.row_end - nb) : PROMP_TILE;
+            const int nb = base + 4 * PROMP_WROWS;
+            const int nn = (wk.row_end - nb) < PROMP_WROWS ? (wk.row_end - nb) : PROMP_WROWS;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = tid + 256 * u;
+                const int e = lane + 64 * u;
                 xr[u] = (nb < wk.row_end && e < nn * O) ? a.obs[(long long)nb * O + e] : 0.f;
             }
         }
@@ -286,45 +322,58 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
         const float ac0 = (rvalid && own0) ? a.act[n * A + q] : 0.f, ac1 = (rvalid && own1) ? a.act[n * A + q + 4] : 0.f;
         const float mo0 = (rvalid && own0) ? a.old_mean[n * A + q] : 0.f, mo1 = (rvalid && own1) ? a.old_mean[n * A + q + 4] : 0.f;
         const float so0 = (rvalid && own0) ? olsp[q] : 0.f, so1 = (rvalid && own1) ? olsp[q + 4] : 0.f;
-        __syncthreads();
-        // ---- layer 1
-        if (w < 2 * NB1) {
-            const int rb = w / NB1, cb = w % NB1;
-            f32x16 acc = zero16();
-            gemm32(acc, Opnd{Xs + (rb * 32 + li) * O + lh, 1}, Opnd{W1s + lh * H1 + cb * 32 + li, H1}, Opad, 1.f);
-            const int col = cb * 32 + li;
-            const float bb = b1s[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) H1s[(rb * 32 + row32(r, lh)) * HS + col] = fast_tanh(acc[r] + bb);
-        }
-        __syncthreads();
-        // ---- layer 2
-        if (w < 2 * NB2) {
-            const int rb = w / NB2, cb = w % NB2;
-            f32x16 acc = zero16();
-            gemm32(acc, Opnd{H1s + (rb * 32 + li) * HS + lh, 1}, Opnd{W2s + lh * (H2 + 1) + cb * 32 + li, H2 + 1}, H1,
-                   1.f);
-            const int col = cb * 32 + li;
-            const float bb = b2s[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) H2s[(rb * 32 + row32(r, lh)) * HS + col] = fast_tanh(acc[r] + bb);
-        }
-        __syncthreads();
-        // ---- output layer (16 rows per wave, 16 padded columns)
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 10);
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 1);
+        // ---- layer 1: H1 = tanh(X W1 + b1)
         {
-            f32x4 acc = zero4();
-            gemm16(acc, Opnd{H2s + (16 * w + i16) * HS + kk, 1}, Opnd{W3s + kk * 16 + i16, 16}, H2, 1.f);
+            f32x4 acc[1][NC1];
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) acc[0][j] = zero4();
+            outer16<1, NC1>(acc, Xw + i16 * XS + kk, 1, 0, W1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
+            PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 11);
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) {
+                const float bb = b1s[16 * j + i16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) H1w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r] + bb);
+            }
+        }
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 2);
+        // ---- layer 2
+        {
+            f32x4 acc[1][NC2];
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) acc[0][j] = zero4();
+            outer16<1, NC2>(acc, H1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
+            PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 12);
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) {
+                const float bb = b2s[16 * j + i16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) H2w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r] + bb);
+            }
+        }
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 3);
+        // ---- output layer (16 padded columns)
+        {
+            f32x4 acc[1][1];
+            acc[0][0] = zero4();
+            outer16<1, 1>(acc, H2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
             const float bb = b3s[i16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ms[(16 * w + 4 * kk + r) * MS + i16] = acc[r] + bb;
+            for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r] + bb;
         }
-        __syncthreads();
-        // ---- distribution + objective epilogue: 4 threads per row, each owns actions {q, q+4}
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 4);
+        // ---- distribution + objective epilogue
         {
             float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
             float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f;
             if (own0) {
-                const float s = lss[q], mu = Ms[erow * MS + q];
+                const float s = lss[q], mu = Msw[erow * MS + q];
                 e0 = ess[q];
                 z0 = (ac0 - mu) * e0;
                 const float zo = (ac0 - mo0) * fast_exp(-so0);
@@ -335,7 +384,7 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
                 kl += ((mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2) / (2.f * sn2 + 1e-8f) + s - so0;
             }
             if (own1) {
-                const float s = lss[q + 4], mu = Ms[erow * MS + q + 4];
+                const float s = lss[q + 4], mu = Msw[erow * MS + q + 4];
                 e1 = ess[q + 4];
                 z1 = (ac1 - mu) * e1;
                 const float zo = (ac1 - mo1) * fast_exp(-so1);
@@ -345,14 +394,14 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
                 const float sn2 = sn2s[q + 4];
                 kl += ((mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2) / (2.f * sn2 + 1e-8f) + s - so1;
             }
-            // reduce over the 4 threads of the row (adjacent lanes)
             dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
             sumz2 += shfl_xor_f32(sumz2, 1);  sumz2 += shfl_xor_f32(sumz2, 2);
             sums += shfl_xor_f32(sums, 1);  sums += shfl_xor_f32(sums, 2);
             kl += shfl_xor_f32(kl, 1);  kl += shfl_xor_f32(kl, 2);
-            float c = 0.f, lrow = 0.f;
+            float c = 0.f;
             if (rvalid) {
                 const float rho = expf(dlp);
+                float lrow;
                 if (a.loss_kind == LOSS_RATIO) {
                     lrow = -rho * advn * invN;
                     c = -advn * rho * invN;
@@ -373,138 +422,160 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
             }
             if (own0) {
                 const float d = c * z0 * e0;
-                Ms[erow * MS + q] = d;
+                Msw[erow * MS + q] = d;
                 gs0 += c * (z0 * z0 - 1.f);
                 gb30 += d;
             }
             if (own1) {
                 const float d = c * z1 * e1;
-                Ms[erow * MS + q + 4] = d;
+                Msw[erow * MS + q + 4] = d;
                 gs1 += c * (z1 * z1 - 1.f);
                 gb31 += d;
             }
-            // columns >= A of Ms already hold exact zeros (zero-padded W3s / b3s)
+            // columns >= A of Msw already hold exact zeros (zero-padded W3s / b3s)
         }
-        __syncthreads();
-        // ---- output-kernel gradient (+=) and dH2 = dmu W3^T (kept in registers until H2 is free)
-        gemm16(acc_w3, Opnd{H2s + (part3 * KS3 + kk) * HS + 16 * rbk3 + i16, HS},
-               Opnd{Ms + (part3 * KS3 + kk) * MS + i16, MS}, KS3, 1.f);
-        f32x16 accd = zero16();
-        if (w < 2 * NB2) {
-            const int rb = w / NB2, cb = w % NB2;
-            gemm32(accd, Opnd{Ms + (rb * 32 + li) * MS + lh, 1}, Opnd{W3Ts + lh * H2 + cb * 32 + li, H2}, 8, 1.f);
-        }
-        __syncthreads();
-        if (w < 2 * NB2) {   // dZ2 = dH2 * (1 - H2^2), in place over H2 ; its column sums are d/d(b2)
-            const int rb = w / NB2, cb = w % NB2, col = cb * 32 + li;
-            float cs = 0.f;
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 5);
+        // ---- output-kernel gradient (+=); dZ2 = (dmu W3^T) * (1 - H2^2) in place over H2
+        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, HS, 16, Msw + kk * MS + i16, MS, 0, PROMP_WROWS, 1.f);
+        {
+            f32x4 acc[1][NC2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = (rb * 32 + row32(r, lh)) * HS + col;
-                const float h = H2s[idx];
-                const float d = accd[r] * (1.f - h * h);
-                H2s[idx] = d;
-                cs += d;
-            }
-            gb2 += cs + shfl_xor_f32(cs, 32);
-        }
-        __syncthreads();
-        // ---- hidden_1 kernel gradient (+=) and dH1 = dZ2 W2^T
-        if (w < NB1 * NB2) {
-            const int kb = w / NB2, jb = w % NB2;
-            gemm32(acc_w2, Opnd{H1s + lh * HS + kb * 32 + li, HS}, Opnd{H2s + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
-                   1.f);
-        }
-        accd = zero16();
-        if (w < 2 * NB1) {
-            const int rb = w / NB1, cb = w % NB1;
-            gemm32(accd, Opnd{H2s + (rb * 32 + li) * HS + lh, 1}, Opnd{W2s + (cb * 32 + li) * (H2 + 1) + lh, 1}, H2, 1.f);
-        }
-        __syncthreads();
-        if (w < 2 * NB1) {   // dZ1 in place over H1
-            const int rb = w / NB1, cb = w % NB1, col = cb * 32 + li;
-            float cs = 0.f;
+            for (int j = 0; j < NC2; ++j) acc[0][j] = zero4();
+            outer16<1, NC2>(acc, Msw + i16 * MS + kk, 1, 0, W3Ts + kk * H2 + i16, H2, 16, 8, 1.f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = (rb * 32 + row32(r, lh)) * HS + col;
-                const float h = H1s[idx];
-                const float d = accd[r] * (1.f - h * h);
-                H1s[idx] = d;
-                cs += d;
+            for (int j = 0; j < NC2; ++j) {
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
+                    const float h = H2w[idx];
+                    const float d = acc[0][j][r] * (1.f - h * h);
+                    H2w[idx] = d;
+                    cs += d;
+                }
+                gb2[j] += cs;
             }
-            gb1 += cs + shfl_xor_f32(cs, 32);
         }
-        __syncthreads();
-        // ---- hidden_0 kernel gradient (+=)
-        gemm32(acc_w1, Opnd{Xs + (part1 * KS1 + lh) * O + li, O}, Opnd{H1s + (part1 * KS1 + lh) * HS + cb1 * 32 + li, HS},
-               KS1, 1.f);
-        __syncthreads();
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 6);
+        // ---- hidden_1 kernel gradient (+=); dZ1 = (dZ2 W2^T) * (1 - H1^2) in place over H1
+        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, HS, 16, H2w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        {
+            f32x4 acc[1][NC1];
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) acc[0][j] = zero4();
+            outer16<1, NC1>(acc, H2w + i16 * HS + kk, 1, 0, W2s + i16 * WS + kk, 1, 16 * WS, H2, 1.f);
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) {
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
+                    const float h = H1w[idx];
+                    const float d = acc[0][j][r] * (1.f - h * h);
+                    H1w[idx] = d;
+                    cs += d;
+                }
+                gb1[j] += cs;
+            }
+        }
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 7);
+        // ---- hidden_0 kernel gradient (+=): rows = observation index (two 16-blocks cover O <= 32)
+        outer16<2, NC1>(aw1, Xw + kk * XS + i16, XS, 16, H1w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        wave_sync();
+        PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 8);
     }
+    PROMP_STAMP(2);
 
-    // ---- one partial per workgroup, in the flat parameter order
-    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
-    if (w < NB1 * NB2) {
-        const int kb = w / NB2, jb = w % NB2;
+    const float lmask_reg0 = lmask[lane & 3], lmask_reg1 = lmask[(lane & 3) + 4];
+    // ---- add the four waves' results in wave order, then one coalesced partial ----
+    // bias sums: lanes with equal i16 hold different row groups -> fold kk
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[oW2 + (kb * 32 + row32(r, lh)) * H2 + jb * 32 + li] = acc_w2[r];
+    for (int j = 0; j < NC1; ++j) {
+        gb1[j] += shfl_xor_f32(gb1[j], 16);
+        gb1[j] += shfl_xor_f32(gb1[j], 32);
     }
-    // scratch (tile buffers are dead): S1 [P1][NB1][32][32] over H1s..H2s (contiguous), S3 [P3][H2][16] over Ms
-    float* S1 = H1s;
-    float* S3 = Ms;
-    float* SB = sm + L.red;                  // [2][H1] + [2][H2] bias partials of the two row blocks
-    float* SE = SB + 2 * H1 + 2 * H2;        // [4 waves][4 q][6] epilogue partials
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S1[((part1 * NB1 + cb1) * 32 + row32(r, lh)) * 32 + li] = acc_w1[r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) S3[(part3 * H2 + 16 * rbk3 + 4 * kk + r) * 16 + i16] = acc_w3[r];
-    if (w < 2 * NB1 && lh == 0) SB[(w / NB1) * H1 + (w % NB1) * 32 + li] = gb1;
-    if (w < 2 * NB2 && lh == 0) SB[2 * H1 + (w / NB2) * H2 + (w % NB2) * 32 + li] = gb2;
+    for (int j = 0; j < NC2; ++j) {
+        gb2[j] += shfl_xor_f32(gb2[j], 16);
+        gb2[j] += shfl_xor_f32(gb2[j], 32);
+    }
     {   // per-action sums over the rows of this wave: lanes with equal q differ in bits 2..5
-        float v0 = gs0, v1 = gs1, v2 = gb30, v3 = gb31, v4 = loss, v5 = klsum;
 #pragma unroll
         for (int m = 4; m <= 32; m <<= 1) {
-            v0 += shfl_xor_f32(v0, m);  v1 += shfl_xor_f32(v1, m);  v2 += shfl_xor_f32(v2, m);
-            v3 += shfl_xor_f32(v3, m);  v4 += shfl_xor_f32(v4, m);  v5 += shfl_xor_f32(v5, m);
+            gs0 += shfl_xor_f32(gs0, m);  gs1 += shfl_xor_f32(gs1, m);  gb30 += shfl_xor_f32(gb30, m);
+            gb31 += shfl_xor_f32(gb31, m);  loss += shfl_xor_f32(loss, m);  klsum += shfl_xor_f32(klsum, m);
+        }
+    }
+    // Each wave stores its tiles to its own LDS slab (plain stores, no read-modify-write), then all 256 threads
+    // add the four slabs in wave order and write the partial: two rounds because 4 x [NP] does not fit in LDS.
+    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    float* S = sm;                                   // whole LDS allocation is free now
+    const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
+    const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
+    __syncthreads();
+    {
+        float* mine = S + w * NW2;
+#pragma unroll
+        for (int i = 0; i < NC1; ++i)
+#pragma unroll
+            for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < NW2; e += 256) P[oW2 + e] = ((S[e] + S[NW2 + e]) + S[2 * NW2 + e]) + S[3 * NW2 + e];
+    __syncthreads();
+    {
+        // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
+        float* mine = S + w * NR2;
+        for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * kk + r;
+                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
+                }
+#pragma unroll
+        for (int j = 0; j < NC2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
+        if (kk == 0) {
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = gb2[j];
         }
         if (lane < 4) {   // lane == q
-            float* se = SE + w * 24 + lane * 6;
-            se[0] = v0; se[1] = v1; se[2] = v2; se[3] = v3; se[4] = v4; se[5] = v5;
+            if (lane < A) {
+                mine[ob3 - NW2 + lane] = gb30;
+                mine[oS - NW2 + lane] = gs0 * lmask_reg0;
+            }
+            if (lane + 4 < A) {
+                mine[ob3 - NW2 + lane + 4] = gb31;
+                mine[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
+            }
+        }
+        if (lane == 0) {
+            mine[NP - NW2] = loss;
+            mine[NP + 1 - NW2] = klsum;
         }
     }
     __syncthreads();
-    for (int e = tid; e < O * H1; e += 256) {
-        const int row = e / H1, col = e - row * H1;
-        float s = 0.f;
-        for (int p = 0; p < P1; ++p) s += S1[((p * NB1 + (col >> 5)) * 32 + row) * 32 + (col & 31)];
-        P[e] = s;
+    for (int e = tid; e < NR2; e += 256) {
+        const float v = ((S[e] + S[NR2 + e]) + S[2 * NR2 + e]) + S[3 * NR2 + e];
+        P[e < oW2 ? e : e + NW2] = v;
     }
-    for (int e = tid; e < H2 * A; e += 256) {
-        const int hid = e / A, aa = e - hid * A;
-        float s = 0.f;
-        for (int p = 0; p < P3; ++p) s += S3[(p * H2 + hid) * 16 + aa];
-        P[oW3 + e] = s;
-    }
-    if (tid < H1) P[ob1 + tid] = SB[tid] + SB[H1 + tid];
-    if (tid < H2) P[ob2 + tid] = SB[2 * H1 + tid] + SB[2 * H1 + H2 + tid];
-    if (tid < 8 && tid < A) {
-        const int qq = tid & 3, hi = tid >> 2;   // action tid = qq + 4*hi
-        float g = 0.f, b = 0.f;
-        for (int ww = 0; ww < 4; ++ww) {
-            g += SE[ww * 24 + qq * 6 + hi];
-            b += SE[ww * 24 + qq * 6 + 2 + hi];
-        }
-        P[ob3 + tid] = b;
-        P[oS + tid] = g * lmask[tid];
-    }
-    if (tid == 0) {
-        float l = 0.f, k = 0.f;
-        for (int ww = 0; ww < 4; ++ww) {
-            l += SE[ww * 24 + 4];
-            k += SE[ww * 24 + 5];
-        }
-        P[NP] = l;
-        P[NP + 1] = k;
-    }
+    PROMP_STAMP(4);
+    if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 128; ++i) a.dbg[i] = dbgs[i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -163,6 +163,9 @@ inline float shfl_xor_f32(float v, int m) { return (float)emu_shfl_f64((double)v
 inline double shfl_xor_f64(double v, int m) { return emu_shfl_f64(v, emu::lane() ^ m); }
 inline double shfl_down_f64(double v, int d) { return emu_shfl_f64(v, emu::lane() + d); }
 inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
+inline void wave_sync() { emu::wave().bar.arrive_and_wait(); }
+inline unsigned long long promp_clock() { return 0; }
+inline unsigned long long promp_wall_clock() { return 0; }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 
