@@ -322,7 +322,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     const int Opad = (dims->obs_dim + 1) & ~1;
     c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
     if (const char* e = getenv("PROMP_DEV_FWD_LDS_PAD")) c->smem_fwd += (size_t)atoi(e);   // developer experiment: force 1 WG/CU
-    c->smem_hvp = sizeof(float) * (size_t)make_layout(Opad, dims->hidden1, dims->hidden2, 1).total;
+    c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;
         promp_ctx_destroy(c);

@@ -581,308 +581,464 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
 // ---------------------------------------------------------------------------------------------
 // k_hvp:  out = -(d^2 L/d theta^2) v + kl_weight * grad KL   (R-operator, see oracle/promp.py:hvp)
 // "q" quantities are (-R{.} + kl_weight * dKL{.}) of the reverse pass.
-// theta in LDS; the direction v is read from global memory (L1/L2 resident, 23.6 KB per task).
+//
+// Same wave-private structure as k_fwd_bwd (16-row tiles, 16x16x4 MFMA, no workgroup barrier in the tile loop);
+// theta AND the direction v are staged in LDS (2 x 28.8 KB) so that no MFMA operand comes from global memory;
+// each wave owns X, H1, RH1, H2, RH2 and two mean tiles (20.4 KB): 140 KB per workgroup, one workgroup per CU.
+// dZ2 / qZ2 overwrite H2 / RH2 and qZ1 overwrites H1 in place.
 // ---------------------------------------------------------------------------------------------
+struct LdsHvp {
+    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2, vls;
+    int vw1, vb1, vw2, vb2, vw3, vw3t, vb3;
+    int wave0, wave_stride, x, h1, rh1, h2, rh2, ms, ms2;
+    int total, HS, WS, Opad4, dbg;
+};
+
+PROMP_HD LdsHvp make_layout_hvp(int O, int H1, int H2, int nwaves, int NP) {
+    LdsHvp L;
+    int o = 0;
+#define PROMP_TAKE(field, n) \
+    L.field = o;             \
+    o += ((n) + 3) & ~3
+    L.Opad4 = (O + 3) & ~3;
+    L.WS = H2 + 1;
+    PROMP_TAKE(w1, L.Opad4 * H1);
+    PROMP_TAKE(b1, H1);
+    PROMP_TAKE(w2, H1 * L.WS);
+    PROMP_TAKE(b2, H2);
+    PROMP_TAKE(w3, H2 * 16);
+    PROMP_TAKE(w3t, 8 * H2);
+    PROMP_TAKE(b3, 16);
+    PROMP_TAKE(ls, 16);
+    PROMP_TAKE(lmask, 16);
+    PROMP_TAKE(es, 16);
+    PROMP_TAKE(sn2, 16);
+    PROMP_TAKE(vls, 16);
+    PROMP_TAKE(vw1, L.Opad4 * H1);
+    PROMP_TAKE(vb1, H1);
+    PROMP_TAKE(vw2, H1 * L.WS);
+    PROMP_TAKE(vb2, H2);
+    PROMP_TAKE(vw3, H2 * 16);
+    PROMP_TAKE(vw3t, 8 * H2);
+    PROMP_TAKE(vb3, 16);
+    L.HS = (H1 > H2 ? H1 : H2) + 1;
+    L.wave0 = o;
+    int q = 0;
+    L.x = q;   q += (PROMP_WROWS * PROMP_XS + 3) & ~3;
+    L.h1 = q;  q += (PROMP_WROWS * L.HS + 3) & ~3;
+    L.rh1 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
+    L.h2 = q;  q += (PROMP_WROWS * L.HS + 3) & ~3;
+    L.rh2 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
+    L.ms = q;  q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
+    L.ms2 = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
+    L.wave_stride = q;
+    o += nwaves * q;
+    if (o < 4 * H1 * H2) o = 4 * H1 * H2;   // the end-of-kernel slabs [4][H1*H2] start at 0
+    L.dbg = o;
+    o += 256;
+#undef PROMP_TAKE
+    L.total = o;
+    return L;
+}
+
+// one task's network weights -> LDS (kernel layouts of make_layout_*); src is a flat [Theta] vector
+template <int H1, int H2>
+PROMP_DEV void stage_net(float* W1s, float* b1s, float* W2s, float* b2s, float* W3s, float* W3Ts, float* b3s,
+                         const float* src, int O, int A, int Opad4, int WS, int tid) {
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
+#pragma unroll 4
+    for (int e = tid; e < Opad4 * H1; e += 256) W1s[e] = (e < O * H1) ? src[e] : 0.f;
+#pragma unroll 4
+    for (int e = tid; e < H1 * H2; e += 256) {
+        const int k = e / H2, j = e - k * H2;
+        W2s[k * WS + j] = src[oW2 + e];
+    }
+#pragma unroll 4
+    for (int e = tid; e < H2 * 16; e += 256) {
+        const int k = e >> 4, j = e & 15;
+        W3s[e] = (j < A) ? src[oW3 + k * A + j] : 0.f;
+    }
+    for (int e = tid; e < 8 * H2; e += 256) {
+        const int aa = e / H2, k = e - aa * H2;
+        W3Ts[e] = (aa < A) ? src[oW3 + k * A + aa] : 0.f;
+    }
+    if (tid < H1) b1s[tid] = src[ob1 + tid];
+    if (tid < H2) b2s[tid] = src[ob2 + tid];
+    if (tid < 16) b3s[tid] = (tid < A) ? src[ob3 + tid] : 0.f;
+}
+
 template <int NB1, int NB2>
-__global__ void __launch_bounds__(256) k_hvp(PassArgs a) {
-    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, MS = PROMP_MS;
+__global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, XS = PROMP_XS;
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5, i16 = lane & 15, kk = lane >> 4;
+    const int i16 = lane & 15, kk = lane >> 4;
     const WorkItem wk = a.work[blockIdx.x];
     const int task = wk.task;
-    const int O = a.O, A = a.A, Opad = (O + 1) & ~1;
-    const LdsLayout L = make_layout(Opad, H1, H2, 1);
-    const int XS = L.XS, HS = L.HS;
+    const int O = a.O, A = a.A;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
+              NP = oS + A;
+    const LdsHvp L = make_layout_hvp(O, H1, H2, 4, NP);
+    const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4;
     float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
-          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *vls = sm + L.vls,
-          *zero = sm + L.zero;
-    float *Xs = sm + L.xs, *H1s = sm + L.h1, *H2s = sm + L.h2, *Ds = sm + L.ds, *Ms = sm + L.ms;
-    float *RH1s = sm + L.rh1, *RH2s = sm + L.rh2, *Qs = sm + L.qs, *Ms2 = sm + L.ms2;
+          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
+          *sn2s = sm + L.sn2, *vls = sm + L.vls;
+    float *vW1s = sm + L.vw1, *vb1s = sm + L.vb1, *vW2s = sm + L.vw2, *vb2s = sm + L.vb2, *vW3s = sm + L.vw3,
+          *vW3Ts = sm + L.vw3t, *vb3s = sm + L.vb3;
+    unsigned long long* dbgs = (unsigned long long*)(sm + L.dbg);
+    if (a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
+    float* wreg = sm + L.wave0 + w * L.wave_stride;
+    float *Xw = wreg + L.x, *H1w = wreg + L.h1, *RH1w = wreg + L.rh1, *H2w = wreg + L.h2, *RH2w = wreg + L.rh2,
+          *Msw = wreg + L.ms, *Ms2w = wreg + L.ms2;
     const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
     const float invN = 1.0f / (float)ntask;
     const float* th = a.theta + (long long)task * a.theta_task_stride;
-    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
-              NP = oS + A;
     const float* v = a.vdir + (long long)task * NP;
-    const float* vW2T = a.vw2t + (long long)task * (H1 * H2);
+    PROMP_STAMP(0);
 
-    stage_params<H1, H2>(sm, L, th, O, A, Opad, tid, a.clip_log_std, a.min_log_std);
+    stage_net<H1, H2>(W1s, b1s, W2s, b2s, W3s, W3Ts, b3s, th, O, A, Opad4, WS, tid);
+    stage_net<H1, H2>(vW1s, vb1s, vW2s, vb2s, vW3s, vW3Ts, vb3s, v, O, A, Opad4, WS, tid);
+    if (tid < 16) {
+        const float sr = (tid < A) ? th[oS + tid] : 0.f;
+        const bool clipped = a.clip_log_std && (sr < a.min_log_std);
+        const float s = clipped ? a.min_log_std : sr;
+        lss[tid] = s;
+        lmask[tid] = clipped ? 0.f : 1.f;
+        ess[tid] = expf(-s);
+        sn2s[tid] = expf(2.f * s);
+        vls[tid] = (tid < A && !clipped) ? v[oS + tid] : 0.f;   // R{s} = mask * v_s
+    }
+    for (int e = lane; e < PROMP_WROWS * XS; e += 64) Xw[e] = 0.f;
     __syncthreads();
-    if (tid < 16) vls[tid] = (tid < A) ? v[oS + tid] * lmask[tid] : 0.f;  // R{s} = mask * v_s
-    __syncthreads();
+    PROMP_STAMP(1);
 
-    f32x16 acc_w2 = zero16(), acc_w1 = zero16();
-    f32x4 acc_w3 = zero4();
-    float klsum = 0.f, ob1acc = 0.f, ob2acc = 0.f;
-    float outs[8], outb3[8];
+    f32x4 aw2[NC1][NC2], aw1[2][NC1], aw3[NC2][1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) outs[i] = outb3[i] = 0.f;
-
-    constexpr int NRB3 = H2 / 16;
-    constexpr int P3 = (NRB3 >= 4) ? 1 : 4 / NRB3;
-    constexpr int KS3 = PROMP_TILE / P3;
-    constexpr int P1 = 4 / NB1;
-    constexpr int KS1 = PROMP_TILE / P1;
-    const int rbk3 = w % NRB3, part3 = (w / NRB3) % P3;
-    const int cb1 = w % NB1, part1 = w / NB1;
+    for (int i = 0; i < NC1; ++i)
+#pragma unroll
+        for (int j = 0; j < NC2; ++j) aw2[i][j] = zero4();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NC1; ++j) aw1[i][j] = zero4();
+#pragma unroll
+    for (int j = 0; j < NC2; ++j) aw3[j][0] = zero4();
+    float ob1acc[NC1], ob2acc[NC2];
+#pragma unroll
+    for (int j = 0; j < NC1; ++j) ob1acc[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC2; ++j) ob2acc[j] = 0.f;
+    float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
     const float klw = a.kl_weight;
 
-    for (int base = wk.row_begin; base < wk.row_end; base += PROMP_TILE) {
-        const int nrows = (wk.row_end - base) < PROMP_TILE ? (wk.row_end - base) : PROMP_TILE;
-        load_obs_tile(Xs, XS, a.obs, base, nrows, O, tid);
-        __syncthreads();
+    const int erow = lane >> 2, q = lane & 3;
+    const bool own0 = q < A, own1 = (q + 4) < A;
+    int xoff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = lane + 64 * u;
+        xoff[u] = (e < PROMP_WROWS * O) ? (e / O) * XS + (e % O) : -1;
+    }
+    const int first = wk.row_begin + PROMP_WROWS * w;
+    float xr[8];
+    {
+        const int nr = (wk.row_end - first) < PROMP_WROWS ? (wk.row_end - first) : PROMP_WROWS;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = lane + 64 * u;
+            xr[u] = (first < wk.row_end && e < nr * O) ? a.obs[(long long)first * O + e] : 0.f;
+        }
+    }
+
+    for (int base = first; base < wk.row_end; base += 4 * PROMP_WROWS) {
+        const int nrows = (wk.row_end - base) < PROMP_WROWS ? (wk.row_end - base) : PROMP_WROWS;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (xoff[u] >= 0) Xw[xoff[u]] = xr[u];
+        {
+            const int nb = base + 4 * PROMP_WROWS;
+            const int nn = (wk.row_end - nb) < PROMP_WROWS ? (wk.row_end - nb) : PROMP_WROWS;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = lane + 64 * u;
+                xr[u] = (nb < wk.row_end && e < nn * O) ? a.obs[(long long)nb * O + e] : 0.f;
+            }
+        }
+        const bool rvalid = erow < nrows;
+        const long long n = (long long)base + (rvalid ? erow : 0);
+        const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+        const float advn = rvalid ? a.adv[n] : 0.f;
+        const float ac0 = (rvalid && own0) ? a.act[n * A + q] : 0.f, ac1 = (rvalid && own1) ? a.act[n * A + q + 4] : 0.f;
+        const float mo0 = (rvalid && own0) ? a.old_mean[n * A + q] : 0.f, mo1 = (rvalid && own1) ? a.old_mean[n * A + q + 4] : 0.f;
+        const float so0 = (rvalid && own0) ? olsp[q] : 0.f, so1 = (rvalid && own1) ? olsp[q + 4] : 0.f;
+        wave_sync();
         // ---- layer 1 and its tangent:  Rz1 = X vW1 + vb1
-        if (w < 2 * NB1) {
-            const int rb = w / NB1, cb = w % NB1;
-            f32x16 az = zero16(), ar = zero16();
-            const Opnd xa{Xs + (rb * 32 + li) * XS + lh, 1};
-            gemm32(az, xa, Opnd{W1s + lh * H1 + cb * 32 + li, H1}, Opad, 1.f);
-            // rows k >= O of v's first kernel do not exist: X's pad column is zero, clamp the row index
-            {
-#pragma unroll 4
-                for (int k = 0; k < Opad; k += 2) {
-                    const int kr = (k + lh < O) ? (k + lh) : (O - 1);
-                    ar = mfma32(xa.p[k], v[kr * H1 + cb * 32 + li], ar);
+        {
+            f32x4 az[1][NC1], ar[1][NC1];
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) az[0][j] = ar[0][j] = zero4();
+            outer16<1, NC1>(az, Xw + i16 * XS + kk, 1, 0, W1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
+            outer16<1, NC1>(ar, Xw + i16 * XS + kk, 1, 0, vW1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) {
+                const float bb = b1s[16 * j + i16], vb = vb1s[16 * j + i16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
+                    const float h = fast_tanh(az[0][j][r] + bb);
+                    H1w[idx] = h;
+                    RH1w[idx] = (1.f - h * h) * (ar[0][j][r] + vb);
                 }
             }
-            const int col = cb * 32 + li;
-            const float bb = b1s[col], vb = v[ob1 + col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + row32(r, lh);
-                const float h = fast_tanh(az[r] + bb);
-                H1s[row * HS + col] = h;
-                RH1s[row * HS + col] = (1.f - h * h) * (ar[r] + vb);
-            }
         }
-        __syncthreads();
+        wave_sync();
         // ---- layer 2 and its tangent:  Rz2 = H1 vW2 + RH1 W2 + vb2
-        if (w < 2 * NB2) {
-            const int rb = w / NB2, cb = w % NB2;
-            f32x16 az = zero16(), ar = zero16();
-            const Opnd ha{H1s + (rb * 32 + li) * HS + lh, 1};
-            const Opnd wb{W2s + lh * (H2 + 1) + cb * 32 + li, H2 + 1};
-            gemm32(az, ha, wb, H1, 1.f);
-            gemm32(ar, ha, Opnd{v + oW2 + lh * H2 + cb * 32 + li, H2}, H1, 1.f);
-            gemm32(ar, Opnd{RH1s + (rb * 32 + li) * HS + lh, 1}, wb, H1, 1.f);
-            const int col = cb * 32 + li;
-            const float bb = b2s[col], vb = v[ob2 + col];
+        {
+            f32x4 az[1][NC2], ar[1][NC2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + row32(r, lh);
-                const float h = fast_tanh(az[r] + bb);
-                H2s[row * HS + col] = h;
-                RH2s[row * HS + col] = (1.f - h * h) * (ar[r] + vb);
+            for (int j = 0; j < NC2; ++j) az[0][j] = ar[0][j] = zero4();
+            outer16<1, NC2>(az, H1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
+            outer16<1, NC2>(ar, H1w + i16 * HS + kk, 1, 0, vW2s + kk * WS + i16, WS, 16, H1, 1.f);
+            outer16<1, NC2>(ar, RH1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) {
+                const float bb = b2s[16 * j + i16], vb = vb2s[16 * j + i16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
+                    const float h = fast_tanh(az[0][j][r] + bb);
+                    H2w[idx] = h;
+                    RH2w[idx] = (1.f - h * h) * (ar[0][j][r] + vb);
+                }
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- output layer and its tangent:  Rmu = H2 vW3 + RH2 W3 + vb3
         {
-            f32x4 am = zero4(), ar = zero4();
-            const Opnd ha{H2s + (16 * w + i16) * HS + kk, 1};
-            const Opnd wb{W3s + kk * 16 + i16, 16};
-            gemm16(am, ha, wb, H2, 1.f);
-            gemm16(ar, Opnd{RH2s + (16 * w + i16) * HS + kk, 1}, wb, H2, 1.f);
-            {   // + H2 vW3 ; columns >= A do not exist (MFMA must stay wave-uniform: mask the value)
-                const int jc = (i16 < A) ? i16 : 0;
-                const float jm = (i16 < A) ? 1.f : 0.f;
-#pragma unroll 4
-                for (int k = 0; k < H2; k += 4) ar = mfma16(ha.p[k], jm * v[oW3 + (k + kk) * A + jc], ar);
-            }
-            const float bb = b3s[i16], vb = (i16 < A) ? v[ob3 + i16] : 0.f;
+            f32x4 am[1][1], ar[1][1];
+            am[0][0] = ar[0][0] = zero4();
+            outer16<1, 1>(am, H2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
+            outer16<1, 1>(ar, H2w + i16 * HS + kk, 1, 0, vW3s + kk * 16 + i16, 16, 0, H2, 1.f);
+            outer16<1, 1>(ar, RH2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
+            const float bb = b3s[i16], vb = vb3s[i16];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                Ms[(16 * w + 4 * kk + r) * MS + i16] = am[r] + bb;
-                Ms2[(16 * w + 4 * kk + r) * MS + i16] = ar[r] + vb;
+                Msw[(4 * kk + r) * MS + i16] = am[0][0][r] + bb;
+                Ms2w[(4 * kk + r) * MS + i16] = ar[0][0][r] + vb;
             }
         }
-        __syncthreads();
-        // ---- loss-level R-operator, one thread per row
-        if (tid < PROMP_TILE) {
-            float dmu[8], qmu[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dmu[i] = qmu[i] = 0.f;
-            if (tid < nrows) {
-                const long long n = (long long)base + tid;
-                const float advn = a.adv[n];
-                const float* ols = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
-                float dlp = 0.f, Rlp = 0.f, kl = 0.f;
-                float z[8], e[8], Rmu[8], dklm[8], dkls[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    z[i] = e[i] = Rmu[i] = dklm[i] = dkls[i] = 0.f;
-                    if (i < A) {
-                        const float s = lss[i], so = ols[i];
-                        const float mu = Ms[tid * MS + i], mo = a.old_mean[n * A + i], ac = a.act[n * A + i];
-                        Rmu[i] = Ms2[tid * MS + i];
-                        e[i] = expf(-s);
-                        z[i] = (ac - mu) * e[i];
-                        const float zo = (ac - mo) * expf(-so);
-                        dlp += (so - s) - 0.5f * (z[i] * z[i] - zo * zo);
-                        Rlp += z[i] * e[i] * Rmu[i] + (z[i] * z[i] - 1.f) * vls[i];
-                        const float so2 = expf(2.f * so), sn2 = expf(2.f * s);
-                        const float num = (mo - mu) * (mo - mu) + so2 - sn2;
-                        const float den = 2.f * sn2 + 1e-8f;
-                        kl += num / den + s - so;
-                        dklm[i] = -2.f * (mo - mu) / den * invN;
-                        dkls[i] = ((-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f) * invN;
-                    }
-                }
-                float c, Rc;
+        wave_sync();
+        // ---- loss-level R-operator: 4 lanes per row, each owns actions {q, q+4}
+        {
+            float dlp = 0.f, Rlp = 0.f, kl = 0.f;
+            float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f, Rmu0 = 0.f, Rmu1 = 0.f, dklm0 = 0.f, dklm1 = 0.f, dkls0 = 0.f,
+                  dkls1 = 0.f, Rs0 = 0.f, Rs1 = 0.f;
+            if (own0) {
+                const float s = lss[q], mu = Msw[erow * MS + q];
+                Rmu0 = Ms2w[erow * MS + q];
+                Rs0 = vls[q];
+                e0 = ess[q];
+                z0 = (ac0 - mu) * e0;
+                const float zo = (ac0 - mo0) * fast_exp(-so0);
+                dlp += (so0 - s) - 0.5f * (z0 * z0 - zo * zo);
+                Rlp += z0 * e0 * Rmu0 + (z0 * z0 - 1.f) * Rs0;
+                const float sn2 = sn2s[q], num = (mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2, den = 2.f * sn2 + 1e-8f;
+                kl += num / den + s - so0;
+                dklm0 = -2.f * (mo0 - mu) / den * invN;
+                dkls0 = ((-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f) * invN;
+            }
+            if (own1) {
+                const float s = lss[q + 4], mu = Msw[erow * MS + q + 4];
+                Rmu1 = Ms2w[erow * MS + q + 4];
+                Rs1 = vls[q + 4];
+                e1 = ess[q + 4];
+                z1 = (ac1 - mu) * e1;
+                const float zo = (ac1 - mo1) * fast_exp(-so1);
+                dlp += (so1 - s) - 0.5f * (z1 * z1 - zo * zo);
+                Rlp += z1 * e1 * Rmu1 + (z1 * z1 - 1.f) * Rs1;
+                const float sn2 = sn2s[q + 4], num = (mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2, den = 2.f * sn2 + 1e-8f;
+                kl += num / den + s - so1;
+                dklm1 = -2.f * (mo1 - mu) / den * invN;
+                dkls1 = ((-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f) * invN;
+            }
+            dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
+            Rlp += shfl_xor_f32(Rlp, 1);  Rlp += shfl_xor_f32(Rlp, 2);
+            kl += shfl_xor_f32(kl, 1);  kl += shfl_xor_f32(kl, 2);
+            float c = 0.f, Rc = 0.f, km = 0.f;
+            if (rvalid) {
+                km = 1.f;
                 if (a.loss_kind == LOSS_RATIO) {
                     c = -advn * expf(dlp) * invN;
                     Rc = c * Rlp;
                 } else {
                     c = -advn * invN;
-                    Rc = 0.f;
                 }
-                klsum += kl * invN;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (i < A) {
-                        const float Rs = vls[i];
-                        const float Rz = -Rmu[i] * e[i] - z[i] * Rs;
-                        dmu[i] = c * z[i] * e[i];
-                        const float Rdmu = Rc * z[i] * e[i] + c * (Rz * e[i] - z[i] * e[i] * Rs);
-                        const float Rds = Rc * (z[i] * z[i] - 1.f) + 2.f * c * z[i] * Rz;
-                        qmu[i] = -Rdmu + klw * dklm[i];
-                        outs[i] += -Rds + klw * dkls[i];
-                        outb3[i] += qmu[i];
-                    }
-                }
+                if (q == 0) klsum += kl * invN;
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                Ms[tid * MS + i] = (i < 8) ? dmu[i] : 0.f;
-                Ms2[tid * MS + i] = (i < 8) ? qmu[i] : 0.f;
+            if (own0) {
+                const float Rz = -Rmu0 * e0 - z0 * Rs0;
+                const float d = c * z0 * e0;
+                const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
+                const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
+                const float qm = km * (-Rd + klw * dklm0);
+                Msw[erow * MS + q] = d;
+                Ms2w[erow * MS + q] = qm;
+                outs0 += km * (-Rds + klw * dkls0);
+                outb30 += qm;
             }
+            if (own1) {
+                const float Rz = -Rmu1 * e1 - z1 * Rs1;
+                const float d = c * z1 * e1;
+                const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
+                const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
+                const float qm = km * (-Rd + klw * dklm1);
+                Msw[erow * MS + q + 4] = d;
+                Ms2w[erow * MS + q + 4] = qm;
+                outs1 += km * (-Rds + klw * dkls1);
+                outb31 += qm;
+            }
+            // columns >= A of Msw / Ms2w already hold exact zeros (zero-padded W3 / vW3 / biases)
         }
-        __syncthreads();
-        // ---- out_W3 += -RH2^T dmu + H2^T qmu ; dZ2, qZ2
+        wave_sync();
+        // ---- out_W3 += -RH2^T dmu + H2^T qmu ; dZ2 over H2, qZ2 over RH2
+        outer16<NC2, 1>(aw3, RH2w + kk * HS + i16, HS, 16, Msw + kk * MS + i16, MS, 0, PROMP_WROWS, -1.f);
+        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, HS, 16, Ms2w + kk * MS + i16, MS, 0, PROMP_WROWS, 1.f);
         {
-            const int r0 = part3 * KS3 + kk;
-            gemm16(acc_w3, Opnd{RH2s + r0 * HS + 16 * rbk3 + i16, HS}, Opnd{Ms + r0 * MS + i16, MS}, KS3, -1.f);
-            gemm16(acc_w3, Opnd{H2s + r0 * HS + 16 * rbk3 + i16, HS}, Opnd{Ms2 + r0 * MS + i16, MS}, KS3, 1.f);
-        }
-        if (w < 2 * NB2) {
-            const int rb = w / NB2, cb = w % NB2;
-            f32x16 ad = zero16(), aq = zero16();
-            const Opnd da{Ms + (rb * 32 + li) * MS + lh, 1};
-            const Opnd wb{W3Ts + lh * H2 + cb * 32 + li, H2};
-            gemm32(ad, da, wb, 8, 1.f);
-            gemm32(aq, Opnd{Ms2 + (rb * 32 + li) * MS + lh, 1}, wb, 8, 1.f);
-            {   // aq -= dmu vW3^T : B[k=a][j=hidden] = vW3[hidden][a], zero for a >= A
-                const int hid = cb * 32 + li;
+            f32x4 ad[1][NC2], aq[1][NC2];
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    const int aa = k + lh;
-                    const float bv = (aa < A) ? v[oW3 + hid * A + aa] : 0.f;
-                    aq = mfma32(-da.p[k], bv, aq);
+            for (int j = 0; j < NC2; ++j) ad[0][j] = aq[0][j] = zero4();
+            outer16<1, NC2>(ad, Msw + i16 * MS + kk, 1, 0, W3Ts + kk * H2 + i16, H2, 16, 8, 1.f);
+            outer16<1, NC2>(aq, Ms2w + i16 * MS + kk, 1, 0, W3Ts + kk * H2 + i16, H2, 16, 8, 1.f);
+            outer16<1, NC2>(aq, Msw + i16 * MS + kk, 1, 0, vW3Ts + kk * H2 + i16, H2, 16, 8, -1.f);
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) {
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
+                    const float h = H2w[idx], rh = RH2w[idx];
+                    const float d1 = 1.f - h * h;
+                    const float qz = aq[0][j][r] * d1 + 2.f * ad[0][j][r] * h * rh;
+                    H2w[idx] = ad[0][j][r] * d1;
+                    RH2w[idx] = qz;
+                    cs += qz;
                 }
+                ob2acc[j] += cs;
             }
-            const int col = cb * 32 + li;
+        }
+        wave_sync();
+        // ---- out_W2 += -RH1^T dZ2 + H1^T qZ2 ; qZ1 over H1
+        outer16<NC1, NC2>(aw2, RH1w + kk * HS + i16, HS, 16, H2w + kk * HS + i16, HS, 16, PROMP_WROWS, -1.f);
+        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, HS, 16, RH2w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        {
+            f32x4 ad[1][NC1], aq[1][NC1];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + row32(r, lh);
-                const float h = H2s[row * HS + col], rh = RH2s[row * HS + col];
-                const float d1 = 1.f - h * h;
-                Ds[row * HS + col] = ad[r] * d1;
-                Qs[row * HS + col] = aq[r] * d1 + 2.f * ad[r] * h * rh;
-            }
-        }
-        __syncthreads();
-        // ---- out_W2 += -RH1^T dZ2 + H1^T qZ2 ; out_b2 ; qZ1 (overwrites H2s)
-        if (w < NB1 * NB2) {
-            const int kb = w / NB2, jb = w % NB2;
-            gemm32(acc_w2, Opnd{RH1s + lh * HS + kb * 32 + li, HS}, Opnd{Ds + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
-                   -1.f);
-            gemm32(acc_w2, Opnd{H1s + lh * HS + kb * 32 + li, HS}, Opnd{Qs + lh * HS + jb * 32 + li, HS}, PROMP_TILE,
-                   1.f);
-        }
-        if (tid >= 128 && tid < 128 + H2) {
-            float s = 0.f;
-            for (int r = 0; r < PROMP_TILE; ++r) s += Qs[r * HS + tid - 128];
-            ob2acc += s;
-        }
-        if (w < 2 * NB1) {
-            const int rb = w / NB1, cb = w % NB1;
-            f32x16 ad = zero16(), aq = zero16();
-            const Opnd da{Ds + (rb * 32 + li) * HS + lh, 1};
-            const Opnd wt{W2s + (cb * 32 + li) * (H2 + 1) + lh, 1};
-            gemm32(ad, da, wt, H2, 1.f);
-            gemm32(aq, Opnd{Qs + (rb * 32 + li) * HS + lh, 1}, wt, H2, 1.f);
-            // aq -= dZ2 vW2^T : B[k=j2][j=k1] = vW2[k1][j2] = vW2T[j2][k1]
-            gemm32(aq, da, Opnd{vW2T + lh * H1 + cb * 32 + li, H1}, H2, -1.f);
-            const int col = cb * 32 + li;
+            for (int j = 0; j < NC1; ++j) ad[0][j] = aq[0][j] = zero4();
+            outer16<1, NC1>(ad, H2w + i16 * HS + kk, 1, 0, W2s + i16 * WS + kk, 1, 16 * WS, H2, 1.f);
+            outer16<1, NC1>(aq, RH2w + i16 * HS + kk, 1, 0, W2s + i16 * WS + kk, 1, 16 * WS, H2, 1.f);
+            outer16<1, NC1>(aq, H2w + i16 * HS + kk, 1, 0, vW2s + i16 * WS + kk, 1, 16 * WS, H2, -1.f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + row32(r, lh);
-                const float h = H1s[row * HS + col], rh = RH1s[row * HS + col];
-                H2s[row * HS + col] = aq[r] * (1.f - h * h) + 2.f * ad[r] * h * rh;
+            for (int j = 0; j < NC1; ++j) {
+                float cs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
+                    const float h = H1w[idx], rh = RH1w[idx];
+                    const float qz = aq[0][j][r] * (1.f - h * h) + 2.f * ad[0][j][r] * h * rh;
+                    H1w[idx] = qz;
+                    cs += qz;
+                }
+                ob1acc[j] += cs;
             }
         }
-        __syncthreads();
-        // ---- out_W1 += X^T qZ1 ; out_b1
-        gemm32(acc_w1, Opnd{Xs + (part1 * KS1 + lh) * XS + li, XS}, Opnd{H2s + (part1 * KS1 + lh) * HS + cb1 * 32 + li, HS},
-               KS1, 1.f);
-        if (tid >= 192 && tid < 192 + H1) {
-            float s = 0.f;
-            for (int r = 0; r < PROMP_TILE; ++r) s += H2s[r * HS + tid - 192];
-            ob1acc += s;
-        }
-        __syncthreads();
+        wave_sync();
+        // ---- out_W1 += X^T qZ1
+        outer16<2, NC1>(aw1, Xw + kk * XS + i16, XS, 16, H1w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        wave_sync();
     }
+    PROMP_STAMP(2);
 
-    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
-    if (w < NB1 * NB2) {
-        const int kb = w / NB2, jb = w % NB2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[oW2 + (kb * 32 + row32(r, lh)) * H2 + jb * 32 + li] = acc_w2[r];
+    for (int j = 0; j < NC1; ++j) {
+        ob1acc[j] += shfl_xor_f32(ob1acc[j], 16);
+        ob1acc[j] += shfl_xor_f32(ob1acc[j], 32);
     }
-    float* S1 = H1s;
-    float* S3 = Ds;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S1[((part1 * NB1 + cb1) * 32 + row32(r, lh)) * 32 + li] = acc_w1[r];
-    if (w < NRB3 * P3) {
+    for (int j = 0; j < NC2; ++j) {
+        ob2acc[j] += shfl_xor_f32(ob2acc[j], 16);
+        ob2acc[j] += shfl_xor_f32(ob2acc[j], 32);
+    }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S3[(part3 * H2 + 16 * rbk3 + 4 * kk + r) * 16 + i16] = acc_w3[r];
+    for (int m = 4; m <= 32; m <<= 1) {
+        outs0 += shfl_xor_f32(outs0, m);  outs1 += shfl_xor_f32(outs1, m);  outb30 += shfl_xor_f32(outb30, m);
+        outb31 += shfl_xor_f32(outb31, m);  klsum += shfl_xor_f32(klsum, m);
+    }
+    const float lmask_reg0 = lmask[lane & 3], lmask_reg1 = lmask[(lane & 3) + 4];
+    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    float* S = sm;
+    const int NW2 = H1 * H2;
+    const int NR2 = NP + 2 - NW2;
+    __syncthreads();
+    {
+        float* mine = S + w * NW2;
+#pragma unroll
+        for (int i = 0; i < NC1; ++i)
+#pragma unroll
+            for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
     }
     __syncthreads();
-    for (int e = tid; e < O * H1; e += 256) {
-        const int row = e / H1, col = e - row * H1;
-        float s = 0.f;
-        for (int p = 0; p < P1; ++p) s += S1[((p * NB1 + (col >> 5)) * 32 + row) * 32 + (col & 31)];
-        P[e] = s;
-    }
-    for (int e = tid; e < H2 * A; e += 256) {
-        const int hid = e / A, aa = e - hid * A;
-        float s = 0.f;
-        for (int p = 0; p < P3; ++p) s += S3[(p * H2 + hid) * 16 + aa];
-        P[oW3 + e] = s;
-    }
-    if (tid >= 192 && tid < 192 + H1) P[ob1 + tid - 192] = ob1acc;
-    if (tid >= 128 && tid < 128 + H2) P[ob2 + tid - 128] = ob2acc;
-    if (w == 0) {
-        klsum = wave_sum_f32(klsum);
+    for (int e = tid; e < NW2; e += 256) P[oW2 + e] = ((S[e] + S[NW2 + e]) + S[2 * NW2 + e]) + S[3 * NW2 + e];
+    __syncthreads();
+    {
+        float* mine = S + w * NR2;
+        for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
+        wave_sync();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            outb3[i] = wave_sum_f32(outb3[i]);
-            outs[i] = wave_sum_f32(outs[i]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * kk + r;
+                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
+                }
+#pragma unroll
+        for (int j = 0; j < NC2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
+        if (kk == 0) {
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = ob1acc[j];
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = ob2acc[j];
+        }
+        if (lane < 4) {
+            if (lane < A) {
+                mine[ob3 - NW2 + lane] = outb30;
+                mine[oS - NW2 + lane] = outs0 * lmask_reg0;
+            }
+            if (lane + 4 < A) {
+                mine[ob3 - NW2 + lane + 4] = outb31;
+                mine[oS - NW2 + lane + 4] = outs1 * lmask_reg1;
+            }
         }
         if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (i < A) {
-                    P[ob3 + i] = outb3[i];
-                    P[oS + i] = outs[i] * lmask[i];
-                }
-            }
-            P[NP] = 0.f;
-            P[NP + 1] = klsum;
+            mine[NP - NW2] = 0.f;
+            mine[NP + 1 - NW2] = klsum;
         }
     }
+    __syncthreads();
+    for (int e = tid; e < NR2; e += 256) {
+        const float vv = ((S[e] + S[NR2 + e]) + S[2 * NR2 + e]) + S[3 * NR2 + e];
+        P[e < oW2 ? e : e + NW2] = vv;
+    }
+    PROMP_STAMP(4);
+    if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 128; ++i) a.dbg[i] = dbgs[i];
 }
 
 // ---------------------------------------------------------------------------------------------
