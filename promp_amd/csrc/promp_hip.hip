@@ -83,6 +83,7 @@ struct promp_ctx {
     float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
     double *gram_partials = nullptr, *red64 = nullptr;
     size_t smem_fwd = 0, smem_hvp = 0;
+    int fwd_waves = 8;                   // waves per k_fwd_bwd workgroup (8 = two per SIMD sharing one copy of the weights)
 #ifndef PROMP_EMU
     ncclComm_t comm = nullptr;
 #endif
@@ -185,8 +186,13 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     if (prof_begin(c, id, S.n_rows)) return -2;
     const bool h64 = c->d.hidden1 == 64;
     if (!hvp) {
-        if (h64) { auto k = k_fwd_bwd<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
-        else     { auto k = k_fwd_bwd<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
+        if (c->fwd_waves == 8) {
+            if (h64) { auto k = k_fwd_bwd<2, 2, 8>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 8>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
+        } else {
+            if (h64) { auto k = k_fwd_bwd<2, 2, 4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
+        }
     } else {
         if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
         else     { auto k = k_hvp<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
@@ -320,8 +326,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     const int Opad = (dims->obs_dim + 1) & ~1;
-    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
-    if (const char* e = getenv("PROMP_DEV_FWD_LDS_PAD")) c->smem_fwd += (size_t)atoi(e);   // developer experiment: force 1 WG/CU
+    if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) c->fwd_waves = atoi(e) == 4 ? 4 : 8;   // developer experiment
+    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, c->fwd_waves, param_count(dims)).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;
@@ -329,7 +335,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         return fail(-1, "LDS budget exceeded (%zu bytes)", need);
     }
     {
-        auto k0 = k_fwd_bwd<2, 2>; auto k1 = k_fwd_bwd<1, 1>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
+        auto k0 = k_fwd_bwd<2, 2, 4>; auto k1 = k_fwd_bwd<1, 1, 4>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
+        auto k4 = k_fwd_bwd<2, 2, 8>; auto k5 = k_fwd_bwd<1, 1, 8>;
+        HIPCHECK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -518,7 +527,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
         const int DA = a.D + 1;
         const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 2 * DA + 2);
-        PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
+        PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 64, fit_smem, st, a, nblk);
         HIPCHECK(hipGetLastError());
     }
     PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), st, a);

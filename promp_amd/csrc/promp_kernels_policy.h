@@ -194,7 +194,11 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     L.wave_stride = q;
     o += nwaves * q;
     // the end-of-kernel reduction buffer [NP + 2] aliases the per-wave regions
-    if (o - L.wave0 < NP + 8) o = L.wave0 + NP + 8;
+    {   // end-of-kernel: 4 slabs of max(H1*H2, NP+2-H1*H2) floats + running sums [NP+2], from offset 0
+        const int nw2 = H1 * H2, nr2 = NP + 2 - nw2;
+        const int need = 4 * (nw2 > nr2 ? nw2 : nr2) + NP + 8;
+        if (o < need) o = need;
+    }
     L.dbg = o;
     o += 256;   // 128 cycle stamps (developer tooling)
 #undef PROMP_TAKE
@@ -202,8 +206,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     return L;
 }
 
-template <int NB1, int NB2>
-__global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
+template <int NB1, int NB2, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
+    constexpr int NT = 64 * NW;
     constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, XS = PROMP_XS;
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
     const int O = a.O, A = a.A;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
               NP = oS + A;
-    const LdsWave L = make_layout_wave(O, H1, H2, 4, NP);
+    const LdsWave L = make_layout_wave(O, H1, H2, NW, NP);
     const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4;
     float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
           *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
@@ -229,16 +234,16 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
     PROMP_STAMP(0);
 
     // ---- stage this task's parameters (shared by the 4 waves) ----
-    for (int e = tid; e < Opad4 * H1; e += 256) W1s[e] = (e < O * H1) ? th[e] : 0.f;
-    for (int e = tid; e < H1 * H2; e += 256) {
+    for (int e = tid; e < Opad4 * H1; e += NT) W1s[e] = (e < O * H1) ? th[e] : 0.f;
+    for (int e = tid; e < H1 * H2; e += NT) {
         const int k = e / H2, j = e - k * H2;
         W2s[k * WS + j] = th[oW2 + e];
     }
-    for (int e = tid; e < H2 * 16; e += 256) {
+    for (int e = tid; e < H2 * 16; e += NT) {
         const int k = e >> 4, j = e & 15;
         W3s[e] = (j < A) ? th[oW3 + k * A + j] : 0.f;
     }
-    for (int e = tid; e < 8 * H2; e += 256) {
+    for (int e = tid; e < 8 * H2; e += NT) {
         const int aa = e / H2, k = e - aa * H2;
         W3Ts[e] = (aa < A) ? th[oW3 + k * A + aa] : 0.f;
     }
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
     }
 
     int tix = 0;
-    for (int base = first; base < wk.row_end; base += 4 * PROMP_WROWS, ++tix) {
+    for (int base = first; base < wk.row_end; base += NW * PROMP_WROWS, ++tix) {
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 0);
         const int nrows = (wk.row_end - base) < PROMP_WROWS ? (wk.row_end - base) : PROMP_WROWS;
 #pragma unroll
@@ -307,7 +312,7 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
             if (xoff[u] >= 0) Xw[xoff[u]] = xr[u];
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 9);
         {
-            const int nb = base + 4 * PROMP_WROWS;
+            const int nb = base + NW * PROMP_WROWS;
             const int nn = (wk.row_end - nb) < PROMP_WROWS ? (wk.row_end - nb) : PROMP_WROWS;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -509,69 +514,82 @@ __global__ void __launch_bounds__(256, 2) k_fwd_bwd(PassArgs a) {
             gb31 += shfl_xor_f32(gb31, m);  loss += shfl_xor_f32(loss, m);  klsum += shfl_xor_f32(klsum, m);
         }
     }
-    // Each wave stores its tiles to its own LDS slab (plain stores, no read-modify-write), then all 256 threads
-    // add the four slabs in wave order and write the partial: two rounds because 4 x [NP] does not fit in LDS.
+    // Each wave stores its tiles to its own LDS slab (plain stores, no read-modify-write), then all threads add four
+    // slabs in wave order.  Two payload rounds because 4 x [NP] does not fit in LDS; with 8 waves the second group of
+    // four waves repeats the rounds and adds onto the first group's sums (kept in LDS), again in a fixed order.
     float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
     float* S = sm;                                   // whole LDS allocation is free now
     const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
     const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
-    __syncthreads();
-    {
-        float* mine = S + w * NW2;
+    float* Rsum = S + 4 * (NW2 > NR2 ? NW2 : NR2);   // [NP + 2] running sums between the groups (NW == 8 only)
+    constexpr int NG = NW / 4;
+    for (int grp = 0; grp < NG; ++grp) {
+        const bool mine_turn = (w >> 2) == grp;
+        const bool last = grp == NG - 1;
+        __syncthreads();
+        if (mine_turn) {
+            float* mine = S + (w & 3) * NW2;
 #pragma unroll
-        for (int i = 0; i < NC1; ++i)
+            for (int i = 0; i < NC1; ++i)
+#pragma unroll
+                for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < NW2; e += NT) {
+            float t = ((S[e] + S[NW2 + e]) + S[2 * NW2 + e]) + S[3 * NW2 + e];
+            if (grp > 0) t += Rsum[oW2 + e];
+            if (last) P[oW2 + e] = t; else Rsum[oW2 + e] = t;
+        }
+        __syncthreads();
+        if (mine_turn) {
+            // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
+            float* mine = S + (w & 3) * NR2;
+            for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * kk + r;
+                        if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
+                    }
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
-    }
-    __syncthreads();
-    for (int e = tid; e < NW2; e += 256) P[oW2 + e] = ((S[e] + S[NW2 + e]) + S[2 * NW2 + e]) + S[3 * NW2 + e];
-    __syncthreads();
-    {
-        // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
-        float* mine = S + w * NR2;
-        for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
-        wave_sync();
+                for (int r = 0; r < 4; ++r)
+                    if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
+            if (kk == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
 #pragma unroll
-            for (int j = 0; j < NC1; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + 4 * kk + r;
-                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
+                for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = gb2[j];
+            }
+            if (lane < 4) {   // lane == q
+                if (lane < A) {
+                    mine[ob3 - NW2 + lane] = gb30;
+                    mine[oS - NW2 + lane] = gs0 * lmask_reg0;
                 }
-#pragma unroll
-        for (int j = 0; j < NC2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
-        if (kk == 0) {
-#pragma unroll
-            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
-#pragma unroll
-            for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = gb2[j];
-        }
-        if (lane < 4) {   // lane == q
-            if (lane < A) {
-                mine[ob3 - NW2 + lane] = gb30;
-                mine[oS - NW2 + lane] = gs0 * lmask_reg0;
+                if (lane + 4 < A) {
+                    mine[ob3 - NW2 + lane + 4] = gb31;
+                    mine[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
+                }
             }
-            if (lane + 4 < A) {
-                mine[ob3 - NW2 + lane + 4] = gb31;
-                mine[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
+            if (lane == 0) {
+                mine[NP - NW2] = loss;
+                mine[NP + 1 - NW2] = klsum;
             }
         }
-        if (lane == 0) {
-            mine[NP - NW2] = loss;
-            mine[NP + 1 - NW2] = klsum;
+        __syncthreads();
+        for (int e = tid; e < NR2; e += NT) {
+            const int dst = e < oW2 ? e : e + NW2;
+            float t = ((S[e] + S[NR2 + e]) + S[2 * NR2 + e]) + S[3 * NR2 + e];
+            if (grp > 0) t += Rsum[dst];
+            if (last) P[dst] = t; else Rsum[dst] = t;
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < NR2; e += 256) {
-        const float v = ((S[e] + S[NR2 + e]) + S[2 * NR2 + e]) + S[3 * NR2 + e];
-        P[e < oW2 ? e : e + NW2] = v;
     }
     PROMP_STAMP(4);
     if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
@@ -633,7 +651,11 @@ PROMP_HD LdsHvp make_layout_hvp(int O, int H1, int H2, int nwaves, int NP) {
     L.ms2 = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
     L.wave_stride = q;
     o += nwaves * q;
-    if (o < 4 * H1 * H2) o = 4 * H1 * H2;   // the end-of-kernel slabs [4][H1*H2] start at 0
+    {
+        const int nw2 = H1 * H2, nr2 = NP + 2 - nw2;
+        const int need = 4 * (nw2 > nr2 ? nw2 : nr2);   // the end-of-kernel slabs start at 0
+        if (o < need) o = need;
+    }
     L.dbg = o;
     o += 256;
 #undef PROMP_TAKE
@@ -1071,8 +1093,9 @@ __global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
     const int task = blockIdx.y;
     if (j >= a.NP + 2) return;
     float g = 0.f;
-    for (int wg = a.task_wg_offsets[task]; wg < a.task_wg_offsets[task + 1]; ++wg)
-        g += a.partials[(long long)wg * a.partial_stride + j];
+    const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
+#pragma unroll 4
+    for (int wg = wg0; wg < wg1; ++wg) g += a.partials[(long long)wg * a.partial_stride + j];
     if (j >= a.NP) {
         a.scal[task * 2 + (j - a.NP)] = g;
         return;
@@ -1115,8 +1138,10 @@ __global__ void __launch_bounds__(256) k_reduce_final(FinalArgs a) {
     if (j >= a.NP + a.K + 2) return;
     float s = 0.f;
     if (j < a.NP) {
-        if (a.want_grad)
+        if (a.want_grad) {
+#pragma unroll 8
             for (int i = 0; i < a.n_tasks; ++i) s += a.lam[(long long)i * a.NP + j];
+        }
     } else if (j == a.NP) {
         for (int i = 0; i < a.n_tasks; ++i) s += a.scal_outer[i * 2 + 0];
     } else if (j <= a.NP + a.K) {
