@@ -151,8 +151,11 @@ def main():
                               ms_per_step=pg['total_ms'] / n_prof)
         ctx.prof_enable(False)
         dom = max(('k_fwd_bwd', 'k_hvp'), key=lambda k: kern[k]['ms_per_step'])
+        traffic = measured_traffic(dom)
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'], 'peak': FP32_PEAK_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS, 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS,
+                           'traffic': traffic['bytes'] if traffic else None, 'traffic_source': traffic['source'] if traffic else None,
+                           'algorithmic_bytes_per_launch': 4 * (O + 2 * A + 2) * kern[dom]['rows_per_launch'],
                            'avg_launch_ms': kern[dom]['avg_ms'], 'kernels': kern,
                            'end_to_end_tflops_per_gpu': value * ((fl['fwd_bwd'] + E * (2 * fl['fwd'] + 3 * fl['bwd'] + fl['hvp'])
                                                                            + 2 * fl['fwd'] + fl['bwd']) / 2.0) / 1e12 / world}
@@ -164,6 +167,20 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_hbm_traffic.json, written by tools/summarize_round.py); bench.py itself cannot read PMCs."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1])).get(kernel)
+        return dict(bytes=t['hbm_bytes_per_launch'], source=os.path.relpath(files[-1], ROOT)) if t else None
+    except Exception:
+        return None
 
 
 def cpu_baseline(cfg, theta0, alpha, eta, opts, E, sample_tasks=20):

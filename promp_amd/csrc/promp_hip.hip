@@ -526,8 +526,8 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         HIPCHECK(hipGetLastError());
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
         const int DA = a.D + 1;
-        const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 2 * DA + 2);
-        PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 64, fit_smem, st, a, nblk);
+        const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2);
+        PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         HIPCHECK(hipGetLastError());
     }
     PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), st, a);

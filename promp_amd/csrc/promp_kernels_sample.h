@@ -175,21 +175,24 @@ __global__ void __launch_bounds__(256) k_gram(SampleArgs a) {
     for (int e = tid; e < NPAIR * 256; e += 256) out[e] = Red[e];
 }
 
-// grid = tasks, block = 64 (ONE wave per task: the factorisation is a chain of ~3*D dependent steps, so a
-// single wave with wave-level ordering beats a workgroup that would need ~300 s_barriers).
-// smem: G[(D+1)^2] + Wm[(D+1)^2] + yv[D+1] + wv[D+1]   (doubles)
-__global__ void __launch_bounds__(64) k_fit(SampleArgs a, int NBLK) {
+// grid = tasks, block = 256.  smem: G[(D+1)^2] + Wm[(D+1)^2] + yv[D+1] + wv[D+1] + dg[D+1]  (doubles)
+// The factorisation is a chain of D dependent column steps; per step: every thread recomputes the pivot (no
+// broadcast barrier), rows scale their column entry, ONE barrier, the trailing update spread over 256 threads,
+// ONE barrier.  The diagonal goes to a side array so nobody reads a value another thread is replacing.
+__global__ void __launch_bounds__(256) k_fit(SampleArgs a, int NBLK) {
     PROMP_SMEM_DECL;
     const int D = a.D, DA = D + 1;
     double* G = (double*)PROMP_SMEM_PTR;
     double* Wm = G + DA * DA;
     double* yv = Wm + DA * DA;
     double* wv = yv + DA;
-    const int lane = threadIdx.x, task = blockIdx.x;
+    double* dg = wv + DA;
+    int* flag = (int*)(dg + DA);
+    const int tid = threadIdx.x, task = blockIdx.x;
     const int NPAIR = NBLK * (NBLK + 1) / 2;
     // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
     const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
-    for (int e = lane; e < NPAIR * 256; e += 64) {
+    for (int e = tid; e < NPAIR * 256; e += 256) {
         double s = 0.0;
 #pragma unroll 4
         for (int wg = wg0; wg < wg1; ++wg) s += a.gram_partials[(long long)wg * (NPAIR * 256) + e];
@@ -205,48 +208,49 @@ __global__ void __launch_bounds__(64) k_fit(SampleArgs a, int NBLK) {
             if (bi != bj) G[col * DA + row] = s;
         }
     }
-    wave_sync();
+    __syncthreads();
     // 2. Cholesky of (G[:D,:D] + reg I) carrying the right-hand-side row D along (forward solve for free),
     //    then back substitution; NaN => reg *= 10, at most 5 tries (linear_baseline.py:68-77)
+    const float rDA = 1.0f / (float)DA;
     double reg = a.reg;
     for (int attempt = 0; attempt < 5; ++attempt) {
-        for (int e = lane; e < DA * DA; e += 64) {
-            const int i = e / DA, j = e - i * DA;
+        for (int e = tid; e < DA * DA; e += 256) {
+            const int i = (int)(((float)e + 0.5f) * rDA), j = e - i * DA;
             Wm[e] = G[e] + ((i == j && i < D) ? reg : 0.0);
         }
-        wave_sync();
+        __syncthreads();
         for (int j = 0; j < D; ++j) {
             const double piv = sqrt(Wm[j * DA + j]);
-            wave_sync();
-            for (int i = j + 1 + lane; i <= D; i += 64) Wm[i * DA + j] /= piv;
-            if (lane == 0) Wm[j * DA + j] = piv;
-            wave_sync();
+            if (tid > j && tid <= D) Wm[tid * DA + j] /= piv;
+            if (tid == j) dg[j] = piv;
+            __syncthreads();
             const int nr = D - j, nc = D - j - 1;  // rows j+1..D, cols j+1..D-1
             const float rnc = 1.0f / (float)(nc > 0 ? nc : 1);
-            for (int e = lane; e < nr * nc; e += 64) {
+            for (int e = tid; e < nr * nc; e += 256) {
                 const int io = (int)(((float)e + 0.5f) * rnc);
                 const int i = j + 1 + io, k = j + 1 + (e - io * nc);
                 if (k <= i) Wm[i * DA + k] -= Wm[i * DA + j] * Wm[k * DA + j];
             }
-            wave_sync();
+            __syncthreads();
         }
-        for (int k = lane; k < D; k += 64) yv[k] = Wm[D * DA + k];
-        wave_sync();
+        if (tid < D) yv[tid] = Wm[D * DA + tid];
+        __syncthreads();
         for (int j = D - 1; j >= 0; --j) {
-            const double wj = yv[j] / Wm[j * DA + j];
-            wave_sync();
-            if (lane == 0) wv[j] = wj;
-            for (int k = lane; k < j; k += 64) yv[k] -= Wm[j * DA + k] * wj;
-            wave_sync();
+            const double wj = yv[j] / dg[j];
+            if (tid == 0) wv[j] = wj;
+            if (tid < j) yv[tid] -= Wm[j * DA + tid] * wj;
+            __syncthreads();
         }
-        double bad = 0.0;
-        for (int k = lane; k < D; k += 64) bad += (wv[k] != wv[k]) ? 1.0 : 0.0;
-        bad = wave_sum_f64(bad);
-        if (bad == 0.0) break;
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (tid < D && wv[tid] != wv[tid]) *flag = 1;
+        __syncthreads();
+        const int bad = *flag;
+        __syncthreads();
+        if (!bad) break;
         reg *= 10.0;
-        wave_sync();
     }
-    for (int k = lane; k < D; k += 64) a.coeffs[(long long)task * a.coeff_stride + k] = wv[k];
+    if (tid < D) a.coeffs[(long long)task * a.coeff_stride + tid] = wv[tid];
 }
 
 // grid = paths, block = 64.  smem: D doubles (the task's coefficients)

@@ -51,6 +51,7 @@ struct Block {
     std::barrier<> bar;
     std::vector<std::unique_ptr<Wave>> waves;
     unsigned char* smem;
+    int or_flag = 0;
     Block(int nthreads, size_t smem_bytes) : bar(nthreads) {
         for (int w = 0; w * 64 < nthreads; ++w) waves.emplace_back(new Wave(std::min(64, nthreads - w * 64)));
         smem = (unsigned char*)aligned_alloc(64, (smem_bytes + 1024 + 63) / 64 * 64);
@@ -99,6 +100,17 @@ void launch(dim3 grid, int block, size_t smem, F body) {
 #define PROMP_LAUNCH(kern, grid, block, smem, stream, ...) emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::tl.blk->bar.arrive_and_wait(); }
+inline int __syncthreads_or(int pred) {
+    emu::Block* b = emu::tl.blk;
+    b->bar.arrive_and_wait();
+    if (pred) __atomic_store_n(&b->or_flag, 1, __ATOMIC_SEQ_CST);
+    b->bar.arrive_and_wait();
+    const int r = __atomic_load_n(&b->or_flag, __ATOMIC_SEQ_CST);
+    b->bar.arrive_and_wait();
+    if (emu::tl.tidx.x == 0) b->or_flag = 0;
+    b->bar.arrive_and_wait();
+    return r;
+}
 
 inline f32x16 mfma32(float a, float b, f32x16 c) {
     emu::Wave& W = emu::wave();

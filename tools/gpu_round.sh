@@ -1,16 +1,21 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, smoke, bench, rocprofv3 kernel trace.  Outputs under gpurun_out/.
-set -x
-mkdir -p gpurun_out
+# One full measured round: GPU parity tests, smoke, bench (with cpu baseline), rocprofv3 kernel trace (csv stats),
+# PMC passes for HBM traffic.  Everything lands under gpurun_out/round/.
+R=gpurun_out/round
+rm -rf $R && mkdir -p $R
 export TMPDIR=/tmp
-rocminfo | grep -E "Marketing Name|gfx" | head -4 > gpurun_out/device.txt 2>&1
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-tail -25 gpurun_out/pytest_gpu.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
-tail -5 gpurun_out/smoke.log
-timeout 600 python bench.py --steps 30 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"
-cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
-rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err); echo "rocprof rc=$?"
-find gpurun_out/prof -name "*stats*" | head; 
-f=$(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -20 "$f"
+rocminfo | grep -E "Marketing Name|gfx" | head -4 > $R/device.txt 2>&1
+timeout 1200 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log; tail -3 $R/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log; tail -2 $R/smoke.log
+timeout 900 python bench.py > $R/bench.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench.json | head -c 400; echo
+ROOT=$GRAFT_REPO_ROOT
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace -o trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $ROOT/$R/trace_bench.json 2> $ROOT/$R/trace.err; echo "trace rc=$?"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$R/pmc$i -o pmc$i -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/$R/pmc$i.err
+  echo "pmc pass $i rc=$?"
+done
+cd $ROOT; rm -f $R/trace/*kernel_trace.csv $R/pmc*/*kernel_trace.csv   # keep the summaries small
+ls -R $R | head -40
