@@ -1,0 +1,41 @@
+"""Copy the judged summaries of gpurun_out/round/ into profiles/ (tracked) under a round tag, and derive the per-launch
+HBM traffic of the pass kernels from the PMC passes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts 64 B per 128-B
+request on gfx950 for wide coalesced reads => doubled; WRITE_SIZE used as reported; both in KiB)."""
+import json
+import os
+import shutil
+import sys
+
+import pandas as pd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src, dst = os.path.join(ROOT, 'gpurun_out/round'), os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+for name, out in [('bench.json', '%s_bench.json'), ('pytest_gpu.log', '%s_pytest_gpu.log'), ('smoke.log', '%s_smoke.log'),
+                  ('device.txt', '%s_device.txt'), ('trace/trace_kernel_stats.csv', '%s_rocprofv3_kernel_stats.csv'),
+                  ('trace/trace_domain_stats.csv', '%s_rocprofv3_domain_stats.csv')]:
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, out % tag))
+rows = {}
+for i in range(1, 9):
+    f = os.path.join(src, 'pmc%d/pmc%d_counter_collection.csv' % (i, i))
+    if not os.path.exists(f):
+        continue
+    df = pd.read_csv(f)
+    g = df.groupby(['Kernel_Name', 'Counter_Name'])['Counter_Value'].mean().unstack()
+    for k, r in g.iterrows():
+        rows.setdefault(k, {}).update({c: float(v) for c, v in r.items()})
+pmc = pd.DataFrame(rows).T
+pmc.index.name = 'kernel'
+pmc.to_csv(os.path.join(dst, '%s_rocprofv3_pmc_per_dispatch_mean.csv' % tag))
+traffic = {}
+for k, r in pmc.iterrows():
+    if 'FETCH_SIZE' in r and 'WRITE_SIZE' in r and r['FETCH_SIZE'] == r['FETCH_SIZE']:
+        short = k.split('(')[0].replace('void ', '').split('<')[0]
+        traffic[short] = dict(fetch_size_kib=r['FETCH_SIZE'], write_size_kib=r['WRITE_SIZE'],
+                              hbm_bytes_per_launch=(2.0 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024.0,
+                              note='(2 x FETCH_SIZE + WRITE_SIZE) KiB; separate --pmc passes of bench.py --steps 3; gfx950 FETCH_SIZE x2 correction')
+json.dump(traffic, open(os.path.join(dst, '%s_hbm_traffic.json' % tag), 'w'), indent=1)
+print(pmc.loc[[k for k in pmc.index if 'k_' in k]].T.to_string())
+print(json.dumps({k: round(v['hbm_bytes_per_launch'] / 1e6, 2) for k, v in traffic.items()}, indent=1))
