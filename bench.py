@@ -45,6 +45,9 @@ def main():
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
                     help='strong: the named config sharded over N GPUs (default); weak: the named config per GPU')
     ap.add_argument('--epochs', type=int, default=5)
+    ap.add_argument('--shard-of', type=int, default=0, metavar='N',
+                    help='developer option: with --gpus 1, run only the shard rank 0 of an N-GPU job would hold '
+                         '(M/N tasks, no collective) to study the per-rank step time of strong scaling')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -58,6 +61,8 @@ def main():
     P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
     M_global = cfg['M'] * (world if args.scaling == 'weak' else 1)
     task_ids = [i for i in range(M_global) if i % world == rank]
+    if args.shard_of > 1 and world == 1:
+        task_ids = [i for i in range(M_global) if i % args.shard_of == 0]
     M = len(task_ids)
     K, E = 1, args.epochs
     N = P * T

@@ -433,10 +433,11 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         if (pro[tpo[i + 1]] == tro[i]) return fail(-1, "task %d has no rows", i);
     }
     tro[M] = R;
-    // work tables: contiguous 64-row-tile ranges, workgroups shared out over tasks in proportion to their tiles
+    // work tables: contiguous ranges of 16-row wave tiles, workgroups shared out over tasks in proportion to their tiles
     std::vector<int> tiles(M);
     long long total_tiles = 0;
-    for (int i = 0; i < M; ++i) { tiles[i] = (tro[i + 1] - tro[i] + PROMP_TILE - 1) / PROMP_TILE; total_tiles += tiles[i]; }
+    const int GR = PROMP_WROWS;   // work granule = one wave tile (16 rows)
+    for (int i = 0; i < M; ++i) { tiles[i] = (tro[i + 1] - tro[i] + GR - 1) / GR; total_tiles += tiles[i]; }
     std::vector<WorkItem> work[2];
     std::vector<int> two[2];
     for (int t = 0; t < 2; ++t) {
@@ -445,16 +446,35 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         int target = (t + 1) * c->n_cus;
         if (const char* e = getenv(t == 0 ? "PROMP_DEV_TARGET0" : "PROMP_DEV_TARGET1")) target = atoi(e);   // developer experiment
         two[t].assign(M + 1, 0);
+        // largest-remainder split: sum of workgroups <= target (one more would cost a whole second round on the chip),
+        // every task gets at least one and at most one per tile
+        std::vector<long long> nw(M), rem(M);
+        long long used = 0;
         for (int i = 0; i < M; ++i) {
-            long long w = (tiles[i] * (long long)target + total_tiles / 2) / total_tiles;
-            if (w < 1) w = 1;
-            if (w > tiles[i]) w = tiles[i];
+            const long long num = tiles[i] * (long long)target;
+            nw[i] = num / total_tiles;
+            rem[i] = num % total_tiles;
+            if (nw[i] < 1) { nw[i] = 1; rem[i] = 0; }
+            if (nw[i] > tiles[i]) { nw[i] = tiles[i]; rem[i] = 0; }
+            used += nw[i];
+        }
+        while (used < target) {
+            int best = -1;
+            for (int i = 0; i < M; ++i)
+                if (nw[i] < tiles[i] && rem[i] > 0 && (best < 0 || rem[i] > rem[best])) best = i;
+            if (best < 0) break;
+            nw[best] += 1;
+            rem[best] = 0;
+            used += 1;
+        }
+        for (int i = 0; i < M; ++i) {
+            const long long w = nw[i];
             for (int g = 0; g < (int)w; ++g) {
                 const int t0 = (int)((long long)tiles[i] * g / w), t1 = (int)((long long)tiles[i] * (g + 1) / w);
                 WorkItem it;
                 it.task = i;
-                it.row_begin = tro[i] + t0 * PROMP_TILE;
-                it.row_end = tro[i] + t1 * PROMP_TILE;
+                it.row_begin = tro[i] + t0 * GR;
+                it.row_end = tro[i] + t1 * GR;
                 if (it.row_end > tro[i + 1]) it.row_end = tro[i + 1];
                 it.pad = 0;
                 work[t].push_back(it);

@@ -157,6 +157,12 @@ PROMP_DEV void load_obs_tile(float* Xs, int XS, const float* obs, long long base
 // developer tooling: cycle stamps of workgroup 0 / thread 0, kept in LDS and dumped when the kernel ends
 #define PROMP_STAMP(i) do { if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0) dbgs[(i)] = promp_clock(); } while (0)
 #define PROMP_WROWS 16
+PROMP_DEV f32x4 splat4(float v) {
+    f32x4 z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = v;
+    return z;
+}
 #define PROMP_XS 33
 
 struct LdsWave {
@@ -285,6 +291,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     // epilogue role: 4 lanes per row, actions {q, q+4}
     const int erow = lane >> 2, q = lane & 3;
     const bool own0 = q < A, own1 = (q + 4) < A;
+    const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;   // clamped action indices for unconditional loads
     // where this lane's share of a [16][O] tile lands in the padded LDS tile
     int xoff[8];
 #pragma unroll
@@ -296,10 +303,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     float xr[8];
     {
         const int nr = (wk.row_end - first) < PROMP_WROWS ? (wk.row_end - first) : PROMP_WROWS;
+        const int lim = (first < wk.row_end) ? nr * O : 0;
+        const float* src = a.obs + (long long)(first < wk.row_end ? first : wk.row_begin) * O;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = lane + 64 * u;
-            xr[u] = (first < wk.row_end && e < nr * O) ? a.obs[(long long)first * O + e] : 0.f;
+            const float x = src[e < lim ? e : 0];      // always a valid address: no exec-masked branch per load
+            xr[u] = (e < lim) ? x : 0.f;
         }
     }
 
@@ -314,19 +324,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         {
             const int nb = base + NW * PROMP_WROWS;
             const int nn = (wk.row_end - nb) < PROMP_WROWS ? (wk.row_end - nb) : PROMP_WROWS;
+            const int lim = (nb < wk.row_end) ? nn * O : 0;
+            const float* src = a.obs + (long long)(nb < wk.row_end ? nb : wk.row_begin) * O;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = lane + 64 * u;
-                xr[u] = (nb < wk.row_end && e < nn * O) ? a.obs[(long long)nb * O + e] : 0.f;
+                const float x = src[e < lim ? e : 0];
+                xr[u] = (e < lim) ? x : 0.f;
             }
         }
         const bool rvalid = erow < nrows;
         const long long n = (long long)base + (rvalid ? erow : 0);
         const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+        // n is a valid row even for padding lanes; q0/q1 are valid action indices even for lanes that own none:
+        // all loads are unconditional, the selects below discard what is not owned
         const float advn = rvalid ? a.adv[n] : 0.f;
-        const float ac0 = (rvalid && own0) ? a.act[n * A + q] : 0.f, ac1 = (rvalid && own1) ? a.act[n * A + q + 4] : 0.f;
-        const float mo0 = (rvalid && own0) ? a.old_mean[n * A + q] : 0.f, mo1 = (rvalid && own1) ? a.old_mean[n * A + q + 4] : 0.f;
-        const float so0 = (rvalid && own0) ? olsp[q] : 0.f, so1 = (rvalid && own1) ? olsp[q + 4] : 0.f;
+        const float ac0 = a.act[n * A + q0], ac1 = a.act[n * A + q1];
+        const float mo0 = a.old_mean[n * A + q0], mo1 = a.old_mean[n * A + q1];
+        const float so0 = olsp[q0], so1 = olsp[q1];
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 10);
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 1);
@@ -334,15 +349,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         {
             f32x4 acc[1][NC1];
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) acc[0][j] = zero4();
+            for (int j = 0; j < NC1; ++j) acc[0][j] = splat4(b1s[16 * j + i16]);   // bias rides in the accumulator
             outer16<1, NC1>(acc, Xw + i16 * XS + kk, 1, 0, W1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
             PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 11);
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) {
-                const float bb = b1s[16 * j + i16];
+            for (int j = 0; j < NC1; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) H1w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r] + bb);
-            }
+                for (int r = 0; r < 4; ++r) H1w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r]);
         }
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 2);
@@ -350,26 +363,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         {
             f32x4 acc[1][NC2];
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) acc[0][j] = zero4();
+            for (int j = 0; j < NC2; ++j) acc[0][j] = splat4(b2s[16 * j + i16]);
             outer16<1, NC2>(acc, H1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
             PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 12);
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) {
-                const float bb = b2s[16 * j + i16];
+            for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) H2w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r] + bb);
-            }
+                for (int r = 0; r < 4; ++r) H2w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r]);
         }
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 3);
         // ---- output layer (16 padded columns)
         {
             f32x4 acc[1][1];
-            acc[0][0] = zero4();
+            acc[0][0] = splat4(b3s[i16]);
             outer16<1, 1>(acc, H2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
-            const float bb = b3s[i16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r] + bb;
+            for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r];
         }
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 4);
@@ -756,6 +766,7 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
 
     const int erow = lane >> 2, q = lane & 3;
     const bool own0 = q < A, own1 = (q + 4) < A;
+    const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;   // clamped action indices for unconditional loads
     int xoff[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -766,10 +777,13 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
     float xr[8];
     {
         const int nr = (wk.row_end - first) < PROMP_WROWS ? (wk.row_end - first) : PROMP_WROWS;
+        const int lim = (first < wk.row_end) ? nr * O : 0;
+        const float* src = a.obs + (long long)(first < wk.row_end ? first : wk.row_begin) * O;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = lane + 64 * u;
-            xr[u] = (first < wk.row_end && e < nr * O) ? a.obs[(long long)first * O + e] : 0.f;
+            const float x = src[e < lim ? e : 0];      // always a valid address: no exec-masked branch per load
+            xr[u] = (e < lim) ? x : 0.f;
         }
     }
 
@@ -781,73 +795,80 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         {
             const int nb = base + 4 * PROMP_WROWS;
             const int nn = (wk.row_end - nb) < PROMP_WROWS ? (wk.row_end - nb) : PROMP_WROWS;
+            const int lim = (nb < wk.row_end) ? nn * O : 0;
+            const float* src = a.obs + (long long)(nb < wk.row_end ? nb : wk.row_begin) * O;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = lane + 64 * u;
-                xr[u] = (nb < wk.row_end && e < nn * O) ? a.obs[(long long)nb * O + e] : 0.f;
+                const float x = src[e < lim ? e : 0];
+                xr[u] = (e < lim) ? x : 0.f;
             }
         }
         const bool rvalid = erow < nrows;
         const long long n = (long long)base + (rvalid ? erow : 0);
         const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+        // n is a valid row even for padding lanes; q0/q1 are valid action indices even for lanes that own none:
+        // all loads are unconditional, the selects below discard what is not owned
         const float advn = rvalid ? a.adv[n] : 0.f;
-        const float ac0 = (rvalid && own0) ? a.act[n * A + q] : 0.f, ac1 = (rvalid && own1) ? a.act[n * A + q + 4] : 0.f;
-        const float mo0 = (rvalid && own0) ? a.old_mean[n * A + q] : 0.f, mo1 = (rvalid && own1) ? a.old_mean[n * A + q + 4] : 0.f;
-        const float so0 = (rvalid && own0) ? olsp[q] : 0.f, so1 = (rvalid && own1) ? olsp[q + 4] : 0.f;
+        const float ac0 = a.act[n * A + q0], ac1 = a.act[n * A + q1];
+        const float mo0 = a.old_mean[n * A + q0], mo1 = a.old_mean[n * A + q1];
+        const float so0 = olsp[q0], so1 = olsp[q1];
         wave_sync();
         // ---- layer 1 and its tangent:  Rz1 = X vW1 + vb1
         {
             f32x4 az[1][NC1], ar[1][NC1];
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) az[0][j] = ar[0][j] = zero4();
+            for (int j = 0; j < NC1; ++j) {
+                az[0][j] = splat4(b1s[16 * j + i16]);     // biases ride in the accumulators
+                ar[0][j] = splat4(vb1s[16 * j + i16]);
+            }
             outer16<1, NC1>(az, Xw + i16 * XS + kk, 1, 0, W1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
             outer16<1, NC1>(ar, Xw + i16 * XS + kk, 1, 0, vW1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) {
-                const float bb = b1s[16 * j + i16], vb = vb1s[16 * j + i16];
+            for (int j = 0; j < NC1; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int idx = (4 * kk + r) * HS + 16 * j + i16;
-                    const float h = fast_tanh(az[0][j][r] + bb);
+                    const float h = fast_tanh(az[0][j][r]);
                     H1w[idx] = h;
-                    RH1w[idx] = (1.f - h * h) * (ar[0][j][r] + vb);
+                    RH1w[idx] = (1.f - h * h) * ar[0][j][r];
                 }
-            }
         }
         wave_sync();
         // ---- layer 2 and its tangent:  Rz2 = H1 vW2 + RH1 W2 + vb2
         {
             f32x4 az[1][NC2], ar[1][NC2];
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) az[0][j] = ar[0][j] = zero4();
+            for (int j = 0; j < NC2; ++j) {
+                az[0][j] = splat4(b2s[16 * j + i16]);
+                ar[0][j] = splat4(vb2s[16 * j + i16]);
+            }
             outer16<1, NC2>(az, H1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
             outer16<1, NC2>(ar, H1w + i16 * HS + kk, 1, 0, vW2s + kk * WS + i16, WS, 16, H1, 1.f);
             outer16<1, NC2>(ar, RH1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) {
-                const float bb = b2s[16 * j + i16], vb = vb2s[16 * j + i16];
+            for (int j = 0; j < NC2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int idx = (4 * kk + r) * HS + 16 * j + i16;
-                    const float h = fast_tanh(az[0][j][r] + bb);
+                    const float h = fast_tanh(az[0][j][r]);
                     H2w[idx] = h;
-                    RH2w[idx] = (1.f - h * h) * (ar[0][j][r] + vb);
+                    RH2w[idx] = (1.f - h * h) * ar[0][j][r];
                 }
-            }
         }
         wave_sync();
         // ---- output layer and its tangent:  Rmu = H2 vW3 + RH2 W3 + vb3
         {
             f32x4 am[1][1], ar[1][1];
-            am[0][0] = ar[0][0] = zero4();
+            am[0][0] = splat4(b3s[i16]);
+            ar[0][0] = splat4(vb3s[i16]);
             outer16<1, 1>(am, H2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
             outer16<1, 1>(ar, H2w + i16 * HS + kk, 1, 0, vW3s + kk * 16 + i16, 16, 0, H2, 1.f);
             outer16<1, 1>(ar, RH2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
-            const float bb = b3s[i16], vb = vb3s[i16];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                Msw[(4 * kk + r) * MS + i16] = am[0][0][r] + bb;
-                Ms2w[(4 * kk + r) * MS + i16] = ar[0][0][r] + vb;
+                Msw[(4 * kk + r) * MS + i16] = am[0][0][r];
+                Ms2w[(4 * kk + r) * MS + i16] = ar[0][0][r];
             }
         }
         wave_sync();
