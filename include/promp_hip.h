@@ -49,7 +49,11 @@ enum { PROMP_BASELINE_ZERO = 0, PROMP_BASELINE_LINEAR_FEATURE = 1, PROMP_BASELIN
 enum { PROMP_INNER_RATIO = 0,   /* -mean(ratio*adv)   meta_algos/pro_mp.py:59-65   */
        PROMP_INNER_LOGLIK = 1   /* -mean(logpi*adv)   meta_algos/trpo_maml.py:58-62 */ };
 enum { PROMP_OUTER_CLIP = 0,    /* PPO clipped surrogate, meta_algos/pro_mp.py:141-145 */
-       PROMP_OUTER_RATIO = 1    /* unclipped,            meta_algos/trpo_maml.py:135    */ };
+       PROMP_OUTER_RATIO = 1,   /* unclipped,            meta_algos/trpo_maml.py:135    */
+       PROMP_OUTER_KL = 2       /* mean KL(old || new) of the last step itself: the TRPO constraint
+                                   (meta_algos/trpo_maml.py:133,147,158); its gradient through the
+                                   adaptation feeds the finite-difference HVP of
+                                   optimizers/conjugate_gradient_optimizer.py:59-89 */ };
 
 /* SampleProcessor.__init__ arguments (samplers/base.py:48-65) + baseline choice */
 typedef struct promp_proc_opts {
@@ -155,7 +159,7 @@ int promp_allreduce_f64(promp_ctx* ctx, double* host_buf, int n, int op /*0 sum,
 /* ---- evaluation hooks used by the parity tests and by alternative optimizers (TRPO-MAML's
  * conjugate-gradient loop calls these per evaluation): per-task objective, mean-KL and their
  * gradient at the CURRENT per-task parameters on step `step`'s data.
- *   kind: 0 ratio surrogate, 1 clipped surrogate, 2 log-likelihood
+ *   kind: 0 ratio surrogate, 1 clipped surrogate, 2 log-likelihood, 3 mean KL(old||new)
  *   grads_out [n_tasks,Theta], loss_out [n_tasks], kl_out [n_tasks] (any may be NULL). */
 int promp_eval_loss_grad(promp_ctx* ctx, int step, int kind, float clip_eps, int clip_log_std,
                          float* grads_out, float* loss_out, float* kl_out);

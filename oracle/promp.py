@@ -28,6 +28,7 @@ INNER_RATIO = 'ratio'      # pro_mp.py:59-65
 INNER_LOGLIK = 'loglik'    # trpo_maml.py:58-62
 OUTER_CLIP = 'clip'        # pro_mp.py:141-145
 OUTER_RATIO = 'ratio'      # trpo_maml.py:135
+OUTER_KL = 'kl'            # mean KL(old || new): the TRPO constraint, trpo_maml.py:133,147,158
 
 
 def _slab(slab):
@@ -57,7 +58,7 @@ def _backprop(spec, cache, dmu, ds):
 def loss_and_grad(spec, theta, slab, kind, clip_log_std, clip_eps=None, want_grad=True):
     """Per-task objective on one slab, mean KL(old||new), and their gradients wrt theta.
 
-    kind: 'ratio' -mean(rho*A) | 'clip' -mean(min(rho*A, clip(rho)*A)) | 'loglik' -mean(logpi*A)
+    kind: 'ratio' -mean(rho*A) | 'clip' -mean(min(rho*A, clip(rho)*A)) | 'loglik' -mean(logpi*A) | 'kl' mean KL
     Returns dict(loss, kl, grad, grad_kl).
     """
     obs, act, adv, om, ols = _slab(slab)
@@ -81,6 +82,9 @@ def loss_and_grad(spec, theta, slab, kind, clip_log_std, clip_eps=None, want_gra
     elif kind == 'loglik':
         loss = -np.mean(lp * adv)
         c = -adv / N
+    elif kind == 'kl':
+        loss = None            # filled in below
+        c = np.zeros(N)
     else:
         raise ValueError(kind)
     # KL(old || new), diagonal_gaussian.py:16-45
@@ -88,14 +92,19 @@ def loss_and_grad(spec, theta, slab, kind, clip_log_std, clip_eps=None, want_gra
     num = (om - mu) ** 2 + so2 - sn2
     den = 2 * sn2 + 1e-8
     kl_rows = np.sum(num / den + s - ols, axis=1)
+    if kind == 'kl':
+        loss = np.mean(kl_rows)
     out = dict(loss=float(loss), kl=float(np.mean(kl_rows)))
     if want_grad:
-        dmu = c[:, None] * z * e
-        ds = np.sum(c[:, None] * (z ** 2 - 1.0), axis=0)
-        out['grad'] = _backprop(spec, cache, dmu, ds)
         dkl_mu = (-2.0 * (om - mu) / den) / N
         dkl_s = np.sum((-2 * sn2 * den - num * 4 * sn2) / den ** 2 + 1.0, axis=0) / N
         out['grad_kl'] = _backprop(spec, cache, dkl_mu, dkl_s)
+        if kind == 'kl':
+            out['grad'] = out['grad_kl']
+        else:
+            dmu = c[:, None] * z * e
+            ds = np.sum(c[:, None] * (z ** 2 - 1.0), axis=0)
+            out['grad'] = _backprop(spec, cache, dmu, ds)
     return out
 
 

@@ -17,8 +17,8 @@ DEFAULT_LIBRARY = os.path.join(_HERE, 'libpromp_hip.so')
 
 BASELINE_ZERO, BASELINE_LINEAR_FEATURE, BASELINE_LINEAR_TIME = 0, 1, 2
 INNER_RATIO, INNER_LOGLIK = 0, 1
-OUTER_CLIP, OUTER_RATIO = 0, 1
-LOSS_RATIO, LOSS_CLIP, LOSS_LOGLIK = 0, 1, 2
+OUTER_CLIP, OUTER_RATIO, OUTER_KL = 0, 1, 2
+LOSS_RATIO, LOSS_CLIP, LOSS_LOGLIK, LOSS_KL = 0, 1, 2, 3
 KERNEL_FWD_BWD, KERNEL_HVP, KERNEL_GRAM = 0, 1, 2
 
 
@@ -257,6 +257,11 @@ class Context:
         self._call('promp_meta_grad', float(clip_eps), _ptr(eta, C.c_float), int(inner_kind), int(outer_kind),
                    _ptr(grad, C.c_float), _ptr(stats, C.c_float))
         return grad, dict(loss=float(stats[0]), inner_kl=stats[1:1 + self.K].copy(), outer_kl=float(stats[1 + self.K]))
+
+    def meta_eval(self, clip_eps, inner_kl_coeff, inner_kind=INNER_RATIO, outer_kind=OUTER_CLIP):
+        """forward-only evaluation of the meta-objective (the compute_stats pass): loss, inner_kl [K], outer_kl"""
+        r = self.optimize(0, 0.0, clip_eps, inner_kl_coeff, inner_kind, outer_kind)
+        return dict(loss=r['loss_after'], inner_kl=r['inner_kl'], outer_kl=r['outer_kl'])
 
     def adam_step(self, lr):
         self._call('promp_adam_step', float(lr))

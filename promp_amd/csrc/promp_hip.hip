@@ -216,7 +216,9 @@ int launch_reduce(promp_ctx* c, StepData& S, int table, int mode, const float* c
 }
 
 int loss_kind_inner(int inner_kind) { return inner_kind == PROMP_INNER_LOGLIK ? LOSS_LOGLIK : LOSS_RATIO; }
-int loss_kind_outer(int outer_kind) { return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : LOSS_CLIP; }
+int loss_kind_outer(int outer_kind) {
+    return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : outer_kind == PROMP_OUTER_KL ? LOSS_KL : LOSS_CLIP;
+}
 
 // One evaluation of the meta-objective (+ gradient, + Adam) enqueued on the stream.
 int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_kind, int outer_kind, bool want_grad,
@@ -326,7 +328,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     const int Opad = (dims->obs_dim + 1) & ~1;
-    if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) c->fwd_waves = atoi(e) == 4 ? 4 : 8;   // developer experiment
+    if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) { c->fwd_waves = atoi(e) == 4 ? 4 : 8; }   // developer experiment
     c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, c->fwd_waves, param_count(dims)).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
     if (c->smem_hvp > 160 * 1024) {
@@ -337,6 +339,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     {
         auto k0 = k_fwd_bwd<2, 2, 4>; auto k1 = k_fwd_bwd<1, 1, 4>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
         auto k4 = k_fwd_bwd<2, 2, 8>; auto k5 = k_fwd_bwd<1, 1, 8>;
+
         HIPCHECK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -701,7 +704,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
                          float* kl_out) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
-    if (kind < 0 || kind > 2) return fail(-1, "unknown objective kind %d", kind);
+    if (kind < 0 || kind > 3) return fail(-1, "unknown objective kind %d", kind);
     StepData& S = c->steps[step];
     const int M = c->d.n_tasks;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f)) return -2;

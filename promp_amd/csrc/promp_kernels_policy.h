@@ -28,7 +28,7 @@ struct WorkItem {
     int task, row_begin, row_end, pad;
 };
 
-enum { LOSS_RATIO = 0, LOSS_CLIP = 1, LOSS_LOGLIK = 2 };
+enum { LOSS_RATIO = 0, LOSS_CLIP = 1, LOSS_LOGLIK = 2, LOSS_KL = 3 };   // LOSS_KL: mean KL(old || new) itself (TRPO constraint)
 
 struct PassArgs {
     const float* obs;           // [rows][O]
@@ -168,7 +168,7 @@ PROMP_DEV f32x4 splat4(float v) {
 struct LdsWave {
     int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2;
     int wave0, wave_stride, x, h1, h2, ms;   // per-wave region: offsets of the private buffers inside it
-    int total, HS, WS, Opad4, dbg;
+    int total, HS, WS, Opad4, dbg, XS;
 };
 
 PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
@@ -193,7 +193,10 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     L.HS = (H1 > H2 ? H1 : H2) + 1;
     L.wave0 = o;
     int q = 0;
-    L.x = q;  q += (PROMP_WROWS * PROMP_XS + 3) & ~3;
+    // X tile [16][XS]: the hidden_0 gradient reads it transposed with observation indices up to 31; indices >= O land
+    // in the following row / buffer (finite values) and only produce gradient rows >= O, which are never written out
+    L.XS = L.Opad4 + 1;
+    L.x = q;  q += (PROMP_WROWS * L.XS + 3) & ~3;
     L.h1 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
     L.h2 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
     L.ms = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
@@ -215,7 +218,7 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
 template <int NB1, int NB2, int NW>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int NT = 64 * NW;
-    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, XS = PROMP_XS;
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS;
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
               NP = oS + A;
     const LdsWave L = make_layout_wave(O, H1, H2, NW, NP);
-    const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4;
+    const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4, XS = L.XS;
     float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
           *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
           *sn2s = sm + L.sn2;
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         ess[tid] = expf(-s);
         sn2s[tid] = expf(2.f * s);
     }
-    for (int e = lane; e < PROMP_WROWS * XS; e += 64) Xw[e] = 0.f;   // pad columns stay zero
+    for (int e = lane; e < L.wave_stride; e += 64) wreg[e] = 0.f;   // pad columns stay zero; over-read cells finite
     __syncthreads();
     PROMP_STAMP(1);
 
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         // ---- distribution + objective epilogue
         {
             float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
-            float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f;
+            float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f, dklm0 = 0.f, dklm1 = 0.f, dkls0 = 0.f, dkls1 = 0.f;
             if (own0) {
                 const float s = lss[q], mu = Msw[erow * MS + q];
                 e0 = ess[q];
@@ -395,8 +398,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 dlp += (so0 - s) - 0.5f * (z0 * z0 - zo * zo);
                 sumz2 += z0 * z0;
                 sums += s;
-                const float sn2 = sn2s[q];
-                kl += ((mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2) / (2.f * sn2 + 1e-8f) + s - so0;
+                const float sn2 = sn2s[q], num = (mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2, den = 2.f * sn2 + 1e-8f;
+                kl += num / den + s - so0;
+                dklm0 = -2.f * (mo0 - mu) / den;
+                dkls0 = (-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f;
             }
             if (own1) {
                 const float s = lss[q + 4], mu = Msw[erow * MS + q + 4];
@@ -406,18 +411,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 dlp += (so1 - s) - 0.5f * (z1 * z1 - zo * zo);
                 sumz2 += z1 * z1;
                 sums += s;
-                const float sn2 = sn2s[q + 4];
-                kl += ((mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2) / (2.f * sn2 + 1e-8f) + s - so1;
+                const float sn2 = sn2s[q + 4], num = (mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2, den = 2.f * sn2 + 1e-8f;
+                kl += num / den + s - so1;
+                dklm1 = -2.f * (mo1 - mu) / den;
+                dkls1 = (-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f;
             }
             dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
             sumz2 += shfl_xor_f32(sumz2, 1);  sumz2 += shfl_xor_f32(sumz2, 2);
             sums += shfl_xor_f32(sums, 1);  sums += shfl_xor_f32(sums, 2);
             kl += shfl_xor_f32(kl, 1);  kl += shfl_xor_f32(kl, 2);
-            float c = 0.f;
+            float c = 0.f, ck = 0.f;   // d loss / d logpi, and the weight of the KL cotangents (LOSS_KL only)
             if (rvalid) {
                 const float rho = expf(dlp);
                 float lrow;
-                if (a.loss_kind == LOSS_RATIO) {
+                if (a.loss_kind == LOSS_KL) {
+                    lrow = kl * invN;
+                    ck = invN;
+                } else if (a.loss_kind == LOSS_RATIO) {
                     lrow = -rho * advn * invN;
                     c = -advn * rho * invN;
                 } else if (a.loss_kind == LOSS_CLIP) {
@@ -436,15 +446,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 }
             }
             if (own0) {
-                const float d = c * z0 * e0;
+                const float d = c * z0 * e0 + ck * dklm0;
                 Msw[erow * MS + q] = d;
-                gs0 += c * (z0 * z0 - 1.f);
+                gs0 += c * (z0 * z0 - 1.f) + ck * dkls0;
                 gb30 += d;
             }
             if (own1) {
-                const float d = c * z1 * e1;
+                const float d = c * z1 * e1 + ck * dklm1;
                 Msw[erow * MS + q + 4] = d;
-                gs1 += c * (z1 * z1 - 1.f);
+                gs1 += c * (z1 * z1 - 1.f) + ck * dkls1;
                 gb31 += d;
             }
             // columns >= A of Msw already hold exact zeros (zero-padded W3s / b3s)

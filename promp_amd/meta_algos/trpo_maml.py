@@ -1,0 +1,87 @@
+"""TRPOMAML (reference: meta_policy_search/meta_algos/trpo_maml.py:8-191): MAML with a TRPO outer step.
+BASELINE.json config 5 (run_scripts/maml_run_mujoco.py).  E-MAML's exploration term is not implemented."""
+import numpy as np
+
+from .. import _lib
+from ..optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+from ..utils import logger
+from .base import MAMLAlgo
+
+
+class _DeviceEvaluator(object):
+    """The four graph evaluations the CG optimizer needs, each one pass of the device kernels over steps 0..K."""
+
+    def __init__(self, algo):
+        self.algo = algo
+
+    @property
+    def ctx(self):
+        return self.algo.session.ctx
+
+    def _eta(self):
+        return np.zeros(self.algo.num_inner_grad_steps, np.float32)
+
+    def loss(self):          # -mean_i mean(ratio * adv) at theta'_i   (trpo_maml.py:135,150)
+        return self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['loss']
+
+    def constraint_val(self):   # mean_i mean KL(old || pi_theta'_i)   (trpo_maml.py:133,147)
+        return self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['outer_kl']
+
+    def gradient(self):
+        return self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0]
+
+    def constraint_gradient(self):
+        return self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_KL)[0]
+
+    def get_theta(self):
+        return self.ctx.get_theta()
+
+    def set_theta(self, theta):
+        self.ctx.set_theta(np.asarray(theta, dtype=np.float32))
+
+
+class TRPOMAML(MAMLAlgo):
+    """
+    Args (trpo_maml.py:23-31): policy, name, step_size (trust region), inner_type in {'log_likelihood',
+    'likelihood_ratio'}, exploration (E-MAML; not implemented), inner_lr, meta_batch_size, num_inner_grad_steps,
+    trainable_inner_step_size
+    """
+
+    def __init__(self, *args, name='trpo_maml', step_size=0.01, inner_type='likelihood_ratio', exploration=False, **kwargs):
+        super(TRPOMAML, self).__init__(*args, **kwargs)
+        assert inner_type in ['log_likelihood', 'likelihood_ratio', 'dice']
+        if inner_type == 'dice':
+            raise NotImplementedError          # as the reference (trpo_maml.py:63-64)
+        if exploration:
+            raise NotImplementedError('E-MAML exploration term (trpo_maml.py:137-144) is not implemented')
+        self.step_size = step_size
+        self.inner_type = inner_type
+        self.inner_kind = _lib.INNER_LOGLIK if inner_type == 'log_likelihood' else _lib.INNER_RATIO
+        self.name = name
+        self.exploration = exploration
+        self._optimization_keys = ['observations', 'actions', 'advantages', 'agent_infos']
+        self.optimizer = ConjugateGradientOptimizer()
+        self.optimizer.build_graph(_DeviceEvaluator(self), step_size)
+
+    def optimize_policy(self, all_samples_data, log=True):
+        """trpo_maml.py:161-191"""
+        assert len(all_samples_data) == self.num_inner_grad_steps + 1
+        slots = [self._slot_of(sd, k) for k, sd in enumerate(all_samples_data)]
+        assert slots == list(range(self.num_inner_grad_steps + 1))
+        logger.log('Computing KL before')
+        mean_kl_before = self.optimizer.constraint_val()
+        logger.log('Computing loss before')
+        loss_before = self.optimizer.loss()
+        logger.log('Optimizing')
+        self.optimizer.optimize()
+        logger.log('Computing loss after')
+        loss_after = self.optimizer.loss()
+        logger.log('Computing KL after')
+        mean_kl = self.optimizer.constraint_val()
+        if log:
+            logger.logkv('MeanKLBefore', mean_kl_before)
+            logger.logkv('MeanKL', mean_kl)
+            logger.logkv('LossBefore', loss_before)
+            logger.logkv('LossAfter', loss_after)
+            logger.logkv('dLoss', loss_before - loss_after)
+        self.last_stats = dict(mean_kl_before=mean_kl_before, mean_kl=mean_kl, loss_before=loss_before, loss_after=loss_after)

@@ -160,3 +160,59 @@ def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, comp
     assert t == epochs
     ctx.close()
     return res
+
+
+def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10):
+    """TRPOMAML.optimize_policy (row a15) through the plugin classes.
+
+    The reference's Hessian-vector product is a finite difference with eps = 1e-5 on float32 parameters
+    (conjugate_gradient_optimizer.py:59-89): its result carries percent-level rounding noise that CG amplifies, so the
+    final step of a float32 run is not comparable digit by digit with a float64 run.  Checked instead:
+      (1) the device ingredients, tightly: loss, constraint value, loss gradient, constraint gradient at theta;
+      (2) the step itself, as properties: descent, constraint satisfied, direction correlated with the float64 one.
+    (The host CG / line-search logic is checked exactly in tests/test_trpo_host_logic.py.)"""
+    from oracle import trpo as otrpo
+    from promp_amd import session
+    from promp_amd.meta_algos.trpo_maml import TRPOMAML
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.utils import logger
+    logger.configure(quiet=True)
+    _lib.set_library_for_testing(lib)
+    try:
+        theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
+        spec = op.PolicySpec(O, A, hidden)
+        kind = 'loglik' if inner_type == 'log_likelihood' else 'ratio'
+        alpha = np.full(spec.n_params, 0.1)
+        policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+        policy.set_params(spec.to_ordered_dict(theta))
+        algo = TRPOMAML(policy=policy, step_size=0.01, inner_type=inner_type, inner_lr=0.1, meta_batch_size=M,
+                        num_inner_grad_steps=1)
+        algo.optimizer._cg_iters = cg_iters
+        samples = [[dict(observations=s['observations'], actions=s['actions'], advantages=s['advantages'],
+                         agent_infos=s['agent_infos']) for s in step] for step in all_slabs]
+        # (1) ingredients at theta
+        for k, sd in enumerate(samples):
+            algo._slot_of(sd, k)
+        ev = algo.optimizer._ev
+        t64 = theta.astype(np.float64)
+        r_loss = pm.meta_objective_and_grad(spec, t64, all_slabs, alpha, np.zeros(1), 0.0, kind, 'ratio')
+        r_kl = pm.meta_objective_and_grad(spec, t64, all_slabs, alpha, np.zeros(1), 0.0, kind, 'kl')
+        np.testing.assert_allclose(ev.loss(), r_loss['loss'], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ev.constraint_val(), r_loss['outer_kl'], rtol=1e-4, atol=1e-7)
+        assert rel_max(ev.gradient(), r_loss['grad']) < 1e-4
+        assert rel_max(ev.constraint_gradient(), r_kl['grad']) < 1e-4
+        # (2) the step
+        algo.optimize_policy(samples, log=False)
+        ref = otrpo.trpo_maml_step(spec, theta, all_slabs, alpha, inner_kind=kind, max_kl=0.01, cg_iters=cg_iters)
+        st, last = algo.last_stats, algo.optimizer.last
+        d, dr = last['descent_direction'].astype(np.float64), ref['descent_direction']
+        cos = d.dot(dr) / (np.linalg.norm(d) * np.linalg.norm(dr))
+        assert cos > 0.5, cos
+        if not last['rejected']:
+            assert st['loss_after'] < st['loss_before'] and st['mean_kl'] <= 0.01 * 1.001
+        else:
+            np.testing.assert_allclose(st['loss_after'], st['loss_before'], rtol=1e-6)     # parameters restored
+        return st, ref
+    finally:
+        _lib.set_library_for_testing(None)
+        session._current = None

@@ -59,3 +59,27 @@ def test_loss_grad_h32_wide_obs(lib):
 
 def test_hvp_h32_wide_obs(lib):
     pc.check_hvp(lib, 15, M=1, P=1, T=40, O=31, A=8, hidden=(32, 32))
+
+
+def test_kl_objective_gradient(lib):
+    # LOSS_KL (3): mean KL(old||new) and its gradient, the building block of the TRPO constraint
+    import numpy as np
+    from oracle import policy as op, promp as pm
+    from promp_amd import _lib
+    theta, all_slabs, all_paths = helpers.make_promp_case(16, 2, 2, 20, 5, 3, (32, 32), 1)
+    spec = op.PolicySpec(5, 3, (32, 32))
+    ctx = pc.make_ctx(lib, 2, 5, 3, (32, 32), 1, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    th = np.tile(theta, (2, 1))
+    ctx.set_task_thetas(th)
+    g, l, k = ctx.eval_loss_grad(1, _lib.LOSS_KL)
+    for i in range(2):
+        r = pm.loss_and_grad(spec, theta.astype(np.float64), all_slabs[1][i], 'kl', False)
+        np.testing.assert_allclose(l[i], r['loss'], rtol=1e-4)
+        np.testing.assert_allclose(k[i], r['kl'], rtol=1e-4)
+        assert pc.rel_max(g[i], r['grad']) < 1e-4
+    ctx.close()
+
+
+def test_trpo_maml_step(lib):
+    pc.check_trpo(lib, 17, M=2, P=1, T=20, O=4, A=2, hidden=(32, 32), cg_iters=2)

@@ -173,3 +173,9 @@ def test_single_rank_communicator(lib):
     ctx.comm_init(0, 1, _lib.comm_unique_id(lib))
     np.testing.assert_array_equal(ctx.allreduce_f64([1.0, 2.0]), [1.0, 2.0])
     ctx.close()
+
+
+def test_kl_objective_and_trpo_maml_step(lib):
+    # row a15 / BASELINE config 5 shapes (reduced M): device ingredients tight, step properties (see parity_checks)
+    st, ref = pc.check_trpo(lib, 61, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood')
+    st2, _ = pc.check_trpo(lib, 62, M=3, P=4, T=60, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio')
