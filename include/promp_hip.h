@@ -130,6 +130,12 @@ int promp_get_task_thetas(promp_ctx* ctx, float* theta_tasks);
  * explicit per-task parameters => raw log_std (policies/gaussian_mlp_policy.py:182).  Asynchronous. */
 int promp_inner_adapt(promp_ctx* ctx, int step, int inner_kind);
 
+/* ---- rollout-side inference: MetaGaussianMLPPolicy.get_actions
+ * (policies/meta_gaussian_mlp_policy.py:99-157): mean network of every task's CURRENT parameters
+ * (theta replicated after promp_switch_to_pre_update, adapted after promp_inner_adapt) on
+ * obs [n_tasks, batch, O] -> mean_out [n_tasks, batch, A].  The Gaussian noise is added by the caller. */
+int promp_policy_forward(promp_ctx* ctx, const float* obs, int batch, float* mean_out);
+
 /* ---- rows a11-a13 ---------------------------------------------------------------------------
  * One evaluation of the ProMP meta-objective (meta_algos/pro_mp.py:67-163) and of its exact
  * gradient (what tf.gradients yields through meta_algos/base.py:206, i.e. including the

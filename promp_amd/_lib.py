@@ -66,6 +66,7 @@ SIGNATURES = {
     'promp_set_task_thetas': (C.c_int, [_P, _F]),
     'promp_get_task_thetas': (C.c_int, [_P, _F]),
     'promp_inner_adapt': (C.c_int, [_P, C.c_int, C.c_int]),
+    'promp_policy_forward': (C.c_int, [_P, _F, C.c_int, _F]),
     'promp_meta_grad': (C.c_int, [_P, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
     'promp_adam_step': (C.c_int, [_P, C.c_float]),
     'promp_optimize': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
@@ -244,6 +245,14 @@ class Context:
     def get_task_thetas(self):
         out = np.empty((self.n_tasks, self.n_params), np.float32)
         self._call('promp_get_task_thetas', _ptr(out, C.c_float))
+        return out
+
+    def policy_forward(self, obs):
+        """obs [n_tasks, B, O] -> means [n_tasks, B, A] under every task's current parameters"""
+        obs = _f32(obs)
+        assert obs.ndim == 3 and obs.shape[0] == self.n_tasks
+        out = np.empty((self.n_tasks, obs.shape[1], self.dims.act_dim), np.float32)
+        self._call('promp_policy_forward', _ptr(obs, C.c_float), int(obs.shape[1]), _ptr(out, C.c_float))
         return out
 
     # ---- algorithm ----

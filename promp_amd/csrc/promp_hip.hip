@@ -78,7 +78,7 @@ struct promp_ctx {
     std::vector<StepData> steps;
     float *theta = nullptr, *step_sizes = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     long long adam_t = 0;
-    float *theta_tasks = nullptr, *chain = nullptr, *lam = nullptr, *vbuf = nullptr, *vw2t = nullptr;
+    float *theta_tasks = nullptr, *chain = nullptr, *lam = nullptr, *vbuf = nullptr;
     float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
     float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
     double *gram_partials = nullptr, *red64 = nullptr;
@@ -90,6 +90,8 @@ struct promp_ctx {
     int rank = 0, nranks = 1;
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
+    float* fwd_buf = nullptr;            // staging for promp_policy_forward
+    size_t fwd_capacity = 0;
     unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
     bool dbg_enabled = false;
 };
@@ -175,7 +177,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
     a.theta = theta; a.theta_task_stride = theta_stride;
-    a.vdir = c->vbuf; a.vw2t = c->vw2t;
+    a.vdir = c->vbuf;
     a.partials = c->partials; a.partial_stride = c->partial_stride;
     a.O = c->d.obs_dim; a.A = c->d.act_dim;
     a.loss_kind = loss_kind; a.clip_eps = clip_eps; a.clip_log_std = clip_ls;
@@ -205,11 +207,10 @@ int launch_reduce(promp_ctx* c, StepData& S, int table, int mode, const float* c
     ReduceArgs r;
     r.partials = c->partials; r.partial_stride = c->partial_stride;
     r.task_wg_offsets = S.task_wg_offsets[table];
-    r.NP = c->NP; r.H1 = c->d.hidden1; r.H2 = c->d.hidden2;
-    r.oW2 = c->d.obs_dim * c->d.hidden1 + c->d.hidden1;
+    r.NP = c->NP;
     r.step_sizes = c->step_sizes; r.mode = mode;
     r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
-    r.lam = c->lam; r.v = c->vbuf; r.vw2t = c->vw2t; r.scal = scal;
+    r.lam = c->lam; r.v = c->vbuf; r.scal = scal;
     PROMP_LAUNCH(k_reduce_task, dim3((c->NP + 2 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, r);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -327,7 +328,6 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
-    const int Opad = (dims->obs_dim + 1) & ~1;
     if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) { c->fwd_waves = atoi(e) == 4 ? 4 : 8; }   // developer experiment
     c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, c->fwd_waves, param_count(dims)).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
@@ -360,7 +360,6 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->adam_m, NP); rc |= dev_alloc(&c->adam_v, NP);
     rc |= dev_alloc(&c->theta_tasks, MNP); rc |= dev_alloc(&c->chain, (size_t)(K + 1) * MNP);
     rc |= dev_alloc(&c->lam, MNP); rc |= dev_alloc(&c->vbuf, MNP);
-    rc |= dev_alloc(&c->vw2t, (size_t)M * dims->hidden1 * dims->hidden2);
     rc |= dev_alloc(&c->partials, (size_t)c->max_work * c->partial_stride);
     rc |= dev_alloc(&c->scal_inner, (size_t)K * M * 2); rc |= dev_alloc(&c->scal_outer, (size_t)M * 2);
     rc |= dev_alloc(&c->scal_tmp, (size_t)M * 2);
@@ -396,9 +395,9 @@ void promp_ctx_destroy(promp_ctx* c) {
     if (c->comm) ncclCommDestroy(c->comm);
 #endif
     for (auto& S : c->steps) free_step(S);
-    void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf, c->vw2t,
+    void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
-                    c->gram_partials, c->red64};
+                    c->gram_partials, c->red64, c->fwd_buf, c->dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& s : c->prof_slots)
@@ -656,6 +655,30 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     return launch_reduce(c, S, 0, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
 }
 
+int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_out) {
+    if (!c || !obs || !mean_out) return fail(-1, "NULL argument");
+    if (batch < 1) return fail(-1, "batch must be positive");
+    const int M = c->d.n_tasks, O = c->d.obs_dim, A = c->d.act_dim;
+    const size_t n_obs = (size_t)M * batch * O, n_out = (size_t)M * batch * A;
+    if (n_obs + n_out > c->fwd_capacity) {
+        if (c->fwd_buf) (void)hipFree(c->fwd_buf);
+        c->fwd_buf = nullptr;
+        c->fwd_capacity = 2 * (n_obs + n_out);
+        HIPCHECK(hipMalloc((void**)&c->fwd_buf, sizeof(float) * c->fwd_capacity));
+    }
+    float* d_obs = c->fwd_buf;
+    float* d_out = c->fwd_buf + n_obs;
+    HIPCHECK(hipMemcpyAsync(d_obs, obs, sizeof(float) * n_obs, hipMemcpyHostToDevice, c->stream));
+    ForwardArgs f;
+    f.obs = d_obs; f.theta_tasks = c->theta_tasks; f.mean = d_out;
+    f.B = batch; f.O = O; f.A = A; f.H1 = c->d.hidden1; f.H2 = c->d.hidden2;
+    PROMP_LAUNCH(k_policy_forward, dim3(M), 256, 0, c->stream, f);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(mean_out, d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_kind, int outer_kind, float* grad_out,
                     float* stats_out) {
     if (!c || !eta) return fail(-1, "NULL argument");
@@ -723,13 +746,8 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     if (!c || !v || !out) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
-    const int M = c->d.n_tasks, NP = c->NP, H1 = c->d.hidden1, H2 = c->d.hidden2;
-    const int oW2 = c->d.obs_dim * H1 + H1;
-    std::vector<float> vt((size_t)M * H1 * H2);
-    for (int i = 0; i < M; ++i)
-        for (int k1 = 0; k1 < H1; ++k1)
-            for (int j2 = 0; j2 < H2; ++j2) vt[(size_t)i * H1 * H2 + (size_t)j2 * H1 + k1] = v[(size_t)i * NP + oW2 + k1 * H2 + j2];
-    if (copy_in(c, c->vbuf, v, (size_t)M * NP) || copy_in(c, c->vw2t, vt.data(), vt.size())) return -2;
+    const int M = c->d.n_tasks, NP = c->NP;
+    if (copy_in(c, c->vbuf, v, (size_t)M * NP)) return -2;
     HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
     if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw)) return -2;
     if (launch_reduce(c, S, 0, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;

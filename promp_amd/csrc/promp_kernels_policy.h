@@ -9,18 +9,15 @@
 // meta_algos/base.py:192-215, policies/networks/mlp.py:65-119,
 // policies/distributions/diagonal_gaussian.py:16-109 of the reference).
 //
-// Work decomposition.  A workgroup (256 threads = 4 wavefronts, one per SIMD) owns a contiguous
-// row range of ONE task and walks it in tiles of 64 rows.  Per tile every GEMM of the pass runs
-// on the matrix cores in exact FP32 (32x32x2 tiles; 16x16x4 for the thin A<=8 output layer), with
-// operands read from LDS: activations live in LDS as [row][unit] (stride = units+1, an odd stride
-// is bank-conflict-free for both the row-major A reads and the transposed weight-gradient reads),
-// the task's parameters as [in][out(+1)].  Weight-gradient tiles stay in accumulator registers
-// across all tiles of the workgroup and are written once, as one partial per workgroup;
-// a second tiny kernel adds the partials of a task in fixed order (bitwise reproducible).
+// Work decomposition.  A workgroup owns a contiguous row range of ONE task and shares that task's parameters in LDS;
+// each of its waves walks its own 16-row tiles through the whole chain with private LDS tiles (no workgroup barrier in
+// the tile loop).  Every GEMM runs on the matrix cores in exact FP32 (v_mfma_f32_16x16x4_f32), operands read from LDS:
+// activations as [row][unit] with an odd stride, parameters as [in][out(+1)].  Weight-gradient tiles stay in registers
+// across all tiles of the wave; the waves' tiles are added in a fixed order and written once, as one partial per
+// workgroup; a second tiny kernel adds the partials of a task in fixed order (bitwise reproducible).
 #pragma once
 #include "promp_device.h"
 
-#define PROMP_TILE 64
 #define PROMP_MS 17          // row stride of the [64][16] mean / d-mean staging tiles
 #define PROMP_PARTIAL_EXTRA 4  // loss, kl, 2 spare
 
@@ -42,7 +39,6 @@ struct PassArgs {
     const float* theta;           // [Theta] or [tasks][Theta]
     long long theta_task_stride;  // 0 => shared
     const float* vdir;            // hvp: [tasks][Theta]
-    const float* vw2t;            // hvp: [tasks][H2*H1] transposed copy of v's hidden_1 kernel
     float* partials;              // [grid][partial_stride]
     int partial_stride;
     int O, A;
@@ -53,94 +49,6 @@ struct PassArgs {
     float kl_weight;
     unsigned long long* dbg;      // optional cycle stamps of block 0 / lane 0 (tools/phase_timing.py), else NULL
 };
-
-struct LdsLayout {
-    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, vls, zero;
-    int xs, h1, h2, ds, ms, rh1, rh2, qs, ms2;
-    int total;  // floats
-    int XS, HS;
-};
-
-PROMP_HD LdsLayout make_layout(int Opad, int H1, int H2, int hvp) {
-    LdsLayout L;
-    int o = 0;
-#define PROMP_TAKE(field, n) \
-    L.field = o;             \
-    o += ((n) + 3) & ~3
-    PROMP_TAKE(w1, Opad * H1);
-    PROMP_TAKE(b1, H1);
-    PROMP_TAKE(w2, H1 * (H2 + 1));
-    PROMP_TAKE(b2, H2);
-    PROMP_TAKE(w3, H2 * 16);
-    PROMP_TAKE(w3t, 8 * H2);
-    PROMP_TAKE(b3, 16);
-    PROMP_TAKE(ls, 16);
-    PROMP_TAKE(lmask, 16);
-    PROMP_TAKE(vls, 16);
-    PROMP_TAKE(zero, 4);
-    L.XS = ((Opad > 32 ? Opad : 32) + 1) | 1;
-    L.HS = (H1 > H2 ? H1 : H2) + 1;
-    PROMP_TAKE(xs, PROMP_TILE * L.XS);
-    PROMP_TAKE(h1, PROMP_TILE * L.HS);
-    PROMP_TAKE(h2, PROMP_TILE * L.HS);
-    PROMP_TAKE(ds, PROMP_TILE * L.HS);
-    PROMP_TAKE(ms, PROMP_TILE * PROMP_MS);
-    L.rh1 = L.rh2 = L.qs = L.ms2 = 0;
-    if (hvp) {
-        PROMP_TAKE(rh1, PROMP_TILE * L.HS);
-        PROMP_TAKE(rh2, PROMP_TILE * L.HS);
-        PROMP_TAKE(qs, PROMP_TILE * L.HS);
-        PROMP_TAKE(ms2, PROMP_TILE * PROMP_MS);
-    }
-#undef PROMP_TAKE
-    L.total = o;
-    return L;
-}
-
-// Stage one task's parameters in LDS.  th is the flat [Theta] vector.
-template <int H1, int H2>
-PROMP_DEV void stage_params(float* sm, const LdsLayout& L, const float* th, int O, int A, int Opad, int tid,
-                            int clip_log_std, float min_log_std) {
-    const int oW1 = 0, ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A,
-              oS = ob3 + A;
-    float* W1s = sm + L.w1;
-    for (int e = tid; e < Opad * H1; e += 256) W1s[e] = (e < O * H1) ? th[oW1 + e] : 0.f;
-    float* W2s = sm + L.w2;
-    for (int e = tid; e < H1 * H2; e += 256) {
-        const int k = e / H2, j = e - k * H2;
-        W2s[k * (H2 + 1) + j] = th[oW2 + e];
-    }
-    float* W3s = sm + L.w3;
-    for (int e = tid; e < H2 * 16; e += 256) {
-        const int k = e >> 4, j = e & 15;
-        W3s[e] = (j < A) ? th[oW3 + k * A + j] : 0.f;
-    }
-    float* W3Ts = sm + L.w3t;
-    for (int e = tid; e < 8 * H2; e += 256) {
-        const int aa = e / H2, k = e - aa * H2;
-        W3Ts[e] = (aa < A) ? th[oW3 + k * A + aa] : 0.f;
-    }
-    if (tid < H1) sm[L.b1 + tid] = th[ob1 + tid];
-    if (tid < H2) sm[L.b2 + tid] = th[ob2 + tid];
-    if (tid < 16) {
-        sm[L.b3 + tid] = (tid < A) ? th[ob3 + tid] : 0.f;
-        const float sr = (tid < A) ? th[oS + tid] : 0.f;
-        // tf.maximum(log_std_var, min_log_std): gradient flows to the variable iff var >= min
-        const bool clipped = clip_log_std && (sr < min_log_std);
-        sm[L.ls + tid] = clipped ? min_log_std : sr;
-        sm[L.lmask + tid] = clipped ? 0.f : 1.f;
-    }
-    if (tid < 4) sm[L.zero + tid] = 0.f;
-    float* Xs = sm + L.xs;
-    for (int e = tid; e < PROMP_TILE * L.XS; e += 256) Xs[e] = 0.f;
-}
-
-PROMP_DEV void load_obs_tile(float* Xs, int XS, const float* obs, long long base, int nrows, int O, int tid) {
-    for (int e = tid; e < PROMP_TILE * O; e += 256) {
-        const int r = e / O, c = e - r * O;
-        Xs[r * XS + c] = (r < nrows) ? obs[base * O + e] : 0.f;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_fwd_bwd -- wave-private pipelines.
@@ -1103,11 +1011,10 @@ struct ReduceArgs {
     int partial_stride;
     const int* task_wg_offsets;  // [tasks+1]: workgroups of task i are [o[i], o[i+1])
     int NP;                      // Theta
-    int H1, H2, oW2;
     const float* step_sizes;     // [Theta]
     // mode 0 (inner step): next[i] = cur[i] - alpha * g ; scal[i] = {loss, kl}
-    // mode 1 (outer)     : lam[i] = g ; v[i] = alpha * g ; vw2t ; scal[i] = {loss, kl}
-    // mode 2 (hvp)       : lam[i] += g ; v[i] = alpha * lam[i] ; vw2t ; scal[i] = {-, kl}
+    // mode 1 (outer)     : lam[i] = g ; v[i] = alpha * g ; scal[i] = {loss, kl}
+    // mode 2 (hvp)       : lam[i] += g ; v[i] = alpha * lam[i] ; scal[i] = {-, kl}
     // mode 3 (plain)     : lam[i] = g ; scal
     int mode;
     const float* cur;            // [Theta] or [tasks][Theta]
@@ -1115,7 +1022,6 @@ struct ReduceArgs {
     float* next;                 // [tasks][Theta]
     float* lam;                  // [tasks][Theta]
     float* v;                    // [tasks][Theta]
-    float* vw2t;                 // [tasks][H2*H1]
     float* scal;                 // [tasks][2]
 };
 
@@ -1140,13 +1046,7 @@ __global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
     if (a.mode == 2) lam += a.lam[tj];
     a.lam[tj] = lam;
     if (a.mode == 3) return;
-    const float vv = a.step_sizes[j] * lam;
-    a.v[tj] = vv;
-    const int q = j - a.oW2;
-    if (q >= 0 && q < a.H1 * a.H2) {
-        const int k1 = q / a.H2, j2 = q - k1 * a.H2;
-        a.vw2t[(long long)task * a.H1 * a.H2 + j2 * a.H1 + k1] = vv;
-    }
+    a.v[tj] = a.step_sizes[j] * lam;
 }
 
 // Task sum of lam (gradient) and of the per-task scalars -> red[NP + K + 2]
@@ -1229,4 +1129,44 @@ __global__ void __launch_bounds__(256) k_replicate(float* dst, const float* src,
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j < NP)
         for (int i = 0; i < n_tasks; ++i) dst[(long long)i * NP + j] = src[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_policy_forward: mean network of every task's CURRENT parameters on a small batch of observations
+// (MetaGaussianMLPPolicy.get_actions, policies/meta_gaussian_mlp_policy.py:99-157: [tasks][B][O] -> [tasks][B][A]).
+// Rollout-time inference is a few hundred rows per environment step: one workgroup per task, one thread per row,
+// weights read through the scalar/L1 path; it is latency-, not throughput-bound.
+// grid = tasks, block = 256
+// ---------------------------------------------------------------------------------------------
+struct ForwardArgs {
+    const float* obs;          // [tasks][B][O]
+    const float* theta_tasks;  // [tasks][Theta]
+    float* mean;               // [tasks][B][A]
+    int B, O, A, H1, H2;
+};
+
+__global__ void __launch_bounds__(256) k_policy_forward(ForwardArgs a) {
+    const int task = blockIdx.x;
+    const int O = a.O, A = a.A, H1 = a.H1, H2 = a.H2;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, NP = ob3 + 2 * A;
+    const float* th = a.theta_tasks + (long long)task * NP;
+    for (int row = threadIdx.x; row < a.B; row += 256) {
+        const float* x = a.obs + ((long long)task * a.B + row) * O;
+        float h1[64], h2[64];
+        for (int j = 0; j < H1; ++j) {
+            float z = th[ob1 + j];
+            for (int k = 0; k < O; ++k) z = fmaf(x[k], th[k * H1 + j], z);
+            h1[j] = fast_tanh(z);
+        }
+        for (int j = 0; j < H2; ++j) {
+            float z = th[ob2 + j];
+            for (int k = 0; k < H1; ++k) z = fmaf(h1[k], th[oW2 + k * H2 + j], z);
+            h2[j] = fast_tanh(z);
+        }
+        for (int j = 0; j < A; ++j) {
+            float z = th[ob3 + j];
+            for (int k = 0; k < H2; ++k) z = fmaf(h2[k], th[oW3 + k * A + j], z);
+            a.mean[((long long)task * a.B + row) * A + j] = z;
+        }
+    }
 }

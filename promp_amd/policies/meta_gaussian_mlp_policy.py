@@ -6,8 +6,9 @@ Parameters live on the GPU as one flat float32 vector in the reference's Ordered
 set_params / policies_params_vals / update_task_parameters expose them under the reference's names
 ('mean_network/hidden_0/kernel', ..., 'log_std_network/log_std_var').
 
-get_actions (rollout-side inference, SURVEY.md 8f "next" row 1) is evaluated on the host here: it belongs to the
-sampling stage that precedes the timed hot path and will move to the device with the sampler.
+get_actions (rollout-side inference, SURVEY.md 8f "next" row 1) evaluates the mean network on the device
+(promp_policy_forward) under every task's current parameters; the Gaussian exploration noise is drawn on the host
+with NumPy's RNG (the reference draws it with TensorFlow's, so rollouts were never bit-reproducible across runs).
 """
 from collections import OrderedDict
 
@@ -127,16 +128,27 @@ class MetaGaussianMLPPolicy(object):
         """observations: list[M] of [B,O] -> (list[M] of [B,A], list[M] of list[B] of {mean, log_std})
         (meta_gaussian_mlp_policy.py:99-157)"""
         assert len(observations) == self.meta_batch_size
-        thetas = self._task_thetas()
+        batch_size = observations[0].shape[0]
+        assert all(obs.shape[0] == batch_size for obs in observations)
+        s = self.session
+        ctx = s.ensure()
+        if s.task_thetas is not None:          # parameters set while no context existed yet
+            ctx.set_task_thetas(s.task_thetas)
+            s.task_thetas = None
+        means = ctx.policy_forward(np.stack([np.asarray(o, dtype=np.float32).reshape(batch_size, -1) for o in observations]))
+        raws = self._log_std_tasks()
         actions, agent_infos = [], []
-        for i, obs in enumerate(observations):
-            th = thetas[i]
-            mean = self._mean(th, obs)
-            raw = th[-self.action_dim:]
+        for i in range(self.meta_batch_size):
+            raw = raws[i]
             log_std = np.maximum(raw, self.min_log_std) if self._pre_update_mode else raw   # gaussian_mlp_policy.py:71 vs :182
-            actions.append(mean + np.random.normal(size=mean.shape) * np.exp(raw))            # noise uses the raw variable (:74)
-            agent_infos.append([dict(mean=m, log_std=log_std) for m in mean])
+            actions.append(means[i] + np.random.normal(size=means[i].shape) * np.exp(raw))   # noise uses the raw variable (:74)
+            agent_infos.append([dict(mean=m, log_std=log_std) for m in means[i]])
         return actions, agent_infos
+
+    def _log_std_tasks(self):
+        """[M, A] raw log_std of every task's current parameters (cached per parameter version)"""
+        th = self._task_thetas()
+        return th[:, -self.action_dim:]
 
     def get_action(self, observation, task=0):
         obs = [np.expand_dims(observation, 0)] * self.meta_batch_size

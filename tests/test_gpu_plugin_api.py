@@ -28,3 +28,7 @@ def test_policy_algo_api_two_inner_steps():
 
 def test_trainer_end_to_end_point_env():
     scen.run_trainer_scenario(n_itr=3)
+
+
+def test_get_actions_on_device():
+    scen.run_get_actions_scenario(M=8, B=20, O=20, A=6, hidden=(64, 64))

@@ -147,3 +147,39 @@ def test_policy_algo_api(emu):
 
 def test_trainer_end_to_end(emu):
     run_trainer_scenario(n_itr=1)
+
+
+def run_get_actions_scenario(M=3, B=7, O=5, A=3, hidden=(32, 32)):
+    """MetaGaussianMLPPolicy.get_actions: device means == oracle forward; agent_infos layout of the reference
+    (reference tests/test_policies.py:43-64: dist info from get_actions is consistent with the parameters)."""
+    from oracle import policy as op
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    np.random.seed(11)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+    spec = op.PolicySpec(O, A, hidden)
+    theta = spec.from_ordered_dict(policy.get_param_values())
+    obs = [np.random.randn(B, O).astype(np.float32) for _ in range(M)]
+    actions, infos = policy.get_actions(obs)
+    assert len(actions) == M and actions[0].shape == (B, A) and len(infos) == M and len(infos[0]) == B
+    for i in range(M):
+        mu, s, _ = op.forward(spec, theta, obs[i], clip_log_std=True)
+        np.testing.assert_allclose(np.stack([d['mean'] for d in infos[i]]), mu, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(infos[i][0]['log_std'], s, rtol=1e-6)
+    # post-update: per-task parameters
+    new = []
+    for i in range(M):
+        d = policy.get_param_values()
+        for k in d:
+            d[k] = d[k] + 0.01 * (i + 1)
+        new.append(d)
+    policy.update_task_parameters(new)
+    actions, infos = policy.get_actions(obs)
+    for i in range(M):
+        mu, s, _ = op.forward(spec, spec.from_ordered_dict(new[i]), obs[i], clip_log_std=False)
+        np.testing.assert_allclose(np.stack([d['mean'] for d in infos[i]]), mu, rtol=1e-5, atol=1e-6)
+    a, info = policy.get_action(obs[0][0], task=1)
+    assert a.shape == (A,) and set(info.keys()) == {'mean', 'log_std'}
+
+
+def test_get_actions(emu):
+    run_get_actions_scenario()
