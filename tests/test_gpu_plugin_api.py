@@ -32,3 +32,24 @@ def test_trainer_end_to_end_point_env():
 
 def test_get_actions_on_device():
     scen.run_get_actions_scenario(M=8, B=20, O=20, A=6, hidden=(64, 64))
+
+
+def test_promp_learns_on_point_env(tmp_path):
+    """End to end on a real environment: the reference's point-mass recipe
+    (run_scripts/pro-mp_run_point_mass.py shapes) improves the post-adaptation return."""
+    import csv
+    import importlib.util
+    import os
+    from promp_amd.utils import logger
+    spec = importlib.util.spec_from_file_location('run_point', os.path.join(scen.__file__.rsplit('/tests/', 1)[0], 'run_scripts', 'pro-mp_run_point_mass.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = dict(mod.DEFAULT, n_itr=40, meta_batch_size=8, rollouts_per_meta_task=10, max_path_length=25, seed=3)
+    logger.configure(dir=str(tmp_path), quiet=True)
+    mod.main(cfg)
+    rows = list(csv.DictReader(open(os.path.join(str(tmp_path), 'progress.csv'))))
+    assert len(rows) == 40
+    post = [float(r['Step_1-AverageReturn']) for r in rows]
+    first, last = sum(post[:5]) / 5, sum(post[-5:]) / 5
+    assert last > first + 0.05 * abs(first), (first, last)       # returns are negative distances: closer to the goal
+    logger.configure(quiet=True)
