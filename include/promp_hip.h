@@ -110,6 +110,12 @@ int promp_download_processed(promp_ctx* ctx, int step, float* returns, float* ad
  * reference stores back into every path dict (samplers/base.py:104,159).  Either pointer may be NULL. */
 int promp_download_raw(promp_ctx* ctx, int step, double* returns64, double* raw_advantages64);
 
+/* LinearBaseline.set_params / predict (baselines/linear_baseline.py:17-53) for the paths uploaded in `step`:
+ * promp_set_coeffs installs coefficients [n_tasks, feature_dim(kind)] (float64); promp_predict_baseline evaluates
+ * b = Phi . w per row with them -> baselines_out [rows] float64 (kind ZERO gives zeros). */
+int promp_set_coeffs(promp_ctx* ctx, int step, int baseline_kind, const double* coeffs);
+int promp_predict_baseline(promp_ctx* ctx, int step, int baseline_kind, double* baselines_out);
+
 /* Use caller-provided advantages for a step instead of promp_process_samples' (float32 [rows]). */
 int promp_set_advantages(promp_ctx* ctx, int step, const float* advantages);
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     'promp_process_samples': (C.c_int, [_P, C.c_int, C.POINTER(ProcOpts)]),
     'promp_download_processed': (C.c_int, [_P, C.c_int, _F, _F, _D, _D, _D, _D]),
     'promp_download_raw': (C.c_int, [_P, C.c_int, _D, _D]),
+    'promp_set_coeffs': (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    'promp_predict_baseline': (C.c_int, [_P, C.c_int, C.c_int, _D]),
     'promp_set_advantages': (C.c_int, [_P, C.c_int, _F]),
     'promp_set_theta': (C.c_int, [_P, _F]),
     'promp_get_theta': (C.c_int, [_P, _F]),
@@ -204,6 +206,15 @@ class Context:
         ret, adv = np.empty(R, np.float64), np.empty(R, np.float64)
         self._call('promp_download_raw', int(step), _ptr(ret, C.c_double), _ptr(adv, C.c_double))
         return ret, adv
+
+    def set_coeffs(self, step, baseline_kind, coeffs):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+        self._call('promp_set_coeffs', int(step), int(baseline_kind), _ptr(coeffs, C.c_double))
+
+    def predict_baseline(self, step, baseline_kind):
+        out = np.empty(self.step_rows[step], np.float64)
+        self._call('promp_predict_baseline', int(step), int(baseline_kind), _ptr(out, C.c_double))
+        return out
 
     def set_advantages(self, step, adv):
         adv = _f32(adv)

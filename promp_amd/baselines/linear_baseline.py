@@ -43,13 +43,18 @@ class LinearBaseline(Baseline):
         ctx.close()
 
     def predict(self, path):
-        """Phi . w through the device: with rewards 0 and discount 1, lambda 1 the GAE recursion gives
-        adv[t] = -b[t], hence b = -adv (zeros when unfit, linear_baseline.py:31-32)."""
+        """Phi . w for one path, evaluated on the device (zeros when unfit, linear_baseline.py:31-32)."""
         n = len(path['observations'])
         if self._coeffs is None:
             return np.zeros(n)
-        raise NotImplementedError('standalone predict() with externally set coefficients is not on the device path; '
-                                  'MetaSampleProcessor fuses fit+predict (see promp_amd/samplers)')
+        from collections import OrderedDict
+        fl = _lib.flatten_paths(OrderedDict([(0, [dict(observations=path['observations'], rewards=np.zeros(n))])]))
+        ctx = _lib.Context(1, fl['obs'].shape[1], 1, (32, 32), 1, max_rows=n, max_paths=1)
+        ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
+        ctx.set_coeffs(0, self.kind, np.asarray(self._coeffs, dtype=np.float64).reshape(1, -1))
+        out = ctx.predict_baseline(0, self.kind)
+        ctx.close()
+        return out
 
     def log_diagnostics(self, paths, prefix):
         pass

@@ -530,6 +530,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     a.ret64 = S.ret64; a.ret32 = S.ret32; a.adv64 = S.adv64; a.adv32 = S.adv32;
     a.path_ret0 = S.path_ret0; a.path_undisc = S.path_undisc; a.path_rsq = S.path_rsq; a.path_mom = S.path_mom;
     a.gram_partials = c->gram_partials; a.coeffs = S.coeffs; a.coeff_stride = c->coeff_stride;
+    a.bl64 = nullptr;
     S.feat_dim = a.D;
     hipStream_t st = c->stream;
     PROMP_LAUNCH(k_returns, dim3(S.n_paths), 64, 0, st, a);
@@ -591,6 +592,44 @@ int promp_download_raw(promp_ctx* c, int step, double* ret64, double* adv64) {
     if (!S.processed) return fail(-3, "step %d has not been processed", step);
     if (ret64) HIPCHECK(hipMemcpyAsync(ret64, S.ret64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
     if (adv64) HIPCHECK(hipMemcpyAsync(adv64, S.adv64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int promp_set_coeffs(promp_ctx* c, int step, int kind, const double* coeffs) {
+    if (!c || !coeffs) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (kind < 1 || kind > 2) return fail(-1, "coefficients exist for the linear baselines only");
+    StepData& S = c->steps[step];
+    const int D = feature_dim(&c->d, kind), M = c->d.n_tasks;
+    std::vector<double> tmp((size_t)M * c->coeff_stride, 0.0);
+    for (int i = 0; i < M; ++i) memcpy(tmp.data() + (size_t)i * c->coeff_stride, coeffs + (size_t)i * D, sizeof(double) * D);
+    HIPCHECK(hipMemcpyAsync(S.coeffs, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    S.feat_dim = D;
+    return 0;
+}
+
+int promp_predict_baseline(promp_ctx* c, int step, int kind, double* out) {
+    if (!c || !out) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (kind < 0 || kind > 2) return fail(-1, "unknown baseline kind %d", kind);
+    StepData& S = c->steps[step];
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    SampleArgs a;
+    memset(&a, 0, sizeof a);
+    a.obs = S.obs; a.rew = S.rew; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
+    a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets;
+    a.O = c->d.obs_dim; a.kind = kind; a.D = feature_dim(&c->d, kind);
+    a.gamma = 1.0; a.lam = 1.0;
+    a.adv64 = S.adv64; a.path_mom = S.path_mom; a.coeffs = S.coeffs; a.coeff_stride = c->coeff_stride;
+    a.bl64 = S.ret64;                              // scratch: returns of this step are recomputed by process_samples
+    if (kind == PROMP_BASELINE_ZERO) HIPCHECK(hipMemsetAsync(S.ret64, 0, sizeof(double) * S.n_rows, c->stream));
+    PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), c->stream, a);
+    HIPCHECK(hipGetLastError());
+    S.processed = false;
+    S.has_adv = false;
+    HIPCHECK(hipMemcpyAsync(out, S.ret64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -42,6 +42,7 @@ struct SampleArgs {
     double* gram_partials;  // [grid][NPAIR*256]
     double* coeffs;         // [tasks][coeff_stride]
     int coeff_stride;
+    double* bl64;           // optional [rows]: the baseline predictions Phi.w (LinearBaseline.predict), else NULL
 };
 
 // grid = paths, block = 64
@@ -297,6 +298,7 @@ __global__ void __launch_bounds__(64) k_gae(SampleArgs a) {
         }
         y += f * carry;
         if (valid) {
+            if (a.bl64 != nullptr) a.bl64[row] = b;
             a.adv64[row] = y;
             s1 += y;
             s2 += y * y;

@@ -74,3 +74,23 @@ assert uid == bytes(range(128))
 ''' % ROOT
     ps = [subprocess.Popen([sys.executable, '-c', code, str(r)]) for r in (0, 1)]
     assert [p.wait(timeout=120) for p in ps] == [0, 0]
+
+
+def test_rendezvous_under_torchrun_agent_store(tmp_path):
+    """The launch the driver uses for N>1: python -m torch.distributed.run --master-addr/--master-port ... bench.py.
+    promp_amd.comm.exchange_unique_id must hand rank 0's 128-byte id to every rank through the agent's TCPStore."""
+    script = tmp_path / 'rdzv.py'
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r)
+from promp_amd import comm
+rank, world, local = comm.env_world()
+uid = comm.exchange_unique_id(rank, world, lambda: bytes((7 * i + 3) %% 256 for i in range(128)))
+assert uid == bytes((7 * i + 3) %% 256 for i in range(128)), uid[:8]
+assert local == rank
+open(os.path.join(%r, 'ok%%d' %% rank), 'w').write('1')
+''' % (ROOT, str(tmp_path)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29641', str(script)]
+    subprocess.run(cmd, check=True, timeout=600, cwd=ROOT)
+    assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')

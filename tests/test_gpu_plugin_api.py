@@ -53,3 +53,7 @@ def test_promp_learns_on_point_env(tmp_path):
     first, last = sum(post[:5]) / 5, sum(post[-5:]) / 5
     assert last > first + 0.05 * abs(first), (first, last)       # returns are negative distances: closer to the goal
     logger.configure(quiet=True)
+
+
+def test_baseline_fit_predict_on_device():
+    scen.run_baseline_fit_predict_scenario()

@@ -183,3 +183,34 @@ def run_get_actions_scenario(M=3, B=7, O=5, A=3, hidden=(32, 32)):
 
 def test_get_actions(emu):
     run_get_actions_scenario()
+
+
+def run_baseline_fit_predict_scenario():
+    """Baseline.fit / predict / get_param_values / set_params used standalone (reference tests/test_baselines.py:67-98)."""
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline, LinearTimeBaseline
+    from promp_amd.baselines.zero_baseline import ZeroBaseline
+    rng = np.random.RandomState(2)
+    paths = []
+    for _ in range(6):
+        T = rng.randint(20, 40)
+        obs = rng.randn(T, 3).astype(np.float32)
+        rew = (rng.randn(T) + 2).astype(np.float32)
+        paths.append(dict(observations=obs, actions=rng.randn(T, 1), rewards=rew, returns=sp.discount_cumsum(rew, 0.99)))
+    for cls, kind in ((LinearFeatureBaseline, sp.BASELINE_LINEAR_FEATURE), (LinearTimeBaseline, sp.BASELINE_LINEAR_TIME)):
+        b = cls()
+        assert np.all(b.predict(paths[0]) == 0)                       # unfit => zeros (linear_baseline.py:31-32)
+        b.fit(paths, target_key='returns')
+        c_ref, _, _ = sp.fit_linear_baseline([p['observations'] for p in paths], [p['returns'] for p in paths], kind)
+        np.testing.assert_allclose(b.get_param_values(), c_ref, rtol=1e-6, atol=1e-8)
+        pred = b.predict(paths[1])
+        np.testing.assert_allclose(pred, sp.predict_linear_baseline(paths[1]['observations'], c_ref, kind), rtol=1e-6, atol=1e-7)
+        # fit lowers the squared error (reference tests/test_baselines.py:67-80)
+        assert np.sum((pred - paths[1]['returns']) ** 2) < np.sum(paths[1]['returns'] ** 2)
+        b2 = cls()
+        b2.set_params(b.get_param_values())                           # round trip (tests/test_baselines.py:82-98)
+        np.testing.assert_allclose(b2.predict(paths[2]), b.predict(paths[2]), rtol=0, atol=0)
+    assert np.all(ZeroBaseline().predict(paths[0]) == 0)
+
+
+def test_baseline_fit_predict(emu):
+    run_baseline_fit_predict_scenario()
