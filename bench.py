@@ -144,7 +144,8 @@ def main():
             iteration()
         fl = flops_per_row(O, hidden[0], hidden[1], A)
         kern = {}
-        for name, kid, f in (('k_fwd_bwd', _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), ('k_hvp', _lib.KERNEL_HVP, fl['hvp'])):
+        for name, kid, f in (('k_fwd_bwd', _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), ('k_hvp', _lib.KERNEL_HVP, fl['hvp']),
+                             ('k_fwd_bwd<fwd-only>', _lib.KERNEL_FWD, fl['fwd'])):
             pr = ctx.prof_read(kid)
             avg_ms = pr['total_ms'] / max(pr['launches'], 1)
             rows = pr['rows'] / max(pr['launches'], 1)

@@ -181,7 +181,8 @@ int promp_eval_hvp(promp_ctx* ctx, int step, int inner_kind, int clip_log_std, f
                    const float* v, float* out);
 
 /* ---- measurement: HIP-event timing of the pass kernels on the context's stream ------------- */
-enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PROMP_KERNEL_COUNT = 3 };
+enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PROMP_KERNEL_FWD = 3 /* forward-only k_fwd_bwd */,
+       PROMP_KERNEL_COUNT = 4 };
 int promp_prof_enable(promp_ctx* ctx, int on);
 int promp_prof_read(promp_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches, int64_t* rows);
 int promp_device_info(promp_ctx* ctx, char* name_out, size_t name_bytes, int32_t* n_cus, int32_t* clock_mhz);

@@ -82,7 +82,7 @@ struct promp_ctx {
     float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
     float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
     double *gram_partials = nullptr, *red64 = nullptr;
-    size_t smem_fwd = 0, smem_hvp = 0;
+    size_t smem_fwd = 0, smem_fwd8 = 0, smem_hvp = 0;
     int fwd_waves = 8;                   // waves per k_fwd_bwd workgroup (8 = two per SIMD sharing one copy of the weights)
 #ifndef PROMP_EMU
     ncclComm_t comm = nullptr;
@@ -168,7 +168,7 @@ int prof_collect(promp_ctx* c) {
 
 // ---- launches ----------------------------------------------------------------------------------
 int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long long theta_stride, int loss_kind,
-                float clip_eps, int clip_ls, float klw) {
+                float clip_eps, int clip_ls, float klw, bool fwd_only = false) {
     if (!S.has_policy) return fail(-3, "step has no actions / agent_infos uploaded");
     if (!S.has_adv) return fail(-3, "step has no advantages: call promp_process_samples or promp_set_advantages first");
     PassArgs a;
@@ -184,16 +184,19 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.min_log_std = logf(1e-6f);   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
     a.kl_weight = klw;
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
-    const int id = hvp ? PROMP_KERNEL_HVP : PROMP_KERNEL_FWD_BWD;
+    const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
     if (prof_begin(c, id, S.n_rows)) return -2;
     const bool h64 = c->d.hidden1 == 64;
     if (!hvp) {
-        if (c->fwd_waves == 8) {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 8>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 8>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
+        if (fwd_only) {
+            if (h64) { auto k = k_fwd_bwd<2, 2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
+        } else if (c->fwd_waves == 8) {
+            if (h64) { auto k = k_fwd_bwd<2, 2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 8, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
         } else {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
+            if (h64) { auto k = k_fwd_bwd<2, 2, 4, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 4, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
         }
     } else {
         if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
@@ -234,8 +237,8 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f)) return -2;
         if (launch_reduce(c, c->steps[k], 0, 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
     }
-    if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f)) return -2;
-    if (launch_reduce(c, c->steps[K], 0, want_grad ? 1 : 3, nullptr, 0, nullptr, c->scal_outer)) return -2;
+    if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f, !want_grad)) return -2;
+    if (launch_reduce(c, c->steps[K], 0, want_grad ? 1 : 4, nullptr, 0, nullptr, c->scal_outer)) return -2;
     if (want_grad) {
         for (int k = K - 1; k >= 0; --k) {
             const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
@@ -330,6 +333,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) { c->fwd_waves = atoi(e) == 4 ? 4 : 8; }   // developer experiment
     c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, c->fwd_waves, param_count(dims)).total;
+    c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;
@@ -337,8 +341,11 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         return fail(-1, "LDS budget exceeded (%zu bytes)", need);
     }
     {
-        auto k0 = k_fwd_bwd<2, 2, 4>; auto k1 = k_fwd_bwd<1, 1, 4>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
-        auto k4 = k_fwd_bwd<2, 2, 8>; auto k5 = k_fwd_bwd<1, 1, 8>;
+        auto k0 = k_fwd_bwd<2, 2, 4, true>; auto k1 = k_fwd_bwd<1, 1, 4, true>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
+        auto k4 = k_fwd_bwd<2, 2, 8, true>; auto k5 = k_fwd_bwd<1, 1, 8, true>;
+        auto k6 = k_fwd_bwd<2, 2, 8, false>; auto k7 = k_fwd_bwd<1, 1, 8, false>;
+        HIPCHECK(hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k7, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
         HIPCHECK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -123,7 +123,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     return L;
 }
 
-template <int NB1, int NB2, int NW>
+// BWD = false: objective and mean KL only (compute_stats / line-search evaluations): the tile loop stops after the
+// distribution epilogue and the partial carries just the two scalars.
+template <int NB1, int NB2, int NW, bool BWD>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS;
@@ -369,6 +371,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         }
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 5);
+        if (BWD) {
         // ---- output-kernel gradient (+=); dZ2 = (dmu W3^T) * (1 - H2^2) in place over H2
         outer16<NC2, 1>(aw3, H2w + kk * HS + i16, HS, 16, Msw + kk * MS + i16, MS, 0, PROMP_WROWS, 1.f);
         {
@@ -418,6 +421,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         // ---- hidden_0 kernel gradient (+=): rows = observation index (two 16-blocks cover O <= 32)
         outer16<2, NC1>(aw1, Xw + kk * XS + i16, XS, 16, H1w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
         wave_sync();
+        }
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 8);
     }
     PROMP_STAMP(2);
@@ -441,6 +445,26 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             gs0 += shfl_xor_f32(gs0, m);  gs1 += shfl_xor_f32(gs1, m);  gb30 += shfl_xor_f32(gb30, m);
             gb31 += shfl_xor_f32(gb31, m);  loss += shfl_xor_f32(loss, m);  klsum += shfl_xor_f32(klsum, m);
         }
+    }
+    if (!BWD) {   // only the two scalars leave the workgroup
+        float* SC = sm;
+        __syncthreads();
+        if (lane == 0) {
+            SC[2 * w] = loss;
+            SC[2 * w + 1] = klsum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float l = 0.f, k = 0.f;
+            for (int ww = 0; ww < NW; ++ww) {
+                l += SC[2 * ww];
+                k += SC[2 * ww + 1];
+            }
+            float* Pq = a.partials + (long long)blockIdx.x * a.partial_stride;
+            Pq[NP] = l;
+            Pq[NP + 1] = k;
+        }
+        return;
     }
     // Each wave stores its tiles to its own LDS slab (plain stores, no read-modify-write), then all threads add four
     // slabs in wave order.  Two payload rounds because 4 x [NP] does not fit in LDS; with 8 waves the second group of
@@ -1016,6 +1040,7 @@ struct ReduceArgs {
     // mode 1 (outer)     : lam[i] = g ; v[i] = alpha * g ; scal[i] = {loss, kl}
     // mode 2 (hvp)       : lam[i] += g ; v[i] = alpha * lam[i] ; scal[i] = {-, kl}
     // mode 3 (plain)     : lam[i] = g ; scal
+    // mode 4 (scalars)   : scal only (forward-only passes write no gradient)
     int mode;
     const float* cur;            // [Theta] or [tasks][Theta]
     long long cur_task_stride;
@@ -1029,6 +1054,7 @@ __global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int task = blockIdx.y;
     if (j >= a.NP + 2) return;
+    if (a.mode == 4 && j < a.NP) return;
     float g = 0.f;
     const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
 #pragma unroll 4
