@@ -529,8 +529,9 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (o->baseline_kind < 0 || o->baseline_kind > 2) return fail(-1, "unknown baseline kind %d", o->baseline_kind);
     SampleArgs a;
     a.obs = S.obs; a.rew = S.rew; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
-    a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets; a.work = S.work[1];
-    a.task_wg_offsets = S.task_wg_offsets[1];
+    a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets;
+    a.work = S.work[0];                         // k_gram / k_fit: one workgroup per CU
+    a.task_wg_offsets = S.task_wg_offsets[0];
     a.O = c->d.obs_dim; a.kind = o->baseline_kind; a.D = feature_dim(&c->d, o->baseline_kind);
     a.gamma = o->discount; a.lam = o->gae_lambda; a.reg = o->reg_coeff;
     a.normalize = o->normalize_adv; a.positive = o->positive_adv;
@@ -546,11 +547,11 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         const int nblk = (a.D + 1 + 15) / 16;
         if (prof_begin(c, PROMP_KERNEL_GRAM, S.n_rows)) return -2;
         switch (nblk) {
-            case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<1>::SMEM_BYTES, st, a); } break;
-            case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<2>::SMEM_BYTES, st, a); } break;
-            case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<3>::SMEM_BYTES, st, a); } break;
-            case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<4>::SMEM_BYTES, st, a); } break;
-            case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[1]), 256, GramCfg<5>::SMEM_BYTES, st, a); } break;
+            case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<1>::NW, GramCfg<1>::SMEM_BYTES, st, a); } break;
+            case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<2>::NW, GramCfg<2>::SMEM_BYTES, st, a); } break;
+            case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<3>::NW, GramCfg<3>::SMEM_BYTES, st, a); } break;
+            case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<4>::NW, GramCfg<4>::SMEM_BYTES, st, a); } break;
+            case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<5>::NW, GramCfg<5>::SMEM_BYTES, st, a); } break;
             default: return fail(-1, "feature dim %d unsupported in this build", a.D);
         }
         HIPCHECK(hipGetLastError());
@@ -562,6 +563,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     }
     PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), st, a);
     HIPCHECK(hipGetLastError());
+    a.work = S.work[1];                         // k_normalize: two workgroups per CU
     PROMP_LAUNCH(k_normalize, dim3(S.n_work[1]), 256, 0, st, a);
     HIPCHECK(hipGetLastError());
     S.processed = true;

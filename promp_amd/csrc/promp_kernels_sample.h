@@ -82,70 +82,85 @@ __global__ void __launch_bounds__(64) k_returns(SampleArgs a) {
     }
 }
 
+// k_gram: partial Gram of [Phi R] over a work item's rows, wave-private like the policy passes: every wave builds
+// the features of its own 16-row chunks in its own LDS tile and feeds them to v_mfma_f64_16x16x4_f64 (the same
+// register is A and B operand of a block pair); no workgroup barrier in the chunk loop.  The waves' blocks are added
+// in wave order through LDS slabs at the end.
 template <int NBLK>
 struct GramCfg {
-    static constexpr int FS = (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16;  // row stride (doubles)
+    static constexpr int NW = (NBLK <= 3) ? 8 : 4;                            // waves per workgroup
+    static constexpr int FS = (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16;   // feature-tile row stride (doubles)
     static constexpr int NPAIR = NBLK * (NBLK + 1) / 2;
-    // Phi [32][FS] f64 | Red [NPAIR][256] f64 | raw obs [32][32] f32 | targets [32] f64 | tau [32] f64
-    static constexpr int SMEM_BYTES = (32 * FS + NPAIR * 256 + 32 + 32) * 8 + 32 * 32 * 4;
+    static constexpr int WAVE_BYTES = 16 * FS * 8 + 16 * 32 * 4 + 2 * 16 * 8;  // Phi | raw obs [16][<=32] | targets | tau
+    static constexpr int SLAB_BYTES = NW * NPAIR * 256 * 8;
+    static constexpr int SMEM_BYTES = (NW * WAVE_BYTES > SLAB_BYTES) ? NW * WAVE_BYTES : SLAB_BYTES;
 };
 
-// grid = work items, block = 256.  Partial Gram of [Phi R] over the item's rows.
+// grid = work items, block = 64 * GramCfg<NBLK>::NW
 template <int NBLK>
-__global__ void __launch_bounds__(256) k_gram(SampleArgs a) {
-    constexpr int FS = GramCfg<NBLK>::FS, NPAIR = GramCfg<NBLK>::NPAIR, NC = 16 * NBLK;
+__global__ void __launch_bounds__(64 * GramCfg<NBLK>::NW) k_gram(SampleArgs a) {
+    constexpr int NW = GramCfg<NBLK>::NW, FS = GramCfg<NBLK>::FS, NPAIR = GramCfg<NBLK>::NPAIR, NC = 16 * NBLK;
     PROMP_SMEM_DECL;
-    double* Phi = (double*)PROMP_SMEM_PTR;
-    double* Red = Phi + 32 * FS;
-    double* Tg = Red + NPAIR * 256;
-    double* Tau = Tg + 32;
-    float* Ob = (float*)(Tau + 32);
+    unsigned char* smem = (unsigned char*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    double* Phi = (double*)(smem + (size_t)w * GramCfg<NBLK>::WAVE_BYTES);
+    float* Ob = (float*)(Phi + 16 * FS);
+    double* Tg = (double*)(Ob + 16 * 32);
+    double* Tau = Tg + 16;
     const WorkItem wk = a.work[blockIdx.x];
     const int O = a.O, D = a.D;
     f64x4 acc[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = zero4d();
-    for (int base = wk.row_begin; base < wk.row_end; base += 32) {
-        const int nrows = (wk.row_end - base) < 32 ? (wk.row_end - base) : 32;
-        // stage the raw rows with unconditional coalesced loads, then build the features out of LDS
-        if (a.kind == BASE_LINFEAT)
-            for (int e = tid; e < 32 * O; e += 256) Ob[e] = (e < nrows * O) ? a.obs[(long long)base * O + e] : 0.f;
-        if (tid < 32) {
-            Tg[tid] = (tid < nrows) ? a.ret64[base + tid] : 0.0;
-            Tau[tid] = (tid < nrows) ? (double)a.row_t[base + tid] / 100.0 : 0.0;
-        }
-        __syncthreads();
-        for (int e = tid; e < 32 * NC; e += 256) {
-            const int r = e / NC, c = e - r * NC;
-            double f = 0.0;
-            if (r < nrows) {
-                int q = c;
-                bool done = false;
-                if (c == D) {
-                    f = Tg[r];
-                    done = true;
-                } else if (c > D) {
-                    done = true;
-                } else if (a.kind == BASE_LINFEAT) {
-                    if (c < 2 * O) {
-                        const float o = Ob[r * O + (c < O ? c : c - O)];
-                        const float oc = fminf(fmaxf(o, -10.f), 10.f);
-                        // the reference squares in the observations' own dtype (float32), then promotes
-                        f = (c < O) ? (double)oc : (double)(oc * oc);
-                        done = true;
-                    }
-                    q = c - 2 * O;
-                }
-                if (!done) {
-                    const double tau = Tau[r];
-                    f = (q == 0) ? tau : (q == 1) ? tau * tau : (q == 2) ? tau * tau * tau : 1.0;
-                }
+    const int fr = lane >> 2, fc0 = lane & 3;   // feature build: 4 lanes per row, columns fc0, fc0+4, ...
+    for (int base = wk.row_begin + 16 * w; base < wk.row_end; base += 16 * NW) {
+        const int nrows = (wk.row_end - base) < 16 ? (wk.row_end - base) : 16;
+        if (a.kind == BASE_LINFEAT) {
+            const int lim = nrows * O;
+            for (int e = lane; e < 16 * O; e += 64) {
+                const float x = a.obs[(long long)base * O + (e < lim ? e : 0)];
+                Ob[e] = (e < lim) ? x : 0.f;
             }
-            Phi[r * FS + c] = f;
         }
-        __syncthreads();
-        for (int s = w; s < 8; s += 4) {
+        if (lane < 16) {
+            const int r = lane < nrows ? lane : 0;
+            const double t = a.ret64[base + r];
+            const double tau = (double)a.row_t[base + r] / 100.0;
+            Tg[lane] = (lane < nrows) ? t : 0.0;
+            Tau[lane] = (lane < nrows) ? tau : 0.0;
+        }
+        wave_sync();
+        {
+            const bool rv = fr < nrows;
+            const double tau = Tau[fr];
+            for (int c = fc0; c < NC; c += 4) {
+                double f = 0.0;
+                if (rv) {
+                    int q = c;
+                    bool done = false;
+                    if (c == D) {
+                        f = Tg[fr];
+                        done = true;
+                    } else if (c > D) {
+                        done = true;
+                    } else if (a.kind == BASE_LINFEAT) {
+                        if (c < 2 * O) {
+                            const float o = Ob[fr * O + (c < O ? c : c - O)];
+                            const float oc = fminf(fmaxf(o, -10.f), 10.f);
+                            // the reference squares in the observations' own dtype (float32), then promotes
+                            f = (c < O) ? (double)oc : (double)(oc * oc);
+                            done = true;
+                        }
+                        q = c - 2 * O;
+                    }
+                    if (!done) f = (q == 0) ? tau : (q == 1) ? tau * tau : (q == 2) ? tau * tau * tau : 1.0;
+                }
+                Phi[fr * FS + c] = f;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
             double av[NBLK];
 #pragma unroll
             for (int b = 0; b < NBLK; ++b) av[b] = Phi[(4 * s + kk) * FS + 16 * b + i16];
@@ -158,22 +173,22 @@ __global__ void __launch_bounds__(256) k_gram(SampleArgs a) {
                     ++p;
                 }
         }
-        __syncthreads();
+        wave_sync();
     }
-    for (int ww = 0; ww < 4; ++ww) {
-        if (w == ww) {
+    __syncthreads();
+    double* S = (double*)smem;   // [NW][NPAIR*256]
 #pragma unroll
-            for (int p = 0; p < NPAIR; ++p)
+    for (int p = 0; p < NPAIR; ++p)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = p * 256 + (kk + 4 * r) * 16 + i16;
-                    Red[idx] = (ww == 0 ? 0.0 : Red[idx]) + acc[p][r];
-                }
-        }
-        __syncthreads();
-    }
+        for (int r = 0; r < 4; ++r) S[(w * NPAIR + p) * 256 + (kk + 4 * r) * 16 + i16] = acc[p][r];
+    __syncthreads();
     double* out = a.gram_partials + (long long)blockIdx.x * (NPAIR * 256);
-    for (int e = tid; e < NPAIR * 256; e += 256) out[e] = Red[e];
+    for (int e = tid; e < NPAIR * 256; e += 64 * NW) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t += S[ww * NPAIR * 256 + e];
+        out[e] = t;
+    }
 }
 
 // grid = tasks, block = 256.  smem: G[(D+1)^2] + Wm[(D+1)^2] + yv[D+1] + wv[D+1] + dg[D+1]  (doubles)
