@@ -46,6 +46,8 @@ PROMP_DEV void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// keeps the compiler from interleaving two independent GEMM groups (which would add their live ranges)
+PROMP_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 PROMP_DEV unsigned long long promp_clock() { return (unsigned long long)clock64(); }
 PROMP_DEV unsigned long long promp_wall_clock() { return (unsigned long long)wall_clock64(); }   // constant 100 MHz
 PROMP_DEV float fast_exp(float x) { return __expf(x); }

@@ -205,13 +205,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     const int erow = lane >> 2, q = lane & 3;
     const bool own0 = q < A, own1 = (q + 4) < A;
     const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;   // clamped action indices for unconditional loads
-    // where this lane's share of a [16][O] tile lands in the padded LDS tile
-    int xoff[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int e = lane + 64 * u;
-        xoff[u] = (e < PROMP_WROWS * O) ? (e / O) * XS + (e % O) : -1;
-    }
+    // this lane's share of a [16][O] tile lands at row e / O, column e % O of the padded LDS tile (e = lane + 64 u);
+    // the quotient comes from a float reciprocal (exact for these small integers) instead of 8 live offset registers
+    const float rO = 1.0f / (float)O;
     const int first = wk.row_begin + PROMP_WROWS * w;
     float xr[8];
     {
@@ -231,8 +227,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 0);
         const int nrows = (wk.row_end - base) < PROMP_WROWS ? (wk.row_end - base) : PROMP_WROWS;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (xoff[u] >= 0) Xw[xoff[u]] = xr[u];
+        for (int u = 0; u < 8; ++u) {
+            const int e = lane + 64 * u;
+            const int r = (int)(((float)e + 0.5f) * rO);
+            if (e < PROMP_WROWS * O) Xw[r * XS + (e - r * O)] = xr[u];
+        }
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 9);
         {
             const int nb = base + NW * PROMP_WROWS;
@@ -309,9 +308,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 sumz2 += z0 * z0;
                 sums += s;
                 const float sn2 = sn2s[q], num = (mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2, den = 2.f * sn2 + 1e-8f;
-                kl += num / den + s - so0;
-                dklm0 = -2.f * (mo0 - mu) / den;
-                dkls0 = (-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f;
+                const float rden = fast_rcp(den);     // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
+                kl += num * rden + s - so0;
+                dklm0 = -2.f * (mo0 - mu) * rden;
+                dkls0 = (-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f;
             }
             if (own1) {
                 const float s = lss[q + 4], mu = Msw[erow * MS + q + 4];
@@ -322,9 +322,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 sumz2 += z1 * z1;
                 sums += s;
                 const float sn2 = sn2s[q + 4], num = (mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2, den = 2.f * sn2 + 1e-8f;
-                kl += num / den + s - so1;
-                dklm1 = -2.f * (mo1 - mu) / den;
-                dkls1 = (-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f;
+                const float rden = fast_rcp(den);     // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
+                kl += num * rden + s - so1;
+                dklm1 = -2.f * (mo1 - mu) * rden;
+                dkls1 = (-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f;
             }
             dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
             sumz2 += shfl_xor_f32(sumz2, 1);  sumz2 += shfl_xor_f32(sumz2, 2);
@@ -374,6 +375,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         if (BWD) {
         // ---- output-kernel gradient (+=); dZ2 = (dmu W3^T) * (1 - H2^2) in place over H2
         outer16<NC2, 1>(aw3, H2w + kk * HS + i16, HS, 16, Msw + kk * MS + i16, MS, 0, PROMP_WROWS, 1.f);
+        sched_fence();
         {
             f32x4 acc[1][NC2];
 #pragma unroll
@@ -397,6 +399,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 6);
         // ---- hidden_1 kernel gradient (+=); dZ1 = (dZ2 W2^T) * (1 - H1^2) in place over H1
         outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, HS, 16, H2w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        sched_fence();
         {
             f32x4 acc[1][NC1];
 #pragma unroll
@@ -829,9 +832,10 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
                 dlp += (so0 - s) - 0.5f * (z0 * z0 - zo * zo);
                 Rlp += z0 * e0 * Rmu0 + (z0 * z0 - 1.f) * Rs0;
                 const float sn2 = sn2s[q], num = (mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2, den = 2.f * sn2 + 1e-8f;
-                kl += num / den + s - so0;
-                dklm0 = -2.f * (mo0 - mu) / den * invN;
-                dkls0 = ((-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f) * invN;
+                const float rden = fast_rcp(den);
+                kl += num * rden + s - so0;
+                dklm0 = -2.f * (mo0 - mu) * rden * invN;
+                dkls0 = ((-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f) * invN;
             }
             if (own1) {
                 const float s = lss[q + 4], mu = Msw[erow * MS + q + 4];
@@ -843,9 +847,10 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
                 dlp += (so1 - s) - 0.5f * (z1 * z1 - zo * zo);
                 Rlp += z1 * e1 * Rmu1 + (z1 * z1 - 1.f) * Rs1;
                 const float sn2 = sn2s[q + 4], num = (mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2, den = 2.f * sn2 + 1e-8f;
-                kl += num / den + s - so1;
-                dklm1 = -2.f * (mo1 - mu) / den * invN;
-                dkls1 = ((-2.f * sn2 * den - 4.f * num * sn2) / (den * den) + 1.f) * invN;
+                const float rden = fast_rcp(den);
+                kl += num * rden + s - so1;
+                dklm1 = -2.f * (mo1 - mu) * rden * invN;
+                dkls1 = ((-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f) * invN;
             }
             dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
             Rlp += shfl_xor_f32(Rlp, 1);  Rlp += shfl_xor_f32(Rlp, 2);

@@ -94,6 +94,8 @@ class ConjugateGradientOptimizer(object):
                                     (1. / (descent_direction.dot(Hx(descent_direction)) + 1e-8)))
         if np.isnan(initial_step_size):
             logger.log('Initial step size is NaN! Rejecting the step!')
+            self.last = dict(loss_before=loss_before, n_backtracks=0, rejected=True, descent_direction=descent_direction,
+                             initial_step_size=float('nan'))
             return
         initial_descent_step = initial_step_size * descent_direction
         prev = ev.get_theta().copy()
