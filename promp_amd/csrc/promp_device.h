@@ -130,12 +130,14 @@ PROMP_DEV void gemm16(f32x4& acc, Opnd a, Opnd b, int K, float sgn) {
     acc = mfma16(sgn * a0, b0, acc);
 }
 
-// acc[ia][ib] (16x16 tiles) += sgn * A_ia * B_ib over K (multiple of 4) with 16x16x4 MFMAs.
-// Operand streams: A block ia feeds a[k*a_ks + ia*a_bs], B block ib feeds b[k*b_ks + ib*b_bs] (pointers already
-// offset for this lane).  NA*NB independent accumulators hide the 40-cycle dependent latency; the operands of
-// step k+4 are requested before the MFMAs of step k issue.
+// acc[ia][ib] (16x16 tiles) += sgn * A_ia * B_ib over NS k-steps of 16x16x4 MFMAs.
+// Operand streams: at step s, A block ia feeds a[s*a_ss + ia*a_bs], B block ib feeds b[s*b_ss + ib*b_bs] (pointers
+// already offset for this lane).  Which four k values a step contracts is the caller's choice (any bijection of K
+// onto (step, lane>>4) works as long as A and B agree) - the kernels pick it per GEMM for conflict-free LDS banks.
+// NA*NB independent accumulators hide the 40-cycle dependent latency; the operands of step s+1 are requested before
+// the MFMAs of step s issue.
 template <int NA, int NB>
-PROMP_DEV void outer16(f32x4 (&acc)[NA][NB], const float* a, int a_ks, int a_bs, const float* b, int b_ks, int b_bs, int K,
+PROMP_DEV void outer16(f32x4 (&acc)[NA][NB], const float* a, int a_ss, int a_bs, const float* b, int b_ss, int b_bs, int NS,
                        float sgn) {
     float a0[NA], b0[NB];
 #pragma unroll
@@ -143,12 +145,12 @@ PROMP_DEV void outer16(f32x4 (&acc)[NA][NB], const float* a, int a_ks, int a_bs,
 #pragma unroll
     for (int j = 0; j < NB; ++j) b0[j] = b[j * b_bs];
 #pragma unroll 2
-    for (int k = 4; k < K; k += 4) {
+    for (int s = 1; s < NS; ++s) {
         float a1[NA], b1[NB];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) a1[i] = a[k * a_ks + i * a_bs];
+        for (int i = 0; i < NA; ++i) a1[i] = a[s * a_ss + i * a_bs];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b1[j] = b[k * b_ks + j * b_bs];
+        for (int j = 0; j < NB; ++j) b1[j] = b[s * b_ss + j * b_bs];
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll

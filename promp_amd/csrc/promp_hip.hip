@@ -855,6 +855,7 @@ int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {
 // parameters with cycle stamps of workgroup 0 enabled, and return the 256 raw stamps.
 int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long* out) {
     if (!c || !out) return fail(-1, "NULL argument");
+    if (!PROMP_STAMPS_ON) return fail(-3, "phase stamps need a build with -DPROMP_DEV_STAMPS");
     StepData& S = c->steps[step];
     HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * 256, c->stream));
     c->dbg_enabled = true;

@@ -18,6 +18,7 @@
 #pragma once
 #include "promp_device.h"
 
+#define PROMP_W3S 17         // row stride of the zero-padded [H2][16] output kernel in LDS
 #define PROMP_MS 17          // row stride of the [64][16] mean / d-mean staging tiles
 #define PROMP_PARTIAL_EXTRA 4  // loss, kl, 2 spare
 
@@ -63,7 +64,14 @@ struct PassArgs {
 // four waves' tiles are added in a fixed order through LDS at the end (bitwise reproducible).
 // ---------------------------------------------------------------------------------------------
 // developer tooling: cycle stamps of workgroup 0 / thread 0, kept in LDS and dumped when the kernel ends
+// (compiled in only with -DPROMP_DEV_STAMPS: each stamp is a divergent region that splits the scheduler's basic blocks)
+#ifdef PROMP_DEV_STAMPS
 #define PROMP_STAMP(i) do { if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0) dbgs[(i)] = promp_clock(); } while (0)
+#define PROMP_STAMPS_ON 1
+#else
+#define PROMP_STAMP(i) do { } while (0)
+#define PROMP_STAMPS_ON 0
+#endif
 #define PROMP_WROWS 16
 PROMP_DEV f32x4 splat4(float v) {
     f32x4 z;
@@ -91,7 +99,7 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     PROMP_TAKE(b1, H1);
     PROMP_TAKE(w2, H1 * L.WS);
     PROMP_TAKE(b2, H2);
-    PROMP_TAKE(w3, H2 * 16);
+    PROMP_TAKE(w3, H2 * PROMP_W3S);
     PROMP_TAKE(w3t, 8 * H2);
     PROMP_TAKE(b3, 16);
     PROMP_TAKE(ls, 16);
@@ -128,7 +136,8 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
 template <int NB1, int NB2, int NW, bool BWD>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int NT = 64 * NW;
-    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS;
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, W3S = PROMP_W3S;
+    constexpr int Q1 = H1 / 4, Q2 = H2 / 4;   // k-slice of lane group kk in the K = H GEMMs: {kk*Q .. kk*Q + Q-1}
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
           *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
           *sn2s = sm + L.sn2;
     unsigned long long* dbgs = (unsigned long long*)(sm + L.dbg);
-    if (a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
+    if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
     float* wreg = sm + L.wave0 + w * L.wave_stride;
     float *Xw = wreg + L.x, *H1w = wreg + L.h1, *H2w = wreg + L.h2, *Msw = wreg + L.ms;
     const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
@@ -160,7 +169,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     }
     for (int e = tid; e < H2 * 16; e += NT) {
         const int k = e >> 4, j = e & 15;
-        W3s[e] = (j < A) ? th[oW3 + k * A + j] : 0.f;
+        W3s[k * W3S + j] = (j < A) ? th[oW3 + k * A + j] : 0.f;
     }
     for (int e = tid; e < 8 * H2; e += NT) {
         const int aa = e / H2, k = e - aa * H2;
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             f32x4 acc[1][NC1];
 #pragma unroll
             for (int j = 0; j < NC1; ++j) acc[0][j] = splat4(b1s[16 * j + i16]);   // bias rides in the accumulator
-            outer16<1, NC1>(acc, Xw + i16 * XS + kk, 1, 0, W1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
+            outer16<1, NC1>(acc, Xw + i16 * XS + kk, 4, 0, W1s + kk * H1 + i16, 4 * H1, 16, Opad4 / 4, 1.f);
             PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 11);
 #pragma unroll
             for (int j = 0; j < NC1; ++j)
@@ -276,7 +285,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             f32x4 acc[1][NC2];
 #pragma unroll
             for (int j = 0; j < NC2; ++j) acc[0][j] = splat4(b2s[16 * j + i16]);
-            outer16<1, NC2>(acc, H1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
+            outer16<1, NC2>(acc, H1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
             PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 12);
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
@@ -289,7 +298,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         {
             f32x4 acc[1][1];
             acc[0][0] = splat4(b3s[i16]);
-            outer16<1, 1>(acc, H2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
+            outer16<1, 1>(acc, H2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r];
         }
@@ -374,13 +383,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 5);
         if (BWD) {
         // ---- output-kernel gradient (+=); dZ2 = (dmu W3^T) * (1 - H2^2) in place over H2
-        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, HS, 16, Msw + kk * MS + i16, MS, 0, PROMP_WROWS, 1.f);
+        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, 4 * HS, 16, Msw + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, 1.f);
         sched_fence();
         {
             f32x4 acc[1][NC2];
 #pragma unroll
             for (int j = 0; j < NC2; ++j) acc[0][j] = zero4();
-            outer16<1, NC2>(acc, Msw + i16 * MS + kk, 1, 0, W3Ts + kk * H2 + i16, H2, 16, 8, 1.f);
+            outer16<1, NC2>(acc, Msw + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, 4 * H2, 16, 2, 1.f);
 #pragma unroll
             for (int j = 0; j < NC2; ++j) {
                 float cs = 0.f;
@@ -398,13 +407,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 6);
         // ---- hidden_1 kernel gradient (+=); dZ1 = (dZ2 W2^T) * (1 - H1^2) in place over H1
-        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, HS, 16, H2w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, 4 * HS, 16, H2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
         sched_fence();
         {
             f32x4 acc[1][NC1];
 #pragma unroll
             for (int j = 0; j < NC1; ++j) acc[0][j] = zero4();
-            outer16<1, NC1>(acc, H2w + i16 * HS + kk, 1, 0, W2s + i16 * WS + kk, 1, 16 * WS, H2, 1.f);
+            outer16<1, NC1>(acc, H2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, 1.f);
 #pragma unroll
             for (int j = 0; j < NC1; ++j) {
                 float cs = 0.f;
@@ -422,7 +431,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         wave_sync();
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 7);
         // ---- hidden_0 kernel gradient (+=): rows = observation index (two 16-blocks cover O <= 32)
-        outer16<2, NC1>(aw1, Xw + kk * XS + i16, XS, 16, H1w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        outer16<2, NC1>(aw1, Xw + kk * XS + i16, 4 * XS, 16, H1w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
         wave_sync();
         }
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 8);
@@ -547,7 +556,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         }
     }
     PROMP_STAMP(4);
-    if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
+    if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
         for (int i = 0; i < 128; ++i) a.dbg[i] = dbgs[i];
 }
 
@@ -579,7 +588,7 @@ PROMP_HD LdsHvp make_layout_hvp(int O, int H1, int H2, int nwaves, int NP) {
     PROMP_TAKE(b1, H1);
     PROMP_TAKE(w2, H1 * L.WS);
     PROMP_TAKE(b2, H2);
-    PROMP_TAKE(w3, H2 * 16);
+    PROMP_TAKE(w3, H2 * PROMP_W3S);
     PROMP_TAKE(w3t, 8 * H2);
     PROMP_TAKE(b3, 16);
     PROMP_TAKE(ls, 16);
@@ -591,7 +600,7 @@ PROMP_HD LdsHvp make_layout_hvp(int O, int H1, int H2, int nwaves, int NP) {
     PROMP_TAKE(vb1, H1);
     PROMP_TAKE(vw2, H1 * L.WS);
     PROMP_TAKE(vb2, H2);
-    PROMP_TAKE(vw3, H2 * 16);
+    PROMP_TAKE(vw3, H2 * PROMP_W3S);
     PROMP_TAKE(vw3t, 8 * H2);
     PROMP_TAKE(vb3, 16);
     L.HS = (H1 > H2 ? H1 : H2) + 1;
@@ -633,7 +642,7 @@ PROMP_DEV void stage_net(float* W1s, float* b1s, float* W2s, float* b2s, float* 
 #pragma unroll 4
     for (int e = tid; e < H2 * 16; e += 256) {
         const int k = e >> 4, j = e & 15;
-        W3s[e] = (j < A) ? src[oW3 + k * A + j] : 0.f;
+        W3s[k * PROMP_W3S + j] = (j < A) ? src[oW3 + k * A + j] : 0.f;
     }
     for (int e = tid; e < 8 * H2; e += 256) {
         const int aa = e / H2, k = e - aa * H2;
@@ -646,7 +655,8 @@ PROMP_DEV void stage_net(float* W1s, float* b1s, float* W2s, float* b2s, float* 
 
 template <int NB1, int NB2>
 __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
-    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, XS = PROMP_XS;
+    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, XS = PROMP_XS, W3S = PROMP_W3S;
+    constexpr int Q1 = H1 / 4, Q2 = H2 / 4;
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -664,7 +674,7 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
     float *vW1s = sm + L.vw1, *vb1s = sm + L.vb1, *vW2s = sm + L.vw2, *vb2s = sm + L.vb2, *vW3s = sm + L.vw3,
           *vW3Ts = sm + L.vw3t, *vb3s = sm + L.vb3;
     unsigned long long* dbgs = (unsigned long long*)(sm + L.dbg);
-    if (a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
+    if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
     float* wreg = sm + L.wave0 + w * L.wave_stride;
     float *Xw = wreg + L.x, *H1w = wreg + L.h1, *RH1w = wreg + L.rh1, *H2w = wreg + L.h2, *RH2w = wreg + L.rh2,
           *Msw = wreg + L.ms, *Ms2w = wreg + L.ms2;
@@ -767,8 +777,8 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
                 az[0][j] = splat4(b1s[16 * j + i16]);     // biases ride in the accumulators
                 ar[0][j] = splat4(vb1s[16 * j + i16]);
             }
-            outer16<1, NC1>(az, Xw + i16 * XS + kk, 1, 0, W1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
-            outer16<1, NC1>(ar, Xw + i16 * XS + kk, 1, 0, vW1s + kk * H1 + i16, H1, 16, Opad4, 1.f);
+            outer16<1, NC1>(az, Xw + i16 * XS + kk, 4, 0, W1s + kk * H1 + i16, 4 * H1, 16, Opad4 / 4, 1.f);
+            outer16<1, NC1>(ar, Xw + i16 * XS + kk, 4, 0, vW1s + kk * H1 + i16, 4 * H1, 16, Opad4 / 4, 1.f);
 #pragma unroll
             for (int j = 0; j < NC1; ++j)
 #pragma unroll
@@ -788,9 +798,9 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
                 az[0][j] = splat4(b2s[16 * j + i16]);
                 ar[0][j] = splat4(vb2s[16 * j + i16]);
             }
-            outer16<1, NC2>(az, H1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
-            outer16<1, NC2>(ar, H1w + i16 * HS + kk, 1, 0, vW2s + kk * WS + i16, WS, 16, H1, 1.f);
-            outer16<1, NC2>(ar, RH1w + i16 * HS + kk, 1, 0, W2s + kk * WS + i16, WS, 16, H1, 1.f);
+            outer16<1, NC2>(az, H1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
+            outer16<1, NC2>(ar, H1w + i16 * HS + kk * Q1, 1, 0, vW2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
+            outer16<1, NC2>(ar, RH1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
@@ -807,9 +817,9 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
             f32x4 am[1][1], ar[1][1];
             am[0][0] = splat4(b3s[i16]);
             ar[0][0] = splat4(vb3s[i16]);
-            outer16<1, 1>(am, H2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
-            outer16<1, 1>(ar, H2w + i16 * HS + kk, 1, 0, vW3s + kk * 16 + i16, 16, 0, H2, 1.f);
-            outer16<1, 1>(ar, RH2w + i16 * HS + kk, 1, 0, W3s + kk * 16 + i16, 16, 0, H2, 1.f);
+            outer16<1, 1>(am, H2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
+            outer16<1, 1>(ar, H2w + i16 * HS + kk * Q2, 1, 0, vW3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
+            outer16<1, 1>(ar, RH2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 Msw[(4 * kk + r) * MS + i16] = am[0][0][r];
@@ -892,15 +902,15 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         }
         wave_sync();
         // ---- out_W3 += -RH2^T dmu + H2^T qmu ; dZ2 over H2, qZ2 over RH2
-        outer16<NC2, 1>(aw3, RH2w + kk * HS + i16, HS, 16, Msw + kk * MS + i16, MS, 0, PROMP_WROWS, -1.f);
-        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, HS, 16, Ms2w + kk * MS + i16, MS, 0, PROMP_WROWS, 1.f);
+        outer16<NC2, 1>(aw3, RH2w + kk * HS + i16, 4 * HS, 16, Msw + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, -1.f);
+        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, 4 * HS, 16, Ms2w + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, 1.f);
         {
             f32x4 ad[1][NC2], aq[1][NC2];
 #pragma unroll
             for (int j = 0; j < NC2; ++j) ad[0][j] = aq[0][j] = zero4();
-            outer16<1, NC2>(ad, Msw + i16 * MS + kk, 1, 0, W3Ts + kk * H2 + i16, H2, 16, 8, 1.f);
-            outer16<1, NC2>(aq, Ms2w + i16 * MS + kk, 1, 0, W3Ts + kk * H2 + i16, H2, 16, 8, 1.f);
-            outer16<1, NC2>(aq, Msw + i16 * MS + kk, 1, 0, vW3Ts + kk * H2 + i16, H2, 16, 8, -1.f);
+            outer16<1, NC2>(ad, Msw + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, 4 * H2, 16, 2, 1.f);
+            outer16<1, NC2>(aq, Ms2w + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, 4 * H2, 16, 2, 1.f);
+            outer16<1, NC2>(aq, Msw + i16 * MS + kk, 4, 0, vW3Ts + kk * H2 + i16, 4 * H2, 16, 2, -1.f);
 #pragma unroll
             for (int j = 0; j < NC2; ++j) {
                 float cs = 0.f;
@@ -919,15 +929,15 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         }
         wave_sync();
         // ---- out_W2 += -RH1^T dZ2 + H1^T qZ2 ; qZ1 over H1
-        outer16<NC1, NC2>(aw2, RH1w + kk * HS + i16, HS, 16, H2w + kk * HS + i16, HS, 16, PROMP_WROWS, -1.f);
-        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, HS, 16, RH2w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        outer16<NC1, NC2>(aw2, RH1w + kk * HS + i16, 4 * HS, 16, H2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, -1.f);
+        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, 4 * HS, 16, RH2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
         {
             f32x4 ad[1][NC1], aq[1][NC1];
 #pragma unroll
             for (int j = 0; j < NC1; ++j) ad[0][j] = aq[0][j] = zero4();
-            outer16<1, NC1>(ad, H2w + i16 * HS + kk, 1, 0, W2s + i16 * WS + kk, 1, 16 * WS, H2, 1.f);
-            outer16<1, NC1>(aq, RH2w + i16 * HS + kk, 1, 0, W2s + i16 * WS + kk, 1, 16 * WS, H2, 1.f);
-            outer16<1, NC1>(aq, H2w + i16 * HS + kk, 1, 0, vW2s + i16 * WS + kk, 1, 16 * WS, H2, -1.f);
+            outer16<1, NC1>(ad, H2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, 1.f);
+            outer16<1, NC1>(aq, RH2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, 1.f);
+            outer16<1, NC1>(aq, H2w + i16 * HS + kk * Q2, 1, 0, vW2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, -1.f);
 #pragma unroll
             for (int j = 0; j < NC1; ++j) {
                 float cs = 0.f;
@@ -944,7 +954,7 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         }
         wave_sync();
         // ---- out_W1 += X^T qZ1
-        outer16<2, NC1>(aw1, Xw + kk * XS + i16, XS, 16, H1w + kk * HS + i16, HS, 16, PROMP_WROWS, 1.f);
+        outer16<2, NC1>(aw1, Xw + kk * XS + i16, 4 * XS, 16, H1w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
         wave_sync();
     }
     PROMP_STAMP(2);
@@ -1027,7 +1037,7 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         P[e < oW2 ? e : e + NW2] = vv;
     }
     PROMP_STAMP(4);
-    if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
+    if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
         for (int i = 0; i < 128; ++i) a.dbg[i] = dbgs[i];
 }
 
