@@ -8,8 +8,9 @@ on BASELINE config 3: 40-task HalfCheetahRandVel shapes (obs 20, act 6, 2x64 tan
 
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Multi-GPU is STRONG scaling of the named config: the 40 tasks are sharded i -> GPU (i mod N); the only
-exchange is one RCCL all-reduce of [Theta+K+2] floats per Adam epoch (+1 for the stats pass).
+Multi-GPU: tasks are sharded i -> GPU (i mod N); the only exchange is one RCCL all-reduce of [Theta+K+2] floats per Adam
+epoch (+1 for the stats pass).  Default is WEAK scaling (40 tasks per GPU, meta_batch_size = 40 N); the same line also
+carries "fixed_batch": the named 40-task batch split over the N ranks (strong scaling), timed right after.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -42,8 +43,8 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3])
-    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
-                    help='strong: the named config sharded over N GPUs (default); weak: the named config per GPU')
+    ap.add_argument('--scaling', default='weak', choices=['strong', 'weak'],
+                    help='weak (default): the named 40-task config per GPU; strong: the named config sharded over the N GPUs')
     ap.add_argument('--epochs', type=int, default=5)
     ap.add_argument('--shard-of', type=int, default=0, metavar='N',
                     help='developer option: with --gpus 1, run only the shard rank 0 of an N-GPU job would hold '
@@ -59,54 +60,55 @@ def main():
         sys.exit(2)
     cfg = synthetic.CONFIGS[args.config]
     P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
-    M_global = cfg['M'] * (world if args.scaling == 'weak' else 1)
-    task_ids = [i for i in range(M_global) if i % world == rank]
-    if args.shard_of > 1 and world == 1:
-        task_ids = [i for i in range(M_global) if i % args.shard_of == 0]
-    M = len(task_ids)
     K, E = 1, args.epochs
     N = P * T
-
-    ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
-    info = ctx.device_info()
-    if world > 1:
-        uid = comm.exchange_unique_id(rank, world, lambda: _lib.comm_unique_id())
-        ctx.comm_init(rank, world, uid)
-
-    # ---- synthetic, seeded, resident in HBM before timing ----
+    opts = dict(discount=0.99, gae_lambda=1.0, normalize_adv=True)
+    eta = np.array([5e-4], np.float32)
     seed = 1000 * args.config
     theta0 = synthetic.init_theta(np.random.RandomState(seed), O, hidden, A)
-    alpha = np.full(ctx.n_params, 0.1, np.float32)
-    eta = np.array([5e-4], np.float32)
-    opts = dict(discount=0.99, gae_lambda=1.0, normalize_adv=True)
-    ctx.set_theta(theta0)
-    ctx.set_step_sizes(alpha)
-    p0 = synthetic.make_paths_for_tasks(seed, task_ids, theta0, P, T, O, A, hidden)
-    f0 = _lib.flatten_paths(p0)
-    ctx.upload_step(0, f0['task_path_offsets'], f0['path_row_offsets'], f0['obs'], f0['rew'], f0['act'], f0['old_mean'],
-                    np.tile(theta0[-A:], (M, 1)))
-    ctx.switch_to_pre_update()
-    ctx.process_samples(0, **opts)
-    ctx.inner_adapt(0)
-    th1 = ctx.get_task_thetas()           # post-update policies "sample" step 1 (ratio == 1 at the first epoch)
-    p1 = synthetic.make_paths_for_tasks(seed + 1, task_ids, th1, P, T, O, A, hidden)
-    f1 = _lib.flatten_paths(p1)
-    ctx.upload_step(1, f1['task_path_offsets'], f1['path_row_offsets'], f1['obs'], f1['rew'], f1['act'], f1['old_mean'],
-                    th1[:, -A:].copy())
 
-    def iteration():
-        ctx.switch_to_pre_update()                       # meta_trainer.py:85
-        ctx.process_samples(0, **opts)                   # :105  (step 0)
-        ctx.inner_adapt(0)                               # :116
-        ctx.process_samples(1, **opts)                   # :105  (step 1)
-        return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
+    def setup(M_global):
+        """One resident meta-batch of M_global tasks, task i on rank i mod world; returns (ctx, iteration, M_local)."""
+        task_ids = [i for i in range(M_global) if i % world == rank]
+        if args.shard_of > 1 and world == 1:
+            task_ids = [i for i in range(M_global) if i % args.shard_of == 0]
+        M = len(task_ids)
+        ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
+        if world > 1:
+            uid = comm.exchange_unique_id(rank, world, lambda: _lib.comm_unique_id())
+            ctx.comm_init(rank, world, uid)
+        # ---- synthetic, seeded, resident in HBM before timing (SURVEY.md 8d) ----
+        ctx.set_theta(theta0)
+        ctx.set_step_sizes(np.full(ctx.n_params, 0.1, np.float32))
+        p0 = synthetic.make_paths_for_tasks(seed, task_ids, theta0, P, T, O, A, hidden)
+        f0 = _lib.flatten_paths(p0)
+        ctx.upload_step(0, f0['task_path_offsets'], f0['path_row_offsets'], f0['obs'], f0['rew'], f0['act'], f0['old_mean'],
+                        np.tile(theta0[-A:], (M, 1)))
+        ctx.switch_to_pre_update()
+        ctx.process_samples(0, **opts)
+        ctx.inner_adapt(0)
+        th1 = ctx.get_task_thetas()           # post-update policies "sample" step 1 (ratio == 1 at the first epoch)
+        p1 = synthetic.make_paths_for_tasks(seed + 1, task_ids, th1, P, T, O, A, hidden)
+        f1 = _lib.flatten_paths(p1)
+        ctx.upload_step(1, f1['task_path_offsets'], f1['path_row_offsets'], f1['obs'], f1['rew'], f1['act'], f1['old_mean'],
+                        th1[:, -A:].copy())
 
-    def barrier():
-        ctx.sync()
-        ctx.allreduce_f64([0.0])
-        ctx.sync()
+        def iteration():
+            ctx.switch_to_pre_update()                       # meta_trainer.py:85
+            ctx.process_samples(0, **opts)                   # :105  (step 0)
+            ctx.inner_adapt(0)                               # :116
+            ctx.process_samples(1, **opts)                   # :105  (step 1)
+            return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
+        return ctx, iteration, M
 
-    def timed(n):
+    def run_timed(ctx, iteration, warmup, n):
+        """warmup untimed steps, then exactly n steps between barrier + device sync on both sides; max over ranks."""
+        def barrier():
+            ctx.sync()
+            ctx.allreduce_f64([0.0])
+            ctx.sync()
+        for _ in range(warmup):
+            iteration()
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -116,9 +118,11 @@ def main():
         dt = time.perf_counter() - t0
         return float(ctx.allreduce_f64([dt], op='max')[0]), res
 
-    for _ in range(args.warmup):
-        iteration()
-    elapsed, res = timed(args.steps)
+    M_global = cfg['M'] * (world if args.scaling == 'weak' else 1)
+    ctx, iteration, M = setup(M_global)
+    info = ctx.device_info()
+    alpha = np.full(ctx.n_params, 0.1, np.float32)
+    elapsed, res = run_timed(ctx, iteration, args.warmup, args.steps)
     if not np.isfinite(res['loss_after']):
         raise SystemExit('bench: non-finite loss')
     env_steps = M_global * N * (K + 1) * args.steps
@@ -170,9 +174,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, theta0, alpha, eta, opts, E)
 
+    ctx.close()
+    # ---- N > 1, weak scaling: also time the named 40-task batch split over the same ranks (fixed total work) ----
+    if world > 1 and args.scaling == 'weak':
+        ctx2, it2, M2 = setup(cfg['M'])
+        el2, _ = run_timed(ctx2, it2, args.warmup, args.steps)
+        out['fixed_batch'] = {'meta_batch_size': cfg['M'], 'tasks_per_gpu': M2, 'scaling': 'strong',
+                              'value': cfg['M'] * N * (K + 1) * args.steps / el2, 'ms_per_step': 1e3 * el2 / args.steps}
+        ctx2.close()
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
 
 
 def measured_traffic(kernel):

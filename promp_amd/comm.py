@@ -46,22 +46,31 @@ def _exchange_socket(rank, world, uid, addr, port, timeout):
     return buf
 
 
+_store = None     # one TCPStore client per process, reused by later exchanges
+_n_exchanges = 0  # every rank exchanges in the same order, so the counter names the exchange
+
+
 def exchange_unique_id(rank, world, make_id, timeout=300):
-    """rank 0 calls make_id() -> bytes[128]; every rank returns the same bytes."""
+    """rank 0 calls make_id() -> bytes[128]; every rank returns the same bytes.  May be called several times per
+    process (one communicator per context): each call uses its own key."""
+    global _store, _n_exchanges
     if world == 1:
         return make_id()
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500'))
     uid = make_id() if rank == 0 else None
+    seq = _n_exchanges
+    _n_exchanges += 1
     try:
         from datetime import timedelta
         from torch.distributed import TCPStore
-        agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True'
-        store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store), timeout=timedelta(seconds=timeout),
-                         wait_for_workers=False)
-        key = 'promp_amd/nccl_uid/%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
-        if rank == 0:
-            store.set(key, uid)
-        return bytes(store.get(key))
     except ImportError:
         return _exchange_socket(rank, world, uid, addr, port + 1, timeout)
+    if _store is None:
+        agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True'
+        _store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent_store), timeout=timedelta(seconds=timeout),
+                          wait_for_workers=False)
+    key = 'promp_amd/nccl_uid/%s/%d' % (os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'), seq)
+    if rank == 0:
+        _store.set(key, uid)
+    return bytes(_store.get(key))

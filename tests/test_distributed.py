@@ -87,6 +87,8 @@ from promp_amd import comm
 rank, world, local = comm.env_world()
 uid = comm.exchange_unique_id(rank, world, lambda: bytes((7 * i + 3) %% 256 for i in range(128)))
 assert uid == bytes((7 * i + 3) %% 256 for i in range(128)), uid[:8]
+uid2 = comm.exchange_unique_id(rank, world, lambda: bytes((5 * i + 1) %% 256 for i in range(128)))   # a second communicator
+assert uid2 == bytes((5 * i + 1) %% 256 for i in range(128)), uid2[:8]
 assert local == rank
 open(os.path.join(%r, 'ok%%d' %% rank), 'w').write('1')
 ''' % (ROOT, str(tmp_path)))
