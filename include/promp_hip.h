@@ -37,9 +37,9 @@ typedef struct promp_ctx promp_ctx;
 typedef struct promp_dims {
     int32_t n_tasks;            /* meta-tasks resident on this GPU (M_local)                       */
     int32_t n_tasks_global;     /* meta_batch_size over all ranks: the task-mean divides by this   */
-    int32_t obs_dim;            /* O                                                               */
+    int32_t obs_dim;            /* O, 1..128 (policy passes with O > 32 need hidden sizes 64 or 128)  */
     int32_t act_dim;            /* A  (<= 8)                                                       */
-    int32_t hidden1, hidden2;   /* hidden_sizes, each 32 or 64 in this build                       */
+    int32_t hidden1, hidden2;   /* hidden_sizes: (32,32), (64,64) or (128,128)                      */
     int32_t num_inner_steps;    /* K = num_inner_grad_steps (>= 1)                                 */
     int32_t max_rows;           /* capacity: rows (env steps) per sampling step over local tasks   */
     int32_t max_paths;          /* capacity: paths per sampling step over local tasks              */

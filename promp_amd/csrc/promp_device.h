@@ -48,6 +48,13 @@ PROMP_DEV void wave_sync() {
 }
 // keeps the compiler from interleaving two independent GEMM groups (which would add their live ranges)
 PROMP_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// A zero the optimiser cannot see through.  Added to the base pointers inside a long unrolled loop body it keeps the
+// hundreds of constant-offset address computations from being hoisted out of the loop (and then spilled) by LICM.
+PROMP_DEV int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return z;
+}
 PROMP_DEV unsigned long long promp_clock() { return (unsigned long long)clock64(); }
 PROMP_DEV unsigned long long promp_wall_clock() { return (unsigned long long)wall_clock64(); }   // constant 100 MHz
 PROMP_DEV float fast_exp(float x) { return __expf(x); }

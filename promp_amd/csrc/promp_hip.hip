@@ -2,6 +2,7 @@
 // See include/promp_hip.h for the contract.  gfx950 only; built by __graft_entry__.build():
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC promp_hip.hip -lrccl -o libpromp_hip.so
 #include "promp_kernels_policy.h"
+#include "promp_kernels_policy_wide.h"
 #include "promp_kernels_sample.h"
 #include "../../include/promp_hip.h"
 
@@ -82,7 +83,9 @@ struct promp_ctx {
     float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
     float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
     double *gram_partials = nullptr, *red64 = nullptr;
+    double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
     size_t smem_fwd = 0, smem_fwd8 = 0, smem_hvp = 0;
+    bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
     int fwd_waves = 8;                   // waves per k_fwd_bwd workgroup (8 = two per SIMD sharing one copy of the weights)
 #ifndef PROMP_EMU
     ncclComm_t comm = nullptr;
@@ -108,11 +111,10 @@ int dev_alloc(T** p, size_t n) {
 int check_dims(const promp_dims* d) {
     if (!d) return fail(-1, "dims is NULL");
     if (d->n_tasks < 1 || d->n_tasks_global < d->n_tasks) return fail(-1, "bad task counts (%d local, %d global)", d->n_tasks, d->n_tasks_global);
-    if (d->obs_dim < 1 || d->obs_dim > 32)
-        return fail(-1, "obs_dim %d unsupported: this build tiles the first layer for obs_dim <= 32 (Ant, O=111, is a later round)", d->obs_dim);
+    if (d->obs_dim < 1 || d->obs_dim > 128) return fail(-1, "obs_dim %d unsupported (1..128)", d->obs_dim);
     if (d->act_dim < 1 || d->act_dim > 8) return fail(-1, "act_dim %d unsupported (1..8)", d->act_dim);
-    if (!((d->hidden1 == 32 || d->hidden1 == 64) && d->hidden1 == d->hidden2))
-        return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates (32,32) and (64,64)", d->hidden1, d->hidden2);
+    if (d->hidden1 != d->hidden2 || !(d->hidden1 == 32 || d->hidden1 == 64 || d->hidden1 == 128))
+        return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates (32,32), (64,64) and (128,128)", d->hidden1, d->hidden2);
     if (d->num_inner_steps < 1) return fail(-1, "num_inner_steps must be >= 1");
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
@@ -187,7 +189,21 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
     if (prof_begin(c, id, S.n_rows)) return -2;
     const bool h64 = c->d.hidden1 == 64;
-    if (!hvp) {
+    if (c->wide && c->d.hidden1 == 32)   // (sample processing alone works for any obs_dim <= 128)
+        return fail(-1, "policy passes with obs_dim %d need hidden sizes 64 or 128 (hidden size 32 is tiled for obs_dim <= 32)", c->d.obs_dim);
+    if (c->wide) {
+        // cooperative kernels (promp_kernels_policy_wide.h): hidden 128, or hidden 64 with obs_dim > 32
+        const int nob = c->d.obs_dim <= 32 ? 2 : c->d.obs_dim <= 64 ? 4 : 8;
+        const size_t sm = hvp ? c->smem_hvp : c->smem_fwd;
+#define PROMP_WIDE_CASE(HH, NOB)                                                                                                \
+    if (c->d.hidden1 == HH && nob == NOB) {                                                                                      \
+        if (hvp) { auto k = k_wide_hvp<HH, NOB>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 4 * HH, sm, c->stream, a); }                 \
+        else if (fwd_only) { auto k = k_wide_fwd_bwd<HH, NOB, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 4 * HH, sm, c->stream, a); } \
+        else { auto k = k_wide_fwd_bwd<HH, NOB, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 4 * HH, sm, c->stream, a); }            \
+    }
+        PROMP_WIDE_CASE(128, 2) PROMP_WIDE_CASE(128, 4) PROMP_WIDE_CASE(128, 8) PROMP_WIDE_CASE(64, 4) PROMP_WIDE_CASE(64, 8)
+#undef PROMP_WIDE_CASE
+    } else if (!hvp) {
         if (fwd_only) {
             if (h64) { auto k = k_fwd_bwd<2, 2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
             else     { auto k = k_fwd_bwd<1, 1, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
@@ -332,9 +348,16 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) { c->fwd_waves = atoi(e) == 4 ? 4 : 8; }   // developer experiment
+    c->wide = dims->hidden1 == 128 || dims->obs_dim > 32;
+    if (c->wide) {
+        const int nob = dims->obs_dim <= 32 ? 2 : dims->obs_dim <= 64 ? 4 : 8;
+        c->smem_fwd = c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
+        c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
+    } else {
     c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, c->fwd_waves, param_count(dims)).total;
     c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
+    }
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;
         promp_ctx_destroy(c);
@@ -353,6 +376,15 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         HIPCHECK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define PROMP_WIDE_ATTR(HH, NOB)                                                                                          \
+    {                                                                                                                     \
+        auto w0 = k_wide_fwd_bwd<HH, NOB, true>; auto w1 = k_wide_fwd_bwd<HH, NOB, false>; auto w2 = k_wide_hvp<HH, NOB>;   \
+        HIPCHECK(hipFuncSetAttribute((const void*)w0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        HIPCHECK(hipFuncSetAttribute((const void*)w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        HIPCHECK(hipFuncSetAttribute((const void*)w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+    }
+        PROMP_WIDE_ATTR(128, 2) PROMP_WIDE_ATTR(128, 4) PROMP_WIDE_ATTR(128, 8) PROMP_WIDE_ATTR(64, 4) PROMP_WIDE_ATTR(64, 8)
+#undef PROMP_WIDE_ATTR
         auto g1 = k_gram<1>; auto g2 = k_gram<2>; auto g3 = k_gram<3>; auto g4 = k_gram<4>; auto g5 = k_gram<5>;
         HIPCHECK(hipFuncSetAttribute((const void*)g1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)g2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -360,6 +392,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         HIPCHECK(hipFuncSetAttribute((const void*)g4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)g5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_gram_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_fit_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const size_t NP = c->NP, MNP = (size_t)M * NP;
     int rc = 0;
@@ -373,6 +407,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->red, NP + K + 2); rc |= dev_alloc(&c->grad_mean, NP);
     rc |= dev_alloc(&c->stats, (size_t)K + 2); rc |= dev_alloc(&c->eta_dev, (size_t)K);
     rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
+    if (nblk_max > 5) rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
     rc |= dev_alloc(&c->red64, 64);
     rc |= dev_alloc(&c->dbg, 256);
     c->steps.resize(K + 1);
@@ -404,7 +439,7 @@ void promp_ctx_destroy(promp_ctx* c) {
     for (auto& S : c->steps) free_step(S);
     void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
-                    c->gram_partials, c->red64, c->fwd_buf, c->dbg};
+                    c->gram_partials, c->red64, c->fwd_buf, c->dbg, c->fit_scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& s : c->prof_slots)
@@ -552,13 +587,19 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<3>::NW, GramCfg<3>::SMEM_BYTES, st, a); } break;
             case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<4>::NW, GramCfg<4>::SMEM_BYTES, st, a); } break;
             case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<5>::NW, GramCfg<5>::SMEM_BYTES, st, a); } break;
-            default: return fail(-1, "feature dim %d unsupported in this build", a.D);
+            default:
+                if (nblk > 17) return fail(-1, "feature dim %d unsupported in this build", a.D);
+                PROMP_LAUNCH(k_gram_wide, dim3(S.n_work[0]), 512, gramw_smem(nblk, a.O), st, a, nblk);
         }
         HIPCHECK(hipGetLastError());
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
         const int DA = a.D + 1;
-        const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2);
-        PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
+        if (nblk <= 5) {
+            const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2);
+            PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
+        } else {
+            PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), 1024, fitw_smem(a.D), st, a, nblk, c->fit_scratch);
+        }
         HIPCHECK(hipGetLastError());
     }
     PROMP_LAUNCH(k_gae, dim3(S.n_paths), 64, sizeof(double) * (size_t)(a.D > 0 ? a.D : 1), st, a);

@@ -1193,7 +1193,7 @@ __global__ void __launch_bounds__(256) k_policy_forward(ForwardArgs a) {
     const float* th = a.theta_tasks + (long long)task * NP;
     for (int row = threadIdx.x; row < a.B; row += 256) {
         const float* x = a.obs + ((long long)task * a.B + row) * O;
-        float h1[64], h2[64];
+        float h1[128], h2[128];   // hidden sizes up to 128
         for (int j = 0; j < H1; ++j) {
             float z = th[ob1 + j];
             for (int k = 0; k < O; ++k) z = fmaf(x[k], th[k * H1 + j], z);

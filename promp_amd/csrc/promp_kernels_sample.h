@@ -364,3 +364,240 @@ __global__ void __launch_bounds__(256) k_normalize(SampleArgs a) {
         a.adv32[row] = (float)x;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Wide feature vectors (D + 1 > 80, i.e. obs_dim > 37: Ant's 2*111 + 4 = 226 features).
+//
+// k_gram_wide: the upper-triangular 16x16 block pairs of [Phi R]^T [Phi R] no longer fit one wave's registers
+// (120 pairs at D = 226), so the workgroup shares the feature tile: 8 waves, wave w owns the pairs p = w, w+8, ...
+// (<= GRAMW_PPW of them) over ALL rows of the work item -- no cross-wave reduction, each partial block is written by
+// its owner.  Rounds of 32 rows; same partial layout as k_gram ([NPAIR][256] doubles per work item).
+// grid = work items (table 0), block = 512.  smem: 32 * FS doubles + raw obs [32][O] floats + 2 * 32 doubles.
+// ---------------------------------------------------------------------------------------------
+#define GRAMW_PPW 20     // pairs per wave: 8 * 20 >= 17 * 18 / 2 (NBLK <= 17, D <= 271)
+#define GRAMW_ROWS 32
+
+PROMP_HD int gramw_fs(int NBLK) { return (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16; }
+PROMP_HD size_t gramw_smem(int NBLK, int O) {
+    return sizeof(double) * (size_t)(GRAMW_ROWS * gramw_fs(NBLK) + 2 * GRAMW_ROWS) + sizeof(float) * (size_t)(GRAMW_ROWS * O);
+}
+
+__global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
+    PROMP_SMEM_DECL;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    const int FS = gramw_fs(NBLK), NPAIR = NBLK * (NBLK + 1) / 2, NC = 16 * NBLK;
+    double* Phi = (double*)PROMP_SMEM_PTR;
+    double* Tg = Phi + GRAMW_ROWS * FS;
+    double* Tau = Tg + GRAMW_ROWS;
+    float* Ob = (float*)(Tau + GRAMW_ROWS);
+    const WorkItem wk = a.work[blockIdx.x];
+    const int O = a.O, D = a.D;
+    // this wave's pairs: offsets of the two 16-column blocks inside a feature row
+    int ca[GRAMW_PPW], cb[GRAMW_PPW];
+#pragma unroll
+    for (int j = 0; j < GRAMW_PPW; ++j) {
+        const int p = w + 8 * j;
+        int bi = 0, rem = p < NPAIR ? p : 0;
+        while (rem >= NBLK - bi) {
+            rem -= NBLK - bi;
+            ++bi;
+        }
+        ca[j] = 16 * bi + i16;
+        cb[j] = 16 * (bi + rem) + i16;
+    }
+    f64x4 acc[GRAMW_PPW];
+#pragma unroll
+    for (int j = 0; j < GRAMW_PPW; ++j) acc[j] = zero4d();
+    for (int base = wk.row_begin; base < wk.row_end; base += GRAMW_ROWS) {
+        const int nrows = (wk.row_end - base) < GRAMW_ROWS ? (wk.row_end - base) : GRAMW_ROWS;
+        __syncthreads();   // the previous round's MFMAs are done with Phi
+        if (a.kind == BASE_LINFEAT) {
+            const int lim = nrows * O;
+            for (int e = tid; e < GRAMW_ROWS * O; e += 512) {
+                const float x = a.obs[(long long)base * O + (e < lim ? e : 0)];
+                Ob[e] = (e < lim) ? x : 0.f;
+            }
+        }
+        if (tid < GRAMW_ROWS) {
+            const int r = tid < nrows ? tid : 0;
+            const double t = a.ret64[base + r];
+            const double tau = (double)a.row_t[base + r] / 100.0;
+            Tg[tid] = (tid < nrows) ? t : 0.0;
+            Tau[tid] = (tid < nrows) ? tau : 0.0;
+        }
+        __syncthreads();
+        {   // features: 16 threads per row, columns fc0, fc0 + 16, ...
+            const int fr = tid >> 4, fc0 = tid & 15;
+            const bool rv = fr < nrows;
+            const double tau = Tau[fr];
+            for (int c = fc0; c < NC; c += 16) {
+                double f = 0.0;
+                if (rv) {
+                    int q = c;
+                    bool done = false;
+                    if (c == D) {
+                        f = Tg[fr];
+                        done = true;
+                    } else if (c > D) {
+                        done = true;
+                    } else if (a.kind == BASE_LINFEAT) {
+                        if (c < 2 * O) {
+                            const float o = Ob[fr * O + (c < O ? c : c - O)];
+                            const float oc = fminf(fmaxf(o, -10.f), 10.f);
+                            f = (c < O) ? (double)oc : (double)(oc * oc);   // squared in float32 like the reference
+                            done = true;
+                        }
+                        q = c - 2 * O;
+                    }
+                    if (!done) f = (q == 0) ? tau : (q == 1) ? tau * tau : (q == 2) ? tau * tau * tau : 1.0;
+                }
+                Phi[fr * FS + c] = f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < GRAMW_ROWS / 4; ++s) {
+            const double* row = Phi + (4 * s + kk) * FS;
+#pragma unroll
+            for (int j = 0; j < GRAMW_PPW; ++j)
+                if (w + 8 * j < NPAIR) acc[j] = mfma16d(row[ca[j]], row[cb[j]], acc[j]);
+        }
+    }
+    double* out = a.gram_partials + (long long)blockIdx.x * (NPAIR * 256);
+#pragma unroll
+    for (int j = 0; j < GRAMW_PPW; ++j) {
+        const int p = w + 8 * j;
+        if (p < NPAIR)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[p * 256 + (kk + 4 * r) * 16 + i16] = acc[j][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fit_wide: the same solve as k_fit when the (D+1)^2 matrices do not fit in LDS.  G and the work matrix live in
+// global memory (L2-resident, 0.4 MB per task); a right-looking blocked Cholesky brings one 32-column panel at a time
+// into LDS, factors it there (carrying the right-hand-side row D along, as k_fit does), and applies its rank-32
+// update to the trailing matrix; the back substitution walks 32-row blocks of L through LDS.
+// grid = tasks, block = 1024.  smem: (D+1) * 33 + 3 * (D+1) + 2 doubles.
+// ---------------------------------------------------------------------------------------------
+#define FITW_NB 32
+#define FITW_PS (FITW_NB + 1)
+PROMP_HD size_t fitw_smem(int D) {
+    const size_t DA = D + 1, panel = DA * FITW_PS, blk = FITW_NB * (DA + 1);
+    return sizeof(double) * ((panel > blk ? panel : blk) + 3 * DA + 2);
+}
+
+__global__ void __launch_bounds__(1024) k_fit_wide(SampleArgs a, int NBLK, double* scratch) {
+    PROMP_SMEM_DECL;
+    const int D = a.D, DA = D + 1, NT = 1024;
+    const int tid = threadIdx.x, task = blockIdx.x;
+    const size_t region = (size_t)DA * FITW_PS > (size_t)FITW_NB * (DA + 1) ? (size_t)DA * FITW_PS : (size_t)FITW_NB * (DA + 1);
+    double* Pn = (double*)PROMP_SMEM_PTR;     // panel [DA - k0][33]  /  back-substitution block [32][DA + 1]
+    double* yv = Pn + region;
+    double* wv = yv + DA;
+    double* dg = wv + DA;
+    int* flag = (int*)(dg + DA);
+    double* G = scratch + (size_t)task * 2 * DA * DA;
+    double* Wm = G + (size_t)DA * DA;
+    const int NPAIR = NBLK * (NBLK + 1) / 2;
+    // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
+    const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
+    for (int e = tid; e < NPAIR * 256; e += NT) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int wg = wg0; wg < wg1; ++wg) s += a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+        int p = e >> 8, bi = 0, rem = p;
+        while (rem >= NBLK - bi) {
+            rem -= NBLK - bi;
+            ++bi;
+        }
+        const int bj = bi + rem;
+        const int row = 16 * bi + ((e & 255) >> 4), col = 16 * bj + (e & 15);
+        if (row < DA && col < DA) {
+            G[(size_t)row * DA + col] = s;
+            if (bi != bj) G[(size_t)col * DA + row] = s;
+        }
+    }
+    __syncthreads();
+    const float rDA = 1.0f / (float)DA;
+    double reg = a.reg;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        for (int e = tid; e < DA * DA; e += NT) {
+            const int i = (int)(((float)e + 0.5f) * rDA), j = e - i * DA;
+            Wm[e] = G[e] + ((i == j && i < D) ? reg : 0.0);
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < D; k0 += FITW_NB) {
+            const int nb = (D - k0) < FITW_NB ? (D - k0) : FITW_NB;   // columns of this panel
+            const int nr = DA - k0;                                  // rows k0..D
+            for (int e = tid; e < nr * FITW_NB; e += NT) {
+                const int i = e >> 5, c = e & 31;
+                Pn[i * FITW_PS + c] = (c < nb) ? Wm[(size_t)(k0 + i) * DA + k0 + c] : 0.0;
+            }
+            __syncthreads();
+            for (int c = 0; c < nb; ++c) {
+                const double piv = sqrt(Pn[c * FITW_PS + c]);   // nobody writes the diagonal entry during this step
+                if (tid == 0) dg[k0 + c] = piv;
+                for (int i = c + 1 + tid; i < nr; i += NT) Pn[i * FITW_PS + c] /= piv;
+                __syncthreads();
+                const int ncr = nb - c - 1;   // panel columns right of c
+                for (int e = tid; e < (nr - c - 1) * ncr; e += NT) {
+                    const int io = e / ncr, i = c + 1 + io, c2 = c + 1 + (e - io * ncr);
+                    if (c2 <= i) Pn[i * FITW_PS + c2] -= Pn[i * FITW_PS + c] * Pn[c2 * FITW_PS + c];
+                }
+                __syncthreads();
+            }
+            // write the factored panel back (strictly-lower part and the right-hand-side row)
+            for (int e = tid; e < nr * FITW_NB; e += NT) {
+                const int i = e >> 5, c = e & 31;
+                if (c < nb && i > c) Wm[(size_t)(k0 + i) * DA + k0 + c] = Pn[i * FITW_PS + c];
+            }
+            // rank-nb update of the trailing matrix: rows k1..D, columns k1..D-1, lower triangle
+            const int k1 = k0 + nb, tr = DA - k1, tc = D - k1;
+            if (tc > 0) {
+                const float rtc = 1.0f / (float)tc;
+                for (int e = tid; e < tr * tc; e += NT) {
+                    const int io = (int)(((float)e + 0.5f) * rtc), jo = e - io * tc;
+                    if (jo <= io) {
+                        const double* pi = Pn + (nb + io) * FITW_PS;
+                        const double* pj = Pn + (nb + jo) * FITW_PS;
+                        double s = 0.0;
+#pragma unroll 8
+                        for (int c = 0; c < FITW_NB; ++c) s += pi[c] * pj[c];   // columns >= nb of the panel are zero
+                        Wm[(size_t)(k1 + io) * DA + k1 + jo] -= s;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // back substitution L^T w = z, z = row D of the factor; 32 rows of L at a time through LDS
+        for (int e = tid; e < D; e += NT) yv[e] = Wm[(size_t)D * DA + e];
+        __syncthreads();
+        for (int kb = ((D - 1) / FITW_NB) * FITW_NB; kb >= 0; kb -= FITW_NB) {
+            const int nb = (D - kb) < FITW_NB ? (D - kb) : FITW_NB;
+            const int ncol = kb + nb;        // row j of L has entries 0..j
+            for (int e = tid; e < nb * ncol; e += NT) {
+                const int r = e / ncol, cc = e - r * ncol;
+                Pn[r * (DA + 1) + cc] = (cc < kb + r) ? Wm[(size_t)(kb + r) * DA + cc] : 0.0;
+            }
+            __syncthreads();
+            for (int r = nb - 1; r >= 0; --r) {
+                const int j = kb + r;
+                const double wj = yv[j] / dg[j];             // yv[j] is final: this step only touches yv[i < j]
+                if (tid == 0) wv[j] = wj;
+                for (int i = tid; i < j; i += NT) yv[i] -= Pn[r * (DA + 1) + i] * wj;
+                __syncthreads();
+            }
+        }
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int e = tid; e < D; e += NT)
+            if (wv[e] != wv[e]) *flag = 1;
+        __syncthreads();
+        const int bad = *flag;
+        __syncthreads();
+        if (!bad) break;
+        reg *= 10.0;
+    }
+    for (int e = tid; e < D; e += NT) a.coeffs[(long long)task * a.coeff_stride + e] = wv[e];
+}

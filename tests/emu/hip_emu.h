@@ -177,6 +177,7 @@ inline double shfl_down_f64(double v, int d) { return emu_shfl_f64(v, emu::lane(
 inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
 inline void wave_sync() { emu::wave().bar.arrive_and_wait(); }
 inline void sched_fence() {}
+inline int opaque_zero() { return 0; }
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }
 inline float fast_exp(float x) { return expf(x); }

@@ -47,9 +47,11 @@ def test_no_cpu_fallback_without_a_gpu():
 def test_argument_errors_are_reported():
     lib = devlib.emu_library()
     with pytest.raises(_lib.PrompError, match='obs_dim'):
-        _lib.Context(2, 111, 8, (64, 64), 1, max_rows=10, max_paths=2, lib=lib)
+        _lib.Context(2, 200, 8, (64, 64), 1, max_rows=10, max_paths=2, lib=lib)
     with pytest.raises(_lib.PrompError, match='hidden'):
-        _lib.Context(2, 4, 2, (128, 128), 1, max_rows=10, max_paths=2, lib=lib)
+        _lib.Context(2, 4, 2, (256, 256), 1, max_rows=10, max_paths=2, lib=lib)
+    with pytest.raises(_lib.PrompError, match='hidden'):
+        _lib.Context(2, 4, 2, (64, 32), 1, max_rows=10, max_paths=2, lib=lib)
     ctx = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)
     with pytest.raises(_lib.PrompError, match='no data'):
         ctx.process_samples(0)

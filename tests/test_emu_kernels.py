@@ -61,6 +61,36 @@ def test_hvp_h32_wide_obs(lib):
     pc.check_hvp(lib, 15, M=1, P=1, T=40, O=31, A=8, hidden=(32, 32))
 
 
+# ---- cooperative kernels for hidden 128 / obs_dim > 32 (promp_kernels_policy_wide.h) and > 80 baseline features ----
+def test_wide_loss_grad_ant_h128(lib):
+    pc.check_loss_grad(lib, 23, M=2, P=1, T=70, O=111, A=8, hidden=(128, 128))      # 64-row rounds: one full, one partial
+
+
+def test_wide_hvp_ant_h128(lib):
+    pc.check_hvp(lib, 24, M=1, P=1, T=45, O=111, A=8, hidden=(128, 128))            # 32-row rounds
+
+
+def test_wide_hvp_h128_narrow_obs(lib):
+    pc.check_hvp(lib, 25, M=1, P=2, T=20, O=20, A=6, hidden=(128, 128), ragged=True)
+
+
+def test_wide_loss_grad_h64_wide_obs(lib):
+    pc.check_loss_grad(lib, 21, M=1, P=1, T=40, O=40, A=8, hidden=(64, 64))
+
+
+def test_wide_hvp_h64_wide_obs(lib):
+    pc.check_hvp(lib, 27, M=1, P=1, T=33, O=100, A=2, hidden=(64, 64))
+
+
+def test_wide_meta_ant_h128(lib):
+    pc.check_meta(lib, 28, M=1, P=1, T=20, O=111, A=8, hidden=(128, 128), K=1, epochs=1)
+
+
+def test_sample_processing_wide_features(lib):
+    pc.check_sample_processing_oracle(lib, 31, M=2, P=3, T=70, O=111, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+
+
 def test_kl_objective_gradient(lib):
     # LOSS_KL (3): mean KL(old||new) and its gradient, the building block of the TRPO constraint
     import numpy as np

@@ -38,12 +38,21 @@ def test_sample_processing_ragged_long_paths(lib):
                                       kwargs=dict(discount=0.97, gae_lambda=0.9, normalize_adv=True, positive_adv=True))
 
 
+def test_sample_processing_ant_shape(lib):
+    # BASELINE config 4 observations: 2*111 + 4 = 226 features -> k_gram_wide / k_fit_wide
+    pc.check_sample_processing_oracle(lib, 24, M=6, P=20, T=200, O=111, ragged=False,
+                                      kwargs=dict(discount=0.99, gae_lambda=1.0, normalize_adv=True))
+    pc.check_sample_processing_oracle(lib, 25, M=3, P=5, T=150, O=45, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.95, normalize_adv=False))
+
+
 def test_sample_processing_point_env_shape(lib):
     pc.check_sample_processing_oracle(lib, 23, M=4, P=20, T=100, O=2, ragged=False,
                                       kwargs=dict(discount=0.99, gae_lambda=1.0, normalize_adv=True))
 
 
-@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 17, 6), ((32, 32), 31, 8)])
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 17, 6), ((32, 32), 31, 8),
+                                        ((128, 128), 111, 8), ((64, 64), 111, 8), ((128, 128), 20, 6), ((64, 64), 40, 3)])
 def test_loss_grad(lib, hidden, O, A):
     pc.check_loss_grad(lib, 31, M=5, P=6, T=150, O=O, A=A, hidden=hidden, ragged=True)
     pc.check_loss_grad(lib, 32, M=3, P=4, T=100, O=O, A=A, hidden=hidden, compact_log_std=True)
@@ -53,12 +62,14 @@ def test_loss_grad_clipped_log_std(lib):
     pc.check_loss_grad(lib, 33, M=2, P=2, T=50, O=4, A=3, hidden=(32, 32), low_log_std=True)
 
 
-@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 5, 3)])
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 5, 3), ((128, 128), 111, 8),
+                                        ((64, 64), 111, 8), ((128, 128), 50, 4), ((64, 64), 40, 3)])
 def test_hvp(lib, hidden, O, A):
     pc.check_hvp(lib, 41, M=4, P=5, T=130, O=O, A=A, hidden=hidden, ragged=True)
 
 
-@pytest.mark.parametrize('hidden,O,A,K', [((64, 64), 20, 6, 1), ((32, 32), 2, 2, 1), ((64, 64), 20, 6, 2), ((32, 32), 7, 3, 3)])
+@pytest.mark.parametrize('hidden,O,A,K', [((64, 64), 20, 6, 1), ((32, 32), 2, 2, 1), ((64, 64), 20, 6, 2), ((32, 32), 7, 3, 3),
+                                          ((128, 128), 111, 8, 1), ((64, 64), 111, 8, 2)])
 def test_meta_objective_adapt_optimize(lib, hidden, O, A, K):
     pc.check_meta(lib, 51, M=6, P=5, T=120, O=O, A=A, hidden=hidden, K=K, ragged=True, epochs=5)
 
