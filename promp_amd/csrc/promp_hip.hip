@@ -201,7 +201,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         else if (fwd_only) { auto k = k_wide_fwd_bwd<HH, NOB, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 4 * HH, sm, c->stream, a); } \
         else { auto k = k_wide_fwd_bwd<HH, NOB, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 4 * HH, sm, c->stream, a); }            \
     }
-        PROMP_WIDE_CASE(128, 2) PROMP_WIDE_CASE(128, 4) PROMP_WIDE_CASE(128, 8) PROMP_WIDE_CASE(64, 4) PROMP_WIDE_CASE(64, 8)
+        PROMP_WIDE_CASE(128, 2) PROMP_WIDE_CASE(128, 4) PROMP_WIDE_CASE(128, 8) PROMP_WIDE_CASE(64, 2) PROMP_WIDE_CASE(64, 4) PROMP_WIDE_CASE(64, 8)
 #undef PROMP_WIDE_CASE
     } else if (!hvp) {
         if (fwd_only) {
@@ -349,6 +349,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) { c->fwd_waves = atoi(e) == 4 ? 4 : 8; }   // developer experiment
     c->wide = dims->hidden1 == 128 || dims->obs_dim > 32;
+    if (const char* e = getenv("PROMP_DEV_FORCE_WIDE")) { if (atoi(e) == 1 && dims->hidden1 == 64) c->wide = true; }   // developer experiment
     if (c->wide) {
         const int nob = dims->obs_dim <= 32 ? 2 : dims->obs_dim <= 64 ? 4 : 8;
         c->smem_fwd = c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
@@ -383,7 +384,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         HIPCHECK(hipFuncSetAttribute((const void*)w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         HIPCHECK(hipFuncSetAttribute((const void*)w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
     }
-        PROMP_WIDE_ATTR(128, 2) PROMP_WIDE_ATTR(128, 4) PROMP_WIDE_ATTR(128, 8) PROMP_WIDE_ATTR(64, 4) PROMP_WIDE_ATTR(64, 8)
+        PROMP_WIDE_ATTR(128, 2) PROMP_WIDE_ATTR(128, 4) PROMP_WIDE_ATTR(128, 8) PROMP_WIDE_ATTR(64, 2) PROMP_WIDE_ATTR(64, 4) PROMP_WIDE_ATTR(64, 8)
 #undef PROMP_WIDE_ATTR
         auto g1 = k_gram<1>; auto g2 = k_gram<2>; auto g3 = k_gram<3>; auto g4 = k_gram<4>; auto g5 = k_gram<5>;
         HIPCHECK(hipFuncSetAttribute((const void*)g1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

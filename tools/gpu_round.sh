@@ -17,5 +17,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$R/pmc$i -o pmc$i -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/$R/pmc$i.err
   echo "pmc pass $i rc=$?"
 done
+# BASELINE config 4 (Ant shapes, cooperative kernels): bench line + kernel trace
+timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 > $ROOT/$R/bench_config4.json 2> $ROOT/$R/bench_config4.err; echo "bench config4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace4 -o trace4 -- python $ROOT/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/$R/trace4.err; echo "trace4 rc=$?"
+cd $ROOT; rm -f $R/trace4/*kernel_trace.csv
 cd $ROOT; rm -f $R/trace/*kernel_trace.csv $R/pmc*/*kernel_trace.csv   # keep the summaries small
 ls -R $R | head -40
