@@ -266,7 +266,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     FinalArgs f;
     f.lam = c->lam; f.NP = NP; f.K = K; f.n_tasks = M;
     f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = want_grad ? 1 : 0;
-    PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 255) / 256), 256, 0, c->stream, f);
+    PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
     HIPCHECK(hipGetLastError());
 #ifndef PROMP_EMU
     if (c->nranks > 1) {

@@ -162,7 +162,7 @@ def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, comp
     return res
 
 
-def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10):
+def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10, max_backtracks=15):
     """TRPOMAML.optimize_policy (row a15) through the plugin classes.
 
     The reference's Hessian-vector product is a finite difference with eps = 1e-5 on float32 parameters
@@ -188,6 +188,7 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
         algo = TRPOMAML(policy=policy, step_size=0.01, inner_type=inner_type, inner_lr=0.1, meta_batch_size=M,
                         num_inner_grad_steps=1)
         algo.optimizer._cg_iters = cg_iters
+        algo.optimizer._max_backtracks = max_backtracks      # (the emulator run shortens the line search)
         samples = [[dict(observations=s['observations'], actions=s['actions'], advantages=s['advantages'],
                          agent_infos=s['agent_infos']) for s in step] for step in all_slabs]
         # (1) ingredients at theta
