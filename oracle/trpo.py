@@ -28,14 +28,34 @@ def conjugate_gradients(f_Ax, b, cg_iters=10, residual_tol=1e-10):
     return x
 
 
+def exploration_term(spec, theta, slabs0, coeffs, want_grad=True):
+    """E-MAML (trpo_maml.py:137-144): mean_i [ -mean(adj_avg_rewards_i) * mean_n log pi_theta(a0_n | s0_n) ] and its gradient.
+    coeffs[i] = mean(adj_avg_rewards of task i at the last sampling step); log_std clipped as in params=None graphs."""
+    val, grad = 0.0, np.zeros(spec.n_params)
+    for c, slab in zip(coeffs, slabs0):
+        unit = dict(slab, advantages=np.ones_like(np.asarray(slab['advantages'], dtype=np.float64)))
+        r = pm.loss_and_grad(spec, theta, unit, 'loglik', True)      # loss = -mean(log pi)
+        val += c * r['loss']
+        if want_grad:
+            grad += c * r['grad']
+    n = len(slabs0)
+    return val / n, grad / n
+
+
 def trpo_maml_step(spec, theta, all_slabs, step_sizes, inner_kind='loglik', max_kl=0.01, cg_iters=10, reg_coeff=0.0,
-                   backtrack_ratio=0.8, max_backtracks=15, fd_eps=1e-5):
+                   backtrack_ratio=0.8, max_backtracks=15, fd_eps=1e-5, explore_coeffs=None):
     K = len(all_slabs) - 1
     eta = np.zeros(K)
     theta = np.asarray(theta, dtype=np.float64)
 
     def ev(th, outer, grad):
-        return pm.meta_objective_and_grad(spec, th, all_slabs, step_sizes, eta, 0.0, inner_kind, outer, want_grad=grad)
+        r = pm.meta_objective_and_grad(spec, th, all_slabs, step_sizes, eta, 0.0, inner_kind, outer, want_grad=grad)
+        if explore_coeffs is not None and outer == 'ratio':
+            v, g = exploration_term(spec, th, all_slabs[0], explore_coeffs, grad)
+            r = dict(r, loss=r['loss'] + v)
+            if grad:
+                r['grad'] = r['grad'] + g
+        return r
 
     r0 = ev(theta, 'ratio', True)
     loss_before, kl_before, g = r0['loss'], r0['outer_kl'], r0['grad']

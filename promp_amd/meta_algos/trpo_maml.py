@@ -1,5 +1,5 @@
 """TRPOMAML (reference: meta_policy_search/meta_algos/trpo_maml.py:8-191): MAML with a TRPO outer step.
-BASELINE.json config 5 (run_scripts/maml_run_mujoco.py).  E-MAML's exploration term is not implemented."""
+BASELINE.json config 5 (run_scripts/maml_run_mujoco.py).  exploration=True adds E-MAML's term (trpo_maml.py:137-144)."""
 import numpy as np
 
 from .. import _lib
@@ -21,14 +21,33 @@ class _DeviceEvaluator(object):
     def _eta(self):
         return np.zeros(self.algo.num_inner_grad_steps, np.float32)
 
+    def _exploration(self, want_grad):
+        """E-MAML term (trpo_maml.py:137-144): mean_i [ -mean(adj_avg_rewards_i) * mean_n log pi_theta(a0_n | s0_n) ], the
+        log-likelihood of the INITIAL (step-0) actions under the pre-update parameters.  On the device that is the
+        LOGLIK objective of slot 0 with unit advantages, evaluated at theta for every task."""
+        a, ctx = self.algo, self.ctx
+        saved = ctx.get_task_thetas()
+        ctx.switch_to_pre_update()
+        ctx.set_advantages(0, np.ones_like(a._explore_adv0))
+        g, l, _ = ctx.eval_loss_grad(0, _lib.LOSS_LOGLIK, clip_log_std=True)      # l_i = -mean log pi ; g_i = d l_i / d theta
+        ctx.set_advantages(0, a._explore_adv0)
+        ctx.set_task_thetas(saved)
+        c = a._explore_coeffs
+        tot = np.concatenate([[np.dot(c, l.astype(np.float64))], c.dot(g.astype(np.float64)) if want_grad else []])
+        if a.meta_batch_size != ctx.n_tasks:          # task-sharded run: sum over ranks (64 doubles per call)
+            tot = np.concatenate([ctx.allreduce_f64(tot[i:i + 64]) for i in range(0, tot.size, 64)])
+        return tot[0] / a.meta_batch_size, (tot[1:] / a.meta_batch_size if want_grad else None)
+
     def loss(self):          # -mean_i mean(ratio * adv) at theta'_i   (trpo_maml.py:135,150)
-        return self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['loss']
+        v = self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['loss']
+        return v + self._exploration(False)[0] if self.algo.exploration else v
 
     def constraint_val(self):   # mean_i mean KL(old || pi_theta'_i)   (trpo_maml.py:133,147)
         return self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['outer_kl']
 
     def gradient(self):
-        return self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0]
+        g = self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0]
+        return (g + self._exploration(True)[1]).astype(np.float32) if self.algo.exploration else g
 
     def constraint_gradient(self):
         return self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_KL)[0]
@@ -43,7 +62,7 @@ class _DeviceEvaluator(object):
 class TRPOMAML(MAMLAlgo):
     """
     Args (trpo_maml.py:23-31): policy, name, step_size (trust region), inner_type in {'log_likelihood',
-    'likelihood_ratio'}, exploration (E-MAML; not implemented), inner_lr, meta_batch_size, num_inner_grad_steps,
+    'likelihood_ratio'}, exploration (E-MAML), inner_lr, meta_batch_size, num_inner_grad_steps,
     trainable_inner_step_size
     """
 
@@ -52,14 +71,14 @@ class TRPOMAML(MAMLAlgo):
         assert inner_type in ['log_likelihood', 'likelihood_ratio', 'dice']
         if inner_type == 'dice':
             raise NotImplementedError          # as the reference (trpo_maml.py:63-64)
-        if exploration:
-            raise NotImplementedError('E-MAML exploration term (trpo_maml.py:137-144) is not implemented')
         self.step_size = step_size
         self.inner_type = inner_type
         self.inner_kind = _lib.INNER_LOGLIK if inner_type == 'log_likelihood' else _lib.INNER_RATIO
         self.name = name
         self.exploration = exploration
         self._optimization_keys = ['observations', 'actions', 'advantages', 'agent_infos']
+        if exploration:      # trpo_maml.py:41-42
+            self._optimization_keys.append('adj_avg_rewards')
         self.optimizer = ConjugateGradientOptimizer()
         self.optimizer.build_graph(_DeviceEvaluator(self), step_size)
 
@@ -68,6 +87,10 @@ class TRPOMAML(MAMLAlgo):
         assert len(all_samples_data) == self.num_inner_grad_steps + 1
         slots = [self._slot_of(sd, k) for k, sd in enumerate(all_samples_data)]
         assert slots == list(range(self.num_inner_grad_steps + 1))
+        if self.exploration:
+            last = all_samples_data[self.num_inner_grad_steps]
+            self._explore_coeffs = np.array([np.mean(np.asarray(d['adj_avg_rewards'], dtype=np.float32)) for d in last], np.float64)
+            self._explore_adv0 = np.concatenate([np.asarray(d['advantages'], dtype=np.float32) for d in all_samples_data[0]])
         logger.log('Computing KL before')
         mean_kl_before = self.optimizer.constraint_val()
         logger.log('Computing loss before')

@@ -162,7 +162,8 @@ def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, comp
     return res
 
 
-def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10, max_backtracks=15):
+def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10, max_backtracks=15,
+               exploration=False):
     """TRPOMAML.optimize_policy (row a15) through the plugin classes.
 
     The reference's Hessian-vector product is a finite difference with eps = 1e-5 on float32 parameters
@@ -186,11 +187,19 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
         policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
         policy.set_params(spec.to_ordered_dict(theta))
         algo = TRPOMAML(policy=policy, step_size=0.01, inner_type=inner_type, inner_lr=0.1, meta_batch_size=M,
-                        num_inner_grad_steps=1)
+                        num_inner_grad_steps=1, exploration=exploration)
         algo.optimizer._cg_iters = cg_iters
         algo.optimizer._max_backtracks = max_backtracks      # (the emulator run shortens the line search)
         samples = [[dict(observations=s['observations'], actions=s['actions'], advantages=s['advantages'],
                          agent_infos=s['agent_infos']) for s in step] for step in all_slabs]
+        coeffs = None
+        if exploration:      # E-MAML: cross-task reward z-scores of the last sampling step (what process_samples attaches)
+            erng = np.random.RandomState(seed + 5)
+            for d in samples[-1]:
+                d['adj_avg_rewards'] = erng.randn(len(d['advantages'])).astype(np.float32) + 0.5
+            coeffs = np.array([np.mean(d['adj_avg_rewards']) for d in samples[-1]], np.float64)
+            algo._explore_coeffs = coeffs
+            algo._explore_adv0 = np.concatenate([np.asarray(d['advantages'], np.float32) for d in samples[0]])
         # (1) ingredients at theta
         for k, sd in enumerate(samples):
             algo._slot_of(sd, k)
@@ -198,13 +207,17 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
         t64 = theta.astype(np.float64)
         r_loss = pm.meta_objective_and_grad(spec, t64, all_slabs, alpha, np.zeros(1), 0.0, kind, 'ratio')
         r_kl = pm.meta_objective_and_grad(spec, t64, all_slabs, alpha, np.zeros(1), 0.0, kind, 'kl')
+        if exploration:
+            xv, xg = otrpo.exploration_term(spec, t64, all_slabs[0], coeffs)
+            r_loss = dict(r_loss, loss=r_loss['loss'] + xv, grad=r_loss['grad'] + xg)
         np.testing.assert_allclose(ev.loss(), r_loss['loss'], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(ev.constraint_val(), r_loss['outer_kl'], rtol=1e-4, atol=1e-7)
         assert rel_max(ev.gradient(), r_loss['grad']) < 1e-4
         assert rel_max(ev.constraint_gradient(), r_kl['grad']) < 1e-4
         # (2) the step
         algo.optimize_policy(samples, log=False)
-        ref = otrpo.trpo_maml_step(spec, theta, all_slabs, alpha, inner_kind=kind, max_kl=0.01, cg_iters=cg_iters)
+        ref = otrpo.trpo_maml_step(spec, theta, all_slabs, alpha, inner_kind=kind, max_kl=0.01, cg_iters=cg_iters,
+                                   explore_coeffs=coeffs)
         st, last = algo.last_stats, algo.optimizer.last
         d, dr = last['descent_direction'].astype(np.float64), ref['descent_direction']
         cos = d.dot(dr) / (np.linalg.norm(d) * np.linalg.norm(dr))

@@ -107,5 +107,9 @@ def test_kl_objective_gradient(lib):
     ctx.close()
 
 
+def test_trpo_e_maml_exploration_term(lib):
+    pc.check_trpo(lib, 18, M=2, P=1, T=16, O=4, A=2, hidden=(32, 32), cg_iters=1, max_backtracks=2, exploration=True)
+
+
 def test_trpo_maml_step(lib):
     pc.check_trpo(lib, 17, M=2, P=1, T=20, O=4, A=2, hidden=(32, 32), cg_iters=2, max_backtracks=4)

@@ -190,3 +190,4 @@ def test_kl_objective_and_trpo_maml_step(lib):
     # row a15 / BASELINE config 5 shapes (reduced M): device ingredients tight, step properties (see parity_checks)
     st, ref = pc.check_trpo(lib, 61, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood')
     st2, _ = pc.check_trpo(lib, 62, M=3, P=4, T=60, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio')
+    pc.check_trpo(lib, 63, M=4, P=4, T=80, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood', exploration=True)   # E-MAML
