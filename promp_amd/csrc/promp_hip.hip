@@ -408,7 +408,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->red, NP + K + 2); rc |= dev_alloc(&c->grad_mean, NP);
     rc |= dev_alloc(&c->stats, (size_t)K + 2); rc |= dev_alloc(&c->eta_dev, (size_t)K);
     rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
-    if (nblk_max > 5) rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
+    if (nblk_max > 5 || dims->obs_dim > 32) rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
     rc |= dev_alloc(&c->red64, 64);
     rc |= dev_alloc(&c->dbg, 256);
     c->steps.resize(K + 1);
@@ -582,7 +582,8 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (a.kind != BASE_ZERO) {
         const int nblk = (a.D + 1 + 15) / 16;
         if (prof_begin(c, PROMP_KERNEL_GRAM, S.n_rows)) return -2;
-        switch (nblk) {
+        const bool small = nblk <= 5 && a.O <= 32;   // k_gram<NBLK> stages raw observation rows of at most 32 floats
+        switch (small ? nblk : 0) {
             case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<1>::NW, GramCfg<1>::SMEM_BYTES, st, a); } break;
             case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<2>::NW, GramCfg<2>::SMEM_BYTES, st, a); } break;
             case 3: { auto k = k_gram<3>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<3>::NW, GramCfg<3>::SMEM_BYTES, st, a); } break;
@@ -595,7 +596,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         HIPCHECK(hipGetLastError());
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
         const int DA = a.D + 1;
-        if (nblk <= 5) {
+        if (small) {
             const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2);
             PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         } else {

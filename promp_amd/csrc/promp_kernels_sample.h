@@ -366,7 +366,8 @@ __global__ void __launch_bounds__(256) k_normalize(SampleArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wide feature vectors (D + 1 > 80, i.e. obs_dim > 37: Ant's 2*111 + 4 = 226 features).
+// Wide observations (obs_dim > 32, i.e. more than 68 features: Ant's 2*111 + 4 = 226).  k_gram<NBLK> stages raw
+// observation rows of at most 32 floats per wave and k_fit keeps two (D+1)^2 matrices in LDS; beyond that:
 //
 // k_gram_wide: the upper-triangular 16x16 block pairs of [Phi R]^T [Phi R] no longer fit one wave's registers
 // (120 pairs at D = 226), so the workgroup shares the feature tile: 8 waves, wave w owns the pairs p = w, w+8, ...

@@ -82,6 +82,12 @@ def test_wide_hvp_h64_wide_obs(lib):
     pc.check_hvp(lib, 27, M=1, P=1, T=33, O=100, A=2, hidden=(64, 64))
 
 
+def test_sample_processing_first_wide_obs_dim(lib):
+    # obs_dim 33 is the first size routed to k_gram_wide / k_fit_wide (5 feature blocks, like the largest k_gram<NBLK>)
+    pc.check_sample_processing_oracle(lib, 333, M=2, P=3, T=60, O=33, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+
+
 def test_sample_processing_wide_features(lib):
     pc.check_sample_processing_oracle(lib, 31, M=2, P=3, T=70, O=111, ragged=True,
                                       kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))

@@ -68,6 +68,31 @@ def test_hvp(lib, hidden, O, A):
     pc.check_hvp(lib, 41, M=4, P=5, T=130, O=O, A=A, hidden=hidden, ragged=True)
 
 
+def _random_shapes(n, seed):
+    """seeded sweep over the supported shape space: every hidden width, obs_dim 1..128 (policy passes with obs > 32 need
+    hidden >= 64), act_dim 1..8, ragged rows that leave partial 16 / 32 / 64-row tiles"""
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        H = int(rng.choice([32, 64, 128]))
+        O = int(rng.randint(1, 33)) if H == 32 else int(rng.choice([rng.randint(1, 33), rng.randint(33, 129)]))
+        out.append((H, O, int(rng.randint(1, 9)), int(rng.randint(1, 5)), int(rng.randint(1, 5)), int(rng.randint(5, 140))))
+    return out
+
+
+@pytest.mark.parametrize('H,O,A,M,P,T', _random_shapes(14, 2024))
+def test_shape_sweep_loss_grad_and_hvp(lib, H, O, A, M, P, T):
+    pc.check_loss_grad(lib, 100 + H + O, M=M, P=P, T=T, O=O, A=A, hidden=(H, H), ragged=True)
+    pc.check_hvp(lib, 200 + H + O, M=M, P=P, T=T, O=O, A=A, hidden=(H, H), ragged=True)
+
+
+@pytest.mark.parametrize('O', [33, 64, 100, 128])
+def test_sample_processing_feature_widths(lib, O):
+    # 2*O+4 features: 70 (last k_gram/k_fit size), 132, 204, 260 (k_gram_wide / k_fit_wide up to 17 blocks)
+    pc.check_sample_processing_oracle(lib, 300 + O, M=3, P=6, T=120, O=O, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+
+
 @pytest.mark.parametrize('hidden,O,A,K', [((64, 64), 20, 6, 1), ((32, 32), 2, 2, 1), ((64, 64), 20, 6, 2), ((32, 32), 7, 3, 3),
                                           ((128, 128), 111, 8, 1), ((64, 64), 111, 8, 2)])
 def test_meta_objective_adapt_optimize(lib, hidden, O, A, K):
