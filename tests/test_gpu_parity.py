@@ -80,10 +80,15 @@ def _random_shapes(n, seed):
     return out
 
 
-@pytest.mark.parametrize('H,O,A,M,P,T', _random_shapes(14, 2024))
+@pytest.mark.parametrize('H,O,A,M,P,T', _random_shapes(24, 2024))
 def test_shape_sweep_loss_grad_and_hvp(lib, H, O, A, M, P, T):
     pc.check_loss_grad(lib, 100 + H + O, M=M, P=P, T=T, O=O, A=A, hidden=(H, H), ragged=True)
     pc.check_hvp(lib, 200 + H + O, M=M, P=P, T=T, O=O, A=A, hidden=(H, H), ragged=True)
+
+
+@pytest.mark.parametrize('H,O,A,M,P,T', _random_shapes(8, 77))
+def test_shape_sweep_meta_update(lib, H, O, A, M, P, T):
+    pc.check_meta(lib, 400 + H + O, M=M, P=P, T=max(T, 30), O=O, A=A, hidden=(H, H), K=1 + (O % 2), ragged=True, epochs=2)
 
 
 @pytest.mark.parametrize('O', [33, 64, 100, 128])
