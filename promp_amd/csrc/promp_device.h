@@ -55,6 +55,9 @@ PROMP_DEV int opaque_zero() {
     asm volatile("" : "+v"(z));
     return z;
 }
+// Tells the compiler a value is the same in every lane of the wave (e.g. the wave index threadIdx.x >> 6), so that
+// everything derived from it lives in scalar registers.
+PROMP_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 PROMP_DEV unsigned long long promp_clock() { return (unsigned long long)clock64(); }
 PROMP_DEV unsigned long long promp_wall_clock() { return (unsigned long long)wall_clock64(); }   // constant 100 MHz
 PROMP_DEV float fast_exp(float x) { return __expf(x); }

@@ -385,7 +385,7 @@ PROMP_HD size_t gramw_smem(int NBLK, int O) {
 
 __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
     PROMP_SMEM_DECL;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), i16 = lane & 15, kk = lane >> 4;
     const int FS = gramw_fs(NBLK), NPAIR = NBLK * (NBLK + 1) / 2, NC = 16 * NBLK;
     double* Phi = (double*)PROMP_SMEM_PTR;
     double* Tg = Phi + GRAMW_ROWS * FS;
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
     float* Ob = (float*)(Tau + GRAMW_ROWS);
     const WorkItem wk = a.work[blockIdx.x];
     const int O = a.O, D = a.D;
-    // this wave's pairs: offsets of the two 16-column blocks inside a feature row
+    // this wave's pairs: offsets of the two 16-column blocks inside a feature row (wave-uniform: scalar registers)
     int ca[GRAMW_PPW], cb[GRAMW_PPW];
 #pragma unroll
     for (int j = 0; j < GRAMW_PPW; ++j) {
@@ -403,8 +403,8 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
             rem -= NBLK - bi;
             ++bi;
         }
-        ca[j] = 16 * bi + i16;
-        cb[j] = 16 * (bi + rem) + i16;
+        ca[j] = 16 * bi;
+        cb[j] = 16 * (bi + rem);
     }
     f64x4 acc[GRAMW_PPW];
 #pragma unroll
@@ -456,12 +456,14 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
             }
         }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll 1
         for (int s = 0; s < GRAMW_ROWS / 4; ++s) {
-            const double* row = Phi + (4 * s + kk) * FS;
+            const double* row = Phi + (4 * s + kk) * FS + i16;
 #pragma unroll
-            for (int j = 0; j < GRAMW_PPW; ++j)
+            for (int j = 0; j < GRAMW_PPW; ++j) {
                 if (w + 8 * j < NPAIR) acc[j] = mfma16d(row[ca[j]], row[cb[j]], acc[j]);
+                if ((j & 3) == 3) sched_fence();       // at most 4 pairs' operands in flight: the pairs own the registers
+            }
         }
     }
     double* out = a.gram_partials + (long long)blockIdx.x * (NPAIR * 256);

@@ -178,6 +178,7 @@ inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
 inline void wave_sync() { emu::wave().bar.arrive_and_wait(); }
 inline void sched_fence() {}
 inline int opaque_zero() { return 0; }
+inline int wave_uniform(int v) { return v; }
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }
 inline float fast_exp(float x) { return expf(x); }
