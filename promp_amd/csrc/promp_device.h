@@ -64,12 +64,6 @@ PROMP_DEV float fast_exp(float x) { return __expf(x); }
 PROMP_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 #endif
 
-PROMP_DEV f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    return z;
-}
 PROMP_DEV f32x4 zero4() {
     f32x4 z;
 #pragma unroll
@@ -104,41 +98,6 @@ PROMP_DEV double wave_min_f64(double v) {
 
 // tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7, saturates correctly at +-1.
 PROMP_DEV float fast_tanh(float x) { return 1.f - 2.f * fast_rcp(fast_exp(2.f * x) + 1.f); }
-
-// row of accumulator register r of a 32x32 MFMA tile for lane-half lh = lane>>5
-PROMP_DEV int row32(int r, int lh) { return (r & 3) + ((r >> 2) << 3) + (lh << 2); }
-
-// One MFMA operand stream: the value this lane feeds at k-step k is p[k*ks].
-struct Opnd {
-    const float* p;
-    int ks;
-};
-
-// acc[32x32] += sgn * A * B over K (even, >= 2) with 32x32x2 MFMAs.  Operands of step k+1 are requested
-// from LDS before the MFMA of step k issues, so the ~64-cycle MFMA covers the LDS latency.
-PROMP_DEV void gemm32(f32x16& acc, Opnd a, Opnd b, int K, float sgn) {
-    float a0 = a.p[0], b0 = b.p[0];
-#pragma unroll 4
-    for (int k = 2; k < K; k += 2) {
-        const float a1 = a.p[k * a.ks], b1 = b.p[k * b.ks];
-        acc = mfma32(sgn * a0, b0, acc);
-        a0 = a1;
-        b0 = b1;
-    }
-    acc = mfma32(sgn * a0, b0, acc);
-}
-// acc[16x16] += sgn * A * B over K (multiple of 4, >= 4) with 16x16x4 MFMAs
-PROMP_DEV void gemm16(f32x4& acc, Opnd a, Opnd b, int K, float sgn) {
-    float a0 = a.p[0], b0 = b.p[0];
-#pragma unroll 4
-    for (int k = 4; k < K; k += 4) {
-        const float a1 = a.p[k * a.ks], b1 = b.p[k * b.ks];
-        acc = mfma16(sgn * a0, b0, acc);
-        a0 = a1;
-        b0 = b1;
-    }
-    acc = mfma16(sgn * a0, b0, acc);
-}
 
 // acc[ia][ib] (16x16 tiles) += sgn * A_ia * B_ib over NS k-steps of 16x16x4 MFMAs.
 // Operand streams: at step s, A block ia feeds a[s*a_ss + ia*a_bs], B block ib feeds b[s*b_ss + ib*b_bs] (pointers

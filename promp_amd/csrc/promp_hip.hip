@@ -86,7 +86,6 @@ struct promp_ctx {
     double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
     size_t smem_fwd = 0, smem_fwd8 = 0, smem_hvp = 0;
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
-    int fwd_waves = 8;                   // waves per k_fwd_bwd workgroup (8 = two per SIMD sharing one copy of the weights)
 #ifndef PROMP_EMU
     ncclComm_t comm = nullptr;
 #endif
@@ -207,12 +206,9 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         if (fwd_only) {
             if (h64) { auto k = k_fwd_bwd<2, 2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
             else     { auto k = k_fwd_bwd<1, 1, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
-        } else if (c->fwd_waves == 8) {
+        } else {
             if (h64) { auto k = k_fwd_bwd<2, 2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
             else     { auto k = k_fwd_bwd<1, 1, 8, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
-        } else {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 4, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 4, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_fwd, c->stream, a); }
         }
     } else {
         if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
@@ -347,7 +343,6 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
-    if (const char* e = getenv("PROMP_DEV_FWD_WAVES")) { c->fwd_waves = atoi(e) == 4 ? 4 : 8; }   // developer experiment
     c->wide = dims->hidden1 == 128 || dims->obs_dim > 32;
     if (const char* e = getenv("PROMP_DEV_FORCE_WIDE")) { if (atoi(e) == 1 && dims->hidden1 == 64) c->wide = true; }   // developer experiment
     if (c->wide) {
@@ -355,7 +350,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         c->smem_fwd = c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
         c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
     } else {
-    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, c->fwd_waves, param_count(dims)).total;
+    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
     c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
     c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
     }
@@ -365,7 +360,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         return fail(-1, "LDS budget exceeded (%zu bytes)", need);
     }
     {
-        auto k0 = k_fwd_bwd<2, 2, 4, true>; auto k1 = k_fwd_bwd<1, 1, 4, true>; auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
+        auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
         auto k4 = k_fwd_bwd<2, 2, 8, true>; auto k5 = k_fwd_bwd<1, 1, 8, true>;
         auto k6 = k_fwd_bwd<2, 2, 8, false>; auto k7 = k_fwd_bwd<1, 1, 8, false>;
         HIPCHECK(hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -373,8 +368,6 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
 
         HIPCHECK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define PROMP_WIDE_ATTR(HH, NOB)                                                                                          \
@@ -489,7 +482,6 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         // table 0: k_hvp and k_fwd_bwd (one workgroup per CU: measured faster than two shorter ones, the parameter
         // staging and the end-of-kernel reduction amortise over twice the tiles); table 1: the sample-processing kernels
         int target = (t + 1) * c->n_cus;
-        if (const char* e = getenv(t == 0 ? "PROMP_DEV_TARGET0" : "PROMP_DEV_TARGET1")) target = atoi(e);   // developer experiment
         two[t].assign(M + 1, 0);
         // largest-remainder split: sum of workgroups <= target (one more would cost a whole second round on the chip),
         // every task gets at least one and at most one per tile
