@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 #endif
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -46,7 +47,8 @@ int fail(int code, const char* fmt, ...) {
 
 struct StepData {
     int n_paths = 0, n_rows = 0;
-    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (policy passes), [1]: two per CU (sample kernels)
+    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (k_hvp, wide passes, gram, fit), [1]: two per CU (k_normalize)
+    int n_pwork = 0;                   // k_fwd_bwd workgroups (wave-granular PassWork table)
     bool has_policy = false, processed = false, has_adv = false;
     int ls_per_row = 0;
     int feat_dim = 0;
@@ -55,10 +57,11 @@ struct StepData {
     double *ret64 = nullptr, *adv64 = nullptr;
     int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
     int *task_row_offsets = nullptr, *task_path_offsets = nullptr;
-    int* task_wg_offsets[2] = {nullptr, nullptr};
+    int* task_wg_offsets[3] = {nullptr, nullptr, nullptr};   // [2]: partial slots of the k_fwd_bwd table per task
     double *path_ret0 = nullptr, *path_undisc = nullptr, *path_rsq = nullptr, *path_mom = nullptr;
     double* coeffs = nullptr;
     WorkItem* work[2] = {nullptr, nullptr};
+    PassWork* pwork = nullptr;
 };
 
 struct ProfSlot {
@@ -177,6 +180,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
+    a.pwork = S.pwork;
     a.theta = theta; a.theta_task_stride = theta_stride;
     a.vdir = c->vbuf;
     a.partials = c->partials; a.partial_stride = c->partial_stride;
@@ -204,11 +208,11 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
 #undef PROMP_WIDE_CASE
     } else if (!hvp) {
         if (fwd_only) {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 8, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd8, c->stream, a); }
+            if (h64) { auto k = k_fwd_bwd<2, 2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd8, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 8, false>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd8, c->stream, a); }
         } else {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 8, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 512, c->smem_fwd, c->stream, a); }
+            if (h64) { auto k = k_fwd_bwd<2, 2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }
+            else     { auto k = k_fwd_bwd<1, 1, 8, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }
         }
     } else {
         if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
@@ -231,6 +235,9 @@ int launch_reduce(promp_ctx* c, StepData& S, int table, int mode, const float* c
     return 0;
 }
 
+// partial-sum table the reduction after a pass reads: k_fwd_bwd writes wave-granular slots (table 2)
+int pass_table(const promp_ctx* c, bool hvp) { return (hvp || c->wide) ? 0 : 2; }
+
 int loss_kind_inner(int inner_kind) { return inner_kind == PROMP_INNER_LOGLIK ? LOSS_LOGLIK : LOSS_RATIO; }
 int loss_kind_outer(int outer_kind) {
     return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : outer_kind == PROMP_OUTER_KL ? LOSS_KL : LOSS_CLIP;
@@ -247,16 +254,16 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
         if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f)) return -2;
-        if (launch_reduce(c, c->steps[k], 0, 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+        if (launch_reduce(c, c->steps[k], pass_table(c, false), 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
     }
     if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f, !want_grad)) return -2;
-    if (launch_reduce(c, c->steps[K], 0, want_grad ? 1 : 4, nullptr, 0, nullptr, c->scal_outer)) return -2;
+    if (launch_reduce(c, c->steps[K], pass_table(c, false), want_grad ? 1 : 4, nullptr, 0, nullptr, c->scal_outer)) return -2;
     if (want_grad) {
         for (int k = K - 1; k >= 0; --k) {
             const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
             const long long st = (k == 0) ? 0 : NP;
             if (launch_pass(c, c->steps[k], true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, eta_host[k] / (float)K)) return -2;
-            if (launch_reduce(c, c->steps[k], 0, 2, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+            if (launch_reduce(c, c->steps[k], pass_table(c, true), 2, nullptr, 0, nullptr, c->scal_tmp)) return -2;
         }
     }
     FinalArgs f;
@@ -294,7 +301,7 @@ int upload_eta(promp_ctx* c, const float* eta) {
 
 void free_step(StepData& S) {
     void* ptrs[] = {S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
-                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.path_ret0,
+                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -414,6 +421,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
         rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
         rc |= dev_alloc(&S.task_wg_offsets[0], (size_t)M + 1); rc |= dev_alloc(&S.task_wg_offsets[1], (size_t)M + 1);
+        rc |= dev_alloc(&S.task_wg_offsets[2], (size_t)M + 1); rc |= dev_alloc(&S.pwork, (size_t)c->max_work);
         rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
         rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
         rc |= dev_alloc(&S.work[0], (size_t)c->max_work); rc |= dev_alloc(&S.work[1], (size_t)c->max_work);
@@ -520,7 +528,88 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         }
         if ((int)work[t].size() > c->max_work) return fail(-5, "internal: work table overflow (%zu > %d)", work[t].size(), c->max_work);
     }
+    // k_fwd_bwd: waves (8 per CU-resident workgroup) shared out over tasks in proportion to their tiles, largest remainder;
+    // a workgroup serves at most two tasks, which holds when every task gets >= 8 waves -- otherwise one task per
+    // workgroup (the WorkItem split above, re-expressed wave by wave)
+    std::vector<PassWork> pwork;
+    std::vector<int> slot_off(M + 1, 0);
+    {
+        const int NWV = 8;
+        const long long total_waves = (long long)NWV * c->n_cus;
+        std::vector<long long> nwv(M), rem(M);
+        long long used = 0;
+        bool fine = true;
+        for (int i = 0; i < M; ++i) {
+            const long long num = tiles[i] * total_waves;
+            nwv[i] = num / total_tiles;
+            rem[i] = num % total_tiles;
+            if (nwv[i] > tiles[i]) { nwv[i] = tiles[i]; rem[i] = 0; }
+            used += nwv[i];
+        }
+        while (used < total_waves) {
+            int best = -1;
+            for (int i = 0; i < M; ++i)
+                if (nwv[i] < tiles[i] && rem[i] > 0 && (best < 0 || rem[i] > rem[best])) best = i;
+            if (best < 0) break;
+            nwv[best] += 1;
+            rem[best] = 0;
+            used += 1;
+        }
+        for (int i = 0; i < M; ++i) fine = fine && nwv[i] >= NWV;
+        auto seg_of = [&](PassWork& w, int sg, int task, int wave0, int wstride) {
+            w.task[sg] = task; w.row0[sg] = tro[task]; w.nrows[sg] = tro[task + 1] - tro[task]; w.ntiles[sg] = tiles[task];
+            w.wave0[sg] = wave0; w.wstride[sg] = wstride;
+        };
+        int nslots = 0;
+        if (fine) {
+            // lay the tasks' waves end to end and cut every 8
+            int task = 0, done = 0;   // `done` waves of `task` already placed
+            while (task < M) {
+                PassWork w{};
+                int room = NWV;
+                const int take0 = (int)std::min<long long>(room, nwv[task] - done);
+                seg_of(w, 0, task, done, (int)nwv[task]);
+                w.slot[0] = nslots++;
+                slot_off[task + 1] = nslots;
+                w.nw0 = take0;
+                done += take0; room -= take0;
+                if (done == nwv[task]) { ++task; done = 0; }
+                if (room > 0 && task < M) {
+                    const int take1 = (int)std::min<long long>(room, nwv[task]);   // nwv >= 8 > room: never completes the task
+                    seg_of(w, 1, task, 0, (int)nwv[task]);
+                    w.slot[1] = nslots++;
+                    slot_off[task + 1] = nslots;
+                    done = take1;
+                } else {
+                    // full workgroup, or a short last one: its spare waves form an empty segment with a scratch slot
+                    seg_of(w, 1, w.task[0], 0, 1);
+                    w.ntiles[1] = 0;
+                    w.slot[1] = w.nw0 < NWV ? -1 : w.slot[0];
+                }
+                pwork.push_back(w);
+            }
+            for (auto& w : pwork)
+                if (w.slot[1] < 0) w.slot[1] = nslots;   // one row past every task's range: nobody reads it
+        } else {
+            for (int i = 0; i < M; ++i) {
+                const int wgs = two[0][i + 1] - two[0][i];
+                for (int g = 0; g < wgs; ++g) {
+                    PassWork w{};
+                    seg_of(w, 0, i, NWV * g, NWV * wgs);
+                    seg_of(w, 1, i, 0, 1);
+                    w.ntiles[1] = 0;
+                    w.nw0 = NWV;
+                    w.slot[0] = w.slot[1] = nslots++;
+                    pwork.push_back(w);
+                }
+                slot_off[i + 1] = nslots;
+            }
+        }
+        if ((int)pwork.size() > c->max_work || nslots + 1 > c->max_work)
+            return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
+    }
     StepData& S = c->steps[step];
+    S.n_pwork = (int)pwork.size();
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false;
     const size_t O = c->d.obs_dim, A = c->d.act_dim;
@@ -539,6 +628,8 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
     HIPCHECK(hipMemcpyAsync(S.path_task, path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.row_t, row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.task_row_offsets, tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[2], slot_off.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.pwork, pwork.data(), sizeof(PassWork) * pwork.size(), hipMemcpyHostToDevice, st));
     for (int t = 0; t < 2; ++t) {
         HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[t], two[t].data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(S.work[t], work[t].data(), sizeof(WorkItem) * work[t].size(), hipMemcpyHostToDevice, st));
@@ -735,7 +826,7 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     StepData& S = c->steps[step];
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f)) return -2;
-    return launch_reduce(c, S, 0, 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
+    return launch_reduce(c, S, pass_table(c, false), 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
 }
 
 int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_out) {
@@ -814,7 +905,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     StepData& S = c->steps[step];
     const int M = c->d.n_tasks;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f)) return -2;
-    if (launch_reduce(c, S, 0, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (launch_reduce(c, S, pass_table(c, false), 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
     std::vector<float> sc((size_t)M * 2);
     if (copy_out(c, sc.data(), c->scal_tmp, sc.size())) return -2;

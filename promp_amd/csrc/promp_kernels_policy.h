@@ -26,6 +26,21 @@ struct WorkItem {
     int task, row_begin, row_end, pad;
 };
 
+// k_fwd_bwd's work item: the 8 waves of a workgroup are shared out at WAVE granularity, so a workgroup may serve two
+// tasks (waves [0, nw0) segment 0, waves [nw0, 8) segment 1).  With 2048 wave slots and 250 tiles per task (config 3)
+// every wave walks at most 5 tiles; at workgroup granularity (6 or 7 workgroups per task) 60 % of the tasks had waves
+// with 6.  Wave i of a task takes the tiles i, i + wstride, ... of the task's 16-row tiles.
+struct PassWork {
+    int task[2];      // task of each segment (segment 1 unused when nw0 == 8)
+    int row0[2];      // first row of the task
+    int nrows[2];     // rows of the task
+    int ntiles[2];    // 16-row tiles of the task
+    int wave0[2];     // index, among the task's waves, of the segment's first wave
+    int wstride[2];   // waves the task has in total
+    int slot[2];      // partial-sum row the segment writes
+    int nw0, pad;
+};
+
 enum { LOSS_RATIO = 0, LOSS_CLIP = 1, LOSS_LOGLIK = 2, LOSS_KL = 3 };   // LOSS_KL: mean KL(old || new) itself (TRPO constraint)
 
 struct PassArgs {
@@ -36,7 +51,8 @@ struct PassArgs {
     const float* old_log_std;   // [rows][A] or [tasks][A]
     int ls_per_row;
     const int* task_row_offsets;  // [tasks+1]
-    const WorkItem* work;         // [grid]
+    const WorkItem* work;
+    const PassWork* pwork;      // k_fwd_bwd only         // [grid]
     const float* theta;           // [Theta] or [tasks][Theta]
     long long theta_task_stride;  // 0 => shared
     const float* vdir;            // hvp: [tasks][Theta]
@@ -84,7 +100,7 @@ PROMP_DEV f32x4 splat4(float v) {
 struct LdsWave {
     int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2;
     int wave0, wave_stride, x, h1, h2, ms;   // per-wave region: offsets of the private buffers inside it
-    int total, HS, WS, Opad4, dbg, XS;
+    int total, HS, WS, Opad4, dbg, XS, copy_stride;
 };
 
 PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
@@ -106,6 +122,8 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     PROMP_TAKE(lmask, 16);
     PROMP_TAKE(es, 16);
     PROMP_TAKE(sn2, 16);
+    L.copy_stride = o;          // one task's parameter block; a second copy follows for the other segment's task
+    o *= 2;
     L.HS = (H1 > H2 ? H1 : H2) + 1;
     L.wave0 = o;
     int q = 0;
@@ -118,10 +136,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     L.ms = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
     L.wave_stride = q;
     o += nwaves * q;
-    // the end-of-kernel reduction buffer [NP + 2] aliases the per-wave regions
-    {   // end-of-kernel: 4 slabs of max(H1*H2, NP+2-H1*H2) floats + running sums [NP+2], from offset 0
+    {   // end-of-kernel: one slab of max(H1*H2, NP+2-H1*H2) floats per wave, from offset 0 (aliases everything)
         const int nw2 = H1 * H2, nr2 = NP + 2 - nw2;
-        const int need = 4 * (nw2 > nr2 ? nw2 : nr2) + NP + 8;
+        const int need = nwaves * (nw2 > nr2 ? nw2 : nr2);
         if (o < need) o = need;
     }
     L.dbg = o;
@@ -140,53 +157,87 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int Q1 = H1 / 4, Q2 = H2 / 4;   // k-slice of lane group kk in the K = H GEMMs: {kk*Q .. kk*Q + Q-1}
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w_ = tid >> 6;
     const int i16 = lane & 15, kk = lane >> 4;
-    const WorkItem wk = a.work[blockIdx.x];
-    const int task = wk.task;
+    const PassWork pw = a.pwork[blockIdx.x];
+    const int w = wave_uniform(w_);
+    const int seg = (w < pw.nw0) ? 0 : 1;      // which of the workgroup's (at most two) tasks this wave serves
+    const int task = pw.task[seg];
     const int O = a.O, A = a.A;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
               NP = oS + A;
     const LdsWave L = make_layout_wave(O, H1, H2, NW, NP);
     const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4, XS = L.XS;
-    float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
-          *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
-          *sn2s = sm + L.sn2;
     unsigned long long* dbgs = (unsigned long long*)(sm + L.dbg);
     if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
     float* wreg = sm + L.wave0 + w * L.wave_stride;
     float *Xw = wreg + L.x, *H1w = wreg + L.h1, *H2w = wreg + L.h2, *Msw = wreg + L.ms;
-    const int ntask = a.task_row_offsets[task + 1] - a.task_row_offsets[task];
-    const float invN = 1.0f / (float)ntask;
-    const float* th = a.theta + (long long)task * a.theta_task_stride;
+    const float invN = 1.0f / (float)pw.nrows[seg];
     PROMP_STAMP(0);
 
-    // ---- stage this task's parameters (shared by the 4 waves) ----
-    for (int e = tid; e < Opad4 * H1; e += NT) W1s[e] = (e < O * H1) ? th[e] : 0.f;
-    for (int e = tid; e < H1 * H2; e += NT) {
-        const int k = e / H2, j = e - k * H2;
-        W2s[k * WS + j] = th[oW2 + e];
+    // ---- stage the parameters of the workgroup's task(s) (shared by the waves of a segment): every global load is
+    //      issued before the first LDS store, so the staging costs one L2 round trip instead of one per loop iteration ----
+    for (int sg = 0; sg < (pw.nw0 < NW ? 2 : 1); ++sg) {
+        float* cp = sm + sg * L.copy_stride;
+        float *W1s = cp + L.w1, *b1s = cp + L.b1, *W2s = cp + L.w2, *b2s = cp + L.b2, *W3s = cp + L.w3, *W3Ts = cp + L.w3t,
+              *b3s = cp + L.b3, *lss = cp + L.ls, *lmask = cp + L.lmask, *ess = cp + L.es, *sn2s = cp + L.sn2;
+        const float* th = a.theta + (long long)pw.task[sg] * a.theta_task_stride;
+        constexpr int N1 = (32 * H1 + NT - 1) / NT, N2 = H1 * H2 / NT, N3 = (H2 * 16 + NT - 1) / NT, N3T = (8 * H2 + NT - 1) / NT;
+        float r1[N1], r2[N2], r3[N3], r3t[N3T];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) {
+            const int e = tid + i * NT;
+            r1[i] = (e < O * H1) ? th[e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < N2; ++i) r2[i] = th[oW2 + tid + i * NT];
+#pragma unroll
+        for (int i = 0; i < N3; ++i) {
+            const int e = tid + i * NT, k = e >> 4, j = e & 15;
+            r3[i] = (e < H2 * 16 && j < A) ? th[oW3 + k * A + j] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < N3T; ++i) {
+            const int e = tid + i * NT, aa = e / H2, k = e - aa * H2;
+            r3t[i] = (e < 8 * H2 && aa < A) ? th[oW3 + k * A + aa] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < N1; ++i) {
+            const int e = tid + i * NT;
+            if (e < Opad4 * H1) W1s[e] = r1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N2; ++i) {
+            const int e = tid + i * NT, k = e / H2, j = e - k * H2;
+            W2s[k * WS + j] = r2[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N3; ++i) {
+            const int e = tid + i * NT, k = e >> 4, j = e & 15;
+            if (e < H2 * 16) W3s[k * W3S + j] = r3[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N3T; ++i) {
+            const int e = tid + i * NT;
+            if (e < 8 * H2) W3Ts[e] = r3t[i];
+        }
+        if (tid < H1) b1s[tid] = th[ob1 + tid];
+        if (tid < H2) b2s[tid] = th[ob2 + tid];
+        if (tid < 16) {
+            b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
+            const float sr = (tid < A) ? th[oS + tid] : 0.f;
+            const bool clipped = a.clip_log_std && (sr < a.min_log_std);   // tf.maximum: gradient iff var >= min
+            const float s = clipped ? a.min_log_std : sr;
+            lss[tid] = s;
+            lmask[tid] = clipped ? 0.f : 1.f;
+            ess[tid] = expf(-s);
+            sn2s[tid] = expf(2.f * s);
+        }
     }
-    for (int e = tid; e < H2 * 16; e += NT) {
-        const int k = e >> 4, j = e & 15;
-        W3s[k * W3S + j] = (j < A) ? th[oW3 + k * A + j] : 0.f;
-    }
-    for (int e = tid; e < 8 * H2; e += NT) {
-        const int aa = e / H2, k = e - aa * H2;
-        W3Ts[e] = (aa < A) ? th[oW3 + k * A + aa] : 0.f;
-    }
-    if (tid < H1) b1s[tid] = th[ob1 + tid];
-    if (tid < H2) b2s[tid] = th[ob2 + tid];
-    if (tid < 16) {
-        b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
-        const float sr = (tid < A) ? th[oS + tid] : 0.f;
-        const bool clipped = a.clip_log_std && (sr < a.min_log_std);   // tf.maximum: gradient iff var >= min
-        const float s = clipped ? a.min_log_std : sr;
-        lss[tid] = s;
-        lmask[tid] = clipped ? 0.f : 1.f;
-        ess[tid] = expf(-s);
-        sn2s[tid] = expf(2.f * s);
-    }
+    // this wave's view of its task's parameter block
+    float* const cp = sm + seg * L.copy_stride;
+    float *W1s = cp + L.w1, *b1s = cp + L.b1, *W2s = cp + L.w2, *b2s = cp + L.b2, *W3s = cp + L.w3, *W3Ts = cp + L.w3t,
+          *b3s = cp + L.b3, *lss = cp + L.ls, *lmask = cp + L.lmask, *ess = cp + L.es, *sn2s = cp + L.sn2;
     for (int e = lane; e < L.wave_stride; e += 64) wreg[e] = 0.f;   // pad columns stay zero; over-read cells finite
     __syncthreads();
     PROMP_STAMP(1);
@@ -217,12 +268,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     // this lane's share of a [16][O] tile lands at row e / O, column e % O of the padded LDS tile (e = lane + 64 u);
     // the quotient comes from a float reciprocal (exact for these small integers) instead of 8 live offset registers
     const float rO = 1.0f / (float)O;
-    const int first = wk.row_begin + PROMP_WROWS * w;
+    // this wave's tiles of its task: wi, wi + wstride, ...
+    const int wi = pw.wave0[seg] + (seg ? w - pw.nw0 : w), wstride = pw.wstride[seg], ntiles = pw.ntiles[seg];
+    const int trow0 = pw.row0[seg], tnrows = pw.nrows[seg];
     float xr[8];
     {
-        const int nr = (wk.row_end - first) < PROMP_WROWS ? (wk.row_end - first) : PROMP_WROWS;
-        const int lim = (first < wk.row_end) ? nr * O : 0;
-        const float* src = a.obs + (long long)(first < wk.row_end ? first : wk.row_begin) * O;
+        const int nr = (tnrows - PROMP_WROWS * wi) < PROMP_WROWS ? (tnrows - PROMP_WROWS * wi) : PROMP_WROWS;
+        const int lim = (wi < ntiles) ? nr * O : 0;
+        const float* src = a.obs + (long long)(trow0 + (wi < ntiles ? PROMP_WROWS * wi : 0)) * O;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = lane + 64 * u;
@@ -232,9 +285,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     }
 
     int tix = 0;
-    for (int base = first; base < wk.row_end; base += NW * PROMP_WROWS, ++tix) {
+    for (int t = wi; t < ntiles; t += wstride, ++tix) {
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 0);
-        const int nrows = (wk.row_end - base) < PROMP_WROWS ? (wk.row_end - base) : PROMP_WROWS;
+        const int base = trow0 + PROMP_WROWS * t;
+        const int nrows = (tnrows - PROMP_WROWS * t) < PROMP_WROWS ? (tnrows - PROMP_WROWS * t) : PROMP_WROWS;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = lane + 64 * u;
@@ -243,10 +297,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         }
         PROMP_STAMP(8 + 16 * (tix < 3 ? tix : 3) + 9);
         {
-            const int nb = base + NW * PROMP_WROWS;
-            const int nn = (wk.row_end - nb) < PROMP_WROWS ? (wk.row_end - nb) : PROMP_WROWS;
-            const int lim = (nb < wk.row_end) ? nn * O : 0;
-            const float* src = a.obs + (long long)(nb < wk.row_end ? nb : wk.row_begin) * O;
+            const int tn = t + wstride;
+            const int nn = (tnrows - PROMP_WROWS * tn) < PROMP_WROWS ? (tnrows - PROMP_WROWS * tn) : PROMP_WROWS;
+            const int lim = (tn < ntiles) ? nn * O : 0;
+            const float* src = a.obs + (long long)(trow0 + (tn < ntiles ? PROMP_WROWS * tn : 0)) * O;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = lane + 64 * u;
@@ -458,7 +512,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             gb31 += shfl_xor_f32(gb31, m);  loss += shfl_xor_f32(loss, m);  klsum += shfl_xor_f32(klsum, m);
         }
     }
-    if (!BWD) {   // only the two scalars leave the workgroup
+    const bool two = pw.nw0 < NW;                  // the workgroup served two tasks
+    float* P0 = a.partials + (long long)pw.slot[0] * a.partial_stride;
+    float* P1 = a.partials + (long long)pw.slot[two ? 1 : 0] * a.partial_stride;
+    if (!BWD) {   // only the two scalars per segment leave the workgroup
         float* SC = sm;
         __syncthreads();
         if (lane == 0) {
@@ -466,94 +523,105 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             SC[2 * w + 1] = klsum;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 2 && (tid == 0 || two)) {
             float l = 0.f, k = 0.f;
-            for (int ww = 0; ww < NW; ++ww) {
+            const int lo = tid ? pw.nw0 : 0, hi = tid ? NW : pw.nw0;
+            for (int ww = lo; ww < hi; ++ww) {
                 l += SC[2 * ww];
                 k += SC[2 * ww + 1];
             }
-            float* Pq = a.partials + (long long)blockIdx.x * a.partial_stride;
+            float* Pq = tid ? P1 : P0;
             Pq[NP] = l;
             Pq[NP + 1] = k;
         }
         return;
     }
-    // Each wave stores its tiles to its own LDS slab (plain stores, no read-modify-write), then all threads add four
-    // slabs in wave order.  Two payload rounds because 4 x [NP] does not fit in LDS; with 8 waves the second group of
-    // four waves repeats the rounds and adds onto the first group's sums (kept in LDS), again in a fixed order.
-    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    // Every wave stores its tiles to its own LDS slab (plain stores, no read-modify-write); then all threads add the slabs
+    // in wave order, the waves of segment 0 into the first task's partial and those of segment 1 into the second's.
+    // Two payload rounds because NW x [NP] does not fit in LDS: the hidden_1 kernel, then everything else (compacted).
     float* S = sm;                                   // whole LDS allocation is free now
     const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
     const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
-    float* Rsum = S + 4 * (NW2 > NR2 ? NW2 : NR2);   // [NP + 2] running sums between the groups (NW == 8 only)
-    constexpr int NG = NW / 4;
-    for (int grp = 0; grp < NG; ++grp) {
-        const bool mine_turn = (w >> 2) == grp;
-        const bool last = grp == NG - 1;
-        __syncthreads();
-        if (mine_turn) {
-            float* mine = S + (w & 3) * NW2;
+    __syncthreads();
+    {
+        float* mine = S + w * NW2;
 #pragma unroll
-            for (int i = 0; i < NC1; ++i)
-#pragma unroll
-                for (int j = 0; j < NC2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
-        }
-        __syncthreads();
-        for (int e = tid; e < NW2; e += NT) {
-            float t = ((S[e] + S[NW2 + e]) + S[2 * NW2 + e]) + S[3 * NW2 + e];
-            if (grp > 0) t += Rsum[oW2 + e];
-            if (last) P[oW2 + e] = t; else Rsum[oW2 + e] = t;
-        }
-        __syncthreads();
-        if (mine_turn) {
-            // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
-            float* mine = S + (w & 3) * NR2;
-            for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
-            wave_sync();
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NC1; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i + 4 * kk + r;
-                        if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
-                    }
+        for (int i = 0; i < NC1; ++i)
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
-            if (kk == 0) {
+                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int e = tid; e < NW2; e += NT) {
+        float v[NW];
 #pragma unroll
-                for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * NW2 + e];      // all slab reads in flight together
+        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-                for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = gb2[j];
-            }
-            if (lane < 4) {   // lane == q
-                if (lane < A) {
-                    mine[ob3 - NW2 + lane] = gb30;
-                    mine[oS - NW2 + lane] = gs0 * lmask_reg0;
+        for (int ww = 0; ww < NW; ++ww) {
+            if (ww < pw.nw0) t0 += v[ww];
+            else t1 += v[ww];
+        }
+        P0[oW2 + e] = t0;
+        if (two) P1[oW2 + e] = t1;
+    }
+    __syncthreads();
+    {
+        // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
+        float* mine = S + w * NR2;
+        for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * kk + r;
+                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
                 }
-                if (lane + 4 < A) {
-                    mine[ob3 - NW2 + lane + 4] = gb31;
-                    mine[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
-                }
+#pragma unroll
+        for (int j = 0; j < NC2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
+        if (kk == 0) {
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = gb2[j];
+        }
+        if (lane < 4) {   // lane == q
+            if (lane < A) {
+                mine[ob3 - NW2 + lane] = gb30;
+                mine[oS - NW2 + lane] = gs0 * lmask_reg0;
             }
-            if (lane == 0) {
-                mine[NP - NW2] = loss;
-                mine[NP + 1 - NW2] = klsum;
+            if (lane + 4 < A) {
+                mine[ob3 - NW2 + lane + 4] = gb31;
+                mine[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
             }
         }
-        __syncthreads();
-        for (int e = tid; e < NR2; e += NT) {
-            const int dst = e < oW2 ? e : e + NW2;
-            float t = ((S[e] + S[NR2 + e]) + S[2 * NR2 + e]) + S[3 * NR2 + e];
-            if (grp > 0) t += Rsum[dst];
-            if (last) P[dst] = t; else Rsum[dst] = t;
+        if (lane == 0) {
+            mine[NP - NW2] = loss;
+            mine[NP + 1 - NW2] = klsum;
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < NR2; e += NT) {
+        const int dst = e < oW2 ? e : e + NW2;
+        float v[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * NR2 + e];
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            if (ww < pw.nw0) t0 += v[ww];
+            else t1 += v[ww];
+        }
+        P0[dst] = t0;
+        if (two) P1[dst] = t1;
     }
     PROMP_STAMP(4);
     if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid == 0)
@@ -632,21 +700,45 @@ template <int H1, int H2>
 PROMP_DEV void stage_net(float* W1s, float* b1s, float* W2s, float* b2s, float* W3s, float* W3Ts, float* b3s,
                          const float* src, int O, int A, int Opad4, int WS, int tid) {
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
-#pragma unroll 4
-    for (int e = tid; e < Opad4 * H1; e += 256) W1s[e] = (e < O * H1) ? src[e] : 0.f;
-#pragma unroll 4
-    for (int e = tid; e < H1 * H2; e += 256) {
-        const int k = e / H2, j = e - k * H2;
-        W2s[k * WS + j] = src[oW2 + e];
+    // every global load is issued before the first LDS store: one L2 round trip, not one per loop iteration
+    constexpr int NT = 256, N1 = (32 * H1 + NT - 1) / NT, N2 = H1 * H2 / NT, N3 = (H2 * 16 + NT - 1) / NT, N3T = (8 * H2 + NT - 1) / NT;
+    float r1[N1], r2[N2], r3[N3], r3t[N3T];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+        const int e = tid + i * NT;
+        r1[i] = (e < O * H1) ? src[e] : 0.f;
     }
-#pragma unroll 4
-    for (int e = tid; e < H2 * 16; e += 256) {
-        const int k = e >> 4, j = e & 15;
-        W3s[k * PROMP_W3S + j] = (j < A) ? src[oW3 + k * A + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < N2; ++i) r2[i] = src[oW2 + tid + i * NT];
+#pragma unroll
+    for (int i = 0; i < N3; ++i) {
+        const int e = tid + i * NT, k = e >> 4, j = e & 15;
+        r3[i] = (e < H2 * 16 && j < A) ? src[oW3 + k * A + j] : 0.f;
     }
-    for (int e = tid; e < 8 * H2; e += 256) {
-        const int aa = e / H2, k = e - aa * H2;
-        W3Ts[e] = (aa < A) ? src[oW3 + k * A + aa] : 0.f;
+#pragma unroll
+    for (int i = 0; i < N3T; ++i) {
+        const int e = tid + i * NT, aa = e / H2, k = e - aa * H2;
+        r3t[i] = (e < 8 * H2 && aa < A) ? src[oW3 + k * A + aa] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < N1; ++i) {
+        const int e = tid + i * NT;
+        if (e < Opad4 * H1) W1s[e] = r1[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const int e = tid + i * NT, k = e / H2, j = e - k * H2;
+        W2s[k * WS + j] = r2[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N3; ++i) {
+        const int e = tid + i * NT, k = e >> 4, j = e & 15;
+        if (e < H2 * 16) W3s[k * PROMP_W3S + j] = r3[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N3T; ++i) {
+        const int e = tid + i * NT;
+        if (e < 8 * H2) W3Ts[e] = r3t[i];
     }
     if (tid < H1) b1s[tid] = src[ob1 + tid];
     if (tid < H2) b2s[tid] = src[ob2 + tid];

@@ -28,6 +28,16 @@ def test_loss_grad_h64(lib):
     pc.check_loss_grad(lib, 7, M=2, P=2, T=37, O=20, A=6, hidden=(64, 64))
 
 
+def test_loss_grad_workgroups_straddling_two_tasks(lib):
+    # 3 tasks x ~12 tiles on the emulator's 4 CUs (32 waves): every task gets >= 8 waves, so the wave-granular split
+    # puts two tasks into one workgroup (two parameter copies in LDS, two partial rows out)
+    pc.check_loss_grad(lib, 41, M=3, P=2, T=100, O=20, A=6, hidden=(64, 64), ragged=True)
+
+
+def test_meta_workgroups_straddling_two_tasks(lib):
+    pc.check_meta(lib, 42, M=3, P=2, T=90, O=7, A=3, hidden=(32, 32), K=1, epochs=1, ragged=True)
+
+
 def test_loss_grad_h32_compact_log_std(lib):
     pc.check_loss_grad(lib, 8, M=2, P=1, T=70, O=3, A=2, hidden=(32, 32), compact_log_std=True)
 
