@@ -542,7 +542,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     float* S = sm;                                   // whole LDS allocation is free now
     const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
     const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
+    PROMP_STAMP(120);
     __syncthreads();
+    PROMP_STAMP(121);
     {
         float* mine = S + w * NW2;
 #pragma unroll
@@ -552,7 +554,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
     }
+    PROMP_STAMP(122);
     __syncthreads();
+    PROMP_STAMP(123);
 #pragma unroll 2
     for (int e = tid; e < NW2; e += NT) {
         float v[NW];
@@ -567,7 +571,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         P0[oW2 + e] = t0;
         if (two) P1[oW2 + e] = t1;
     }
+    PROMP_STAMP(124);
     __syncthreads();
+    PROMP_STAMP(125);
     {
         // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
         float* mine = S + w * NR2;
@@ -608,7 +614,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             mine[NP + 1 - NW2] = klsum;
         }
     }
+    PROMP_STAMP(126);
     __syncthreads();
+    PROMP_STAMP(127);
     for (int e = tid; e < NR2; e += NT) {
         const int dst = e < oW2 ? e : e + NW2;
         float v[NW];

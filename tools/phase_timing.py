@@ -25,6 +25,8 @@ for hvp in (0, 1):
     s = buf.astype(np.int64)
     t0 = s[0]
     print('kernel', 'hvp' if hvp else 'fwd_bwd', ' stage->%d  loop_end->%d  reduce_end->%d  write_end->%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
+    if not hvp:
+        print('  end phase (cycles after loop end): ', [int(x - s[2]) for x in s[120:128]], ' write_end', int(s[4] - s[2]))
     for tix in range(4):
         st = s[8 + 16 * tix: 8 + 16 * tix + 16]
         if st[0] == 0:
