@@ -34,6 +34,11 @@ def test_loss_grad_workgroups_straddling_two_tasks(lib):
     pc.check_loss_grad(lib, 41, M=3, P=2, T=100, O=20, A=6, hidden=(64, 64), ragged=True)
 
 
+def test_loss_grad_short_last_workgroup(lib):
+    # 2 tasks x 10 tiles on 32 wave slots: one wave per tile (20 waves), the third workgroup has 4 spare waves
+    pc.check_loss_grad(lib, 43, M=2, P=1, T=160, O=6, A=2, hidden=(32, 32))
+
+
 def test_meta_workgroups_straddling_two_tasks(lib):
     pc.check_meta(lib, 42, M=3, P=2, T=90, O=7, A=3, hidden=(32, 32), K=1, epochs=1, ragged=True)
 
