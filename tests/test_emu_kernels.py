@@ -93,6 +93,12 @@ def test_wide_loss_grad_h64_wide_obs(lib):
     pc.check_loss_grad(lib, 21, M=1, P=1, T=40, O=40, A=8, hidden=(64, 64))
 
 
+def test_wide_three_tasks_uneven_workgroups(lib):
+    # 3 tasks x 3 rounds of 64 rows over the emulator's 4 workgroups (1 or 2 workgroups per task)
+    pc.check_loss_grad(lib, 44, M=3, P=1, T=150, O=40, A=3, hidden=(64, 64))
+    pc.check_hvp(lib, 45, M=3, P=1, T=150, O=40, A=3, hidden=(64, 64))
+
+
 def test_wide_hvp_h64_wide_obs(lib):
     pc.check_hvp(lib, 27, M=1, P=1, T=33, O=100, A=2, hidden=(64, 64))
 
