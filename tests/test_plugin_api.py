@@ -10,6 +10,11 @@ from promp_amd import _lib, session
 from tests import devlib, helpers
 
 
+@pytest.fixture(autouse=True)
+def _two_emulated_cus(monkeypatch):
+    monkeypatch.setenv('PROMP_EMU_CUS', '2')   # API-level tests: fewer host threads per emulated launch
+
+
 @pytest.fixture()
 def emu():
     lib = devlib.emu_library()
