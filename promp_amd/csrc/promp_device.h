@@ -96,6 +96,128 @@ PROMP_DEV double wave_min_f64(double v) {
     return v;
 }
 
+// The primal / tangent pair of one layer in a single pass over k (R-operator kernels):
+//     P[i][j] += A0_i B0_j                       T[i][j] += A1_i B0_j + s1 * A0_i B1_j
+// One software pipeline instead of three: the A0 / B0 operands are loaded once, a k-step issues 3 NA NB independent
+// MFMAs (enough to cover the LDS latency of the next step's operands), and two pipeline ramp-ups disappear.
+// a1 == nullptr drops the A1 term (first layer: the input has no tangent).
+template <int NA, int NB, bool HAS_A1>
+PROMP_DEV void outer16_pt(f32x4 (&P)[NA][NB], f32x4 (&T)[NA][NB], const float* a0, const float* a1, int a_ss, int a_bs,
+                          const float* b0, const float* b1, int b_ss, int b_bs, int NS, float s1) {
+    float x0[NA], x1[NA], y0[NB], y1[NB];
+    f32x4 T2[NA][NB];          // the A1 B0 term accumulates apart from the A0 B1 term and joins T at the end
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) T2[i][j] = zero4();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        x0[i] = a0[i * a_bs];
+        x1[i] = HAS_A1 ? a1[i * a_bs] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        y0[j] = b0[j * b_bs];
+        y1[j] = s1 * b1[j * b_bs];
+    }
+#pragma unroll 2
+    for (int s = 1; s <= NS; ++s) {
+        float nx0[NA], nx1[NA], ny0[NB], ny1[NB];
+        const int sn = s < NS ? s : 0;          // the last step re-reads step 0 (harmless) instead of branching
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            nx0[i] = a0[sn * a_ss + i * a_bs];
+            nx1[i] = HAS_A1 ? a1[sn * a_ss + i * a_bs] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            ny0[j] = b0[sn * b_ss + j * b_bs];
+            ny1[j] = s1 * b1[sn * b_ss + j * b_bs];
+        }
+        // three independent accumulator sets, each walked completely before the next: no MFMA waits for its predecessor
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) P[i][j] = mfma16(x0[i], y0[j], P[i][j]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) T[i][j] = mfma16(x0[i], y1[j], T[i][j]);
+        if (HAS_A1) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) T2[i][j] = mfma16(x1[i], y0[j], T2[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            x0[i] = nx0[i];
+            x1[i] = nx1[i];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            y0[j] = ny0[j];
+            y1[j] = ny1[j];
+        }
+    }
+    if (HAS_A1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) T[i][j] += T2[i][j];
+    }
+}
+
+// acc[i][j] += s0 * A0_i B0_j + A1_i B1_j   (the two gradient terms of one kernel in the R-operator pass)
+template <int NA, int NB>
+PROMP_DEV void outer16_two(f32x4 (&acc)[NA][NB], const float* a0, const float* a1, int a_ss, int a_bs, const float* b0,
+                           const float* b1, int b_ss, int b_bs, int NS, float s0) {
+    float x0[NA], x1[NA], y0[NB], y1[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        x0[i] = a0[i * a_bs];
+        x1[i] = a1[i * a_bs];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        y0[j] = s0 * b0[j * b_bs];
+        y1[j] = b1[j * b_bs];
+    }
+#pragma unroll 2
+    for (int s = 1; s <= NS; ++s) {
+        float nx0[NA], nx1[NA], ny0[NB], ny1[NB];
+        const int sn = s < NS ? s : 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            nx0[i] = a0[sn * a_ss + i * a_bs];
+            nx1[i] = a1[sn * a_ss + i * a_bs];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            ny0[j] = s0 * b0[sn * b_ss + j * b_bs];
+            ny1[j] = b1[sn * b_ss + j * b_bs];
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = mfma16(x0[i], y0[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = mfma16(x1[i], y1[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            x0[i] = nx0[i];
+            x1[i] = nx1[i];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            y0[j] = ny0[j];
+            y1[j] = ny1[j];
+        }
+    }
+}
+
 // tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7, saturates correctly at +-1.
 PROMP_DEV float fast_tanh(float x) { return 1.f - 2.f * fast_rcp(fast_exp(2.f * x) + 1.f); }
 

@@ -357,9 +357,9 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         c->smem_fwd = c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
         c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
     } else {
-    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
-    c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wave(dims->obs_dim, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
-    c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(dims->obs_dim, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;
+    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
+    c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
+    c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(32, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;   // (sized for obs_dim 32: constant offsets in the kernel)
     }
     if (c->smem_hvp > 160 * 1024) {
         const size_t need = c->smem_hvp;

@@ -166,9 +166,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     const int O = a.O, A = a.A;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
               NP = oS + A;
-    const LdsWave L = make_layout_wave(O, H1, H2, NW, NP);
-    const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4, XS = L.XS;
-    unsigned long long* dbgs = (unsigned long long*)(sm + L.dbg);
+    // the layout is sized for obs_dim 32 whatever O is: every LDS offset is then a compile-time constant and folds into
+    // the ds_read / ds_write immediates instead of costing address arithmetic in the tile loop
+    const LdsWave L = make_layout_wave(32, H1, H2, NW, 0);
+    const int HS = L.HS, WS = L.WS, Opad4 = (O + 3) & ~3, XS = L.XS;
+    unsigned long long* dbgs = (unsigned long long*)(sm + make_layout_wave(32, H1, H2, NW, NP).dbg);   // (after the slabs: needs NP)
     if (PROMP_STAMPS_ON && a.dbg != nullptr && blockIdx.x == 0 && tid < 128) dbgs[tid] = 0;
     float* wreg = sm + L.wave0 + w * L.wave_stride;
     float *Xw = wreg + L.x, *H1w = wreg + L.h1, *H2w = wreg + L.h2, *Msw = wreg + L.ms;
@@ -766,8 +768,10 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
     const int O = a.O, A = a.A;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
               NP = oS + A;
-    const LdsHvp L = make_layout_hvp(O, H1, H2, 4, NP);
-    const int HS = L.HS, WS = L.WS, Opad4 = L.Opad4;
+    // the layout is sized for obs_dim 32 whatever O is: every LDS offset is then a compile-time constant and folds into
+    // the ds_read / ds_write immediates instead of costing address arithmetic in the tile loop
+    const LdsHvp L = make_layout_hvp(32, H1, H2, 4, 0);
+    const int HS = L.HS, WS = L.WS, Opad4 = (O + 3) & ~3;
     float *W1s = sm + L.w1, *b1s = sm + L.b1, *W2s = sm + L.w2, *b2s = sm + L.b2, *W3s = sm + L.w3,
           *W3Ts = sm + L.w3t, *b3s = sm + L.b3, *lss = sm + L.ls, *lmask = sm + L.lmask, *ess = sm + L.es,
           *sn2s = sm + L.sn2, *vls = sm + L.vls;
@@ -877,8 +881,8 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
                 az[0][j] = splat4(b1s[16 * j + i16]);     // biases ride in the accumulators
                 ar[0][j] = splat4(vb1s[16 * j + i16]);
             }
-            outer16<1, NC1>(az, Xw + i16 * XS + kk, 4, 0, W1s + kk * H1 + i16, 4 * H1, 16, Opad4 / 4, 1.f);
-            outer16<1, NC1>(ar, Xw + i16 * XS + kk, 4, 0, vW1s + kk * H1 + i16, 4 * H1, 16, Opad4 / 4, 1.f);
+            outer16_pt<1, NC1, false>(az, ar, Xw + i16 * XS + kk, nullptr, 4, 0, W1s + kk * H1 + i16, vW1s + kk * H1 + i16, 4 * H1, 16,
+                                      Opad4 / 4, 1.f);
 #pragma unroll
             for (int j = 0; j < NC1; ++j)
 #pragma unroll
@@ -898,9 +902,8 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
                 az[0][j] = splat4(b2s[16 * j + i16]);
                 ar[0][j] = splat4(vb2s[16 * j + i16]);
             }
-            outer16<1, NC2>(az, H1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
-            outer16<1, NC2>(ar, H1w + i16 * HS + kk * Q1, 1, 0, vW2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
-            outer16<1, NC2>(ar, RH1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
+            outer16_pt<1, NC2, true>(az, ar, H1w + i16 * HS + kk * Q1, RH1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16,
+                                     vW2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
@@ -917,9 +920,8 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
             f32x4 am[1][1], ar[1][1];
             am[0][0] = splat4(b3s[i16]);
             ar[0][0] = splat4(vb3s[i16]);
-            outer16<1, 1>(am, H2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
-            outer16<1, 1>(ar, H2w + i16 * HS + kk * Q2, 1, 0, vW3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
-            outer16<1, 1>(ar, RH2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
+            outer16_pt<1, 1, true>(am, ar, H2w + i16 * HS + kk * Q2, RH2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16,
+                                   vW3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 Msw[(4 * kk + r) * MS + i16] = am[0][0][r];
@@ -1002,15 +1004,14 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         }
         wave_sync();
         // ---- out_W3 += -RH2^T dmu + H2^T qmu ; dZ2 over H2, qZ2 over RH2
-        outer16<NC2, 1>(aw3, RH2w + kk * HS + i16, 4 * HS, 16, Msw + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, -1.f);
-        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, 4 * HS, 16, Ms2w + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, 1.f);
+        outer16_two<NC2, 1>(aw3, RH2w + kk * HS + i16, H2w + kk * HS + i16, 4 * HS, 16, Msw + kk * MS + i16, Ms2w + kk * MS + i16,
+                            4 * MS, 0, PROMP_WROWS / 4, -1.f);
         {
             f32x4 ad[1][NC2], aq[1][NC2];
 #pragma unroll
             for (int j = 0; j < NC2; ++j) ad[0][j] = aq[0][j] = zero4();
-            outer16<1, NC2>(ad, Msw + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, 4 * H2, 16, 2, 1.f);
-            outer16<1, NC2>(aq, Ms2w + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, 4 * H2, 16, 2, 1.f);
-            outer16<1, NC2>(aq, Msw + i16 * MS + kk, 4, 0, vW3Ts + kk * H2 + i16, 4 * H2, 16, 2, -1.f);
+            outer16_pt<1, NC2, true>(ad, aq, Msw + i16 * MS + kk, Ms2w + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, vW3Ts + kk * H2 + i16,
+                                     4 * H2, 16, 2, -1.f);
 #pragma unroll
             for (int j = 0; j < NC2; ++j) {
                 float cs = 0.f;
@@ -1029,15 +1030,14 @@ __global__ void __launch_bounds__(256, 1) k_hvp(PassArgs a) {
         }
         wave_sync();
         // ---- out_W2 += -RH1^T dZ2 + H1^T qZ2 ; qZ1 over H1
-        outer16<NC1, NC2>(aw2, RH1w + kk * HS + i16, 4 * HS, 16, H2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, -1.f);
-        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, 4 * HS, 16, RH2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
+        outer16_two<NC1, NC2>(aw2, RH1w + kk * HS + i16, H1w + kk * HS + i16, 4 * HS, 16, H2w + kk * HS + i16, RH2w + kk * HS + i16,
+                              4 * HS, 16, PROMP_WROWS / 4, -1.f);
         {
             f32x4 ad[1][NC1], aq[1][NC1];
 #pragma unroll
             for (int j = 0; j < NC1; ++j) ad[0][j] = aq[0][j] = zero4();
-            outer16<1, NC1>(ad, H2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, 1.f);
-            outer16<1, NC1>(aq, RH2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, 1.f);
-            outer16<1, NC1>(aq, H2w + i16 * HS + kk * Q2, 1, 0, vW2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, -1.f);
+            outer16_pt<1, NC1, true>(ad, aq, H2w + i16 * HS + kk * Q2, RH2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2,
+                                     vW2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, -1.f);
 #pragma unroll
             for (int j = 0; j < NC1; ++j) {
                 float cs = 0.f;
