@@ -294,8 +294,8 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
 }
 
 int upload_eta(promp_ctx* c, const float* eta) {
+    // (a pageable source is staged before hipMemcpyAsync returns: no need to drain the stream, the host keeps running ahead)
     HIPCHECK(hipMemcpyAsync(c->eta_dev, eta, sizeof(float) * c->d.num_inner_steps, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
