@@ -126,11 +126,13 @@ def test_meta_gradient_vs_torch_autograd_golden(lib, name):
     ctx.close()
 
 
-# ---- full BASELINE config 3 (M=40, P=20, T=200, O=20, A=6, 2x64): properties + one oracle comparison ----
-@pytest.fixture(scope='module')
-def config3(lib):
-    M, P, T, O, A, hidden = 40, 20, 200, 20, 6, (64, 64)
-    rng = np.random.RandomState(3)
+# ---- full BASELINE configs 3 (M=40, P=20, T=200, O=20, A=6, 2x64) and 4 (Ant: O=111, A=8, 2x128):
+#      size-independent properties + one oracle comparison each ----
+@pytest.fixture(scope='module', params=[3, 4], ids=['config3', 'config4'])
+def config_full(lib, request):
+    cfg = synthetic.CONFIGS[request.param]
+    M, P, T, O, A, hidden = cfg['M'], cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
+    rng = np.random.RandomState(request.param)
     theta = synthetic.init_theta(rng, O, hidden, A)
     ctx = _lib.Context(M, O, A, hidden, 1, max_rows=M * P * T, max_paths=M * P, lib=lib)
     ctx.set_theta(theta)
@@ -151,23 +153,23 @@ def config3(lib):
     ctx.close()
 
 
-def test_config3_ratio_is_one_at_unchanged_params(config3):
+def test_full_config_ratio_is_one_at_unchanged_params(config_full):
     # reference tests/test_integration.py:128-175: likelihood ratio == 1 when params are unchanged
-    ctx, M = config3['ctx'], config3['dims'][0]
+    ctx, M = config_full['ctx'], config_full['dims'][0]
     adv0 = ctx.download_processed(0)['advantages'].reshape(M, -1)
     ctx.switch_to_pre_update()
     g, l, k = ctx.eval_loss_grad(0, 0, clip_log_std=True)
     np.testing.assert_allclose(l, -adv0.mean(axis=1), atol=2e-6)      # -mean(1 * adv)
     np.testing.assert_allclose(k, 0.0, atol=1e-6)                      # KL(old || same) == 0
     # post-update policy on its own samples
-    ctx.set_task_thetas(config3['th1'])
+    ctx.set_task_thetas(config_full['th1'])
     g, l, k = ctx.eval_loss_grad(1, 1, clip_eps=0.3)
     np.testing.assert_allclose(k, 0.0, atol=1e-6)
 
 
-def test_config3_hvp_is_linear_and_deterministic(config3):
-    ctx = config3['ctx']
-    M = config3['dims'][0]
+def test_full_config_hvp_is_linear_and_deterministic(config_full):
+    ctx = config_full['ctx']
+    M = config_full['dims'][0]
     rng = np.random.RandomState(5)
     ctx.switch_to_pre_update()
     v1 = rng.randn(M, ctx.n_params).astype(np.float32)
@@ -178,18 +180,18 @@ def test_config3_hvp_is_linear_and_deterministic(config3):
     np.testing.assert_array_equal(h1, ctx.eval_hvp(0, v1, clip_log_std=True))    # fixed-order reductions: bitwise
 
 
-def test_config3_meta_gradient_vs_oracle_and_determinism(config3):
+def test_full_config_meta_gradient_vs_oracle_and_determinism(config_full):
     from oracle import sample_processing as sp
-    ctx, theta = config3['ctx'], config3['theta']
-    M, P, T, O, A, hidden = config3['dims']
+    ctx, theta = config_full['ctx'], config_full['theta']
+    M, P, T, O, A, hidden = config_full['dims']
     spec = op.PolicySpec(O, A, hidden)
     eta = np.array([5e-4], np.float32)
     ctx.set_theta(theta)
     g1, st1 = ctx.meta_grad(0.3, eta)
     g2, st2 = ctx.meta_grad(0.3, eta)
     np.testing.assert_array_equal(g1, g2)
-    s0, _, _ = sp.process_samples_meta(config3['p0'], baseline_kind=sp.BASELINE_LINEAR_FEATURE, **config3['opts'])
-    s1, _, _ = sp.process_samples_meta(config3['p1'], baseline_kind=sp.BASELINE_LINEAR_FEATURE, **config3['opts'])
+    s0, _, _ = sp.process_samples_meta(config_full['p0'], baseline_kind=sp.BASELINE_LINEAR_FEATURE, **config_full['opts'])
+    s1, _, _ = sp.process_samples_meta(config_full['p1'], baseline_kind=sp.BASELINE_LINEAR_FEATURE, **config_full['opts'])
     r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), [s0, s1], np.full(spec.n_params, 0.1), eta.astype(np.float64), 0.3)
     np.testing.assert_allclose(st1['loss'], r['loss'], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(st1['inner_kl'], r['inner_kl'], rtol=1e-3, atol=1e-9)
@@ -197,12 +199,12 @@ def test_config3_meta_gradient_vs_oracle_and_determinism(config3):
     assert pc.rel_max(g1, r['grad']) < 1e-3      # meta-gradient 1e-3 of its max-norm
 
 
-def test_config3_zero_advantages_give_zero_surrogate_gradient(config3):
-    ctx = config3['ctx']
-    M, P, T = config3['dims'][:3]
+def test_full_config_zero_advantages_give_zero_surrogate_gradient(config_full):
+    ctx = config_full['ctx']
+    M, P, T = config_full['dims'][:3]
     adv = ctx.download_processed(1)['advantages']
     ctx.set_advantages(1, np.zeros(M * P * T, np.float32))
-    ctx.set_task_thetas(config3['th1'])
+    ctx.set_task_thetas(config_full['th1'])
     g, l, k = ctx.eval_loss_grad(1, 1, clip_eps=0.3)
     assert np.all(g == 0.0) and np.all(l == 0.0)
     ctx.set_advantages(1, adv)
