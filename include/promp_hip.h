@@ -142,6 +142,24 @@ int promp_inner_adapt(promp_ctx* ctx, int step, int inner_kind);
  * obs [n_tasks, batch, O] -> mean_out [n_tasks, batch, A].  The Gaussian noise is added by the caller. */
 int promp_policy_forward(promp_ctx* ctx, const float* obs, int batch, float* mean_out);
 
+/* ---- a whole rollout on the device: the 2-D point-mass meta-environment of BASELINE
+ * config 0 (run_scripts/pro-mp_run_point_mass.py; the reference steps it in NumPy,
+ * envs/point_envs/point_env_2d_corner.py, and collects paths in samplers/meta_sampler.py:59-137).
+ * Every environment (envs_per_task per task) runs path_length steps under its task's CURRENT parameters:
+ *   obs = state; mean = policy(obs); action = mean + exp(log_std) * noise; state += clip(action, +-0.1);
+ *   reward = -|state - goal|
+ * and the trajectories land in step `step`'s slab as n_tasks * envs_per_task fixed-length paths, ready for
+ * promp_process_samples (no upload).  goals [n_tasks][2], start [n_tasks][envs_per_task][2] (float64 like the NumPy
+ * environment), noise [n_tasks][envs_per_task][path_length][2] standard normals drawn by the caller.
+ * clip_infos != 0: the log_std recorded for agent_infos is max(log_std, log 1e-6) (pre-update policy,
+ * policies/gaussian_mlp_policy.py:71); the noise scale always uses the raw value (:74).  Asynchronous. */
+int promp_rollout_point_env(promp_ctx* ctx, int step, int envs_per_task, int path_length, const double* goals,
+                            const double* start, const float* noise, int clip_infos);
+
+/* Step slab back on the host (any pointer may be NULL): obs [rows][O], act [rows][A], rew [rows],
+ * old_mean [rows][A], old_log_std [rows | n_tasks][A] as uploaded / produced by a device rollout. */
+int promp_download_step(promp_ctx* ctx, int step, float* obs, float* act, float* rew, float* old_mean, float* old_log_std);
+
 /* ---- rows a11-a13 ---------------------------------------------------------------------------
  * One evaluation of the ProMP meta-objective (meta_algos/pro_mp.py:67-163) and of its exact
  * gradient (what tf.gradients yields through meta_algos/base.py:206, i.e. including the

@@ -69,6 +69,8 @@ SIGNATURES = {
     'promp_get_task_thetas': (C.c_int, [_P, _F]),
     'promp_inner_adapt': (C.c_int, [_P, C.c_int, C.c_int]),
     'promp_policy_forward': (C.c_int, [_P, _F, C.c_int, _F]),
+    'promp_rollout_point_env': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D, _D, _F, C.c_int]),
+    'promp_download_step': (C.c_int, [_P, C.c_int, _F, _F, _F, _F, _F]),
     'promp_meta_grad': (C.c_int, [_P, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
     'promp_adam_step': (C.c_int, [_P, C.c_float]),
     'promp_optimize': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
@@ -142,6 +144,7 @@ class Context:
         self.n_params = self.lib.cdll.promp_param_count(C.byref(self.dims))
         self.n_tasks, self.K = int(n_tasks), int(num_inner_steps)
         self.step_rows = {}
+        self.step_ls_rows = {}
         self.step_paths = {}
 
     def close(self):
@@ -180,6 +183,7 @@ class Context:
                    _ptr(old_log_std, C.c_float), per_row)
         self.step_rows[step] = int(pro[-1])
         self.step_paths[step] = int(n_paths)
+        self.step_ls_rows[step] = int(pro[-1]) if per_row else self.n_tasks
 
     def process_samples(self, step, discount=0.99, gae_lambda=1.0, normalize_adv=False, positive_adv=False,
                         baseline_kind=BASELINE_LINEAR_FEATURE, reg_coeff=1e-5):
@@ -264,6 +268,29 @@ class Context:
         assert obs.ndim == 3 and obs.shape[0] == self.n_tasks
         out = np.empty((self.n_tasks, obs.shape[1], self.dims.act_dim), np.float32)
         self._call('promp_policy_forward', _ptr(obs, C.c_float), int(obs.shape[1]), _ptr(out, C.c_float))
+        return out
+
+    def rollout_point_env(self, step, goals, start, noise, clip_infos=True):
+        """Device rollout of the 2-D point-mass meta-environment: goals [M,2], start [M,B,2] (float64), noise [M,B,T,2]
+        standard normals -> fills step `step`'s slab with M*B paths of length T (see promp_rollout_point_env)."""
+        goals = np.ascontiguousarray(goals, dtype=np.float64)
+        start = np.ascontiguousarray(start, dtype=np.float64)
+        noise = _f32(noise)
+        M, B, T = self.n_tasks, start.shape[1], noise.shape[2]
+        assert goals.shape == (M, 2) and start.shape == (M, B, 2) and noise.shape == (M, B, T, 2)
+        self._call('promp_rollout_point_env', int(step), int(B), int(T), _ptr(goals, C.c_double), _ptr(start, C.c_double),
+                   _ptr(noise, C.c_float), int(bool(clip_infos)))
+        self.step_rows[step], self.step_paths[step] = M * B * T, M * B
+        self.step_ls_rows[step] = M
+
+    def download_step(self, step):
+        """the slab of a sampling step back on the host: dict(obs, act, rew, old_mean, old_log_std)"""
+        R, A, O = self.step_rows[step], self.dims.act_dim, self.dims.obs_dim
+        ls_rows = self.step_ls_rows.get(step, R)
+        out = dict(obs=np.empty((R, O), np.float32), act=np.empty((R, A), np.float32), rew=np.empty(R, np.float32),
+                   old_mean=np.empty((R, A), np.float32), old_log_std=np.empty((ls_rows, A), np.float32))
+        self._call('promp_download_step', int(step), _ptr(out['obs'], C.c_float), _ptr(out['act'], C.c_float),
+                   _ptr(out['rew'], C.c_float), _ptr(out['old_mean'], C.c_float), _ptr(out['old_log_std'], C.c_float))
         return out
 
     # ---- algorithm ----

@@ -4,6 +4,7 @@
 #include "promp_kernels_policy.h"
 #include "promp_kernels_policy_wide.h"
 #include "promp_kernels_sample.h"
+#include "promp_kernels_rollout.h"
 #include "../../include/promp_hip.h"
 
 #ifndef PROMP_EMU
@@ -86,6 +87,8 @@ struct promp_ctx {
     float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
     float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
     double *gram_partials = nullptr, *red64 = nullptr;
+    void* rollout_buf = nullptr;         // goals, start states and noise of a device rollout
+    size_t rollout_capacity = 0;
     double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
     size_t smem_fwd = 0, smem_fwd8 = 0, smem_hvp = 0;
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
@@ -441,7 +444,7 @@ void promp_ctx_destroy(promp_ctx* c) {
     for (auto& S : c->steps) free_step(S);
     void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
-                    c->gram_partials, c->red64, c->fwd_buf, c->dbg, c->fit_scratch};
+                    c->gram_partials, c->red64, c->fwd_buf, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& s : c->prof_slots)
@@ -456,11 +459,11 @@ int promp_sync(promp_ctx* c) {
     return 0;
 }
 
-int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro, const float* obs,
-                      const float* act, const float* rew, const float* old_mean, const float* old_ls, int ls_per_row) {
+// Offsets, time indices and the three work tables of one sampling step (everything of promp_upload_step but the data).
+static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
-    if (!tpo || !pro || !obs || !rew) return fail(-1, "offsets, obs and rew are required");
+    if (!tpo || !pro) return fail(-1, "offsets are required");
     const int M = c->d.n_tasks;
     if (n_paths < 1 || n_paths > c->d.max_paths) return fail(-1, "n_paths %d outside [1, max_paths=%d]", n_paths, c->d.max_paths);
     if (tpo[0] != 0 || tpo[M] != n_paths) return fail(-1, "task_path_offsets must start at 0 and end at n_paths");
@@ -612,17 +615,7 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
     S.n_pwork = (int)pwork.size();
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false;
-    const size_t O = c->d.obs_dim, A = c->d.act_dim;
     hipStream_t st = c->stream;
-    HIPCHECK(hipMemcpyAsync(S.obs, obs, sizeof(float) * R * O, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * R, hipMemcpyHostToDevice, st));
-    S.has_policy = act && old_mean && old_ls;
-    if (S.has_policy) {
-        S.ls_per_row = ls_per_row ? 1 : 0;
-        HIPCHECK(hipMemcpyAsync(S.act, act, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(S.old_mean, old_mean, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(S.old_ls, old_ls, sizeof(float) * (ls_per_row ? (size_t)R : (size_t)M) * A, hipMemcpyHostToDevice, st));
-    }
     HIPCHECK(hipMemcpyAsync(S.path_row_offsets, pro, sizeof(int) * (n_paths + 1), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.task_path_offsets, tpo, sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.path_task, path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
@@ -635,6 +628,28 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         HIPCHECK(hipMemcpyAsync(S.work[t], work[t].data(), sizeof(WorkItem) * work[t].size(), hipMemcpyHostToDevice, st));
     }
     HIPCHECK(hipStreamSynchronize(st));  // host staging vectors go out of scope
+    return 0;
+}
+
+int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro, const float* obs,
+                      const float* act, const float* rew, const float* old_mean, const float* old_ls, int ls_per_row) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (!obs || !rew) return fail(-1, "offsets, obs and rew are required");
+    if (set_step_layout(c, step, n_paths, tpo, pro)) return -2;
+    StepData& S = c->steps[step];
+    const int M = c->d.n_tasks;
+    const size_t R = (size_t)S.n_rows;
+    const size_t O = c->d.obs_dim, A = c->d.act_dim;
+    hipStream_t st = c->stream;
+    HIPCHECK(hipMemcpyAsync(S.obs, obs, sizeof(float) * R * O, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * R, hipMemcpyHostToDevice, st));
+    S.has_policy = act && old_mean && old_ls;
+    if (S.has_policy) {
+        S.ls_per_row = ls_per_row ? 1 : 0;
+        HIPCHECK(hipMemcpyAsync(S.act, act, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.old_mean, old_mean, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.old_ls, old_ls, sizeof(float) * (ls_per_row ? (size_t)R : (size_t)M) * A, hipMemcpyHostToDevice, st));
+    }
     return 0;
 }
 
@@ -850,6 +865,63 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(mean_out, d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_length, const double* goals,
+                            const double* start, const float* noise, int clip_infos) {
+    if (!c || !goals || !start || !noise) return fail(-1, "NULL argument");
+    if (c->d.obs_dim != 2 || c->d.act_dim != 2) return fail(-1, "the point environment has obs_dim = act_dim = 2 (context: %d, %d)", c->d.obs_dim, c->d.act_dim);
+    if (envs_per_task < 1 || path_length < 1) return fail(-1, "envs_per_task and path_length must be positive");
+    const int M = c->d.n_tasks, B = envs_per_task, T = path_length;
+    const long long rows = (long long)M * B * T;
+    if (rows > c->d.max_rows) return fail(-1, "rollout of %lld rows exceeds max_rows = %d", rows, c->d.max_rows);
+    // fixed-length paths: path p of task i is rows [(i B + p) T, (i B + p + 1) T)
+    std::vector<int32_t> tpo(M + 1), pro((size_t)M * B + 1);
+    for (int i = 0; i <= M; ++i) tpo[i] = i * B;
+    for (int p = 0; p <= M * B; ++p) pro[p] = p * T;
+    if (set_step_layout(c, step, M * B, tpo.data(), pro.data())) return -2;
+    StepData& S = c->steps[step];
+    const size_t need = sizeof(double) * ((size_t)M * 2 + (size_t)M * B * 2) + sizeof(float) * (size_t)rows * 2;
+    if (need > c->rollout_capacity) {
+        if (c->rollout_buf) (void)hipFree(c->rollout_buf);
+        c->rollout_buf = nullptr;
+        c->rollout_capacity = 2 * need;
+        HIPCHECK(hipMalloc((void**)&c->rollout_buf, c->rollout_capacity));
+    }
+    double* d_goals = (double*)c->rollout_buf;
+    double* d_start = d_goals + (size_t)M * 2;
+    float* d_noise = (float*)(d_start + (size_t)M * B * 2);
+    hipStream_t st = c->stream;
+    HIPCHECK(hipMemcpyAsync(d_goals, goals, sizeof(double) * M * 2, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_start, start, sizeof(double) * M * B * 2, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_noise, noise, sizeof(float) * rows * 2, hipMemcpyHostToDevice, st));
+    PointRolloutArgs a;
+    a.theta_tasks = c->theta_tasks; a.NP = c->NP; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2;
+    a.B = B; a.T = T; a.goals = d_goals; a.start = d_start; a.noise = d_noise;
+    a.obs = S.obs; a.act = S.act; a.rew = S.rew; a.mean = S.old_mean; a.old_ls = S.old_ls;
+    a.clip_infos = clip_infos; a.min_log_std = logf(1e-6f); a.max_step = 0.1;
+    PROMP_LAUNCH(k_point_rollout, dim3(M), 64, 0, st, a);
+    HIPCHECK(hipGetLastError());
+    S.has_policy = true;
+    S.ls_per_row = 0;
+    return 0;
+}
+
+int promp_download_step(promp_ctx* c, int step, float* obs, float* act, float* rew, float* old_mean, float* old_log_std) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    const size_t R = S.n_rows, O = c->d.obs_dim, A = c->d.act_dim, M = c->d.n_tasks;
+    hipStream_t st = c->stream;
+    if (obs) HIPCHECK(hipMemcpyAsync(obs, S.obs, sizeof(float) * R * O, hipMemcpyDeviceToHost, st));
+    if (rew) HIPCHECK(hipMemcpyAsync(rew, S.rew, sizeof(float) * R, hipMemcpyDeviceToHost, st));
+    if ((act || old_mean || old_log_std) && !S.has_policy) return fail(-3, "step %d holds no actions / agent_infos", step);
+    if (act) HIPCHECK(hipMemcpyAsync(act, S.act, sizeof(float) * R * A, hipMemcpyDeviceToHost, st));
+    if (old_mean) HIPCHECK(hipMemcpyAsync(old_mean, S.old_mean, sizeof(float) * R * A, hipMemcpyDeviceToHost, st));
+    if (old_log_std) HIPCHECK(hipMemcpyAsync(old_log_std, S.old_ls, sizeof(float) * (S.ls_per_row ? R : M) * A, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -54,13 +54,19 @@ class SampleProcessor(object):
     def _process_on_device(self, paths_meta_batch):
         """-> (list[M] of SamplesData, per-path float64 stats) ; mutates the path dicts like the reference."""
         M = len(paths_meta_batch)
-        fl = _lib.flatten_paths(paths_meta_batch)
-        O = fl['obs'].shape[1]
-        first = next(iter(paths_meta_batch.values()))[0]
-        A = int(np.asarray(first['actions']).reshape(len(first['rewards']), -1).shape[1]) if 'actions' in first else 1
-        sess = self._session_for(M, O, A)
-        slot = sess.next_slot()
-        upload = sess.upload_flat(slot, fl)
+        sess, ref = session_mod.current(), getattr(paths_meta_batch, 'device_ref', None)
+        if ref is not None and sess is not None and sess.ctx is not None and ref[0] == sess.serial \
+                and sess.upload_serial[ref[2]] == ref[1]:
+            # a device rollout (samplers/device_point_sampler.py): the slab is already resident, nothing to upload
+            fl, upload, slot = paths_meta_batch.flat, ref[1], ref[2]
+        else:
+            fl = _lib.flatten_paths(paths_meta_batch)
+            O = fl['obs'].shape[1]
+            first = next(iter(paths_meta_batch.values()))[0]
+            A = int(np.asarray(first['actions']).reshape(len(first['rewards']), -1).shape[1]) if 'actions' in first else 1
+            sess = self._session_for(M, O, A)
+            slot = sess.next_slot()
+            upload = sess.upload_flat(slot, fl)
         ctx = sess.ctx
         kind = getattr(self.baseline, 'kind', _lib.BASELINE_ZERO)
         ctx.process_samples(slot, discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=self.normalize_adv,

@@ -1,0 +1,71 @@
+"""Rollouts of the 2-D point-mass meta-environment collected ON THE DEVICE.
+
+Same interface as MetaSampler (update_tasks / obtain_samples / total_timesteps_sampled), for environments of type
+promp_amd.envs.point_env.MetaPointEnv.  One kernel launch runs every environment for the whole horizon under its task's
+current policy parameters and writes the trajectories straight into the sampling step's slab
+(promp_rollout_point_env); MetaSampleProcessor.process_samples then finds the data resident and uploads nothing.
+The host keeps what it is good at: drawing tasks, start states and the exploration noise from NumPy's RNG, and
+materialising the path dicts the plugin API returns (one small download per sampling step)."""
+from collections import OrderedDict
+
+import numpy as np
+
+from ..utils import logger
+
+
+class DevicePaths(OrderedDict):
+    """{task -> [path dicts]} as obtain_samples returns, plus where the same data already lives on the device"""
+    device_ref = None     # (session serial, upload serial, step slot)
+    flat = None           # dict(task_path_offsets, path_row_offsets) of the resident slab
+
+
+class DevicePointEnvSampler(object):
+    def __init__(self, env, policy, rollouts_per_meta_task, meta_batch_size, max_path_length, envs_per_task=None,
+                 parallel=False):
+        assert hasattr(env, 'sample_tasks') and hasattr(env, 'set_task')
+        assert policy.obs_dim == 2 and policy.action_dim == 2, 'the device environment is the 2-D point mass'
+        self.env, self.policy = env, policy
+        self.batch_size = rollouts_per_meta_task
+        self.meta_batch_size = meta_batch_size
+        self.max_path_length = max_path_length
+        self.envs_per_task = rollouts_per_meta_task       # one environment per rollout: every path runs the full horizon
+        self.total_samples = meta_batch_size * rollouts_per_meta_task * max_path_length
+        self.total_timesteps_sampled = 0
+        self.goals = None
+
+    def update_tasks(self):
+        tasks = self.env.sample_tasks(self.meta_batch_size)
+        assert len(tasks) == self.meta_batch_size
+        self.goals = np.asarray(tasks, dtype=np.float64).reshape(self.meta_batch_size, 2)
+
+    def obtain_samples(self, log=False, log_prefix=''):
+        assert self.goals is not None, 'call update_tasks() first'
+        M, B, T = self.meta_batch_size, self.envs_per_task, self.max_path_length
+        sess = self.policy.session
+        ctx = sess.ensure(M * B * T, M * B)
+        if sess.task_thetas is not None:           # parameters set while no context existed yet
+            ctx.set_task_thetas(sess.task_thetas)
+            sess.task_thetas = None
+        start = np.random.uniform(-0.2, 0.2, size=(M, B, 2))         # MetaPointEnv.reset
+        noise = np.random.normal(size=(M, B, T, 2)).astype(np.float32)
+        slot = sess.next_slot()
+        ctx.rollout_point_env(slot, self.goals, start, noise, clip_infos=self.policy._pre_update_mode)
+        sess.upload_serial[slot] += 1
+        slab = ctx.download_step(slot)
+        paths = DevicePaths()
+        for i in range(M):
+            paths[i] = []
+            log_std = np.tile(slab['old_log_std'][i], (T, 1))
+            for b in range(B):
+                rows = slice((i * B + b) * T, (i * B + b + 1) * T)
+                paths[i].append(dict(observations=slab['obs'][rows], actions=slab['act'][rows], rewards=slab['rew'][rows],
+                                     env_infos=dict(goal_dist=-slab['rew'][rows].astype(np.float64)),
+                                     agent_infos=dict(mean=slab['old_mean'][rows], log_std=log_std)))
+        paths.device_ref = (sess.serial, sess.upload_serial[slot], slot)
+        paths.flat = dict(task_path_offsets=np.arange(M + 1, dtype=np.int32) * B,
+                          path_row_offsets=np.arange(M * B + 1, dtype=np.int32) * T)
+        self.total_timesteps_sampled += M * B * T
+        if log:
+            logger.logkv(log_prefix + 'PolicyExecTime', 0.0)
+            logger.logkv(log_prefix + 'EnvExecTime', 0.0)
+        return paths

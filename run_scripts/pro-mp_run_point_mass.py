@@ -19,6 +19,7 @@ from promp_amd.meta_algos.pro_mp import ProMP  # noqa: E402
 from promp_amd.meta_trainer import Trainer  # noqa: E402
 from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy  # noqa: E402
 from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor  # noqa: E402
+from promp_amd.samplers.device_point_sampler import DevicePointEnvSampler  # noqa: E402
 from promp_amd.samplers.meta_sampler import MetaSampler  # noqa: E402
 from promp_amd.utils import logger  # noqa: E402
 
@@ -30,6 +31,7 @@ DEFAULT = {
     'inner_lr': 0.1, 'learning_rate': 1e-3, 'num_promp_steps': 5, 'clip_eps': 0.3, 'target_inner_step': 0.01,
     'init_inner_kl_penalty': 5e-4, 'adaptive_inner_kl_penalty': False,
     'n_itr': 100, 'meta_batch_size': 4, 'num_inner_grad_steps': 1,
+    'device_rollouts': False,      # True: the environment itself runs on the GPU (samplers/device_point_sampler.py)
 }
 
 
@@ -39,7 +41,8 @@ def main(config):
     env = MetaPointEnv()
     policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=2, action_dim=2, meta_batch_size=config['meta_batch_size'],
                                    hidden_sizes=config['hidden_sizes'])
-    sampler = MetaSampler(env=env, policy=policy, rollouts_per_meta_task=config['rollouts_per_meta_task'],
+    sampler_cls = DevicePointEnvSampler if config.get('device_rollouts') else MetaSampler
+    sampler = sampler_cls(env=env, policy=policy, rollouts_per_meta_task=config['rollouts_per_meta_task'],
                           meta_batch_size=config['meta_batch_size'], max_path_length=config['max_path_length'],
                           parallel=config['parallel'])
     sample_processor = MetaSampleProcessor(baseline=baseline, discount=config['discount'], gae_lambda=config['gae_lambda'],

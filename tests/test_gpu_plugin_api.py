@@ -30,11 +30,21 @@ def test_trainer_end_to_end_point_env():
     scen.run_trainer_scenario(n_itr=3)
 
 
+def test_device_rollout_point_env():
+    scen.run_device_rollout_scenario(M=4, B=20, T=100)          # BASELINE config 0 shapes
+    scen.run_device_rollout_scenario(M=5, B=3, T=33, hidden=(64, 64))
+
+
+def test_trainer_with_device_rollouts():
+    scen.run_trainer_scenario(n_itr=3, device_rollouts=True)
+
+
 def test_get_actions_on_device():
     scen.run_get_actions_scenario(M=8, B=20, O=20, A=6, hidden=(64, 64))
 
 
-def test_promp_learns_on_point_env(tmp_path):
+@pytest.mark.parametrize('device_rollouts', [False, True], ids=['host_rollouts', 'device_rollouts'])
+def test_promp_learns_on_point_env(tmp_path, device_rollouts):
     """End to end on a real environment: the reference's point-mass recipe
     (run_scripts/pro-mp_run_point_mass.py shapes) improves the post-adaptation return."""
     import csv
@@ -44,7 +54,7 @@ def test_promp_learns_on_point_env(tmp_path):
     spec = importlib.util.spec_from_file_location('run_point', os.path.join(scen.__file__.rsplit('/tests/', 1)[0], 'run_scripts', 'pro-mp_run_point_mass.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    cfg = dict(mod.DEFAULT, n_itr=40, meta_batch_size=8, rollouts_per_meta_task=10, max_path_length=25, seed=3)
+    cfg = dict(mod.DEFAULT, n_itr=40, meta_batch_size=8, rollouts_per_meta_task=10, max_path_length=25, seed=3, device_rollouts=device_rollouts)
     logger.configure(dir=str(tmp_path), quiet=True)
     mod.main(cfg)
     rows = list(csv.DictReader(open(os.path.join(str(tmp_path), 'progress.csv'))))

@@ -100,7 +100,7 @@ def run_algo_scenario(M=2, P=2, T=30, O=5, A=3, hidden=(32, 32), K=1, epochs=2):
     np.testing.assert_allclose(algo.last_stats['loss_before'], algo2_stats_before, rtol=1e-5, atol=1e-6)
 
 
-def run_trainer_scenario(n_itr=2):
+def run_trainer_scenario(n_itr=2, device_rollouts=False):
     from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
     from promp_amd.envs.point_env import MetaPointEnv
     from promp_amd.meta_algos.pro_mp import ProMP
@@ -114,7 +114,9 @@ def run_trainer_scenario(n_itr=2):
     M, P, T = 2, 3, 12
     env = MetaPointEnv()
     policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=(32, 32))
-    sampler = MetaSampler(env=env, policy=policy, rollouts_per_meta_task=P, meta_batch_size=M, max_path_length=T, parallel=False)
+    from promp_amd.samplers.device_point_sampler import DevicePointEnvSampler
+    sampler = (DevicePointEnvSampler if device_rollouts else MetaSampler)(
+        env=env, policy=policy, rollouts_per_meta_task=P, meta_batch_size=M, max_path_length=T, parallel=False)
     proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
     algo = ProMP(policy=policy, inner_lr=0.1, meta_batch_size=M, num_inner_grad_steps=1, learning_rate=1e-3, num_ppo_steps=2,
                  clip_eps=0.3, init_inner_kl_penalty=5e-4, adaptive_inner_kl_penalty=False)
@@ -140,6 +142,60 @@ def run_trainer_scenario(n_itr=2):
     assert seen['n_timesteps'] == n_itr * 2 * M * P * T
     after = policy.get_param_values()
     assert any(np.any(before[k] != after[k]) for k in before) and all(np.all(np.isfinite(v)) for v in after.values())
+
+
+def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32)):
+    """DevicePointEnvSampler: the trajectories equal a float64 NumPy rollout of the same environment with the same start
+    states and noise (oracle/point_rollout.py); process_samples takes the resident slab (no upload) and returns what
+    it returns for the same paths handed over as plain host dicts."""
+    from oracle import policy as op, point_rollout as pr
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.envs.point_env import MetaPointEnv
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.device_point_sampler import DevicePointEnvSampler
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    np.random.seed(21)
+    env = MetaPointEnv()
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=hidden)
+    sampler = DevicePointEnvSampler(env=env, policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
+    sampler.update_tasks()
+    policy.switch_to_pre_update()
+    state = np.random.get_state()
+    paths = sampler.obtain_samples()
+    np.random.set_state(state)                                   # replay the sampler's draws for the oracle
+    start = np.random.uniform(-0.2, 0.2, size=(M, B, 2))
+    noise = np.random.normal(size=(M, B, T, 2)).astype(np.float32)
+    spec = op.PolicySpec(2, 2, hidden)
+    theta = spec.from_ordered_dict(policy.get_param_values())
+    ref = pr.rollout(spec, np.tile(theta, (M, 1)), sampler.goals, start, noise, clip_infos=True)
+    assert list(paths.keys()) == list(range(M)) and all(len(paths[i]) == B for i in range(M))
+    cat = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths[i]])
+    np.testing.assert_allclose(cat('observations'), ref['obs'], atol=2e-6)
+    np.testing.assert_allclose(cat('actions'), ref['act'], atol=2e-6)
+    np.testing.assert_allclose(cat('rewards'), ref['rew'], atol=2e-6)
+    np.testing.assert_allclose(cat('agent_infos', 'mean'), ref['mean'], atol=2e-6)
+    np.testing.assert_allclose(paths[0][0]['agent_infos']['log_std'][0], ref['log_std'][0], atol=1e-6)
+    assert sampler.total_timesteps_sampled == M * B * T
+    # processing: resident (no upload) == uploaded
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
+    sess = policy.session
+    serial_before = list(sess.upload_serial)
+    sd_dev = proc.process_samples(paths)
+    assert sess.upload_serial == serial_before, 'device paths must not be uploaded again'
+    host_paths = OrderedDict((i, [dict(observations=p['observations'], actions=p['actions'], rewards=p['rewards'],
+                                        env_infos=p['env_infos'], agent_infos=p['agent_infos']) for p in paths[i]]) for i in range(M))
+    sd_host = proc.process_samples(host_paths)
+    for a, b in zip(sd_dev, sd_host):
+        for key in ('observations', 'actions', 'rewards', 'returns', 'advantages', 'adj_avg_rewards'):
+            np.testing.assert_allclose(a[key], b[key], rtol=1e-6, atol=1e-7)
+
+
+def test_device_rollout_point_env(emu):
+    run_device_rollout_scenario()
+
+
+def test_trainer_with_device_rollouts(emu):
+    run_trainer_scenario(n_itr=1, device_rollouts=True)
 
 
 def test_meta_sample_processor_api(emu):
