@@ -23,5 +23,8 @@ Pinning status (see DESIGN.md "Oracle"):
   unchanged params, tests/test_integration.py:128-175).  The restatement is
   cross-checked by finite differences and by ``torch.autograd`` double
   backward (tests/test_oracle_policy.py); relative to the reference itself
-  its parity is "unpinned by reference vectors".
+  the autodiff / Adam parts are "unpinned by reference vectors".  The part of
+  these rows the reference also implements in NumPy IS pinned by its outputs
+  (``tests/golden/dist_reference.npz``): DiagonalGaussian.kl / log_likelihood
+  / entropy (row a9) and the KL-coefficient rule of ProMP.optimize_policy.
 """

@@ -6,6 +6,11 @@ TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python oracle/gen_golden.py
   * sample_proc_<case>.npz : inputs + outputs of the reference's own
     MetaSampleProcessor / LinearFeatureBaseline / utils (imported from /root/reference, which is
     importable after stubbing the absent ``pyprind`` progress-bar package -- SURVEY.md 8c).
+  * dist_reference.npz : inputs + outputs of the reference's own NumPy DiagonalGaussian.kl / log_likelihood / entropy
+    (policies/distributions/diagonal_gaussian.py:46-69, 111-127, 142-153: the NumPy twins of the *_sym graph functions,
+    including the +1e-8 in the KL denominator) and of ProMP's KL-coefficient rule (meta_algos/pro_mp.py:201-214).
+    Those modules import TensorFlow at the top; a module object that answers every attribute with a dummy lets the import
+    go through -- only NumPy code of the reference is ever executed.
   * promp_autograd_<case>.npz : inputs + loss / KLs / exact meta-gradient of the ProMP
     meta-objective computed by torch.autograd (float64, double backward) on a direct
     transcription of the TF graph's forward arithmetic.  TensorFlow is absent, so this is the
@@ -239,7 +244,45 @@ def gen_promp():
         print('wrote promp_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
 
 
+def gen_dist_reference():
+    """the reference's NumPy distribution arithmetic and KL-coefficient rule, run here, saved as vectors"""
+    class _Anything(object):
+        def __getattr__(self, name):
+            return _Anything()
+
+        def __call__(self, *a, **k):
+            return _Anything()
+
+    class _TensorFlowStandIn(types.ModuleType):     # import-time attribute access only; no graph code is executed
+        def __getattr__(self, name):
+            return _Anything()
+    sys.modules['tensorflow'] = _TensorFlowStandIn('tensorflow')
+    if not hasattr(np, 'cast'):      # the reference predates NumPy 2 (np.cast['float32'](x) in a class body it imports)
+        np.cast = type('_Cast', (), {'__getitem__': lambda self, dt: (lambda x: np.asarray(x, dtype=dt))})()
+    _import_reference()
+    from meta_policy_search.policies.distributions.diagonal_gaussian import DiagonalGaussian
+    from meta_policy_search.meta_algos import pro_mp as ref_promp
+    rng = np.random.RandomState(777)
+    N, A = 64, 6
+    dist = DiagonalGaussian(A)
+    old = dict(mean=rng.randn(N, A), log_std=0.4 * rng.randn(N, A))
+    new = dict(mean=old['mean'] + 0.3 * rng.randn(N, A), log_std=old['log_std'] + 0.2 * rng.randn(N, A))
+    new['log_std'][:4] = np.log(1e-6)               # the min_std floor
+    xs = old['mean'] + np.exp(old['log_std']) * rng.randn(N, A)
+    kl_values = np.array([0.001, 0.0066, 0.0067, 0.01, 0.0149, 0.015, 0.0151, 0.3])
+    coeffs = np.array([5e-4, 1e-3, 2e-3, 0.5, 1.0, 4.0, 0.25, 8.0])
+    adapted = np.array([ref_promp._adapt_kl_coeff(float(c), float(k), 0.01) for c, k in zip(coeffs, kl_values)])
+    np.savez_compressed(os.path.join(GOLDEN, 'dist_reference.npz'),
+                        old_mean=old['mean'], old_log_std=old['log_std'], new_mean=new['mean'], new_log_std=new['log_std'],
+                        xs=xs, kl=dist.kl(old, new), log_likelihood_new=dist.log_likelihood(xs, new),
+                        log_likelihood_old=dist.log_likelihood(xs, old), entropy_new=dist.entropy(new),
+                        kl_values=kl_values, kl_coeffs=coeffs, kl_target=0.01, kl_coeffs_adapted=adapted)
+    print('dist_reference.npz written')
+
+
 if __name__ == '__main__':
     os.makedirs(GOLDEN, exist_ok=True)
-    gen_sample_proc()
-    gen_promp()
+    if '--dist-only' not in sys.argv:
+        gen_sample_proc()
+        gen_promp()
+    gen_dist_reference()

@@ -115,6 +115,27 @@ def test_adam_fits_sine():
     assert loss_grad(theta)[0] < 0.02
 
 
+def test_distribution_arithmetic_matches_reference_numpy_outputs():
+    """a9 pinned by the reference itself: tests/golden/dist_reference.npz holds what the reference's NumPy
+    DiagonalGaussian.kl / log_likelihood / entropy return (generated by oracle/gen_golden.py in the build container)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dist_reference.npz'))
+    np.testing.assert_allclose(op.kl(g['old_mean'], g['old_log_std'], g['new_mean'], g['new_log_std']), g['kl'], rtol=1e-12)
+    np.testing.assert_allclose(op.log_likelihood(g['xs'], g['new_mean'], g['new_log_std']), g['log_likelihood_new'], rtol=1e-12)
+    np.testing.assert_allclose(op.log_likelihood(g['xs'], g['old_mean'], g['old_log_std']), g['log_likelihood_old'], rtol=1e-12)
+    ratio = op.likelihood_ratio(g['xs'], g['old_mean'], g['old_log_std'], g['new_mean'], g['new_log_std'])
+    np.testing.assert_allclose(ratio, np.exp(g['log_likelihood_new'] - g['log_likelihood_old']), rtol=1e-12)
+
+
+def test_kl_coeff_rule_matches_reference_outputs():
+    import os
+    from promp_amd.meta_algos.pro_mp import _adapt_kl_coeff
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'dist_reference.npz'))
+    mine = [_adapt_kl_coeff(float(c), float(k), float(g['kl_target'])) for c, k in zip(g['kl_coeffs'], g['kl_values'])]
+    np.testing.assert_array_equal(mine, g['kl_coeffs_adapted'])
+    np.testing.assert_array_equal(pm.adapt_kl_coeff(g['kl_coeffs'], g['kl_values'], float(g['kl_target'])), g['kl_coeffs_adapted'])
+
+
 def test_kl_coeff_rule():
     # meta_algos/pro_mp.py:201-214
     out = pm.adapt_kl_coeff(np.array([1.0, 1.0, 1.0]), [0.001, 0.01, 0.02], 0.01)
