@@ -95,12 +95,20 @@ def main():
         ctx.upload_step(1, f1['task_path_offsets'], f1['path_row_offsets'], f1['obs'], f1['rew'], f1['act'], f1['old_mean'],
                         th1[:, -A:].copy())
 
+        def upload():      # what a host-side sampler pays on top of the timed path: both slabs over PCIe (pageable memory)
+            ctx.upload_step(0, f0['task_path_offsets'], f0['path_row_offsets'], f0['obs'], f0['rew'], f0['act'], f0['old_mean'],
+                            np.tile(theta0[-A:], (M, 1)))
+            ctx.upload_step(1, f1['task_path_offsets'], f1['path_row_offsets'], f1['obs'], f1['rew'], f1['act'], f1['old_mean'],
+                            th1[:, -A:].copy())
+            ctx.sync()
+
         def iteration():
             ctx.switch_to_pre_update()                       # meta_trainer.py:85
             ctx.process_samples(0, **opts)                   # :105  (step 0)
             ctx.inner_adapt(0)                               # :116
             ctx.process_samples(1, **opts)                   # :105  (step 1)
             return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
+        iteration.upload = upload
         return ctx, iteration, M
 
     def run_timed(ctx, iteration, warmup, n):
@@ -141,6 +149,19 @@ def main():
                    'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
                    'device': info['name']},
     }
+
+    # ---- host -> device cost of the two slabs (never part of `value`: the timed region starts with the batch in HBM) ----
+    if rank == 0 and world == 1:
+        iteration.upload()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            iteration.upload()
+        h2d_ms = 1e3 * (time.perf_counter() - t0) / 3
+        step_ms = 1e3 * elapsed / args.steps
+        out['h2d'] = {'upload_ms_per_step': h2d_ms, 'bytes_per_step': int(4 * M * N * 2 * (O + 2 * A + 1)),
+                      'value_including_upload': M_global * N * (K + 1) / ((step_ms + h2d_ms) * 1e-3),
+                      'note': 'promp_upload_step of both slabs from pageable host memory, incl. the host-side work tables'}
+        iteration()       # (re-create the processed state the uploads reset)
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the stream it runs on ----
     if not args.no_roofline:
