@@ -86,6 +86,15 @@ def test_shape_sweep_loss_grad_and_hvp(lib, H, O, A, M, P, T):
     pc.check_hvp(lib, 200 + H + O, M=M, P=P, T=T, O=O, A=A, hidden=(H, H), ragged=True)
 
 
+@pytest.mark.parametrize('M,P,T', [(1, 3, 50), (2, 20, 200), (3, 7, 90), (5, 20, 200), (7, 3, 40), (13, 9, 77), (29, 6, 130),
+                                   (41, 2, 60), (57, 3, 50), (8, 1, 10)])
+def test_loss_grad_task_count_sweep(lib, M, P, T):
+    # the wave-granular work split of k_fwd_bwd over 2048 wave slots: tasks with fewer tiles than waves, workgroups that
+    # straddle two tasks, short last workgroups, and the one-task-per-workgroup fallback (tasks with < 8 waves)
+    pc.check_loss_grad(lib, 500 + M, M=M, P=P, T=T, O=11, A=5, hidden=(64, 64), ragged=True)
+    pc.check_hvp(lib, 600 + M, M=M, P=P, T=T, O=11, A=5, hidden=(64, 64), ragged=True)
+
+
 @pytest.mark.parametrize('H,O,A,M,P,T', _random_shapes(8, 77))
 def test_shape_sweep_meta_update(lib, H, O, A, M, P, T):
     pc.check_meta(lib, 400 + H + O, M=M, P=P, T=max(T, 30), O=O, A=A, hidden=(H, H), K=1 + (O % 2), ragged=True, epochs=2)
