@@ -272,14 +272,14 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     FinalArgs f;
     f.lam = c->lam; f.NP = NP; f.K = K; f.n_tasks = M;
     f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = want_grad ? 1 : 0;
-    PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
-    HIPCHECK(hipGetLastError());
-#ifndef PROMP_EMU
     if (c->nranks > 1) {
+        PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
+        HIPCHECK(hipGetLastError());
+#ifndef PROMP_EMU
         ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)(NP + K + 2), ncclFloat, ncclSum, c->comm, c->stream);
         if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
-    }
 #endif
+    }
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
     ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = NP; ad.K = K;
@@ -291,7 +291,8 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         const double t = (double)c->adam_t;
         ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
     }
-    PROMP_LAUNCH(k_mean_adam, dim3((NP + 1 + 255) / 256), 256, 0, c->stream, ad);
+    if (c->nranks > 1) PROMP_LAUNCH(k_mean_adam, dim3((NP + 1 + 255) / 256), 256, 0, c->stream, ad);
+    else PROMP_LAUNCH(k_final_adam, dim3((NP + K + 2 + 63) / 64 + 1), 256, 0, c->stream, f, ad);   // one rank: nothing in between
     HIPCHECK(hipGetLastError());
     return 0;
 }

@@ -1270,6 +1270,62 @@ __global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
     }
 }
 
+// k_reduce_final + k_mean_adam in one launch, for the single-rank case (no all-reduce in between).  Column sums in the
+// same order as k_reduce_final (bitwise the same red[]); the thread that finishes a parameter column applies its Adam
+// update; one extra workgroup re-sums the K + 2 scalar columns and writes the statistics.
+// grid = ceil((NP + K + 2) / 64) + 1, block = 256
+__global__ void __launch_bounds__(256) k_final_adam(FinalArgs a, AdamArgs ad) {
+    __shared__ float part[4][64];
+    __shared__ float sums[64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const bool stats_block = blockIdx.x == gridDim.x - 1;
+    const int j = stats_block ? a.NP + c : blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (j < a.NP) {
+        if (a.want_grad) {
+#pragma unroll 4
+            for (int i = q; i < a.n_tasks; i += 4) s += a.lam[(long long)i * a.NP + j];
+        }
+    } else if (j == a.NP) {
+        for (int i = q; i < a.n_tasks; i += 4) s += a.scal_outer[i * 2 + 0];
+    } else if (j <= a.NP + a.K) {
+        const int k = j - a.NP - 1;
+        for (int i = q; i < a.n_tasks; i += 4) s += a.scal_inner[((long long)k * a.n_tasks + i) * 2 + 1];
+    } else if (j == a.NP + a.K + 1) {
+        for (int i = q; i < a.n_tasks; i += 4) s += a.scal_outer[i * 2 + 1];
+    }
+    part[q][c] = s;
+    __syncthreads();
+    if (q == 0 && j < a.NP + a.K + 2) {
+        const float t = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        if (!stats_block) a.red[j] = t;
+        sums[c] = t;
+        if (!stats_block && j < a.NP) {
+            const float g = t * ad.inv_tasks;
+            ad.grad_mean[j] = g;
+            if (ad.do_update) {
+                const float m = 0.9f * ad.m[j] + 0.1f * g;
+                const float v = 0.999f * ad.v[j] + 0.001f * g * g;
+                ad.m[j] = m;
+                ad.v[j] = v;
+                ad.theta[j] -= ad.lr_t * m / (sqrtf(v) + 1e-8f);
+            }
+        }
+    }
+    if (!stats_block) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {      // sums[0] = J, sums[1..K] = inner KLs, sums[K+1] = outer KL (sums over the tasks)
+        float pen = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            const float ikl = sums[1 + k] * ad.inv_tasks;
+            ad.stats[1 + k] = ikl;
+            pen += ad.eta[k] * ikl;
+        }
+        ad.stats[0] = sums[0] * ad.inv_tasks + pen / (float)a.K;
+        ad.stats[1 + a.K] = sums[1 + a.K] * ad.inv_tasks;
+    }
+}
+
 // dst[i][:] = src[:] for i < n_tasks   (MetaPolicy.switch_to_pre_update)
 __global__ void __launch_bounds__(256) k_replicate(float* dst, const float* src, int NP, int n_tasks) {
     const int j = blockIdx.x * 256 + threadIdx.x;
