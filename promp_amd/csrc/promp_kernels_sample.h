@@ -559,15 +559,21 @@ __global__ void __launch_bounds__(1024) k_fit_wide(SampleArgs a, int NBLK, doubl
             const int k1 = k0 + nb, tr = DA - k1, tc = D - k1;
             if (tc > 0) {
                 const float rtc = 1.0f / (float)tc;
+#pragma unroll 2
                 for (int e = tid; e < tr * tc; e += NT) {
                     const int io = (int)(((float)e + 0.5f) * rtc), jo = e - io * tc;
                     if (jo <= io) {
+                        double* dst = Wm + (size_t)(k1 + io) * DA + k1 + jo;
+                        const double w0 = *dst;                                  // L2 round trip overlaps the dot product
                         const double* pi = Pn + (nb + io) * FITW_PS;
                         const double* pj = Pn + (nb + jo) * FITW_PS;
-                        double s = 0.0;
-#pragma unroll 8
-                        for (int c = 0; c < FITW_NB; ++c) s += pi[c] * pj[c];   // columns >= nb of the panel are zero
-                        Wm[(size_t)(k1 + io) * DA + k1 + jo] -= s;
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int c = 0; c < FITW_NB; c += 2) {                   // columns >= nb of the panel are zero
+                            s0 += pi[c] * pj[c];
+                            s1 += pi[c + 1] * pj[c + 1];
+                        }
+                        *dst = w0 - (s0 + s1);
                     }
                 }
             }
