@@ -15,7 +15,9 @@
 #include <hip/hip_runtime.h>
 
 #define PROMP_DEV __device__ __forceinline__
+#define PROMP_DEV_NOINLINE __device__ __attribute__((noinline))
 #define PROMP_HD __host__ __device__ inline
+#define PROMP_CX __host__ __device__ constexpr
 #define PROMP_SMEM_DECL extern __shared__ __attribute__((aligned(16))) unsigned char promp_smem_raw[]
 #define PROMP_SMEM_PTR promp_smem_raw
 #define PROMP_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -23,6 +25,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // D[32x32] += A[32x2] * B[2x32].  lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
@@ -46,6 +49,25 @@ PROMP_DEV void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// Compiler-only ordering point for wave-private LDS traffic: LDS executes one wave's instructions in issue order, so a
+// read issued after a write of the same wave sees it whichever lane wrote; nothing has to be waited for here.
+PROMP_DEV void wave_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// Workgroup barrier that orders LDS traffic only: global stores in flight (partial rows on their way to L2) are not
+// waited for, unlike __syncthreads().
+PROMP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Agent-scope hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility): the producer writes its
+// data, releases (L2 write-back + drain), then bumps a counter with a relaxed agent-scope atomic; the workgroup that
+// reads the final count acquires (L1 invalidate) before it loads the others' data.
+PROMP_DEV void fence_release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler may drop the wait after buffer_wbl2; the asm stays)
+}
+PROMP_DEV void fence_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+PROMP_DEV int atomic_add_agent(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PROMP_DEV void atomic_store_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // keeps the compiler from interleaving two independent GEMM groups (which would add their live ranges)
 PROMP_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // A zero the optimiser cannot see through.  Added to the base pointers inside a long unrolled loop body it keeps the
@@ -57,6 +79,13 @@ PROMP_DEV int opaque_zero() {
 }
 // Tells the compiler a value is the same in every lane of the wave (e.g. the wave index threadIdx.x >> 6), so that
 // everything derived from it lives in scalar registers.
+// Pins a value into the accumulator half of the register file (AGPRs: usable as MFMA operands and load / store data
+// only).  At one wave per SIMD a lane has 256 + 256 registers; weights that only ever feed MFMAs belong in the second
+// half, where they do not compete with the activations and epilogue temporaries for the 256 VALU-visible registers.
+PROMP_DEV f32x4 pin_agpr(f32x4 v) {
+    asm volatile("" : "+a"(v));
+    return v;
+}
 PROMP_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 PROMP_DEV unsigned long long promp_clock() { return (unsigned long long)clock64(); }
 PROMP_DEV unsigned long long promp_wall_clock() { return (unsigned long long)wall_clock64(); }   // constant 100 MHz

@@ -1,6 +1,7 @@
 // promp_hip.hip -- host side of libpromp_hip.so: context, device memory, launch sequences, C ABI.
 // See include/promp_hip.h for the contract.  gfx950 only; built by __graft_entry__.build():
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC promp_hip.hip -lrccl -o libpromp_hip.so
+#include "promp_kernels_chain.h"
 #include "promp_kernels_policy.h"
 #include "promp_kernels_policy_wide.h"
 #include "promp_kernels_sample.h"
@@ -48,8 +49,9 @@ int fail(int code, const char* fmt, ...) {
 
 struct StepData {
     int n_paths = 0, n_rows = 0;
-    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (k_hvp, wide passes, gram, fit), [1]: two per CU (k_normalize)
+    int n_work[2] = {0, 0};            // [0]: one workgroup per CU (wide passes, gram, fit), [1]: two per CU (k_normalize)
     int n_pwork = 0;                   // k_fwd_bwd workgroups (wave-granular PassWork table)
+    int n_chain_wg = 0;                // k_chain_hvp workgroups (segment table)
     bool has_policy = false, processed = false, has_adv = false;
     int ls_per_row = 0;
     int feat_dim = 0;
@@ -59,11 +61,20 @@ struct StepData {
     int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
     int *task_row_offsets = nullptr, *task_path_offsets = nullptr;
     int* task_wg_offsets[3] = {nullptr, nullptr, nullptr};   // [2]: partial slots of the k_fwd_bwd table per task
+    ChainSeg* chain_segs = nullptr;                          // segment table of k_chain_hvp
+    int* chain_wg_offsets = nullptr;                         // [workgroups+1]
+    int* chain_slot_offsets = nullptr;                       // [tasks+1]: partial rows (= segments) of each task
     double *path_ret0 = nullptr, *path_undisc = nullptr, *path_rsq = nullptr, *path_mom = nullptr;
     double* coeffs = nullptr;
     WorkItem* work[2] = {nullptr, nullptr};
     PassWork* pwork = nullptr;
 };
+
+// waves per workgroup of k_chain_hvp (one per SIMD: 512 registers per lane)
+constexpr int CHAIN_NW_HVP = 4;
+// layer-1 k-steps k_chain_hvp is instantiated for (4 observation entries per step, zero-padded)
+int chain_ksteps(int obs_dim) { return obs_dim <= 8 ? 2 : obs_dim <= 20 ? 5 : 8; }
+#define PROMP_CHAIN_ALL(X) X(2, 2, 2) X(2, 2, 5) X(2, 2, 8) X(2, 4, 2) X(2, 4, 5) X(2, 4, 8) X(4, 2, 2) X(4, 2, 5) X(4, 2, 8) X(4, 4, 2) X(4, 4, 5) X(4, 4, 8)
 
 struct ProfSlot {
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -90,18 +101,20 @@ struct promp_ctx {
     void* rollout_buf = nullptr;         // goals, start states and noise of a device rollout
     size_t rollout_capacity = 0;
     double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
-    size_t smem_fwd = 0, smem_fwd8 = 0, smem_hvp = 0;
+    size_t smem_fwd = 0, smem_hvp = 0;
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
+    unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
+    bool dbg_enabled = false;
+    int* task_counters = nullptr;        // [tasks] arrival counters of the chain kernels' fused reductions (zero between launches)
 #ifndef PROMP_EMU
     ncclComm_t comm = nullptr;
 #endif
     int rank = 0, nranks = 1;
+    bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
     float* fwd_buf = nullptr;            // staging for promp_policy_forward
     size_t fwd_capacity = 0;
-    unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
-    bool dbg_enabled = false;
 };
 
 namespace {
@@ -113,13 +126,22 @@ int dev_alloc(T** p, size_t n) {
     return 0;
 }
 
+// which family of pass kernels serves a network shape (sample processing alone works for any obs_dim <= 128)
+bool policy_shape_chain(const promp_dims* d) {     // register-chained kernels: hidden widths from {32, 64}, obs_dim <= 32
+    return d->obs_dim <= 32 && (d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64);
+}
+bool policy_shape_coop(const promp_dims* d) {      // cooperative kernels: (128,128), or (64,64) with wide observations
+    return d->hidden1 == d->hidden2 && (d->hidden1 == 128 || (d->hidden1 == 64 && d->obs_dim > 32));
+}
+
 int check_dims(const promp_dims* d) {
     if (!d) return fail(-1, "dims is NULL");
     if (d->n_tasks < 1 || d->n_tasks_global < d->n_tasks) return fail(-1, "bad task counts (%d local, %d global)", d->n_tasks, d->n_tasks_global);
     if (d->obs_dim < 1 || d->obs_dim > 128) return fail(-1, "obs_dim %d unsupported (1..128)", d->obs_dim);
     if (d->act_dim < 1 || d->act_dim > 8) return fail(-1, "act_dim %d unsupported (1..8)", d->act_dim);
-    if (d->hidden1 != d->hidden2 || !(d->hidden1 == 32 || d->hidden1 == 64 || d->hidden1 == 128))
-        return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates (32,32), (64,64) and (128,128)", d->hidden1, d->hidden2);
+    if (!policy_shape_chain(d) && !policy_shape_coop(d) && !((d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64)))
+        return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates every combination of {32, 64} (obs_dim <= 32) "
+                    "and (64,64) / (128,128) (obs_dim <= 128)", d->hidden1, d->hidden2);
     if (d->num_inner_steps < 1) return fail(-1, "num_inner_steps must be >= 1");
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
@@ -174,16 +196,26 @@ int prof_collect(promp_ctx* c) {
 }
 
 // ---- launches ----------------------------------------------------------------------------------
+// One policy pass over a step's slabs plus the per-task reduction that consumes it:
+//   red_mode RED_STEP / RED_OUTER / RED_HVP / RED_PLAIN / RED_SCAL (promp_kernels_chain.h).
+// k_chain_hvp does both in one launch; k_fwd_bwd and the cooperative kernels (hidden 128 / wide observations) are
+// followed by k_reduce_task.
 int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long long theta_stride, int loss_kind,
-                float clip_eps, int clip_ls, float klw, bool fwd_only = false) {
+                float clip_eps, int clip_ls, float klw, bool fwd_only, int red_mode, const float* cur, long long cur_stride,
+                float* next, float* scal) {
     if (!S.has_policy) return fail(-3, "step has no actions / agent_infos uploaded");
     if (!S.has_adv) return fail(-3, "step has no advantages: call promp_process_samples or promp_set_advantages first");
+    if (!policy_shape_chain(&c->d) && !c->wide)
+        return fail(-1, "policy passes with obs_dim %d need hidden sizes (64,64) or (128,128); (%d,%d) is tiled for obs_dim <= 32",
+                    c->d.obs_dim, c->d.hidden1, c->d.hidden2);
     PassArgs a;
+    memset(&a, 0, sizeof a);
     a.obs = S.obs; a.act = S.act; a.adv = S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
     a.pwork = S.pwork;
+    a.segs = S.chain_segs; a.wg_seg_offsets = S.chain_wg_offsets;
     a.theta = theta; a.theta_task_stride = theta_stride;
     a.vdir = c->vbuf;
     a.partials = c->partials; a.partial_stride = c->partial_stride;
@@ -191,12 +223,12 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.loss_kind = loss_kind; a.clip_eps = clip_eps; a.clip_log_std = clip_ls;
     a.min_log_std = logf(1e-6f);   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
     a.kl_weight = klw;
+    a.task_counters = c->task_counters; a.task_slot_offsets = S.chain_slot_offsets;
+    a.red_mode = red_mode; a.step_sizes = c->step_sizes; a.cur = cur; a.cur_task_stride = cur_stride; a.next = next;
+    a.lam = c->lam; a.v = c->vbuf; a.scal = scal;
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
     const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
     if (prof_begin(c, id, S.n_rows)) return -2;
-    const bool h64 = c->d.hidden1 == 64;
-    if (c->wide && c->d.hidden1 == 32)   // (sample processing alone works for any obs_dim <= 128)
-        return fail(-1, "policy passes with obs_dim %d need hidden sizes 64 or 128 (hidden size 32 is tiled for obs_dim <= 32)", c->d.obs_dim);
     if (c->wide) {
         // cooperative kernels (promp_kernels_policy_wide.h): hidden 128, or hidden 64 with obs_dim > 32
         const int nob = c->d.obs_dim <= 32 ? 2 : c->d.obs_dim <= 64 ? 4 : 8;
@@ -209,37 +241,38 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     }
         PROMP_WIDE_CASE(128, 2) PROMP_WIDE_CASE(128, 4) PROMP_WIDE_CASE(128, 8) PROMP_WIDE_CASE(64, 2) PROMP_WIDE_CASE(64, 4) PROMP_WIDE_CASE(64, 8)
 #undef PROMP_WIDE_CASE
-    } else if (!hvp) {
-        if (fwd_only) {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd8, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 8, false>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd8, c->stream, a); }
-        } else {
-            if (h64) { auto k = k_fwd_bwd<2, 2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }
-            else     { auto k = k_fwd_bwd<1, 1, 8, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }
-        }
+    } else if (hvp) {
+        // register-chained R-operator pass: the per-task reduction happens inside the launch (last-arriving workgroup)
+        const int n1 = c->d.hidden1 / 16, n2 = c->d.hidden2 / 16, ks = chain_ksteps(c->d.obs_dim);
+#define PROMP_CHAIN_CASE(N1, N2, KS)                                                                                             \
+    if (n1 == N1 && n2 == N2 && ks == KS) { auto k = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_hvp, c->stream, a); }
+        PROMP_CHAIN_ALL(PROMP_CHAIN_CASE)
+#undef PROMP_CHAIN_CASE
+        HIPCHECK(hipGetLastError());
+        return prof_end(c, id);
     } else {
-        if (h64) { auto k = k_hvp<2, 2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
-        else     { auto k = k_hvp<1, 1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_hvp, c->stream, a); }
+        const int b1 = c->d.hidden1 / 32, b2 = c->d.hidden2 / 32;
+#define PROMP_PASS_CASE(B1, B2)                                                                                                   \
+    if (b1 == B1 && b2 == B2) {                                                                                                   \
+        if (fwd_only) { auto k = k_fwd_bwd<B1, B2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
+        else { auto k = k_fwd_bwd<B1, B2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }          \
+    }
+        PROMP_PASS_CASE(1, 1) PROMP_PASS_CASE(1, 2) PROMP_PASS_CASE(2, 1) PROMP_PASS_CASE(2, 2)
+#undef PROMP_PASS_CASE
     }
     HIPCHECK(hipGetLastError());
-    return prof_end(c, id);
-}
-
-int launch_reduce(promp_ctx* c, StepData& S, int table, int mode, const float* cur, long long cur_stride, float* next, float* scal) {
+    if (prof_end(c, id)) return -2;
     ReduceArgs r;
     r.partials = c->partials; r.partial_stride = c->partial_stride;
-    r.task_wg_offsets = S.task_wg_offsets[table];
+    r.task_wg_offsets = S.task_wg_offsets[c->wide ? 0 : 2];      // k_fwd_bwd writes wave-granular slots (table 2)
     r.NP = c->NP;
-    r.step_sizes = c->step_sizes; r.mode = mode;
+    r.step_sizes = c->step_sizes; r.mode = red_mode;
     r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
     r.lam = c->lam; r.v = c->vbuf; r.scal = scal;
     PROMP_LAUNCH(k_reduce_task, dim3((c->NP + 2 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, r);
     HIPCHECK(hipGetLastError());
     return 0;
 }
-
-// partial-sum table the reduction after a pass reads: k_fwd_bwd writes wave-granular slots (table 2)
-int pass_table(const promp_ctx* c, bool hvp) { return (hvp || c->wide) ? 0 : 2; }
 
 int loss_kind_inner(int inner_kind) { return inner_kind == PROMP_INNER_LOGLIK ? LOSS_LOGLIK : LOSS_RATIO; }
 int loss_kind_outer(int outer_kind) {
@@ -256,28 +289,31 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     for (int k = 0; k < K; ++k) {
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
-        if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f)) return -2;
-        if (launch_reduce(c, c->steps[k], pass_table(c, false), 0, th, st, c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+        if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f, false, RED_STEP, th, st,
+                        c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
     }
-    if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f, !want_grad)) return -2;
-    if (launch_reduce(c, c->steps[K], pass_table(c, false), want_grad ? 1 : 4, nullptr, 0, nullptr, c->scal_outer)) return -2;
+    if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f, !want_grad,
+                    want_grad ? RED_OUTER : RED_SCAL, nullptr, 0, nullptr, c->scal_outer)) return -2;
     if (want_grad) {
         for (int k = K - 1; k >= 0; --k) {
             const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
             const long long st = (k == 0) ? 0 : NP;
-            if (launch_pass(c, c->steps[k], true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, eta_host[k] / (float)K)) return -2;
-            if (launch_reduce(c, c->steps[k], pass_table(c, true), 2, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+            if (launch_pass(c, c->steps[k], true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, eta_host[k] / (float)K, false,
+                            RED_HVP, nullptr, 0, nullptr, c->scal_tmp)) return -2;
         }
     }
     FinalArgs f;
     f.lam = c->lam; f.NP = NP; f.K = K; f.n_tasks = M;
     f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = want_grad ? 1 : 0;
-    if (c->nranks > 1) {
+    const bool split = c->nranks > 1 || c->force_split;
+    if (split) {
         PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
         HIPCHECK(hipGetLastError());
 #ifndef PROMP_EMU
-        ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)(NP + K + 2), ncclFloat, ncclSum, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+        if (c->comm) {
+            ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)(NP + K + 2), ncclFloat, ncclSum, c->comm, c->stream);
+            if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+        }
 #endif
     }
     AdamArgs ad;
@@ -291,7 +327,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         const double t = (double)c->adam_t;
         ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
     }
-    if (c->nranks > 1) PROMP_LAUNCH(k_mean_adam, dim3((NP + 1 + 255) / 256), 256, 0, c->stream, ad);
+    if (split) PROMP_LAUNCH(k_mean_adam, dim3((NP + 1 + 255) / 256), 256, 0, c->stream, ad);
     else PROMP_LAUNCH(k_final_adam, dim3((NP + K + 2 + 63) / 64 + 1), 256, 0, c->stream, f, ad);   // one rank: nothing in between
     HIPCHECK(hipGetLastError());
     return 0;
@@ -305,7 +341,8 @@ int upload_eta(promp_ctx* c, const float* eta) {
 
 void free_step(StepData& S) {
     void* ptrs[] = {S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
-                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.path_ret0,
+                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.chain_segs, S.chain_wg_offsets,
+                    S.chain_slot_offsets, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -354,33 +391,36 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
-    c->wide = dims->hidden1 == 128 || dims->obs_dim > 32;
-    if (const char* e = getenv("PROMP_DEV_FORCE_WIDE")) { if (atoi(e) == 1 && dims->hidden1 == 64) c->wide = true; }   // developer experiment
+    c->wide = policy_shape_coop(dims);
     if (c->wide) {
         const int nob = dims->obs_dim <= 32 ? 2 : dims->obs_dim <= 64 ? 4 : 8;
-        c->smem_fwd = c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
+        c->smem_fwd = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
         c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
     } else {
-    c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
-    c->smem_fwd8 = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;
-    c->smem_hvp = sizeof(float) * (size_t)make_layout_hvp(32, dims->hidden1, dims->hidden2, 4, param_count(dims)).total;   // (sized for obs_dim 32: constant offsets in the kernel)
+        c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;   // (sized for obs_dim 32: constant offsets in the kernel)
+        c->smem_hvp = sizeof(float) * (size_t)chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(dims)).total;
     }
-    if (c->smem_hvp > 160 * 1024) {
-        const size_t need = c->smem_hvp;
+    if (c->smem_hvp > 160 * 1024 || c->smem_fwd > 160 * 1024) {
+        const size_t need = c->smem_hvp > c->smem_fwd ? c->smem_hvp : c->smem_fwd;
         promp_ctx_destroy(c);
         return fail(-1, "LDS budget exceeded (%zu bytes)", need);
     }
     {
-        auto k2 = k_hvp<2, 2>; auto k3 = k_hvp<1, 1>;
-        auto k4 = k_fwd_bwd<2, 2, 8, true>; auto k5 = k_fwd_bwd<1, 1, 8, true>;
-        auto k6 = k_fwd_bwd<2, 2, 8, false>; auto k7 = k_fwd_bwd<1, 1, 8, false>;
-        HIPCHECK(hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void*)k7, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-
-        HIPCHECK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define PROMP_CHAIN_ATTR(N1, N2, KS)                                                                                        \
+    {                                                                                                                     \
+        auto c2 = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP>;                                                                   \
+        HIPCHECK(hipFuncSetAttribute((const void*)c2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+    }
+        PROMP_CHAIN_ALL(PROMP_CHAIN_ATTR)
+#undef PROMP_CHAIN_ATTR
+#define PROMP_PASS_ATTR(B1, B2)                                                                                              \
+    {                                                                                                                     \
+        auto c0 = k_fwd_bwd<B1, B2, 8, true>; auto c1 = k_fwd_bwd<B1, B2, 8, false>;                                       \
+        HIPCHECK(hipFuncSetAttribute((const void*)c0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        HIPCHECK(hipFuncSetAttribute((const void*)c1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+    }
+        PROMP_PASS_ATTR(1, 1) PROMP_PASS_ATTR(1, 2) PROMP_PASS_ATTR(2, 1) PROMP_PASS_ATTR(2, 2)
+#undef PROMP_PASS_ATTR
 #define PROMP_WIDE_ATTR(HH, NOB)                                                                                          \
     {                                                                                                                     \
         auto w0 = k_wide_fwd_bwd<HH, NOB, true>; auto w1 = k_wide_fwd_bwd<HH, NOB, false>; auto w2 = k_wide_hvp<HH, NOB>;   \
@@ -414,7 +454,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
     if (nblk_max > 5 || dims->obs_dim > 32) rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
     rc |= dev_alloc(&c->red64, 64);
-    rc |= dev_alloc(&c->dbg, 256);
+    rc |= dev_alloc(&c->task_counters, (size_t)M);
+    rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
     c->steps.resize(K + 1);
     for (int s = 0; s <= K && !rc; ++s) {
         StepData& S = c->steps[s];
@@ -426,6 +467,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
         rc |= dev_alloc(&S.task_wg_offsets[0], (size_t)M + 1); rc |= dev_alloc(&S.task_wg_offsets[1], (size_t)M + 1);
         rc |= dev_alloc(&S.task_wg_offsets[2], (size_t)M + 1); rc |= dev_alloc(&S.pwork, (size_t)c->max_work);
+        rc |= dev_alloc(&S.chain_segs, (size_t)c->max_work); rc |= dev_alloc(&S.chain_wg_offsets, (size_t)c->max_work + 1);
+        rc |= dev_alloc(&S.chain_slot_offsets, (size_t)M + 1);
         rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
         rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
         rc |= dev_alloc(&S.work[0], (size_t)c->max_work); rc |= dev_alloc(&S.work[1], (size_t)c->max_work);
@@ -445,7 +488,7 @@ void promp_ctx_destroy(promp_ctx* c) {
     for (auto& S : c->steps) free_step(S);
     void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
-                    c->gram_partials, c->red64, c->fwd_buf, c->dbg, c->fit_scratch, c->rollout_buf};
+                    c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& s : c->prof_slots)
@@ -486,7 +529,7 @@ static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* t
     // work tables: contiguous ranges of 16-row wave tiles, workgroups shared out over tasks in proportion to their tiles
     std::vector<int> tiles(M);
     long long total_tiles = 0;
-    const int GR = PROMP_WROWS;   // work granule = one wave tile (16 rows)
+    const int GR = 16;   // work granule = one wave tile (16 rows)
     for (int i = 0; i < M; ++i) { tiles[i] = (tro[i + 1] - tro[i] + GR - 1) / GR; total_tiles += tiles[i]; }
     std::vector<WorkItem> work[2];
     std::vector<int> two[2];
@@ -531,6 +574,63 @@ static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* t
             two[t][i + 1] = (int)work[t].size();
         }
         if ((int)work[t].size() > c->max_work) return fail(-5, "internal: work table overflow (%zu > %d)", work[t].size(), c->max_work);
+    }
+    // chain kernels: the NW waves of a workgroup walk a segment's tiles round-robin, so a task of n tiles costs
+    // ceil(n / NW) rounds; the global list of rounds is cut into equal shares, one per CU; a share that straddles task
+    // boundaries becomes one segment per task (walked one after the other).  Segments are generated in task order, so a
+    // task's partial rows are the contiguous segment indices [slot_off[i], slot_off[i+1]).
+    struct ChainTable { std::vector<ChainSeg> segs; std::vector<int> wg_off, slot_off; };
+    ChainTable T;
+    {
+        const int NW = CHAIN_NW_HVP;
+        std::vector<long long> rounds(M);
+        long long total = 0;
+        for (int i = 0; i < M; ++i) { rounds[i] = (tiles[i] + NW - 1) / NW; total += rounds[i]; }
+        // A segment also costs its parameter staging and end reduction, about SEGC rounds' worth: workgroups are filled
+        // up to a common cost limit (rounds + SEGC per segment, in quarter rounds), the smallest limit that needs no more
+        // workgroups than there are CUs.
+        const long long SEGC = 2;                  // quarter rounds per segment
+        auto cut = [&](long long limit, bool emit) -> long long {
+            long long nwg = 0, cost = 0;
+            bool open = false;
+            for (int i = 0; i < M; ++i) {
+                long long done = 0;
+                while (done < rounds[i]) {
+                    long long room = open ? (limit - cost - SEGC) / 4 : 0;   // rounds of task i that still fit
+                    if (!open || room < 1) {
+                        if (open && emit) T.wg_off.push_back((int)T.segs.size());
+                        ++nwg; open = true; cost = 0;
+                        room = (limit - SEGC) / 4;
+                        if (room < 1) room = 1;
+                    }
+                    const long long take = std::min(room, rounds[i] - done);
+                    if (emit) {
+                        ChainSeg sg;
+                        sg.task = i;
+                        sg.tile0 = (int)(done * NW);
+                        sg.ntiles = (int)std::min<long long>(tiles[i], (done + take) * NW) - sg.tile0;
+                        sg.pad = 0;
+                        T.segs.push_back(sg);
+                        T.slot_off[i + 1] = (int)T.segs.size();
+                    }
+                    done += take;
+                    cost += 4 * take + SEGC;
+                }
+            }
+            if (open && emit) T.wg_off.push_back((int)T.segs.size());
+            return nwg;
+        };
+        long long lo = 4 + SEGC, hi = 4 * total + SEGC * M + 4;
+        while (lo < hi) {
+            const long long mid = (lo + hi) / 2;
+            if (cut(mid, false) <= c->n_cus) hi = mid; else lo = mid + 1;
+        }
+        T.slot_off.assign(M + 1, 0);
+        T.wg_off.assign(1, 0);
+        cut(lo, true);
+        for (int i = 0; i < M; ++i)
+            if (T.slot_off[i + 1] < T.slot_off[i]) T.slot_off[i + 1] = T.slot_off[i];
+        if ((int)T.segs.size() > c->max_work) return fail(-5, "internal: segment table overflow (%zu > %d)", T.segs.size(), c->max_work);
     }
     // k_fwd_bwd: waves (8 per CU-resident workgroup) shared out over tasks in proportion to their tiles, largest remainder;
     // a workgroup serves at most two tasks, which holds when every task gets >= 8 waves -- otherwise one task per
@@ -613,7 +713,6 @@ static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* t
             return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
     }
     StepData& S = c->steps[step];
-    S.n_pwork = (int)pwork.size();
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false;
     hipStream_t st = c->stream;
@@ -622,6 +721,11 @@ static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* t
     HIPCHECK(hipMemcpyAsync(S.path_task, path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.row_t, row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.task_row_offsets, tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    S.n_chain_wg = (int)T.wg_off.size() - 1;
+    S.n_pwork = (int)pwork.size();
+    HIPCHECK(hipMemcpyAsync(S.chain_segs, T.segs.data(), sizeof(ChainSeg) * T.segs.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.chain_wg_offsets, T.wg_off.data(), sizeof(int) * T.wg_off.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.chain_slot_offsets, T.slot_off.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[2], slot_off.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.pwork, pwork.data(), sizeof(PassWork) * pwork.size(), hipMemcpyHostToDevice, st));
     for (int t = 0; t < 2; ++t) {
@@ -841,8 +945,8 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
-    if (launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f)) return -2;
-    return launch_reduce(c, S, pass_table(c, false), 0, c->theta_tasks, c->NP, c->theta_tasks, c->scal_tmp);
+    return launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f, false, RED_STEP, c->theta_tasks,
+                       c->NP, c->theta_tasks, c->scal_tmp);
 }
 
 int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_out) {
@@ -977,8 +1081,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     if (kind < 0 || kind > 3) return fail(-1, "unknown objective kind %d", kind);
     StepData& S = c->steps[step];
     const int M = c->d.n_tasks;
-    if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f)) return -2;
-    if (launch_reduce(c, S, pass_table(c, false), 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
     std::vector<float> sc((size_t)M * 2);
     if (copy_out(c, sc.data(), c->scal_tmp, sc.size())) return -2;
@@ -996,8 +1099,7 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     const int M = c->d.n_tasks, NP = c->NP;
     if (copy_in(c, c->vbuf, v, (size_t)M * NP)) return -2;
     HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
-    if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw)) return -2;
-    if (launch_reduce(c, S, 0, 3, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+    if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     return copy_out(c, out, c->lam, (size_t)M * NP);
 }
 
@@ -1050,18 +1152,18 @@ int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {
     return 0;
 }
 
-// Developer tooling (not part of include/promp_hip.h): run one k_fwd_bwd / k_hvp launch on the current per-task
-// parameters with cycle stamps of workgroup 0 enabled, and return the 256 raw stamps.
+// Developer tooling (not part of include/promp_hip.h): run one chain-kernel launch on the current per-task parameters
+// with the cycle stamps of workgroup 0 enabled, and return the 256 raw stamps (needs a -DPROMP_DEV_STAMPS build).
 int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long* out) {
     if (!c || !out) return fail(-1, "NULL argument");
     if (!PROMP_STAMPS_ON) return fail(-3, "phase stamps need a build with -DPROMP_DEV_STAMPS");
     StepData& S = c->steps[step];
-    HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * 256, c->stream));
+    HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * (256 + 4 * 1024), c->stream));
     c->dbg_enabled = true;
-    const int rc = launch_pass(c, S, hvp != 0, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f);
+    const int rc = launch_pass(c, S, hvp != 0, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
     c->dbg_enabled = false;
     if (rc) return rc;
-    HIPCHECK(hipMemcpyAsync(out, c->dbg, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(out, c->dbg, sizeof(unsigned long long) * (256 + 4 * 1024), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -1,0 +1,873 @@
+// promp_kernels_chain.h -- per-task Gaussian-MLP policy passes for hidden widths <= 64 (reference rows a8-a13).
+//
+//   k_chain_pass : objective + mean KL (+ gradient) of the tasks' slabs                      (K8-K11)
+//   k_chain_hvp  : out = -H v + kl_weight * grad KL, H = Hessian of the inner objective      (K12, K13)
+// both followed, inside the same launch, by the fixed-order sum of a task's partial rows and the update that
+// consumes it (inner SGD step / multiplier update), done by whichever workgroup of the task finishes last.
+//
+// Arithmetic follows oracle/promp.py (which restates meta_algos/pro_mp.py:59-155, meta_algos/base.py:192-215,
+// policies/networks/mlp.py:65-119, policies/distributions/diagonal_gaussian.py:16-109 of the reference).
+//
+// Register-chained layers.  v_mfma_f32_16x16x4_f32 computes D[m][n] += sum_k A[m][k] B[k][n]; lane (i16, kk) feeds
+// A[i16][kk] and B[kk][i16] and receives D[4 kk + r][i16], r = 0..3.  A wave owns a tile of 16 samples and keeps its
+// activations TRANSPOSED: samples along n (= i16), units along m.  The four registers a lane receives are units
+// 16 c + 4 kk + r of sample i16 -- exactly what lane (i16, kk) must feed as B[k][n] to the next layer if the
+// contraction visits the units in the order k-step (c, r) <-> unit 16 c + 4 kk + r.  So H^T_next = W^T H^T runs from
+// accumulator registers to operand registers with no LDS round trip, forward (weights as A[m = out unit][k = in unit])
+// and backward (A[m = in unit][k = out unit]) alike; the tanh / cotangent epilogues are plain per-register VALU work.
+// The weights are staged once per task into LDS in fragment order (each lane's four k-steps contiguous: one
+// ds_read_b128 per 4 MFMAs, no address arithmetic); the backward pass reads the same copy with 4-byte reads (the
+// lane-group rows are padded to 68 floats so that both access patterns are bank-conflict free).
+//
+// Only the weight gradients contract over SAMPLES and need both operands with the unit along i16: those operands
+// go through a per-wave [16][68] LDS tile (written as 4 ds_write_b128 per 64 units, read as 4-byte columns); the
+// contraction visits the samples in the order k-step t <-> sample 4 kk + t.  The observation tile is read from
+// global memory in both orientations.
+//
+// Work split.  A 16-sample tile is the unit; the NW waves of a workgroup walk a segment (tiles [tile0, tile0+n) of
+// one task) round-robin, so a segment costs ceil(n / NW) rounds.  The host cuts the global list of rounds into equal
+// shares, one per CU; a share that straddles a task boundary becomes two segments that the workgroup walks one after
+// the other (restaging the parameters in between).  Every (workgroup, segment) writes one partial row.
+#pragma once
+#include "promp_device.h"
+
+#define PROMP_PARTIAL_EXTRA 4   // loss, kl, 2 spare
+#define PROMP_CH_TS 68          // row stride of a [16 samples][<= 64 units] transpose tile
+#define PROMP_CH_DS 20          // row stride of the [16 samples][16 action slots] cotangent tile
+#define PROMP_CH_ROW 68         // floats per lane-group row of a hidden_1 fragment block (64 + 4 pad)
+#define PROMP_CH_BLK (4 * PROMP_CH_ROW)
+
+enum { LOSS_RATIO = 0, LOSS_CLIP = 1, LOSS_LOGLIK = 2, LOSS_KL = 3 };   // LOSS_KL: mean KL(old || new) itself (TRPO constraint)
+
+struct WorkItem {
+    int task, row_begin, row_end, pad;
+};
+
+struct ChainSeg {
+    int task, tile0, ntiles, pad;   // 16-row tiles [tile0, tile0 + ntiles) of the task; slot = index of the segment
+};
+
+// What the last-arriving workgroup of a task does with the task's summed partial row g (fixed slot order):
+//   RED_STEP  : next[i] = cur[i] - alpha * g                  ; scal[i] = {loss, kl}     (inner SGD step)
+//   RED_OUTER : lam[i] = g ; v[i] = alpha * g                 ; scal[i] = {loss, kl}
+//   RED_HVP   : lam[i] += g ; v[i] = alpha * lam[i]           ; scal[i] = {-, kl}
+//   RED_PLAIN : lam[i] = g                                    ; scal
+//   RED_SCAL  : scal only (forward-only passes write no gradient)
+enum { RED_STEP = 0, RED_OUTER = 1, RED_HVP = 2, RED_PLAIN = 3, RED_SCAL = 4 };
+
+struct PassArgs {
+    const float* obs;           // [rows][O]
+    const float* act;           // [rows][A]
+    const float* adv;           // [rows]
+    const float* old_mean;      // [rows][A]
+    const float* old_log_std;   // [rows][A] or [tasks][A]
+    int ls_per_row;
+    const int* task_row_offsets;  // [tasks+1]
+    const WorkItem* work;         // cooperative (wide) kernels: one row range per workgroup
+    const struct PassWork* pwork; // k_fwd_bwd: wave-granular work items
+    const ChainSeg* segs;         // k_chain_hvp
+    const int* wg_seg_offsets;    // [grid+1]
+    const float* theta;           // [Theta] or [tasks][Theta]
+    long long theta_task_stride;  // 0 => shared
+    const float* vdir;            // hvp: [tasks][Theta]
+    float* partials;              // [slots][partial_stride]
+    int partial_stride;
+    int O, A;
+    int loss_kind;
+    float clip_eps;
+    int clip_log_std;
+    float min_log_std;
+    float kl_weight;
+    // fused per-task reduction (chain kernels)
+    int* task_counters;             // [tasks]; zero between launches (the last arriver resets its task's counter)
+    const int* task_slot_offsets;   // [tasks+1]
+    int red_mode;
+    const float* step_sizes;        // [Theta]
+    const float* cur;               // RED_STEP: [Theta] or [tasks][Theta]
+    long long cur_task_stride;
+    float* next;                    // [tasks][Theta]
+    float* lam;                     // [tasks][Theta]
+    float* v;                       // [tasks][Theta]
+    float* scal;                    // [tasks][2]
+    unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
+};
+
+struct ChainLds {
+    int w1, w2, w3, w3b, b1, b2, b3, dist;   // inside one network block
+    int net_stride;
+    int flag;                                // one int: "this workgroup arrived last"
+    int wave0, wave_stride, tb0, tb1, db0, db1;
+    int total;
+};
+
+// dist block of the theta network: 6 x 8 floats
+enum { CH_LS = 0, CH_ES = 8, CH_SN2 = 16, CH_LMASK = 24, CH_VLS = 32, CH_RDEN = 40 };
+
+PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP) {
+    ChainLds L{};
+    int o = 4;                    // [0, 4): flag
+    L.flag = 0;
+    int n = 0;
+    L.w1 = n;  n += NC1 * 512;                      // [c][t4][lane][4]: W1[4 (4 t4 + r) + kk][16 c + i16], obs padded to 32
+    L.w2 = n;  n += NC2 * NC1 * PROMP_CH_BLK;       // [c2][c1][kk][i16][r]: W2[16 c1 + 4 kk + r][16 c2 + i16]
+    L.w3 = n;  n += NC2 * 256;                      // [c][lane][r]: W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
+    L.w3b = n; n += NC2 * 128;                      // [c][lane][ro]: W3[16 c + i16][2 kk + ro]
+    L.b1 = n;  n += 16 * NC1;
+    L.b2 = n;  n += 16 * NC2;
+    L.b3 = n;  n += 8;
+    L.dist = n; n += 48;
+    L.net_stride = n;
+    o += (hvp ? 2 : 1) * n;
+    L.wave0 = o;
+    int q = 0;
+    L.tb0 = q; q += 16 * PROMP_CH_TS;
+    L.tb1 = q; q += 16 * PROMP_CH_TS;
+    L.db0 = q; q += 16 * PROMP_CH_DS;
+    L.db1 = q; q += hvp ? 16 * PROMP_CH_DS : 0;
+    L.wave_stride = q;
+    o += nwaves * q;
+    {   // end-of-segment: one slab of [NP + 2] floats per wave, from offset 4 (aliases everything else)
+        const int need = 4 + nwaves * ((NP + 2 + 3) & ~3);
+        if (o < need) o = need;
+    }
+    L.total = o;
+    return L;
+}
+
+// developer tooling: cycle stamps of workgroup 0 / thread 0 (compiled in only with -DPROMP_DEV_STAMPS, tools/phase_timing.py)
+#ifdef PROMP_DEV_STAMPS
+#define CH_STAMP(i) do { if (a.dbg != nullptr && blockIdx.x == 0 && tid == 0) a.dbg[(i)] = promp_clock(); } while (0)
+#define CH_TSTAMP(j) CH_STAMP(8 + 16 * (tix < 3 ? tix : 3) + (j))
+// every workgroup: wall clock (100 MHz, chip-wide) when it starts / ends, and its XCC id
+#define CH_WGSTAMP(j) do { if (a.dbg != nullptr && tid == 0) a.dbg[256 + 4 * blockIdx.x + (j)] = promp_wall_clock(); } while (0)
+#define PROMP_STAMPS_ON 1
+#else
+#define CH_STAMP(i) do { } while (0)
+#define CH_TSTAMP(j) do { } while (0)
+#define CH_WGSTAMP(j) do { } while (0)
+#define PROMP_STAMPS_ON 0
+#endif
+
+PROMP_DEV f32x4 splat4(float v) {
+    f32x4 z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = v;
+    return z;
+}
+PROMP_DEV f32x4 lds4(const float* p) { return *(const f32x4*)p; }
+PROMP_DEV f32x2 lds2(const float* p) { return *(const f32x2*)p; }
+PROMP_DEV void sts4(float* p, f32x4 v) { *(f32x4*)p = v; }
+PROMP_DEV void sts2(float* p, f32x2 v) { *(f32x2*)p = v; }
+
+// The networks of a segment (theta, and for the R-operator pass the direction, negated) -> fragment order in LDS.
+// All global loads of all regions of all networks are issued before the first LDS store: the staging costs ONE round trip
+// to L2 / memory (the parameters were written by another CU's reduction moments ago and are nowhere near this CU).
+// Invalid elements (padding) load a clamped valid weight and are multiplied by a zero mask: a select on the loaded value
+// would be turned back into an exec-masked branch around the load and serialise the loads.
+template <int NC1, int NC2, int NT, int NNETS>
+PROMP_DEV void chain_stage_nets(float* blk0, const float* src0, const float* src1, int O, int A, int tid_) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2;
+    constexpr ChainLds L = chain_layout(NC1, NC2, 1, false, 0);
+    constexpr int N1 = NC1 * 512, N2 = NC1 * NC2 * 256, N3 = NC2 * 256, N4 = NC2 * 128, N5 = H1 + H2 + 8;
+    constexpr int E1 = N1, E2 = E1 + N2, E3 = E2 + N3, E4 = E3 + N4, NTOT = E4 + N5, IT = (NTOT + NT - 1) / NT;
+    const int tid = tid_ + opaque_zero();      // (keeps the index arithmetic inside the segment loop: hoisted, it would occupy registers for the whole kernel)
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
+    float r[NNETS][IT];
+    int off[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = tid + i * NT;
+        int idx = 0;
+        float m = 0.f;
+        off[i] = -1;
+        if (e < E1) {
+            const int d = e, c = d >> 9, t4 = (d >> 8) & 1, l = (d >> 2) & 63, rr = d & 3;
+            const int o = 4 * (4 * t4 + rr) + (l >> 4);
+            off[i] = L.w1 + d;
+            idx = (o < O ? o : O - 1) * H1 + 16 * c + (l & 15);
+            m = o < O ? 1.f : 0.f;
+        } else if (e < E2) {                       // (the 4 pad floats of a fragment row are never read)
+            const int d = e - E1, b = d >> 8, kk = (d >> 6) & 3, jl = (d >> 2) & 15, rr = d & 3;
+            const int c2 = b / NC1, c1 = b - c2 * NC1;
+            off[i] = L.w2 + b * PROMP_CH_BLK + kk * PROMP_CH_ROW + jl * 4 + rr;
+            idx = oW2 + (16 * c1 + 4 * kk + rr) * H2 + 16 * c2 + jl;
+            m = 1.f;
+        } else if (e < E3) {
+            const int d = e - E2, c = d >> 8, l = (d >> 2) & 63, rr = d & 3;
+            const int mm = l & 15, ro = mm & 3, aa = 2 * (mm >> 2) + ro;
+            off[i] = L.w3 + d;
+            idx = oW3 + (16 * c + 4 * (l >> 4) + rr) * A + (aa < A ? aa : A - 1);
+            m = (ro < 2 && aa < A) ? 1.f : 0.f;
+        } else if (e < E4) {
+            const int d = e - E3, c = d >> 7, l = (d >> 1) & 63, ro = d & 1;
+            const int aa = 2 * (l >> 4) + ro;
+            off[i] = L.w3b + d;
+            idx = oW3 + (16 * c + (l & 15)) * A + (aa < A ? aa : A - 1);
+            m = aa < A ? 1.f : 0.f;
+        } else if (e < NTOT) {
+            const int d = e - E4;
+            if (d < H1) {
+                off[i] = L.b1 + d;
+                idx = ob1 + d;
+                m = 1.f;
+            } else if (d < H1 + H2) {
+                off[i] = L.b2 + d - H1;
+                idx = ob2 + d - H1;
+                m = 1.f;
+            } else {
+                const int aa = d - H1 - H2;
+                off[i] = L.b3 + aa;
+                idx = ob3 + (aa < A ? aa : A - 1);
+                m = aa < A ? 1.f : 0.f;
+            }
+        }
+        r[0][i] = src0[idx] * m;
+        if (NNETS > 1) r[NNETS - 1][i] = src1[idx] * -m;
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        if (off[i] >= 0) {
+            blk0[off[i]] = r[0][i];
+            if (NNETS > 1) blk0[L.net_stride + off[i]] = r[NNETS - 1][i];
+        }
+}
+
+// distribution constants of the theta network: s (clipped), exp(-s), exp(2 s), gradient mask, R{s}, 1 / (2 exp(2 s) + 1e-8)
+PROMP_DEV void chain_stage_dist(float* dist, const float* th, const float* v, int oS, int A, int clip_log_std, float min_log_std,
+                                int tid) {
+    if (tid < 8) {
+        const float sr = (tid < A) ? th[oS + tid] : 0.f;
+        const bool clipped = clip_log_std && (sr < min_log_std);   // tf.maximum: gradient iff var >= min
+        const float s = clipped ? min_log_std : sr;
+        const float sn2 = expf(2.f * s);
+        dist[CH_LS + tid] = s;
+        dist[CH_ES + tid] = expf(-s);
+        dist[CH_SN2 + tid] = sn2;
+        dist[CH_LMASK + tid] = clipped ? 0.f : 1.f;
+        dist[CH_VLS + tid] = (v != nullptr && tid < A && !clipped) ? -v[oS + tid] : 0.f;   // tangent along -v
+        dist[CH_RDEN + tid] = fast_rcp(2.f * sn2 + 1e-8f);      // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
+    }
+}
+
+// Observation tile in the two operand orientations.  Invalid rows / columns read as 0.
+//   xT[t] = X[row i16][col 4 t + kk]           (B operand of layer 1; k-step t)
+//   xN[ob][t] = X[row 4 kk + t][col 16 ob + i16]   (A operand of the hidden_0 gradient; k-step t <-> sample 4 kk + t)
+template <int KS>
+PROMP_DEV void chain_load_xT(float (&xT)[KS], const float* obs, long long row0, int nvalid, int O, int i16, int kk) {
+    const bool rv = i16 < nvalid;
+    const float* src = obs + (row0 + (rv ? i16 : 0)) * O;
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        const int o = 4 * t + kk;
+        const bool ok = rv && o < O;
+        // always a valid address, and a multiplicative mask: a select on the loaded value would come back as an exec-masked
+        // branch around the load and the loads of a tile would no longer be in flight together
+        xT[t] = src[ok ? o : 0] * (ok ? 1.f : 0.f);
+    }
+}
+template <int NOB>
+PROMP_DEV void chain_load_xN(float (&xN)[NOB][4], const float* obs, long long row0, int nvalid, int O, int i16, int kk) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = 4 * kk + t, o = 16 * ob + i16;
+            const bool ok = r < nvalid && o < O;
+            xN[ob][t] = obs[ok ? (row0 + r) * O + o : row0 * O] * (ok ? 1.f : 0.f);
+        }
+}
+
+PROMP_DEV f32x4 tanh4(f32x4 z) {
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = fast_tanh(z[r]);
+    return h;
+}
+
+// Cross-wave, fixed-order sum of the waves' gradient tiles -> one partial row in global memory.
+// Every wave stores its tiles to its own LDS slab of [NP + 2] floats (plain stores, every entry written exactly once);
+// then all threads add the slabs in wave order.  (NW x [NP + 2] floats alias the parameter / transpose regions.)
+template <int NC1, int NC2, int NOB, int NW>
+PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC1][NC2], const f32x4 (&aw1)[NOB][NC1],
+                                       const f32x4 (&aw3)[NC2], const float (&gb1)[NC1], const float (&gb2)[NC2], float gs0,
+                                       float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
+    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
+    const int SL = (NP + 2 + 3) & ~3;
+    lds_barrier();                // every wave is done with the parameter / transpose regions
+    {
+        float* mine = S + w * SL;
+#pragma unroll
+        for (int i = 0; i < NC1; ++i)
+#pragma unroll
+            for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[oW2 + (16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+#pragma unroll
+        for (int i = 0; i < NOB; ++i)
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * kk + r;
+                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
+                }
+#pragma unroll
+        for (int j = 0; j < NC2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (i16 < A) mine[oW3 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][r];
+        if (kk == 0) {
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) mine[ob2 + 16 * j + i16] = gb2[j];
+        }
+        if (i16 == 0) {           // lane (0, kk) holds the sums of actions 2 kk, 2 kk + 1
+            if (2 * kk < A) {
+                mine[ob3 + 2 * kk] = gb30;
+                mine[oS + 2 * kk] = gs0;
+            }
+            if (2 * kk + 1 < A) {
+                mine[ob3 + 2 * kk + 1] = gb31;
+                mine[oS + 2 * kk + 1] = gs1;
+            }
+        }
+        if (lane == 0) {
+            mine[NP] = loss;
+            mine[NP + 1] = klsum;
+        }
+    }
+    lds_barrier();
+#pragma unroll 4
+    for (int e = tid; e < NP + 2; e += NT) {
+        float v[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SL + e];      // all slab reads in flight together
+        float t = v[0];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) t += v[ww];
+        P[e] = t;
+    }
+}
+
+// Sum of a task's partial rows in slot order + the update that consumes it.
+struct TaskRedArgs {
+    const float* partials;
+    int partial_stride, s0, s1, NP, mode, task;
+    const float* step_sizes;
+    const float* cur;
+    long long cur_task_stride;
+    float *next, *lam, *v, *scal;
+};
+template <int NT>
+PROMP_DEV void chain_task_sum(TaskRedArgs r, int tid) {
+    const int NP = r.NP, mode = r.mode, task = r.task;
+    // 4 columns per thread and up to 8 rows per round in flight: the rows live in other CUs' L2 lines, so the sum is
+    // paced by how many loads are outstanding, not by arithmetic
+    const int jbeg = (mode == RED_SCAL) ? NP : 0;
+    for (int j0 = jbeg + tid; j0 < NP + 2; j0 += 4 * NT) {
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sb = r.s0; sb < r.s1; sb += 8) {
+            float x[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * NT;
+                    const bool ok = sb + q < r.s1 && j < NP + 2;
+                    // clamped to a row / column of this task (all written: every workgroup has arrived) and masked by a
+                    // multiplication, so that the loads stay unconditional and in flight together
+                    const int sq = sb + q < r.s1 ? sb + q : r.s1 - 1, jc = j < NP + 2 ? j : NP + 1;
+                    x[q][u] = r.partials[sq * r.partial_stride + jc] * (ok ? 1.f : 0.f);
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g[u] += x[q][u];       // slot order within a column: fixed
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * NT;
+            if (j >= NP + 2) continue;
+            if (j >= NP) {
+                r.scal[task * 2 + (j - NP)] = g[u];
+                continue;
+            }
+            const long long tj = (long long)task * NP + j;
+            if (mode == RED_STEP) {
+                r.next[tj] = r.cur[(long long)task * r.cur_task_stride + j] - r.step_sizes[j] * g[u];
+                continue;
+            }
+            float lam = g[u];
+            if (mode == RED_HVP) lam += r.lam[tj];
+            r.lam[tj] = lam;
+            if (mode == RED_PLAIN) continue;
+            r.v[tj] = r.step_sizes[j] * lam;
+        }
+    }
+}
+
+// The workgroup has written a partial row of `task`.  Whichever workgroup of the task arrives last adds the task's
+// rows in slot order (bitwise reproducible whatever the arrival order) and applies the update that consumes the sum.
+template <int NT>
+PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP, int tid) {
+    const int s0 = a.task_slot_offsets[task], s1 = a.task_slot_offsets[task + 1];
+    __syncthreads();                                   // all of this workgroup's partial stores are issued
+    if (tid == 0) {
+        fence_release_agent();
+        const int old = atomic_add_agent(a.task_counters + task, 1);
+        const int last = (old == s1 - s0 - 1) ? 1 : 0;
+        if (last) {
+            atomic_store_agent(a.task_counters + task, 0);   // ready for the next launch
+            fence_acquire_agent();
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();                                   // flag may be rewritten by the next segment
+    if (!last) return;
+    TaskRedArgs r;
+    r.partials = a.partials; r.partial_stride = a.partial_stride; r.s0 = s0; r.s1 = s1; r.NP = NP; r.mode = a.red_mode; r.task = task;
+    r.step_sizes = a.step_sizes; r.cur = a.cur; r.cur_task_stride = a.cur_task_stride;
+    r.next = a.next; r.lam = a.lam; r.v = a.v; r.scal = a.scal;
+    chain_task_sum<NT>(r, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_hvp:  out = -(d^2 L/d theta^2) v + kl_weight * grad KL   (R-operator, see oracle/promp.py:hvp)
+//
+// The direction is staged NEGATED, so every tangent below is the derivative along -v ("R'"): the reverse-pass
+// quantities q = R'{.} + kl_weight * dKL{.} then need no operand negation anywhere (MFMA has no negate modifier for
+// f32 operands).  theta and -v are both staged in fragment order (2 x 32.5 KB at 64/64).
+// ---------------------------------------------------------------------------------------------
+template <int NC1, int NC2, int KS, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
+    constexpr int NT = 64 * NW, H1 = 16 * NC1, H2 = 16 * NC2, TS = PROMP_CH_TS, DS = PROMP_CH_DS, NOB = KS > 4 ? 2 : 1;
+    constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0);
+    PROMP_SMEM_DECL;
+    float* sm = (float*)PROMP_SMEM_PTR;
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int O = a.O, A = a.A;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
+    float* net = sm + 4;
+    float* vnet = net + L.net_stride;
+    constexpr int VO = L.net_stride;                  // the -v fragments sit at the same offsets, one block further
+    float* wreg = sm + L.wave0 + w * L.wave_stride;
+    float *TB0 = wreg + L.tb0, *TB1 = wreg + L.tb1, *DB0 = wreg + L.db0, *DB1 = wreg + L.db1;
+    const float* W1l = net + L.w1 + lane * 4;
+    const float* W2l = net + L.w2 + kk * PROMP_CH_ROW + i16 * 4;
+    const float* W2b = net + L.w2 + (i16 >> 2) * PROMP_CH_ROW + (i16 & 3) + 16 * kk;
+    const float* W3l = net + L.w3 + lane * 4;
+    const float* W3b = net + L.w3b + lane * 2;
+    const float *B1l = net + L.b1 + 4 * kk, *B2l = net + L.b2 + 4 * kk, *B3l = net + L.b3 + 2 * kk;
+    float* TB0w = TB0 + i16 * TS + 4 * kk;
+    float* TB1w = TB1 + i16 * TS + 4 * kk;
+    const float* TB0r = TB0 + kk * 4 * TS + i16;
+    const float* TB1r = TB1 + kk * 4 * TS + i16;
+    float* DB0w = DB0 + i16 * DS + 2 * kk;
+    float* DB1w = DB1 + i16 * DS + 2 * kk;
+    const float* DB0r = DB0 + kk * 4 * DS + i16;
+    const float* DB1r = DB1 + kk * 4 * DS + i16;
+    const int a0 = 2 * kk, a1 = 2 * kk + 1;
+    const bool own0 = a0 < A, own1 = a1 < A;
+    const int q0 = own0 ? a0 : 0, q1 = own1 ? a1 : 0;
+    const float klw = a.kl_weight;
+
+    const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
+    CH_WGSTAMP(0);
+    for (int sg = sg0; sg < sg1; ++sg) {
+        const ChainSeg seg = a.segs[sg];
+        const int task = seg.task;
+        const int trow0 = a.task_row_offsets[task], tnrows = a.task_row_offsets[task + 1] - trow0;
+        const float invN = 1.0f / (float)tnrows;
+        const float* th = a.theta + (long long)task * a.theta_task_stride;
+        const float* v = a.vdir + (long long)task * NP;
+        __syncthreads();
+        CH_STAMP(0);
+        chain_stage_nets<NC1, NC2, NT, 2>(net, th, v, O, A, tid);
+        CH_STAMP(5);
+        chain_stage_dist(net + L.dist, th, v, oS, A, a.clip_log_std, a.min_log_std, tid);
+        CH_STAMP(6);
+        for (int e = lane; e < L.wave_stride; e += 64) wreg[e] = 0.f;
+        CH_STAMP(7);
+        __syncthreads();
+        CH_STAMP(1);
+        const float* dist = net + L.dist;
+        const float s0 = dist[CH_LS + q0], s1 = dist[CH_LS + q1], e0 = dist[CH_ES + q0], e1 = dist[CH_ES + q1];
+        const float sn20 = dist[CH_SN2 + q0], sn21 = dist[CH_SN2 + q1], rden0 = dist[CH_RDEN + q0], rden1 = dist[CH_RDEN + q1];
+        const float Rs0 = dist[CH_VLS + q0], Rs1 = dist[CH_VLS + q1];       // R'{s}
+
+        f32x4 aw2[NC1][NC2], aw1[NOB][NC1], aw3[NC2];
+#pragma unroll
+        for (int i = 0; i < NC1; ++i)
+#pragma unroll
+            for (int j = 0; j < NC2; ++j) aw2[i][j] = zero4();
+#pragma unroll
+        for (int i = 0; i < NOB; ++i)
+#pragma unroll
+            for (int j = 0; j < NC1; ++j) aw1[i][j] = zero4();
+#pragma unroll
+        for (int j = 0; j < NC2; ++j) aw3[j] = zero4();
+        float ob1acc[NC1], ob2acc[NC2];
+#pragma unroll
+        for (int j = 0; j < NC1; ++j) ob1acc[j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC2; ++j) ob2acc[j] = 0.f;
+        float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
+
+        const int tend = seg.tile0 + seg.ntiles;
+        float xT[KS];
+        {
+            const int t = seg.tile0 + w;
+            const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
+            chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
+        }
+        int tix = 0;
+        for (int t = seg.tile0 + w; t < tend; t += NW, ++tix) {
+            CH_TSTAMP(0);
+            const int nrows = (tnrows - 16 * t) < 16 ? (tnrows - 16 * t) : 16;
+            const long long base = (long long)trow0 + 16 * t;
+            const bool rvalid = i16 < nrows;
+            const long long n = base + (rvalid ? i16 : 0);
+            const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
+            const float advn = rvalid ? a.adv[n] : 0.f;
+            const float ac0 = a.act[n * A + q0], ac1 = a.act[n * A + q1];
+            const float mo0 = a.old_mean[n * A + q0], mo1 = a.old_mean[n * A + q1];
+            const float so0 = olsp[q0], so1 = olsp[q1];
+
+            // ---- layer 1 and its tangent:  R'z1 = X (-vW1) + (-vb1)
+            f32x4 h1[NC1], rh1[NC1];
+            {
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) {
+                    h1[c] = lds4(B1l + 16 * c);
+                    rh1[c] = lds4(B1l + VO + 16 * c);
+                }
+#pragma unroll
+                for (int t4 = 0; t4 < NOB; ++t4) {
+                    f32x4 wf[NC1], vf[NC1];
+#pragma unroll
+                    for (int c = 0; c < NC1; ++c) {
+                        wf[c] = lds4(W1l + (2 * c + t4) * 256);
+                        vf[c] = lds4(W1l + VO + (2 * c + t4) * 256);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * t4 + r < KS) {
+#pragma unroll
+                            for (int c = 0; c < NC1; ++c) h1[c] = mfma16(wf[c][r], xT[4 * t4 + r], h1[c]);
+#pragma unroll
+                            for (int c = 0; c < NC1; ++c) rh1[c] = mfma16(vf[c][r], xT[4 * t4 + r], rh1[c]);
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < NC1; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h = fast_tanh(h1[c][r]);
+                        h1[c][r] = h;
+                        rh1[c][r] *= (1.f - h * h);
+                    }
+            }
+            {
+                const int tn = t + NW;
+                const int nv = (tn < tend) ? (tnrows - 16 * tn < 16 ? tnrows - 16 * tn : 16) : 0;
+                chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (tn < tend ? 16 * tn : 0), nv, O, i16, kk);
+            }
+            CH_TSTAMP(1);
+            // ---- layer 2 and its tangent:  R'z2 = W2^T R'H1 + (-vW2)^T H1 + (-vb2)
+            f32x4 h2[NC2], rh2[NC2];
+            {
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) {
+                    h2[c] = lds4(B2l + 16 * c);
+                    rh2[c] = lds4(B2l + VO + 16 * c);
+                }
+#pragma unroll
+                for (int c1 = 0; c1 < NC1; ++c1) {
+                    f32x4 wf[NC2], vf[NC2];
+#pragma unroll
+                    for (int c2 = 0; c2 < NC2; ++c2) {
+                        wf[c2] = lds4(W2l + (c2 * NC1 + c1) * PROMP_CH_BLK);
+                        vf[c2] = lds4(W2l + VO + (c2 * NC1 + c1) * PROMP_CH_BLK);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int c2 = 0; c2 < NC2; ++c2) h2[c2] = mfma16(wf[c2][r], h1[c1][r], h2[c2]);
+#pragma unroll
+                        for (int c2 = 0; c2 < NC2; ++c2) rh2[c2] = mfma16(wf[c2][r], rh1[c1][r], rh2[c2]);
+#pragma unroll
+                        for (int c2 = 0; c2 < NC2; ++c2) rh2[c2] = mfma16(vf[c2][r], h1[c1][r], rh2[c2]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h = fast_tanh(h2[c][r]);
+                        h2[c][r] = h;
+                        rh2[c][r] *= (1.f - h * h);
+                    }
+            }
+            CH_TSTAMP(2);
+            wave_fence();         // the previous tile's reads of TB0 / TB1 precede these writes
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) {
+                sts4(TB0w + 16 * c, rh2[c]);
+                sts4(TB1w + 16 * c, h2[c]);
+            }
+            // ---- output layer and its tangent:  R'mu = W3^T R'H2 + (-vW3)^T H2 + (-vb3)
+            float mu0, mu1, Rmu0, Rmu1;
+            {
+                f32x4 m0 = zero4(), m1 = zero4(), ra0 = zero4(), ra1 = zero4(), rb0 = zero4(), rb1 = zero4();
+                const f32x2 bb = lds2(B3l), vb = lds2(B3l + VO);
+                m0[0] = bb[0];
+                m0[1] = bb[1];
+                ra0[0] = vb[0];
+                ra0[1] = vb[1];
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) {
+                    const f32x4 wf = lds4(W3l + c * 256), vf = lds4(W3l + VO + c * 256);
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        m0 = mfma16(wf[r], h2[c][r], m0);
+                        ra0 = mfma16(wf[r], rh2[c][r], ra0);
+                        rb0 = mfma16(vf[r], h2[c][r], rb0);
+                        m1 = mfma16(wf[r + 1], h2[c][r + 1], m1);
+                        ra1 = mfma16(wf[r + 1], rh2[c][r + 1], ra1);
+                        rb1 = mfma16(vf[r + 1], h2[c][r + 1], rb1);
+                    }
+                }
+                mu0 = m0[0] + m1[0];
+                mu1 = m0[1] + m1[1];
+                Rmu0 = (ra0[0] + ra1[0]) + (rb0[0] + rb1[0]);
+                Rmu1 = (ra0[1] + ra1[1]) + (rb0[1] + rb1[1]);
+            }
+            CH_TSTAMP(3);
+            // ---- loss-level R-operator: lane (i16, kk) = sample i16, actions 2 kk and 2 kk + 1
+            float d0, d1, qm0, qm1;
+            {
+                const float z0 = (ac0 - mu0) * e0, z1 = (ac1 - mu1) * e1;
+                const float zo0 = (ac0 - mo0) * fast_exp(-so0), zo1 = (ac1 - mo1) * fast_exp(-so1);
+                const float num0 = (mo0 - mu0) * (mo0 - mu0) + fast_exp(2.f * so0) - sn20;
+                const float num1 = (mo1 - mu1) * (mo1 - mu1) + fast_exp(2.f * so1) - sn21;
+                const float den0 = 2.f * sn20 + 1e-8f, den1 = 2.f * sn21 + 1e-8f;
+                float dlp = (own0 ? (so0 - s0) - 0.5f * (z0 * z0 - zo0 * zo0) : 0.f) + (own1 ? (so1 - s1) - 0.5f * (z1 * z1 - zo1 * zo1) : 0.f);
+                float Rlp = (own0 ? z0 * e0 * Rmu0 + (z0 * z0 - 1.f) * Rs0 : 0.f) + (own1 ? z1 * e1 * Rmu1 + (z1 * z1 - 1.f) * Rs1 : 0.f);
+                float kl = (own0 ? num0 * rden0 + s0 - so0 : 0.f) + (own1 ? num1 * rden1 + s1 - so1 : 0.f);
+                dlp += shfl_xor_f32(dlp, 16);  dlp += shfl_xor_f32(dlp, 32);
+                Rlp += shfl_xor_f32(Rlp, 16);  Rlp += shfl_xor_f32(Rlp, 32);
+                kl += shfl_xor_f32(kl, 16);    kl += shfl_xor_f32(kl, 32);
+                float c = 0.f, Rc = 0.f, km = 0.f;
+                if (rvalid) {
+                    km = 1.f;
+                    if (a.loss_kind == LOSS_RATIO) {
+                        c = -advn * expf(dlp) * invN;
+                        Rc = c * Rlp;
+                    } else {
+                        c = -advn * invN;
+                    }
+                    if (kk == 0) klsum += kl * invN;
+                }
+                const float dklm0 = -2.f * (mo0 - mu0) * rden0 * invN, dklm1 = -2.f * (mo1 - mu1) * rden1 * invN;
+                const float dkls0 = ((-2.f * sn20 * den0 - 4.f * num0 * sn20) * (rden0 * rden0) + 1.f) * invN;
+                const float dkls1 = ((-2.f * sn21 * den1 - 4.f * num1 * sn21) * (rden1 * rden1) + 1.f) * invN;
+                {
+                    const float Rz = -Rmu0 * e0 - z0 * Rs0;
+                    const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
+                    const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
+                    d0 = own0 ? c * z0 * e0 : 0.f;
+                    qm0 = own0 ? km * (Rd + klw * dklm0) : 0.f;
+                    outs0 += own0 ? km * (Rds + klw * dkls0) : 0.f;
+                    outb30 += qm0;
+                }
+                {
+                    const float Rz = -Rmu1 * e1 - z1 * Rs1;
+                    const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
+                    const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
+                    d1 = own1 ? c * z1 * e1 : 0.f;
+                    qm1 = own1 ? km * (Rd + klw * dklm1) : 0.f;
+                    outs1 += own1 ? km * (Rds + klw * dkls1) : 0.f;
+                    outb31 += qm1;
+                }
+            }
+            CH_TSTAMP(4);
+            {
+                f32x2 dd, qq;
+                dd[0] = d0;  dd[1] = d1;
+                qq[0] = qm0; qq[1] = qm1;
+                sts2(DB0w, dd);
+                sts2(DB1w, qq);
+            }
+            wave_fence();
+            // ---- out_W3 += R'H2^T dmu + H2^T qmu
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const float bd = DB0r[t4 * DS], bq = DB1r[t4 * DS];
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) aw3[c] = mfma16(TB0r[t4 * TS + 16 * c], bd, aw3[c]);
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) aw3[c] = mfma16(TB1r[t4 * TS + 16 * c], bq, aw3[c]);
+            }
+            CH_TSTAMP(5);
+            // ---- dZ2, qZ2 (transposed): ad = W3 dmu^T, aq = W3 qmu^T + (-vW3) dmu^T
+            f32x4 dz2[NC2], qz2[NC2];
+            {
+                f32x2 wb[NC2], vb[NC2];
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) {
+                    wb[c] = lds2(W3b + c * 128);
+                    vb[c] = lds2(W3b + VO + c * 128);
+                    dz2[c] = zero4();
+                    qz2[c] = zero4();
+                }
+#pragma unroll
+                for (int ro = 0; ro < 2; ++ro) {
+                    const float dd = ro ? d1 : d0, qq = ro ? qm1 : qm0;
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) dz2[c] = mfma16(wb[c][ro], dd, dz2[c]);
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) qz2[c] = mfma16(wb[c][ro], qq, qz2[c]);
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) qz2[c] = mfma16(vb[c][ro], dd, qz2[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < NC2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h = h2[c][r], dd1 = 1.f - h * h, ad = dz2[c][r];
+                        qz2[c][r] = qz2[c][r] * dd1 - 2.f * ad * h * rh2[c][r];
+                        dz2[c][r] = ad * dd1;
+                    }
+            }
+            CH_TSTAMP(6);
+            // ---- out_W2 += R'H1^T dZ2 + H1^T qZ2 (two rounds through the transpose tiles); out_b2 += sum qZ2
+            wave_fence();
+#pragma unroll
+            for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, rh1[c]);
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) sts4(TB1w + 16 * c, dz2[c]);
+            wave_fence();
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                float aop[NC1], bop[NC2];
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) aop[c] = TB0r[t4 * TS + 16 * c];
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) bop[c] = TB1r[t4 * TS + 16 * c];
+#pragma unroll
+                for (int i = 0; i < NC1; ++i)
+#pragma unroll
+                    for (int j = 0; j < NC2; ++j) aw2[i][j] = mfma16(aop[i], bop[j], aw2[i][j]);
+            }
+            wave_fence();
+#pragma unroll
+            for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, h1[c]);
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) sts4(TB1w + 16 * c, qz2[c]);
+            wave_fence();
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                float aop[NC1], bop[NC2];
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) aop[c] = TB0r[t4 * TS + 16 * c];
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) {
+                    bop[c] = TB1r[t4 * TS + 16 * c];
+                    ob2acc[c] += bop[c];
+                }
+#pragma unroll
+                for (int i = 0; i < NC1; ++i)
+#pragma unroll
+                    for (int j = 0; j < NC2; ++j) aw2[i][j] = mfma16(aop[i], bop[j], aw2[i][j]);
+            }
+            CH_TSTAMP(7);
+            float xN[NOB][4];
+            chain_load_xN<NOB>(xN, a.obs, base, nrows, O, i16, kk);           // (needed after the next 48 NC1 NC2 MFMAs)
+            // ---- qZ1 (transposed): ad = W2 dZ2^T, aq = W2 qZ2^T + (-vW2) dZ2^T
+            f32x4 qz1[NC1];
+            {
+                f32x4 ad1[NC1];
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) {
+                    ad1[c] = zero4();
+                    qz1[c] = zero4();
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < NC2; ++c2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float wb[NC1], vb[NC1];
+#pragma unroll
+                        for (int c1 = 0; c1 < NC1; ++c1) {
+                            wb[c1] = W2b[(c2 * NC1 + c1) * PROMP_CH_BLK + 4 * r];
+                            vb[c1] = W2b[VO + (c2 * NC1 + c1) * PROMP_CH_BLK + 4 * r];
+                        }
+#pragma unroll
+                        for (int c1 = 0; c1 < NC1; ++c1) ad1[c1] = mfma16(wb[c1], dz2[c2][r], ad1[c1]);
+#pragma unroll
+                        for (int c1 = 0; c1 < NC1; ++c1) qz1[c1] = mfma16(wb[c1], qz2[c2][r], qz1[c1]);
+#pragma unroll
+                        for (int c1 = 0; c1 < NC1; ++c1) qz1[c1] = mfma16(vb[c1], dz2[c2][r], qz1[c1]);
+                    }
+#pragma unroll
+                for (int c = 0; c < NC1; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h = h1[c][r];
+                        qz1[c][r] = qz1[c][r] * (1.f - h * h) - 2.f * ad1[c][r] * h * rh1[c][r];
+                    }
+            }
+            CH_TSTAMP(8);
+            wave_fence();
+#pragma unroll
+            for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, qz1[c]);
+            wave_fence();
+            // ---- out_W1 += X^T qZ1 ; out_b1 += sum qZ1
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                float bop[NC1];
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) {
+                    bop[c] = TB0r[t4 * TS + 16 * c];
+                    ob1acc[c] += bop[c];
+                }
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int c = 0; c < NC1; ++c) aw1[ob][c] = mfma16(xN[ob][t4], bop[c], aw1[ob][c]);
+            }
+            CH_TSTAMP(9);
+        }
+        CH_STAMP(2);
+
+#pragma unroll
+        for (int m = 1; m <= 8; m <<= 1) {
+            outs0 += shfl_xor_f32(outs0, m);  outs1 += shfl_xor_f32(outs1, m);  outb30 += shfl_xor_f32(outb30, m);
+            outb31 += shfl_xor_f32(outb31, m);  klsum += shfl_xor_f32(klsum, m);
+        }
+#pragma unroll
+        for (int j = 0; j < NC1; ++j) {
+            ob1acc[j] += shfl_xor_f32(ob1acc[j], 16);
+            ob1acc[j] += shfl_xor_f32(ob1acc[j], 32);
+        }
+#pragma unroll
+        for (int j = 0; j < NC2; ++j) {
+            ob2acc[j] += shfl_xor_f32(ob2acc[j], 16);
+            ob2acc[j] += shfl_xor_f32(ob2acc[j], 32);
+        }
+        outs0 *= dist[CH_LMASK + q0];
+        outs1 *= dist[CH_LMASK + q1];
+        float* P = a.partials + (long long)sg * a.partial_stride;
+        chain_reduce_to_partial<NC1, NC2, NOB, NW>(sm + 4, P, aw2, aw1, aw3, ob1acc, ob2acc, outs0, outs1, outb30, outb31, 0.f, klsum, O, A, tid);
+        CH_STAMP(3);
+        chain_task_reduce<NT>(a, (int*)sm, task, NP, tid);
+        CH_STAMP(4);
+        CH_WGSTAMP(1 + (sg - sg0 < 2 ? sg - sg0 : 1));
+    }
+}

@@ -22,7 +22,9 @@
 #include <vector>
 
 #define PROMP_DEV inline
+#define PROMP_DEV_NOINLINE inline
 #define PROMP_HD inline
+#define PROMP_CX constexpr
 #define __global__
 #define __device__
 #define __host__
@@ -36,6 +38,7 @@ struct dim3 {
 
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x2 __attribute__((vector_size(8)));
 typedef double f64x4 __attribute__((vector_size(32)));
 
 namespace emu {
@@ -176,8 +179,15 @@ inline double shfl_xor_f64(double v, int m) { return emu_shfl_f64(v, emu::lane()
 inline double shfl_down_f64(double v, int d) { return emu_shfl_f64(v, emu::lane() + d); }
 inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
 inline void wave_sync() { emu::wave().bar.arrive_and_wait(); }
+inline void lds_barrier() { emu::tl.blk->bar.arrive_and_wait(); }
+inline void wave_fence() { emu::wave().bar.arrive_and_wait(); }
+inline void fence_release_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void fence_acquire_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline void atomic_store_agent(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline void sched_fence() {}
 inline int opaque_zero() { return 0; }
+inline f32x4 pin_agpr(f32x4 v) { return v; }
 inline int wave_uniform(int v) { return v; }
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }

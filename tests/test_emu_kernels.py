@@ -51,6 +51,18 @@ def test_loss_grad_clipped_log_std(lib):
     pc.check_loss_grad(lib, 9, M=2, P=2, T=20, O=4, A=3, hidden=(32, 32), low_log_std=True)
 
 
+def test_unequal_hidden_widths(lib):
+    pc.check_loss_grad(lib, 15, M=1, P=2, T=40, O=6, A=3, hidden=(32, 64))
+    pc.check_hvp(lib, 16, M=1, P=2, T=40, O=6, A=3, hidden=(64, 32))
+
+
+def test_hvp_segments_straddling_tasks(lib, monkeypatch):
+    # 3 tasks x ~12 tiles on 2 emulated CUs: the round list is cut into two shares, so a workgroup of k_chain_hvp walks
+    # segments of two (or all three) tasks one after the other and is the last arriver for some of them
+    monkeypatch.setenv('PROMP_EMU_CUS', '2')
+    pc.check_hvp(lib, 17, M=3, P=2, T=100, O=20, A=6, hidden=(64, 64), ragged=True)
+
+
 def test_hvp_h64(lib):
     pc.check_hvp(lib, 10, M=2, P=2, T=37, O=20, A=6, hidden=(64, 64))
 

@@ -58,6 +58,20 @@ def test_loss_grad(lib, hidden, O, A):
     pc.check_loss_grad(lib, 32, M=3, P=4, T=100, O=O, A=A, hidden=hidden, compact_log_std=True)
 
 
+@pytest.mark.parametrize('hidden,O,A', [((32, 64), 20, 6), ((64, 32), 20, 6), ((32, 64), 3, 2), ((64, 32), 29, 8)])
+def test_unequal_hidden_widths(lib, hidden, O, A):
+    # policies/networks/mlp.py:5-62 takes any hidden_sizes: every combination of {32, 64} is instantiated
+    pc.check_loss_grad(lib, 34, M=3, P=4, T=90, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_hvp(lib, 35, M=3, P=4, T=90, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_meta(lib, 36, M=3, P=3, T=60, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2)
+
+
+def test_unsupported_hidden_widths_are_rejected(lib):
+    for hidden, O in (((48, 48), 4), ((64, 128), 4), ((32, 32, 32), 4)):
+        with pytest.raises((_lib.PrompError, ValueError, TypeError)):
+            _lib.Context(2, O, 2, hidden, 1, max_rows=10, max_paths=2, lib=lib)
+
+
 def test_loss_grad_clipped_log_std(lib):
     pc.check_loss_grad(lib, 33, M=2, P=2, T=50, O=4, A=3, hidden=(32, 32), low_log_std=True)
 

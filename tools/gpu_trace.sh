@@ -1,9 +1,15 @@
 #!/bin/bash
-# rocprofv3 kernel trace + stats of the default bench command -> gpurun_out/trace/
+# developer tool: rocprofv3 kernel trace of a short bench run -> gpurun_out/trace/ (stats csv) and a printed summary
 export TMPDIR=/tmp
-rm -rf gpurun_out/trace && mkdir -p gpurun_out/trace
+ROOT=$GRAFT_REPO_ROOT
+rm -rf $ROOT/gpurun_out/trace; mkdir -p $ROOT/gpurun_out/trace
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/trace/bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/trace/err.txt
-echo rc=$?
-ls $GRAFT_REPO_ROOT/gpurun_out/trace
-cat $GRAFT_REPO_ROOT/gpurun_out/trace/*kernel_stats.csv | head -30
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace -o trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline "$@" > $ROOT/gpurun_out/trace/bench.json 2> $ROOT/gpurun_out/trace/err.txt
+cd $ROOT
+python - <<'PY'
+import csv, glob
+f = glob.glob('gpurun_out/trace/**/*kernel_stats.csv', recursive=True)
+for r in csv.DictReader(open(f[0])):
+    print('%-70s calls %5s  avg %9.1f us  total %6.2f %%' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+PY
+rm -f gpurun_out/trace/*/*kernel_trace.csv gpurun_out/trace/*kernel_trace.csv

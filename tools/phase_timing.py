@@ -1,4 +1,6 @@
-"""Developer tool: cycle stamps of workgroup 0 / lane 0 inside k_fwd_bwd (and k_hvp) on config-3 shapes."""
+"""Developer tool: cycle stamps of workgroup 0 / thread 0 inside the chain kernels on config-3 shapes.
+Needs a library built with -DPROMP_DEV_STAMPS (tools/build_variant.sh stamps -DPROMP_DEV_STAMPS; copy it over
+promp_amd/libpromp_hip.so for the run)."""
 import ctypes as C
 import sys
 import numpy as np
@@ -17,21 +19,26 @@ ctx.process_samples(0, normalize_adv=True)
 fn = ctx.lib.cdll.promp_debug_phase_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+names = ['L1', 'L2', 'L3', 'epi', 'dW3', 'dz2', 'dW2', 'dz1', 'dW1']
 for hvp in (0, 1):
     for rep in range(3):
-        buf = np.zeros(256, np.uint64)
+        buf = np.zeros(256 + 4096, np.uint64)
         rc = fn(ctx._h, 0, hvp, buf.ctypes.data_as(C.POINTER(C.c_uint64)))
         assert rc == 0, ctx.lib.cdll.promp_last_error()
     s = buf.astype(np.int64)
     t0 = s[0]
-    print('kernel', 'hvp' if hvp else 'fwd_bwd', ' stage->%d  loop_end->%d  reduce_end->%d  write_end->%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
-    if not hvp:
-        print('  end phase (cycles after loop end): ', [int(x - s[2]) for x in s[120:128]], ' write_end', int(s[4] - s[2]))
+    print('kernel', 'hvp' if hvp else 'pass', ' net1@%d nets@%d zeroed@%d' % (s[5] - t0, s[6] - t0, s[7] - t0), ' staged@%d  loop_end@%d  partial_written@%d  task_reduce_done@%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
+    wg = s[256:].reshape(-1, 4)
+    wg = wg[wg[:, 0] > 0]
+    w0 = wg[:, 0].min()
+    end = np.maximum(wg[:, 1], wg[:, 2])
+    two = wg[:, 2] > 0
+    print('  workgroups %d (two-segment %d): start spread %.1f us; end min/median/max %.1f / %.1f / %.1f us after the first start; two-seg median end %.1f; one-seg median end %.1f'
+          % (len(wg), two.sum(), (wg[:, 0].max() - w0) / 100.0, (end.min() - w0) / 100.0, np.median(end - w0) / 100.0, (end.max() - w0) / 100.0,
+             np.median((end - w0)[two]) / 100.0 if two.any() else 0, np.median((end - w0)[~two]) / 100.0))
+    print('  own duration (us) one-seg median %.1f max %.1f; two-seg median %.1f max %.1f' % (np.median((end - wg[:, 0])[~two]) / 100., ((end - wg[:, 0])[~two]).max() / 100., np.median((end - wg[:, 0])[two]) / 100. if two.any() else 0, ((end - wg[:, 0])[two]).max() / 100. if two.any() else 0))
     for tix in range(4):
-        st = s[8 + 16 * tix: 8 + 16 * tix + 16]
+        st = s[8 + 16 * tix: 8 + 16 * tix + 10]
         if st[0] == 0:
             continue
-        sub = st[9:13] - st[0]
-        st = st[:9]
-        nz = [int(x) for x in st if x > 0]
-        print('  tile', tix, 'start@%d' % (nz[0] - t0), 'phase deltas:', [nz[i + 1] - nz[i] for i in range(len(nz) - 1)], ' sub(after Xstore, after loads issued, after L1 gemm, after L2 gemm):', [int(x) for x in sub])
+        print('  tile', tix, 'start@%d' % (st[0] - t0), ' '.join('%s %d' % (names[i], st[i + 1] - st[i]) for i in range(9)), ' total', st[9] - st[0])
