@@ -9,8 +9,8 @@ on BASELINE config 3: 40-task HalfCheetahRandVel shapes (obs 20, act 6, 2x64 tan
   python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
 
 Multi-GPU: tasks are sharded i -> GPU (i mod N); the only exchange is one RCCL all-reduce of [Theta+K+2] floats per Adam
-epoch (+1 for the stats pass).  Default is WEAK scaling (40 tasks per GPU, meta_batch_size = 40 N); the same line also
-carries "fixed_batch": the named 40-task batch split over the N ranks (strong scaling), timed right after.
+epoch (+1 for the stats pass).  Default is STRONG scaling: the named 40-task batch split over the N ranks (5 tasks per GPU
+at N = 8); the same line also carries "weak_batch": 40 tasks per GPU (meta_batch_size = 40 N), timed right after.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -45,8 +45,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3, 4],
                     help='BASELINE.json config; 3 is the one the metric is quoted on, the others are shape studies')
-    ap.add_argument('--scaling', default='weak', choices=['strong', 'weak'],
-                    help='weak (default): the named 40-task config per GPU; strong: the named config sharded over the N GPUs')
+    ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
+                    help='strong (default): the named 40-task config sharded over the N GPUs; weak: the named config per GPU')
     ap.add_argument('--epochs', type=int, default=5)
     ap.add_argument('--shard-of', type=int, default=0, metavar='N',
                     help='developer option: with --gpus 1, run only the shard rank 0 of an N-GPU job would hold '
@@ -171,8 +171,10 @@ def main():
             iteration()
         fl = flops_per_row(O, hidden[0], hidden[1], A)
         kern = {}
-        for name, kid, f in (('k_fwd_bwd', _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), ('k_hvp', _lib.KERNEL_HVP, fl['hvp']),
-                             ('k_fwd_bwd<fwd-only>', _lib.KERNEL_FWD, fl['fwd'])):
+        hvp_name = 'k_chain_hvp' if (hidden[0] <= 64 and O <= 32) else 'k_wide_hvp'
+        pass_name = 'k_fwd_bwd' if (hidden[0] <= 64 and O <= 32) else 'k_wide_fwd_bwd'
+        for name, kid, f in ((pass_name, _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), (hvp_name, _lib.KERNEL_HVP, fl['hvp']),
+                             (pass_name + '<fwd-only>', _lib.KERNEL_FWD, fl['fwd'])):
             pr = ctx.prof_read(kid)
             avg_ms = pr['total_ms'] / max(pr['launches'], 1)
             rows = pr['rows'] / max(pr['launches'], 1)
@@ -183,7 +185,7 @@ def main():
         kern['k_gram'] = dict(avg_ms=pg['total_ms'] / max(pg['launches'], 1), launches_per_step=pg['launches'] / n_prof,
                               ms_per_step=pg['total_ms'] / n_prof)
         ctx.prof_enable(False)
-        dom = max(('k_fwd_bwd', 'k_hvp'), key=lambda k: kern[k]['ms_per_step'])
+        dom = max((pass_name, hvp_name), key=lambda k: kern[k]['ms_per_step'])
         traffic = measured_traffic(dom) if args.config == 3 else None   # the committed PMC passes are of config 3
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'], 'peak': FP32_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS,
@@ -198,16 +200,19 @@ def main():
         out['cpu_baseline'] = cpu_baseline(cfg, theta0, alpha, eta, opts, E, sample_tasks=min(cfg['M'], 20 if args.config != 4 else 4))
 
     ctx.close()
-    # ---- N > 1, weak scaling: also time the named 40-task batch split over the same ranks (fixed total work) ----
-    if world > 1 and args.scaling == 'weak':
+    # ---- N > 1: also time the other scaling mode on the same ranks (weak: a 40-task batch per GPU) ----
+    if world > 1:
+        other = 'weak' if args.scaling == 'strong' else 'strong'
         try:
-            ctx2, it2, M2 = setup(cfg['M'])
+            M_other = cfg['M'] * (world if other == 'weak' else 1)
+            ctx2, it2, M2 = setup(M_other)
             el2, _ = run_timed(ctx2, it2, args.warmup, args.steps)
-            out['fixed_batch'] = {'meta_batch_size': cfg['M'], 'tasks_per_gpu': M2, 'scaling': 'strong',
-                                  'value': cfg['M'] * N * (K + 1) * args.steps / el2, 'ms_per_step': 1e3 * el2 / args.steps}
+            out['weak_batch' if other == 'weak' else 'fixed_batch'] = {
+                'meta_batch_size': M_other, 'tasks_per_gpu': M2, 'scaling': other,
+                'value': M_other * N * (K + 1) * args.steps / el2, 'ms_per_step': 1e3 * el2 / args.steps}
             ctx2.close()
         except Exception as e:      # the secondary measurement must never cost the primary line
-            print('bench.py: fixed-batch measurement skipped: %r' % (e,), file=sys.stderr)
+            print('bench.py: %s-scaling measurement skipped: %r' % (other, e), file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
 

@@ -123,6 +123,10 @@ int promp_set_advantages(promp_ctx* ctx, int step, const float* advantages);
 int promp_set_theta(promp_ctx* ctx, const float* theta);                 /* [Theta] meta-parameters     */
 int promp_get_theta(promp_ctx* ctx, float* theta);
 int promp_set_step_sizes(promp_ctx* ctx, const float* step_sizes);       /* [Theta], base.py:303-313     */
+/* GaussianMLPPolicy(learn_std=False) (policies/gaussian_mlp_policy.py:63-69: log_std_var created with trainable=False):
+ * the trailing act_dim parameters are neither adapted by the inner step (their step sizes are forced to 0) nor updated
+ * by Adam.  Default: learned. */
+int promp_set_learn_std(promp_ctx* ctx, int learn_std);
 int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
 int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);
 /* MetaPolicy.switch_to_pre_update: replicate theta into every task's parameter slot */
@@ -185,6 +189,19 @@ int promp_optimize(promp_ctx* ctx, int num_epochs, float learning_rate, float cl
 int promp_comm_unique_id(void* id_out, size_t id_bytes);                  /* rank 0; 128 bytes  */
 int promp_comm_init(promp_ctx* ctx, int rank, int nranks, const void* id, size_t id_bytes);
 int promp_allreduce_f64(promp_ctx* ctx, double* host_buf, int n, int op /*0 sum, 1 max*/);
+/* Hand the communicator of `src` over to `dst` (same device): a context that is re-created with more capacity
+ * keeps its communicator instead of running a new rendezvous -- ranks with ragged batches regrow at different
+ * times, a rendezvous per regrow would deadlock.  `src` is left single-rank. */
+int promp_comm_move(promp_ctx* dst, promp_ctx* src);
+/* Take the several-rank launch sequence (per-rank sums -> [all-reduce] -> mean + Adam as separate launches) even on
+ * one rank; numerically identical to the fused single-rank launch (the parity tests assert bitwise equality). */
+int promp_comm_split_path(promp_ctx* ctx, int on);
+/* The buffer the all-reduce acts on, [Theta + K + 2] floats = { grad sums | J sum | inner-KL sums [K] | outer-KL sum }
+ * over the LOCAL tasks after promp_meta_grad (when n_tasks_global > n_tasks and no communicator is attached, the
+ * exchange is the caller's: get, reduce over ranks with any collective, set, then promp_adam_step -- which divides by
+ * n_tasks_global). */
+int promp_reduced_get(promp_ctx* ctx, float* out);
+int promp_reduced_set(promp_ctx* ctx, const float* in);
 
 /* ---- evaluation hooks used by the parity tests and by alternative optimizers (TRPO-MAML's
  * conjugate-gradient loop calls these per evaluation): per-task objective, mean-KL and their

@@ -62,6 +62,7 @@ SIGNATURES = {
     'promp_set_theta': (C.c_int, [_P, _F]),
     'promp_get_theta': (C.c_int, [_P, _F]),
     'promp_set_step_sizes': (C.c_int, [_P, _F]),
+    'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
     'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
     'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
     'promp_switch_to_pre_update': (C.c_int, [_P]),
@@ -76,6 +77,10 @@ SIGNATURES = {
     'promp_optimize': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
     'promp_comm_unique_id': (C.c_int, [_P, C.c_size_t]),
     'promp_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
+    'promp_comm_move': (C.c_int, [_P, _P]),
+    'promp_comm_split_path': (C.c_int, [_P, C.c_int]),
+    'promp_reduced_get': (C.c_int, [_P, _F]),
+    'promp_reduced_set': (C.c_int, [_P, _F]),
     'promp_allreduce_f64': (C.c_int, [_P, _D, C.c_int, C.c_int]),
     'promp_eval_loss_grad': (C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_int, _F, _F, _F]),
     'promp_eval_hvp': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F]),
@@ -310,6 +315,9 @@ class Context:
         r = self.optimize(0, 0.0, clip_eps, inner_kl_coeff, inner_kind, outer_kind)
         return dict(loss=r['loss_after'], inner_kl=r['inner_kl'], outer_kl=r['outer_kl'])
 
+    def set_learn_std(self, on=True):
+        self._call('promp_set_learn_std', int(bool(on)))
+
     def adam_step(self, lr):
         self._call('promp_adam_step', float(lr))
 
@@ -341,6 +349,23 @@ class Context:
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._call('promp_comm_init', int(rank), int(nranks), C.cast(buf, _P), 128)
+
+    def comm_move_from(self, other):
+        """take over `other`'s communicator (a context re-created with more capacity keeps it: no new rendezvous)"""
+        self.lib.check(self.lib.cdll.promp_comm_move(self._h, other._h))
+
+    def comm_split_path(self, on=True):
+        self._call('promp_comm_split_path', int(bool(on)))
+
+    def reduced_get(self):
+        out = np.empty(self.n_params + self.K + 2, np.float32)
+        self._call('promp_reduced_get', _ptr(out, C.c_float))
+        return out
+
+    def reduced_set(self, values):
+        v = _f32(values)
+        assert v.shape == (self.n_params + self.K + 2,)
+        self._call('promp_reduced_set', _ptr(v, C.c_float))
 
     def allreduce_f64(self, values, op='sum'):
         a = np.ascontiguousarray(values, dtype=np.float64).copy()

@@ -110,6 +110,7 @@ struct promp_ctx {
     ncclComm_t comm = nullptr;
 #endif
     int rank = 0, nranks = 1;
+    bool learn_std = true;               // false: log_std is neither adapted (step size 0) nor trained (no Adam update)
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
@@ -305,7 +306,8 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     FinalArgs f;
     f.lam = c->lam; f.NP = NP; f.K = K; f.n_tasks = M;
     f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = want_grad ? 1 : 0;
-    const bool split = c->nranks > 1 || c->force_split;
+    // several ranks (or an external collective: more global than local tasks): sums first, mean + Adam after the exchange
+    const bool split = c->nranks > 1 || c->force_split || c->d.n_tasks_global != c->d.n_tasks;
     if (split) {
         PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
         HIPCHECK(hipGetLastError());
@@ -321,6 +323,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = NP; ad.K = K;
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
     ad.do_update = do_adam ? 1 : 0;
+    ad.n_trainable = c->learn_std ? NP : NP - c->d.act_dim;
     ad.lr_t = 0.f;
     if (do_adam) {
         c->adam_t += 1;
@@ -915,7 +918,22 @@ static int copy_out(promp_ctx* c, float* dst, const float* src, size_t n) {
 
 int promp_set_theta(promp_ctx* c, const float* th) { return c ? copy_in(c, c->theta, th, c->NP) : fail(-1, "ctx is NULL"); }
 int promp_get_theta(promp_ctx* c, float* th) { return c ? copy_out(c, th, c->theta, c->NP) : fail(-1, "ctx is NULL"); }
-int promp_set_step_sizes(promp_ctx* c, const float* s) { return c ? copy_in(c, c->step_sizes, s, c->NP) : fail(-1, "ctx is NULL"); }
+static int mask_log_std_step_sizes(promp_ctx* c) {
+    if (c->learn_std) return 0;
+    HIPCHECK(hipMemsetAsync(c->step_sizes + (c->NP - c->d.act_dim), 0, sizeof(float) * c->d.act_dim, c->stream));
+    return 0;
+}
+int promp_set_step_sizes(promp_ctx* c, const float* s) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (copy_in(c, c->step_sizes, s, c->NP)) return -2;
+    return mask_log_std_step_sizes(c);
+}
+int promp_set_learn_std(promp_ctx* c, int on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (on && !c->learn_std) return fail(-3, "learn_std cannot be switched back on: the log_std step sizes were zeroed (set the step sizes again)");
+    c->learn_std = on != 0;
+    return mask_log_std_step_sizes(c);
+}
 int promp_set_task_thetas(promp_ctx* c, const float* t) { return c ? copy_in(c, c->theta_tasks, t, (size_t)c->d.n_tasks * c->NP) : fail(-1, "ctx is NULL"); }
 int promp_get_task_thetas(promp_ctx* c, float* t) { return c ? copy_out(c, t, c->theta_tasks, (size_t)c->d.n_tasks * c->NP) : fail(-1, "ctx is NULL"); }
 
@@ -1049,6 +1067,7 @@ int promp_adam_step(promp_ctx* c, float lr) {
     ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = c->NP; ad.K = c->d.num_inner_steps;
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
     ad.do_update = 1;
+    ad.n_trainable = c->learn_std ? c->NP : c->NP - c->d.act_dim;
     c->adam_t += 1;
     const double t = (double)c->adam_t;
     ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
@@ -1136,6 +1155,36 @@ int promp_comm_init(promp_ctx* c, int rank, int nranks, const void* id, size_t i
     if (nranks != 1) return fail(-4, "no communicator in the kernel-emulation build");
     return 0;
 #endif
+}
+
+int promp_comm_split_path(promp_ctx* c, int on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->force_split = on != 0;
+    return 0;
+}
+
+int promp_comm_move(promp_ctx* dst, promp_ctx* src) {
+    if (!dst || !src) return fail(-1, "ctx is NULL");
+    if (dst == src) return 0;
+#ifndef PROMP_EMU
+    if (dst->comm) return fail(-3, "destination context already holds a communicator");
+    if (dst->device != src->device) return fail(-1, "contexts live on different devices (%d, %d)", dst->device, src->device);
+    HIPCHECK(hipStreamSynchronize(src->stream));    // nothing of the old context may still be using it
+    dst->comm = src->comm;
+    src->comm = nullptr;
+#endif
+    dst->rank = src->rank; dst->nranks = src->nranks;
+    src->rank = 0; src->nranks = 1;
+    return 0;
+}
+
+int promp_reduced_get(promp_ctx* c, float* out) {
+    if (!c || !out) return fail(-1, "NULL argument");
+    return copy_out(c, out, c->red, (size_t)c->NP + c->d.num_inner_steps + 2);
+}
+int promp_reduced_set(promp_ctx* c, const float* in) {
+    if (!c || !in) return fail(-1, "NULL argument");
+    return copy_in(c, c->red, in, (size_t)c->NP + c->d.num_inner_steps + 2);
 }
 
 int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {

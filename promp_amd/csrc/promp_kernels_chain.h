@@ -364,17 +364,27 @@ struct TaskRedArgs {
 template <int NT>
 PROMP_DEV void chain_task_sum(TaskRedArgs r, int tid) {
     const int NP = r.NP, mode = r.mode, task = r.task;
-    // 4 columns per thread and up to 8 rows per round in flight: the rows live in other CUs' L2 lines, so the sum is
-    // paced by how many loads are outstanding, not by arithmetic
+    // CW columns per thread, up to 8 rows per round, and the operands of the update (step sizes, current parameters /
+    // multipliers) requested in the same batch: the rows live in other CUs' L2 lines or in memory, so the sum is paced by
+    // how many loads are outstanding, not by arithmetic
+    constexpr int CW = 6;
     const int jbeg = (mode == RED_SCAL) ? NP : 0;
-    for (int j0 = jbeg + tid; j0 < NP + 2; j0 += 4 * NT) {
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = jbeg + tid; j0 < NP + 2; j0 += CW * NT) {
+        float g[CW], al[CW], old[CW];
+#pragma unroll
+        for (int u = 0; u < CW; ++u) {
+            const int j = j0 + u * NT, jc = j < NP ? j : NP - 1;
+            g[u] = 0.f;
+            al[u] = r.step_sizes[jc];
+            old[u] = (mode == RED_STEP) ? r.cur[(long long)task * r.cur_task_stride + jc]
+                                        : (mode == RED_HVP) ? r.lam[(long long)task * NP + jc] : 0.f;
+        }
         for (int sb = r.s0; sb < r.s1; sb += 8) {
-            float x[8][4];
+            float x[8][CW];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < CW; ++u) {
                     const int j = j0 + u * NT;
                     const bool ok = sb + q < r.s1 && j < NP + 2;
                     // clamped to a row / column of this task (all written: every workgroup has arrived) and masked by a
@@ -385,10 +395,10 @@ PROMP_DEV void chain_task_sum(TaskRedArgs r, int tid) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) g[u] += x[q][u];       // slot order within a column: fixed
+                for (int u = 0; u < CW; ++u) g[u] += x[q][u];       // slot order within a column: fixed
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CW; ++u) {
             const int j = j0 + u * NT;
             if (j >= NP + 2) continue;
             if (j >= NP) {
@@ -397,14 +407,13 @@ PROMP_DEV void chain_task_sum(TaskRedArgs r, int tid) {
             }
             const long long tj = (long long)task * NP + j;
             if (mode == RED_STEP) {
-                r.next[tj] = r.cur[(long long)task * r.cur_task_stride + j] - r.step_sizes[j] * g[u];
+                r.next[tj] = old[u] - al[u] * g[u];
                 continue;
             }
-            float lam = g[u];
-            if (mode == RED_HVP) lam += r.lam[tj];
+            const float lam = (mode == RED_HVP) ? g[u] + old[u] : g[u];
             r.lam[tj] = lam;
             if (mode == RED_PLAIN) continue;
-            r.v[tj] = r.step_sizes[j] * lam;
+            r.v[tj] = al[u] * lam;
         }
     }
 }
@@ -492,7 +501,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         CH_STAMP(5);
         chain_stage_dist(net + L.dist, th, v, oS, A, a.clip_log_std, a.min_log_std, tid);
         CH_STAMP(6);
-        for (int e = lane; e < L.wave_stride; e += 64) wreg[e] = 0.f;
+        // action slots >= 8 of the cotangent tiles must read as zero (slots < 8 and the transpose tiles are rewritten by
+        // every tile before they are read); the end-of-segment slabs alias them, so once per segment
+        for (int e = lane; e < 2 * 16 * DS; e += 64) DB0[e] = 0.f;
         CH_STAMP(7);
         __syncthreads();
         CH_STAMP(1);
@@ -630,17 +641,22 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 m0[1] = bb[1];
                 ra0[0] = vb[0];
                 ra0[1] = vb[1];
+                f32x4 wf[NC2], vf[NC2];
 #pragma unroll
                 for (int c = 0; c < NC2; ++c) {
-                    const f32x4 wf = lds4(W3l + c * 256), vf = lds4(W3l + VO + c * 256);
+                    wf[c] = lds4(W3l + c * 256);
+                    vf[c] = lds4(W3l + VO + c * 256);
+                }
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        m0 = mfma16(wf[r], h2[c][r], m0);
-                        ra0 = mfma16(wf[r], rh2[c][r], ra0);
-                        rb0 = mfma16(vf[r], h2[c][r], rb0);
-                        m1 = mfma16(wf[r + 1], h2[c][r + 1], m1);
-                        ra1 = mfma16(wf[r + 1], rh2[c][r + 1], ra1);
-                        rb1 = mfma16(vf[r + 1], h2[c][r + 1], rb1);
+                        m0 = mfma16(wf[c][r], h2[c][r], m0);
+                        ra0 = mfma16(wf[c][r], rh2[c][r], ra0);
+                        rb0 = mfma16(vf[c][r], h2[c][r], rb0);
+                        m1 = mfma16(wf[c][r + 1], h2[c][r + 1], m1);
+                        ra1 = mfma16(wf[c][r + 1], rh2[c][r + 1], ra1);
+                        rb1 = mfma16(vf[c][r + 1], h2[c][r + 1], rb1);
                     }
                 }
                 mu0 = m0[0] + m1[0];

@@ -114,6 +114,7 @@ struct AdamArgs {
     float inv_tasks;
     float lr_t;        // lr * sqrt(1-b2^t)/(1-b1^t); 0 => no parameter update (stats / grad only)
     int do_update;
+    int n_trainable;   // parameters [n_trainable, NP) are left alone (learn_std = False: the trailing log_std entries)
 };
 
 __global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
     if (j < a.NP) {
         const float g = a.red[j] * a.inv_tasks;
         a.grad_mean[j] = g;
-        if (a.do_update) {
+        if (a.do_update && j < a.n_trainable) {
             const float m = 0.9f * a.m[j] + 0.1f * g;
             const float v = 0.999f * a.v[j] + 0.001f * g * g;
             a.m[j] = m;
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) k_final_adam(FinalArgs a, AdamArgs ad) {
         if (!stats_block && j < a.NP) {
             const float g = t * ad.inv_tasks;
             ad.grad_mean[j] = g;
-            if (ad.do_update) {
+            if (ad.do_update && j < ad.n_trainable) {
                 const float m = 0.9f * ad.m[j] + 0.1f * g;
                 const float v = 0.999f * ad.v[j] + 0.001f * g * g;
                 ad.m[j] = m;

@@ -53,4 +53,5 @@ class MAMLAlgo(MetaAlgo):
         self.session.ctx.inner_adapt(slot, self.inner_kind)
         self._adapt_count += 1
         self.session.task_thetas = None
+        self.session.param_version += 1
         self.policy._pre_update_mode = False

@@ -35,9 +35,9 @@ class ProMP(MAMLAlgo):
     def optimize_policy(self, all_samples_data, log=True):
         """MAML outer step: E Adam epochs on the meta-objective, then stats (pro_mp.py:165-199)"""
         assert len(all_samples_data) == self.num_inner_grad_steps + 1
-        slots = [self._slot_of(sd, k) for k, sd in enumerate(all_samples_data)]
-        assert slots == list(range(self.num_inner_grad_steps + 1)), \
-            'samples of sampling step k must be resident in slot k (got %r)' % (slots,)
+        for k, sd in enumerate(all_samples_data):
+            if self._slot_of(sd, k) != k:             # resident, but in another slot (an extra process_samples call in between):
+                self.session.upload_samples(k, sd)    # sampling step k must sit in slot k
         if log: logger.log('Optimizing')
         res = self.session.ctx.optimize(self.num_ppo_steps, self.learning_rate, self.clip_eps, self.inner_kl_coeff,
                                         self.inner_kind, self.outer_kind)
@@ -52,6 +52,7 @@ class ProMP(MAMLAlgo):
             logger.logkv('KLInner', np.mean(inner_kls))
             logger.logkv('KLCoeffInner', np.mean(self.inner_kl_coeff))
         self.last_stats = res
+        self.session.param_version += 1
 
     def adapt_kl_coeff(self, kl_coeff, kl_values, kl_target):
         if hasattr(kl_values, '__iter__'):

@@ -34,9 +34,10 @@ class _DeviceEvaluator(object):
         ctx.set_task_thetas(saved)
         c = a._explore_coeffs
         tot = np.concatenate([[np.dot(c, l.astype(np.float64))], c.dot(g.astype(np.float64)) if want_grad else []])
-        if a.meta_batch_size != ctx.n_tasks:          # task-sharded run: sum over ranks (64 doubles per call)
+        n_global = a.session.M_global
+        if a.session.world > 1:                       # task-sharded run: sum over ranks (64 doubles per call)
             tot = np.concatenate([ctx.allreduce_f64(tot[i:i + 64]) for i in range(0, tot.size, 64)])
-        return tot[0] / a.meta_batch_size, (tot[1:] / a.meta_batch_size if want_grad else None)
+        return tot[0] / n_global, (tot[1:] / n_global if want_grad else None)
 
     def loss(self):          # -mean_i mean(ratio * adv) at theta'_i   (trpo_maml.py:135,150)
         v = self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['loss']

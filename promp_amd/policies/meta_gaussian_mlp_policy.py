@@ -21,7 +21,11 @@ from .distributions.diagonal_gaussian import DiagonalGaussian
 
 class MetaGaussianMLPPolicy(object):
     def __init__(self, meta_batch_size, obs_dim, action_dim, name='policy', hidden_sizes=(32, 32), learn_std=True,
-                 hidden_nonlinearity='tanh', output_nonlinearity=None, init_std=1., min_std=1e-6, **kwargs):
+                 hidden_nonlinearity='tanh', output_nonlinearity=None, init_std=1., min_std=1e-6,
+                 n_tasks_global=None, rank=None, world=None, device_id=None, **kwargs):
+        """meta_batch_size is the number of tasks THIS process holds.  In a task-sharded run (one process per GPU under
+        torchrun) rank / world / device default to RANK / WORLD_SIZE / LOCAL_RANK and n_tasks_global to
+        meta_batch_size * world: the meta-gradient is then the mean over all ranks' tasks (one RCCL all-reduce per epoch)."""
         assert output_nonlinearity is None, 'only a linear output layer is implemented'
         assert hidden_nonlinearity in ('tanh', None) or getattr(hidden_nonlinearity, '__name__', '') == 'tanh', \
             'only tanh hidden units are implemented (the reference default, policies/base.py:31)'
@@ -51,8 +55,17 @@ class MetaGaussianMLPPolicy(object):
                 parts.append(np.zeros(shp))
             else:
                 parts.append(np.full(shp, self.init_log_std))
-        self.session = session_mod.DeviceSession(self.meta_batch_size, self.obs_dim, self.action_dim, self.hidden_sizes)
+        from .. import comm
+        env_rank, env_world, env_local = comm.env_world()
+        rank = env_rank if rank is None else int(rank)
+        world = env_world if world is None else int(world)
+        device_id = (env_local if world > 1 else 0) if device_id is None else int(device_id)
+        self.session = session_mod.DeviceSession(self.meta_batch_size, self.obs_dim, self.action_dim, self.hidden_sizes,
+                                                 n_tasks_global=n_tasks_global or self.meta_batch_size * world,
+                                                 device_id=device_id, rank=rank, world=world)
+        self.session.learn_std = bool(learn_std)      # False: log_std is neither adapted nor trained (gaussian_mlp_policy.py:63-69)
         self.session.set_theta(self._flatten(parts))
+        self._log_std_cache = None                    # ([M, A] raw log_std of the tasks' current parameters, parameter version)
         self._pre_update_mode = True
         self.switch_to_pre_update()
 
@@ -83,12 +96,14 @@ class MetaGaussianMLPPolicy(object):
         assert all(k1 == k2 for k1, k2 in zip(self.policy_params_keys, policy_params.keys())), \
             'parameter keys must match with variable'
         self.session.set_theta(self._flatten(list(policy_params.values())))
+        self.session.param_version += 1
 
     def switch_to_pre_update(self):
         """policies/base.py:234-240: get_action uses the pre-update policy; per-task params = theta replicated"""
         self._pre_update_mode = True
         s = self.session
         s.step_cursor = 0
+        s.param_version += 1
         if s.ctx is not None:
             s.ctx.switch_to_pre_update()
             s.task_thetas = None
@@ -108,22 +123,12 @@ class MetaGaussianMLPPolicy(object):
         th = np.stack([self._flatten(list(d.values())) for d in updated_policies_parameters])
         s = self.session
         s.task_thetas = th
+        s.param_version += 1
         if s.ctx is not None:
             s.ctx.set_task_thetas(th)
         self._pre_update_mode = False
 
-    # ---- reference API: acting (host side, see module docstring) ----
-    def _mean(self, theta, obs):
-        x, off = np.asarray(obs, dtype=np.float32), 0
-        sizes = (self.obs_dim,) + self.hidden_sizes + (self.action_dim,)
-        for i in range(len(sizes) - 1):
-            W = theta[off:off + sizes[i] * sizes[i + 1]].reshape(sizes[i], sizes[i + 1]); off += W.size
-            b = theta[off:off + sizes[i + 1]]; off += b.size
-            x = x @ W + b
-            if i < len(sizes) - 2:
-                x = np.tanh(x)
-        return x
-
+    # ---- reference API: acting ----
     def get_actions(self, observations):
         """observations: list[M] of [B,O] -> (list[M] of [B,A], list[M] of list[B] of {mean, log_std})
         (meta_gaussian_mlp_policy.py:99-157)"""
@@ -146,9 +151,13 @@ class MetaGaussianMLPPolicy(object):
         return actions, agent_infos
 
     def _log_std_tasks(self):
-        """[M, A] raw log_std of every task's current parameters (cached per parameter version)"""
-        th = self._task_thetas()
-        return th[:, -self.action_dim:]
+        """[M, A] raw log_std of every task's current parameters.  Cached per parameter version: the sampler calls
+        get_actions once per environment step, and a download of all [M, Theta] parameters per step would dominate the
+        rollout (the version is bumped by everything that changes the tasks' parameters)."""
+        ver = self.session.param_version
+        if self._log_std_cache is None or self._log_std_cache[1] != ver:
+            self._log_std_cache = (np.array(self._task_thetas()[:, -self.action_dim:], dtype=np.float32), ver)
+        return self._log_std_cache[0]
 
     def get_action(self, observation, task=0):
         obs = [np.expand_dims(observation, 0)] * self.meta_batch_size

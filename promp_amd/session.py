@@ -43,7 +43,10 @@ class DeviceSession:
         self.task_thetas = None
         self.step_cursor = 0
         self.upload_serial = [0] * (self.K + 1)
-        self._uid = None
+        self.param_version = 0        # bumped by whatever changes the tasks' parameters (host-side caches key on it)
+        self.learn_std = True
+        self._upload_counter = 0      # never reset: a SamplesData from before a context re-creation can never match a later upload
+        self._comm_ready = False      # the RCCL communicator is created once per session and moved across context re-creations
         _current = self
 
     def set_num_inner_steps(self, K):
@@ -58,6 +61,7 @@ class DeviceSession:
             self.ctx.close()
             self.ctx = None
             self.capacity = (0, 0)
+            self._comm_ready = False
 
     def pull_state(self):
         if self.ctx is not None:
@@ -69,22 +73,32 @@ class DeviceSession:
         """Context with room for `rows` rows / `paths` paths per sampling step (grown geometrically)."""
         if self.ctx is None or rows > self.capacity[0] or paths > self.capacity[1]:
             cap = (max(rows, int(1.25 * self.capacity[0])), max(paths, int(1.25 * self.capacity[1])))
-            self._drop()
+            old = self.ctx
+            if old is not None:
+                self.pull_state()
             self.ctx = _lib.Context(self.M, self.O, self.A, self.hidden, self.K, max_rows=cap[0], max_paths=cap[1],
                                     n_tasks_global=self.M_global, device_id=self.device_id)
+            if old is not None:
+                # ranks with ragged batches regrow at different times: the communicator moves to the new context instead
+                # of a fresh rendezvous (which would wait for peers that are not regrowing)
+                if self._comm_ready:
+                    self.ctx.comm_move_from(old)
+                old.close()
             self.capacity = cap
             if self.theta is not None:
                 self.ctx.set_theta(self.theta)
             if self.step_sizes is not None:
                 self.ctx.set_step_sizes(self.step_sizes)
+            self.ctx.set_learn_std(self.learn_std)
             if self.adam is not None:
                 self.ctx.set_adam_state(*self.adam)
             if self.task_thetas is not None:
                 self.ctx.set_task_thetas(self.task_thetas)
-            if self.world > 1:
+            if self.world > 1 and not self._comm_ready:
                 from . import comm
                 self.ctx.comm_init(self.rank, self.world, comm.exchange_unique_id(self.rank, self.world, _lib.comm_unique_id))
-            self.upload_serial = [0] * (self.K + 1)
+                self._comm_ready = True
+            self.upload_serial = [-1] * (self.K + 1)       # nothing is resident in the new context
         return self.ctx
 
     # ---- parameters ----
@@ -112,7 +126,8 @@ class DeviceSession:
         ctx = self.ensure(len(fl['rew']), len(fl['path_row_offsets']) - 1)
         ctx.upload_step(slot, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'], fl['act'],
                         fl['old_mean'], fl['old_log_std'])
-        self.upload_serial[slot] += 1
+        self._upload_counter += 1
+        self.upload_serial[slot] = self._upload_counter
         return self.upload_serial[slot]
 
     def upload_samples(self, slot, samples_data_meta_batch):

@@ -162,6 +162,75 @@ def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, comp
     return res
 
 
+def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, attach_comm=False):
+    """the several-rank launch sequence (k_reduce_final -> [ncclAllReduce] -> k_mean_adam) on ONE rank must reproduce the
+    fused single-rank launch (k_final_adam) bit for bit: same column sums in the same order, same Adam arithmetic"""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=True)
+    spec = op.PolicySpec(O, A, hidden)
+    eta = np.array([5e-4], np.float32)
+    out = []
+    for split in (False, True):
+        ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+        helpers.upload_slabs(ctx, all_paths, all_slabs)
+        ctx.set_theta(theta)
+        ctx.set_step_sizes(np.full(spec.n_params, 0.1, np.float32))
+        if split:
+            if attach_comm:
+                ctx.comm_init(0, 1, _lib.comm_unique_id(lib))      # a real (one-rank) RCCL communicator: the all-reduce is enqueued
+            ctx.comm_split_path(True)
+        res = ctx.optimize(epochs, 1e-3, 0.3, eta)
+        g, st = ctx.meta_grad(0.3, eta)
+        m, v, t = ctx.get_adam_state()
+        out.append((ctx.get_theta(), m, v, t, res, g, st, ctx.reduced_get()))
+        ctx.close()
+    a, b = out
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_array_equal(x, y)
+    assert a[3] == b[3] == epochs
+    assert a[4] == pytest_approx_dict(b[4])
+    np.testing.assert_array_equal(a[5], b[5])
+    np.testing.assert_array_equal(a[7], b[7])
+
+
+def pytest_approx_dict(d):
+    class _Eq(dict):
+        def __eq__(self, other):
+            return all(np.array_equal(np.asarray(self[k]), np.asarray(other[k])) for k in self) and set(self) == set(other)
+    return _Eq(d)
+
+
+def check_learn_std_false(lib, seed, M, P, T, O, A, hidden):
+    """GaussianMLPPolicy(learn_std=False): log_std is neither adapted by the inner step nor updated by Adam; everything else
+    equals the oracle run with zero inner step sizes on the log_std entries"""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
+    spec = op.PolicySpec(O, A, hidden)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    alpha = np.full(spec.n_params, 0.1, np.float32)
+    eta = np.array([5e-4], np.float32)
+    ctx.set_theta(theta)
+    ctx.set_learn_std(False)
+    ctx.set_step_sizes(alpha)                     # (order must not matter: the mask is re-applied)
+    a64 = alpha.astype(np.float64)
+    a64[-A:] = 0.0
+    g, st = ctx.meta_grad(0.3, eta)
+    r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), all_slabs, a64, eta.astype(np.float64), 0.3)
+    np.testing.assert_allclose(st['loss'], r['loss'], rtol=1e-4, atol=1e-6)
+    assert rel_max(g, r['grad']) < 1e-4
+    ctx.switch_to_pre_update()
+    ctx.inner_adapt(0)
+    th1 = ctx.get_task_thetas()
+    np.testing.assert_array_equal(th1[:, -A:], np.tile(theta[-A:], (M, 1)))
+    assert np.all(np.any(th1[:, :-A] != theta[:-A], axis=1))
+    ctx.optimize(3, 1e-3, 0.3, eta)
+    th = ctx.get_theta()
+    np.testing.assert_array_equal(th[-A:], theta[-A:])
+    assert np.all(th[:-A] != theta[:-A]) or np.mean(th[:-A] != theta[:-A]) > 0.99
+    with __import__('pytest').raises(_lib.PrompError, match='learn_std'):
+        ctx.set_learn_std(True)
+    ctx.close()
+
+
 def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10, max_backtracks=15,
                exploration=False):
     """TRPOMAML.optimize_policy (row a15) through the plugin classes.

@@ -62,6 +62,78 @@ def test_two_rank_sharded_meta_update_equals_single_process(tmp_path):
     np.testing.assert_allclose(np.load(out), th, rtol=1e-10, atol=1e-12)
 
 
+LIB_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+from promp_amd import _lib
+from tests import devlib, helpers
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+os.environ['PROMP_EMU_CUS'] = '2'
+lib = devlib.emu_library()          # the library's own kernel + host sources (SIMT interpreter build): no GPU in this container
+M, P, T, O, A, hidden, K = 4, 1, 24, 5, 3, (32, 32), 1
+theta, all_slabs, all_paths = helpers.make_promp_case(78, M, P, T, O, A, hidden, K)
+mine = [i for i in range(M) if i %% world == rank]            # task i -> rank i %% world (bench.py, DeviceSession)
+sub_paths = [type(p)((j, p[i]) for j, i in enumerate(mine)) for p in all_paths]
+sub_slabs = [[s[i] for i in mine] for s in all_slabs]
+R = max(sum(len(q['rewards']) for pl in p.values() for q in pl) for p in sub_paths)
+ctx = _lib.Context(len(mine), O, A, hidden, K, max_rows=R, max_paths=len(mine) * P, lib=lib, n_tasks_global=M)
+helpers.upload_slabs(ctx, sub_paths, sub_slabs)
+ctx.set_theta(theta)
+ctx.set_step_sizes(np.full(theta.size, 0.1, np.float32))
+eta = np.array([5e-4], np.float32)
+for epoch in range(2):
+    ctx.meta_grad(0.3, eta)                                    # local SUMS stay in the exchange buffer (no communicator attached)
+    buf = torch.from_numpy(ctx.reduced_get())                  # [grad | J | inner_kl[K] | outer_kl]
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)                 # gloo stands in for ncclAllReduce
+    ctx.reduced_set(buf.numpy())
+    ctx.adam_step(1e-3)                                        # k_mean_adam: 1 / n_tasks_global, replicated Adam
+th = ctx.get_theta()
+ths = [torch.zeros(theta.size) for _ in range(world)]
+dist.all_gather(ths, torch.from_numpy(th))
+assert all(torch.equal(ths[0], t) for t in ths), 'replicated parameters diverged'
+if rank == 0:
+    np.save(os.environ['OUT'], th)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_library_kernels_with_external_collective(tmp_path):
+    """The library itself on two gloo ranks: each rank runs libpromp's kernels (SIMT-interpreter build, no GPU here) on
+    its shard of the tasks, the [Theta+K+2] exchange buffer crosses the ranks through promp_reduced_get / _set, and
+    promp_adam_step applies the replicated update.  Must equal the one-process run over all tasks."""
+    from promp_amd import _lib
+    from tests import devlib, helpers
+    out = str(tmp_path / 'theta.npy')
+    script = tmp_path / 'worker.py'
+    script.write_text(LIB_WORKER % dict(root=ROOT))
+    devlib.emu_library()               # build once, before two processes race for it
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29651', str(script)]
+    subprocess.run(cmd, check=True, env=dict(os.environ, OUT=out, MASTER_ADDR='127.0.0.1'), timeout=900, cwd=ROOT)
+    os.environ['PROMP_EMU_CUS'] = '2'
+    try:
+        lib = devlib.emu_library()
+        M, P, T, O, A, hidden, K = 4, 1, 24, 5, 3, (32, 32), 1
+        theta, all_slabs, all_paths = helpers.make_promp_case(78, M, P, T, O, A, hidden, K)
+        R = max(sum(len(q['rewards']) for pl in p.values() for q in pl) for p in all_paths)
+        ctx = _lib.Context(M, O, A, hidden, K, max_rows=R, max_paths=M * P, lib=lib)
+        helpers.upload_slabs(ctx, all_paths, all_slabs)
+        ctx.set_theta(theta)
+        ctx.set_step_sizes(np.full(theta.size, 0.1, np.float32))
+        ctx.optimize(2, 1e-3, 0.3, np.array([5e-4], np.float32))
+        ref = ctx.get_theta()
+        ctx.close()
+    finally:
+        del os.environ['PROMP_EMU_CUS']
+    got = np.load(out)
+    # float32 sums in a different task order (rank-major instead of task-major): Adam steps are ~lr per element
+    assert np.max(np.abs(got - ref)) < 2e-5 and np.mean(np.abs(got - ref)) < 2e-6
+    assert np.max(np.abs(ref - theta)) > 5e-4
+
+
 def test_rendezvous_socket_fallback_two_processes(tmp_path):
     """promp_amd.comm.exchange_unique_id without torch: rank 0 serves the 128-byte id over a socket."""
     code = r'''

@@ -12,6 +12,12 @@ def lib():
     return devlib.emu_library()
 
 
+@pytest.fixture
+def two_cus(monkeypatch):
+    """sequencing tests launch dozens of kernels; two emulated CUs (half the host threads per launch) keep them short"""
+    monkeypatch.setenv('PROMP_EMU_CUS', '2')
+
+
 @pytest.mark.parametrize('name', ['default', 'gae095', 'positive', 'ragged', 'clipped_obs', 'zero_base', 'time_base',
                                   'undiscounted', 'float64_obs'])
 def test_sample_processing_vs_reference_outputs(lib, name):
@@ -63,18 +69,20 @@ def test_hvp_segments_straddling_tasks(lib, monkeypatch):
     pc.check_hvp(lib, 17, M=3, P=2, T=100, O=20, A=6, hidden=(64, 64), ragged=True)
 
 
+def test_split_path_equals_fused_launch(lib, two_cus):
+    pc.check_split_path_equals_fused(lib, 18, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), epochs=2)
+
+
+def test_learn_std_false(lib, two_cus):
+    pc.check_learn_std_false(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32))
+
+
 def test_hvp_h64(lib):
     pc.check_hvp(lib, 10, M=2, P=2, T=37, O=20, A=6, hidden=(64, 64))
 
 
 def test_hvp_h32_odd_obs(lib):
     pc.check_hvp(lib, 11, M=1, P=2, T=50, O=5, A=3, hidden=(32, 32), ragged=True)
-
-
-@pytest.fixture
-def two_cus(monkeypatch):
-    """sequencing tests launch dozens of kernels; two emulated CUs (half the host threads per launch) keep them short"""
-    monkeypatch.setenv('PROMP_EMU_CUS', '2')
 
 
 def test_meta_k1_h64(lib, two_cus):

@@ -233,6 +233,27 @@ def test_full_config_zero_advantages_give_zero_surrogate_gradient(config_full):
     ctx.set_advantages(1, adv)
 
 
+def test_split_reduce_allreduce_adam_equals_fused_launch(lib):
+    # the N>1 kernels (k_reduce_final, ncclAllReduce enqueue, k_mean_adam) on hardware, one-rank communicator
+    pc.check_split_path_equals_fused(lib, 71, M=5, P=4, T=90, O=20, A=6, hidden=(64, 64), attach_comm=True)
+    pc.check_split_path_equals_fused(lib, 72, M=3, P=3, T=50, O=111, A=8, hidden=(128, 128), epochs=2, attach_comm=False)
+
+
+def test_communicator_moves_to_a_regrown_context(lib):
+    a = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)
+    a.comm_init(0, 1, _lib.comm_unique_id(lib))
+    b = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=100, max_paths=20, lib=lib)
+    b.comm_move_from(a)
+    a.close()
+    np.testing.assert_array_equal(b.allreduce_f64([3.0, 4.0]), [3.0, 4.0])
+    b.close()
+
+
+def test_learn_std_false(lib):
+    pc.check_learn_std_false(lib, 73, M=3, P=3, T=60, O=20, A=6, hidden=(64, 64))
+    pc.check_learn_std_false(lib, 74, M=2, P=2, T=40, O=40, A=3, hidden=(128, 128))
+
+
 def test_single_rank_communicator(lib):
     # nranks == 1 goes through ncclCommInitRank and the data path skips the all-reduce
     ctx = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)

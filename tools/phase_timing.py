@@ -1,4 +1,4 @@
-"""Developer tool: cycle stamps of workgroup 0 / thread 0 inside the chain kernels on config-3 shapes.
+"""Developer tool: cycle stamps of workgroup 0 / thread 0 inside k_chain_hvp on config-3 shapes.
 Needs a library built with -DPROMP_DEV_STAMPS (tools/build_variant.sh stamps -DPROMP_DEV_STAMPS; copy it over
 promp_amd/libpromp_hip.so for the run)."""
 import ctypes as C
@@ -20,7 +20,7 @@ fn = ctx.lib.cdll.promp_debug_phase_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
 names = ['L1', 'L2', 'L3', 'epi', 'dW3', 'dz2', 'dW2', 'dz1', 'dW1']
-for hvp in (0, 1):
+for hvp in (1,):
     for rep in range(3):
         buf = np.zeros(256 + 4096, np.uint64)
         rc = fn(ctx._h, 0, hvp, buf.ctypes.data_as(C.POINTER(C.c_uint64)))
