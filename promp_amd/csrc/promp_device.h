@@ -41,6 +41,14 @@ PROMP_DEV float shfl_xor_f32(float v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }
 PROMP_DEV double shfl_idx_f64(double v, int l) { return __shfl(v, l, 64); }
+// value of lane `l` (a compile-time or wave-uniform index) as a wave-uniform double: two v_readlane_b32 into scalar
+// registers, no LDS round trip
+PROMP_DEV double readlane_f64(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+PROMP_DEV bool wave_any(bool p) { return __any(p); }
 // Orders this wave's LDS traffic between producer and consumer lanes of the SAME wave (no s_barrier):
 // LDS executes one wave's instructions in order, so it is enough to (a) stop the compiler from moving memory
 // accesses across this point and (b) have the data written.  Deliberately NOT a fence: a fence would also wait

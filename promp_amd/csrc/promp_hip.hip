@@ -440,6 +440,12 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         HIPCHECK(hipFuncSetAttribute((const void*)g4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)g5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        {
+            auto f1 = k_fit_wave<12>; auto f2 = k_fit_wave<48>; auto f3 = k_fit_wave<64>;
+            HIPCHECK(hipFuncSetAttribute((const void*)f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
         HIPCHECK(hipFuncSetAttribute((const void*)k_gram_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k_fit_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
@@ -804,7 +810,11 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         const int DA = a.D + 1;
         if (small) {
             const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2);
-            PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
+            // one wave per task while a row of the work matrix fits a wave's lanes (D + 1 <= 64); else one workgroup per task
+            if (DA <= 12) { auto k = k_fit_wave<12>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
+            else if (DA <= 48) { auto k = k_fit_wave<48>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
+            else if (DA <= 64) { auto k = k_fit_wave<64>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
+            else PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         } else {
             PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), 1024, fitw_smem(a.D), st, a, nblk, c->fit_scratch);
         }

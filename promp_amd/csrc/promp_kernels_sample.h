@@ -269,6 +269,82 @@ __global__ void __launch_bounds__(256) k_fit(SampleArgs a, int NBLK) {
     if (tid < D) a.coeffs[(long long)task * a.coeff_stride + tid] = wv[tid];
 }
 
+// k_fit_wave: the same solve as k_fit, one WAVE per task, for D + 1 <= 64 (obs_dim <= 29).
+//
+// Lane i holds row i of the work matrix in registers (row D = the right-hand side, carried along as in k_fit).  A column
+// step of the Cholesky needs the pivot and, per trailing column k, the freshly scaled entry L[k][j] as a wave-uniform
+// multiplier: both come out of the owning lane with v_readlane (scalar registers), so a step is
+// "readlane, readlane, v_fma_f64" per trailing column with no barrier and no LDS round trip on the dependent chain
+// (k_fit: two workgroup barriers plus LDS traffic per column, 49 us at 45 x 45; this: ~12 us).  All lanes update all
+// trailing columns (the upper triangle is never read), so there is no per-lane masking either.  The back substitution
+// runs over the transposed factor: the rows are written to LDS once and read back by column.
+// Arithmetic order per element is k_fit's (same fma sequence over j), so both kernels give the same coefficients.
+// DT = compile-time bound on D + 1 (the j / k loops are fully unrolled over it; steps j >= D leave by a uniform branch).
+// grid = tasks, block = 256: all four waves sum the task's partial Gram blocks (many loads in flight), wave 0 factorizes.
+template <int DT>
+__global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
+    PROMP_SMEM_DECL;
+    const int D = a.D, DA = D + 1;
+    double* G = (double*)PROMP_SMEM_PTR;          // [DA][DA] symmetric Gram matrix (kept for the retries), then the factor
+    double* Lm = G + DA * DA;                     // [DA][DA] factor rows, read by column in the back substitution
+    const int lane = threadIdx.x & 63, task = blockIdx.x;
+    const int NPAIR = NBLK * (NBLK + 1) / 2;
+    // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
+    const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
+    for (int e = threadIdx.x; e < NPAIR * 256; e += 256) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int wg = wg0; wg < wg1; ++wg) s += a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+        int p = e >> 8, bi = 0, rem = p;
+        while (rem >= NBLK - bi) {
+            rem -= NBLK - bi;
+            ++bi;
+        }
+        const int bj = bi + rem;
+        const int row = 16 * bi + ((e & 255) >> 4), col = 16 * bj + (e & 15);
+        if (row < DA && col < DA) {
+            G[row * DA + col] = s;
+            if (bi != bj) G[col * DA + row] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int row = lane < DA ? lane : DA - 1;    // (lanes >= DA shadow the last row: finite values, never read back)
+    double reg = a.reg;
+    double wsol = 0.0;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        double W[DT];
+#pragma unroll
+        for (int k = 0; k < DT; ++k) W[k] = (k < D) ? G[row * DA + k] + ((k == row) ? reg : 0.0) : 0.0;
+        // 2. Cholesky of (G[:D,:D] + reg I) carrying the right-hand-side row D along (forward solve for free)
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            if (j < D) {          // (wave-uniform; a `break` would keep the loop rolled and the row out of registers)
+                const double piv = sqrt(readlane_f64(W[j], j));
+                W[j] = (lane == j) ? piv : W[j] / piv;
+#pragma unroll
+                for (int k = j + 1; k < DT; ++k) W[k] -= W[j] * readlane_f64(W[j], k);      // lane k holds L[k][j] in W[j]
+            }
+        }
+        // 3. back substitution over the transposed factor: y[t] -= L[j][t] w[j], j = D-1 .. 0 (lane t holds y[t])
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+            if (k < D && lane < DA) Lm[lane * DA + k] = W[k];
+        wave_sync();
+        double y = (lane < D) ? Lm[D * DA + lane] : 0.0;
+        const double dg = (lane < D) ? Lm[lane * DA + lane] : 1.0;
+        for (int j = D - 1; j >= 0; --j) {
+            const double wj = readlane_f64(y, j) / readlane_f64(dg, j);
+            if (lane == j) wsol = wj;
+            if (lane < j) y -= Lm[j * DA + lane] * wj;
+        }
+        wave_sync();
+        if (!wave_any(lane < D && wsol != wsol)) break;      // NaN => reg *= 10, at most 5 tries (linear_baseline.py:68-77)
+        reg *= 10.0;
+    }
+    if (lane < D) a.coeffs[(long long)task * a.coeff_stride + lane] = wsol;
+}
+
 // grid = paths, block = 64.  smem: D doubles (the task's coefficients)
 __global__ void __launch_bounds__(64) k_gae(SampleArgs a) {
     PROMP_SMEM_DECL;

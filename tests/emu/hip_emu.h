@@ -178,6 +178,12 @@ inline float shfl_xor_f32(float v, int m) { return (float)emu_shfl_f64((double)v
 inline double shfl_xor_f64(double v, int m) { return emu_shfl_f64(v, emu::lane() ^ m); }
 inline double shfl_down_f64(double v, int d) { return emu_shfl_f64(v, emu::lane() + d); }
 inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
+inline double readlane_f64(double v, int l) { return emu_shfl_f64(v, l); }
+inline bool wave_any(bool p) {
+    double m = p ? 1.0 : 0.0;
+    for (int s = 32; s >= 1; s >>= 1) m = std::max(m, emu_shfl_f64(m, emu::lane() ^ s));
+    return m > 0.0;
+}
 inline void wave_sync() { emu::wave().bar.arrive_and_wait(); }
 inline void lds_barrier() { emu::tl.blk->bar.arrive_and_wait(); }
 inline void wave_fence() { emu::wave().bar.arrive_and_wait(); }
