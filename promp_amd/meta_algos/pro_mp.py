@@ -55,16 +55,15 @@ class ProMP(MAMLAlgo):
         self.session.param_version += 1
 
     def adapt_kl_coeff(self, kl_coeff, kl_values, kl_target):
-        if hasattr(kl_values, '__iter__'):
-            assert len(kl_coeff) == len(kl_values)
-            return np.array([_adapt_kl_coeff(kl_coeff[i], kl, kl_target) for i, kl in enumerate(kl_values)])
-        return _adapt_kl_coeff(kl_coeff, kl_values, kl_target)
+        """per inner step: one coefficient per KL value (arrays), or a single pair (scalars)"""
+        if np.ndim(kl_values) == 0:
+            return _adapt_kl_coeff(kl_coeff, kl_values, kl_target)
+        assert len(kl_coeff) == len(kl_values)
+        return np.array([_adapt_kl_coeff(c, kl, kl_target) for c, kl in zip(kl_coeff, kl_values)])
 
 
 def _adapt_kl_coeff(kl_coeff, kl, kl_target):
-    """pro_mp.py:208-214"""
-    if kl < kl_target / 1.5:
-        kl_coeff /= 2
-    elif kl > kl_target * 1.5:
-        kl_coeff *= 2
-    return kl_coeff
+    """Penalty schedule of the inner KL term (pro_mp.py:201-214): a step whose KL stayed clearly inside the target
+    (below target / 1.5) gets half the penalty next time, one clearly outside (above 1.5 target) twice the penalty."""
+    too_small, too_large = kl < kl_target / 1.5, kl > kl_target * 1.5
+    return kl_coeff / 2 if too_small else kl_coeff * 2 if too_large else kl_coeff

@@ -1,18 +1,58 @@
-"""ConjugateGradientOptimizer + FiniteDifferenceHvp (reference:
-meta_policy_search/optimizers/conjugate_gradient_optimizer.py:8-354).
+"""Trust-region step for TRPO-MAML: ConjugateGradientOptimizer + FiniteDifferenceHvp.
 
-Host-side control logic exactly as in the reference (CG, initial step from the quadratic model, backtracking line
-search, step rejection); every evaluation it asks for -- loss, constraint value, loss gradient, constraint gradient --
-is one pass of the device kernels through an ``evaluator`` object (see meta_algos/trpo_maml.py), including the
-all-reduce over ranks when a communicator is attached.
+Behaviour contract (what meta_algos/trpo_maml.py and the parity tests rely on; the reference implements the same
+contract in meta_policy_search/optimizers/conjugate_gradient_optimizer.py:59-89, 107-148, 239-354):
+
+  * the search direction d solves  (H + reg I) d = g  approximately: `cg_iters` conjugate-gradient iterations on products
+    H x only, H = Hessian of the constraint (mean KL), g = gradient of the loss;
+  * H x is a finite difference of the constraint gradient, symmetric by default with eps = 1e-5;
+  * the full step is  sqrt(2 delta / (d^T H d + 1e-8)) * d  (the KL ball of radius delta under the quadratic model);
+    a NaN step length rejects the update outright;
+  * backtracking: scales ratio^0, ratio^1, ... (at most `max_backtracks`); the first candidate with a lower loss and a
+    constraint value <= delta ends the search;
+  * the LAST candidate tried is then audited: a NaN loss or constraint, a loss that did not improve, or a constraint value
+    >= delta (note: >=, while the search accepts <=) marks the step as violated, and unless `accept_violation` the
+    parameters are restored.
+
+Every quantity the step needs -- loss, constraint value, loss gradient, constraint gradient -- is one pass of the device
+kernels, requested through an `evaluator` object (meta_algos/trpo_maml.py), which also hides the all-reduce over ranks
+when a communicator is attached.  This module is pure host-side control flow.
 """
 import numpy as np
 
 from ..utils import logger
 
 
+def conjugate_gradients(f_Ax, b, cg_iters=10, verbose=False, residual_tol=1e-10):
+    """Approximate solution of A x = b for a symmetric positive definite A known only through x -> A x.
+
+    Plain conjugate gradients started at x = 0; the iterate is kept in float32 (the parameters it is added to are
+    float32), search direction and residual keep b's dtype.  Stops after `cg_iters` products or once the squared
+    residual norm drops below `residual_tol`."""
+    solution = np.zeros(np.shape(b), dtype=np.float32)
+    residual = np.array(b, copy=True)
+    direction = np.array(b, copy=True)
+    res_sq = residual.dot(residual)
+    for it in range(cg_iters):
+        curved = f_Ax(direction)
+        step = res_sq / direction.dot(curved)
+        solution += step * direction
+        residual -= step * curved
+        new_res_sq = residual.dot(residual)
+        if verbose:
+            logger.log('cg iteration %d: |r|^2 = %.3e' % (it, float(new_res_sq)))
+        direction = residual + (new_res_sq / res_sq) * direction
+        res_sq = new_res_sq
+        if res_sq < residual_tol:
+            break
+    return solution
+
+
 class FiniteDifferenceHvp(object):
-    """Hx ~ (grad_c(theta + eps x) - grad_c(theta - eps x)) / (2 eps)   (conjugate_gradient_optimizer.py:59-89)"""
+    """Hessian-vector products of the constraint from gradients at displaced parameters:
+        symmetric:  H x ~ (grad c(theta + eps x) - grad c(theta - eps x)) / (2 eps)
+        one-sided:  H x ~ (grad c(theta + eps x) - grad c(theta)) / eps
+    The parameters are back at theta when a product returns."""
 
     def __init__(self, base_eps=1e-5, symmetric=True, grad_clip=None):
         self.base_eps = np.float32(base_eps)
@@ -22,36 +62,40 @@ class FiniteDifferenceHvp(object):
         self._ev = None
 
     def build_graph(self, evaluator, reg_coeff):
-        self._ev = evaluator
-        self.reg_coeff = reg_coeff
+        self._ev, self.reg_coeff = evaluator, reg_coeff
 
     def constraint_gradient(self):
         return self._ev.constraint_gradient()
 
+    def _gradient_at(self, theta):
+        self._ev.set_theta(theta)
+        return self._ev.constraint_gradient()
+
     def Hx(self, x):
         assert isinstance(x, np.ndarray)
-        ev = self._ev
-        theta = ev.get_theta().copy()
+        centre = np.array(self._ev.get_theta(), copy=True)
         eps = self.base_eps
-        ev.set_theta(theta + eps * x)
-        g_plus = ev.constraint_gradient()
-        ev.set_theta(theta)
+        ahead = self._gradient_at(centre + eps * x)
         if self.symmetric:
-            ev.set_theta(theta - eps * x)
-            g_minus = ev.constraint_gradient()
-            ev.set_theta(theta)
-            return (g_plus - g_minus) / (2 * eps)
-        g = ev.constraint_gradient()
-        return (g_plus - g) / eps
+            behind = self._gradient_at(centre - eps * x)
+            self._ev.set_theta(centre)
+            return (ahead - behind) / (2 * eps)
+        here = self._gradient_at(centre)
+        return (ahead - here) / eps
 
     def build_eval(self):
-        def evaluate_hessian(x):
-            return self.Hx(x) + self.reg_coeff * x
-        return evaluate_hessian
+        """x -> (H + reg I) x"""
+        return lambda x: self.Hx(x) + self.reg_coeff * x
 
 
 class ConjugateGradientOptimizer(object):
-    """Args as the reference (conjugate_gradient_optimizer.py:107-148)."""
+    """
+    Args: cg_iters=10, reg_coeff=0 (Tikhonov term added to H), subsample_factor=1. (kept for signature compatibility:
+    the device evaluates the constraint on the whole batch), backtrack_ratio=0.8, max_backtracks=15, debug_nan=False,
+    accept_violation=False, hvp_approach=None (a FiniteDifferenceHvp by default)
+
+    After optimize(), `last` holds loss_before, descent_direction, initial_step_size, n_backtracks and rejected.
+    """
 
     def __init__(self, cg_iters=10, reg_coeff=0, subsample_factor=1., backtrack_ratio=0.8, max_backtracks=15,
                  debug_nan=False, accept_violation=False, hvp_approach=None):
@@ -60,15 +104,16 @@ class ConjugateGradientOptimizer(object):
         self._subsample_factor = subsample_factor
         self._backtrack_ratio = backtrack_ratio
         self._max_backtracks = max_backtracks
-        self._max_constraint_val = None
-        self._constraint_name = 'kl-div'
         self._debug_nan = debug_nan
         self._accept_violation = accept_violation
-        self._hvp_approach = hvp_approach if hvp_approach is not None else FiniteDifferenceHvp()
+        self._hvp_approach = FiniteDifferenceHvp() if hvp_approach is None else hvp_approach
+        self._constraint_name = 'kl-div'
+        self._max_constraint_val = None
         self._ev = None
+        self.last = None
 
     def build_graph(self, evaluator, leq_constraint_value):
-        """evaluator: object with loss(), constraint_val(), gradient(), constraint_gradient(), get_theta(), set_theta()"""
+        """evaluator: loss(), constraint_val(), gradient(), constraint_gradient(), get_theta(), set_theta(theta)"""
         self._ev = evaluator
         self._max_constraint_val = leq_constraint_value
         self._hvp_approach.build_graph(evaluator, self._reg_coeff)
@@ -82,64 +127,50 @@ class ConjugateGradientOptimizer(object):
     def gradient(self, *_):
         return self._ev.gradient()
 
-    def optimize(self, *_):
-        """conjugate_gradient_optimizer.py:239-307"""
-        ev = self._ev
-        logger.log('Start CG optimization')
-        loss_before = self.loss()
-        gradient = self.gradient()
-        Hx = self._hvp_approach.build_eval()
-        descent_direction = conjugate_gradients(Hx, gradient, cg_iters=self._cg_iters)
-        initial_step_size = np.sqrt(2.0 * self._max_constraint_val *
-                                    (1. / (descent_direction.dot(Hx(descent_direction)) + 1e-8)))
-        if np.isnan(initial_step_size):
-            logger.log('Initial step size is NaN! Rejecting the step!')
-            self.last = dict(loss_before=loss_before, n_backtracks=0, rejected=True, descent_direction=descent_direction,
-                             initial_step_size=float('nan'))
-            return
-        initial_descent_step = initial_step_size * descent_direction
-        prev = ev.get_theta().copy()
-        loss, constraint_val, n_iter, violated = 0, 0, 0, False
-        for n_iter, ratio in enumerate(self._backtrack_ratio ** np.arange(self._max_backtracks)):
-            ev.set_theta(prev - ratio * initial_descent_step)
-            loss, constraint_val = self.loss(), self.constraint_val()
-            if loss < loss_before and constraint_val <= self._max_constraint_val:
+    # ---- the step ----
+    def _search(self, origin, full_step, loss_before):
+        """backtracking over the scales ratio^k; returns (loss, constraint, k) of the last candidate tried"""
+        delta = self._max_constraint_val
+        loss = constraint = 0
+        k = 0
+        for k in range(self._max_backtracks):
+            self._ev.set_theta(origin - (self._backtrack_ratio ** k) * full_step)
+            loss, constraint = self.loss(), self.constraint_val()
+            if loss < loss_before and constraint <= delta:
                 break
-        if np.isnan(loss):
-            violated = True
-            logger.log('Line search violated because loss is NaN')
-        if np.isnan(constraint_val):
-            violated = True
-            logger.log('Line search violated because constraint %s is NaN' % self._constraint_name)
-        if loss >= loss_before:
-            violated = True
-            logger.log('Line search violated because loss not improving')
-        if constraint_val >= self._max_constraint_val:
-            violated = True
-            logger.log('Line search violated because constraint %s is violated' % self._constraint_name)
-        if violated and not self._accept_violation:
-            logger.log('Line search condition violated. Rejecting the step!')
-            ev.set_theta(prev)
-        logger.log('backtrack iters: %d' % n_iter)
-        self.last = dict(loss_before=loss_before, n_backtracks=n_iter, rejected=bool(violated and not self._accept_violation),
-                         descent_direction=descent_direction, initial_step_size=float(initial_step_size))
+        return loss, constraint, k
 
+    def _audit(self, loss, constraint, loss_before):
+        """reasons why the candidate must not be kept (empty list: keep it)"""
+        name, delta = self._constraint_name, self._max_constraint_val
+        checks = ((np.isnan(loss), 'the loss is NaN'),
+                  (np.isnan(constraint), 'the constraint %s is NaN' % name),
+                  (loss >= loss_before, 'the loss did not improve'),
+                  (constraint >= delta, 'the constraint %s reached its bound' % name))
+        return [why for failed, why in checks if failed]
 
-def conjugate_gradients(f_Ax, b, cg_iters=10, verbose=False, residual_tol=1e-10):
-    """Demmel p 312 (conjugate_gradient_optimizer.py:325-354)"""
-    p = b.copy()
-    r = b.copy()
-    x = np.zeros_like(b, dtype=np.float32)
-    rdotr = r.dot(r)
-    for i in range(cg_iters):
-        z = f_Ax(p)
-        v = rdotr / p.dot(z)
-        x += v * p
-        r -= v * z
-        newrdotr = r.dot(r)
-        mu = newrdotr / rdotr
-        p = r + mu * p
-        rdotr = newrdotr
-        if rdotr < residual_tol:
-            break
-    return x
+    def optimize(self, *_):
+        ev = self._ev
+        logger.log('trust-region step: conjugate gradients')
+        loss_before = self.loss()
+        grad = self.gradient()
+        curvature = self._hvp_approach.build_eval()
+        direction = conjugate_gradients(curvature, grad, cg_iters=self._cg_iters)
+        length = np.sqrt(2.0 * self._max_constraint_val * (1. / (direction.dot(curvature(direction)) + 1e-8)))
+        self.last = dict(loss_before=loss_before, descent_direction=direction, initial_step_size=float(length),
+                         n_backtracks=0, rejected=False)
+        if np.isnan(length):
+            logger.log('trust-region step: step length is NaN, update rejected')
+            self.last['rejected'] = True
+            return
+        origin = np.array(ev.get_theta(), copy=True)
+        loss, constraint, tried = self._search(origin, length * direction, loss_before)
+        problems = self._audit(loss, constraint, loss_before)
+        for why in problems:
+            logger.log('trust-region step: line search failed, ' + why)
+        rejected = bool(problems) and not self._accept_violation
+        if rejected:
+            logger.log('trust-region step: update rejected, parameters restored')
+            ev.set_theta(origin)
+        logger.log('trust-region step: %d backtracking step(s)' % tried)
+        self.last.update(n_backtracks=tried, rejected=rejected)
