@@ -146,19 +146,41 @@ int promp_inner_adapt(promp_ctx* ctx, int step, int inner_kind);
  * obs [n_tasks, batch, O] -> mean_out [n_tasks, batch, A].  The Gaussian noise is added by the caller. */
 int promp_policy_forward(promp_ctx* ctx, const float* obs, int batch, float* mean_out);
 
-/* ---- a whole rollout on the device: the 2-D point-mass meta-environment of BASELINE
- * config 0 (run_scripts/pro-mp_run_point_mass.py; the reference steps it in NumPy,
- * envs/point_envs/point_env_2d_corner.py, and collects paths in samplers/meta_sampler.py:59-137).
- * Every environment (envs_per_task per task) runs path_length steps under its task's CURRENT parameters:
- *   obs = state; mean = policy(obs); action = mean + exp(log_std) * noise; state += clip(action, +-0.1);
- *   reward = -|state - goal|
- * and the trajectories land in step `step`'s slab as n_tasks * envs_per_task fixed-length paths, ready for
- * promp_process_samples (no upload).  goals [n_tasks][2], start [n_tasks][envs_per_task][2] (float64 like the NumPy
- * environment), noise [n_tasks][envs_per_task][path_length][2] standard normals drawn by the caller.
- * clip_infos != 0: the log_std recorded for agent_infos is max(log_std, log 1e-6) (pre-update policy,
- * policies/gaussian_mlp_policy.py:71); the noise scale always uses the raw value (:74).  Asynchronous. */
+/* ---- rollouts that fill the step slab on the device -------------------------------
+ * A device-side rollout lays the sampling step out as n_tasks * envs_per_task fixed-length paths:
+ * path p of task i = rows [(i B + p) T, (i B + p + 1) T).
+ *
+ * (a) environments stepped by the host (MuJoCo ...): promp_begin_rollout once per sampling step, then per
+ *     environment step t = 0 .. T-1 promp_policy_step: observations [n_tasks][B][O] in, actions [n_tasks][B][A] out.
+ *     The device evaluates each task's mean network under its current parameters, draws the exploration noise
+ *     (Philox4x32-10 keyed by `seed`, counter = slab row, Box-Muller), and writes observation, action and mean
+ *     into the slab at row (task, env, t): what policies/meta_gaussian_mlp_policy.py:99-157 +
+ *     samplers/meta_sampler.py:87-125 do with one sess.run and a Python loop per environment step.  The rewards
+ *     follow once at the end (promp_set_rewards, float32 [rows]); promp_process_samples then needs no upload.
+ *     clip_infos != 0: the log_std recorded for agent_infos is max(log_std, log 1e-6) (pre-update policy,
+ *     policies/gaussian_mlp_policy.py:71); the noise scale always uses the raw value (:74). */
+int promp_begin_rollout(promp_ctx* ctx, int step, int envs_per_task, int path_length);
+int promp_policy_step(promp_ctx* ctx, int step, int t, const float* obs, uint64_t seed, int clip_infos, float* actions_out);
+int promp_set_rewards(promp_ctx* ctx, int step, const float* rewards);
+
+/* (b) the 2-D point-mass meta-environment of BASELINE config 1, run_scripts/pro-mp_run_point_mass.py:
+ *     normalize(MetaPointEnvCorner()) -- whole rollouts in one launch, one thread per environment:
+ *       e = lb + (a + s)(ub - lb)/(2 s), clipped to [lb, ub]             envs/normalized_env.py:109-123: the normalize wrapper,
+ *                                                                        s = normalization_scale (10), [lb, ub] = -+max_step;
+ *                                                                        s = 0: bare environment, e = a
+ *       state += clip(e, -max_step, max_step)                            envs/point_envs/point_env_2d_corner.py:37
+ *       reward_type 0 dense -|s' - goal|, 1 dense_squared, 2 sparse      point_env_2d_corner.py:62-81
+ *       no early termination                                             point_env_2d_corner.py:39
+ *     goals [n_tasks][2], start [n_tasks][envs_per_task][2] (float64 like the NumPy environment);
+ *     noise [n_tasks][envs_per_task][path_length][2] standard normals drawn by the caller, or NULL: drawn on the device
+ *     from `seed` as in (a).  Asynchronous. */
+typedef struct {
+    double normalization_scale, max_step, sparse_radius;
+    int32_t reward_type, clip_infos;
+    uint64_t seed;
+} promp_point_env_opts;
 int promp_rollout_point_env(promp_ctx* ctx, int step, int envs_per_task, int path_length, const double* goals,
-                            const double* start, const float* noise, int clip_infos);
+                            const double* start, const float* noise, const promp_point_env_opts* opts);
 
 /* Step slab back on the host (any pointer may be NULL): obs [rows][O], act [rows][A], rew [rows],
  * old_mean [rows][A], old_log_std [rows | n_tasks][A] as uploaded / produced by a device rollout. */

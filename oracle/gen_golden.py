@@ -16,6 +16,11 @@ TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python oracle/gen_golden.py
     transcription of the TF graph's forward arithmetic.  TensorFlow is absent, so this is the
     independent autodiff that pins oracle/promp.py's hand-derived gradient + HVP.
 
+  * point_env_<reward type>.npz : trajectories of the reference's own normalize(MetaPointEnvCorner(reward_type)) (BASELINE
+    config 1, run_scripts/pro-mp_run_point_mass.py) under given action sequences: start states, goals, policy-scale actions,
+    next states and rewards.  The env modules import gym / rand_param_envs (absent) only for `spaces.Box`; a minimal Box
+    (low / high / shape attributes) lets the import go through -- only the reference's NumPy code is executed.
+
 Only data (inputs and expected outputs) is written; no reference source is copied.
 /root/reference does not exist on the GPU box: nothing imports this module at test time.
 """
@@ -244,6 +249,59 @@ def gen_promp():
         print('wrote promp_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
 
 
+def gen_point_env():
+    sys.path.insert(0, '/root/reference')
+
+    class Box(object):
+        def __init__(self, low, high, shape=None, dtype=None):
+            self.low = np.broadcast_to(np.asarray(low, dtype=np.float64), shape if shape is not None else np.shape(low)).copy()
+            self.high = np.broadcast_to(np.asarray(high, dtype=np.float64), shape if shape is not None else np.shape(high)).copy()
+            self.shape = self.low.shape
+    for name in ('gym', 'gym.core', 'gym.spaces', 'gym.envs', 'gym.envs.mujoco', 'rand_param_envs', 'rand_param_envs.gym',
+                 'rand_param_envs.gym.spaces'):
+        mod = types.ModuleType(name)
+        mod.Box = Box
+        mod.Env = object
+        mod.MujocoEnv = object
+        mod.__path__ = []
+        sys.modules.setdefault(name, mod)
+    sys.modules['gym'].spaces = sys.modules['gym.spaces']
+    sys.modules['gym'].core = sys.modules['gym.core']
+    sys.modules['rand_param_envs'].gym = sys.modules['rand_param_envs.gym']
+    sys.modules['rand_param_envs.gym'].spaces = sys.modules['rand_param_envs.gym.spaces']
+    import io
+    import contextlib
+    from meta_policy_search.envs.point_envs.point_env_2d_corner import MetaPointEnvCorner
+    from meta_policy_search.envs.normalized_env import normalize
+    for reward_type in ('dense', 'dense_squared', 'sparse'):
+        rng = np.random.RandomState({'dense': 31, 'dense_squared': 32, 'sparse': 33}[reward_type])
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = normalize(MetaPointEnvCorner(reward_type=reward_type))
+        np.random.seed(int(rng.randint(1 << 30)))
+        goals = env.sample_tasks(6)
+        B, T = len(goals), 60
+        start = np.zeros((B, 2))
+        actions = np.zeros((B, T, 2))
+        nxt = np.zeros((B, T, 2))
+        rew = np.zeros((B, T))
+        for b, goal in enumerate(goals):
+            env.set_task(goal)
+            start[b] = env.reset()
+            # policy-scale actions: a drift towards the goal (so that the sparse reward fires) plus noise, with entries
+            # beyond +-10 (the wrapper's clip) in some rows
+            drift = 6.0 * np.sign(goal) * (1.0 if b % 2 == 0 else -0.5)
+            actions[b] = drift + 5.0 * rng.randn(T, 2)
+            for t in range(T):
+                o, r, done, info = env.step(actions[b, t])
+                assert done is False and info == {}
+                nxt[b, t], rew[b, t] = o, r
+        np.savez(os.path.join(GOLDEN, 'point_env_%s.npz' % reward_type), goals=np.asarray(goals, dtype=np.float64), start=start,
+                 actions=actions, next_states=nxt, rewards=rew,
+                 action_low=np.asarray(env._wrapped_env.action_space.low), action_high=np.asarray(env._wrapped_env.action_space.high),
+                 normalization_scale=float(env._normalization_scale), sparse_reward_radius=float(env._wrapped_env.sparse_reward_radius))
+        print('wrote point_env_%s.npz  (nonzero rewards: %d of %d)' % (reward_type, int(np.count_nonzero(rew)), rew.size))
+
+
 def gen_dist_reference():
     """the reference's NumPy distribution arithmetic and KL-coefficient rule, run here, saved as vectors"""
     class _Anything(object):
@@ -286,3 +344,4 @@ if __name__ == '__main__':
         gen_sample_proc()
         gen_promp()
     gen_dist_reference()
+    gen_point_env()

@@ -38,6 +38,13 @@ class ProcOpts(C.Structure):
                 ('reserved', C.c_int32)]
 
 
+class PointEnvOpts(C.Structure):
+    _fields_ = [('normalization_scale', C.c_double), ('max_step', C.c_double), ('sparse_radius', C.c_double),
+                ('reward_type', C.c_int32), ('clip_infos', C.c_int32), ('seed', C.c_uint64)]
+
+
+POINT_REWARD = dict(dense=0, dense_squared=1, sparse=2)
+
 _F = C.POINTER(C.c_float)
 _D = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int32)
@@ -70,7 +77,10 @@ SIGNATURES = {
     'promp_get_task_thetas': (C.c_int, [_P, _F]),
     'promp_inner_adapt': (C.c_int, [_P, C.c_int, C.c_int]),
     'promp_policy_forward': (C.c_int, [_P, _F, C.c_int, _F]),
-    'promp_rollout_point_env': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D, _D, _F, C.c_int]),
+    'promp_rollout_point_env': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D, _D, _F, C.POINTER(PointEnvOpts)]),
+    'promp_begin_rollout': (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    'promp_policy_step': (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_uint64, C.c_int, _F]),
+    'promp_set_rewards': (C.c_int, [_P, C.c_int, _F]),
     'promp_download_step': (C.c_int, [_P, C.c_int, _F, _F, _F, _F, _F]),
     'promp_meta_grad': (C.c_int, [_P, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
     'promp_adam_step': (C.c_int, [_P, C.c_float]),
@@ -275,18 +285,49 @@ class Context:
         self._call('promp_policy_forward', _ptr(obs, C.c_float), int(obs.shape[1]), _ptr(out, C.c_float))
         return out
 
-    def rollout_point_env(self, step, goals, start, noise, clip_infos=True):
-        """Device rollout of the 2-D point-mass meta-environment: goals [M,2], start [M,B,2] (float64), noise [M,B,T,2]
-        standard normals -> fills step `step`'s slab with M*B paths of length T (see promp_rollout_point_env)."""
+    def rollout_point_env(self, step, goals, start, noise=None, clip_infos=True, reward_type='dense', normalization_scale=0.0,
+                          max_step=0.2, sparse_radius=0.5, seed=0, path_length=None):
+        """Device rollout of the 2-D point-mass meta-environment (normalize(MetaPointEnvCorner()) with normalization_scale=10; 0 = the bare environment):
+        goals [M,2], start [M,B,2] (float64), noise [M,B,T,2] standard normals or None (drawn on the device from `seed`;
+        then path_length is required) -> fills step `step`'s slab with M*B paths of length T (see promp_rollout_point_env)."""
         goals = np.ascontiguousarray(goals, dtype=np.float64)
         start = np.ascontiguousarray(start, dtype=np.float64)
-        noise = _f32(noise)
-        M, B, T = self.n_tasks, start.shape[1], noise.shape[2]
-        assert goals.shape == (M, 2) and start.shape == (M, B, 2) and noise.shape == (M, B, T, 2)
+        M, B = self.n_tasks, start.shape[1]
+        if noise is not None:
+            noise = _f32(noise)
+            T = noise.shape[2]
+            assert noise.shape == (M, B, T, 2)
+        else:
+            T = int(path_length)
+        assert goals.shape == (M, 2) and start.shape == (M, B, 2)
+        opts = PointEnvOpts(float(normalization_scale), float(max_step), float(sparse_radius), POINT_REWARD[reward_type],
+                            int(bool(clip_infos)), int(seed))
         self._call('promp_rollout_point_env', int(step), int(B), int(T), _ptr(goals, C.c_double), _ptr(start, C.c_double),
-                   _ptr(noise, C.c_float), int(bool(clip_infos)))
+                   _ptr(noise, C.c_float) if noise is not None else None, C.byref(opts))
         self.step_rows[step], self.step_paths[step] = M * B * T, M * B
         self.step_ls_rows[step] = M
+
+    def begin_rollout(self, step, envs_per_task, path_length):
+        """lay step `step` out as n_tasks * envs_per_task fixed-length paths for policy_step to fill"""
+        self._call('promp_begin_rollout', int(step), int(envs_per_task), int(path_length))
+        self._rollout_shape = (int(envs_per_task), int(path_length))
+        self.step_rows[step] = self.n_tasks * envs_per_task * path_length
+        self.step_paths[step] = self.n_tasks * envs_per_task
+        self.step_ls_rows[step] = self.n_tasks
+
+    def policy_step(self, step, t, obs, seed=0, clip_infos=True):
+        """obs [M, B, O] -> actions [M, B, A]; observation, action and mean land in the slab at row (task, env, t)"""
+        B = self._rollout_shape[0]
+        obs = _f32(obs).reshape(self.n_tasks, B, self.dims.obs_dim)
+        out = np.empty((self.n_tasks, B, self.dims.act_dim), np.float32)
+        self._call('promp_policy_step', int(step), int(t), _ptr(obs, C.c_float), int(seed), int(bool(clip_infos)),
+                   _ptr(out, C.c_float))
+        return out
+
+    def set_rewards(self, step, rewards):
+        r = _f32(rewards).reshape(-1)
+        assert r.size == self.step_rows[step]
+        self._call('promp_set_rewards', int(step), _ptr(r, C.c_float))
 
     def download_step(self, step):
         """the slab of a sampling step back on the host: dict(obs, act, rew, old_mean, old_log_std)"""

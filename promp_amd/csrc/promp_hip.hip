@@ -50,6 +50,7 @@ int fail(int code, const char* fmt, ...) {
 struct StepData {
     int n_paths = 0, n_rows = 0;
     int n_work[2] = {0, 0};            // [0]: one workgroup per CU (wide passes, gram, fit), [1]: two per CU (k_normalize)
+    int rollout_B = 0, rollout_T = 0;  // environments per task / horizon of a device-side rollout in progress (promp_begin_rollout)
     int n_pwork = 0;                   // k_fwd_bwd workgroups (wave-granular PassWork table)
     int n_chain_wg = 0;                // k_chain_hvp workgroups (segment table)
     bool has_policy = false, processed = false, has_adv = false;
@@ -356,7 +357,7 @@ void free_step(StepData& S) {
 extern "C" {
 
 const char* promp_last_error(void) { return g_err.c_str(); }
-int promp_abi_version(void) { return 1; }
+int promp_abi_version(void) { return 2; }
 
 int promp_param_count(const promp_dims* d) {
     if (!d) return fail(-1, "dims is NULL");
@@ -1001,43 +1002,104 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     return 0;
 }
 
-int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_length, const double* goals,
-                            const double* start, const float* noise, int clip_infos) {
-    if (!c || !goals || !start || !noise) return fail(-1, "NULL argument");
-    if (c->d.obs_dim != 2 || c->d.act_dim != 2) return fail(-1, "the point environment has obs_dim = act_dim = 2 (context: %d, %d)", c->d.obs_dim, c->d.act_dim);
-    if (envs_per_task < 1 || path_length < 1) return fail(-1, "envs_per_task and path_length must be positive");
-    const int M = c->d.n_tasks, B = envs_per_task, T = path_length;
+// fixed-length layout of a device-side rollout: path p of task i is rows [(i B + p) T, (i B + p + 1) T)
+static int begin_fixed_rollout(promp_ctx* c, int step, int B, int T) {
+    if (B < 1 || T < 1) return fail(-1, "envs_per_task and path_length must be positive");
+    const int M = c->d.n_tasks;
     const long long rows = (long long)M * B * T;
     if (rows > c->d.max_rows) return fail(-1, "rollout of %lld rows exceeds max_rows = %d", rows, c->d.max_rows);
-    // fixed-length paths: path p of task i is rows [(i B + p) T, (i B + p + 1) T)
     std::vector<int32_t> tpo(M + 1), pro((size_t)M * B + 1);
     for (int i = 0; i <= M; ++i) tpo[i] = i * B;
     for (int p = 0; p <= M * B; ++p) pro[p] = p * T;
     if (set_step_layout(c, step, M * B, tpo.data(), pro.data())) return -2;
     StepData& S = c->steps[step];
-    const size_t need = sizeof(double) * ((size_t)M * 2 + (size_t)M * B * 2) + sizeof(float) * (size_t)rows * 2;
+    S.has_policy = true;
+    S.ls_per_row = 0;
+    S.rollout_B = B; S.rollout_T = T;
+    return 0;
+}
+
+static int ensure_rollout_buf(promp_ctx* c, size_t need) {
     if (need > c->rollout_capacity) {
         if (c->rollout_buf) (void)hipFree(c->rollout_buf);
         c->rollout_buf = nullptr;
         c->rollout_capacity = 2 * need;
         HIPCHECK(hipMalloc((void**)&c->rollout_buf, c->rollout_capacity));
     }
+    return 0;
+}
+
+int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_length, const double* goals,
+                            const double* start, const float* noise, const promp_point_env_opts* o) {
+    if (!c || !goals || !start || !o) return fail(-1, "NULL argument");
+    if (c->d.obs_dim != 2 || c->d.act_dim != 2) return fail(-1, "the point environment has obs_dim = act_dim = 2 (context: %d, %d)", c->d.obs_dim, c->d.act_dim);
+    if (c->d.hidden1 > 128 || c->d.hidden2 > 128) return fail(-1, "hidden widths above 128 are not supported by the rollout kernels");
+    if (o->reward_type < 0 || o->reward_type > 2) return fail(-1, "unknown reward type %d", o->reward_type);
+    if (begin_fixed_rollout(c, step, envs_per_task, path_length)) return -2;
+    const int M = c->d.n_tasks, B = envs_per_task, T = path_length;
+    const long long rows = (long long)M * B * T;
+    StepData& S = c->steps[step];
+    const size_t need = sizeof(double) * ((size_t)M * 2 + (size_t)M * B * 2) + sizeof(float) * (size_t)rows * 2;
+    if (ensure_rollout_buf(c, need)) return -2;
     double* d_goals = (double*)c->rollout_buf;
     double* d_start = d_goals + (size_t)M * 2;
     float* d_noise = (float*)(d_start + (size_t)M * B * 2);
     hipStream_t st = c->stream;
     HIPCHECK(hipMemcpyAsync(d_goals, goals, sizeof(double) * M * 2, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(d_start, start, sizeof(double) * M * B * 2, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(d_noise, noise, sizeof(float) * rows * 2, hipMemcpyHostToDevice, st));
+    if (noise) HIPCHECK(hipMemcpyAsync(d_noise, noise, sizeof(float) * rows * 2, hipMemcpyHostToDevice, st));
     PointRolloutArgs a;
     a.theta_tasks = c->theta_tasks; a.NP = c->NP; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2;
-    a.B = B; a.T = T; a.goals = d_goals; a.start = d_start; a.noise = d_noise;
+    a.B = B; a.T = T; a.goals = d_goals; a.start = d_start; a.noise = noise ? d_noise : nullptr;
+    a.seed = o->seed; a.stream = (unsigned)step;
     a.obs = S.obs; a.act = S.act; a.rew = S.rew; a.mean = S.old_mean; a.old_ls = S.old_ls;
-    a.clip_infos = clip_infos; a.min_log_std = logf(1e-6f); a.max_step = 0.1;
+    a.clip_infos = o->clip_infos; a.min_log_std = logf(1e-6f);
+    a.normalization_scale = o->normalization_scale; a.max_step = o->max_step; a.reward_type = o->reward_type; a.sparse_radius = o->sparse_radius;
     PROMP_LAUNCH(k_point_rollout, dim3(M), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
-    S.has_policy = true;
-    S.ls_per_row = 0;
+    return 0;
+}
+
+int promp_begin_rollout(promp_ctx* c, int step, int envs_per_task, int path_length) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (c->d.hidden1 > 128 || c->d.hidden2 > 128 || c->d.act_dim > 8) return fail(-1, "shape not supported by the rollout kernels");
+    return begin_fixed_rollout(c, step, envs_per_task, path_length);
+}
+
+int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t seed, int clip_infos, float* actions_out) {
+    if (!c || !obs || !actions_out) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (S.rollout_B < 1) return fail(-3, "promp_begin_rollout has not been called for step %d", step);
+    const int M = c->d.n_tasks, B = S.rollout_B, T = S.rollout_T, O = c->d.obs_dim, A = c->d.act_dim;
+    if (t < 0 || t >= T) return fail(-1, "time step %d outside the horizon %d", t, T);
+    const size_t n_obs = (size_t)M * B * O, n_act = (size_t)M * B * A;
+    if (ensure_rollout_buf(c, sizeof(float) * (n_obs + n_act))) return -2;
+    float* d_obs = (float*)c->rollout_buf;
+    float* d_act = d_obs + n_obs;
+    hipStream_t st = c->stream;
+    HIPCHECK(hipMemcpyAsync(d_obs, obs, sizeof(float) * n_obs, hipMemcpyHostToDevice, st));
+    PolicyStepArgs a;
+    a.obs_in = d_obs; a.theta_tasks = c->theta_tasks;
+    a.obs = S.obs; a.act = S.act; a.mean = S.old_mean; a.old_ls = S.old_ls; a.actions_out = d_act;
+    a.B = B; a.T = T; a.t = t; a.O = O; a.A = A; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2; a.NP = c->NP;
+    a.clip_infos = clip_infos; a.min_log_std = logf(1e-6f);
+    a.seed = seed; a.stream = (unsigned)step;
+    PROMP_LAUNCH(k_policy_step, dim3((B + 63) / 64, M), 64, 0, st, a);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(actions_out, d_act, sizeof(float) * n_act, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int promp_set_rewards(promp_ctx* c, int step, const float* rew) {
+    if (!c || !rew) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    S.processed = false;
     return 0;
 }
 

@@ -1,7 +1,7 @@
 """Rollouts of the 2-D point-mass meta-environment collected ON THE DEVICE.
 
-Same interface as MetaSampler (update_tasks / obtain_samples / total_timesteps_sampled), for environments of type
-promp_amd.envs.point_env.MetaPointEnv.  One kernel launch runs every environment for the whole horizon under its task's
+Same interface as MetaSampler (update_tasks / obtain_samples / total_timesteps_sampled), for the environment of BASELINE
+config 1: promp_amd.envs.point_env.MetaPointEnvCorner, bare or wrapped in promp_amd.envs.normalized_env.normalize.  One kernel launch runs every environment for the whole horizon under its task's
 current policy parameters and writes the trajectories straight into the sampling step's slab
 (promp_rollout_point_env); MetaSampleProcessor.process_samples then finds the data resident and uploads nothing.
 The host keeps what it is good at: drawing tasks, start states and the exploration noise from NumPy's RNG, and
@@ -19,12 +19,35 @@ class DevicePaths(OrderedDict):
     flat = None           # dict(task_path_offsets, path_row_offsets) of the resident slab
 
 
+def _point_env_options(env):
+    """(bare environment, kernel options) of MetaPointEnvCorner, wrapped in normalize(...) or not"""
+    from ..envs.normalized_env import NormalizedEnv
+    from ..envs.point_env import MetaPointEnvCorner
+    scale = 0.0                              # bare environment
+    if isinstance(env, NormalizedEnv):
+        assert not (env._normalize_obs or env._normalize_reward), 'running observation / reward normalisation is host-side state'
+        bare = env.wrapped_env
+        scale = float(env._normalization_scale)
+        assert np.allclose(bare.action_space.low, -bare.action_space.high)
+    else:
+        bare = env
+    assert isinstance(bare, MetaPointEnvCorner), 'the device environment is MetaPointEnvCorner (optionally normalize()d)'
+    return bare, dict(reward_type=bare.reward_type, normalization_scale=scale, max_step=float(bare.action_space.high[0]),
+                      sparse_radius=float(bare.sparse_reward_radius))
+
+
 class DevicePointEnvSampler(object):
+    """device_noise=False: start states and exploration noise come from NumPy's RNG (reproducible from np.random.seed, and
+    comparable step by step with the NumPy environment); True: the noise is drawn on the device (Philox4x32-10 keyed by a
+    seed taken from NumPy's RNG once per sampling step), nothing but goals and start states is uploaded."""
+
     def __init__(self, env, policy, rollouts_per_meta_task, meta_batch_size, max_path_length, envs_per_task=None,
-                 parallel=False):
+                 parallel=False, device_noise=False):
         assert hasattr(env, 'sample_tasks') and hasattr(env, 'set_task')
         assert policy.obs_dim == 2 and policy.action_dim == 2, 'the device environment is the 2-D point mass'
         self.env, self.policy = env, policy
+        self._bare, self._env_opts = _point_env_options(env)
+        self.device_noise = device_noise
         self.batch_size = rollouts_per_meta_task
         self.meta_batch_size = meta_batch_size
         self.max_path_length = max_path_length
@@ -46,11 +69,16 @@ class DevicePointEnvSampler(object):
         if sess.task_thetas is not None:           # parameters set while no context existed yet
             ctx.set_task_thetas(sess.task_thetas)
             sess.task_thetas = None
-        start = np.random.uniform(-0.2, 0.2, size=(M, B, 2))         # MetaPointEnv.reset
-        noise = np.random.normal(size=(M, B, T, 2)).astype(np.float32)
+        start = np.random.uniform(-0.2, 0.2, size=(M, B, 2))         # MetaPointEnvCorner.reset
         slot = sess.next_slot()
-        ctx.rollout_point_env(slot, self.goals, start, noise, clip_infos=self.policy._pre_update_mode)
-        sess.upload_serial[slot] += 1
+        if self.device_noise:
+            ctx.rollout_point_env(slot, self.goals, start, None, clip_infos=self.policy._pre_update_mode, path_length=T,
+                                  seed=int(np.random.randint(0, 2 ** 31 - 1)), **self._env_opts)
+        else:
+            noise = np.random.normal(size=(M, B, T, 2)).astype(np.float32)
+            ctx.rollout_point_env(slot, self.goals, start, noise, clip_infos=self.policy._pre_update_mode, **self._env_opts)
+        sess._upload_counter += 1
+        sess.upload_serial[slot] = sess._upload_counter
         slab = ctx.download_step(slot)
         paths = DevicePaths()
         for i in range(M):
@@ -59,7 +87,7 @@ class DevicePointEnvSampler(object):
             for b in range(B):
                 rows = slice((i * B + b) * T, (i * B + b + 1) * T)
                 paths[i].append(dict(observations=slab['obs'][rows], actions=slab['act'][rows], rewards=slab['rew'][rows],
-                                     env_infos=dict(goal_dist=-slab['rew'][rows].astype(np.float64)),
+                                     env_infos={},
                                      agent_infos=dict(mean=slab['old_mean'][rows], log_std=log_std)))
         paths.device_ref = (sess.serial, sess.upload_serial[slot], slot)
         paths.flat = dict(task_path_offsets=np.arange(M + 1, dtype=np.int32) * B,

@@ -14,7 +14,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from promp_amd.baselines.linear_baseline import LinearFeatureBaseline  # noqa: E402
-from promp_amd.envs.point_env import MetaPointEnv  # noqa: E402
+from promp_amd.envs.normalized_env import normalize  # noqa: E402
+from promp_amd.envs.point_env import MetaPointEnvCorner  # noqa: E402
 from promp_amd.meta_algos.pro_mp import ProMP  # noqa: E402
 from promp_amd.meta_trainer import Trainer  # noqa: E402
 from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy  # noqa: E402
@@ -24,7 +25,7 @@ from promp_amd.samplers.meta_sampler import MetaSampler  # noqa: E402
 from promp_amd.utils import logger  # noqa: E402
 
 DEFAULT = {
-    'seed': 1, 'baseline': 'LinearFeatureBaseline', 'env': 'MetaPointEnv',
+    'seed': 1, 'baseline': 'LinearFeatureBaseline', 'env': 'MetaPointEnvCorner', 'reward_type': 'sparse', 'normalize_env': True,
     'rollouts_per_meta_task': 20, 'max_path_length': 100, 'parallel': False,
     'discount': 0.99, 'gae_lambda': 1, 'normalize_adv': True,
     'hidden_sizes': (32, 32),
@@ -32,19 +33,25 @@ DEFAULT = {
     'init_inner_kl_penalty': 5e-4, 'adaptive_inner_kl_penalty': False,
     'n_itr': 100, 'meta_batch_size': 4, 'num_inner_grad_steps': 1,
     'device_rollouts': False,      # True: the environment itself runs on the GPU (samplers/device_point_sampler.py)
+    'device_noise': False,         # with device_rollouts: exploration noise drawn on the device (Philox) instead of NumPy's RNG
 }
 
 
 def main(config):
     np.random.seed(config['seed'])
     baseline = {'LinearFeatureBaseline': LinearFeatureBaseline}[config['baseline']]()
-    env = MetaPointEnv()
+    env = MetaPointEnvCorner(reward_type=config.get('reward_type', 'sparse'))
+    if config.get('normalize_env', True):
+        env = normalize(env)                      # as the reference script (pro-mp_run_point_mass.py:27-28)
     policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=2, action_dim=2, meta_batch_size=config['meta_batch_size'],
                                    hidden_sizes=config['hidden_sizes'])
-    sampler_cls = DevicePointEnvSampler if config.get('device_rollouts') else MetaSampler
-    sampler = sampler_cls(env=env, policy=policy, rollouts_per_meta_task=config['rollouts_per_meta_task'],
+    sampler_kwargs = dict(env=env, policy=policy, rollouts_per_meta_task=config['rollouts_per_meta_task'],
                           meta_batch_size=config['meta_batch_size'], max_path_length=config['max_path_length'],
                           parallel=config['parallel'])
+    if config.get('device_rollouts'):
+        sampler = DevicePointEnvSampler(device_noise=bool(config.get('device_noise')), **sampler_kwargs)
+    else:
+        sampler = MetaSampler(**sampler_kwargs)
     sample_processor = MetaSampleProcessor(baseline=baseline, discount=config['discount'], gae_lambda=config['gae_lambda'],
                                            normalize_adv=config['normalize_adv'])
     algo = ProMP(policy=policy, inner_lr=config['inner_lr'], meta_batch_size=config['meta_batch_size'],

@@ -24,7 +24,7 @@ def test_emulated_library_exports_every_symbol():
     lib = devlib.emu_library()
     for s in header_symbols():
         assert hasattr(lib.cdll, s)
-    assert lib.cdll.promp_abi_version() == 1
+    assert lib.cdll.promp_abi_version() == 2
 
 
 @pytest.mark.skipif(not os.path.exists(_lib.DEFAULT_LIBRARY), reason='libpromp_hip.so not built (run __graft_entry__.build())')

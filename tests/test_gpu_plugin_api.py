@@ -31,8 +31,18 @@ def test_trainer_end_to_end_point_env():
 
 
 def test_device_rollout_point_env():
-    scen.run_device_rollout_scenario(M=4, B=20, T=100)          # BASELINE config 0 shapes
-    scen.run_device_rollout_scenario(M=5, B=3, T=33, hidden=(64, 64))
+    scen.run_device_rollout_scenario(M=4, B=20, T=100, reward_type='sparse')          # BASELINE config 1 shapes, default reward
+    scen.run_device_rollout_scenario(M=5, B=3, T=33, hidden=(64, 64), reward_type='dense')
+    scen.run_device_rollout_scenario(M=3, B=5, T=40, reward_type='dense_squared')
+
+
+def test_device_rollout_point_env_with_device_noise():
+    scen.test_device_rollout_point_env_with_device_noise(None)
+
+
+def test_policy_step_fills_the_slab():
+    scen.run_policy_step_scenario()
+    scen.run_policy_step_scenario(M=8, B=20, T=12, O=20, A=6, hidden=(64, 64))       # HalfCheetah shapes
 
 
 def test_trainer_with_device_rollouts():
@@ -54,7 +64,8 @@ def test_promp_learns_on_point_env(tmp_path, device_rollouts):
     spec = importlib.util.spec_from_file_location('run_point', os.path.join(scen.__file__.rsplit('/tests/', 1)[0], 'run_scripts', 'pro-mp_run_point_mass.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    cfg = dict(mod.DEFAULT, n_itr=40, meta_batch_size=8, rollouts_per_meta_task=10, max_path_length=25, seed=3, device_rollouts=device_rollouts)
+    cfg = dict(mod.DEFAULT, n_itr=40, meta_batch_size=8, rollouts_per_meta_task=10, max_path_length=25, seed=3, device_rollouts=device_rollouts,
+               reward_type='dense', normalize_env=False)      # dense reward, bare action box: a learning signal within 40 iterations
     logger.configure(dir=str(tmp_path), quiet=True)
     mod.main(cfg)
     rows = list(csv.DictReader(open(os.path.join(str(tmp_path), 'progress.csv'))))

@@ -102,7 +102,8 @@ def run_algo_scenario(M=2, P=2, T=30, O=5, A=3, hidden=(32, 32), K=1, epochs=2):
 
 def run_trainer_scenario(n_itr=2, device_rollouts=False):
     from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
-    from promp_amd.envs.point_env import MetaPointEnv
+    from promp_amd.envs.normalized_env import normalize
+    from promp_amd.envs.point_env import MetaPointEnvCorner
     from promp_amd.meta_algos.pro_mp import ProMP
     from promp_amd.meta_trainer import Trainer
     from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
@@ -112,7 +113,7 @@ def run_trainer_scenario(n_itr=2, device_rollouts=False):
     logger.configure(quiet=True)
     np.random.seed(1)
     M, P, T = 2, 3, 12
-    env = MetaPointEnv()
+    env = normalize(MetaPointEnvCorner(reward_type='dense'))       # run_scripts/pro-mp_run_point_mass.py:27-28
     policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=(32, 32))
     from promp_amd.samplers.device_point_sampler import DevicePointEnvSampler
     sampler = (DevicePointEnvSampler if device_rollouts else MetaSampler)(
@@ -144,35 +145,41 @@ def run_trainer_scenario(n_itr=2, device_rollouts=False):
     assert any(np.any(before[k] != after[k]) for k in before) and all(np.all(np.isfinite(v)) for v in after.values())
 
 
-def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32)):
+def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sparse'):
     """DevicePointEnvSampler: the trajectories equal a float64 NumPy rollout of the same environment with the same start
-    states and noise (oracle/point_rollout.py); process_samples takes the resident slab (no upload) and returns what
-    it returns for the same paths handed over as plain host dicts."""
+    states and noise (oracle/point_rollout.py, itself pinned by the reference environment's own trajectories); process_samples
+    takes the resident slab (no upload) and returns what it returns for the same paths handed over as plain host dicts."""
     from oracle import policy as op, point_rollout as pr
     from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
-    from promp_amd.envs.point_env import MetaPointEnv
+    from promp_amd.envs.normalized_env import normalize
+    from promp_amd.envs.point_env import MetaPointEnvCorner
     from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
     from promp_amd.samplers.device_point_sampler import DevicePointEnvSampler
     from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
     np.random.seed(21)
-    env = MetaPointEnv()
+    env = normalize(MetaPointEnvCorner(reward_type=reward_type))
     policy = MetaGaussianMLPPolicy(name='p', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=hidden)
     sampler = DevicePointEnvSampler(env=env, policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
     sampler.update_tasks()
+    spec = op.PolicySpec(2, 2, hidden)
+    theta = spec.from_ordered_dict(policy.get_param_values())
+    theta[-2:] = np.log(12.0)             # wide exploration: actions beyond the wrapper's +-10 box, points that leave the start region
+    policy.set_params(spec.to_ordered_dict(theta))
     policy.switch_to_pre_update()
     state = np.random.get_state()
     paths = sampler.obtain_samples()
     np.random.set_state(state)                                   # replay the sampler's draws for the oracle
     start = np.random.uniform(-0.2, 0.2, size=(M, B, 2))
     noise = np.random.normal(size=(M, B, T, 2)).astype(np.float32)
-    spec = op.PolicySpec(2, 2, hidden)
-    theta = spec.from_ordered_dict(policy.get_param_values())
-    ref = pr.rollout(spec, np.tile(theta, (M, 1)), sampler.goals, start, noise, clip_infos=True)
+    ref = pr.rollout(spec, np.tile(theta, (M, 1)), sampler.goals, start, noise, clip_infos=True, reward_type=reward_type,
+                     normalization_scale=10.0, max_step=0.2, sparse_radius=0.5)
     assert list(paths.keys()) == list(range(M)) and all(len(paths[i]) == B for i in range(M))
     cat = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths[i]])
     np.testing.assert_allclose(cat('observations'), ref['obs'], atol=2e-6)
     np.testing.assert_allclose(cat('actions'), ref['act'], atol=2e-6)
     np.testing.assert_allclose(cat('rewards'), ref['rew'], atol=2e-6)
+    if reward_type == 'sparse':
+        assert 0 < np.count_nonzero(ref['rew']) < ref['rew'].size
     np.testing.assert_allclose(cat('agent_infos', 'mean'), ref['mean'], atol=2e-6)
     np.testing.assert_allclose(paths[0][0]['agent_infos']['log_std'][0], ref['log_std'][0], atol=1e-6)
     assert sampler.total_timesteps_sampled == M * B * T
@@ -191,7 +198,103 @@ def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32)):
 
 
 def test_device_rollout_point_env(emu):
-    run_device_rollout_scenario()
+    run_device_rollout_scenario(reward_type='sparse')
+    run_device_rollout_scenario(M=2, B=3, T=9, reward_type='dense_squared')
+
+
+def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
+    """DeviceSlabSampler: every environment step is one promp_policy_step; the slab rows equal the oracle's forward pass plus
+    the oracle's Philox noise; rewards arrive once; process_samples uploads nothing; an early `done` falls back to the host."""
+    from oracle import philox, policy as op
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.device_slab_sampler import DeviceSlabSampler
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+
+    class DriftEnv(object):
+        """obs = running sum of clipped actions (first O entries cycled); reward = -|obs|; never done unless told"""
+        def __init__(self, stop_at=None):
+            self.stop_at, self.t, self.s, self.task = stop_at, 0, np.zeros(O), 0.0
+        def sample_tasks(self, n): return list(np.arange(n, dtype=np.float64))
+        def set_task(self, task): self.task = float(task)
+        def reset(self):
+            self.t, self.s = 0, np.full(O, 0.1 * self.task)
+            return self.s.copy()
+        def step(self, a):
+            self.t += 1
+            self.s = self.s + 0.05 * np.resize(np.clip(a, -1, 1), O)
+            return self.s.copy(), -float(np.abs(self.s).sum()), bool(self.stop_at and self.t >= self.stop_at), dict(t=self.t)
+
+    np.random.seed(5)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+    sampler = DeviceSlabSampler(env=DriftEnv(), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
+    sampler.update_tasks()
+    policy.switch_to_pre_update()
+    state = np.random.get_state()
+    paths = sampler.obtain_samples()
+    np.random.set_state(state)
+    seed = int(np.random.randint(0, 2 ** 31 - 1))
+    spec = op.PolicySpec(O, A, hidden)
+    theta = spec.from_ordered_dict(policy.get_param_values()).astype(np.float64)
+    assert sampler.host_fallbacks == 0 and all(len(paths[i]) == B for i in range(M))
+    cat = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths[i]])
+    obs = cat('observations')
+    mean = op.forward(spec, theta, obs.astype(np.float64), False)[0]
+    noise = philox.action_noise(seed, np.arange(M * B * T), A, stream=0)          # slab row -> counter; sampling step 0 -> stream
+    np.testing.assert_allclose(cat('agent_infos', 'mean'), mean, atol=2e-6)
+    np.testing.assert_allclose(cat('actions'), mean + np.exp(theta[-A:]) * noise, atol=5e-6)
+    act = cat('actions')
+    nxt = obs.astype(np.float64) + 0.05 * np.stack([np.resize(np.clip(a, -1, 1), O) for a in act.astype(np.float64)])
+    np.testing.assert_allclose(cat('rewards'), -np.abs(nxt).sum(axis=1), atol=2e-6)             # what the host uploaded at the end
+    for i in range(M):
+        for p in paths[i]:
+            assert p['observations'].shape == (T, O) and p['actions'].shape == (T, A)
+            np.testing.assert_array_equal(p['env_infos']['t'], np.arange(1, T + 1))
+            np.testing.assert_allclose(p['observations'][0], 0.1 * i, atol=1e-7)             # filed under its own task
+            np.testing.assert_allclose(p['observations'][1:], p['observations'][:-1] + 0.05 * np.resize(
+                np.clip(p['actions'][:-1], -1, 1).T, (O, T - 1)).T, atol=1e-6)              # the env really got these actions
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
+    before = list(policy.session.upload_serial)
+    sd = proc.process_samples(paths)
+    assert policy.session.upload_serial == before and len(sd) == M
+    # ragged episodes: the sampling step is collected by the host-side logic instead
+    sampler2 = DeviceSlabSampler(env=DriftEnv(stop_at=3), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
+    sampler2.update_tasks()
+    policy.switch_to_pre_update()
+    paths2 = sampler2.obtain_samples()
+    assert sampler2.host_fallbacks == 1 and all(len(p['rewards']) == 3 for i in range(M) for p in paths2[i])
+    assert len(proc.process_samples(paths2)) == M
+
+
+def test_policy_step_fills_the_slab(emu):
+    run_policy_step_scenario()
+
+
+def test_device_rollout_point_env_with_device_noise(emu):
+    from oracle import philox, policy as op, point_rollout as pr
+    from promp_amd.envs.normalized_env import normalize
+    from promp_amd.envs.point_env import MetaPointEnvCorner
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.device_point_sampler import DevicePointEnvSampler
+    M, B, T, hidden = 2, 3, 7, (32, 32)
+    np.random.seed(8)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=hidden)
+    sampler = DevicePointEnvSampler(env=normalize(MetaPointEnvCorner(reward_type='dense')), policy=policy, rollouts_per_meta_task=B,
+                                    meta_batch_size=M, max_path_length=T, device_noise=True)
+    sampler.update_tasks()
+    policy.switch_to_pre_update()
+    state = np.random.get_state()
+    paths = sampler.obtain_samples()
+    np.random.set_state(state)
+    start = np.random.uniform(-0.2, 0.2, size=(M, B, 2))
+    seed = int(np.random.randint(0, 2 ** 31 - 1))
+    noise = philox.action_noise(seed, np.arange(M * B * T), 2, stream=0).reshape(M, B, T, 2)
+    spec = op.PolicySpec(2, 2, hidden)
+    theta = spec.from_ordered_dict(policy.get_param_values())
+    ref = pr.rollout(spec, np.tile(theta, (M, 1)), sampler.goals, start, noise, reward_type='dense')
+    cat = lambda key: np.concatenate([p[key] for i in range(M) for p in paths[i]])
+    np.testing.assert_allclose(cat('actions'), ref['act'], atol=5e-6)
+    np.testing.assert_allclose(cat('rewards'), ref['rew'], atol=5e-6)
 
 
 def test_trainer_with_device_rollouts(emu):
