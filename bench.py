@@ -28,7 +28,7 @@ from promp_amd import _lib, comm, synthetic  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
 HBM_PEAK_GBS = 8000.0
-ENV_NAMES = {1: 'Point2D', 2: 'HalfCheetahRandVel', 3: 'HalfCheetahRandVel', 4: 'AntRandDirec'}
+ENV_NAMES = {1: 'Point2D', 2: 'HalfCheetahRandVel', 3: 'HalfCheetahRandVel', 4: 'AntRandDirec', 5: 'HalfCheetahRandVel'}
 
 
 def flops_per_row(O, H1, H2, A):
@@ -43,8 +43,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3, 4],
-                    help='BASELINE.json config; 3 is the one the metric is quoted on, the others are shape studies')
+    ap.add_argument('--config', type=int, default=3, choices=[1, 2, 3, 4, 5],
+                    help='BASELINE.json config; 3 is the one the metric is quoted on; 5 = config 3 shapes with the TRPO-MAML outer step '
+                         '(conjugate gradients + line search instead of E Adam epochs); the others are shape studies')
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
                     help='strong (default): the named 40-task config sharded over the N GPUs; weak: the named config per GPU')
     ap.add_argument('--epochs', type=int, default=5)
@@ -60,7 +61,8 @@ def main():
         print('bench.py: --gpus %d but WORLD_SIZE=%d; for N>1 launch with python -m torch.distributed.run '
               '--nproc-per-node N bench.py --gpus N' % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    cfg = synthetic.CONFIGS[args.config]
+    trpo = args.config == 5
+    cfg = synthetic.CONFIGS[3 if trpo else args.config]
     P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
     K, E = 1, args.epochs
     N = P * T
@@ -102,11 +104,30 @@ def main():
                             th1[:, -A:].copy())
             ctx.sync()
 
+        if trpo:
+            # TRPOMAML.optimize_policy (meta_algos/trpo_maml.py:161-191) on the same device passes: KL before, loss before,
+            # ConjugateGradientOptimizer.optimize (10 CG iterations on finite-difference HVPs of the constraint, backtracking
+            # line search), loss after, KL after; inner objective = log-likelihood (run_scripts/maml_run_mujoco.py:119)
+            from types import SimpleNamespace
+            from promp_amd.meta_algos.trpo_maml import _DeviceEvaluator
+            from promp_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+            from promp_amd.utils import logger as plog
+            plog.configure(quiet=True)
+            shim = SimpleNamespace(session=SimpleNamespace(ctx=ctx, M_global=M_global, world=world), num_inner_grad_steps=K,
+                                   inner_kind=_lib.INNER_LOGLIK, exploration=False, meta_batch_size=M)
+            cg = ConjugateGradientOptimizer()
+            cg.build_graph(_DeviceEvaluator(shim), 0.01)
+
         def iteration():
             ctx.switch_to_pre_update()                       # meta_trainer.py:85
             ctx.process_samples(0, **opts)                   # :105  (step 0)
-            ctx.inner_adapt(0)                               # :116
+            ctx.inner_adapt(0, _lib.INNER_LOGLIK if trpo else _lib.INNER_RATIO)     # :116
             ctx.process_samples(1, **opts)                   # :105  (step 1)
+            if trpo:
+                kl0, l0 = cg.constraint_val(), cg.loss()
+                cg.optimize()
+                return dict(loss_before=l0, loss_after=cg.loss(), kl_before=kl0, kl_after=cg.constraint_val(),
+                            n_backtracks=cg.last['n_backtracks'], rejected=cg.last['rejected'])
             return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
         iteration.upload = upload
         return ctx, iteration, M
@@ -143,8 +164,10 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE config %d: %d-task %s shapes (obs=%d, act=%d, 2x%d tanh MLP, H=%d, '
-                               'P=%d paths/task, K=1 inner step, E=%d ProMP epochs + stats); process_samples x2 + _adapt + '
-                               'optimize_policy per step' % (args.config, M_global, ENV_NAMES[args.config], O, A, hidden[0], T, P, E),
+                               'P=%d paths/task, K=1 inner step, %s); process_samples x2 + _adapt + '
+                               'optimize_policy per step' % (args.config, M_global, ENV_NAMES[args.config], O, A, hidden[0], T, P,
+                                                             'TRPO-MAML outer step: 10 CG iterations on finite-difference HVPs + line search' if trpo
+                                                             else 'E=%d ProMP epochs + stats' % E),
                    'meta_batch_size': M_global, 'tasks_per_gpu': M, 'rows_per_task_per_step': N,
                    'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
                    'device': info['name']},
@@ -192,12 +215,13 @@ def main():
                            'traffic': traffic['bytes'] if traffic else None, 'traffic_source': traffic['source'] if traffic else None,
                            'algorithmic_bytes_per_launch': 4 * (O + 2 * A + 2) * kern[dom]['rows_per_launch'],
                            'avg_launch_ms': kern[dom]['avg_ms'], 'kernels': kern,
-                           'end_to_end_tflops_per_gpu': value * ((fl['fwd_bwd'] + E * (2 * fl['fwd'] + 3 * fl['bwd'] + fl['hvp'])
-                                                                           + 2 * fl['fwd'] + fl['bwd']) / 2.0) / 1e12 / world}
+                           'end_to_end_tflops_per_gpu': None if trpo else value * ((fl['fwd_bwd'] + E * (2 * fl['fwd'] + 3 * fl['bwd'] + fl['hvp'])
+                                                                                           + 2 * fl['fwd'] + fl['bwd']) / 2.0) / 1e12 / world}
 
-    # ---- CPU baseline: the float64 NumPy oracle ("port") on the host cores, rank 0, bounded sample ----
+    # ---- CPU baseline: the C + OpenMP restatement ("port") on the host cores, rank 0, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg, theta0, alpha, eta, opts, E, sample_tasks=min(cfg['M'], 20 if args.config != 4 else 4))
+        out['cpu_baseline'] = cpu_baseline(cfg, theta0, alpha, eta, opts, E, trpo=trpo, steps=3 if args.config != 4 else 1,
+                                           oracle_tasks=8 if args.config != 4 else 2)
 
     ctx.close()
     # ---- N > 1: also time the other scaling mode on the same ranks (weak: a 40-task batch per GPU) ----
@@ -231,33 +255,79 @@ def measured_traffic(kernel):
         return None
 
 
-def cpu_baseline(cfg, theta0, alpha, eta, opts, E, sample_tasks=20):
-    """Time the oracle (CPU restatement of the reference; the reference's TF graph cannot run here) on a bounded
-    sample: the same per-task shapes, `sample_tasks` tasks instead of 40, ONE full step."""
-    from oracle import policy as op, promp as pm, sample_processing as sp
-    P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
-    Ms = min(sample_tasks, cfg['M'])
-    spec = op.PolicySpec(O, A, hidden)
+def cpu_baseline(cfg, theta0, alpha, eta, opts, E, trpo=False, steps=3, oracle_tasks=8):
+    """The hot path on the host cores: oracle/promp_cpu.c, a C + OpenMP restatement of the reference's path (one thread per
+    task, float32 policy arithmetic like the TF graph, float64 sample processing like NumPy / SciPy; pinned against the NumPy
+    oracle by tests/test_oracle_cpu_port.py), timed on the WHOLE named batch for `steps` steps.  The reference's own TF-1
+    graph cannot run here (TensorFlow absent), hence "kind": "port".  The float64 NumPy oracle's rate on a sample of the
+    tasks is reported beside it."""
+    from oracle import cpu_port, policy as op, promp as pm, sample_processing as sp
+    M, P, T, O, A, hidden = cfg['M'], cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
+    port = cpu_port.CpuPort(M, P, T, O, A, hidden)
     rng = np.random.RandomState(99)
-    p0 = synthetic.make_paths(rng, theta0, Ms, P, T, O, A, hidden)
-    t64, a64, e64 = theta0.astype(np.float64), alpha.astype(np.float64), eta.astype(np.float64)
+
+    def raw(theta_tasks):
+        fl = _lib.flatten_paths(synthetic.make_paths(rng, theta_tasks, M, P, T, O, A, hidden))
+        th = np.asarray(theta_tasks, np.float32)
+        ls = np.tile(th[-A:], (M, 1)) if th.ndim == 1 else th[:, -A:].copy()
+        return dict(obs=fl['obs'], rew=fl['rew'], act=fl['act'], old_mean=fl['old_mean'], old_log_std=ls)
+    raw0 = raw(theta0)
+    adv0, _ = port.process_samples(raw0['obs'], raw0['rew'], **opts)
+    th1 = port.adapt(theta0, alpha, dict(raw0, adv=adv0), inner='loglik' if trpo else 'ratio')
+    raw1 = raw(th1)
+
+    def trpo_step(theta):
+        from promp_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+        from promp_amd.utils import logger as plog
+        plog.configure(quiet=True)
+        s0 = dict(raw0, adv=port.process_samples(raw0['obs'], raw0['rew'], **opts)[0])
+        port.adapt(theta, alpha, s0, inner='loglik')
+        s1 = dict(raw1, adv=port.process_samples(raw1['obs'], raw1['rew'], **opts)[0])
+
+        class Ev(object):
+            th = np.array(theta, np.float32)
+            def _e(self, outer, grad): return port.meta_grad(self.th, alpha, 0.0, 0.0, s0, s1, inner='loglik', outer=outer, want_grad=grad)
+            def loss(self): return self._e('ratio', False)[1]['loss']
+            def constraint_val(self): return self._e('ratio', False)[1]['outer_kl']
+            def gradient(self): return self._e('ratio', True)[0]
+            def constraint_gradient(self): return self._e('kl', True)[0]
+            def get_theta(self): return self.th
+            def set_theta(self, t): self.th = np.asarray(t, np.float32)
+        cg = ConjugateGradientOptimizer()
+        ev = Ev()
+        cg.build_graph(ev, 0.01)
+        cg.constraint_val(); cg.loss(); cg.optimize(); cg.loss(); cg.constraint_val()
+        return ev.th
+
+    theta = np.array(theta0, np.float32)
     t0 = time.perf_counter()
-    s0, _, _ = sp.process_samples_meta(p0, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **opts)
-    ad = pm.adapt(spec, [t64] * Ms, s0, a64)
-    t_a = time.perf_counter()
-    p1 = synthetic.make_paths(rng, np.stack(ad).astype(np.float32), Ms, P, T, O, A, hidden)   # not timed
-    t_b = time.perf_counter()
-    s1, _, _ = sp.process_samples_meta(p1, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **opts)
-    pm.optimize_policy(spec, t64, [s0, s1], a64, e64, 0.3, pm.AdamState(spec.n_params), 1e-3, E)
-    dt = (t_a - t0) + (time.perf_counter() - t_b)
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {'value': Ms * P * T * 2 / dt, 'unit': 'env-steps/s', 'cores': int(threads), 'kind': 'port',
-            'sample': 'float64 NumPy oracle (BLAS threads=%d of %d host cores), one full step on %d of the %d tasks '
-                      '(same per-task shapes), %.1f s' % (threads, os.cpu_count() or 1, Ms, cfg['M'], dt)}
+    for _ in range(steps):
+        if trpo:
+            theta = trpo_step(theta)
+        else:
+            theta, res = port.promp_step(theta, alpha, float(eta[0]), 0.3, 1e-3, E, raw0, raw1, opts)
+    dt = time.perf_counter() - t0
+    out = {'value': M * P * T * 2 * steps / dt, 'unit': 'env-steps/s', 'cores': min(port.threads(), M), 'kind': 'port',
+           'sample': 'oracle/promp_cpu.c (C + OpenMP restatement, one thread per task: %d busy threads on %d host cores), the whole '
+                     '%d-task batch, %d full steps, %.1f s' % (min(port.threads(), M), os.cpu_count() or 1, M, steps, dt)}
+    if not trpo and oracle_tasks:
+        # the float64 NumPy oracle on a sample of the tasks, one full step
+        Ms = min(oracle_tasks, M)
+        spec = op.PolicySpec(O, A, hidden)
+        p0 = synthetic.make_paths(rng, theta0, Ms, P, T, O, A, hidden)
+        t64, a64, e64 = theta0.astype(np.float64), alpha.astype(np.float64), eta.astype(np.float64)
+        t0 = time.perf_counter()
+        s0, _, _ = sp.process_samples_meta(p0, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **opts)
+        ad = pm.adapt(spec, [t64] * Ms, s0, a64)
+        t_a = time.perf_counter()
+        p1 = synthetic.make_paths(rng, np.stack(ad).astype(np.float32), Ms, P, T, O, A, hidden)   # not timed
+        t_b = time.perf_counter()
+        s1, _, _ = sp.process_samples_meta(p1, baseline_kind=sp.BASELINE_LINEAR_FEATURE, **opts)
+        pm.optimize_policy(spec, t64, [s0, s1], a64, e64, 0.3, pm.AdamState(spec.n_params), 1e-3, E)
+        dt2 = (t_a - t0) + (time.perf_counter() - t_b)
+        out['numpy_oracle'] = {'value': Ms * P * T * 2 / dt2, 'unit': 'env-steps/s',
+                               'sample': 'float64 NumPy oracle, one full step on %d of the %d tasks, %.1f s' % (Ms, M, dt2)}
+    return out
 
 
 if __name__ == '__main__':

@@ -232,7 +232,7 @@ def check_learn_std_false(lib, seed, M, P, T, O, A, hidden):
 
 
 def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10, max_backtracks=15,
-               exploration=False):
+               exploration=False, oracle_step=True):
     """TRPOMAML.optimize_policy (row a15) through the plugin classes.
 
     The reference's Hessian-vector product is a finite difference with eps = 1e-5 on float32 parameters
@@ -285,13 +285,19 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
         assert rel_max(ev.constraint_gradient(), r_kl['grad']) < 1e-4
         # (2) the step
         algo.optimize_policy(samples, log=False)
-        ref = otrpo.trpo_maml_step(spec, theta, all_slabs, alpha, inner_kind=kind, max_kl=0.01, cg_iters=cg_iters,
-                                   explore_coeffs=coeffs)
         st, last = algo.last_stats, algo.optimizer.last
-        d, dr = last['descent_direction'].astype(np.float64), ref['descent_direction']
-        cos = d.dot(dr) / (np.linalg.norm(d) * np.linalg.norm(dr))
-        if np.isfinite(last['initial_step_size']):      # a negative-curvature FD estimate rejects the step (as the reference)
-            assert cos > 0.5, cos
+        ref = None
+        if oracle_step:      # (skipped at full BASELINE size: ~70 float64 meta-gradient evaluations of the NumPy oracle)
+            ref = otrpo.trpo_maml_step(spec, theta, all_slabs, alpha, inner_kind=kind, max_kl=0.01, cg_iters=cg_iters,
+                                       explore_coeffs=coeffs)
+            d, dr = last['descent_direction'].astype(np.float64), ref['descent_direction']
+            cos = d.dot(dr) / (np.linalg.norm(d) * np.linalg.norm(dr))
+            if np.isfinite(last['initial_step_size']):      # a negative-curvature FD estimate rejects the step (as the reference)
+                assert cos > 0.5, cos
+        else:                # the direction is a descent direction of the loss (g^T d > 0 for the step theta - s d)
+            g = r_loss['grad']
+            if np.isfinite(last['initial_step_size']):
+                assert g.dot(last['descent_direction'].astype(np.float64)) > 0
         if not last['rejected']:
             assert st['loss_after'] < st['loss_before'] and st['mean_kl'] <= 0.01 * 1.001
         else:

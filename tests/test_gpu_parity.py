@@ -262,6 +262,13 @@ def test_single_rank_communicator(lib):
     ctx.close()
 
 
+def test_trpo_maml_full_config5(lib):
+    # BASELINE config 5 at full size: 40 tasks x 20 paths x 200 steps, HalfCheetah shapes, inner log-likelihood
+    # (run_scripts/maml_run_mujoco.py:119): device ingredients vs the float64 oracle, step checked by its properties
+    st, _ = pc.check_trpo(lib, 65, M=40, P=20, T=200, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood', oracle_step=False)
+    assert np.isfinite(st['loss_after']) and np.isfinite(st['mean_kl'])
+
+
 def test_kl_objective_and_trpo_maml_step(lib):
     # row a15 / BASELINE config 5 shapes (reduced M): device ingredients tight, step properties (see parity_checks)
     st, ref = pc.check_trpo(lib, 61, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood')
