@@ -127,6 +127,9 @@ int promp_set_step_sizes(promp_ctx* ctx, const float* step_sizes);       /* [The
  * the trailing act_dim parameters are neither adapted by the inner step (their step sizes are forced to 0) nor updated
  * by Adam.  Default: learned. */
 int promp_set_learn_std(promp_ctx* ctx, int learn_std);
+/* GaussianMLPPolicy(min_std) (policies/gaussian_mlp_policy.py:31,35,71): log_std evaluated from the shared variables is
+ * max(log_std_var, log min_std), gradient iff log_std_var >= log min_std (tf.maximum).  Default 1e-6. */
+int promp_set_min_std(promp_ctx* ctx, float min_std);
 int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
 int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);
 /* MetaPolicy.switch_to_pre_update: replicate theta into every task's parameter slot */

@@ -70,6 +70,7 @@ SIGNATURES = {
     'promp_get_theta': (C.c_int, [_P, _F]),
     'promp_set_step_sizes': (C.c_int, [_P, _F]),
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
+    'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
     'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
     'promp_switch_to_pre_update': (C.c_int, [_P]),
@@ -355,6 +356,9 @@ class Context:
         """forward-only evaluation of the meta-objective (the compute_stats pass): loss, inner_kl [K], outer_kl"""
         r = self.optimize(0, 0.0, clip_eps, inner_kl_coeff, inner_kind, outer_kind)
         return dict(loss=r['loss_after'], inner_kl=r['inner_kl'], outer_kl=r['outer_kl'])
+
+    def set_min_std(self, min_std):
+        self._call('promp_set_min_std', float(min_std))
 
     def set_learn_std(self, on=True):
         self._call('promp_set_learn_std', int(bool(on)))

@@ -111,6 +111,7 @@ struct promp_ctx {
     ncclComm_t comm = nullptr;
 #endif
     int rank = 0, nranks = 1;
+    float min_log_std = -13.815510558f;  // log(1e-6): GaussianMLPPolicy's default min_std
     bool learn_std = true;               // false: log_std is neither adapted (step size 0) nor trained (no Adam update)
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
@@ -223,7 +224,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.partials = c->partials; a.partial_stride = c->partial_stride;
     a.O = c->d.obs_dim; a.A = c->d.act_dim;
     a.loss_kind = loss_kind; a.clip_eps = clip_eps; a.clip_log_std = clip_ls;
-    a.min_log_std = logf(1e-6f);   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
+    a.min_log_std = c->min_log_std;   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
     a.kl_weight = klw;
     a.task_counters = c->task_counters; a.task_slot_offsets = S.chain_slot_offsets;
     a.red_mode = red_mode; a.step_sizes = c->step_sizes; a.cur = cur; a.cur_task_stride = cur_stride; a.next = next;
@@ -939,6 +940,12 @@ int promp_set_step_sizes(promp_ctx* c, const float* s) {
     if (copy_in(c, c->step_sizes, s, c->NP)) return -2;
     return mask_log_std_step_sizes(c);
 }
+int promp_set_min_std(promp_ctx* c, float min_std) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (!(min_std > 0.f)) return fail(-1, "min_std must be positive");
+    c->min_log_std = logf(min_std);
+    return 0;
+}
 int promp_set_learn_std(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
     if (on && !c->learn_std) return fail(-3, "learn_std cannot be switched back on: the log_std step sizes were zeroed (set the step sizes again)");
@@ -1053,7 +1060,7 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     a.B = B; a.T = T; a.goals = d_goals; a.start = d_start; a.noise = noise ? d_noise : nullptr;
     a.seed = o->seed; a.stream = (unsigned)step;
     a.obs = S.obs; a.act = S.act; a.rew = S.rew; a.mean = S.old_mean; a.old_ls = S.old_ls;
-    a.clip_infos = o->clip_infos; a.min_log_std = logf(1e-6f);
+    a.clip_infos = o->clip_infos; a.min_log_std = c->min_log_std;
     a.normalization_scale = o->normalization_scale; a.max_step = o->max_step; a.reward_type = o->reward_type; a.sparse_radius = o->sparse_radius;
     PROMP_LAUNCH(k_point_rollout, dim3(M), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
@@ -1083,7 +1090,7 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     a.obs_in = d_obs; a.theta_tasks = c->theta_tasks;
     a.obs = S.obs; a.act = S.act; a.mean = S.old_mean; a.old_ls = S.old_ls; a.actions_out = d_act;
     a.B = B; a.T = T; a.t = t; a.O = O; a.A = A; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2; a.NP = c->NP;
-    a.clip_infos = clip_infos; a.min_log_std = logf(1e-6f);
+    a.clip_infos = clip_infos; a.min_log_std = c->min_log_std;
     a.seed = seed; a.stream = (unsigned)step;
     PROMP_LAUNCH(k_policy_step, dim3((B + 63) / 64, M), 64, 0, st, a);
     HIPCHECK(hipGetLastError());

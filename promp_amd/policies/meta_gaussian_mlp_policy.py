@@ -29,7 +29,6 @@ class MetaGaussianMLPPolicy(object):
         assert output_nonlinearity is None, 'only a linear output layer is implemented'
         assert hidden_nonlinearity in ('tanh', None) or getattr(hidden_nonlinearity, '__name__', '') == 'tanh', \
             'only tanh hidden units are implemented (the reference default, policies/base.py:31)'
-        assert abs(min_std - 1e-6) < 1e-12, 'min_std is fixed at the reference default 1e-6 in the kernels'
         self.meta_batch_size = int(meta_batch_size)
         self.obs_dim, self.action_dim = int(np.prod(obs_dim)), int(np.prod(action_dim))
         self.name = name
@@ -63,6 +62,7 @@ class MetaGaussianMLPPolicy(object):
         self.session = session_mod.DeviceSession(self.meta_batch_size, self.obs_dim, self.action_dim, self.hidden_sizes,
                                                  n_tasks_global=n_tasks_global or self.meta_batch_size * world,
                                                  device_id=device_id, rank=rank, world=world)
+        self.session.min_std = float(min_std)
         self.session.learn_std = bool(learn_std)      # False: log_std is neither adapted nor trained (gaussian_mlp_policy.py:63-69)
         self.session.set_theta(self._flatten(parts))
         self._log_std_cache = None                    # ([M, A] raw log_std of the tasks' current parameters, parameter version)

@@ -45,6 +45,7 @@ class DeviceSession:
         self.upload_serial = [0] * (self.K + 1)
         self.param_version = 0        # bumped by whatever changes the tasks' parameters (host-side caches key on it)
         self.learn_std = True
+        self.min_std = 1e-6
         self._upload_counter = 0      # never reset: a SamplesData from before a context re-creation can never match a later upload
         self._comm_ready = False      # the RCCL communicator is created once per session and moved across context re-creations
         _current = self
@@ -90,6 +91,7 @@ class DeviceSession:
             if self.step_sizes is not None:
                 self.ctx.set_step_sizes(self.step_sizes)
             self.ctx.set_learn_std(self.learn_std)
+            self.ctx.set_min_std(self.min_std)
             if self.adam is not None:
                 self.ctx.set_adam_state(*self.adam)
             if self.task_thetas is not None:

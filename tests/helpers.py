@@ -53,7 +53,7 @@ def load_promp(name):
     return c, g['theta'], all_slabs, g
 
 
-def make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=False, low_log_std=False, per_task_log_std=False):
+def make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=False, low_log_std=False, per_task_log_std=False, min_std=1e-6):
     """Seeded slabs for steps 0..K (same recipe as oracle/gen_golden.py:make_promp_inputs): the 'old' policy
     differs from theta so that ratio != 1 and the PPO clip is active on some rows."""
     from promp_amd import synthetic
@@ -61,7 +61,7 @@ def make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=False, low_log_std=Fa
     theta = synthetic.init_theta(rng, O, hidden, A)
     theta = (theta + 0.05 * rng.randn(theta.size)).astype(np.float32)
     if low_log_std:
-        theta[-A:] = np.log(1e-6) + np.array([-0.5, 0.5, -1.0, 0.2, -0.2, 0.1, 0.3, -0.3][:A])
+        theta[-A:] = np.log(min_std) + np.array([-0.5, 0.5, -1.0, 0.2, -0.2, 0.1, 0.3, -0.3][:A])
     all_slabs, all_paths = [], []
     for k in range(K + 1):
         theta_old = (theta + 0.1 * rng.randn(M, theta.size)).astype(np.float32)

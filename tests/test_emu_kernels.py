@@ -77,6 +77,14 @@ def test_learn_std_false(lib, two_cus):
     pc.check_learn_std_false(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32))
 
 
+def test_loss_grad_clipped_log_std_values_at_benign_min_std(lib):
+    pc.check_loss_grad(lib, 20, M=2, P=2, T=20, O=4, A=3, hidden=(32, 32), low_log_std=True, min_std=0.5)
+
+
+def test_fit_retries_with_larger_reg_on_rank_deficient_features(lib):
+    pc.check_fit_retry_on_rank_deficient_features(lib, 21)
+
+
 def test_hvp_h64(lib):
     pc.check_hvp(lib, 10, M=2, P=2, T=37, O=20, A=6, hidden=(64, 64))
 

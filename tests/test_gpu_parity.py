@@ -74,6 +74,15 @@ def test_unsupported_hidden_widths_are_rejected(lib):
 
 def test_loss_grad_clipped_log_std(lib):
     pc.check_loss_grad(lib, 33, M=2, P=2, T=50, O=4, A=3, hidden=(32, 32), low_log_std=True)
+    # value-level: the same clip (tf.maximum, gradient mask) at a benign min_std, float32 comparable with the float64 oracle
+    pc.check_loss_grad(lib, 37, M=3, P=3, T=80, O=20, A=6, hidden=(64, 64), low_log_std=True, min_std=0.5)
+    pc.check_loss_grad(lib, 38, M=2, P=2, T=60, O=40, A=8, hidden=(128, 128), low_log_std=True, min_std=0.5)
+
+
+def test_fit_retries_with_larger_reg_on_rank_deficient_features(lib):
+    pc.check_fit_retry_on_rank_deficient_features(lib, 39)
+    pc.check_fit_retry_on_rank_deficient_features(lib, 40, M=3, P=4, T=120, O=20)       # k_fit_wave<48>
+    pc.check_fit_retry_on_rank_deficient_features(lib, 41, M=2, P=4, T=100, O=40)       # k_fit_wide
 
 
 @pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 5, 3), ((128, 128), 111, 8),

@@ -22,6 +22,11 @@ def test_policy_algo_api_halfcheetah_shapes():
     scen.run_algo_scenario(M=8, P=5, T=200, O=20, A=6, hidden=(64, 64), K=1, epochs=5)
 
 
+def test_policy_algo_api_config2_full_size():
+    # BASELINE config 2 as named: 8 tasks x 20 paths x 200 steps, HalfCheetah shapes, 2x64 MLP
+    scen.run_algo_scenario(M=8, P=20, T=200, O=20, A=6, hidden=(64, 64), K=1, epochs=5)
+
+
 def test_policy_algo_api_two_inner_steps():
     scen.run_algo_scenario(M=3, P=4, T=50, O=5, A=3, hidden=(32, 32), K=2, epochs=3)
 
