@@ -53,7 +53,8 @@ enum { PROMP_OUTER_CLIP = 0,    /* PPO clipped surrogate, meta_algos/pro_mp.py:1
        PROMP_OUTER_KL = 2       /* mean KL(old || new) of the last step itself: the TRPO constraint
                                    (meta_algos/trpo_maml.py:133,147,158); its gradient through the
                                    adaptation feeds the finite-difference HVP of
-                                   optimizers/conjugate_gradient_optimizer.py:59-89 */ };
+                                   optimizers/conjugate_gradient_optimizer.py:59-89 */,
+       PROMP_OUTER_LOGLIK = 3   /* -mean(logpi*adv) at the adapted parameters: VPG-MAML, meta_algos/vpg_maml.py:122-124 */ };
 
 /* SampleProcessor.__init__ arguments (samplers/base.py:48-65) + baseline choice */
 typedef struct promp_proc_opts {

@@ -17,7 +17,7 @@ DEFAULT_LIBRARY = os.path.join(_HERE, 'libpromp_hip.so')
 
 BASELINE_ZERO, BASELINE_LINEAR_FEATURE, BASELINE_LINEAR_TIME = 0, 1, 2
 INNER_RATIO, INNER_LOGLIK = 0, 1
-OUTER_CLIP, OUTER_RATIO, OUTER_KL = 0, 1, 2
+OUTER_CLIP, OUTER_RATIO, OUTER_KL, OUTER_LOGLIK = 0, 1, 2, 3
 LOSS_RATIO, LOSS_CLIP, LOSS_LOGLIK, LOSS_KL = 0, 1, 2, 3
 KERNEL_FWD_BWD, KERNEL_HVP, KERNEL_GRAM, KERNEL_FWD = 0, 1, 2, 3
 

@@ -279,7 +279,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
 
 int loss_kind_inner(int inner_kind) { return inner_kind == PROMP_INNER_LOGLIK ? LOSS_LOGLIK : LOSS_RATIO; }
 int loss_kind_outer(int outer_kind) {
-    return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : outer_kind == PROMP_OUTER_KL ? LOSS_KL : LOSS_CLIP;
+    return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : outer_kind == PROMP_OUTER_KL ? LOSS_KL
+           : outer_kind == PROMP_OUTER_LOGLIK ? LOSS_LOGLIK : LOSS_CLIP;
 }
 
 // One evaluation of the meta-objective (+ gradient, + Adam) enqueued on the stream.

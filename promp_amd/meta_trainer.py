@@ -85,10 +85,29 @@ class Trainer(object):
             logger.dumpkvs()
         logger.log('Training finished')
 
+    def load_snapshot(self, snapshot):
+        """Resume from what get_itr_snapshot wrote (a dict, or the path of a params.pkl / itr_<n>.pkl file): policy parameters,
+        Adam moments and step count, inner KL coefficients, baseline coefficients; training continues at the next iteration."""
+        if isinstance(snapshot, str):
+            snapshot = logger.load_params(snapshot)
+        self.policy.set_params(snapshot['policy_params'])
+        self.policy.switch_to_pre_update()
+        sess = self.policy.session
+        if snapshot.get('adam_m') is not None:
+            sess.adam = (snapshot['adam_m'], snapshot['adam_v'], int(snapshot['adam_t']))
+            if sess.ctx is not None:
+                sess.ctx.set_adam_state(*sess.adam)
+        if snapshot.get('inner_kl_coeff') is not None and hasattr(self.algo, 'inner_kl_coeff'):
+            self.algo.inner_kl_coeff = snapshot['inner_kl_coeff']
+        if snapshot.get('baseline') is not None:
+            self.baseline.set_params(snapshot['baseline'])
+        self.start_itr = int(snapshot['itr']) + 1
+
     def get_itr_snapshot(self, itr):
         """what is needed to resume: flat policy parameters, Adam state, KL coefficients, baseline coefficients"""
-        ctx = self.policy.session.ctx
-        adam_m, adam_v, adam_t = ctx.get_adam_state() if ctx is not None else (None, None, 0)
+        sess = self.policy.session
+        ctx = sess.ctx
+        adam_m, adam_v, adam_t = ctx.get_adam_state() if ctx is not None else (sess.adam or (None, None, 0))
         return dict(itr=itr, policy_params=self.policy.get_param_values(), adam_m=adam_m, adam_v=adam_v, adam_t=adam_t,
                     inner_kl_coeff=getattr(self.algo, 'inner_kl_coeff', None), baseline=self.baseline.get_param_values())
 

@@ -81,5 +81,14 @@ def test_promp_learns_on_point_env(tmp_path, device_rollouts):
     logger.configure(quiet=True)
 
 
+def test_vpg_maml_on_device():
+    scen.run_vpg_scenario(M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood')
+    scen.run_vpg_scenario(M=3, P=3, T=40, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio', exploration=True)
+
+
+def test_trainer_snapshot_round_trip_on_device(tmp_path):
+    scen.test_trainer_snapshot_round_trip(None, tmp_path)
+
+
 def test_baseline_fit_predict_on_device():
     scen.run_baseline_fit_predict_scenario()

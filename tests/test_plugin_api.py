@@ -1,5 +1,6 @@
 """The drop-in boundary: the reference's plugin classes re-created over the HIP library.
 CPU: runs against the kernel emulator at tiny shapes.  The same scenarios run on the GPU in test_gpu_plugin_api.py."""
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -100,7 +101,7 @@ def run_algo_scenario(M=2, P=2, T=30, O=5, A=3, hidden=(32, 32), K=1, epochs=2):
     np.testing.assert_allclose(algo.last_stats['loss_before'], algo2_stats_before, rtol=1e-5, atol=1e-6)
 
 
-def run_trainer_scenario(n_itr=2, device_rollouts=False):
+def run_trainer_scenario(n_itr=2, device_rollouts=False, log_dir=None, resume=None, build_only=False):
     from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
     from promp_amd.envs.normalized_env import normalize
     from promp_amd.envs.point_env import MetaPointEnvCorner
@@ -110,7 +111,7 @@ def run_trainer_scenario(n_itr=2, device_rollouts=False):
     from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
     from promp_amd.samplers.meta_sampler import MetaSampler
     from promp_amd.utils import logger
-    logger.configure(quiet=True)
+    logger.configure(dir=log_dir, snapshot_mode='last', quiet=True)
     np.random.seed(1)
     M, P, T = 2, 3, 12
     env = normalize(MetaPointEnvCorner(reward_type='dense'))       # run_scripts/pro-mp_run_point_mass.py:27-28
@@ -122,6 +123,10 @@ def run_trainer_scenario(n_itr=2, device_rollouts=False):
     algo = ProMP(policy=policy, inner_lr=0.1, meta_batch_size=M, num_inner_grad_steps=1, learning_rate=1e-3, num_ppo_steps=2,
                  clip_eps=0.3, init_inner_kl_penalty=5e-4, adaptive_inner_kl_penalty=False)
     trainer = Trainer(algo=algo, policy=policy, env=env, sampler=sampler, sample_processor=proc, n_itr=n_itr, num_inner_grad_steps=1)
+    if resume:
+        trainer.load_snapshot(resume)
+    if build_only:
+        return trainer
     before = policy.get_param_values()
     seen = {}
     orig = logger.dumpkvs
@@ -264,6 +269,102 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
     paths2 = sampler2.obtain_samples()
     assert sampler2.host_fallbacks == 1 and all(len(p['rewards']) == 3 for i in range(M) for p in paths2[i])
     assert len(proc.process_samples(paths2)) == M
+
+
+def run_vpg_scenario(M=3, P=3, T=30, O=5, A=3, hidden=(32, 32), inner_type='log_likelihood', exploration=False):
+    """VPGMAML.optimize_policy: one Adam step on the log-likelihood meta-objective (vpg_maml.py:65-175), against the oracle"""
+    from oracle import policy as op, promp as pm, trpo as otrpo
+    from promp_amd.meta_algos.vpg_maml import VPGMAML
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.utils import logger
+    logger.configure(quiet=True)
+    theta, all_slabs, _ = helpers.make_promp_case(55, M, P, T, O, A, hidden, 1)
+    spec = op.PolicySpec(O, A, hidden)
+    kind = 'loglik' if inner_type == 'log_likelihood' else 'ratio'
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+    policy.set_params(spec.to_ordered_dict(theta))
+    algo = VPGMAML(policy=policy, learning_rate=1e-3, inner_type=inner_type, inner_lr=0.1, meta_batch_size=M,
+                   num_inner_grad_steps=1, exploration=exploration)
+    samples = [[dict(observations=s['observations'], actions=s['actions'], advantages=s['advantages'],
+                     agent_infos=s['agent_infos']) for s in step] for step in all_slabs]
+    coeffs = None
+    if exploration:
+        rng = np.random.RandomState(56)
+        for d in samples[-1]:
+            d['adj_avg_rewards'] = rng.randn(len(d['advantages'])).astype(np.float32) + 0.5
+        coeffs = np.array([np.mean(d['adj_avg_rewards']) for d in samples[-1]], np.float64)
+    algo.optimize_policy(samples, log=False)
+    t64, alpha = theta.astype(np.float64), np.full(spec.n_params, 0.1)
+
+    def objective(th, grad):
+        r = pm.meta_objective_and_grad(spec, th, all_slabs, alpha, np.zeros(1), 0.0, kind, 'loglik', want_grad=grad)
+        v, g = (otrpo.exploration_term(spec, th, all_slabs[0], coeffs, grad) if exploration else (0.0, 0.0))
+        return r['loss'] + v, (r['grad'] + g if grad else None)
+    loss_before, g = objective(t64, True)
+    th_ref = pm.adam_step(t64, g, pm.AdamState(spec.n_params), 1e-3)
+    loss_after, _ = objective(th_ref, False)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], loss_before, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(algo.last_stats['loss_after'], loss_after, rtol=2e-4, atol=1e-6)
+    got = spec.from_ordered_dict(policy.get_param_values())
+    d_dev, d_ref = got - theta, th_ref - t64            # Adam's first step is lr * sign(g) wherever |g| >> eps
+    assert np.mean(np.sign(d_dev) == np.sign(d_ref)) > 0.98 and np.max(np.abs(d_dev)) < 1.01e-3
+
+
+def test_vpg_maml(emu):
+    run_vpg_scenario(inner_type='log_likelihood')
+    run_vpg_scenario(M=2, P=2, T=20, inner_type='likelihood_ratio', exploration=True)
+
+
+def test_logger_formats_and_snapshot_modes(tmp_path):
+    from promp_amd.utils import logger
+    d = str(tmp_path / 'run')
+    logger.configure(dir=d, format_strs=['csv', 'json', 'log'], snapshot_mode='last_gap', snapshot_gap=2, quiet=True)
+    for itr in range(4):
+        logger.logkv('Itr', itr)
+        logger.logkv('LossAfter', np.float32(0.5 - itr))
+        if itr >= 2:
+            logger.logkv('LateKey', 7 * itr)                  # a key that first appears later extends the csv header
+        logger.log('iteration', itr)
+        logger.save_itr_params(itr, dict(itr=itr, x=np.arange(3) + itr))
+        logger.dumpkvs()
+    import csv, json
+    rows = list(csv.DictReader(open(os.path.join(d, 'progress.csv'))))
+    assert [r['Itr'] for r in rows] == ['0', '1', '2', '3'] and rows[0]['LateKey'] == '' and rows[3]['LateKey'] == '21'
+    js = [json.loads(l) for l in open(os.path.join(d, 'progress.json'))]
+    assert len(js) == 4 and js[2]['LateKey'] == 14 and abs(js[1]['LossAfter'] + 0.5) < 1e-6
+    assert 'iteration 3' in open(os.path.join(d, 'log.txt')).read()
+    snap = logger.load_params(os.path.join(d, 'params.pkl'))     # last_gap: params.pkl only on multiples of the gap (0, 2)
+    assert snap['itr'] == 2 and not any(f.startswith('itr_') for f in os.listdir(d))
+    for mode, expect in (('all', {'itr_0.pkl', 'itr_1.pkl', 'itr_2.pkl'}), ('gap', {'itr_0.pkl', 'itr_2.pkl'}), ('last', {'params.pkl'}),
+                         ('none', set())):
+        dd = str(tmp_path / mode)
+        logger.configure(dir=dd, format_strs=['csv'], snapshot_mode=mode, snapshot_gap=2, quiet=True)
+        for itr in range(3):
+            logger.save_itr_params(itr, dict(itr=itr))
+        assert {f for f in os.listdir(dd) if f.endswith('.pkl')} == expect, mode
+    with pytest.raises(NotImplementedError):
+        logger.configure(dir=str(tmp_path / 'bad'), snapshot_mode='sometimes')
+    logger.configure(quiet=True)
+
+
+def test_trainer_snapshot_round_trip(emu, tmp_path):
+    """a run resumed from its snapshot continues with the same parameters, Adam state and KL coefficients"""
+    from promp_amd.utils import logger
+    d = str(tmp_path / 'snap')
+    run_trainer_scenario(n_itr=2, log_dir=d)
+    snap = logger.load_params(os.path.join(d, 'params.pkl'))
+    assert snap['itr'] == 1 and snap['adam_t'] == 2 * 2
+    trainer = run_trainer_scenario(n_itr=3, resume=os.path.join(d, 'params.pkl'), build_only=True)
+    assert trainer.start_itr == 2
+    now = trainer.policy.get_param_values()
+    for k, v in snap['policy_params'].items():
+        np.testing.assert_array_equal(now[k], v)
+    m, v, t = trainer.policy.session.ensure().get_adam_state()
+    np.testing.assert_array_equal(m, snap['adam_m'])
+    assert t == snap['adam_t']
+    np.testing.assert_array_equal(trainer.algo.inner_kl_coeff, snap['inner_kl_coeff'])
+    trainer.train()                                            # one more iteration (itr 2) runs from the restored state
+    assert trainer.policy.session.ctx.get_adam_state()[2] == 3 * 2
 
 
 def test_policy_step_fills_the_slab(emu):
