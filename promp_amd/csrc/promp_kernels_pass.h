@@ -455,12 +455,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     float* P1 = a.partials + (long long)pw.slot[two ? 1 : 0] * a.partial_stride;
     if (!BWD) {   // only the two scalars per segment leave the workgroup
         float* SC = sm;
-        __syncthreads();
+        lds_barrier();
         if (lane == 0) {
             SC[2 * w] = loss;
             SC[2 * w + 1] = klsum;
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 2 && (tid == 0 || two)) {
             float l = 0.f, k = 0.f;
             const int lo = tid ? pw.nw0 : 0, hi = tid ? NW : pw.nw0;
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     float* S = sm;                                   // whole LDS allocation is free now
     const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
     const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
-    __syncthreads();
+    lds_barrier();
     {
         float* mine = S + w * NW2;
 #pragma unroll
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll 2
     for (int e = tid; e < NW2; e += NT) {
         float v[NW];
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         P0[oW2 + e] = t0;
         if (two) P1[oW2 + e] = t1;
     }
-    __syncthreads();
+    lds_barrier();        // (LDS ordering only: the partial-row stores in flight are not waited for)
     {
         // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
         float* mine = S + w * NR2;
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             mine[NP + 1 - NW2] = klsum;
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (int e = tid; e < NR2; e += NT) {
         const int dst = e < oW2 ? e : e + NW2;
         float v[NW];

@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256) k_fit(SampleArgs a, int NBLK) {
 // (k_fit: two workgroup barriers plus LDS traffic per column, 49 us at 45 x 45; this: ~12 us).  All lanes update all
 // trailing columns (the upper triangle is never read), so there is no per-lane masking either.  The back substitution
 // runs over the transposed factor: the rows are written to LDS once and read back by column.
-// Arithmetic order per element is k_fit's (same fma sequence over j), so both kernels give the same coefficients.
+// Same elimination order as k_fit; the column scaling multiplies by 1/sqrt(pivot) instead of dividing by sqrt(pivot), so
+// the two kernels agree to rounding (1e-15 relative), not bit for bit.
 // DT = compile-time bound on D + 1 (the j / k loops are fully unrolled over it; steps j >= D leave by a uniform branch).
 // grid = tasks, block = 256: all four waves sum the task's partial Gram blocks (many loads in flight), wave 0 factorizes.
 template <int DT>
@@ -320,8 +321,10 @@ __global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
 #pragma unroll
         for (int j = 0; j < DT; ++j) {
             if (j < D) {          // (wave-uniform; a `break` would keep the loop rolled and the row out of registers)
-                const double piv = sqrt(readlane_f64(W[j], j));
-                W[j] = (lane == j) ? piv : W[j] / piv;
+                // pivot and its reciprocal from ONE reciprocal square root (the dependent chain of a column step is the
+                // kernel's critical path: sqrt followed by a division is two long software sequences, this is one)
+                const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
+                W[j] = (lane == j) ? piv : W[j] * rs;
 #pragma unroll
                 for (int k = j + 1; k < DT; ++k) W[k] -= W[j] * readlane_f64(W[j], k);      // lane k holds L[k][j] in W[j]
             }

@@ -197,6 +197,7 @@ inline f32x4 pin_agpr(f32x4 v) { return v; }
 inline int wave_uniform(int v) { return v; }
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }
+inline double rsqrt(double x) { return 1.0 / sqrt(x); }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 

@@ -8,6 +8,6 @@ for f in tools/ablate/lib_*.so; do
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['roofline']['kernels']
-print('  step %.3f ms | fwd_bwd %.1f us  hvp %.1f us  fwd %.1f us'%(d['ms_per_step'],k['k_fwd_bwd']['avg_ms']*1e3,k['k_hvp']['avg_ms']*1e3,k['k_fwd_bwd<fwd-only>']['avg_ms']*1e3))"
+print('  step %.3f ms | ' % d['ms_per_step'] + '  '.join('%s %.1f us' % (n, v['avg_ms']*1e3) for n, v in k.items()))"
 done
 cp /tmp/lib_keep.so promp_amd/libpromp_hip.so
