@@ -131,6 +131,13 @@ int promp_set_learn_std(promp_ctx* ctx, int learn_std);
 /* GaussianMLPPolicy(min_std) (policies/gaussian_mlp_policy.py:31,35,71): log_std evaluated from the shared variables is
  * max(log_std_var, log min_std), gradient iff log_std_var >= log min_std (tf.maximum).  Default 1e-6. */
 int promp_set_min_std(promp_ctx* ctx, float min_std);
+/* Launch scheduling knobs (no reference counterpart; results are identical for every setting, -1 keeps a value):
+ *   stage_overlap  != 0 (default): promp_process_samples of steps >= 1 is enqueued on a second stream, ordered behind the
+ *                  last main-stream work on that step's slabs, and joined in front of the first launch that reads its
+ *                  outputs -- it then runs under process_samples(0) + the inner step the host enqueued just before.
+ *   fuse_min_tasks (default 16): from this many local tasks on, the Hessian-vector pass sums each task's partial rows
+ *                  inside its own launch (last-arriving workgroup); below, a separate grid-wide reduction follows. */
+int promp_set_schedule(promp_ctx* ctx, int stage_overlap, int fuse_min_tasks);
 int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
 int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);
 /* MetaPolicy.switch_to_pre_update: replicate theta into every task's parameter slot */

@@ -71,6 +71,7 @@ SIGNATURES = {
     'promp_set_step_sizes': (C.c_int, [_P, _F]),
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
+    'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
     'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
     'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
     'promp_switch_to_pre_update': (C.c_int, [_P]),
@@ -356,6 +357,10 @@ class Context:
         """forward-only evaluation of the meta-objective (the compute_stats pass): loss, inner_kl [K], outer_kl"""
         r = self.optimize(0, 0.0, clip_eps, inner_kl_coeff, inner_kind, outer_kind)
         return dict(loss=r['loss_after'], inner_kl=r['inner_kl'], outer_kl=r['outer_kl'])
+
+    def set_schedule(self, stage_overlap=-1, fuse_min_tasks=-1):
+        """launch scheduling knobs (results do not depend on them); -1 keeps a value"""
+        self._call('promp_set_schedule', int(stage_overlap), int(fuse_min_tasks))
 
     def set_min_std(self, min_std):
         self._call('promp_set_min_std', float(min_std))

@@ -69,6 +69,10 @@ struct StepData {
     double* coeffs = nullptr;
     WorkItem* work[2] = {nullptr, nullptr};
     PassWork* pwork = nullptr;
+    // second-stream sample processing (promp_process_samples of steps >= 1, see stage_a_stream):
+    hipEvent_t ev_use = nullptr;       // main stream: the last enqueued work that reads or writes this step's slabs
+    hipEvent_t ev_done = nullptr;      // side stream: the step's processed outputs are complete
+    bool use_set = false, side_pending = false, dirty = false;
 };
 
 // waves per workgroup of k_chain_hvp (one per SIMD: 512 registers per lane)
@@ -92,6 +96,9 @@ struct promp_ctx {
     char dev_name[256];
     int NP = 0, Dmax = 0, coeff_stride = 0, max_work = 0, partial_stride = 0, gram_stride = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // sample processing of steps >= 1 runs here, under the main stream's step-0 work
+    bool overlap = true;
+    double *gram_partials_side = nullptr, *fit_scratch_side = nullptr;
     std::vector<StepData> steps;
     float *theta = nullptr, *step_sizes = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     long long adam_t = 0;
@@ -113,6 +120,8 @@ struct promp_ctx {
     int rank = 0, nranks = 1;
     float min_log_std = -13.815510558f;  // log(1e-6): GaussianMLPPolicy's default min_std
     bool learn_std = true;               // false: log_std is neither adapted (step size 0) nor trained (no Adam update)
+    int fuse_min_tasks = 16;             // k_chain_hvp sums a task's partial rows in-launch from this many local tasks on
+    int stats_slot = 0;                  // promp_optimize parks the first epoch's statistics in slot 1 (loss_before)
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
@@ -128,6 +137,43 @@ int dev_alloc(T** p, size_t n) {
     HIPCHECK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
     return 0;
 }
+
+// ---- second stream for sample processing -------------------------------------------------------
+// process_samples of a step >= 1 has no data dependence on the main stream's step-0 work (process_samples(0), _adapt):
+// it is enqueued on c->side behind the last main-stream work that touched the step's slabs (ev_use), and the main stream
+// picks the results up (ev_done) in front of the first launch that reads them.
+//
+// Event records are not free on the queue (a few microseconds of bubble each), so the uses are marked lazily: an entry
+// point that touches a step only sets S.dirty on exit; the event is recorded when the next entry point that does NOT
+// touch the step is about to enqueue (settle_others) -- in the training loop that is once per iteration, in front of
+// process_samples(0).  A step still dirty when its processing goes to the side stream is marked on the spot, which
+// orders it behind everything enqueued so far: always correct, merely no overlap.
+int join_side(promp_ctx* c, StepData& S) {
+    if (!S.side_pending) return 0;
+    HIPCHECK(hipStreamWaitEvent(c->stream, S.ev_done, 0));
+    S.side_pending = false;
+    return 0;
+}
+int mark_use(promp_ctx* c, StepData& S) {
+    if (!S.dirty || !S.ev_use) return 0;
+    HIPCHECK(hipEventRecord(S.ev_use, c->stream));
+    S.use_set = true;
+    S.dirty = false;
+    return 0;
+}
+int settle_others(promp_ctx* c, const StepData* touched) {
+    if (!c->overlap) return 0;
+    for (auto& S : c->steps)
+        if (&S != touched && mark_use(c, S)) return -2;
+    return 0;
+}
+struct StepScope {
+    promp_ctx* c;
+    StepData& S;
+    int rc;
+    StepScope(promp_ctx* c_, StepData& S_) : c(c_), S(S_), rc(join_side(c_, S_) | settle_others(c_, &S_)) {}
+    ~StepScope() { S.dirty = true; }
+};
 
 // which family of pass kernels serves a network shape (sample processing alone works for any obs_dim <= 128)
 bool policy_shape_chain(const promp_dims* d) {     // register-chained kernels: hidden widths from {32, 64}, obs_dim <= 32
@@ -227,6 +273,10 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.min_log_std = c->min_log_std;   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
     a.kl_weight = klw;
     a.task_counters = c->task_counters; a.task_slot_offsets = S.chain_slot_offsets;
+    // With many tasks the last arrivers' sums hide under the other tasks' tiles (164 us fused vs 187 + 5 us at 40 tasks);
+    // with few, every task finishes at once and one workgroup per task streaming ~50 partial rows is exposed
+    // (66 us vs 46 + 5 us at 5 tasks): there the grid-wide k_reduce_task follows instead.
+    a.fuse_reduce = (hvp && !c->wide && c->d.n_tasks >= c->fuse_min_tasks) ? 1 : 0;
     a.red_mode = red_mode; a.step_sizes = c->step_sizes; a.cur = cur; a.cur_task_stride = cur_stride; a.next = next;
     a.lam = c->lam; a.v = c->vbuf; a.scal = scal;
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
@@ -252,7 +302,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         PROMP_CHAIN_ALL(PROMP_CHAIN_CASE)
 #undef PROMP_CHAIN_CASE
         HIPCHECK(hipGetLastError());
-        return prof_end(c, id);
+        if (a.fuse_reduce) return prof_end(c, id);
     } else {
         const int b1 = c->d.hidden1 / 32, b2 = c->d.hidden2 / 32;
 #define PROMP_PASS_CASE(B1, B2)                                                                                                   \
@@ -267,7 +317,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     if (prof_end(c, id)) return -2;
     ReduceArgs r;
     r.partials = c->partials; r.partial_stride = c->partial_stride;
-    r.task_wg_offsets = S.task_wg_offsets[c->wide ? 0 : 2];      // k_fwd_bwd writes wave-granular slots (table 2)
+    // k_fwd_bwd writes wave-granular slots (table 2), k_chain_hvp one row per segment
+    r.task_wg_offsets = c->wide ? S.task_wg_offsets[0] : hvp ? S.chain_slot_offsets : S.task_wg_offsets[2];
     r.NP = c->NP;
     r.step_sizes = c->step_sizes; r.mode = red_mode;
     r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
@@ -288,8 +339,10 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
                  bool do_adam, float lr) {
     const int K = c->d.num_inner_steps, M = c->d.n_tasks, NP = c->NP;
     const size_t MNP = (size_t)M * NP;
-    for (int k = 0; k <= K; ++k)
+    for (int k = 0; k <= K; ++k) {
         if (c->steps[k].n_rows == 0) return fail(-3, "step %d has no data", k);
+        if (join_side(c, c->steps[k])) return -2;
+    }
     for (int k = 0; k < K; ++k) {
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
@@ -323,7 +376,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     }
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
-    ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = NP; ad.K = K;
+    ad.stats = c->stats + (size_t)c->stats_slot * (K + 2); ad.eta = c->eta_dev; ad.NP = NP; ad.K = K;
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
     ad.do_update = do_adam ? 1 : 0;
     ad.n_trainable = c->learn_std ? NP : NP - c->d.act_dim;
@@ -336,6 +389,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     if (split) PROMP_LAUNCH(k_mean_adam, dim3((NP + 1 + 255) / 256), 256, 0, c->stream, ad);
     else PROMP_LAUNCH(k_final_adam, dim3((NP + K + 2 + 63) / 64 + 1), 256, 0, c->stream, f, ad);   // one rank: nothing in between
     HIPCHECK(hipGetLastError());
+    for (int k = 0; k <= K; ++k) c->steps[k].dirty = true;
     return 0;
 }
 
@@ -389,6 +443,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->clock_mhz = prop.clockRate / 1000;
     snprintf(c->dev_name, sizeof c->dev_name, "%s", prop.name[0] ? prop.name : PROMP_ARCH_NAME(prop));
     HIPCHECK(hipStreamCreate(&c->stream));
+    HIPCHECK(hipStreamCreate(&c->side));
     const int K = dims->num_inner_steps, M = dims->n_tasks;
     c->NP = param_count(dims);
     c->Dmax = 2 * dims->obs_dim + 4;
@@ -462,9 +517,13 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->scal_inner, (size_t)K * M * 2); rc |= dev_alloc(&c->scal_outer, (size_t)M * 2);
     rc |= dev_alloc(&c->scal_tmp, (size_t)M * 2);
     rc |= dev_alloc(&c->red, NP + K + 2); rc |= dev_alloc(&c->grad_mean, NP);
-    rc |= dev_alloc(&c->stats, (size_t)K + 2); rc |= dev_alloc(&c->eta_dev, (size_t)K);
+    rc |= dev_alloc(&c->stats, (size_t)2 * (K + 2)); rc |= dev_alloc(&c->eta_dev, (size_t)K);
     rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
-    if (nblk_max > 5 || dims->obs_dim > 32) rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
+    rc |= dev_alloc(&c->gram_partials_side, (size_t)c->max_work * c->gram_stride);
+    if (nblk_max > 5 || dims->obs_dim > 32) {
+        rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
+        rc |= dev_alloc(&c->fit_scratch_side, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
+    }
     rc |= dev_alloc(&c->red64, 64);
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
@@ -484,6 +543,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
         rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
         rc |= dev_alloc(&S.work[0], (size_t)c->max_work); rc |= dev_alloc(&S.work[1], (size_t)c->max_work);
+        if (hipEventCreateWithFlags(&S.ev_use, hipEventDisableTiming) != hipSuccess) rc |= 1;
+        if (hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) != hipSuccess) rc |= 1;
     }
     if (rc) { promp_ctx_destroy(c); return -2; }
     *out = c;
@@ -493,24 +554,31 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
 void promp_ctx_destroy(promp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
 #ifndef PROMP_EMU
     if (c->comm) ncclCommDestroy(c->comm);
 #endif
-    for (auto& S : c->steps) free_step(S);
-    void* ptrs[] = {c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    for (auto& S : c->steps) {
+        free_step(S);
+        if (S.ev_use) (void)hipEventDestroy(S.ev_use);
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+    }
+    void* ptrs[] = {c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
                     c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& s : c->prof_slots)
         for (auto ev : s.ev) (void)hipEventDestroy(ev);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int promp_sync(promp_ctx* c) {
     if (!c) return fail(-1, "ctx is NULL");
+    HIPCHECK(hipStreamSynchronize(c->side));
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -725,6 +793,8 @@ static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* t
             return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
     }
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false;
     hipStream_t st = c->stream;
@@ -754,6 +824,8 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
     if (!obs || !rew) return fail(-1, "offsets, obs and rew are required");
     if (set_step_layout(c, step, n_paths, tpo, pro)) return -2;
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     const int M = c->d.n_tasks;
     const size_t R = (size_t)S.n_rows;
     const size_t O = c->d.obs_dim, A = c->d.act_dim;
@@ -774,6 +846,8 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (!c || !o) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     if (!(o->discount >= 0 && o->discount <= 1)) return fail(-1, "discount factor must be in [0,1]");      // samplers/base.py:57
     if (!(o->gae_lambda >= 0 && o->gae_lambda <= 1)) return fail(-1, "gae_lambda must be in [0,1]");       // samplers/base.py:58
@@ -788,10 +862,20 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     a.normalize = o->normalize_adv; a.positive = o->positive_adv;
     a.ret64 = S.ret64; a.ret32 = S.ret32; a.adv64 = S.adv64; a.adv32 = S.adv32;
     a.path_ret0 = S.path_ret0; a.path_undisc = S.path_undisc; a.path_rsq = S.path_rsq; a.path_mom = S.path_mom;
-    a.gram_partials = c->gram_partials; a.coeffs = S.coeffs; a.coeff_stride = c->coeff_stride;
+    a.coeffs = S.coeffs; a.coeff_stride = c->coeff_stride;
     a.bl64 = nullptr;
     S.feat_dim = a.D;
-    hipStream_t st = c->stream;
+    // Steps >= 1 go to the second stream (no data dependence on the step-0 work the host enqueued just before: their
+    // samples are resident), behind the last main-stream work that touched this step's slabs.  Per-kernel timing
+    // (promp_profile) keeps everything on the one stream it brackets.
+    const bool on_side = c->overlap && !c->prof && step >= 1;
+    hipStream_t st = on_side ? c->side : c->stream;
+    a.gram_partials = on_side ? c->gram_partials_side : c->gram_partials;
+    double* fit_scratch = on_side ? c->fit_scratch_side : c->fit_scratch;
+    if (on_side) {
+        if (mark_use(c, S)) return -2;
+        if (S.use_set) HIPCHECK(hipStreamWaitEvent(c->side, S.ev_use, 0));
+    }
     PROMP_LAUNCH(k_returns, dim3(S.n_paths), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
     if (a.kind != BASE_ZERO) {
@@ -819,7 +903,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             else if (DA <= 64) { auto k = k_fit_wave<64>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
             else PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         } else {
-            PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), 1024, fitw_smem(a.D), st, a, nblk, c->fit_scratch);
+            PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), 1024, fitw_smem(a.D), st, a, nblk, fit_scratch);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -828,6 +912,10 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     a.work = S.work[1];                         // k_normalize: two workgroups per CU
     PROMP_LAUNCH(k_normalize, dim3(S.n_work[1]), 256, 0, st, a);
     HIPCHECK(hipGetLastError());
+    if (on_side) {
+        HIPCHECK(hipEventRecord(S.ev_done, c->side));
+        S.side_pending = true;
+    }
     S.processed = true;
     S.has_adv = true;
     return 0;
@@ -838,6 +926,8 @@ int promp_download_processed(promp_ctx* c, int step, float* returns, float* adv,
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (!S.processed) return fail(-3, "step %d has not been processed", step);
     hipStream_t st = c->stream;
     if (returns) HIPCHECK(hipMemcpyAsync(returns, S.ret32, sizeof(float) * S.n_rows, hipMemcpyDeviceToHost, st));
@@ -860,6 +950,8 @@ int promp_download_raw(promp_ctx* c, int step, double* ret64, double* adv64) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (!S.processed) return fail(-3, "step %d has not been processed", step);
     if (ret64) HIPCHECK(hipMemcpyAsync(ret64, S.ret64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
     if (adv64) HIPCHECK(hipMemcpyAsync(adv64, S.adv64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
@@ -872,6 +964,8 @@ int promp_set_coeffs(promp_ctx* c, int step, int kind, const double* coeffs) {
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (kind < 1 || kind > 2) return fail(-1, "coefficients exist for the linear baselines only");
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     const int D = feature_dim(&c->d, kind), M = c->d.n_tasks;
     std::vector<double> tmp((size_t)M * c->coeff_stride, 0.0);
     for (int i = 0; i < M; ++i) memcpy(tmp.data() + (size_t)i * c->coeff_stride, coeffs + (size_t)i * D, sizeof(double) * D);
@@ -886,6 +980,8 @@ int promp_predict_baseline(promp_ctx* c, int step, int kind, double* out) {
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (kind < 0 || kind > 2) return fail(-1, "unknown baseline kind %d", kind);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     SampleArgs a;
     memset(&a, 0, sizeof a);
@@ -909,6 +1005,8 @@ int promp_set_advantages(promp_ctx* c, int step, const float* adv) {
     if (!c || !adv) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     HIPCHECK(hipMemcpyAsync(S.adv32, adv, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -947,6 +1045,15 @@ int promp_set_min_std(promp_ctx* c, float min_std) {
     c->min_log_std = logf(min_std);
     return 0;
 }
+int promp_set_schedule(promp_ctx* c, int stage_overlap, int fuse_min_tasks) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (stage_overlap >= 0) {
+        HIPCHECK(hipStreamSynchronize(c->side));
+        c->overlap = stage_overlap != 0;
+    }
+    if (fuse_min_tasks >= 0) c->fuse_min_tasks = fuse_min_tasks;
+    return 0;
+}
 int promp_set_learn_std(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
     if (on && !c->learn_std) return fail(-3, "learn_std cannot be switched back on: the log_std step sizes were zeroed (set the step sizes again)");
@@ -981,6 +1088,8 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     return launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f, false, RED_STEP, c->theta_tasks,
                        c->NP, c->theta_tasks, c->scal_tmp);
@@ -1021,6 +1130,8 @@ static int begin_fixed_rollout(promp_ctx* c, int step, int B, int T) {
     for (int p = 0; p <= M * B; ++p) pro[p] = p * T;
     if (set_step_layout(c, step, M * B, tpo.data(), pro.data())) return -2;
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     S.has_policy = true;
     S.ls_per_row = 0;
     S.rollout_B = B; S.rollout_T = T;
@@ -1047,6 +1158,8 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     const int M = c->d.n_tasks, B = envs_per_task, T = path_length;
     const long long rows = (long long)M * B * T;
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     const size_t need = sizeof(double) * ((size_t)M * 2 + (size_t)M * B * 2) + sizeof(float) * (size_t)rows * 2;
     if (ensure_rollout_buf(c, need)) return -2;
     double* d_goals = (double*)c->rollout_buf;
@@ -1078,6 +1191,8 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     if (!c || !obs || !actions_out) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.rollout_B < 1) return fail(-3, "promp_begin_rollout has not been called for step %d", step);
     const int M = c->d.n_tasks, B = S.rollout_B, T = S.rollout_T, O = c->d.obs_dim, A = c->d.act_dim;
     if (t < 0 || t >= T) return fail(-1, "time step %d outside the horizon %d", t, T);
@@ -1104,6 +1219,8 @@ int promp_set_rewards(promp_ctx* c, int step, const float* rew) {
     if (!c || !rew) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1115,6 +1232,8 @@ int promp_download_step(promp_ctx* c, int step, float* obs, float* act, float* r
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     const size_t R = S.n_rows, O = c->d.obs_dim, A = c->d.act_dim, M = c->d.n_tasks;
     hipStream_t st = c->stream;
@@ -1163,13 +1282,18 @@ int promp_optimize(promp_ctx* c, int num_epochs, float lr, float clip_eps, const
     if (upload_eta(c, eta)) return -2;
     const int K = c->d.num_inner_steps;
     for (int e = 0; e < num_epochs; ++e) {
-        if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, true, true, lr)) return -2;
-        if (e == 0 && loss_before)  // the loss evaluated by the first epoch, before its update
-            HIPCHECK(hipMemcpyAsync(loss_before, c->stats, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        // the loss evaluated by the first epoch, before its update, stays on the device (second statistics slot) until the
+        // end: a download here would hold the host back until the epoch has run, and the next one would start late
+        c->stats_slot = (e == 0) ? 1 : 0;
+        const int rc = enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, true, true, lr);
+        c->stats_slot = 0;
+        if (rc) return -2;
     }
     if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, false, false, 0.f)) return -2;   // compute_stats
-    if (stats_after) HIPCHECK(hipMemcpyAsync(stats_after, c->stats, sizeof(float) * (K + 2), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<float> st((size_t)2 * (K + 2));
+    if (copy_out(c, st.data(), c->stats, st.size())) return -2;
+    if (stats_after) memcpy(stats_after, st.data(), sizeof(float) * (K + 2));
+    if (loss_before) *loss_before = num_epochs > 0 ? st[K + 2] : st[0];
     return 0;
 }
 
@@ -1179,6 +1303,8 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (kind < 0 || kind > 3) return fail(-1, "unknown objective kind %d", kind);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     const int M = c->d.n_tasks;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
@@ -1195,6 +1321,8 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     if (!c || !v || !out) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     const int M = c->d.n_tasks, NP = c->NP;
     if (copy_in(c, c->vbuf, v, (size_t)M * NP)) return -2;
     HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
@@ -1287,6 +1415,8 @@ int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long
     if (!c || !out) return fail(-1, "NULL argument");
     if (!PROMP_STAMPS_ON) return fail(-3, "phase stamps need a build with -DPROMP_DEV_STAMPS");
     StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
     HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * (256 + 4 * 1024), c->stream));
     c->dbg_enabled = true;
     const int rc = launch_pass(c, S, hvp != 0, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);

@@ -82,6 +82,7 @@ struct PassArgs {
     int* task_counters;             // [tasks]; zero between launches (the last arriver resets its task's counter)
     const int* task_slot_offsets;   // [tasks+1]
     int red_mode;
+    int fuse_reduce;                // chain kernels: the last-arriving workgroup of a task sums its partial rows (else k_reduce_task follows)
     const float* step_sizes;        // [Theta]
     const float* cur;               // RED_STEP: [Theta] or [tasks][Theta]
     long long cur_task_stride;
@@ -882,7 +883,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         float* P = a.partials + (long long)sg * a.partial_stride;
         chain_reduce_to_partial<NC1, NC2, NOB, NW>(sm + 4, P, aw2, aw1, aw3, ob1acc, ob2acc, outs0, outs1, outb30, outb31, 0.f, klsum, O, A, tid);
         CH_STAMP(3);
-        chain_task_reduce<NT>(a, (int*)sm, task, NP, tid);
+        if (a.fuse_reduce) chain_task_reduce<NT>(a, (int*)sm, task, NP, tid);
         CH_STAMP(4);
         CH_WGSTAMP(1 + (sg - sg0 < 2 ? sg - sg0 : 1));
     }

@@ -221,6 +221,45 @@ def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, at
     np.testing.assert_array_equal(a[7], b[7])
 
 
+def check_schedule_invariance(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, epochs=2):
+    """launch scheduling must not change a single bit: sample processing of steps >= 1 on the second stream vs all on one
+    stream, and the Hessian-vector pass's in-launch task reduction vs the separate reduction kernel.  Several iterations of
+    process_samples(0) -> adapt -> process_samples(1..K) -> optimize on resident samples, with nothing synchronising the host
+    in between, so that an ordering hole between the two streams (iteration n+1's processing overwriting advantages that
+    iteration n's passes still read) would show up as a difference"""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=True)
+    spec = op.PolicySpec(O, A, hidden)
+    eta = np.full(K, 5e-4, np.float32)
+    kwargs = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True, positive_adv=False)
+    out = []
+    for overlap, fuse_min in ((0, 0), (1, 0), (0, 10 ** 6), (1, 10 ** 6)):
+        ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+        ctx.set_schedule(overlap, fuse_min)
+        helpers.upload_slabs(ctx, all_paths, all_slabs)
+        ctx.set_theta(theta)
+        ctx.set_step_sizes(np.full(spec.n_params, 0.1, np.float32))
+        for _ in range(iters):
+            ctx.switch_to_pre_update()
+            ctx.process_samples(0, baseline_kind=KIND['linear_feature'], **kwargs)
+            for k in range(K):
+                ctx.inner_adapt(k)
+                ctx.process_samples(k + 1, baseline_kind=KIND['linear_feature'], **kwargs)
+            res = ctx.optimize(epochs, 1e-3, 0.3, eta)
+        g, st = ctx.meta_grad(0.3, eta)
+        proc = [ctx.download_processed(k) for k in range(K + 1)]
+        out.append((ctx.get_theta(), g, ctx.get_task_thetas(), res, st, proc))
+        ctx.close()
+    ref = out[0]
+    for other in out[1:]:
+        np.testing.assert_array_equal(ref[0], other[0])
+        np.testing.assert_array_equal(ref[1], other[1])
+        np.testing.assert_array_equal(ref[2], other[2])
+        assert ref[3] == pytest_approx_dict(other[3])
+        for a, b in zip(ref[5], other[5]):
+            for key in a:
+                np.testing.assert_array_equal(a[key], b[key])
+
+
 def pytest_approx_dict(d):
     class _Eq(dict):
         def __eq__(self, other):

@@ -248,6 +248,12 @@ def test_split_reduce_allreduce_adam_equals_fused_launch(lib):
     pc.check_split_path_equals_fused(lib, 72, M=3, P=3, T=50, O=111, A=8, hidden=(128, 128), epochs=2, attach_comm=False)
 
 
+def test_launch_scheduling_does_not_change_results(lib):
+    """second-stream sample processing and the fused / separate task reduction of the Hessian-vector pass: bitwise the same"""
+    pc.check_schedule_invariance(lib, 81, M=6, P=5, T=120, O=20, A=6, hidden=(64, 64), K=1, iters=4)
+    pc.check_schedule_invariance(lib, 82, M=3, P=3, T=60, O=12, A=4, hidden=(64, 32), K=2, iters=2)
+
+
 def test_communicator_moves_to_a_regrown_context(lib):
     a = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)
     a.comm_init(0, 1, _lib.comm_unique_id(lib))

@@ -12,4 +12,5 @@ f = glob.glob('gpurun_out/trace/**/*kernel_stats.csv', recursive=True)
 for r in csv.DictReader(open(f[0])):
     print('%-70s calls %5s  avg %9.1f us  total %6.2f %%' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, float(r['Percentage'])))
 PY
+[ -n "$TIMELINE" ] && python tools/timeline.py gpurun_out/trace | tee gpurun_out/trace/timeline.txt
 rm -f gpurun_out/trace/*/*kernel_trace.csv gpurun_out/trace/*kernel_trace.csv
