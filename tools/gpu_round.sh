@@ -21,5 +21,16 @@ done
 timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 > $ROOT/$R/bench_config4.json 2> $ROOT/$R/bench_config4.err; echo "bench config4 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace4 -o trace4 -- python $ROOT/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/$R/trace4.err; echo "trace4 rc=$?"
 cd $ROOT; rm -f $R/trace4/*kernel_trace.csv
+# BASELINE config 5 (TRPO-MAML on config 3's shapes)
+timeout 600 python $ROOT/bench.py --config 5 --steps 5 --warmup 1 > $ROOT/$R/bench_config5.json 2> $ROOT/$R/bench_config5.err; echo "bench config5 rc=$?"
+# one rank's share of the fixed 40-task batch at 2 / 4 / 8 ranks, timed on this one GPU (no collective: kernels only)
+for n in 2 4 8; do
+  timeout 300 python $ROOT/bench.py --shard-of $n --steps 30 --warmup 3 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('shard-of $n: %d tasks on this GPU, %.4f ms/step' % (d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/shard_timings.txt
+done
+cat $ROOT/$R/shard_timings.txt
+# per-launch timeline of one step (both streams) from the kernel trace
+python $ROOT/tools/timeline.py $ROOT/$R/trace > $ROOT/$R/timeline.txt 2>&1
 cd $ROOT; rm -f $R/trace/*kernel_trace.csv $R/pmc*/*kernel_trace.csv   # keep the summaries small
 ls -R $R | head -40
