@@ -115,8 +115,11 @@ def main():
             plog.configure(quiet=True)
             shim = SimpleNamespace(session=SimpleNamespace(ctx=ctx, M_global=M_global, world=world), num_inner_grad_steps=K,
                                    inner_kind=_lib.INNER_LOGLIK, exploration=False, meta_batch_size=M)
-            cg = ConjugateGradientOptimizer()
-            cg.build_graph(_DeviceEvaluator(shim), 0.01)
+            from promp_amd.optimizers.conjugate_gradient_optimizer import ExactDeviceHvp
+            cgs = dict(finite_difference=ConjugateGradientOptimizer(), exact=ConjugateGradientOptimizer(hvp_approach=ExactDeviceHvp()))
+            for o in cgs.values():
+                o.build_graph(_DeviceEvaluator(shim), 0.01)
+            mode = dict(hvp='finite_difference')     # the reference's construction is the timed default (parity mode)
 
         def iteration():
             ctx.switch_to_pre_update()                       # meta_trainer.py:85
@@ -124,12 +127,15 @@ def main():
             ctx.inner_adapt(0, _lib.INNER_LOGLIK if trpo else _lib.INNER_RATIO)     # :116
             ctx.process_samples(1, **opts)                   # :105  (step 1)
             if trpo:
+                cg = cgs[mode['hvp']]
                 kl0, l0 = cg.constraint_val(), cg.loss()
                 cg.optimize()
                 return dict(loss_before=l0, loss_after=cg.loss(), kl_before=kl0, kl_after=cg.constraint_val(),
                             n_backtracks=cg.last['n_backtracks'], rejected=cg.last['rejected'])
             return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
         iteration.upload = upload
+        iteration.mode = mode if trpo else None
+        iteration.reset = lambda: ctx.set_theta(theta0)
         return ctx, iteration, M
 
     def run_timed(ctx, iteration, warmup, n):
@@ -172,6 +178,21 @@ def main():
                    'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
                    'device': info['name']},
     }
+
+    # ---- config 5 with the exact constraint Hessian-vector product (promp_constraint_hvp) instead of the reference's finite
+    # difference: reported beside the timed default, never as `value` ----
+    if trpo and rank == 0 and world == 1 and iteration.mode is not None:
+        iteration.reset()
+        iteration.mode['hvp'] = 'exact'
+        n_ex = max(2, min(args.steps, 5))
+        el_ex, res_ex = run_timed(ctx, iteration, 1, n_ex)
+        iteration.mode['hvp'] = 'finite_difference'
+        iteration.reset()
+        iteration()
+        out['exact_hvp'] = {'ms_per_step': 1e3 * el_ex / n_ex, 'value': M_global * N * (K + 1) * n_ex / el_ex, 'steps': n_ex,
+                            'loss_after': float(res_ex['loss_after']), 'kl_after': float(res_ex['kl_after']),
+                            'note': 'same step with hvp_approach=exact: 3 R-operator passes per product instead of two '
+                                    'displaced constraint gradients (6 passes)'}
 
     # ---- host -> device cost of the two slabs (never part of `value`: the timed region starts with the batch in HBM) ----
     if rank == 0 and world == 1:

@@ -205,6 +205,15 @@ int promp_download_step(promp_ctx* ctx, int step, float* obs, float* act, float*
  *   stats_out [K+2] = { loss, inner_kl[0..K-1], outer_kl };  grad_out [Theta] (may be NULL). */
 int promp_meta_grad(promp_ctx* ctx, float clip_eps, const float* inner_kl_coeff, int inner_kind, int outer_kind,
                     float* grad_out, float* stats_out);
+/* ConjugateGradientOptimizer's Hessian-vector product of the constraint (optimizers/conjugate_gradient_optimizer.py:59-89
+ * builds it by finite differences of the constraint gradient, hvp_approach=FiniteDifferenceHvp; SURVEY 8f row 2 asks
+ * for the exact one): out [Theta] = H v, H = Hessian wrt theta of mean_i KL(pi_old || pi_{theta'_i(theta)}) on the last
+ * step's samples (trpo_maml.py:146-158), through the K inner steps (Gauss-Newton form J^T H_KL J: exact where the old
+ * distribution is the adapted policy's, i.e. at the parameters TRPO evaluates it).  The mean is over the GLOBAL
+ * meta-batch (all-reduce when a communicator is attached).  refresh_chain != 0 recomputes the adapted parameters
+ * theta_k from the current theta first (needed once per theta).  No reg_coeff term: the caller adds reg_coeff * v.
+ * Register-chained kernels only (hidden sizes from {32,64}, obs_dim <= 32); other shapes fail with -1. */
+int promp_constraint_hvp(promp_ctx* ctx, int inner_kind, const float* v, int refresh_chain, float* out);
 /* tf.train.AdamOptimizer step on theta with the gradient left by promp_meta_grad
  * (optimizers/maml_first_order_optimizer.py:24,64; b1=.9 b2=.999 eps=1e-8, bias-corrected lr). */
 int promp_adam_step(promp_ctx* ctx, float learning_rate);

@@ -42,6 +42,20 @@ def exploration_term(spec, theta, slabs0, coeffs, want_grad=True):
     return val / n, grad / n
 
 
+def constraint_hvp_fd64(spec, theta, all_slabs, step_sizes, x, inner_kind='loglik', rel_eps=1e-6):
+    """Hessian-vector product of the TRPO constraint (mean outer KL through the adaptation, trpo_maml.py:146-158) by a
+    central difference of the float64 constraint gradient -- the reference's own construction
+    (conjugate_gradient_optimizer.py:59-89) carried out in float64 with a step scaled to the direction, where its
+    truncation + rounding error is ~1e-9 relative: the checker for the device's exact product."""
+    theta = np.asarray(theta, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    K = len(all_slabs) - 1
+    eps = rel_eps / max(np.linalg.norm(x), 1e-30) * max(np.linalg.norm(theta), 1.0)
+    ev = lambda th: pm.meta_objective_and_grad(spec, th, all_slabs, step_sizes, np.zeros(K), 0.0, inner_kind, 'kl',
+                                               want_grad=True)['grad']
+    return (ev(theta + eps * x) - ev(theta - eps * x)) / (2 * eps)
+
+
 def trpo_maml_step(spec, theta, all_slabs, step_sizes, inner_kind='loglik', max_kl=0.01, cg_iters=10, reg_coeff=0.0,
                    backtrack_ratio=0.8, max_backtracks=15, fd_eps=1e-5, explore_coeffs=None):
     K = len(all_slabs) - 1

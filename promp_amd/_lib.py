@@ -72,6 +72,7 @@ SIGNATURES = {
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
+    'promp_constraint_hvp': (C.c_int, [_P, C.c_int, _F, C.c_int, _F]),
     'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
     'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
     'promp_switch_to_pre_update': (C.c_int, [_P]),
@@ -386,6 +387,14 @@ class Context:
         self._call('promp_eval_loss_grad', int(step), int(kind), float(clip_eps), int(bool(clip_log_std)),
                    _ptr(g, C.c_float), _ptr(l, C.c_float), _ptr(k, C.c_float))
         return g, l, k
+
+    def constraint_hvp(self, v, inner_kind=INNER_LOGLIK, refresh_chain=True):
+        """exact Hessian-vector product of the mean outer KL through the adaptation (promp_constraint_hvp)"""
+        v = _f32(v)
+        assert v.shape == (self.n_params,)
+        out = np.empty_like(v)
+        self._call('promp_constraint_hvp', int(inner_kind), _ptr(v, C.c_float), int(bool(refresh_chain)), _ptr(out, C.c_float))
+        return out
 
     def eval_hvp(self, step, v, inner_kind=INNER_RATIO, clip_log_std=False, kl_weight=0.0):
         v = _f32(v)

@@ -103,6 +103,7 @@ struct promp_ctx {
     float *theta = nullptr, *step_sizes = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     long long adam_t = 0;
     float *theta_tasks = nullptr, *chain = nullptr, *lam = nullptr, *vbuf = nullptr;
+    float* wbuf = nullptr;               // promp_constraint_hvp: [tasks][Theta], allocated on first use
     float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
     float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
     double *gram_partials = nullptr, *red64 = nullptr;
@@ -564,7 +565,7 @@ void promp_ctx_destroy(promp_ctx* c) {
         if (S.ev_use) (void)hipEventDestroy(S.ev_use);
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
     }
-    void* ptrs[] = {c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    void* ptrs[] = {c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
                     c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
@@ -1255,6 +1256,70 @@ int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_ki
     if (grad_out && copy_out(c, grad_out, c->grad_mean, c->NP)) return -2;
     if (stats_out && copy_out(c, stats_out, c->stats, c->d.num_inner_steps + 2)) return -2;
     HIPCHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Exact Hessian-vector product of the TRPO constraint, mean_i KL(pi_old || pi_{theta'_i(theta)}) on the last step's samples,
+// through the adaptation: with J_k = I - diag(alpha) H_k(theta_k) (H_k = Hessian of task i's inner objective on step k),
+//     H v = mean_i  J_0^T ... J_{K-1}^T  H_KL(theta_K)  J_{K-1} ... J_0  v .
+// The terms that differentiate the J_k are contracted with grad_{theta_K} KL, which is zero where TRPO builds the
+// product: at the parameters the samples were drawn with (old distribution == adapted policy).  2K + 1 R-operator passes.
+int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refresh_chain, float* out) {
+    if (!c || !v || !out) return fail(-1, "NULL argument");
+    if (c->wide) return fail(-1, "the exact constraint Hessian-vector product runs on the register-chained pass kernels "
+                                 "(hidden sizes from {32, 64}, obs_dim <= 32); use the finite-difference product for this shape");
+    const int K = c->d.num_inner_steps, M = c->d.n_tasks, NP = c->NP;
+    const size_t MNP = (size_t)M * NP;
+    for (int k = 0; k <= K; ++k) {
+        if (c->steps[k].n_rows == 0) return fail(-3, "step %d has no data", k);
+        if (join_side(c, c->steps[k])) return -2;
+    }
+    if (!c->wbuf && dev_alloc(&c->wbuf, MNP)) return -2;
+    auto theta_of = [&](int k, long long* stride) -> const float* {
+        *stride = (k == 0) ? 0 : NP;
+        return (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
+    };
+    const int lk = loss_kind_inner(inner_kind);
+    long long st = 0;
+    if (refresh_chain)
+        for (int k = 0; k < K; ++k) {
+            const float* th = theta_of(k, &st);
+            if (launch_pass(c, c->steps[k], false, th, st, lk, 0.f, k == 0, 0.f, false, RED_STEP, th, st,
+                            c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+        }
+    HIPCHECK(hipMemcpyAsync(c->grad_mean, v, sizeof(float) * NP, hipMemcpyHostToDevice, c->stream));
+    PROMP_LAUNCH(k_replicate, dim3((NP + 255) / 256), 256, 0, c->stream, c->vbuf, c->grad_mean, NP, M);
+    const dim3 eg((NP + 255) / 256, M);
+    auto pass = [&](int k, int kind) -> int {
+        const float* th = theta_of(k, &st);
+        return launch_pass(c, c->steps[k], true, th, st, kind, 0.f, k == 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
+    };
+    for (int k = 0; k < K; ++k) {                      // u = J_{K-1} ... J_0 v
+        if (pass(k, lk)) return -2;
+        PROMP_LAUNCH(k_jstep, eg, 256, 0, c->stream, c->vbuf, c->wbuf, c->lam, c->step_sizes, NP, 0);
+    }
+    if (pass(K, LOSS_KL)) return -2;                   // w = H_KL(theta_K) u
+    PROMP_LAUNCH(k_jstep, eg, 256, 0, c->stream, c->vbuf, c->wbuf, c->lam, c->step_sizes, NP, 1);
+    for (int k = K - 1; k >= 0; --k) {                 // w = J_k^T w
+        if (pass(k, lk)) return -2;
+        PROMP_LAUNCH(k_jstep, eg, 256, 0, c->stream, c->vbuf, c->wbuf, c->lam, c->step_sizes, NP, 2);
+    }
+    HIPCHECK(hipGetLastError());
+    FinalArgs f;
+    f.lam = c->wbuf; f.NP = NP; f.K = K; f.n_tasks = M;
+    f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = 1;
+    PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
+    HIPCHECK(hipGetLastError());
+#ifndef PROMP_EMU
+    if (c->comm) {
+        ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)NP, ncclFloat, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    }
+#endif
+    if (copy_out(c, out, c->red, NP)) return -2;
+    const float inv = 1.0f / (float)c->d.n_tasks_global;
+    for (int j = 0; j < NP; ++j) out[j] *= inv;
+    for (int k = 0; k <= K; ++k) c->steps[k].dirty = true;
     return 0;
 }
 

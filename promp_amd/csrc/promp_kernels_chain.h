@@ -694,23 +694,51 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 const float dklm0 = -2.f * (mo0 - mu0) * rden0 * invN, dklm1 = -2.f * (mo1 - mu1) * rden1 * invN;
                 const float dkls0 = ((-2.f * sn20 * den0 - 4.f * num0 * sn20) * (rden0 * rden0) + 1.f) * invN;
                 const float dkls1 = ((-2.f * sn21 * den1 - 4.f * num1 * sn21) * (rden1 * rden1) + 1.f) * invN;
-                {
-                    const float Rz = -Rmu0 * e0 - z0 * Rs0;
-                    const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
-                    const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
-                    d0 = own0 ? c * z0 * e0 : 0.f;
-                    qm0 = own0 ? km * (Rd + klw * dklm0) : 0.f;
-                    outs0 += own0 ? km * (Rds + klw * dkls0) : 0.f;
-                    outb30 += qm0;
-                }
-                {
-                    const float Rz = -Rmu1 * e1 - z1 * Rs1;
-                    const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
-                    const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
-                    d1 = own1 ? c * z1 * e1 : 0.f;
-                    qm1 = own1 ? km * (Rd + klw * dklm1) : 0.f;
-                    outs1 += own1 ? km * (Rds + klw * dkls1) : 0.f;
-                    outb31 += qm1;
+                if (a.loss_kind == LOSS_KL) {
+                    // The objective is the mean KL itself (the TRPO constraint): primal cotangent dKL/dmu, tangent cotangents
+                    // R'{dKL/dmu}, R'{dKL/ds}.  With D = mu_old - mu, den = 2 e^{2s} + 1e-8, num = D^2 + e^{2 s_old} - e^{2s}:
+                    //   dKL/dmu = -2 D / den                     R'{.} = 2 R'mu / den + 8 D e^{2s} R's / den^2
+                    //   dKL/ds  = 1 - 2 P / den^2, P = e^{2s} (den + 2 num)
+                    //   R'{P}   = 2 e^{2s} R's (den + 2 num) - 4 e^{2s} D R'mu ;  R'{dKL/ds} = -2 R'{P} / den^2 + 16 P e^{2s} R's / den^3
+                    {
+                        const float D = mo0 - mu0, P = sn20 * (den0 + 2.f * num0);
+                        const float RP = 2.f * sn20 * Rs0 * (den0 + 2.f * num0) - 4.f * sn20 * D * Rmu0;
+                        const float Rdm = 2.f * Rmu0 * rden0 + 8.f * D * sn20 * Rs0 * (rden0 * rden0);
+                        const float Rds = (-2.f * RP + 16.f * P * sn20 * Rs0 * rden0) * (rden0 * rden0);
+                        d0 = own0 ? km * dklm0 : 0.f;
+                        qm0 = own0 ? km * Rdm * invN : 0.f;
+                        outs0 += own0 ? km * Rds * invN : 0.f;
+                        outb30 += qm0;
+                    }
+                    {
+                        const float D = mo1 - mu1, P = sn21 * (den1 + 2.f * num1);
+                        const float RP = 2.f * sn21 * Rs1 * (den1 + 2.f * num1) - 4.f * sn21 * D * Rmu1;
+                        const float Rdm = 2.f * Rmu1 * rden1 + 8.f * D * sn21 * Rs1 * (rden1 * rden1);
+                        const float Rds = (-2.f * RP + 16.f * P * sn21 * Rs1 * rden1) * (rden1 * rden1);
+                        d1 = own1 ? km * dklm1 : 0.f;
+                        qm1 = own1 ? km * Rdm * invN : 0.f;
+                        outs1 += own1 ? km * Rds * invN : 0.f;
+                        outb31 += qm1;
+                    }
+                } else {
+                    {
+                        const float Rz = -Rmu0 * e0 - z0 * Rs0;
+                        const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
+                        const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
+                        d0 = own0 ? c * z0 * e0 : 0.f;
+                        qm0 = own0 ? km * (Rd + klw * dklm0) : 0.f;
+                        outs0 += own0 ? km * (Rds + klw * dkls0) : 0.f;
+                        outb30 += qm0;
+                    }
+                    {
+                        const float Rz = -Rmu1 * e1 - z1 * Rs1;
+                        const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
+                        const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
+                        d1 = own1 ? c * z1 * e1 : 0.f;
+                        qm1 = own1 ? km * (Rd + klw * dklm1) : 0.f;
+                        outs1 += own1 ? km * (Rds + klw * dkls1) : 0.f;
+                        outb31 += qm1;
+                    }
                 }
             }
             CH_TSTAMP(4);

@@ -204,6 +204,24 @@ __global__ void __launch_bounds__(256) k_replicate(float* dst, const float* src,
         for (int i = 0; i < n_tasks; ++i) dst[(long long)i * NP + j] = src[j];
 }
 
+// Elementwise glue of promp_constraint_hvp (products with the adaptation Jacobian J = I - diag(alpha) H):
+//   mode 0:  dir += alpha * lam                       (dir <- J dir, lam = -H dir from the pass before)
+//   mode 1:  w = -lam ;      dir = alpha * w          (w <- H_KL u, lam = -H_KL u)
+//   mode 2:  w += lam ;      dir = alpha * w          (w <- J^T w, lam = -H (alpha * w))
+// grid = (ceil(NP / 256), tasks)
+__global__ void __launch_bounds__(256) k_jstep(float* dir, float* w, const float* lam, const float* alpha, int NP, int mode) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= NP) return;
+    const long long tj = (long long)blockIdx.y * NP + j;
+    if (mode == 0) {
+        dir[tj] += alpha[j] * lam[tj];
+        return;
+    }
+    const float x = (mode == 1) ? -lam[tj] : w[tj] + lam[tj];
+    w[tj] = x;
+    dir[tj] = alpha[j] * x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_policy_forward: mean network of every task's CURRENT parameters on a small batch of observations
 // (MetaGaussianMLPPolicy.get_actions, policies/meta_gaussian_mlp_policy.py:99-157: [tasks][B][O] -> [tasks][B][A]).

@@ -3,7 +3,7 @@ BASELINE.json config 5 (run_scripts/maml_run_mujoco.py).  exploration=True adds 
 import numpy as np
 
 from .. import _lib
-from ..optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
+from ..optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer, ExactDeviceHvp, FiniteDifferenceHvp
 from ..utils import logger
 from .base import MAMLAlgo
 
@@ -53,6 +53,9 @@ class _DeviceEvaluator(object):
     def constraint_gradient(self):
         return self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_KL)[0]
 
+    def constraint_hvp(self, x, refresh_chain=True):   # exact (d2 constraint / d theta2) x on the device
+        return self.ctx.constraint_hvp(np.asarray(x, dtype=np.float32), self.algo.inner_kind, refresh_chain)
+
     def get_theta(self):
         return self.ctx.get_theta()
 
@@ -64,11 +67,13 @@ class TRPOMAML(MAMLAlgo):
     """
     Args (trpo_maml.py:23-31): policy, name, step_size (trust region), inner_type in {'log_likelihood',
     'likelihood_ratio'}, exploration (E-MAML), inner_lr, meta_batch_size, num_inner_grad_steps,
-    trainable_inner_step_size
+    trainable_inner_step_size; plus hvp_approach in {'finite_difference' (the reference's, default), 'exact'}
     """
 
-    def __init__(self, *args, name='trpo_maml', step_size=0.01, inner_type='likelihood_ratio', exploration=False, **kwargs):
+    def __init__(self, *args, name='trpo_maml', step_size=0.01, inner_type='likelihood_ratio', exploration=False,
+                 hvp_approach='finite_difference', **kwargs):
         super(TRPOMAML, self).__init__(*args, **kwargs)
+        assert hvp_approach in ('finite_difference', 'exact')
         assert inner_type in ['log_likelihood', 'likelihood_ratio', 'dice']
         if inner_type == 'dice':
             raise NotImplementedError          # as the reference (trpo_maml.py:63-64)
@@ -80,7 +85,8 @@ class TRPOMAML(MAMLAlgo):
         self._optimization_keys = ['observations', 'actions', 'advantages', 'agent_infos']
         if exploration:      # trpo_maml.py:41-42
             self._optimization_keys.append('adj_avg_rewards')
-        self.optimizer = ConjugateGradientOptimizer()
+        self.optimizer = ConjugateGradientOptimizer(
+            hvp_approach=ExactDeviceHvp() if hvp_approach == 'exact' else FiniteDifferenceHvp())
         self.optimizer.build_graph(_DeviceEvaluator(self), step_size)
 
     def optimize_policy(self, all_samples_data, log=True):

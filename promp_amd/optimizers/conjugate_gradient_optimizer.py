@@ -88,6 +88,37 @@ class FiniteDifferenceHvp(object):
         return lambda x: self.Hx(x) + self.reg_coeff * x
 
 
+class ExactDeviceHvp(object):
+    """Hessian-vector products of the constraint computed exactly on the device (promp_constraint_hvp: 2K+1 R-operator
+    passes, J^T H_KL J through the K inner steps) instead of two displaced constraint gradients per product.  Not in the
+    reference, which only has the finite-difference approach (SURVEY 8f row 2 asks for this one); FiniteDifferenceHvp stays
+    the default and the parity mode.  Exact where the constraint is evaluated by TRPO: at the parameters the last step's
+    samples were drawn with (there the constraint's gradient wrt the adapted parameters is zero, and with it every term
+    that differentiates the adaptation Jacobians)."""
+
+    def __init__(self):
+        self.reg_coeff = None
+        self._ev = None
+        self._fresh = False
+
+    def build_graph(self, evaluator, reg_coeff):
+        self._ev, self.reg_coeff = evaluator, reg_coeff
+
+    def constraint_gradient(self):
+        return self._ev.constraint_gradient()
+
+    def Hx(self, x):
+        assert isinstance(x, np.ndarray)
+        out = self._ev.constraint_hvp(x, refresh_chain=not self._fresh)   # the adapted parameters are computed once per theta
+        self._fresh = True
+        return out
+
+    def build_eval(self):
+        """x -> (H + reg I) x at the evaluator's current parameters"""
+        self._fresh = False
+        return lambda x: self.Hx(x) + self.reg_coeff * x
+
+
 class ConjugateGradientOptimizer(object):
     """
     Args: cg_iters=10, reg_coeff=0 (Tikhonov term added to H), subsample_factor=1. (kept for signature compatibility:

@@ -221,6 +221,57 @@ def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, at
     np.testing.assert_array_equal(a[7], b[7])
 
 
+def on_policy_case(seed, M, P, T, O, A, hidden, K, alpha, inner_kind, ragged=True):
+    """make_promp_case with the LAST step's old distribution replaced by the adapted policy's own outputs (what sampling
+    with the adapted parameters records, meta_trainer.py:97-116): the operating point of TRPO's constraint"""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=ragged)
+    spec = op.PolicySpec(O, A, hidden)
+    thetas = np.tile(theta.astype(np.float64), (M, 1))
+    for k in range(K):
+        thetas = pm.adapt(spec, thetas, all_slabs[k], alpha.astype(np.float64), kind=inner_kind)
+    for i, (slab, plist) in enumerate(zip(all_slabs[K], all_paths[K].values())):
+        mean, log_std = op.forward(spec, thetas[i], slab['observations'].astype(np.float64), False)[:2]
+        slab['agent_infos'] = dict(mean=mean.astype(np.float32), log_std=np.tile(log_std.astype(np.float32), (len(mean), 1)))
+        r = 0
+        for p in plist:
+            n = len(p['rewards'])
+            p['agent_infos'] = dict(mean=slab['agent_infos']['mean'][r:r + n], log_std=slab['agent_infos']['log_std'][r:r + n])
+            r += n
+    return theta, all_slabs, all_paths
+
+
+def check_exact_constraint_hvp(lib, seed, M, P, T, O, A, hidden, K=1, inner='loglik', tol=1e-4):
+    """promp_constraint_hvp (2K+1 R-operator passes, Gauss-Newton form through the adaptation) against the float64 central
+    difference of the oracle's constraint gradient, at the operating point of TRPO (old distribution = adapted policy)"""
+    from oracle import trpo as otr
+    spec = op.PolicySpec(O, A, hidden)
+    alpha = np.full(spec.n_params, 0.05, np.float32)
+    kind = dict(loglik=_lib.INNER_LOGLIK, ratio=_lib.INNER_RATIO)[inner]
+    okind = dict(loglik=pm.INNER_LOGLIK, ratio=pm.INNER_RATIO)[inner]
+    theta, all_slabs, all_paths = on_policy_case(seed, M, P, T, O, A, hidden, K, alpha, okind)
+    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(alpha)
+    rng = np.random.RandomState(seed + 1)
+    g, st = ctx.meta_grad(0.0, np.zeros(K, np.float32), inner_kind=kind, outer_kind=_lib.OUTER_KL)
+    assert abs(st['outer_kl']) < 1e-6 and np.abs(g).max() < 1e-4      # on-policy: KL and its gradient vanish
+    for trial in range(2):
+        x = rng.randn(spec.n_params).astype(np.float32)
+        if trial == 1:
+            x[-A:] = 0.0                                              # a direction that leaves log_std alone
+        hv = ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=(trial == 0))
+        ref = otr.constraint_hvp_fd64(spec, theta, all_slabs, alpha.astype(np.float64), x, inner_kind=okind)
+        assert rel_max(hv, ref) < tol, rel_max(hv, ref)
+        assert float(np.dot(x, hv)) > 0                               # positive semi-definite (J^T H_KL J), strictly here
+    # symmetry: <y, H x> == <x, H y>
+    x, y = rng.randn(spec.n_params).astype(np.float32), rng.randn(spec.n_params).astype(np.float32)
+    a = float(np.dot(y, ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=False)))
+    b = float(np.dot(x, ctx.constraint_hvp(y, inner_kind=kind, refresh_chain=False)))
+    assert abs(a - b) <= 1e-3 * max(abs(a), abs(b))
+    ctx.close()
+
+
 def check_schedule_invariance(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, epochs=2):
     """launch scheduling must not change a single bit: sample processing of steps >= 1 on the second stream vs all on one
     stream, and the Hessian-vector pass's in-launch task reduction vs the separate reduction kernel.  Several iterations of
@@ -300,7 +351,7 @@ def check_learn_std_false(lib, seed, M, P, T, O, A, hidden):
 
 
 def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg_iters=10, max_backtracks=15,
-               exploration=False, oracle_step=True):
+               exploration=False, oracle_step=True, hvp_approach='finite_difference', on_policy=False):
     """TRPOMAML.optimize_policy (row a15) through the plugin classes.
 
     The reference's Hessian-vector product is a finite difference with eps = 1e-5 on float32 parameters
@@ -317,14 +368,17 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
     logger.configure(quiet=True)
     _lib.set_library_for_testing(lib)
     try:
-        theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
         spec = op.PolicySpec(O, A, hidden)
         kind = 'loglik' if inner_type == 'log_likelihood' else 'ratio'
         alpha = np.full(spec.n_params, 0.1)
+        if on_policy:        # the last step's old distribution IS the adapted policy: TRPO's operating point
+            theta, all_slabs, all_paths = on_policy_case(seed, M, P, T, O, A, hidden, 1, alpha.astype(np.float32), kind, ragged=False)
+        else:
+            theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
         policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
         policy.set_params(spec.to_ordered_dict(theta))
         algo = TRPOMAML(policy=policy, step_size=0.01, inner_type=inner_type, inner_lr=0.1, meta_batch_size=M,
-                        num_inner_grad_steps=1, exploration=exploration)
+                        num_inner_grad_steps=1, exploration=exploration, hvp_approach=hvp_approach)
         algo.optimizer._cg_iters = cg_iters
         algo.optimizer._max_backtracks = max_backtracks      # (the emulator run shortens the line search)
         samples = [[dict(observations=s['observations'], actions=s['actions'], advantages=s['advantages'],
@@ -348,9 +402,12 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
             xv, xg = otrpo.exploration_term(spec, t64, all_slabs[0], coeffs)
             r_loss = dict(r_loss, loss=r_loss['loss'] + xv, grad=r_loss['grad'] + xg)
         np.testing.assert_allclose(ev.loss(), r_loss['loss'], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(ev.constraint_val(), r_loss['outer_kl'], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(ev.constraint_val(), r_loss['outer_kl'], rtol=1e-4, atol=1e-6 if on_policy else 1e-7)
         assert rel_max(ev.gradient(), r_loss['grad']) < 1e-4
-        assert rel_max(ev.constraint_gradient(), r_kl['grad']) < 1e-4
+        if on_policy:        # KL(old || adapted) == 0 and stationary here: only rounding noise left on either side
+            assert np.abs(ev.constraint_gradient()).max() < 1e-4 and np.abs(r_kl['grad']).max() < 1e-4
+        else:
+            assert rel_max(ev.constraint_gradient(), r_kl['grad']) < 1e-4
         # (2) the step
         algo.optimize_policy(samples, log=False)
         st, last = algo.last_stats, algo.optimizer.last
@@ -360,7 +417,11 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
                                        explore_coeffs=coeffs)
             d, dr = last['descent_direction'].astype(np.float64), ref['descent_direction']
             cos = d.dot(dr) / (np.linalg.norm(d) * np.linalg.norm(dr))
-            if np.isfinite(last['initial_step_size']):      # a negative-curvature FD estimate rejects the step (as the reference)
+            if hvp_approach == 'exact':     # no finite-difference noise: the float32 run tracks the float64 one closely
+                assert cos > 0.995, cos
+                np.testing.assert_allclose(last['initial_step_size'], ref['initial_step_size'], rtol=2e-2)
+                assert not last['rejected']
+            elif np.isfinite(last['initial_step_size']):      # a negative-curvature FD estimate rejects the step (as the reference)
                 assert cos > 0.5, cos
         else:                # the direction is a descent direction of the loss (g^T d > 0 for the step theta - s d)
             g = r_loss['grad']

@@ -248,6 +248,19 @@ def test_split_reduce_allreduce_adam_equals_fused_launch(lib):
     pc.check_split_path_equals_fused(lib, 72, M=3, P=3, T=50, O=111, A=8, hidden=(128, 128), epochs=2, attach_comm=False)
 
 
+def test_trpo_maml_step_with_exact_constraint_hvp(lib):
+    """the plugin with hvp_approach='exact': with the finite-difference noise gone, the float32 step tracks the float64 oracle"""
+    pc.check_trpo(lib, 66, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood', hvp_approach='exact', on_policy=True)
+    pc.check_trpo(lib, 67, M=3, P=4, T=60, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio', hvp_approach='exact', on_policy=True)
+
+
+def test_exact_constraint_hvp_through_the_adaptation(lib):
+    """the exact Hessian-vector product of TRPO-MAML's constraint instead of the finite-difference one"""
+    pc.check_exact_constraint_hvp(lib, 91, M=4, P=4, T=80, O=20, A=6, hidden=(64, 64), K=1)
+    pc.check_exact_constraint_hvp(lib, 92, M=3, P=3, T=50, O=11, A=3, hidden=(64, 32), K=2, inner='ratio')
+    pc.check_exact_constraint_hvp(lib, 93, M=20, P=2, T=60, O=20, A=6, hidden=(64, 64), K=1)     # fused in-launch task reduction
+
+
 def test_launch_scheduling_does_not_change_results(lib):
     """second-stream sample processing and the fused / separate task reduction of the Hessian-vector pass: bitwise the same"""
     pc.check_schedule_invariance(lib, 81, M=6, P=5, T=120, O=20, A=6, hidden=(64, 64), K=1, iters=4)
