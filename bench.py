@@ -54,6 +54,8 @@ def main():
                          '(M/N tasks, no collective) to study the per-rank step time of strong scaling')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--staged-only', action='store_true',
+                    help='developer switch: feed the timed loop by staged uploads (tools/gpu_round.sh traces the copy / compute overlap with it)')
     args = ap.parse_args()
 
     rank, world, local_rank = comm.env_world()
@@ -133,7 +135,34 @@ def main():
                 return dict(loss_before=l0, loss_after=cg.loss(), kl_before=kl0, kl_after=cg.constraint_val(),
                             n_backtracks=cg.last['n_backtracks'], rejected=cg.last['rejected'])
             return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
+        def staged_iteration_factory():
+            """the same iteration fed by staged uploads: the batch of iteration n+1 (here: the same synthetic batch again)
+            leaves pinned host memory on the copy stream while iteration n is being optimised"""
+            lib = ctx.lib
+            pin = []
+            for f, ls in ((f0, np.tile(theta0[-A:], (M, 1))), (f1, th1[:, -A:].copy())):
+                d = {}
+                for key, src in (('obs', f['obs']), ('rew', f['rew']), ('act', f['act']), ('old_mean', f['old_mean']), ('ls', ls)):
+                    src = np.ascontiguousarray(src, dtype=np.float32)
+                    d[key] = _lib.pinned_empty(lib, src.shape)
+                    d[key][...] = src
+                d['tpo'], d['pro'] = f['task_path_offsets'], f['path_row_offsets']
+                pin.append(d)
+            stage = lambda k: ctx.stage_step(k, pin[k]['tpo'], pin[k]['pro'], pin[k]['obs'], pin[k]['rew'], pin[k]['act'],
+                                             pin[k]['old_mean'], pin[k]['ls'])
+            stage(0), stage(1)
+
+            def it():
+                ctx.commit_step(0), ctx.commit_step(1)
+                ctx.switch_to_pre_update()
+                ctx.process_samples(0, **opts)
+                ctx.inner_adapt(0, _lib.INNER_LOGLIK if trpo else _lib.INNER_RATIO)
+                ctx.process_samples(1, **opts)
+                stage(0), stage(1)                               # next batch: copy stream, under the epochs below
+                return ctx.optimize(E, 1e-3, 0.3, eta)
+            return it
         iteration.upload = upload
+        iteration.staged = staged_iteration_factory
         iteration.mode = mode if trpo else None
         iteration.reset = lambda: ctx.set_theta(theta0)
         return ctx, iteration, M
@@ -159,7 +188,12 @@ def main():
     ctx, iteration, M = setup(M_global)
     info = ctx.device_info()
     alpha = np.full(ctx.n_params, 0.1, np.float32)
-    elapsed, res = run_timed(ctx, iteration, args.warmup, args.steps)
+    if args.staged_only:
+        staged_it = iteration.staged()
+        elapsed, res = run_timed(ctx, staged_it, args.warmup, args.steps)
+        ctx.stage_wait()
+    else:
+        elapsed, res = run_timed(ctx, iteration, args.warmup, args.steps)
     if not np.isfinite(res['loss_after']):
         raise SystemExit('bench: non-finite loss')
     env_steps = M_global * N * (K + 1) * args.steps
@@ -195,7 +229,7 @@ def main():
                                     'displaced constraint gradients (6 passes)'}
 
     # ---- host -> device cost of the two slabs (never part of `value`: the timed region starts with the batch in HBM) ----
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.staged_only:
         iteration.upload()
         t0 = time.perf_counter()
         for _ in range(3):
@@ -204,8 +238,23 @@ def main():
         step_ms = 1e3 * elapsed / args.steps
         out['h2d'] = {'upload_ms_per_step': h2d_ms, 'bytes_per_step': int(4 * M * N * 2 * (O + 2 * A + 1)),
                       'value_including_upload': M_global * N * (K + 1) / ((step_ms + h2d_ms) * 1e-3),
-                      'note': 'promp_upload_step of both slabs from pageable host memory, incl. the host-side work tables'}
+                      'note': 'promp_upload_step of both slabs from pageable host memory, incl. the host-side work tables, '
+                              'serial with the step'}
         iteration()       # (re-create the processed state the uploads reset)
+        if not trpo:
+            # staged uploads from pinned memory, double-buffered slabs: the transfer of the next batch under this one's epochs
+            it2 = iteration.staged()
+            iteration.reset()
+            n_st = max(3, min(args.steps, 20))
+            el_st, _ = run_timed(ctx, it2, 2, n_st)
+            ctx.stage_wait()
+            out['h2d']['staged'] = {'ms_per_step': 1e3 * el_st / n_st, 'steps': n_st,
+                                    'value_including_upload': M_global * N * (K + 1) * n_st / el_st,
+                                    'note': 'promp_stage_step (pinned host arrays, copy stream) + promp_commit_step: every step '
+                                            'uploads both slabs of the next batch while the current one is optimised'}
+            iteration.reset()
+            iteration.upload()
+            iteration()
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the stream it runs on ----
     if not args.no_roofline:

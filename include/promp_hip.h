@@ -92,6 +92,24 @@ int promp_upload_step(promp_ctx* ctx, int step, int n_paths,
                       const float* obs, const float* act, const float* rew,
                       const float* old_mean, const float* old_log_std, int log_std_per_row);
 
+/* Staged upload: the same arguments, but the copies go to the step's SECOND slab set on a copy stream and return at once;
+ * promp_commit_step then makes that set the step's current one (a pointer swap on the host; the first launch that reads
+ * it waits for the copies).  A trainer whose next batch exists while the current one is still being optimised (replayed
+ * or asynchronously collected samples; bench.py's upload-inclusive number) hides the transfer under the compute:
+ *     commit(0), commit(1), process_samples / adapt ..., stage(next 0), stage(next 1), optimize
+ * Host arrays from promp_host_alloc (pinned) are read by DMA after the call returns: leave them untouched until
+ * promp_stage_wait or the step's next commit + use; pageable arrays work too (the call then returns when they are read).
+ * The reference has no counterpart (its feed_dict copies are synchronous, meta_algos/base.py:245-301). */
+int promp_stage_step(promp_ctx* ctx, int step, int n_paths,
+                     const int32_t* task_path_offsets, const int32_t* path_row_offsets,
+                     const float* obs, const float* act, const float* rew,
+                     const float* old_mean, const float* old_log_std, int log_std_per_row);
+int promp_commit_step(promp_ctx* ctx, int step);
+int promp_stage_wait(promp_ctx* ctx);
+/* page-locked host memory for the arrays above (hipHostMalloc); NULL on failure */
+void* promp_host_alloc(size_t bytes);
+void promp_host_free(void* p);
+
 /* ---- rows a1-a7: MetaSampleProcessor.process_samples (samplers/meta_sample_processor.py:8-49,
  * samplers/base.py:99-173, utils/utils.py:59-81, baselines/linear_baseline.py:17-106).
  * Computes on the device, per task: returns -> baseline fit -> GAE -> normalise; results stay

@@ -72,6 +72,11 @@ SIGNATURES = {
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
+    'promp_stage_step': (C.c_int, [_P, C.c_int, C.c_int, _I, _I, _F, _F, _F, _F, _F, C.c_int]),
+    'promp_commit_step': (C.c_int, [_P, C.c_int]),
+    'promp_stage_wait': (C.c_int, [_P]),
+    'promp_host_alloc': (C.c_void_p, [C.c_size_t]),
+    'promp_host_free': (None, [C.c_void_p]),
     'promp_constraint_hvp': (C.c_int, [_P, C.c_int, _F, C.c_int, _F]),
     'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
     'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
@@ -146,6 +151,20 @@ def _ptr(a, ctype):
     return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
 
 
+def pinned_empty(lib, shape, dtype=np.float32):
+    """an uninitialised ndarray in page-locked host memory (promp_host_alloc): DMA source of Context.stage_step"""
+    import weakref
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    count = int(np.prod(shape))
+    nbytes = max(count * np.dtype(dtype).itemsize, 1)
+    ptr = lib.cdll.promp_host_alloc(C.c_size_t(nbytes))
+    if not ptr:
+        raise PrompError(lib.cdll.promp_last_error().decode())
+    raw = (C.c_char * nbytes).from_address(ptr)
+    weakref.finalize(raw, lib.cdll.promp_host_free, C.c_void_p(ptr))     # every view keeps `raw` alive through .base
+    return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape)
+
+
 class Context:
     """One promp_ctx (one GPU).  Thin, NumPy-in / NumPy-out."""
 
@@ -162,6 +181,7 @@ class Context:
         self.n_params = self.lib.cdll.promp_param_count(C.byref(self.dims))
         self.n_tasks, self.K = int(n_tasks), int(num_inner_steps)
         self.step_rows = {}
+        self._staged, self._live_refs = {}, {}
         self.step_ls_rows = {}
         self.step_paths = {}
 
@@ -202,6 +222,33 @@ class Context:
         self.step_rows[step] = int(pro[-1])
         self.step_paths[step] = int(n_paths)
         self.step_ls_rows[step] = int(pro[-1]) if per_row else self.n_tasks
+
+    def stage_step(self, step, task_path_offsets, path_row_offsets, obs, rew, act, old_mean, old_log_std):
+        """promp_stage_step: upload_step's arguments, copied on the copy stream into the step's second slab set; call
+        commit_step(step) to make it current.  The arrays are read after the call returns when they are pinned
+        (pinned_empty): they are kept referenced here, and must not be written until stage_wait() or the commit's first use."""
+        tpo = np.ascontiguousarray(task_path_offsets, dtype=np.int32)
+        pro = np.ascontiguousarray(path_row_offsets, dtype=np.int32)
+        obs, rew, act, old_mean, old_log_std = _f32(obs), _f32(rew), _f32(act), _f32(old_mean), _f32(old_log_std)
+        old_log_std = old_log_std.reshape(-1, act.shape[1])
+        if old_log_std.shape[0] not in (obs.shape[0], self.n_tasks):
+            raise PrompError('old_log_std must be [rows, A] or [n_tasks, A]')
+        per_row = 1 if old_log_std.shape[0] == obs.shape[0] and obs.shape[0] != self.n_tasks else 0
+        n_paths = len(pro) - 1
+        self._call('promp_stage_step', int(step), int(n_paths), _ptr(tpo, C.c_int32), _ptr(pro, C.c_int32),
+                   _ptr(obs, C.c_float), _ptr(act, C.c_float), _ptr(rew, C.c_float), _ptr(old_mean, C.c_float),
+                   _ptr(old_log_std, C.c_float), per_row)
+        self._staged[step] = dict(rows=int(pro[-1]), paths=int(n_paths), ls_rows=int(pro[-1]) if per_row else self.n_tasks,
+                                  refs=(obs, rew, act, old_mean, old_log_std))
+
+    def commit_step(self, step):
+        st = self._staged.pop(step)
+        self._call('promp_commit_step', int(step))
+        self.step_rows[step], self.step_paths[step], self.step_ls_rows[step] = st['rows'], st['paths'], st['ls_rows']
+        self._live_refs[step] = st['refs']       # until the next commit: the copies may still be in flight
+
+    def stage_wait(self):
+        self._call('promp_stage_wait')
 
     def process_samples(self, step, discount=0.99, gae_lambda=1.0, normalize_adv=False, positive_adv=False,
                         baseline_kind=BASELINE_LINEAR_FEATURE, reg_coeff=1e-5):

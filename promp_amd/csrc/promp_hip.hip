@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -73,6 +74,10 @@ struct StepData {
     hipEvent_t ev_use = nullptr;       // main stream: the last enqueued work that reads or writes this step's slabs
     hipEvent_t ev_done = nullptr;      // side stream: the step's processed outputs are complete
     bool use_set = false, side_pending = false, dirty = false;
+    // staged uploads (promp_stage_step / promp_commit_step): the slab set is written by the copy stream
+    hipEvent_t ev_ready = nullptr;     // copy stream: every array of this slab set has arrived
+    bool ready_set = false, wait_ready_main = false, wait_ready_side = false, staged = false;
+    std::shared_ptr<void> host_tables; // host-side sources of the asynchronous table copies, alive until the next staging
 };
 
 // waves per workgroup of k_chain_hvp (one per SIMD: 512 registers per lane)
@@ -97,6 +102,8 @@ struct promp_ctx {
     int NP = 0, Dmax = 0, coeff_stride = 0, max_work = 0, partial_stride = 0, gram_stride = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // sample processing of steps >= 1 runs here, under the main stream's step-0 work
+    hipStream_t copy = nullptr;          // promp_stage_step: host -> device copies of the NEXT batch, under the current one's compute
+    std::vector<StepData> back;          // the slab sets being staged (swapped with `steps` entries by promp_commit_step)
     bool overlap = true;
     double *gram_partials_side = nullptr, *fit_scratch_side = nullptr;
     std::vector<StepData> steps;
@@ -150,6 +157,10 @@ int dev_alloc(T** p, size_t n) {
 // process_samples(0).  A step still dirty when its processing goes to the side stream is marked on the spot, which
 // orders it behind everything enqueued so far: always correct, merely no overlap.
 int join_side(promp_ctx* c, StepData& S) {
+    if (S.wait_ready_main) {           // slabs staged by the copy stream
+        HIPCHECK(hipStreamWaitEvent(c->stream, S.ev_ready, 0));
+        S.wait_ready_main = false;
+    }
     if (!S.side_pending) return 0;
     HIPCHECK(hipStreamWaitEvent(c->stream, S.ev_done, 0));
     S.side_pending = false;
@@ -163,8 +174,10 @@ int mark_use(promp_ctx* c, StepData& S) {
     return 0;
 }
 int settle_others(promp_ctx* c, const StepData* touched) {
-    if (!c->overlap) return 0;
+    if (!c->overlap && c->back.empty()) return 0;
     for (auto& S : c->steps)
+        if (&S != touched && mark_use(c, S)) return -2;
+    for (auto& S : c->back)
         if (&S != touched && mark_use(c, S)) return -2;
     return 0;
 }
@@ -409,6 +422,29 @@ void free_step(StepData& S) {
         if (p) (void)hipFree(p);
 }
 
+int alloc_step(promp_ctx* c, StepData& S) {
+    const promp_dims* dims = &c->d;
+    const int M = dims->n_tasks;
+    const size_t R = dims->max_rows, P = dims->max_paths, A = dims->act_dim, O = dims->obs_dim;
+    int rc = 0;
+    rc |= dev_alloc(&S.obs, R * O); rc |= dev_alloc(&S.act, R * A); rc |= dev_alloc(&S.rew, R);
+    rc |= dev_alloc(&S.old_mean, R * A); rc |= dev_alloc(&S.old_ls, R * A);
+    rc |= dev_alloc(&S.ret32, R); rc |= dev_alloc(&S.adv32, R); rc |= dev_alloc(&S.ret64, R); rc |= dev_alloc(&S.adv64, R);
+    rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
+    rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
+    rc |= dev_alloc(&S.task_wg_offsets[0], (size_t)M + 1); rc |= dev_alloc(&S.task_wg_offsets[1], (size_t)M + 1);
+    rc |= dev_alloc(&S.task_wg_offsets[2], (size_t)M + 1); rc |= dev_alloc(&S.pwork, (size_t)c->max_work);
+    rc |= dev_alloc(&S.chain_segs, (size_t)c->max_work); rc |= dev_alloc(&S.chain_wg_offsets, (size_t)c->max_work + 1);
+    rc |= dev_alloc(&S.chain_slot_offsets, (size_t)M + 1);
+    rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
+    rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
+    rc |= dev_alloc(&S.work[0], (size_t)c->max_work); rc |= dev_alloc(&S.work[1], (size_t)c->max_work);
+    if (hipEventCreateWithFlags(&S.ev_use, hipEventDisableTiming) != hipSuccess) rc |= 1;
+    if (hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) != hipSuccess) rc |= 1;
+    if (hipEventCreateWithFlags(&S.ev_ready, hipEventDisableTiming) != hipSuccess) rc |= 1;
+    return rc ? -2 : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -529,24 +565,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
     c->steps.resize(K + 1);
-    for (int s = 0; s <= K && !rc; ++s) {
-        StepData& S = c->steps[s];
-        const size_t R = dims->max_rows, P = dims->max_paths, A = dims->act_dim, O = dims->obs_dim;
-        rc |= dev_alloc(&S.obs, R * O); rc |= dev_alloc(&S.act, R * A); rc |= dev_alloc(&S.rew, R);
-        rc |= dev_alloc(&S.old_mean, R * A); rc |= dev_alloc(&S.old_ls, R * A);
-        rc |= dev_alloc(&S.ret32, R); rc |= dev_alloc(&S.adv32, R); rc |= dev_alloc(&S.ret64, R); rc |= dev_alloc(&S.adv64, R);
-        rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
-        rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
-        rc |= dev_alloc(&S.task_wg_offsets[0], (size_t)M + 1); rc |= dev_alloc(&S.task_wg_offsets[1], (size_t)M + 1);
-        rc |= dev_alloc(&S.task_wg_offsets[2], (size_t)M + 1); rc |= dev_alloc(&S.pwork, (size_t)c->max_work);
-        rc |= dev_alloc(&S.chain_segs, (size_t)c->max_work); rc |= dev_alloc(&S.chain_wg_offsets, (size_t)c->max_work + 1);
-        rc |= dev_alloc(&S.chain_slot_offsets, (size_t)M + 1);
-        rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
-        rc |= dev_alloc(&S.path_mom, 3 * P); rc |= dev_alloc(&S.coeffs, (size_t)M * c->coeff_stride);
-        rc |= dev_alloc(&S.work[0], (size_t)c->max_work); rc |= dev_alloc(&S.work[1], (size_t)c->max_work);
-        if (hipEventCreateWithFlags(&S.ev_use, hipEventDisableTiming) != hipSuccess) rc |= 1;
-        if (hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming) != hipSuccess) rc |= 1;
-    }
+    for (int s = 0; s <= K && !rc; ++s) rc |= alloc_step(c, c->steps[s]);
     if (rc) { promp_ctx_destroy(c); return -2; }
     *out = c;
     return 0;
@@ -555,16 +574,19 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
 void promp_ctx_destroy(promp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
 #ifndef PROMP_EMU
     if (c->comm) ncclCommDestroy(c->comm);
 #endif
-    for (auto& S : c->steps) {
-        free_step(S);
-        if (S.ev_use) (void)hipEventDestroy(S.ev_use);
-        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-    }
+    for (auto* set : {&c->steps, &c->back})
+        for (auto& S : *set) {
+            free_step(S);
+            if (S.ev_use) (void)hipEventDestroy(S.ev_use);
+            if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+            if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
+        }
     void* ptrs[] = {c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
                     c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
@@ -572,6 +594,7 @@ void promp_ctx_destroy(promp_ctx* c) {
         if (p) (void)hipFree(p);
     for (auto& s : c->prof_slots)
         for (auto ev : s.ev) (void)hipEventDestroy(ev);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -579,15 +602,17 @@ void promp_ctx_destroy(promp_ctx* c) {
 
 int promp_sync(promp_ctx* c) {
     if (!c) return fail(-1, "ctx is NULL");
+    if (c->copy) HIPCHECK(hipStreamSynchronize(c->copy));
     HIPCHECK(hipStreamSynchronize(c->side));
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 // Offsets, time indices and the three work tables of one sampling step (everything of promp_upload_step but the data).
-static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro) {
-    if (!c) return fail(-1, "ctx is NULL");
-    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+// `S` is the slab set to describe and `st` the stream the table copies go to: the step's current set on the main stream
+// (promp_upload_step; synchronous), or its back set on the copy stream (promp_stage_step; the host-side tables are
+// then kept alive in S.host_tables until the set is staged again).
+static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async, int n_paths, const int32_t* tpo, const int32_t* pro) {
     if (!tpo || !pro) return fail(-1, "offsets are required");
     const int M = c->d.n_tasks;
     if (n_paths < 1 || n_paths > c->d.max_paths) return fail(-1, "n_paths %d outside [1, max_paths=%d]", n_paths, c->d.max_paths);
@@ -793,44 +818,48 @@ static int set_step_layout(promp_ctx* c, int step, int n_paths, const int32_t* t
         if ((int)pwork.size() > c->max_work || nslots + 1 > c->max_work)
             return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
     }
-    StepData& S = c->steps[step];
-    StepScope scope_(c, S);
-    if (scope_.rc) return -2;
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false;
-    hipStream_t st = c->stream;
-    HIPCHECK(hipMemcpyAsync(S.path_row_offsets, pro, sizeof(int) * (n_paths + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.task_path_offsets, tpo, sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.path_task, path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.row_t, row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.task_row_offsets, tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    S.n_chain_wg = (int)T.wg_off.size() - 1;
-    S.n_pwork = (int)pwork.size();
-    HIPCHECK(hipMemcpyAsync(S.chain_segs, T.segs.data(), sizeof(ChainSeg) * T.segs.size(), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.chain_wg_offsets, T.wg_off.data(), sizeof(int) * T.wg_off.size(), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.chain_slot_offsets, T.slot_off.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[2], slot_off.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.pwork, pwork.data(), sizeof(PassWork) * pwork.size(), hipMemcpyHostToDevice, st));
+    // every source below lives in `keep` (asynchronous mode: until the set is staged again)
+    struct Keep {
+        std::vector<int> pro, tpo, path_task, row_t, tro, wg_off, slot_chain, slot_pass, two[2];
+        std::vector<ChainSeg> segs;
+        std::vector<PassWork> pwork;
+        std::vector<WorkItem> work[2];
+    };
+    auto keep = std::make_shared<Keep>();
+    keep->pro.assign(pro, pro + n_paths + 1); keep->tpo.assign(tpo, tpo + M + 1);
+    keep->path_task = std::move(path_task); keep->row_t = std::move(row_t); keep->tro = std::move(tro);
+    keep->wg_off = std::move(T.wg_off); keep->slot_chain = std::move(T.slot_off); keep->slot_pass = std::move(slot_off);
+    keep->segs = std::move(T.segs); keep->pwork = std::move(pwork);
+    for (int t = 0; t < 2; ++t) { keep->two[t] = std::move(two[t]); keep->work[t] = std::move(work[t]); }
+    const Keep& k = *keep;
+    HIPCHECK(hipMemcpyAsync(S.path_row_offsets, k.pro.data(), sizeof(int) * (n_paths + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_path_offsets, k.tpo.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.path_task, k.path_task.data(), sizeof(int) * n_paths, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.row_t, k.row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_row_offsets, k.tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    S.n_chain_wg = (int)k.wg_off.size() - 1;
+    S.n_pwork = (int)k.pwork.size();
+    HIPCHECK(hipMemcpyAsync(S.chain_segs, k.segs.data(), sizeof(ChainSeg) * k.segs.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.chain_wg_offsets, k.wg_off.data(), sizeof(int) * k.wg_off.size(), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.chain_slot_offsets, k.slot_chain.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[2], k.slot_pass.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(S.pwork, k.pwork.data(), sizeof(PassWork) * k.pwork.size(), hipMemcpyHostToDevice, st));
     for (int t = 0; t < 2; ++t) {
-        HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[t], two[t].data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-        HIPCHECK(hipMemcpyAsync(S.work[t], work[t].data(), sizeof(WorkItem) * work[t].size(), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[t], k.two[t].data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(S.work[t], k.work[t].data(), sizeof(WorkItem) * k.work[t].size(), hipMemcpyHostToDevice, st));
     }
-    HIPCHECK(hipStreamSynchronize(st));  // host staging vectors go out of scope
+    if (async) S.host_tables = keep;
+    else HIPCHECK(hipStreamSynchronize(st));  // the sources go out of scope
     return 0;
 }
 
-int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro, const float* obs,
-                      const float* act, const float* rew, const float* old_mean, const float* old_ls, int ls_per_row) {
-    if (!c) return fail(-1, "ctx is NULL");
-    if (!obs || !rew) return fail(-1, "offsets, obs and rew are required");
-    if (set_step_layout(c, step, n_paths, tpo, pro)) return -2;
-    StepData& S = c->steps[step];
-    StepScope scope_(c, S);
-    if (scope_.rc) return -2;
+static int copy_step_data(promp_ctx* c, StepData& S, hipStream_t st, const float* obs, const float* act, const float* rew,
+                          const float* old_mean, const float* old_ls, int ls_per_row) {
     const int M = c->d.n_tasks;
     const size_t R = (size_t)S.n_rows;
     const size_t O = c->d.obs_dim, A = c->d.act_dim;
-    hipStream_t st = c->stream;
     HIPCHECK(hipMemcpyAsync(S.obs, obs, sizeof(float) * R * O, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * R, hipMemcpyHostToDevice, st));
     S.has_policy = act && old_mean && old_ls;
@@ -840,6 +869,77 @@ int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, c
         HIPCHECK(hipMemcpyAsync(S.old_mean, old_mean, sizeof(float) * R * A, hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(S.old_ls, old_ls, sizeof(float) * (ls_per_row ? (size_t)R : (size_t)M) * A, hipMemcpyHostToDevice, st));
     }
+    return 0;
+}
+
+int promp_upload_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro, const float* obs,
+                      const float* act, const float* rew, const float* old_mean, const float* old_ls, int ls_per_row) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (!obs || !rew) return fail(-1, "offsets, obs and rew are required");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
+    if (set_step_layout(c, S, c->stream, false, n_paths, tpo, pro)) return -2;
+    return copy_step_data(c, S, c->stream, obs, act, rew, old_mean, old_ls, ls_per_row);
+}
+
+// ---- staged uploads: the NEXT batch travels while the current one is computed ------------------------------------------
+void* promp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(-2, "hipHostMalloc of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void promp_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int promp_stage_step(promp_ctx* c, int step, int n_paths, const int32_t* tpo, const int32_t* pro, const float* obs,
+                     const float* act, const float* rew, const float* old_mean, const float* old_ls, int ls_per_row) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (!obs || !rew) return fail(-1, "offsets, obs and rew are required");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (!c->copy) HIPCHECK(hipStreamCreate(&c->copy));
+    if (c->back.empty()) {
+        c->back.resize(c->steps.size());
+        for (auto& B : c->back)
+            if (alloc_step(c, B)) return -2;
+    }
+    StepData& B = c->back[step];
+    // the set's previous life: host tables of its last staging, and whatever the compute streams still read from it
+    if (B.ready_set) HIPCHECK(hipEventSynchronize(B.ev_ready));
+    if (mark_use(c, B)) return -2;           // (normally settled already by the entry points that came after its last use)
+    if (B.use_set) HIPCHECK(hipStreamWaitEvent(c->copy, B.ev_use, 0));
+    if (B.side_pending) {
+        HIPCHECK(hipStreamWaitEvent(c->copy, B.ev_done, 0));
+        B.side_pending = false;
+    }
+    if (set_step_layout(c, B, c->copy, true, n_paths, tpo, pro)) return -2;
+    if (copy_step_data(c, B, c->copy, obs, act, rew, old_mean, old_ls, ls_per_row)) return -2;
+    HIPCHECK(hipEventRecord(B.ev_ready, c->copy));
+    B.ready_set = true;
+    B.wait_ready_main = B.wait_ready_side = true;
+    B.staged = true;
+    return 0;
+}
+
+int promp_commit_step(promp_ctx* c, int step) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (c->back.empty() || !c->back[step].staged) return fail(-3, "step %d has nothing staged", step);
+    // uses of the outgoing set that are still unmarked get their mark now, while "everything enqueued so far" is tight
+    if (mark_use(c, c->steps[step])) return -2;
+    std::swap(c->steps[step], c->back[step]);
+    c->steps[step].staged = false;
+    return 0;
+}
+
+int promp_stage_wait(promp_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (c->copy) HIPCHECK(hipStreamSynchronize(c->copy));
     return 0;
 }
 
@@ -876,7 +976,9 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (on_side) {
         if (mark_use(c, S)) return -2;
         if (S.use_set) HIPCHECK(hipStreamWaitEvent(c->side, S.ev_use, 0));
+        if (S.wait_ready_side) HIPCHECK(hipStreamWaitEvent(c->side, S.ev_ready, 0));
     }
+    S.wait_ready_side = false;
     PROMP_LAUNCH(k_returns, dim3(S.n_paths), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
     if (a.kind != BASE_ZERO) {
@@ -1129,10 +1231,10 @@ static int begin_fixed_rollout(promp_ctx* c, int step, int B, int T) {
     std::vector<int32_t> tpo(M + 1), pro((size_t)M * B + 1);
     for (int i = 0; i <= M; ++i) tpo[i] = i * B;
     for (int p = 0; p <= M * B; ++p) pro[p] = p * T;
-    if (set_step_layout(c, step, M * B, tpo.data(), pro.data())) return -2;
     StepData& S = c->steps[step];
     StepScope scope_(c, S);
     if (scope_.rc) return -2;
+    if (set_step_layout(c, S, c->stream, false, M * B, tpo.data(), pro.data())) return -2;
     S.has_policy = true;
     S.ls_per_row = 0;
     S.rollout_B = B; S.rollout_T = T;

@@ -234,6 +234,10 @@ inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent(); return 0;
 enum { hipEventDisableTiming = 2 };
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new EmuEvent(); return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+enum { hipHostMallocDefault = 0 };
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 2; }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {

@@ -311,6 +311,63 @@ def check_schedule_invariance(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, ep
                 np.testing.assert_array_equal(a[key], b[key])
 
 
+def check_staged_upload(lib, seed, M, P, T, O, A, hidden, iters=4, epochs=2):
+    """promp_stage_step / promp_commit_step: two different batches alternate, the next one staged from pinned host arrays
+    while the current one is optimised, nothing synchronising the host in between; every iteration's outcome must equal,
+    bit for bit, the plain sequence upload_step -> process -> adapt -> process -> optimize on the same batches"""
+    spec = op.PolicySpec(O, A, hidden)
+    cases = [helpers.make_promp_case(seed + b, M, P, T, O, A, hidden, 1, ragged=(b == 1)) for b in range(2)]
+    theta = cases[0][0]
+    flat = [[_lib.flatten_paths(paths) for paths in c[2]] for c in cases]
+    eta = np.array([5e-4], np.float32)
+    kwargs = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True, positive_adv=False)
+    cap = [c[2] for c in cases]
+    big = max(range(2), key=lambda b: sum(len(f['obs']) for f in flat[b]))
+
+    def run(staged):
+        ctx = make_ctx(lib, M, O, A, hidden, 1, cap[big])
+        ctx.set_theta(theta)
+        ctx.set_step_sizes(np.full(spec.n_params, 0.1, np.float32))
+        args = lambda f: (f['task_path_offsets'], f['path_row_offsets'], f['obs'], f['rew'], f['act'], f['old_mean'], f['old_log_std'])
+        if staged:      # pinned copies of both batches (the DMA sources)
+            pin = [[{k: None for k in f} for f in fb] for fb in flat]
+            for b in range(2):
+                for k in range(2):
+                    for key in ('obs', 'rew', 'act', 'old_mean', 'old_log_std'):
+                        src = np.ascontiguousarray(flat[b][k][key], dtype=np.float32)
+                        dst = _lib.pinned_empty(lib, src.shape)
+                        dst[...] = src
+                        pin[b][k][key] = dst
+                    pin[b][k]['task_path_offsets'] = flat[b][k]['task_path_offsets']
+                    pin[b][k]['path_row_offsets'] = flat[b][k]['path_row_offsets']
+            for k in range(2):
+                ctx.stage_step(k, *args(pin[0][k]))
+        out = []
+        for it in range(iters):
+            b = it % 2
+            if staged:
+                ctx.commit_step(0), ctx.commit_step(1)
+            else:
+                for k in range(2):
+                    ctx.upload_step(k, *args(flat[b][k]))
+            ctx.switch_to_pre_update()
+            ctx.process_samples(0, baseline_kind=KIND['linear_feature'], **kwargs)
+            ctx.inner_adapt(0)
+            ctx.process_samples(1, baseline_kind=KIND['linear_feature'], **kwargs)
+            if staged and it + 1 < iters:
+                for k in range(2):
+                    ctx.stage_step(k, *args(pin[1 - b][k]))
+            res = ctx.optimize(epochs, 1e-3, 0.3, eta)
+            out.append((ctx.get_theta(), res, ctx.download_processed(1)['advantages']))
+        ctx.close()
+        return out
+
+    for (ta, ra, aa), (tb, rb, ab) in zip(run(False), run(True)):
+        np.testing.assert_array_equal(ta, tb)
+        assert ra == pytest_approx_dict(rb)
+        np.testing.assert_array_equal(aa, ab)
+
+
 def pytest_approx_dict(d):
     class _Eq(dict):
         def __eq__(self, other):

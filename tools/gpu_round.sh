@@ -30,6 +30,12 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('shard-of $n: %d tasks on this GPU, %.4f ms/step' % (d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/shard_timings.txt
 done
 cat $ROOT/$R/shard_timings.txt
+# staged uploads: kernel + memory-copy trace of a run fed only by promp_stage_step, and the copy / compute overlap in it
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $ROOT/$R/trace_staged -o staged -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --staged-only > $ROOT/$R/bench_staged.json 2> $ROOT/$R/trace_staged.err; echo "staged trace rc=$?"
+cd $ROOT
+python tools/overlap.py $R/trace_staged > $R/h2d_overlap.txt 2>&1; cat $R/h2d_overlap.txt
+rm -f $R/trace_staged/*kernel_trace.csv $R/trace_staged/*memory_copy_trace.csv
 # per-launch timeline of one step (both streams) from the kernel trace
 python $ROOT/tools/timeline.py $ROOT/$R/trace > $ROOT/$R/timeline.txt 2>&1
 cd $ROOT; rm -f $R/trace/*kernel_trace.csv $R/pmc*/*kernel_trace.csv   # keep the summaries small
