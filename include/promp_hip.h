@@ -191,6 +191,10 @@ int promp_policy_forward(promp_ctx* ctx, const float* obs, int batch, float* mea
 int promp_begin_rollout(promp_ctx* ctx, int step, int envs_per_task, int path_length);
 int promp_policy_step(promp_ctx* ctx, int step, int t, const float* obs, uint64_t seed, int clip_infos, float* actions_out);
 int promp_set_rewards(promp_ctx* ctx, int step, const float* rewards);
+/* The same in the environment's float64: the reference scans float64 rewards (utils/utils.py:74-81 on the arrays the env
+ * returned) and LinearBaseline.fit can be given arbitrary float64 targets; returns, GAE deltas and path statistics then
+ * read these instead of the float32 copy (which is refreshed too, for promp_download_step). */
+int promp_set_rewards_f64(promp_ctx* ctx, int step, const double* rewards);
 
 /* (b) the 2-D point-mass meta-environment of BASELINE config 1, run_scripts/pro-mp_run_point_mass.py:
  *     normalize(MetaPointEnvCorner()) -- whole rollouts in one launch, one thread per environment:

@@ -72,6 +72,7 @@ SIGNATURES = {
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
+    'promp_set_rewards_f64': (C.c_int, [_P, C.c_int, _D]),
     'promp_stage_step': (C.c_int, [_P, C.c_int, C.c_int, _I, _I, _F, _F, _F, _F, _F, C.c_int]),
     'promp_commit_step': (C.c_int, [_P, C.c_int]),
     'promp_stage_wait': (C.c_int, [_P]),
@@ -204,6 +205,7 @@ class Context:
                     old_log_std=None):
         tpo = np.ascontiguousarray(task_path_offsets, dtype=np.int32)
         pro = np.ascontiguousarray(path_row_offsets, dtype=np.int32)
+        rew64 = np.ascontiguousarray(rew, dtype=np.float64) if np.asarray(rew).dtype == np.float64 else None
         obs, rew = _f32(obs), _f32(rew)
         per_row = 0
         if act is not None:
@@ -222,6 +224,8 @@ class Context:
         self.step_rows[step] = int(pro[-1])
         self.step_paths[step] = int(n_paths)
         self.step_ls_rows[step] = int(pro[-1]) if per_row else self.n_tasks
+        if rew64 is not None:        # float64 rewards stay float64 on the device (the reference scans the env's float64)
+            self._call('promp_set_rewards_f64', int(step), _ptr(rew64, C.c_double))
 
     def stage_step(self, step, task_path_offsets, path_row_offsets, obs, rew, act, old_mean, old_log_std):
         """promp_stage_step: upload_step's arguments, copied on the copy stream into the step's second slab set; call
@@ -513,7 +517,8 @@ def flatten_paths(paths_meta_batch):
             n = len(p['rewards'])
             pro.append(pro[-1] + n)
             obs.append(np.asarray(p['observations'], dtype=np.float32).reshape(n, -1))
-            rew.append(np.asarray(p['rewards'], dtype=np.float32).reshape(n))
+            r = np.asarray(p['rewards'])
+            rew.append(r.reshape(n) if r.dtype == np.float64 else r.astype(np.float32).reshape(n))
             if 'actions' in p and 'agent_infos' in p and p['agent_infos'] and 'mean' in p['agent_infos']:
                 act.append(np.asarray(p['actions'], dtype=np.float32).reshape(n, -1))
                 mean.append(np.asarray(p['agent_infos']['mean'], dtype=np.float32).reshape(n, -1))

@@ -58,6 +58,8 @@ struct StepData {
     int ls_per_row = 0;
     int feat_dim = 0;
     float *obs = nullptr, *act = nullptr, *rew = nullptr, *old_mean = nullptr, *old_ls = nullptr;
+    double* rew64 = nullptr;           // promp_set_rewards_f64 (allocated on first use); valid while has_rew64
+    bool has_rew64 = false;
     float *ret32 = nullptr, *adv32 = nullptr;
     double *ret64 = nullptr, *adv64 = nullptr;
     int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
@@ -414,7 +416,7 @@ int upload_eta(promp_ctx* c, const float* eta) {
 }
 
 void free_step(StepData& S) {
-    void* ptrs[] = {S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
+    void* ptrs[] = {S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
                     S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.chain_segs, S.chain_wg_offsets,
                     S.chain_slot_offsets, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
@@ -819,7 +821,7 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
             return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
     }
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
-    S.processed = false; S.has_adv = false;
+    S.processed = false; S.has_adv = false; S.has_rew64 = false;
     // every source below lives in `keep` (asynchronous mode: until the set is staged again)
     struct Keep {
         std::vector<int> pro, tpo, path_task, row_t, tro, wg_off, slot_chain, slot_pass, two[2];
@@ -954,7 +956,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (!(o->gae_lambda >= 0 && o->gae_lambda <= 1)) return fail(-1, "gae_lambda must be in [0,1]");       // samplers/base.py:58
     if (o->baseline_kind < 0 || o->baseline_kind > 2) return fail(-1, "unknown baseline kind %d", o->baseline_kind);
     SampleArgs a;
-    a.obs = S.obs; a.rew = S.rew; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
+    a.obs = S.obs; a.rew = S.rew; a.rew64 = S.has_rew64 ? S.rew64 : nullptr; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
     a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets;
     a.work = S.work[0];                         // k_gram / k_fit: one workgroup per CU
     a.task_wg_offsets = S.task_wg_offsets[0];
@@ -1088,7 +1090,7 @@ int promp_predict_baseline(promp_ctx* c, int step, int kind, double* out) {
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     SampleArgs a;
     memset(&a, 0, sizeof a);
-    a.obs = S.obs; a.rew = S.rew; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
+    a.obs = S.obs; a.rew = S.rew; a.rew64 = S.has_rew64 ? S.rew64 : nullptr; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
     a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets;
     a.O = c->d.obs_dim; a.kind = kind; a.D = feature_dim(&c->d, kind);
     a.gamma = 1.0; a.lam = 1.0;
@@ -1328,6 +1330,25 @@ int promp_set_rewards(promp_ctx* c, int step, const float* rew) {
     HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     S.processed = false;
+    S.has_rew64 = false;
+    return 0;
+}
+
+int promp_set_rewards_f64(promp_ctx* c, int step, const double* rew) {
+    if (!c || !rew) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    if (!S.rew64 && dev_alloc(&S.rew64, (size_t)c->d.max_rows)) return -2;
+    std::vector<float> r32((size_t)S.n_rows);
+    for (int i = 0; i < S.n_rows; ++i) r32[i] = (float)rew[i];
+    HIPCHECK(hipMemcpyAsync(S.rew64, rew, sizeof(double) * S.n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(S.rew, r32.data(), sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    S.processed = false;
+    S.has_rew64 = true;
     return 0;
 }
 

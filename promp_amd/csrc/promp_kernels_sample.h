@@ -21,6 +21,7 @@ enum { BASE_ZERO = 0, BASE_LINFEAT = 1, BASE_LINTIME = 2 };
 struct SampleArgs {
     const float* obs;              // [rows][O]
     const float* rew;              // [rows]
+    const double* rew64;           // optional [rows]: the rewards in the environment's float64 (else NULL: rew is used)
     const int* path_row_offsets;   // [paths+1]
     const int* path_task;          // [paths]
     const int* row_t;              // [rows] time index inside the path
@@ -54,7 +55,8 @@ __global__ void __launch_bounds__(64) k_returns(SampleArgs a) {
     double carry = 0.0, usum = 0.0, rsq = 0.0, y0 = 0.0;
     for (int end = T; end > 0; end -= 64) {
         const int t = end - 64 + lane;
-        const double x = (t >= 0) ? (double)a.rew[row0 + t] : 0.0;
+        const int rr = row0 + (t >= 0 ? t : 0);
+        const double x = (t >= 0) ? (a.rew64 ? a.rew64[rr] : (double)a.rew[rr]) : 0.0;
         double y = x, gg = g;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -382,7 +384,8 @@ __global__ void __launch_bounds__(64) k_gae(SampleArgs a) {
         }
         double bn = shfl_down_f64(b, 1);
         if (lane == 63) bn = bcarry;
-        const double x = valid ? ((double)a.rew[valid ? row : 0] + g * bn - b) : 0.0;
+        const double rw = a.rew64 ? a.rew64[valid ? row : 0] : (double)a.rew[valid ? row : 0];
+        const double x = valid ? (rw + g * bn - b) : 0.0;
         double y = x, gg = gl;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {

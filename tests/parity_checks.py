@@ -69,6 +69,31 @@ def check_sample_processing_oracle(lib, seed, M, P, T, O, ragged, kwargs, baseli
     return out
 
 
+def check_float64_rewards(lib, seed, M=2, P=3, T=60, O=4):
+    """rewards of large magnitude with small float64 structure (1e4 + N(0,1)): the reference scans the env's float64
+    rewards, so returns must match the oracle to float64 accuracy and the raw GAE advantages (differences of large
+    numbers) far better than a float32 round trip of the rewards would allow"""
+    from promp_amd import synthetic
+    rng = np.random.RandomState(seed)
+    theta = synthetic.init_theta(rng, O, (8, 8), 2)
+    paths = synthetic.make_paths(rng, theta, M, P, T, O, 2, (8, 8), ragged=True)
+    for plist in paths.values():
+        for p in plist:
+            p['rewards'] = 1e4 + rng.randn(len(p['rewards']))          # float64
+    kwargs = dict(discount=0.99, gae_lambda=0.95, normalize_adv=False, positive_adv=False)
+    fl = _lib.flatten_paths(paths)
+    assert fl['rew'].dtype == np.float64
+    ctx = _lib.Context(M, O, 2, (32, 32), 1, max_rows=len(fl['rew']), max_paths=len(fl['path_row_offsets']) - 1, lib=lib)
+    ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
+    ctx.process_samples(0, baseline_kind=KIND['linear_time'], **kwargs)
+    ret64, adv64 = ctx.download_raw(0)
+    ctx.close()
+    ref, _, _ = sp.process_samples_meta(paths, baseline_kind=KIND['linear_time'], **kwargs)
+    np.testing.assert_allclose(ret64, np.concatenate([r['returns'] for r in ref]), rtol=1e-12)
+    # float32 rewards would be off by ~5e-4 each (ulp of 1e4 in float32 is ~1e-3), i.e. ~1e-2 after the GAE scan
+    np.testing.assert_allclose(adv64, np.concatenate([r['advantages'] for r in ref]), rtol=0, atol=2e-5)
+
+
 def check_fit_retry_on_rank_deficient_features(lib, seed, M=2, P=3, T=40, O=4):
     """LinearBaseline.fit's "NaN -> reg *= 10, at most 5 tries" (linear_baseline.py:68-77).  Two identical observation columns
     make Phi^T Phi exactly singular and reg = 1e-13 is below one ulp of its diagonal, so the first factorization attempts meet a

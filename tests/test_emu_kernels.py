@@ -77,6 +77,10 @@ def test_staged_upload_sequence(lib, two_cus):
     pc.check_staged_upload(lib, 29, M=2, P=1, T=20, O=5, A=3, hidden=(32, 32), iters=2, epochs=1)
 
 
+def test_float64_rewards(lib, two_cus):
+    pc.check_float64_rewards(lib, 31, M=2, P=2, T=30, O=3)
+
+
 def test_fused_and_separate_task_reduction_agree(lib, two_cus):
     pc.check_schedule_invariance(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), K=1, iters=1, epochs=1)
 

@@ -265,6 +265,10 @@ def test_staged_uploads_from_pinned_memory_equal_plain_uploads(lib):
     pc.check_staged_upload(lib, 95, M=6, P=5, T=100, O=20, A=6, hidden=(64, 64), iters=5)
 
 
+def test_float64_rewards_stay_float64_on_the_device(lib):
+    pc.check_float64_rewards(lib, 97)
+
+
 def test_launch_scheduling_does_not_change_results(lib):
     """second-stream sample processing and the fused / separate task reduction of the Hessian-vector pass: bitwise the same"""
     pc.check_schedule_invariance(lib, 81, M=6, P=5, T=120, O=20, A=6, hidden=(64, 64), K=1, iters=4)
