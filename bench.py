@@ -123,7 +123,7 @@ def main():
                 o.build_graph(_DeviceEvaluator(shim), 0.01)
             mode = dict(hvp='finite_difference')     # the reference's construction is the timed default (parity mode)
 
-        def iteration():
+        def iteration(deferred=False):
             ctx.switch_to_pre_update()                       # meta_trainer.py:85
             ctx.process_samples(0, **opts)                   # :105  (step 0)
             ctx.inner_adapt(0, _lib.INNER_LOGLIK if trpo else _lib.INNER_RATIO)     # :116
@@ -134,7 +134,25 @@ def main():
                 cg.optimize()
                 return dict(loss_before=l0, loss_after=cg.loss(), kl_before=kl0, kl_after=cg.constraint_val(),
                             n_backtracks=cg.last['n_backtracks'], rejected=cg.last['rejected'])
-            return ctx.optimize(E, 1e-3, 0.3, eta)           # :128  (E Adam epochs + compute_stats; syncs)
+            # :128  E Adam epochs + compute_stats.  The statistics of iteration n are collected (promp_optimize_end) in front of
+            # the optimisation of iteration n+1, where the KL-coefficient rule needs them (pro_mp.py:201-214): the host is
+            # not held at the end of the step and enqueues the next batch's sample processing while this one is optimised.
+            # run_timed() collects the last one inside the timed region.
+            return optimize(deferred)
+        pending = {'on': False}
+
+        def optimize(deferred):
+            prev = ctx.optimize_end() if pending['on'] else None
+            ctx.optimize_begin(E, 1e-3, 0.3, eta)
+            pending['on'] = deferred
+            return prev if deferred else ctx.optimize_end()
+
+        def collect():
+            if pending['on']:
+                pending['on'] = False
+                return ctx.optimize_end()
+            return None
+        iteration.collect = collect
         def staged_iteration_factory():
             """the same iteration fed by staged uploads: the batch of iteration n+1 (here: the same synthetic batch again)
             leaves pinned host memory on the copy stream while iteration n is being optimised"""
@@ -152,14 +170,15 @@ def main():
                                              pin[k]['old_mean'], pin[k]['ls'])
             stage(0), stage(1)
 
-            def it():
+            def it(deferred=False):
                 ctx.commit_step(0), ctx.commit_step(1)
                 ctx.switch_to_pre_update()
                 ctx.process_samples(0, **opts)
                 ctx.inner_adapt(0, _lib.INNER_LOGLIK if trpo else _lib.INNER_RATIO)
                 ctx.process_samples(1, **opts)
                 stage(0), stage(1)                               # next batch: copy stream, under the epochs below
-                return ctx.optimize(E, 1e-3, 0.3, eta)
+                return optimize(deferred)
+            it.collect = collect
             return it
         iteration.upload = upload
         iteration.staged = staged_iteration_factory
@@ -173,12 +192,16 @@ def main():
             ctx.sync()
             ctx.allreduce_f64([0.0])
             ctx.sync()
+        res = None
         for _ in range(warmup):
             iteration()
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
-            res = iteration()
+            r = iteration(deferred=True)
+            res = r if r is not None else res
+        r = iteration.collect()          # the last step's statistics: waited for inside the timed region
+        res = r if r is not None else res
         ctx.sync()
         barrier()
         dt = time.perf_counter() - t0

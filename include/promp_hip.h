@@ -246,6 +246,14 @@ int promp_adam_step(promp_ctx* ctx, float learning_rate);
 int promp_optimize(promp_ctx* ctx, int num_epochs, float learning_rate, float clip_eps,
                    const float* inner_kl_coeff, int inner_kind, int outer_kind,
                    float* loss_before, float* stats_after);
+/* The same in two halves.  promp_optimize_begin enqueues everything (epochs, compute_stats, an asynchronous copy of
+ * the statistics to page-locked memory) and returns without waiting; promp_optimize_end waits for that copy and hands
+ * out loss_before / stats_after.  Between the two the caller may enqueue work that does not depend on the statistics --
+ * Trainer.train's next process_samples / _adapt (meta_trainer.py:105-116); the KL-coefficient rule (pro_mp.py:201-214)
+ * needs them only in front of the next optimize_policy.  One optimisation may be pending at a time. */
+int promp_optimize_begin(promp_ctx* ctx, int num_epochs, float learning_rate, float clip_eps,
+                         const float* inner_kl_coeff, int inner_kind, int outer_kind);
+int promp_optimize_end(promp_ctx* ctx, float* loss_before, float* stats_after);
 
 /* ---- multi-GPU: task-sharded data parallelism, one process per GPU, RCCL over xGMI.
  * The only exchange on the path is the task-mean of the meta-objective / its gradient

@@ -94,6 +94,8 @@ SIGNATURES = {
     'promp_meta_grad': (C.c_int, [_P, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
     'promp_adam_step': (C.c_int, [_P, C.c_float]),
     'promp_optimize': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
+    'promp_optimize_begin': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int]),
+    'promp_optimize_end': (C.c_int, [_P, _F, _F]),
     'promp_comm_unique_id': (C.c_int, [_P, C.c_size_t]),
     'promp_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     'promp_comm_move': (C.c_int, [_P, _P]),
@@ -429,6 +431,20 @@ class Context:
         lb, stats = C.c_float(0), np.empty(self.K + 2, np.float32)
         self._call('promp_optimize', int(num_epochs), float(lr), float(clip_eps), _ptr(eta, C.c_float), int(inner_kind),
                    int(outer_kind), C.byref(lb), _ptr(stats, C.c_float))
+        return dict(loss_before=float(lb.value), loss_after=float(stats[0]), inner_kl=stats[1:1 + self.K].copy(),
+                    outer_kl=float(stats[1 + self.K]))
+
+    def optimize_begin(self, num_epochs, lr, clip_eps, inner_kl_coeff, inner_kind=INNER_RATIO, outer_kind=OUTER_CLIP):
+        """promp_optimize_begin: enqueue the whole optimisation and return at once; optimize_end() collects the statistics
+        (the host is free to enqueue the next batch's process_samples / inner_adapt in between)"""
+        eta = _f32(inner_kl_coeff)
+        assert eta.shape == (self.K,)
+        self._call('promp_optimize_begin', int(num_epochs), float(lr), float(clip_eps), _ptr(eta, C.c_float), int(inner_kind),
+                   int(outer_kind))
+
+    def optimize_end(self):
+        lb, stats = C.c_float(0), np.empty(self.K + 2, np.float32)
+        self._call('promp_optimize_end', C.byref(lb), _ptr(stats, C.c_float))
         return dict(loss_before=float(lb.value), loss_after=float(stats[0]), inner_kl=stats[1:1 + self.K].copy(),
                     outer_kl=float(stats[1 + self.K]))
 

@@ -95,10 +95,20 @@ PROMP_DEV f32x4 pin_agpr(f32x4 v) {
     return v;
 }
 PROMP_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate: 0..3)
+PROMP_DEV void wave_priority(int p) {
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 PROMP_DEV unsigned long long promp_clock() { return (unsigned long long)clock64(); }
 PROMP_DEV unsigned long long promp_wall_clock() { return (unsigned long long)wall_clock64(); }   // constant 100 MHz
 PROMP_DEV float fast_exp(float x) { return __expf(x); }
 PROMP_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+PROMP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+// two fused multiply-adds in one v_pk_fma_f32 (an FMA costs two issue slots next to FP32 MFMAs, packed or not)
+PROMP_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 
 PROMP_DEV f32x4 zero4() {
@@ -257,6 +267,28 @@ PROMP_DEV void outer16_two(f32x4 (&acc)[NA][NB], const float* a0, const float* a
 
 // tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7, saturates correctly at +-1.
 PROMP_DEV float fast_tanh(float x) { return 1.f - 2.f * fast_rcp(fast_exp(2.f * x) + 1.f); }
+
+// The same for a pre-activation that arrives already scaled by PROMP_TANH_PRESCALE = 2 log2(e) (the kernels fold the
+// factor into the staged kernel / bias of the layer): tanh(x) = 1 - 2 / (2^y + 1), y = 2 log2(e) x.  Two elements at a time:
+// v_exp_f32, v_add_f32, v_rcp_f32 each and ONE v_pk_fma_f32 for the pair.
+#define PROMP_TANH_PRESCALE 2.8853900817779268f
+PROMP_DEV f32x2 tanh2_prescaled(float y0, float y1) {
+    f32x2 r;
+    r[0] = fast_rcp(fast_exp2(y0) + 1.f);
+    r[1] = fast_rcp(fast_exp2(y1) + 1.f);
+    f32x2 m2, one;
+    m2[0] = m2[1] = -2.f;
+    one[0] = one[1] = 1.f;
+    return pk_fma(r, m2, one);
+}
+// h^2 - 1 (the NEGATED tanh derivative) for two elements in one v_pk_fma_f32; the caller's multiply takes the sign back
+// as a source modifier (negating h first would cost a v_xor per element)
+PROMP_DEV f32x2 neg_dtanh2(float h0, float h1) {
+    f32x2 h, m1;
+    h[0] = h0; h[1] = h1;
+    m1[0] = m1[1] = -1.f;
+    return pk_fma(h, h, m1);
+}
 
 // acc[ia][ib] (16x16 tiles) += sgn * A_ia * B_ib over NS k-steps of 16x16x4 MFMAs.
 // Operand streams: at step s, A block ia feeds a[s*a_ss + ia*a_bs], B block ib feeds b[s*b_ss + ib*b_bs] (pointers

@@ -86,6 +86,14 @@ struct StepData {
 constexpr int CHAIN_NW_HVP = 4;
 // layer-1 k-steps k_chain_hvp is instantiated for (4 observation entries per step, zero-padded)
 int chain_ksteps(int obs_dim) { return obs_dim <= 8 ? 2 : obs_dim <= 20 ? 5 : 8; }
+// k_fwd_bwd instances: the first layer's k-steps are a compile-time constant for the widths the BASELINE configs use
+// (17..20 observations: 5 steps); every other width takes the runtime loop (KS = 0)
+#ifdef PROMP_NO_KS1
+int pass_ksteps(int) { return 0; }
+#else
+int pass_ksteps(int obs_dim) { return (obs_dim + 3) / 4 == 5 ? 5 : 0; }
+#endif
+#define PROMP_PASS_ALL(X) X(1, 1, 0) X(1, 2, 0) X(2, 1, 0) X(2, 2, 0) X(1, 1, 5) X(1, 2, 5) X(2, 1, 5) X(2, 2, 5)
 #define PROMP_CHAIN_ALL(X) X(2, 2, 2) X(2, 2, 5) X(2, 2, 8) X(2, 4, 2) X(2, 4, 5) X(2, 4, 8) X(4, 2, 2) X(4, 2, 5) X(4, 2, 8) X(4, 4, 2) X(4, 4, 5) X(4, 4, 8)
 
 struct ProfSlot {
@@ -135,6 +143,10 @@ struct promp_ctx {
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
+    float* stats_host = nullptr;         // pinned: promp_optimize_begin parks both statistics slots here (async copy)
+    hipEvent_t stats_ev = nullptr;       // ... and records this event behind the copy
+    bool opt_pending = false;
+    int opt_epochs = 0;
     float* fwd_buf = nullptr;            // staging for promp_policy_forward
     size_t fwd_capacity = 0;
 };
@@ -320,13 +332,13 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         HIPCHECK(hipGetLastError());
         if (a.fuse_reduce) return prof_end(c, id);
     } else {
-        const int b1 = c->d.hidden1 / 32, b2 = c->d.hidden2 / 32;
-#define PROMP_PASS_CASE(B1, B2)                                                                                                   \
-    if (b1 == B1 && b2 == B2) {                                                                                                   \
-        if (fwd_only) { auto k = k_fwd_bwd<B1, B2, 8, false>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
-        else { auto k = k_fwd_bwd<B1, B2, 8, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }          \
+        const int b1 = c->d.hidden1 / 32, b2 = c->d.hidden2 / 32, ks1 = pass_ksteps(c->d.obs_dim);
+#define PROMP_PASS_CASE(B1, B2, KS)                                                                                                    \
+    if (b1 == B1 && b2 == B2 && ks1 == KS) {                                                                                           \
+        if (fwd_only) { auto k = k_fwd_bwd<B1, B2, 8, false, KS>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
+        else { auto k = k_fwd_bwd<B1, B2, 8, true, KS>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }          \
     }
-        PROMP_PASS_CASE(1, 1) PROMP_PASS_CASE(1, 2) PROMP_PASS_CASE(2, 1) PROMP_PASS_CASE(2, 2)
+        PROMP_PASS_ALL(PROMP_PASS_CASE)
 #undef PROMP_PASS_CASE
     }
     HIPCHECK(hipGetLastError());
@@ -513,13 +525,13 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     }
         PROMP_CHAIN_ALL(PROMP_CHAIN_ATTR)
 #undef PROMP_CHAIN_ATTR
-#define PROMP_PASS_ATTR(B1, B2)                                                                                              \
+#define PROMP_PASS_ATTR(B1, B2, KS)                                                                                          \
     {                                                                                                                     \
-        auto c0 = k_fwd_bwd<B1, B2, 8, true>; auto c1 = k_fwd_bwd<B1, B2, 8, false>;                                       \
+        auto c0 = k_fwd_bwd<B1, B2, 8, true, KS>; auto c1 = k_fwd_bwd<B1, B2, 8, false, KS>;                               \
         HIPCHECK(hipFuncSetAttribute((const void*)c0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         HIPCHECK(hipFuncSetAttribute((const void*)c1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
     }
-        PROMP_PASS_ATTR(1, 1) PROMP_PASS_ATTR(1, 2) PROMP_PASS_ATTR(2, 1) PROMP_PASS_ATTR(2, 2)
+        PROMP_PASS_ALL(PROMP_PASS_ATTR)
 #undef PROMP_PASS_ATTR
 #define PROMP_WIDE_ATTR(HH, NOB)                                                                                          \
     {                                                                                                                     \
@@ -566,6 +578,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->red64, 64);
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
+    if (hipHostMalloc((void**)&c->stats_host, sizeof(float) * 2 * (K + 2), hipHostMallocDefault) != hipSuccess) rc |= 1;
+    if (hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming) != hipSuccess) rc |= 1;
     c->steps.resize(K + 1);
     for (int s = 0; s <= K && !rc; ++s) rc |= alloc_step(c, c->steps[s]);
     if (rc) { promp_ctx_destroy(c); return -2; }
@@ -594,6 +608,8 @@ void promp_ctx_destroy(promp_ctx* c) {
                     c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->stats_host) (void)hipHostFree(c->stats_host);
+    if (c->stats_ev) (void)hipEventDestroy(c->stats_ev);
     for (auto& s : c->prof_slots)
         for (auto ev : s.ev) (void)hipEventDestroy(ev);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -1463,10 +1479,10 @@ int promp_adam_step(promp_ctx* c, float lr) {
     return 0;
 }
 
-int promp_optimize(promp_ctx* c, int num_epochs, float lr, float clip_eps, const float* eta, int inner_kind, int outer_kind,
-                   float* loss_before, float* stats_after) {
+int promp_optimize_begin(promp_ctx* c, int num_epochs, float lr, float clip_eps, const float* eta, int inner_kind, int outer_kind) {
     if (!c || !eta) return fail(-1, "NULL argument");
     if (num_epochs < 0) return fail(-1, "num_epochs must be >= 0");
+    if (c->opt_pending) return fail(-1, "promp_optimize_begin: the previous optimisation has not been collected (promp_optimize_end)");
     if (upload_eta(c, eta)) return -2;
     const int K = c->d.num_inner_steps;
     for (int e = 0; e < num_epochs; ++e) {
@@ -1478,11 +1494,30 @@ int promp_optimize(promp_ctx* c, int num_epochs, float lr, float clip_eps, const
         if (rc) return -2;
     }
     if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, false, false, 0.f)) return -2;   // compute_stats
-    std::vector<float> st((size_t)2 * (K + 2));
-    if (copy_out(c, st.data(), c->stats, st.size())) return -2;
-    if (stats_after) memcpy(stats_after, st.data(), sizeof(float) * (K + 2));
-    if (loss_before) *loss_before = num_epochs > 0 ? st[K + 2] : st[0];
+    // both statistics slots leave for page-locked host memory behind the last launch; nothing waits here, so the host can
+    // enqueue the next batch's sample processing while this optimisation still runs
+    HIPCHECK(hipMemcpyAsync(c->stats_host, c->stats, sizeof(float) * 2 * (K + 2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipEventRecord(c->stats_ev, c->stream));
+    c->opt_pending = true;
+    c->opt_epochs = num_epochs;
     return 0;
+}
+
+int promp_optimize_end(promp_ctx* c, float* loss_before, float* stats_after) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (!c->opt_pending) return fail(-1, "promp_optimize_end without promp_optimize_begin");
+    c->opt_pending = false;
+    HIPCHECK(hipEventSynchronize(c->stats_ev));
+    const int K = c->d.num_inner_steps;
+    if (stats_after) memcpy(stats_after, c->stats_host, sizeof(float) * (K + 2));
+    if (loss_before) *loss_before = c->opt_epochs > 0 ? c->stats_host[K + 2] : c->stats_host[0];
+    return 0;
+}
+
+int promp_optimize(promp_ctx* c, int num_epochs, float lr, float clip_eps, const float* eta, int inner_kind, int outer_kind,
+                   float* loss_before, float* stats_after) {
+    if (promp_optimize_begin(c, num_epochs, lr, clip_eps, eta, inner_kind, outer_kind)) return -2;
+    return promp_optimize_end(c, loss_before, stats_after);
 }
 
 int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int clip_ls, float* grads_out, float* loss_out,

@@ -104,7 +104,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
 
 // BWD = false: objective and mean KL only (compute_stats / line-search evaluations): the tile loop stops after the
 // distribution epilogue and the partial carries just the two scalars.
-template <int NB1, int NB2, int NW, bool BWD>
+// KS1 > 0: the observation width is known at compile time (ceil(O / 4) == KS1 k-steps in the first layer): the k-loop
+// unrolls and its accumulators stay in place (the runtime loop pays a register copy per accumulator element and step).
+template <int NB1, int NB2, int NW, bool BWD, int KS1 = 0>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, W3S = PROMP_W3S;
@@ -113,6 +115,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w_ = tid >> 6;
     const int i16 = lane & 15, kk = lane >> 4;
+    CH_WGSTAMP(0);
+    CH_STAMP(0);
     const PassWork pw = a.pwork[blockIdx.x];
     const int w = wave_uniform(w_);
     const int seg = (w < pw.nw0) ? 0 : 1;      // which of the workgroup's (at most two) tasks this wave serves
@@ -140,10 +144,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
 #pragma unroll
         for (int i = 0; i < N1; ++i) {
             const int e = tid + i * NT;
-            r1[i] = (e < O * H1) ? th[e] : 0.f;
+            r1[i] = (e < O * H1) ? PROMP_TANH_PRESCALE * th[e] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < N2; ++i) r2[i] = th[oW2 + tid + i * NT];
+        for (int i = 0; i < N2; ++i) r2[i] = PROMP_TANH_PRESCALE * th[oW2 + tid + i * NT];
 #pragma unroll
         for (int i = 0; i < N3; ++i) {
             const int e = tid + i * NT, k = e >> 4, j = e & 15;
@@ -174,8 +178,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             const int e = tid + i * NT;
             if (e < 8 * H2) W3Ts[e] = r3t[i];
         }
-        if (tid < H1) b1s[tid] = th[ob1 + tid];
-        if (tid < H2) b2s[tid] = th[ob2 + tid];
+        if (tid < H1) b1s[tid] = PROMP_TANH_PRESCALE * th[ob1 + tid];
+        if (tid < H2) b2s[tid] = PROMP_TANH_PRESCALE * th[ob2 + tid];
         if (tid < 16) {
             b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
             const float sr = (tid < A) ? th[oS + tid] : 0.f;
@@ -193,6 +197,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
           *b3s = cp + L.b3, *lss = cp + L.ls, *lmask = cp + L.lmask, *ess = cp + L.es, *sn2s = cp + L.sn2;
     for (int e = lane; e < L.wave_stride; e += 64) wreg[e] = 0.f;   // pad columns stay zero; over-read cells finite
     __syncthreads();
+    CH_STAMP(1);
 
     // ---- persistent accumulators of this wave ----
     f32x4 aw2[NC1][NC2], aw1[2][NC1], aw3[NC2][1];
@@ -237,7 +242,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     }
 
     int tix = 0;
+#ifndef PROMP_NO_TILE_PRIO
+    // The two waves of a SIMD share its issue slots oldest-first, so the older wave runs ahead and the younger one is
+    // left to finish alone (one wave per SIMD pays twice as many issue cycles per VALU / LDS instruction): the wave with
+    // more tiles left gets the higher priority, which keeps the pair within a tile of each other up to the end.
+    const int my_tiles = (wi < ntiles) ? (ntiles - wi + wstride - 1) / wstride : 0;
+#endif
     for (int t = wi; t < ntiles; t += wstride, ++tix) {
+#ifndef PROMP_NO_TILE_PRIO
+        wave_priority(my_tiles - 1 - tix);
+#endif
+        CH_TSTAMP(0);
         const int base = trow0 + PROMP_WROWS * t;
         const int nrows = (tnrows - PROMP_WROWS * t) < PROMP_WROWS ? (tnrows - PROMP_WROWS * t) : PROMP_WROWS;
 #pragma unroll
@@ -273,13 +288,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             f32x4 acc[1][NC1];
 #pragma unroll
             for (int j = 0; j < NC1; ++j) acc[0][j] = splat4(b1s[16 * j + i16]);   // bias rides in the accumulator
-            outer16<1, NC1>(acc, Xw + i16 * XS + kk, 4, 0, W1s + kk * H1 + i16, 4 * H1, 16, Opad4 / 4, 1.f);
+            outer16<1, NC1>(acc, Xw + i16 * XS + kk, 4, 0, W1s + kk * H1 + i16, 4 * H1, 16, KS1 > 0 ? KS1 : Opad4 / 4, 1.f);
 #pragma unroll
             for (int j = 0; j < NC1; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) H1w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r]);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 h = tanh2_prescaled(acc[0][j][r], acc[0][j][r + 1]);
+                    H1w[(4 * kk + r) * HS + 16 * j + i16] = h[0];
+                    H1w[(4 * kk + r + 1) * HS + 16 * j + i16] = h[1];
+                }
         }
         wave_sync();
+        CH_TSTAMP(1);
         // ---- layer 2
         {
             f32x4 acc[1][NC2];
@@ -289,9 +309,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) H2w[(4 * kk + r) * HS + 16 * j + i16] = fast_tanh(acc[0][j][r]);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 h = tanh2_prescaled(acc[0][j][r], acc[0][j][r + 1]);
+                    H2w[(4 * kk + r) * HS + 16 * j + i16] = h[0];
+                    H2w[(4 * kk + r + 1) * HS + 16 * j + i16] = h[1];
+                }
         }
         wave_sync();
+        CH_TSTAMP(2);
         // ---- output layer (16 padded columns)
         {
             f32x4 acc[1][1];
@@ -301,6 +326,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r];
         }
         wave_sync();
+        CH_TSTAMP(3);
         // ---- distribution + objective epilogue
         {
             float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
@@ -377,10 +403,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             // columns >= A of Msw already hold exact zeros (zero-padded W3s / b3s)
         }
         wave_sync();
+        CH_TSTAMP(4);
         if (BWD) {
         // ---- output-kernel gradient (+=); dZ2 = (dmu W3^T) * (1 - H2^2) in place over H2
         outer16<NC2, 1>(aw3, H2w + kk * HS + i16, 4 * HS, 16, Msw + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, 1.f);
         sched_fence();
+        CH_TSTAMP(5);
         {
             f32x4 acc[1][NC2];
 #pragma unroll
@@ -390,20 +418,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             for (int j = 0; j < NC2; ++j) {
                 float cs = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; r += 2) {
                     const int idx = (4 * kk + r) * HS + 16 * j + i16;
-                    const float h = H2w[idx];
-                    const float d = acc[0][j][r] * (1.f - h * h);
-                    H2w[idx] = d;
-                    cs += d;
+                    const f32x2 ns = neg_dtanh2(H2w[idx], H2w[idx + HS]);
+                    const float d0 = acc[0][j][r] * -ns[0], d1 = acc[0][j][r + 1] * -ns[1];
+                    H2w[idx] = d0;
+                    H2w[idx + HS] = d1;
+                    cs += d0;
+                    cs += d1;
                 }
                 gb2[j] += cs;
             }
         }
         wave_sync();
+        CH_TSTAMP(6);
         // ---- hidden_1 kernel gradient (+=); dZ1 = (dZ2 W2^T) * (1 - H1^2) in place over H1
         outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, 4 * HS, 16, H2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
         sched_fence();
+        CH_TSTAMP(7);
         {
             f32x4 acc[1][NC1];
 #pragma unroll
@@ -413,23 +445,45 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             for (int j = 0; j < NC1; ++j) {
                 float cs = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < 4; r += 2) {
                     const int idx = (4 * kk + r) * HS + 16 * j + i16;
-                    const float h = H1w[idx];
-                    const float d = acc[0][j][r] * (1.f - h * h);
-                    H1w[idx] = d;
-                    cs += d;
+                    const f32x2 ns = neg_dtanh2(H1w[idx], H1w[idx + HS]);
+                    const float d0 = acc[0][j][r] * -ns[0], d1 = acc[0][j][r + 1] * -ns[1];
+                    H1w[idx] = d0;
+                    H1w[idx + HS] = d1;
+                    cs += d0;
+                    cs += d1;
                 }
                 gb1[j] += cs;
             }
         }
         wave_sync();
+        CH_TSTAMP(8);
         // ---- hidden_0 kernel gradient (+=): rows = observation index (two 16-blocks cover O <= 32)
         outer16<2, NC1>(aw1, Xw + kk * XS + i16, 4 * XS, 16, H1w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
         wave_sync();
+        CH_TSTAMP(9);
         }
     }
+    CH_STAMP(2);
+#ifdef PROMP_DEV_STAMPS
+    if (a.dbg != nullptr && blockIdx.x < 4 && lane == 0) { a.dbg[208 + 8 * blockIdx.x + w] = promp_clock(); a.dbg[128 + 8 * blockIdx.x + w] = tix; }
+#endif
 
+    if (BWD) {
+        // the hidden_1 kernel is staged pre-scaled by PROMP_TANH_PRESCALE (so that the forward pass feeds v_exp_f32 without a
+        // multiply); the backward product through it therefore carried that factor into dZ1, i.e. into the hidden_0
+        // kernel / bias gradients, and leaves here
+        constexpr float inv_c = 1.0f / PROMP_TANH_PRESCALE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aw1[i][j][r] *= inv_c;
+#pragma unroll
+        for (int j = 0; j < NC1; ++j) gb1[j] *= inv_c;
+    }
     const float lmask_reg0 = lmask[lane & 3], lmask_reg1 = lmask[(lane & 3) + 4];
     // ---- add the four waves' results in wave order, then one coalesced partial ----
     // bias sums: lanes with equal i16 hold different row groups -> fold kk
@@ -480,7 +534,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     float* S = sm;                                   // whole LDS allocation is free now
     const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
     const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
+    CH_STAMP(4);
     lds_barrier();
+    CH_STAMP(5);
     {
         float* mine = S + w * NW2;
 #pragma unroll
@@ -491,6 +547,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
     }
     lds_barrier();
+    CH_STAMP(6);
 #pragma unroll 2
     for (int e = tid; e < NW2; e += NT) {
         float v[NW];
@@ -505,6 +562,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         P0[oW2 + e] = t0;
         if (two) P1[oW2 + e] = t1;
     }
+    CH_STAMP(7);
     lds_barrier();        // (LDS ordering only: the partial-row stores in flight are not waited for)
     {
         // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
@@ -546,7 +604,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             mine[NP + 1 - NW2] = klsum;
         }
     }
+    CH_STAMP(200);
     lds_barrier();
+    CH_STAMP(201);
     for (int e = tid; e < NR2; e += NT) {
         const int dst = e < oW2 ? e : e + NW2;
         float v[NW];
@@ -561,4 +621,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         P0[dst] = t0;
         if (two) P1[dst] = t1;
     }
+    CH_STAMP(3);
+    CH_WGSTAMP(1);
 }

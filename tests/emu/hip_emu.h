@@ -200,6 +200,9 @@ inline unsigned long long promp_wall_clock() { return 0; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
+inline float fast_exp2(float x) { return exp2f(x); }
+inline void wave_priority(int) {}
+inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 
 // ---- host runtime shims -------------------------------------------------------------------------
 typedef int hipError_t;

@@ -20,7 +20,8 @@ fn = ctx.lib.cdll.promp_debug_phase_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
 names = ['L1', 'L2', 'L3', 'epi', 'dW3', 'dz2', 'dW2', 'dz1', 'dW1']
-for hvp in (1,):
+import os
+for hvp in tuple(int(x) for x in os.environ.get('PROMP_STAMP_KERNELS', '0,1').split(',')):
     for rep in range(3):
         buf = np.zeros(256 + 4096, np.uint64)
         rc = fn(ctx._h, 0, hvp, buf.ctypes.data_as(C.POINTER(C.c_uint64)))
@@ -28,6 +29,11 @@ for hvp in (1,):
     s = buf.astype(np.int64)
     t0 = s[0]
     print('kernel', 'hvp' if hvp else 'pass', ' net1@%d nets@%d zeroed@%d' % (s[5] - t0, s[6] - t0, s[7] - t0), ' staged@%d  loop_end@%d  partial_written@%d  task_reduce_done@%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
+    if not hvp:
+        print('  pass end phase: loop_end@%d  shuffles_done@%d barrier1@%d slab1_written@%d sum1_done@%d slab2_written@%d barrier@%d end@%d' % tuple(int(x - t0) for x in (s[2], s[4], s[5], s[6], s[7], s[200], s[201], s[3])))
+    if not hvp:
+        for b in range(4):
+            print('  wg', b, 'wave loop ends', [int(x - t0) for x in s[208 + 8 * b: 216 + 8 * b]], 'tiles', [int(x) for x in s[128 + 8 * b: 136 + 8 * b]])
     wg = s[256:].reshape(-1, 4)
     wg = wg[wg[:, 0] > 0]
     w0 = wg[:, 0].min()

@@ -6,7 +6,9 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 # a step starts at the first k_returns after a k_final_adam / k_mean_adam
 starts = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_returns') or 'k_returns' in r['Kernel_Name']]
 steps = [i for j, i in enumerate(starts) if j % 2 == 0]
-a, b = steps[-2], steps[-1]
+import os
+sel = int(os.environ.get('TIMELINE_STEP', '-2'))
+a, b = steps[sel], steps[sel + 1]
 t0 = int(rows[a]['Start_Timestamp']); prev = None; busy = 0
 for r in rows[a:b]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
