@@ -47,7 +47,9 @@ typedef struct promp_dims {
 
 enum { PROMP_BASELINE_ZERO = 0, PROMP_BASELINE_LINEAR_FEATURE = 1, PROMP_BASELINE_LINEAR_TIME = 2 };
 enum { PROMP_INNER_RATIO = 0,   /* -mean(ratio*adv)   meta_algos/pro_mp.py:59-65   */
-       PROMP_INNER_LOGLIK = 1   /* -mean(logpi*adv)   meta_algos/trpo_maml.py:58-62 */ };
+       PROMP_INNER_LOGLIK = 1,  /* -mean(logpi*adv)   meta_algos/trpo_maml.py:58-62 */
+       PROMP_INNER_DICE = 2     /* -mean(magic_box(cumsum logpi) * adjusted_reward * mask), meta_algos/dice_maml.py:39-45,245-258;
+                                   needs promp_set_dice_rewards on every step; outer kind PROMP_OUTER_LOGLIK */ };
 enum { PROMP_OUTER_CLIP = 0,    /* PPO clipped surrogate, meta_algos/pro_mp.py:141-145 */
        PROMP_OUTER_RATIO = 1,   /* unclipped,            meta_algos/trpo_maml.py:135    */
        PROMP_OUTER_KL = 2       /* mean KL(old || new) of the last step itself: the TRPO constraint
@@ -137,6 +139,15 @@ int promp_predict_baseline(promp_ctx* ctx, int step, int baseline_kind, double* 
 
 /* Use caller-provided advantages for a step instead of promp_process_samples' (float32 [rows]). */
 int promp_set_advantages(promp_ctx* ctx, int step, const float* advantages);
+/* DICE-MAML (meta_algos/dice_maml.py:39-45, 84-152, 245-258): the step's per-row rewards of the DiCE objective
+ *   -mean_{p,t}( magic_box(sum_{t'<=t} logpi_{p,t'}) * adjusted_reward_{p,t} * mask_{p,t} ),
+ * rewards [rows] float32 = adjusted_reward of every VALID row (path by path, as uploaded), already multiplied by
+ * rows / (paths * max_path_length) of its task so that the slab mean equals the reference's mean over the zero-padded
+ * [paths, max_path_length] array (samplers/dice_sample_processor.py:165-191).  Computes the suffix sums within each path
+ * that weight the log-likelihood gradient and installs them as the step's advantages; PROMP_INNER_DICE additionally
+ * couples the time steps of a path in the second-order term (two extra launches per R-operator pass).
+ * Register-chained kernels only (hidden sizes from {32,64}, obs_dim <= 32). */
+int promp_set_dice_rewards(promp_ctx* ctx, int step, const float* rewards);
 
 /* ---- parameters (rows a14: policies/base.py:173-203, 234-240, 262-286) ---------------------- */
 int promp_set_theta(promp_ctx* ctx, const float* theta);                 /* [Theta] meta-parameters     */

@@ -249,6 +249,142 @@ def gen_promp():
         print('wrote promp_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
 
 
+# --------------------------------------------------------------------------------------------------
+DICE_PROC_CASES = {
+    # name: (seed, dims, max_path_length, processor kwargs, baseline, ragged)
+    'default':  (31, dict(M=3, P=4, T=30, O=5, A=2), 30, dict(discount=0.99, normalize_adv=True), 'linear_time', False),
+    'ragged':   (32, dict(M=3, P=5, T=40, O=4, A=3), 40, dict(discount=0.95, normalize_adv=True), 'linear_feature', True),
+    'raw':      (33, dict(M=2, P=4, T=25, O=3, A=2), 32, dict(discount=1.0, normalize_adv=False), 'zero', True),
+    'positive': (34, dict(M=2, P=3, T=20, O=3, A=2), 20, dict(discount=0.99, normalize_adv=True, positive_adv=True), 'linear_time', False),
+}
+
+
+def gen_dice_proc():
+    """inputs + outputs of the reference's own DiceMetaSampleProcessor (samplers/dice_sample_processor.py,
+    samplers/meta_sample_processor.py:50-51)"""
+    _, baselines, _ = _import_reference()
+    from meta_policy_search.samplers.meta_sample_processor import DiceMetaSampleProcessor
+    for name, (seed, dims, tmax, kw, bname, ragged) in DICE_PROC_CASES.items():
+        paths = make_sample_proc_inputs(seed, dims, dict(ragged=ragged))
+        lens = np.array([[len(p['rewards']) for p in plist] for plist in paths.values()], dtype=np.int32)
+        obs = np.concatenate([p['observations'] for plist in paths.values() for p in plist])
+        act = np.concatenate([p['actions'] for plist in paths.values() for p in plist])
+        rew = np.concatenate([p['rewards'] for plist in paths.values() for p in plist])
+        mean = np.concatenate([p['agent_infos']['mean'] for plist in paths.values() for p in plist])
+        lstd = np.concatenate([p['agent_infos']['log_std'] for plist in paths.values() for p in plist])
+        proc = DiceMetaSampleProcessor(baselines[bname](), max_path_length=tmax, **kw)
+        out = proc.process_samples(paths, log=False)
+        np.savez_compressed(
+            os.path.join(GOLDEN, 'dice_proc_%s.npz' % name),
+            meta=json.dumps(dict(seed=seed, dims=dims, max_path_length=tmax, kwargs=kw, baseline=bname, ragged=ragged,
+                                 keys=sorted(out[0].keys()))),
+            path_lengths=lens, observations=obs, actions=act, rewards=rew, agent_mean=mean, agent_log_std=lstd,
+            mask=np.stack([sd['mask'] for sd in out]),
+            adjusted_rewards=np.stack([sd['adjusted_rewards'] for sd in out]),
+            padded_rewards=np.stack([sd['rewards'] for sd in out]),
+            padded_observations=np.stack([sd['observations'] for sd in out]))
+        print('wrote dice_proc_%s.npz  N=%d' % (name, len(rew)))
+
+
+DICE_CASES = {
+    # hidden widths the device kernels are built for ({32, 64}); float64 torch graph on the padded arrays
+    'k1_small': dict(seed=201, M=3, P=3, T=10, Tmax=10, O=5, A=3, hidden=(32, 32), K=1, alpha=0.1, ragged=False),
+    'k1_ragged': dict(seed=202, M=2, P=3, T=12, Tmax=14, O=4, A=2, hidden=(32, 32), K=1, alpha=0.1, ragged=True),
+    'k2_small': dict(seed=203, M=2, P=2, T=8, Tmax=8, O=4, A=2, hidden=(32, 32), K=2, alpha=0.05, ragged=False),
+    'k1_hc':    dict(seed=204, M=2, P=2, T=16, Tmax=16, O=20, A=6, hidden=(64, 64), K=1, alpha=0.1, ragged=False),
+    'k1_long':  dict(seed=205, M=2, P=3, T=150, Tmax=160, O=6, A=2, hidden=(32, 64), K=1, alpha=0.05, ragged=True),
+}
+
+
+def make_dice_inputs(c):
+    """padded DiCE samples (mask, observations, actions, adjusted_rewards, agent_infos) for steps 0..K"""
+    rng = np.random.RandomState(c['seed'])
+    O, A, hidden, M = c['O'], c['A'], c['hidden'], c['M']
+    theta = synthetic.init_theta(rng, O, hidden, A)
+    theta = (theta + 0.05 * rng.randn(theta.size)).astype(np.float32)
+    all_samples = []
+    for k in range(c['K'] + 1):
+        paths = synthetic.make_paths(rng, np.tile(theta, (M, 1)), M, c['P'], c['T'], O, A, hidden, ragged=c['ragged'])
+        step = []
+        for plist in paths.values():
+            def pad(a):
+                a = np.asarray(a)
+                return np.pad(a, ((0, c['Tmax'] - a.shape[0]),) + ((0, 0),) * (a.ndim - 1), mode='constant')
+            step.append(dict(mask=np.stack([pad(np.ones(len(p['rewards']))) for p in plist]),
+                             observations=np.stack([pad(p['observations']) for p in plist]),
+                             actions=np.stack([pad(p['actions']) for p in plist]),
+                             adjusted_rewards=rng.randn(len(plist), c['Tmax']),
+                             agent_infos=dict(mean=np.stack([pad(p['agent_infos']['mean']) for p in plist]),
+                                              log_std=np.stack([pad(p['agent_infos']['log_std']) for p in plist]))))
+        all_samples.append(step)
+    return theta, all_samples
+
+
+def torch_dice_meta_objective(theta, all_samples, c, min_log_std=float(np.log(1e-6))):
+    """Direct transcription of DICEMAML.build_graph's forward arithmetic (meta_algos/dice_maml.py:39-45, 84-152, 245-258) on
+    the PADDED [P, Tmax] arrays in torch float64: cumulative log-likelihoods, magic box, mask; gradients by torch.autograd."""
+    import torch
+    O, A, hidden = c['O'], c['A'], c['hidden']
+    sizes = (O,) + tuple(hidden) + (A,)
+    th = torch.tensor(np.asarray(theta, dtype=np.float64), requires_grad=True)
+
+    def split(t):
+        parts, off = [], 0
+        for i in range(len(sizes) - 1):
+            n = sizes[i] * sizes[i + 1]
+            parts.append(t[off:off + n].reshape(sizes[i], sizes[i + 1])); off += n
+            parts.append(t[off:off + sizes[i + 1]]); off += sizes[i + 1]
+        parts.append(t[off:off + A])
+        return parts
+
+    def dice_obj(t, sd, clip):
+        T = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
+        p = split(t)
+        P_, Tm = sd['mask'].shape
+        x = T(sd['observations']).reshape(P_ * Tm, O)
+        for i in range(len(sizes) - 1):
+            x = x @ p[2 * i] + p[2 * i + 1]
+            if i < len(sizes) - 2:
+                x = torch.tanh(x)
+        s = p[-1]
+        if clip:
+            s = torch.maximum(s, torch.tensor(min_log_std, dtype=torch.float64))
+        a = T(sd['actions']).reshape(P_ * Tm, A)
+        z = (a - x) / torch.exp(s)
+        ll = (-(s * torch.ones_like(x)).sum(-1) - 0.5 * (z ** 2).sum(-1) - 0.5 * A * np.log(2 * np.pi)).reshape(P_, Tm)
+        tau = torch.cumsum(ll, dim=1)
+        box = torch.exp(tau - tau.detach())
+        return -(box * T(sd['adjusted_rewards']) * T(sd['mask'])).mean()
+
+    K, M = c['K'], c['M']
+    objs = []
+    for i in range(M):
+        cur, clip = th, True
+        for k in range(K):
+            inner = dice_obj(cur, all_samples[k][i], clip)
+            g, = torch.autograd.grad(inner, cur, create_graph=True)
+            cur, clip = cur - c['alpha'] * g, False
+        objs.append(dice_obj(cur, all_samples[K][i], False))
+    loss = torch.stack(objs).mean()
+    grad, = torch.autograd.grad(loss, th)
+    return float(loss.detach()), grad.numpy()
+
+
+def gen_dice():
+    for name, c in DICE_CASES.items():
+        theta, all_samples = make_dice_inputs(c)
+        loss, grad = torch_dice_meta_objective(theta, all_samples, c)
+        flat = {}
+        for k, step in enumerate(all_samples):
+            for key in ('mask', 'observations', 'actions', 'adjusted_rewards'):
+                flat['step%d_%s' % (k, key)] = np.stack([sd[key] for sd in step])
+            flat['step%d_mean' % k] = np.stack([sd['agent_infos']['mean'] for sd in step])
+            flat['step%d_log_std' % k] = np.stack([sd['agent_infos']['log_std'] for sd in step])
+        np.savez_compressed(os.path.join(GOLDEN, 'dice_autograd_%s.npz' % name), meta=json.dumps(c), theta=theta, loss=loss,
+                            grad=grad, **flat)
+        print('wrote dice_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
+
+
 def gen_point_env():
     sys.path.insert(0, '/root/reference')
 
@@ -340,8 +476,14 @@ def gen_dist_reference():
 
 if __name__ == '__main__':
     os.makedirs(GOLDEN, exist_ok=True)
+    if '--dice-only' in sys.argv:
+        gen_dice_proc()
+        gen_dice()
+        sys.exit(0)
     if '--dist-only' not in sys.argv:
         gen_sample_proc()
         gen_promp()
     gen_dist_reference()
     gen_point_env()
+    gen_dice_proc()
+    gen_dice()

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, 'libpromp_hip.so')
 
 BASELINE_ZERO, BASELINE_LINEAR_FEATURE, BASELINE_LINEAR_TIME = 0, 1, 2
-INNER_RATIO, INNER_LOGLIK = 0, 1
+INNER_RATIO, INNER_LOGLIK, INNER_DICE = 0, 1, 2
 OUTER_CLIP, OUTER_RATIO, OUTER_KL, OUTER_LOGLIK = 0, 1, 2, 3
 LOSS_RATIO, LOSS_CLIP, LOSS_LOGLIK, LOSS_KL = 0, 1, 2, 3
 KERNEL_FWD_BWD, KERNEL_HVP, KERNEL_GRAM, KERNEL_FWD = 0, 1, 2, 3
@@ -94,6 +94,7 @@ SIGNATURES = {
     'promp_meta_grad': (C.c_int, [_P, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
     'promp_adam_step': (C.c_int, [_P, C.c_float]),
     'promp_optimize': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int, _F, _F]),
+    'promp_set_dice_rewards': (C.c_int, [_P, C.c_int, _F]),
     'promp_optimize_begin': (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _F, C.c_int, C.c_int]),
     'promp_optimize_end': (C.c_int, [_P, _F, _F]),
     'promp_comm_unique_id': (C.c_int, [_P, C.c_size_t]),
@@ -295,6 +296,12 @@ class Context:
         adv = _f32(adv)
         assert adv.shape == (self.step_rows[step],)
         self._call('promp_set_advantages', int(step), _ptr(adv, C.c_float))
+
+    def set_dice_rewards(self, step, rw):
+        """promp_set_dice_rewards: per-row DiCE rewards (valid rows, pre-scaled); the device derives the gradient weights"""
+        rw = _f32(rw)
+        assert rw.shape == (self.step_rows[step],)
+        self._call('promp_set_dice_rewards', int(step), _ptr(rw, C.c_float))
 
     # ---- parameters ----
     def set_theta(self, theta):

@@ -59,6 +59,11 @@ struct StepData {
     int feat_dim = 0;
     float *obs = nullptr, *act = nullptr, *rew = nullptr, *old_mean = nullptr, *old_ls = nullptr;
     double* rew64 = nullptr;           // promp_set_rewards_f64 (allocated on first use); valid while has_rew64
+    // DiCE (promp_set_dice_rewards; allocated on first use): per-row adjusted rewards, row tangents of the R-operator pass,
+    // coupling weights, scan scratch
+    float *dice_rw = nullptr, *dice_c = nullptr, *dice_u = nullptr;
+    double* dice_tmp = nullptr;
+    bool has_dice = false;
     bool has_rew64 = false;
     float *ret32 = nullptr, *adv32 = nullptr;
     double *ret64 = nullptr, *adv64 = nullptr;
@@ -140,6 +145,8 @@ struct promp_ctx {
     bool learn_std = true;               // false: log_std is neither adapted (step size 0) nor trained (no Adam update)
     int fuse_min_tasks = 16;             // k_chain_hvp sums a task's partial rows in-launch from this many local tasks on
     int stats_slot = 0;                  // promp_optimize parks the first epoch's statistics in slot 1 (loss_before)
+    const float* pass_adv = nullptr;     // launch_pass: per-row weights instead of the step's advantages (DiCE coupling pass)
+    float* pass_row_tan = nullptr;       // launch_pass (R-operator pass): where the rows' log-likelihood tangents go
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
@@ -287,7 +294,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
                     c->d.obs_dim, c->d.hidden1, c->d.hidden2);
     PassArgs a;
     memset(&a, 0, sizeof a);
-    a.obs = S.obs; a.act = S.act; a.adv = S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
+    a.obs = S.obs; a.act = S.act; a.adv = c->pass_adv ? c->pass_adv : S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
+    a.row_tan = hvp ? c->pass_row_tan : nullptr;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
@@ -356,7 +364,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     return 0;
 }
 
-int loss_kind_inner(int inner_kind) { return inner_kind == PROMP_INNER_LOGLIK ? LOSS_LOGLIK : LOSS_RATIO; }
+// (the DiCE objective's gradient is the log-likelihood objective's with the suffix-sum weights of promp_set_dice_rewards)
+int loss_kind_inner(int inner_kind) { return (inner_kind == PROMP_INNER_LOGLIK || inner_kind == PROMP_INNER_DICE) ? LOSS_LOGLIK : LOSS_RATIO; }
 int loss_kind_outer(int outer_kind) {
     return outer_kind == PROMP_OUTER_RATIO ? LOSS_RATIO : outer_kind == PROMP_OUTER_KL ? LOSS_KL
            : outer_kind == PROMP_OUTER_LOGLIK ? LOSS_LOGLIK : LOSS_CLIP;
@@ -383,8 +392,28 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         for (int k = K - 1; k >= 0; --k) {
             const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
             const long long st = (k == 0) ? 0 : NP;
-            if (launch_pass(c, c->steps[k], true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, eta_host[k] / (float)K, false,
-                            RED_HVP, nullptr, 0, nullptr, c->scal_tmp)) return -2;
+            StepData& Sk = c->steps[k];
+            const bool dice = inner_kind == PROMP_INNER_DICE;
+            if (dice && !Sk.has_dice) return fail(-3, "step %d has no DiCE rewards: call promp_set_dice_rewards first", k);
+            c->pass_row_tan = dice ? Sk.dice_c : nullptr;
+            const int rc1 = launch_pass(c, Sk, true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, dice ? 0.f : eta_host[k] / (float)K, false,
+                                        RED_HVP, nullptr, 0, nullptr, c->scal_tmp);
+            c->pass_row_tan = nullptr;
+            if (rc1) return -2;
+            if (dice) {
+                // The magic box couples the time steps of a path: H v = H_loglik(w) v + grad_loglik(u(v)), u from the row tangents
+                // c_t = dlogpi_t . v of the pass above (meta_algos/dice_maml.py:245-258).  The pass ran on the direction -v, so its
+                // tangents and with them u carry the sign that makes the second piece ANOTHER "lam += g" reduction.
+                DiceScanArgs ds;
+                ds.path_row_offsets = Sk.path_row_offsets; ds.rw = Sk.dice_rw; ds.c = Sk.dice_c; ds.out = Sk.dice_u; ds.tmp = Sk.dice_tmp;
+                ds.mode = 1;
+                PROMP_LAUNCH(k_dice_scan, dim3(Sk.n_paths), 64, 0, c->stream, ds);
+                HIPCHECK(hipGetLastError());
+                c->pass_adv = Sk.dice_u;
+                const int rc2 = launch_pass(c, Sk, false, th, st, LOSS_LOGLIK, 0.f, k == 0, 0.f, false, RED_HVP, nullptr, 0, nullptr, c->scal_tmp);
+                c->pass_adv = nullptr;
+                if (rc2) return -2;
+            }
         }
     }
     FinalArgs f;
@@ -428,7 +457,7 @@ int upload_eta(promp_ctx* c, const float* eta) {
 }
 
 void free_step(StepData& S) {
-    void* ptrs[] = {S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
+    void* ptrs[] = {S.dice_rw, S.dice_c, S.dice_u, S.dice_tmp, S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
                     S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.chain_segs, S.chain_wg_offsets,
                     S.chain_slot_offsets, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
@@ -837,7 +866,7 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
             return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
     }
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
-    S.processed = false; S.has_adv = false; S.has_rew64 = false;
+    S.processed = false; S.has_adv = false; S.has_rew64 = false; S.has_dice = false;
     // every source below lives in `keep` (asynchronous mode: until the set is staged again)
     struct Keep {
         std::vector<int> pro, tpo, path_task, row_t, tro, wg_off, slot_chain, slot_pass, two[2];
@@ -1132,6 +1161,32 @@ int promp_set_advantages(promp_ctx* c, int step, const float* adv) {
     HIPCHECK(hipMemcpyAsync(S.adv32, adv, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     S.has_adv = true;
+    return 0;
+}
+
+int promp_set_dice_rewards(promp_ctx* c, int step, const float* rw) {
+    if (!c || !rw) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (c->wide) return fail(-1, "the DiCE objective is built on the register-chained kernels (hidden sizes from {32,64}, obs_dim <= 32)");
+    StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
+    if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
+    if (!S.dice_rw) {
+        const size_t R = c->d.max_rows;
+        int rc = dev_alloc(&S.dice_rw, R);
+        rc |= dev_alloc(&S.dice_c, R); rc |= dev_alloc(&S.dice_u, R); rc |= dev_alloc(&S.dice_tmp, R);
+        if (rc) return -2;
+    }
+    HIPCHECK(hipMemcpyAsync(S.dice_rw, rw, sizeof(float) * S.n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));      // (the source may be a temporary of the caller)
+    // the gradient weights w_t = sum_{t' >= t} rw_t' take the advantages' place in the log-likelihood objective
+    DiceScanArgs ds;
+    ds.path_row_offsets = S.path_row_offsets; ds.rw = S.dice_rw; ds.c = nullptr; ds.out = S.adv32; ds.tmp = nullptr; ds.mode = 0;
+    PROMP_LAUNCH(k_dice_scan, dim3(S.n_paths), 64, 0, c->stream, ds);
+    HIPCHECK(hipGetLastError());
+    S.has_adv = true;
+    S.has_dice = true;
     return 0;
 }
 

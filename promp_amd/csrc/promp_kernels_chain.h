@@ -90,6 +90,7 @@ struct PassArgs {
     float* lam;                     // [tasks][Theta]
     float* v;                       // [tasks][Theta]
     float* scal;                    // [tasks][2]
+    float* row_tan;                 // k_chain_hvp, optional [rows]: R'{log pi} of every row = dlogpi_row . (-v)  (DiCE coupling)
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
 };
 
@@ -680,6 +681,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 dlp += shfl_xor_f32(dlp, 16);  dlp += shfl_xor_f32(dlp, 32);
                 Rlp += shfl_xor_f32(Rlp, 16);  Rlp += shfl_xor_f32(Rlp, 32);
                 kl += shfl_xor_f32(kl, 16);    kl += shfl_xor_f32(kl, 32);
+                if (a.row_tan != nullptr && rvalid && kk == 0) a.row_tan[n] = Rlp;
                 float c = 0.f, Rc = 0.f, km = 0.f;
                 if (rvalid) {
                     km = 1.f;

@@ -84,6 +84,57 @@ __global__ void __launch_bounds__(64) k_returns(SampleArgs a) {
     }
 }
 
+// DiCE weights (meta_algos/dice_maml.py:39-45, 245-258: the magic box couples the time steps of a path).
+//   mode 0:  out[t] = sum_{t' >= t} rw[t']                                   (gradient weights w)
+//   mode 1:  out[t] = sum_{t' >= t} rw[t'] C[t'],  C[t'] = sum_{t'' <= t'} c[t'']   (Hessian-vector coupling weights u)
+// One wave per path, float64 suffix scans in 64-row chunks from the end (as k_returns with discount 1); the prefix sum
+// is total - suffix + own.  grid = paths, block = 64.
+struct DiceScanArgs {
+    const int* path_row_offsets;
+    const float* rw;       // [rows] adjusted reward * rows / (paths * max_path_length) of every valid row
+    const float* c;        // [rows] row tangents (mode 1)
+    float* out;            // [rows]
+    double* tmp;           // [rows] scratch (mode 1)
+    int mode;
+};
+PROMP_DEV double dice_suffix_chunk(double x, int lane) {
+    double y = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double up = shfl_down_f64(y, d);
+        if (lane + d < 64) y += up;
+    }
+    return y;
+}
+__global__ void __launch_bounds__(64) k_dice_scan(DiceScanArgs a) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int row0 = a.path_row_offsets[p], T = a.path_row_offsets[p + 1] - row0;
+    double total = 0.0;
+    if (a.mode == 1) {
+        double carry = 0.0;
+        for (int end = T; end > 0; end -= 64) {
+            const int t = end - 64 + lane;
+            const double x = (t >= 0) ? (double)a.c[row0 + t] : 0.0;
+            const double y = dice_suffix_chunk(x, lane) + carry;
+            if (t >= 0) a.tmp[row0 + t] = y;
+            carry = shfl_idx_f64(y, 0);
+        }
+        total = carry;
+    }
+    double carry = 0.0;
+    for (int end = T; end > 0; end -= 64) {
+        const int t = end - 64 + lane;
+        double x = 0.0;
+        if (t >= 0) {
+            x = (double)a.rw[row0 + t];
+            if (a.mode == 1) x *= total - a.tmp[row0 + t] + (double)a.c[row0 + t];     // C[t]
+        }
+        const double y = dice_suffix_chunk(x, lane) + carry;
+        if (t >= 0) a.out[row0 + t] = (float)y;
+        carry = shfl_idx_f64(y, 0);
+    }
+}
+
 // k_gram: partial Gram of [Phi R] over a work item's rows, wave-private like the policy passes: every wave builds
 // the features of its own 16-row chunks in its own LDS tile and feeds them to v_mfma_f64_16x16x4_f64 (the same
 // register is A and B operand of a block pair); no workgroup barrier in the chunk loop.  The waves' blocks are added

@@ -43,6 +43,16 @@ class MAMLAlgo(MetaAlgo):
             self.session.upload_samples(slot, samples)
         return slot
 
+    def _place_steps(self, all_samples_data):
+        """sampling step k into slot k for every k.  The context is sized for the largest step that has to be uploaded BEFORE
+        the first upload: a context that grows between two uploads would drop the slabs uploaded so far."""
+        missing = [sd for k, sd in enumerate(all_samples_data) if self.session.resident_slot(sd) != k]
+        if missing:
+            self.session.ensure(max(sum(len(d['advantages']) for d in sd) for sd in missing), self.meta_batch_size)
+        for k, sd in enumerate(all_samples_data):
+            if self._slot_of(sd, k) != k:             # resident, but in another slot (an extra process_samples call in between)
+                self.session.upload_samples(k, sd)
+
     def _adapt(self, samples):
         """MAML inner step for each task; stores the adapted parameters in the policy (base.py:217-242)"""
         assert len(samples) == self.meta_batch_size

@@ -35,9 +35,7 @@ class ProMP(MAMLAlgo):
     def optimize_policy(self, all_samples_data, log=True):
         """MAML outer step: E Adam epochs on the meta-objective, then stats (pro_mp.py:165-199)"""
         assert len(all_samples_data) == self.num_inner_grad_steps + 1
-        for k, sd in enumerate(all_samples_data):
-            if self._slot_of(sd, k) != k:             # resident, but in another slot (an extra process_samples call in between):
-                self.session.upload_samples(k, sd)    # sampling step k must sit in slot k
+        self._place_steps(all_samples_data)           # sampling step k must sit in slot k
         if log: logger.log('Optimizing')
         res = self.session.ctx.optimize(self.num_ppo_steps, self.learning_rate, self.clip_eps, self.inner_kl_coeff,
                                         self.inner_kind, self.outer_kind)

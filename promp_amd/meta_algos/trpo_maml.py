@@ -92,8 +92,7 @@ class TRPOMAML(MAMLAlgo):
     def optimize_policy(self, all_samples_data, log=True):
         """trpo_maml.py:161-191"""
         assert len(all_samples_data) == self.num_inner_grad_steps + 1
-        slots = [self._slot_of(sd, k) for k, sd in enumerate(all_samples_data)]
-        assert slots == list(range(self.num_inner_grad_steps + 1))
+        self._place_steps(all_samples_data)
         if self.exploration:
             last = all_samples_data[self.num_inner_grad_steps]
             self._explore_coeffs = np.array([np.mean(np.asarray(d['adj_avg_rewards'], dtype=np.float32)) for d in last], np.float64)

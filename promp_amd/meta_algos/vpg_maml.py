@@ -43,9 +43,7 @@ class VPGMAML(MAMLAlgo):
     def optimize_policy(self, all_samples_data, log=True):
         K = self.num_inner_grad_steps
         assert len(all_samples_data) == K + 1
-        for k, sd in enumerate(all_samples_data):
-            if self._slot_of(sd, k) != k:
-                self.session.upload_samples(k, sd)
+        self._place_steps(all_samples_data)
         ctx, sess = self.session.ctx, self.session
         eta = np.zeros(K, np.float32)
         if log: logger.log('Optimizing')

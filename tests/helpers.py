@@ -93,3 +93,40 @@ def upload_slabs(ctx, all_paths, all_slabs, compact_log_std=False):
         ctx.upload_step(k, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'], fl['act'],
                         fl['old_mean'], ls)
         ctx.set_advantages(k, np.concatenate([s['advantages'] for s in all_slabs[k]]))
+
+
+def dice_paths_from_golden(g):
+    """paths_meta_batch (OrderedDict task -> list of path dicts) from a tests/golden/dice_proc_*.npz fixture"""
+    from collections import OrderedDict
+    lens = g['path_lengths']
+    out, r = OrderedDict(), 0
+    for i in range(lens.shape[0]):
+        plist = []
+        for n in lens[i]:
+            n = int(n)
+            plist.append(dict(observations=g['observations'][r:r + n], actions=g['actions'][r:r + n], rewards=g['rewards'][r:r + n],
+                              env_infos={}, agent_infos=dict(mean=g['agent_mean'][r:r + n], log_std=g['agent_log_std'][r:r + n])))
+            r += n
+        out[i] = plist
+    return out
+
+
+def dice_case_from_golden(g):
+    """(config dict, theta float64, all_slabs [K+1][M]) from a tests/golden/dice_autograd_*.npz fixture; the slabs are the flat
+    valid-row form of oracle/dice.py:to_slab, the padded samples are kept under 'padded'"""
+    import json
+    from oracle import dice
+    c = json.loads(str(g['meta']))
+    c['hidden'] = tuple(c['hidden'])
+    all_slabs = []
+    for k in range(c['K'] + 1):
+        step = []
+        for i in range(c['M']):
+            sd = dict(mask=g['step%d_mask' % k][i], observations=g['step%d_observations' % k][i], actions=g['step%d_actions' % k][i],
+                      adjusted_rewards=g['step%d_adjusted_rewards' % k][i],
+                      agent_infos=dict(mean=g['step%d_mean' % k][i], log_std=g['step%d_log_std' % k][i]))
+            slab = dice.to_slab(sd)
+            slab['padded'] = sd
+            step.append(slab)
+        all_slabs.append(step)
+    return c, g['theta'].astype(np.float64), all_slabs

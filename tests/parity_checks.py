@@ -9,6 +9,8 @@ Stated tolerances (float32 device arithmetic vs float64 oracle; BASELINE.md sect
   loss / KL    : rtol 1e-4
   gradients    : 1e-4 of the max-norm (meta-gradient: 1e-3 in BASELINE.md; we hold 1e-4)
 """
+import os
+
 import numpy as np
 
 from oracle import policy as op
@@ -517,3 +519,48 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
     finally:
         _lib.set_library_for_testing(None)
         session._current = None
+
+
+def upload_dice_slabs(ctx, all_slabs):
+    """steps 0..K of a DiCE case (oracle/dice.py:to_slab form) -> device slabs with the DiCE rewards"""
+    for k, step in enumerate(all_slabs):
+        n_paths = [len(sl['path_row_offsets']) - 1 for sl in step]
+        tpo = np.concatenate([[0], np.cumsum(n_paths)]).astype(np.int32)
+        lens = np.concatenate([np.diff(sl['path_row_offsets']) for sl in step])
+        pro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        cat = lambda f: np.concatenate([np.asarray(f(sl), dtype=np.float32) for sl in step])
+        ctx.upload_step(k, tpo, pro, cat(lambda sl: sl['observations']), np.zeros(pro[-1], np.float32), cat(lambda sl: sl['actions']),
+                        cat(lambda sl: sl['agent_infos']['mean']), cat(lambda sl: sl['agent_infos']['log_std']))
+        ctx.set_dice_rewards(k, cat(lambda sl: sl['dice_rw']))
+
+
+def check_dice(lib, name, tol=1e-4):
+    """DICE-MAML on the device (PROMP_INNER_DICE / PROMP_OUTER_LOGLIK) against the oracle and, through the committed fixture,
+    against torch.autograd on the reference's forward graph: gradient weights, inner step, exact meta-gradient."""
+    from oracle import dice
+    g = np.load(os.path.join(helpers.GOLDEN, 'dice_autograd_%s.npz' % name))
+    c, t64, all_slabs = helpers.dice_case_from_golden(g)
+    spec = op.PolicySpec(c['O'], c['A'], c['hidden'])
+    M, K = c['M'], c['K']
+    R = max(sum(len(sl['dice_rw']) for sl in step) for step in all_slabs)
+    NPaths = max(sum(len(sl['path_row_offsets']) - 1 for sl in step) for step in all_slabs)
+    ctx = _lib.Context(M, c['O'], c['A'], c['hidden'], K, max_rows=R, max_paths=NPaths, lib=lib)
+    upload_dice_slabs(ctx, all_slabs)
+    theta = t64.astype(np.float32)
+    alpha = np.full(spec.n_params, c['alpha'], np.float32)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(alpha)
+    # inner step (log-likelihood gradient with the suffix sums the device derives from the per-row rewards)
+    ctx.switch_to_pre_update()
+    ctx.inner_adapt(0, _lib.INNER_DICE)
+    ad = dice.adapt(spec, [t64] * M, all_slabs[0], alpha.astype(np.float64))
+    assert rel_max(ctx.get_task_thetas() - theta, np.stack(ad) - t64) < tol
+    # exact meta-gradient through the adaptation, incl. the path-coupled second-order term
+    grad, _ = ctx.meta_grad(0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
+    r = dice.meta_objective_and_grad(spec, t64, all_slabs, alpha.astype(np.float64))
+    assert rel_max(grad, r['grad']) < tol
+    assert rel_max(grad, g['grad']) < tol                      # torch.autograd on the padded magic-box graph
+    # without the coupling term the gradient is measurably different (the check above is not vacuous)
+    grad_ll, _ = ctx.meta_grad(0.0, np.zeros(K, np.float32), _lib.INNER_LOGLIK, _lib.OUTER_LOGLIK)
+    assert rel_max(grad_ll, r['grad']) > 10 * tol
+    ctx.close()

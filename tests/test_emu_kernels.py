@@ -117,6 +117,11 @@ def test_meta_k2_h32(lib, two_cus):
     pc.check_meta(lib, 13, M=2, P=2, T=33, O=5, A=3, hidden=(32, 32), K=2, epochs=2, compact_log_std=True)
 
 
+@pytest.mark.parametrize('name', ['k1_ragged', 'k2_small'])
+def test_dice_maml_gradient(lib, two_cus, name):
+    pc.check_dice(lib, name)
+
+
 def test_loss_grad_h32_wide_obs(lib):
     # O=31, A=8, H=32: the compact (non hidden_1) part of the gradient is larger than the hidden_1 kernel
     pc.check_loss_grad(lib, 14, M=1, P=1, T=40, O=31, A=8, hidden=(32, 32))

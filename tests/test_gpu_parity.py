@@ -310,3 +310,10 @@ def test_kl_objective_and_trpo_maml_step(lib):
     st, ref = pc.check_trpo(lib, 61, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood')
     st2, _ = pc.check_trpo(lib, 62, M=3, P=4, T=60, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio')
     pc.check_trpo(lib, 63, M=4, P=4, T=80, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood', exploration=True)   # E-MAML
+
+
+@pytest.mark.parametrize('name', ['k1_small', 'k1_ragged', 'k2_small', 'k1_hc', 'k1_long'])
+def test_dice_maml_gradient_vs_oracle_and_autograd(lib, name):
+    """PROMP_INNER_DICE: exact meta-gradient of the DiCE objective (path-coupled second-order term) against the float64 oracle
+    and torch.autograd on the reference's padded magic-box graph (tests/golden/dice_autograd_*.npz)"""
+    pc.check_dice(lib, name)

@@ -92,3 +92,13 @@ def test_trainer_snapshot_round_trip_on_device(tmp_path):
 
 def test_baseline_fit_predict_on_device():
     scen.run_baseline_fit_predict_scenario()
+
+
+@pytest.mark.parametrize('name', ['default', 'ragged', 'raw', 'positive'])
+def test_dice_sample_processor_vs_reference_outputs(name):
+    scen.run_dice_processor_scenario(name)
+
+
+@pytest.mark.parametrize('name', ['k1_small', 'k1_ragged', 'k2_small', 'k1_hc', 'k1_long'])
+def test_dice_maml_plugin(name):
+    scen.run_dice_maml_scenario(name)

@@ -310,6 +310,73 @@ def run_vpg_scenario(M=3, P=3, T=30, O=5, A=3, hidden=(32, 32), inner_type='log_
     assert np.mean(np.sign(d_dev) == np.sign(d_ref)) > 0.98 and np.max(np.abs(d_dev)) < 1.01e-3
 
 
+def run_dice_processor_scenario(name='ragged'):
+    """DiceMetaSampleProcessor against the reference's own outputs (tests/golden/dice_proc_*.npz)"""
+    import json
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline, LinearTimeBaseline
+    from promp_amd.baselines.zero_baseline import ZeroBaseline
+    from promp_amd.samplers.dice_sample_processor import DiceMetaSampleProcessor
+    g = np.load(os.path.join(helpers.GOLDEN, 'dice_proc_%s.npz' % name))
+    meta = json.loads(str(g['meta']))
+    paths = helpers.dice_paths_from_golden(g)
+    base = dict(zero=ZeroBaseline, linear_feature=LinearFeatureBaseline, linear_time=LinearTimeBaseline)[meta['baseline']]()
+    proc = DiceMetaSampleProcessor(base, max_path_length=meta['max_path_length'], **meta['kwargs'])
+    with pytest.raises(AssertionError):
+        proc.process_samples(list(paths.values()))
+    out = proc.process_samples(paths, log=False)
+    assert len(out) == len(paths)
+    assert set(out[0].keys()) >= set(meta['keys'])                 # the reference's keys (mask, adjusted_rewards, ...)
+    for i, sd in enumerate(out):
+        np.testing.assert_array_equal(sd['mask'], g['mask'][i])
+        np.testing.assert_array_equal(sd['rewards'], g['padded_rewards'][i])
+        np.testing.assert_array_equal(sd['observations'], g['padded_observations'][i])
+        np.testing.assert_allclose(sd['adjusted_rewards'], g['adjusted_rewards'][i], rtol=1e-5, atol=1e-6)
+    return proc, out
+
+
+def run_dice_maml_scenario(name='k1_ragged'):
+    """DICEMAML._adapt + optimize_policy (one Adam step on the exact DiCE meta-gradient) against the oracle"""
+    from oracle import dice, policy as op, promp as pm
+    from promp_amd.meta_algos.dice_maml import DICEMAML
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.utils import logger
+    logger.configure(quiet=True)
+    g = np.load(os.path.join(helpers.GOLDEN, 'dice_autograd_%s.npz' % name))
+    c, t64, all_slabs = helpers.dice_case_from_golden(g)
+    spec = op.PolicySpec(c['O'], c['A'], c['hidden'])
+    theta = t64.astype(np.float32)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=c['O'], action_dim=c['A'], meta_batch_size=c['M'], hidden_sizes=c['hidden'])
+    policy.set_params(spec.to_ordered_dict(theta))
+    algo = DICEMAML(c['Tmax'], policy=policy, learning_rate=1e-3, inner_lr=c['alpha'], meta_batch_size=c['M'],
+                    num_inner_grad_steps=c['K'])
+    samples = [[sl['padded'] for sl in step] for step in all_slabs]
+    alpha = np.full(spec.n_params, c['alpha'])
+    # inner step through the plugin API
+    policy.switch_to_pre_update()
+    algo._adapt(samples[0])
+    ad = dice.adapt(spec, [t64] * c['M'], all_slabs[0], alpha)
+    got = np.stack([spec.from_ordered_dict(d) for d in policy.policies_params_vals])
+    assert np.max(np.abs((got - theta) - (np.stack(ad) - t64))) < 1e-4 * np.max(np.abs(np.stack(ad) - t64))
+    # outer step
+    algo.optimize_policy(samples, log=False)
+    r = dice.meta_objective_and_grad(spec, t64, all_slabs, alpha)
+    th_ref = pm.adam_step(t64, r['grad'], pm.AdamState(spec.n_params), 1e-3)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], r['loss'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], float(g['loss']), rtol=1e-6, atol=1e-9)
+    got = spec.from_ordered_dict(policy.get_param_values())
+    d_dev, d_ref = got - theta, th_ref - t64
+    assert np.mean(np.sign(d_dev) == np.sign(d_ref)) > 0.98 and np.max(np.abs(d_dev)) < 1.01e-3
+
+
+def test_dice_sample_processor(emu):
+    run_dice_processor_scenario('ragged')
+    run_dice_processor_scenario('raw')
+
+
+def test_dice_maml(emu):
+    run_dice_maml_scenario('k1_ragged')
+
+
 def test_vpg_maml(emu):
     run_vpg_scenario(inner_type='log_likelihood')
     run_vpg_scenario(M=2, P=2, T=20, inner_type='likelihood_ratio', exploration=True)
