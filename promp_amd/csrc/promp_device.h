@@ -76,6 +76,12 @@ PROMP_DEV void fence_release_agent() {
 PROMP_DEV void fence_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 PROMP_DEV int atomic_add_agent(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PROMP_DEV void atomic_store_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// hand-off to the HOST through page-locked memory: everything this thread stored before is visible to a host thread that
+// reads the flag with acquire semantics and finds the new value
+PROMP_DEV void release_store_system(unsigned* p, unsigned v) {
+    __threadfence_system();
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // keeps the compiler from interleaving two independent GEMM groups (which would add their live ranges)
 PROMP_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // A zero the optimiser cannot see through.  Added to the base pointers inside a long unrolled loop body it keeps the

@@ -125,9 +125,11 @@ struct promp_ctx {
     float *theta = nullptr, *step_sizes = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     long long adam_t = 0;
     float *theta_tasks = nullptr, *chain = nullptr, *lam = nullptr, *vbuf = nullptr;
+    bool tasks_shared = false;           // switch_to_pre_update: every task's parameters ARE theta; theta_tasks is written when somebody reads it
     float* wbuf = nullptr;               // promp_constraint_hvp: [tasks][Theta], allocated on first use
     float *partials = nullptr, *scal_inner = nullptr, *scal_outer = nullptr, *scal_tmp = nullptr;
-    float *red = nullptr, *grad_mean = nullptr, *stats = nullptr, *eta_dev = nullptr;
+    float *red = nullptr, *grad_mean = nullptr, *stats = nullptr;
+    float eta_last[PROMP_ETA_MAX] = {};
     double *gram_partials = nullptr, *red64 = nullptr;
     void* rollout_buf = nullptr;         // goals, start states and noise of a device rollout
     size_t rollout_capacity = 0;
@@ -151,7 +153,9 @@ struct promp_ctx {
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
     float* stats_host = nullptr;         // pinned: promp_optimize_begin parks both statistics slots here (async copy)
-    hipEvent_t stats_ev = nullptr;       // ... and records this event behind the copy
+    unsigned* stats_seq_host = nullptr;  // pinned: sequence number the last launch of an optimisation writes behind the statistics
+    unsigned stats_seq = 0;              // the number the pending optimisation will write
+    bool publish_next = false;           // enqueue_meta: this launch is the one that publishes
     bool opt_pending = false;
     int opt_epochs = 0;
     float* fwd_buf = nullptr;            // staging for promp_policy_forward
@@ -226,7 +230,7 @@ int check_dims(const promp_dims* d) {
     if (!policy_shape_chain(d) && !policy_shape_coop(d) && !((d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64)))
         return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates every combination of {32, 64} (obs_dim <= 32) "
                     "and (64,64) / (128,128) (obs_dim <= 128)", d->hidden1, d->hidden2);
-    if (d->num_inner_steps < 1) return fail(-1, "num_inner_steps must be >= 1");
+    if (d->num_inner_steps < 1 || d->num_inner_steps > PROMP_ETA_MAX) return fail(-1, "num_inner_steps must be in [1, %d]", PROMP_ETA_MAX);
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
 }
@@ -376,16 +380,18 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
                  bool do_adam, float lr) {
     const int K = c->d.num_inner_steps, M = c->d.n_tasks, NP = c->NP;
     const size_t MNP = (size_t)M * NP;
-    for (int k = 0; k <= K; ++k) {
+    for (int k = 0; k <= K; ++k)
         if (c->steps[k].n_rows == 0) return fail(-3, "step %d has no data", k);
-        if (join_side(c, c->steps[k])) return -2;
-    }
+    // a step's second-stream sample processing is waited for right in front of the first pass that reads its advantages:
+    // the passes on earlier steps run while it finishes
     for (int k = 0; k < K; ++k) {
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
+        if (join_side(c, c->steps[k])) return -2;
         if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f, false, RED_STEP, th, st,
                         c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
     }
+    if (join_side(c, c->steps[K])) return -2;
     if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f, !want_grad,
                     want_grad ? RED_OUTER : RED_SCAL, nullptr, 0, nullptr, c->scal_outer)) return -2;
     if (want_grad) {
@@ -433,7 +439,9 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     }
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
-    ad.stats = c->stats + (size_t)c->stats_slot * (K + 2); ad.eta = c->eta_dev; ad.NP = NP; ad.K = K;
+    ad.stats = c->stats + (size_t)c->stats_slot * (K + 2); ad.NP = NP; ad.K = K;
+    for (int k = 0; k < PROMP_ETA_MAX; ++k) ad.eta[k] = k < K ? eta_host[k] : 0.f;
+    ad.host_stats = c->publish_next ? c->stats_host : nullptr; ad.host_seq = c->stats_seq_host; ad.seq = c->stats_seq;
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
     ad.do_update = do_adam ? 1 : 0;
     ad.n_trainable = c->learn_std ? NP : NP - c->d.act_dim;
@@ -451,8 +459,8 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
 }
 
 int upload_eta(promp_ctx* c, const float* eta) {
-    // (a pageable source is staged before hipMemcpyAsync returns: no need to drain the stream, the host keeps running ahead)
-    HIPCHECK(hipMemcpyAsync(c->eta_dev, eta, sizeof(float) * c->d.num_inner_steps, hipMemcpyHostToDevice, c->stream));
+    // the coefficients travel by value in the launch arguments of the final reduction; promp_adam_step reuses the last set
+    for (int k = 0; k < c->d.num_inner_steps; ++k) c->eta_last[k] = eta[k];
     return 0;
 }
 
@@ -523,7 +531,12 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     c->clock_mhz = prop.clockRate / 1000;
     snprintf(c->dev_name, sizeof c->dev_name, "%s", prop.name[0] ? prop.name : PROMP_ARCH_NAME(prop));
     HIPCHECK(hipStreamCreate(&c->stream));
-    HIPCHECK(hipStreamCreate(&c->side));
+    {   // sample processing of steps >= 1 is a string of small latency-bound kernels under a chip-filling pass: with the
+        // higher priority their workgroups are placed first, the string finishes before the main stream needs its result
+        int lo = 0, hi = 0;
+        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHECK(hipStreamCreateWithPriority(&c->side, hipStreamDefault, hi));
+    }
     const int K = dims->num_inner_steps, M = dims->n_tasks;
     c->NP = param_count(dims);
     c->Dmax = 2 * dims->obs_dim + 4;
@@ -597,7 +610,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->scal_inner, (size_t)K * M * 2); rc |= dev_alloc(&c->scal_outer, (size_t)M * 2);
     rc |= dev_alloc(&c->scal_tmp, (size_t)M * 2);
     rc |= dev_alloc(&c->red, NP + K + 2); rc |= dev_alloc(&c->grad_mean, NP);
-    rc |= dev_alloc(&c->stats, (size_t)2 * (K + 2)); rc |= dev_alloc(&c->eta_dev, (size_t)K);
+    rc |= dev_alloc(&c->stats, (size_t)2 * (K + 2));
     rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
     rc |= dev_alloc(&c->gram_partials_side, (size_t)c->max_work * c->gram_stride);
     if (nblk_max > 5 || dims->obs_dim > 32) {
@@ -608,7 +621,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
     if (hipHostMalloc((void**)&c->stats_host, sizeof(float) * 2 * (K + 2), hipHostMallocDefault) != hipSuccess) rc |= 1;
-    if (hipEventCreateWithFlags(&c->stats_ev, hipEventDisableTiming) != hipSuccess) rc |= 1;
+    if (hipHostMalloc((void**)&c->stats_seq_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) rc |= 1;
+    else *c->stats_seq_host = 0;
     c->steps.resize(K + 1);
     for (int s = 0; s <= K && !rc; ++s) rc |= alloc_step(c, c->steps[s]);
     if (rc) { promp_ctx_destroy(c); return -2; }
@@ -633,12 +647,12 @@ void promp_ctx_destroy(promp_ctx* c) {
             if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
         }
     void* ptrs[] = {c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
-                    c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats, c->eta_dev,
+                    c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
-    if (c->stats_ev) (void)hipEventDestroy(c->stats_ev);
+    if (c->stats_seq_host) (void)hipHostFree(c->stats_seq_host);
     for (auto& s : c->prof_slots)
         for (auto ev : s.ev) (void)hipEventDestroy(ev);
     if (c->copy) (void)hipStreamDestroy(c->copy);
@@ -1236,8 +1250,17 @@ int promp_set_learn_std(promp_ctx* c, int on) {
     c->learn_std = on != 0;
     return mask_log_std_step_sizes(c);
 }
-int promp_set_task_thetas(promp_ctx* c, const float* t) { return c ? copy_in(c, c->theta_tasks, t, (size_t)c->d.n_tasks * c->NP) : fail(-1, "ctx is NULL"); }
-int promp_get_task_thetas(promp_ctx* c, float* t) { return c ? copy_out(c, t, c->theta_tasks, (size_t)c->d.n_tasks * c->NP) : fail(-1, "ctx is NULL"); }
+static int tasks_materialize(promp_ctx* c);
+int promp_set_task_thetas(promp_ctx* c, const float* t) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->tasks_shared = false;
+    return copy_in(c, c->theta_tasks, t, (size_t)c->d.n_tasks * c->NP);
+}
+int promp_get_task_thetas(promp_ctx* c, float* t) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (tasks_materialize(c)) return -2;
+    return copy_out(c, t, c->theta_tasks, (size_t)c->d.n_tasks * c->NP);
+}
 
 int promp_set_adam_state(promp_ctx* c, const float* m, const float* v, int64_t t) {
     if (!c) return fail(-1, "ctx is NULL");
@@ -1253,10 +1276,19 @@ int promp_get_adam_state(promp_ctx* c, float* m, float* v, int64_t* t) {
     return 0;
 }
 
+// MetaPolicy.switch_to_pre_update (policies/base.py:173-179): every task's parameters are the meta-parameters again.  Nothing is
+// launched here: the inner step reads theta with a task stride of zero, and the per-task copies are only written
+// (tasks_materialize) for the entry points that hand them out or index them per task.
 int promp_switch_to_pre_update(promp_ctx* c) {
     if (!c) return fail(-1, "ctx is NULL");
+    c->tasks_shared = true;
+    return 0;
+}
+static int tasks_materialize(promp_ctx* c) {
+    if (!c->tasks_shared) return 0;
     PROMP_LAUNCH(k_replicate, dim3((c->NP + 255) / 256), 256, 0, c->stream, c->theta_tasks, (const float*)c->theta, c->NP, c->d.n_tasks);
     HIPCHECK(hipGetLastError());
+    c->tasks_shared = false;
     return 0;
 }
 
@@ -1267,8 +1299,11 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     StepScope scope_(c, S);
     if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
-    return launch_pass(c, S, false, c->theta_tasks, c->NP, loss_kind_inner(inner_kind), 0.f, 0, 0.f, false, RED_STEP, c->theta_tasks,
-                       c->NP, c->theta_tasks, c->scal_tmp);
+    // pre-update mode: all tasks start from theta itself (stride 0); the step writes every task's row of theta_tasks
+    const float* cur = c->tasks_shared ? c->theta : c->theta_tasks;
+    const long long st = c->tasks_shared ? 0 : c->NP;
+    c->tasks_shared = false;
+    return launch_pass(c, S, false, cur, st, loss_kind_inner(inner_kind), 0.f, 0, 0.f, false, RED_STEP, cur, st, c->theta_tasks, c->scal_tmp);
 }
 
 int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_out) {
@@ -1286,6 +1321,7 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     float* d_out = c->fwd_buf + n_obs;
     HIPCHECK(hipMemcpyAsync(d_obs, obs, sizeof(float) * n_obs, hipMemcpyHostToDevice, c->stream));
     ForwardArgs f;
+    if (tasks_materialize(c)) return -2;
     f.obs = d_obs; f.theta_tasks = c->theta_tasks; f.mean = d_out;
     f.B = batch; f.O = O; f.A = A; f.H1 = c->d.hidden1; f.H2 = c->d.hidden2;
     PROMP_LAUNCH(k_policy_forward, dim3(M), 256, 0, c->stream, f);
@@ -1346,6 +1382,7 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     HIPCHECK(hipMemcpyAsync(d_start, start, sizeof(double) * M * B * 2, hipMemcpyHostToDevice, st));
     if (noise) HIPCHECK(hipMemcpyAsync(d_noise, noise, sizeof(float) * rows * 2, hipMemcpyHostToDevice, st));
     PointRolloutArgs a;
+    if (tasks_materialize(c)) return -2;
     a.theta_tasks = c->theta_tasks; a.NP = c->NP; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2;
     a.B = B; a.T = T; a.goals = d_goals; a.start = d_start; a.noise = noise ? d_noise : nullptr;
     a.seed = o->seed; a.stream = (unsigned)step;
@@ -1379,6 +1416,7 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     hipStream_t st = c->stream;
     HIPCHECK(hipMemcpyAsync(d_obs, obs, sizeof(float) * n_obs, hipMemcpyHostToDevice, st));
     PolicyStepArgs a;
+    if (tasks_materialize(c)) return -2;
     a.obs_in = d_obs; a.theta_tasks = c->theta_tasks;
     a.obs = S.obs; a.act = S.act; a.mean = S.old_mean; a.old_ls = S.old_ls; a.actions_out = d_act;
     a.B = B; a.T = T; a.t = t; a.O = O; a.A = A; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2; a.NP = c->NP;
@@ -1522,7 +1560,9 @@ int promp_adam_step(promp_ctx* c, float lr) {
     // red still holds the (all-reduced) sums of the last promp_meta_grad
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
-    ad.stats = c->stats; ad.eta = c->eta_dev; ad.NP = c->NP; ad.K = c->d.num_inner_steps;
+    ad.stats = c->stats; ad.NP = c->NP; ad.K = c->d.num_inner_steps;
+    for (int k = 0; k < PROMP_ETA_MAX; ++k) ad.eta[k] = k < ad.K ? c->eta_last[k] : 0.f;
+    ad.host_stats = nullptr; ad.host_seq = nullptr; ad.seq = 0;
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
     ad.do_update = 1;
     ad.n_trainable = c->learn_std ? c->NP : c->NP - c->d.act_dim;
@@ -1548,11 +1588,15 @@ int promp_optimize_begin(promp_ctx* c, int num_epochs, float lr, float clip_eps,
         c->stats_slot = 0;
         if (rc) return -2;
     }
-    if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, false, false, 0.f)) return -2;   // compute_stats
-    // both statistics slots leave for page-locked host memory behind the last launch; nothing waits here, so the host can
-    // enqueue the next batch's sample processing while this optimisation still runs
-    HIPCHECK(hipMemcpyAsync(c->stats_host, c->stats, sizeof(float) * 2 * (K + 2), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipEventRecord(c->stats_ev, c->stream));
+    // compute_stats.  Its final launch stores both statistics slots into page-locked host memory and then a sequence number
+    // (system-scope release): no copy operation and no event on the queue, and nothing waits here -- the host can enqueue
+    // the next batch's sample processing while this optimisation still runs
+    c->stats_seq += 1;
+    c->publish_next = true;
+    const int rc_stats = enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, false, false, 0.f);
+    c->publish_next = false;
+    if (rc_stats) return -2;
+    (void)K;
     c->opt_pending = true;
     c->opt_epochs = num_epochs;
     return 0;
@@ -1562,7 +1606,18 @@ int promp_optimize_end(promp_ctx* c, float* loss_before, float* stats_after) {
     if (!c) return fail(-1, "ctx is NULL");
     if (!c->opt_pending) return fail(-1, "promp_optimize_end without promp_optimize_begin");
     c->opt_pending = false;
-    HIPCHECK(hipEventSynchronize(c->stats_ev));
+    // poll the sequence number (the stream is queried now and then: a failed launch must not turn into an endless wait)
+    for (unsigned long long spins = 0;; ++spins) {
+        if (__atomic_load_n(c->stats_seq_host, __ATOMIC_ACQUIRE) == c->stats_seq) break;
+        if ((spins & 0xfff) == 0xfff) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(c->stats_seq_host, __ATOMIC_ACQUIRE) == c->stats_seq) break;
+                return fail(-2, "promp_optimize_end: the stream drained without publishing the statistics");
+            }
+            if (q != hipErrorNotReady) return fail(-2, "promp_optimize_end: %s", hipGetErrorString(q));
+        }
+    }
     const int K = c->d.num_inner_steps;
     if (stats_after) memcpy(stats_after, c->stats_host, sizeof(float) * (K + 2));
     if (loss_before) *loss_before = c->opt_epochs > 0 ? c->stats_host[K + 2] : c->stats_host[0];
@@ -1584,6 +1639,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     StepScope scope_(c, S);
     if (scope_.rc) return -2;
     const int M = c->d.n_tasks;
+    if (tasks_materialize(c)) return -2;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
     std::vector<float> sc((size_t)M * 2);
@@ -1604,6 +1660,7 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     const int M = c->d.n_tasks, NP = c->NP;
     if (copy_in(c, c->vbuf, v, (size_t)M * NP)) return -2;
     HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
+    if (tasks_materialize(c)) return -2;
     if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
     return copy_out(c, out, c->lam, (size_t)M * NP);
 }
@@ -1697,6 +1754,7 @@ int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long
     if (scope_.rc) return -2;
     HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * (256 + 4 * 1024), c->stream));
     c->dbg_enabled = true;
+    if (tasks_materialize(c)) return -2;
     const int rc = launch_pass(c, S, hvp != 0, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
     c->dbg_enabled = false;
     if (rc) return rc;

@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256) k_reduce_final(FinalArgs a) {
 
 // Mean over the global meta-batch + Adam.  red holds SUMS over all tasks (after the all-reduce).
 // stats[0] = loss = mean_i J_i + mean_k(eta_k * mean_i KL^k_i); stats[1+k] = inner_kl[k]; stats[1+K] = outer_kl
+#define PROMP_ETA_MAX 8        // most inner gradient steps a context is created for
 struct AdamArgs {
     float* theta;
     float* m;
@@ -109,13 +110,24 @@ struct AdamArgs {
     const float* red;
     float* grad_mean;  // [NP] task-mean gradient (kept for promp_meta_grad's output)
     float* stats;      // [K+2]
-    const float* eta;  // [K]
+    float eta[PROMP_ETA_MAX];   // inner KL coefficients, by value (K <= PROMP_ETA_MAX): no host -> device copy per optimisation
     int NP, K;
     float inv_tasks;
     float lr_t;        // lr * sqrt(1-b2^t)/(1-b1^t); 0 => no parameter update (stats / grad only)
     int do_update;
     int n_trainable;   // parameters [n_trainable, NP) are left alone (learn_std = False: the trailing log_std entries)
+    // promp_optimize_begin's last launch: both statistics slots go straight to page-locked host memory, followed by a
+    // sequence number the host polls (no copy operation, no event on the queue)
+    float* host_stats;       // [2 (K + 2)] or NULL
+    unsigned* host_seq;
+    unsigned seq;
 };
+// (called by the one thread that has just written stats[0 .. K+2); the second slot was written by an earlier launch)
+PROMP_DEV void publish_stats(const AdamArgs& a) {
+    if (a.host_stats == nullptr) return;
+    for (int i = 0; i < 2 * (a.K + 2); ++i) a.host_stats[i] = a.stats[i];
+    release_store_system(a.host_seq, a.seq);
+}
 
 __global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -138,6 +150,7 @@ __global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
         }
         a.stats[0] = a.red[a.NP] * a.inv_tasks + pen / (float)a.K;
         a.stats[1 + a.K] = a.red[a.NP + 1 + a.K] * a.inv_tasks;
+        publish_stats(a);
     }
 }
 
@@ -194,6 +207,7 @@ __global__ void __launch_bounds__(256) k_final_adam(FinalArgs a, AdamArgs ad) {
         }
         ad.stats[0] = sums[0] * ad.inv_tasks + pen / (float)a.K;
         ad.stats[1 + a.K] = sums[1 + a.K] * ad.inv_tasks;
+        publish_stats(ad);
     }
 }
 

@@ -202,11 +202,13 @@ inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline void wave_priority(int) {}
+inline void release_store_system(unsigned* p, unsigned v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; r[0] = fmaf(a[0], b[0], c[0]); r[1] = fmaf(a[1], b[1], c[1]); return r; }
 
 // ---- host runtime shims -------------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0 };
+enum { hipSuccess = 0, hipErrorNotReady = 600 };
+inline hipError_t hipStreamQuery(void*) { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated-hip-error"; }
 typedef void* hipStream_t;
 struct EmuEvent { std::chrono::steady_clock::time_point t; };
@@ -224,6 +226,9 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     return 0;
 }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return 0; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return 0; }
+constexpr unsigned hipStreamDefault = 0;
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(64, (n + 63) / 64 * 64); return *p ? 0 : 1; }
