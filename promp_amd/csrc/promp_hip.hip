@@ -551,8 +551,12 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         c->smem_fwd = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
         c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
     } else {
-        c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(dims)).total;   // (sized for obs_dim 32: constant offsets in the kernel)
-        c->smem_hvp = sizeof(float) * (size_t)chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(dims)).total;
+        // (sized for obs_dim 32: constant offsets in the kernels; contexts with wider observations and these hidden sizes run
+        //  sample processing only -- the policy passes reject them at launch -- and must not fail here on LDS they never use)
+        promp_dims pd = *dims;
+        if (pd.obs_dim > 32) pd.obs_dim = 32;
+        c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(&pd)).total;
+        c->smem_hvp = sizeof(float) * (size_t)chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total;
     }
     if (c->smem_hvp > 160 * 1024 || c->smem_fwd > 160 * 1024) {
         const size_t need = c->smem_hvp > c->smem_fwd ? c->smem_hvp : c->smem_fwd;

@@ -92,8 +92,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
     L.ms = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
     L.wave_stride = q;
     o += nwaves * q;
-    {   // end-of-kernel: one slab of max(H1*H2, NP+2-H1*H2) floats per wave, from offset 0 (aliases everything)
-        const int nw2 = H1 * H2, nr2 = NP + 2 - nw2;
+    {   // end-of-kernel: one slab per wave from offset 0 (aliases everything): the hidden_1 kernel with rows padded to
+        // H2 + 4, then the hidden_0 kernel (32 rows padded to H1 + 4) followed by everything else
+        const int nw2 = H1 * (H2 + 4), nr2 = 32 * (H1 + 4) + (NP + 2 - H1 * H2);
         const int need = nwaves * (nw2 > nr2 ? nw2 : nr2);
         if (o < need) o = need;
     }
@@ -531,28 +532,35 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     // Every wave stores its tiles to its own LDS slab (plain stores, no read-modify-write); then all threads add the slabs
     // in wave order, the waves of segment 0 into the first task's partial and those of segment 1 into the second's.
     // Two payload rounds because NW x [NP] does not fit in LDS: the hidden_1 kernel, then everything else (compacted).
+    // Slab rows are padded by 4 floats: the four lane groups of an accumulator tile (rows 4 kk + r) then fall into two
+    // bank halves instead of one (a [64]-float row stride puts all four on the same 16 banks).  Every cell of a slab is
+    // written by exactly one lane, so nothing is cleared first.
     float* S = sm;                                   // whole LDS allocation is free now
-    const int NW2 = H1 * H2;                         // round 1: hidden_1 kernel
-    const int NR2 = NP + 2 - NW2;                    // round 2: everything else, compacted
+    constexpr int SP2 = H2 + 4, SLAB1 = H1 * SP2;    // round 1: hidden_1 kernel, padded rows
+    constexpr int SP1 = H1 + 4, RESTB = 32 * SP1;    // round 2: hidden_0 kernel rows [0, 32) padded, the rest behind them
+    const int NW2 = H1 * H2;
+    const int NR2 = NP + 2 - NW2;                    // compact index space of round 2
+    const int SLAB2 = RESTB + (NR2 - ob1);
     CH_STAMP(4);
     lds_barrier();
     CH_STAMP(5);
     {
-        float* mine = S + w * NW2;
+        float* mine = S + w * SLAB1;
 #pragma unroll
         for (int i = 0; i < NC1; ++i)
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * SP2 + 16 * j + i16] = aw2[i][j][r];
     }
     lds_barrier();
     CH_STAMP(6);
 #pragma unroll 2
     for (int e = tid; e < NW2; e += NT) {
+        const int src = (e / H2) * SP2 + (e % H2);
         float v[NW];
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * NW2 + e];      // all slab reads in flight together
+        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SLAB1 + src];      // all slab reads in flight together
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) {
@@ -565,43 +573,40 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     CH_STAMP(7);
     lds_barrier();        // (LDS ordering only: the partial-row stores in flight are not waited for)
     {
-        // compact index space of round 2: [0,oW2) hidden_0 kernel+bias | then everything after the hidden_1 kernel
-        float* mine = S + w * NR2;
-        for (int e = lane; e < NR2; e += 64) mine[e] = 0.f;
-        wave_sync();
+        // round 2: [0, RESTB) hidden_0 kernel rows (padded) | then bias_0 and everything after the hidden_1 kernel, in
+        // parameter order; `rest` maps a parameter index >= ob1 (hidden_1 kernel cut out) to its cell
+        float* mine = S + w * SLAB2;
+        float* rest = mine + RESTB - ob1;            // rest[ob1 + u] = bias_0[u];  rest[p - NW2] for parameters p >= ob2
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NC1; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + 4 * kk + r;
-                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
-                }
+                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * SP1 + 16 * j + i16] = aw1[i][j][r];
 #pragma unroll
         for (int j = 0; j < NC2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (i16 < A) mine[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
+                if (i16 < A) rest[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
         if (kk == 0) {
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+            for (int j = 0; j < NC1; ++j) rest[ob1 + 16 * j + i16] = gb1[j];
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) mine[ob2 - NW2 + 16 * j + i16] = gb2[j];
+            for (int j = 0; j < NC2; ++j) rest[ob2 - NW2 + 16 * j + i16] = gb2[j];
         }
         if (lane < 4) {   // lane == q
             if (lane < A) {
-                mine[ob3 - NW2 + lane] = gb30;
-                mine[oS - NW2 + lane] = gs0 * lmask_reg0;
+                rest[ob3 - NW2 + lane] = gb30;
+                rest[oS - NW2 + lane] = gs0 * lmask_reg0;
             }
             if (lane + 4 < A) {
-                mine[ob3 - NW2 + lane + 4] = gb31;
-                mine[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
+                rest[ob3 - NW2 + lane + 4] = gb31;
+                rest[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
             }
         }
         if (lane == 0) {
-            mine[NP - NW2] = loss;
-            mine[NP + 1 - NW2] = klsum;
+            rest[NP - NW2] = loss;
+            rest[NP + 1 - NW2] = klsum;
         }
     }
     CH_STAMP(200);
@@ -609,9 +614,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     CH_STAMP(201);
     for (int e = tid; e < NR2; e += NT) {
         const int dst = e < oW2 ? e : e + NW2;
+        // compact index e: hidden_0 kernel entries [0, ob1) sit in padded rows, the others behind them
+        const int src = e < ob1 ? (e / H1) * SP1 + (e % H1) : RESTB - ob1 + e;
         float v[NW];
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * NR2 + e];
+        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SLAB2 + src];
         float t0 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) {
