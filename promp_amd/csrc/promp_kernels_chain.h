@@ -369,7 +369,7 @@ PROMP_DEV void chain_task_sum(TaskRedArgs r, int tid) {
     // CW columns per thread, up to 8 rows per round, and the operands of the update (step sizes, current parameters /
     // multipliers) requested in the same batch: the rows live in other CUs' L2 lines or in memory, so the sum is paced by
     // how many loads are outstanding, not by arithmetic
-    constexpr int CW = 6;
+    constexpr int CW = 12;
     const int jbeg = (mode == RED_SCAL) ? NP : 0;
     for (int j0 = jbeg + tid; j0 < NP + 2; j0 += CW * NT) {
         float g[CW], al[CW], old[CW];

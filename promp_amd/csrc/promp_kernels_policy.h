@@ -42,8 +42,19 @@ __global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
     if (a.mode == 4 && j < a.NP) return;
     float g = 0.f;
     const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
-#pragma unroll 4
-    for (int wg = wg0; wg < wg1; ++wg) g += a.partials[(long long)wg * a.partial_stride + j];
+    // eight rows per round, all requested together (the rows sit in other CUs' cache lines or in memory: the kernel is one
+    // or two memory round trips long, so what matters is how many loads are in flight); rows past the task's last are
+    // clamped to a valid row and masked by a multiplication, which keeps the loads unconditional.  Added in slot order.
+    for (int wb = wg0; wb < wg1; wb += 8) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int wg = wb + q < wg1 ? wb + q : wg1 - 1;
+            x[q] = a.partials[(long long)wg * a.partial_stride + j] * (wb + q < wg1 ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g += x[q];
+    }
     if (j >= a.NP) {
         a.scal[task * 2 + (j - a.NP)] = g;
         return;
@@ -84,8 +95,17 @@ __global__ void __launch_bounds__(256) k_reduce_final(FinalArgs a) {
     float s = 0.f;
     if (j < a.NP) {
         if (a.want_grad) {
-#pragma unroll 4
-            for (int i = q; i < a.n_tasks; i += 4) s += a.lam[(long long)i * a.NP + j];
+            // (up to 12 tasks of the quarter requested together, clamped + masked like k_reduce_task; order i = q, q + 4, ...)
+            for (int ib = q; ib < a.n_tasks; ib += 48) {
+                float x[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = ib + 4 * u;
+                    x[u] = a.lam[(long long)(i < a.n_tasks ? i : q) * a.NP + j] * (i < a.n_tasks ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 12; ++u) s += x[u];
+            }
         }
     } else if (j == a.NP) {
         for (int i = q; i < a.n_tasks; i += 4) s += a.scal_outer[i * 2 + 0];
@@ -167,8 +187,17 @@ __global__ void __launch_bounds__(256) k_final_adam(FinalArgs a, AdamArgs ad) {
     float s = 0.f;
     if (j < a.NP) {
         if (a.want_grad) {
-#pragma unroll 4
-            for (int i = q; i < a.n_tasks; i += 4) s += a.lam[(long long)i * a.NP + j];
+            // (up to 12 tasks of the quarter requested together, clamped + masked like k_reduce_task; order i = q, q + 4, ...)
+            for (int ib = q; ib < a.n_tasks; ib += 48) {
+                float x[12];
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    const int i = ib + 4 * u;
+                    x[u] = a.lam[(long long)(i < a.n_tasks ? i : q) * a.NP + j] * (i < a.n_tasks ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 12; ++u) s += x[u];
+            }
         }
     } else if (j == a.NP) {
         for (int i = q; i < a.n_tasks; i += 4) s += a.scal_outer[i * 2 + 0];
