@@ -54,6 +54,9 @@ def main():
                          '(M/N tasks, no collective) to study the per-rank step time of strong scaling')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-primal-cache', action='store_true',
+                    help='developer switch: the second-order pass recomputes the activations instead of reading the gradient '
+                         'pass\'s copies back (promp_set_primal_cache)')
     ap.add_argument('--staged-only', action='store_true',
                     help='developer switch: feed the timed loop by staged uploads (tools/gpu_round.sh traces the copy / compute overlap with it)')
     args = ap.parse_args()
@@ -80,6 +83,8 @@ def main():
             task_ids = [i for i in range(M_global) if i % args.shard_of == 0]
         M = len(task_ids)
         ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
+        if args.no_primal_cache:
+            ctx.set_primal_cache(False)
         if world > 1:
             uid = comm.exchange_unique_id(rank, world, lambda: _lib.comm_unique_id())
             ctx.comm_init(rank, world, uid)

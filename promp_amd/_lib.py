@@ -70,6 +70,7 @@ SIGNATURES = {
     'promp_get_theta': (C.c_int, [_P, _F]),
     'promp_set_step_sizes': (C.c_int, [_P, _F]),
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
+    'promp_set_primal_cache': (C.c_int, [_P, C.c_int]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
     'promp_set_rewards_f64': (C.c_int, [_P, C.c_int, _D]),
@@ -422,6 +423,10 @@ class Context:
     def set_schedule(self, stage_overlap=-1, fuse_min_tasks=-1):
         """launch scheduling knobs (results do not depend on them); -1 keeps a value"""
         self._call('promp_set_schedule', int(stage_overlap), int(fuse_min_tasks))
+
+    def set_primal_cache(self, on=True):
+        """the second-order pass reads the inner gradient pass's activations back instead of recomputing them (default on)"""
+        self._call('promp_set_primal_cache', int(bool(on)))
 
     def set_min_std(self, min_std):
         self._call('promp_set_min_std', float(min_std))

@@ -67,6 +67,7 @@ struct StepData {
     bool has_rew64 = false;
     float *ret32 = nullptr, *adv32 = nullptr;
     double *ret64 = nullptr, *adv64 = nullptr;
+    float* hcache = nullptr;           // primal cache (promp_kernels_chain.h: chain_cache_row), allocated on first use
     int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
     int *task_row_offsets = nullptr, *task_path_offsets = nullptr;
     int* task_wg_offsets[3] = {nullptr, nullptr, nullptr};   // [2]: partial slots of the k_fwd_bwd table per task
@@ -149,6 +150,8 @@ struct promp_ctx {
     int stats_slot = 0;                  // promp_optimize parks the first epoch's statistics in slot 1 (loss_before)
     const float* pass_adv = nullptr;     // launch_pass: per-row weights instead of the step's advantages (DiCE coupling pass)
     float* pass_row_tan = nullptr;       // launch_pass (R-operator pass): where the rows' log-likelihood tangents go
+    int pass_cache = 0;                  // launch_pass: 1 = the gradient pass fills the step's primal cache, 2 = the R-operator pass reads it
+    bool primal_cache = true;            // promp_set_primal_cache
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
@@ -300,6 +303,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     memset(&a, 0, sizeof a);
     a.obs = S.obs; a.act = S.act; a.adv = c->pass_adv ? c->pass_adv : S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
     a.row_tan = hvp ? c->pass_row_tan : nullptr;
+    const int cache = (c->wide || fwd_only || !S.hcache) ? 0 : c->pass_cache;
+    a.hcache = cache ? S.hcache : nullptr;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
@@ -338,7 +343,10 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         // register-chained R-operator pass: the per-task reduction happens inside the launch (last-arriving workgroup)
         const int n1 = c->d.hidden1 / 16, n2 = c->d.hidden2 / 16, ks = chain_ksteps(c->d.obs_dim);
 #define PROMP_CHAIN_CASE(N1, N2, KS)                                                                                             \
-    if (n1 == N1 && n2 == N2 && ks == KS) { auto k = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_hvp, c->stream, a); }
+    if (n1 == N1 && n2 == N2 && ks == KS) {                                                                                      \
+        if (cache == 2) { auto k = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP, true>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_hvp, c->stream, a); } \
+        else { auto k = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_hvp, c->stream, a); }           \
+    }
         PROMP_CHAIN_ALL(PROMP_CHAIN_CASE)
 #undef PROMP_CHAIN_CASE
         HIPCHECK(hipGetLastError());
@@ -348,6 +356,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
 #define PROMP_PASS_CASE(B1, B2, KS)                                                                                                    \
     if (b1 == B1 && b2 == B2 && ks1 == KS) {                                                                                           \
         if (fwd_only) { auto k = k_fwd_bwd<B1, B2, 8, false, KS>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
+        else if (cache == 1) { auto k = k_fwd_bwd<B1, B2, 8, true, KS, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
         else { auto k = k_fwd_bwd<B1, B2, 8, true, KS>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }          \
     }
         PROMP_PASS_ALL(PROMP_PASS_CASE)
@@ -384,12 +393,22 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         if (c->steps[k].n_rows == 0) return fail(-3, "step %d has no data", k);
     // a step's second-stream sample processing is waited for right in front of the first pass that reads its advantages:
     // the passes on earlier steps run while it finishes
+    bool filled[PROMP_ETA_MAX] = {};      // steps whose primal cache this evaluation has written
     for (int k = 0; k < K; ++k) {
         const float* th = (k == 0) ? c->theta : c->chain + (size_t)k * MNP;
         const long long st = (k == 0) ? 0 : NP;
         if (join_side(c, c->steps[k])) return -2;
-        if (launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f, false, RED_STEP, th, st,
-                        c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+        // the R-operator pass of this step (below) runs at these parameters on this slab: it reads the activations and means
+        // back instead of recomputing them (primal cache, promp_kernels_chain.h)
+        const bool cached = want_grad && c->primal_cache && !c->wide && policy_shape_chain(&c->d);
+        if (cached && !c->steps[k].hcache &&
+            dev_alloc(&c->steps[k].hcache, ((size_t)c->d.max_rows + 16 * (size_t)M) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
+        c->pass_cache = cached ? 1 : 0;
+        const int rc0 = launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f, false, RED_STEP, th, st,
+                                    c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2);
+        c->pass_cache = 0;
+        if (rc0) return -2;
+        filled[k] = cached;
     }
     if (join_side(c, c->steps[K])) return -2;
     if (launch_pass(c, c->steps[K], false, c->chain + (size_t)K * MNP, NP, loss_kind_outer(outer_kind), clip_eps, 0, 0.f, !want_grad,
@@ -402,9 +421,11 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
             const bool dice = inner_kind == PROMP_INNER_DICE;
             if (dice && !Sk.has_dice) return fail(-3, "step %d has no DiCE rewards: call promp_set_dice_rewards first", k);
             c->pass_row_tan = dice ? Sk.dice_c : nullptr;
+            c->pass_cache = filled[k] ? 2 : 0;
             const int rc1 = launch_pass(c, Sk, true, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, dice ? 0.f : eta_host[k] / (float)K, false,
                                         RED_HVP, nullptr, 0, nullptr, c->scal_tmp);
             c->pass_row_tan = nullptr;
+            c->pass_cache = 0;
             if (rc1) return -2;
             if (dice) {
                 // The magic box couples the time steps of a path: H v = H_loglik(w) v + grad_loglik(u(v)), u from the row tangents
@@ -465,7 +486,7 @@ int upload_eta(promp_ctx* c, const float* eta) {
 }
 
 void free_step(StepData& S) {
-    void* ptrs[] = {S.dice_rw, S.dice_c, S.dice_u, S.dice_tmp, S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
+    void* ptrs[] = {S.hcache, S.dice_rw, S.dice_c, S.dice_u, S.dice_tmp, S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
                     S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.chain_segs, S.chain_wg_offsets,
                     S.chain_slot_offsets, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
@@ -1246,6 +1267,11 @@ int promp_set_schedule(promp_ctx* c, int stage_overlap, int fuse_min_tasks) {
         c->overlap = stage_overlap != 0;
     }
     if (fuse_min_tasks >= 0) c->fuse_min_tasks = fuse_min_tasks;
+    return 0;
+}
+int promp_set_primal_cache(promp_ctx* c, int on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->primal_cache = on != 0;
     return 0;
 }
 int promp_set_learn_std(promp_ctx* c, int on) {

@@ -43,6 +43,17 @@ struct WorkItem {
     int task, row_begin, row_end, pad;
 };
 
+// Primal cache.  The R-operator pass at theta on a step's slab recomputes what the gradient pass at the SAME theta on the
+// SAME slab computed moments earlier: the hidden activations and the means.  Both kernels are bound by the matrix pipe
+// while HBM idles (2 % of its bandwidth), so the gradient pass writes them out and the R-operator pass reads them back:
+// 100 of its 688 MFMAs per tile and all 32 tanh per lane disappear for 4 (H1 + H2 + 8) bytes per row each way.
+// One block per 16-row tile, in the R-operator pass's operand order (a lane's four units contiguous):
+//     [c < NC1][sample 16][unit 16]  hidden_0 activations     [c < NC2][sample 16][unit 16]  hidden_1 activations
+//     [sample 16][action 8]          means
+// The block of tile t of a task starts at "row" row0(task) + 16 t + 16 task: a task's last tile may be partial, the 16
+// spare rows per task keep the next task's first block clear of it without a tile-offset table.
+PROMP_CX int chain_cache_row(int H1, int H2) { return H1 + H2 + 8; }     // floats per row
+
 struct ChainSeg {
     int task, tile0, ntiles, pad;   // 16-row tiles [tile0, tile0 + ntiles) of the task; slot = index of the segment
 };
@@ -91,6 +102,7 @@ struct PassArgs {
     float* v;                       // [tasks][Theta]
     float* scal;                    // [tasks][2]
     float* row_tan;                 // k_chain_hvp, optional [rows]: R'{log pi} of every row = dlogpi_row . (-v)  (DiCE coupling)
+    float* hcache;                  // primal cache of the step (k_fwd_bwd<STORE> writes it, k_chain_hvp<CACHED> reads it), see chain_cache_row
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
 };
 
@@ -454,9 +466,14 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
 // quantities q = R'{.} + kl_weight * dKL{.} then need no operand negation anywhere (MFMA has no negate modifier for
 // f32 operands).  theta and -v are both staged in fragment order (2 x 32.5 KB at 64/64).
 // ---------------------------------------------------------------------------------------------
-template <int NC1, int NC2, int KS, int NW>
+//
+// CACHED: the primal activations and means of every tile come from the step's primal cache (written by the gradient pass at
+// the same parameters, see chain_cache_row) instead of being recomputed: the primal products of the three layers and the
+// tanh evaluations drop out; the next tile's block is requested half a tile ahead.
+template <int NC1, int NC2, int KS, int NW, bool CACHED = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     constexpr int NT = 64 * NW, H1 = 16 * NC1, H2 = 16 * NC2, TS = PROMP_CH_TS, DS = PROMP_CH_DS, NOB = KS > 4 ? 2 : 1;
+    constexpr int HCR = chain_cache_row(H1, H2);
     constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0);
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -539,6 +556,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
             chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
         }
+        // CACHED: this lane's share of a tile's cache block (sample i16, units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1)
+        f32x4 ch1[NC1], ch2[NC2];
+        f32x2 cmu;
+        const float* hcl = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + i16 * 16 + 4 * kk : nullptr;
+        const float* hcm = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + 256 * (NC1 + NC2) + i16 * 8 + 2 * kk : nullptr;
+        if (CACHED) {
+            const int t = seg.tile0 + w;
+            const long long o = (long long)(t < tend ? 16 * t : 16 * seg.tile0) * HCR;     // always a block of this segment
+#pragma unroll
+            for (int c = 0; c < NC1; ++c) ch1[c] = *(const f32x4*)(hcl + o + 256 * c);
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
+            cmu = *(const f32x2*)(hcm + o);
+        }
         int tix = 0;
         for (int t = seg.tile0 + w; t < tend; t += NW, ++tix) {
             CH_TSTAMP(0);
@@ -557,7 +588,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             {
 #pragma unroll
                 for (int c = 0; c < NC1; ++c) {
-                    h1[c] = lds4(B1l + 16 * c);
+                    h1[c] = CACHED ? ch1[c] : lds4(B1l + 16 * c);
                     rh1[c] = lds4(B1l + VO + 16 * c);
                 }
 #pragma unroll
@@ -565,14 +596,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     f32x4 wf[NC1], vf[NC1];
 #pragma unroll
                     for (int c = 0; c < NC1; ++c) {
-                        wf[c] = lds4(W1l + (2 * c + t4) * 256);
+                        if (!CACHED) wf[c] = lds4(W1l + (2 * c + t4) * 256);
                         vf[c] = lds4(W1l + VO + (2 * c + t4) * 256);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (4 * t4 + r < KS) {
+                            if (!CACHED) {
 #pragma unroll
-                            for (int c = 0; c < NC1; ++c) h1[c] = mfma16(wf[c][r], xT[4 * t4 + r], h1[c]);
+                                for (int c = 0; c < NC1; ++c) h1[c] = mfma16(wf[c][r], xT[4 * t4 + r], h1[c]);
+                            }
 #pragma unroll
                             for (int c = 0; c < NC1; ++c) rh1[c] = mfma16(vf[c][r], xT[4 * t4 + r], rh1[c]);
                         }
@@ -581,7 +614,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 for (int c = 0; c < NC1; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float h = fast_tanh(h1[c][r]);
+                        const float h = CACHED ? h1[c][r] : fast_tanh(h1[c][r]);
                         h1[c][r] = h;
                         rh1[c][r] *= (1.f - h * h);
                     }
@@ -597,7 +630,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             {
 #pragma unroll
                 for (int c = 0; c < NC2; ++c) {
-                    h2[c] = lds4(B2l + 16 * c);
+                    h2[c] = CACHED ? ch2[c] : lds4(B2l + 16 * c);
                     rh2[c] = lds4(B2l + VO + 16 * c);
                 }
 #pragma unroll
@@ -610,8 +643,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        if (!CACHED) {
 #pragma unroll
-                        for (int c2 = 0; c2 < NC2; ++c2) h2[c2] = mfma16(wf[c2][r], h1[c1][r], h2[c2]);
+                            for (int c2 = 0; c2 < NC2; ++c2) h2[c2] = mfma16(wf[c2][r], h1[c1][r], h2[c2]);
+                        }
 #pragma unroll
                         for (int c2 = 0; c2 < NC2; ++c2) rh2[c2] = mfma16(wf[c2][r], rh1[c1][r], rh2[c2]);
 #pragma unroll
@@ -622,7 +657,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 for (int c = 0; c < NC2; ++c)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float h = fast_tanh(h2[c][r]);
+                        const float h = CACHED ? h2[c][r] : fast_tanh(h2[c][r]);
                         h2[c][r] = h;
                         rh2[c][r] *= (1.f - h * h);
                     }
@@ -653,16 +688,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 for (int c = 0; c < NC2; ++c) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        m0 = mfma16(wf[c][r], h2[c][r], m0);
+                        if (!CACHED) m0 = mfma16(wf[c][r], h2[c][r], m0);
                         ra0 = mfma16(wf[c][r], rh2[c][r], ra0);
                         rb0 = mfma16(vf[c][r], h2[c][r], rb0);
-                        m1 = mfma16(wf[c][r + 1], h2[c][r + 1], m1);
+                        if (!CACHED) m1 = mfma16(wf[c][r + 1], h2[c][r + 1], m1);
                         ra1 = mfma16(wf[c][r + 1], rh2[c][r + 1], ra1);
                         rb1 = mfma16(vf[c][r + 1], h2[c][r + 1], rb1);
                     }
                 }
-                mu0 = m0[0] + m1[0];
-                mu1 = m0[1] + m1[1];
+                mu0 = CACHED ? cmu[0] : m0[0] + m1[0];
+                mu1 = CACHED ? cmu[1] : m0[1] + m1[1];
                 Rmu0 = (ra0[0] + ra1[0]) + (rb0[0] + rb1[0]);
                 Rmu1 = (ra0[1] + ra1[1]) + (rb0[1] + rb1[1]);
             }
@@ -836,6 +871,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             CH_TSTAMP(7);
             float xN[NOB][4];
             chain_load_xN<NOB>(xN, a.obs, base, nrows, O, i16, kk);           // (needed after the next 48 NC1 NC2 MFMAs)
+            if (CACHED) {         // the next tile's cache block (the registers' current contents were copied out at the top)
+                const int tn = t + NW;
+                const long long o = (long long)(tn < tend ? 16 * tn : 16 * seg.tile0) * HCR;
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) ch1[c] = *(const f32x4*)(hcl + o + 256 * c);
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
+                cmu = *(const f32x2*)(hcm + o);
+            }
             // ---- qZ1 (transposed): ad = W2 dZ2^T, aq = W2 qZ2^T + (-vW2) dZ2^T
             f32x4 qz1[NC1];
             {

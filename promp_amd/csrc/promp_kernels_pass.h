@@ -107,7 +107,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
 // distribution epilogue and the partial carries just the two scalars.
 // KS1 > 0: the observation width is known at compile time (ceil(O / 4) == KS1 k-steps in the first layer): the k-loop
 // unrolls and its accumulators stay in place (the runtime loop pays a register copy per accumulator element and step).
-template <int NB1, int NB2, int NW, bool BWD, int KS1 = 0>
+// STORE: the hidden activations and the means of every tile also go to the step's primal cache (chain_cache_row in
+// promp_kernels_chain.h) for the R-operator pass that follows at the same parameters: 36 four-byte stores per lane and tile.
+template <int NB1, int NB2, int NW, bool BWD, int KS1 = 0, bool STORE = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, W3S = PROMP_W3S;
@@ -242,6 +244,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
         }
     }
 
+    const unsigned hoff = 64 * kk + i16;     // STORE: this lane's offset inside a cache block
     int tix = 0;
 #ifndef PROMP_NO_TILE_PRIO
     // The two waves of a SIMD share its issue slots oldest-first, so the older wave runs ahead and the younger one is
@@ -274,6 +277,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 xr[u] = (e < lim) ? x : 0.f;
             }
         }
+        // STORE: this lane's cells of the tile's cache block are sample 4 kk (+ r), unit i16 (+ 16 j) / action i16
+        // (a wave-uniform block address in scalar registers + one constant 32-bit offset per lane)
+        float* const hcb = STORE ? a.hcache + ((long long)base + 16 * task) * chain_cache_row(H1, H2) : nullptr;
         const bool rvalid = erow < nrows;
         const long long n = (long long)base + (rvalid ? erow : 0);
         const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
@@ -297,6 +303,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                     const f32x2 h = tanh2_prescaled(acc[0][j][r], acc[0][j][r + 1]);
                     H1w[(4 * kk + r) * HS + 16 * j + i16] = h[0];
                     H1w[(4 * kk + r + 1) * HS + 16 * j + i16] = h[1];
+                    if (STORE) {
+                        hcb[hoff + 256 * j + 16 * r] = h[0];
+                        hcb[hoff + 256 * j + 16 * (r + 1)] = h[1];
+                    }
                 }
         }
         wave_sync();
@@ -314,6 +324,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                     const f32x2 h = tanh2_prescaled(acc[0][j][r], acc[0][j][r + 1]);
                     H2w[(4 * kk + r) * HS + 16 * j + i16] = h[0];
                     H2w[(4 * kk + r + 1) * HS + 16 * j + i16] = h[1];
+                    if (STORE) {
+                        hcb[hoff + 256 * (NC1 + j) + 16 * r] = h[0];
+                        hcb[hoff + 256 * (NC1 + j) + 16 * (r + 1)] = h[1];
+                    }
                 }
         }
         wave_sync();
@@ -325,6 +339,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
             outer16<1, 1>(acc, H2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
 #pragma unroll
             for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r];
+            if (STORE && i16 < 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hcb[hoff + 256 * (NC1 + NC2) - 32 * kk - (i16 & 8) + 8 * r] = acc[0][0][r];
+            }
         }
         wave_sync();
         CH_TSTAMP(3);

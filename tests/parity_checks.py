@@ -218,6 +218,35 @@ def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, comp
     return res
 
 
+def check_primal_cache(lib, seed, M, P, T, O, A, hidden, K=1, ragged=True):
+    """the second-order pass reading the gradient pass's activations / means back from the primal cache must agree with
+    the recomputing path to float32 rounding (tile blocks of ragged tasks, partial last tiles, every adaptation step),
+    and both with the oracle; everything that does not go through the cache must not change at all"""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=ragged)
+    spec = op.PolicySpec(O, A, hidden)
+    alpha = np.full(spec.n_params, 0.1, np.float32)
+    eta = np.array([5e-4, 1e-3, 2e-3][:K], np.float32)
+    out = []
+    for on in (True, False):
+        ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+        ctx.set_primal_cache(on)
+        helpers.upload_slabs(ctx, all_paths, all_slabs)
+        ctx.set_theta(theta)
+        ctx.set_step_sizes(alpha)
+        g, st = ctx.meta_grad(0.3, eta)
+        g2, _ = ctx.meta_grad(0.3, eta)          # a second evaluation overwrites the cache blocks in place
+        np.testing.assert_array_equal(g, g2)
+        out.append((g, st))
+        ctx.close()
+    (g_on, st_on), (g_off, st_off) = out
+    for key in ('loss', 'inner_kl', 'outer_kl'):
+        np.testing.assert_array_equal(st_on[key], st_off[key])
+    assert rel_max(g_on, g_off.astype(np.float64)) < 2e-6
+    r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), all_slabs, alpha.astype(np.float64), eta.astype(np.float64), 0.3)
+    assert rel_max(g_on, r['grad']) < 1e-4
+    assert rel_max(g_off, r['grad']) < 1e-4
+
+
 def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, attach_comm=False):
     """the several-rank launch sequence (k_reduce_final -> [ncclAllReduce] -> k_mean_adam) on ONE rank must reproduce the
     fused single-rank launch (k_final_adam) bit for bit: same column sums in the same order, same Adam arithmetic"""

@@ -85,6 +85,12 @@ def test_fused_and_separate_task_reduction_agree(lib, two_cus):
     pc.check_schedule_invariance(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), K=1, iters=1, epochs=1)
 
 
+def test_primal_cache_matches_recomputation(lib, two_cus):
+    # ragged tasks (partial last tiles, cache blocks of consecutive tasks 16 spare rows apart), unequal widths, K = 2
+    pc.check_primal_cache(lib, 51, M=3, P=2, T=45, O=7, A=3, hidden=(32, 64), K=1)
+    pc.check_primal_cache(lib, 52, M=2, P=1, T=40, O=20, A=6, hidden=(64, 64), K=2)
+
+
 def test_split_path_equals_fused_launch(lib, two_cus):
     pc.check_split_path_equals_fused(lib, 18, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), epochs=2)
 

@@ -275,6 +275,13 @@ def test_launch_scheduling_does_not_change_results(lib):
     pc.check_schedule_invariance(lib, 82, M=3, P=3, T=60, O=12, A=4, hidden=(64, 32), K=2, iters=2)
 
 
+def test_primal_cache_matches_recomputation(lib):
+    """the second-order pass fed from the gradient pass's cached activations / means vs the recomputing path vs the oracle"""
+    pc.check_primal_cache(lib, 83, M=7, P=4, T=110, O=20, A=6, hidden=(64, 64), K=1)
+    pc.check_primal_cache(lib, 84, M=3, P=3, T=60, O=12, A=4, hidden=(64, 32), K=2)
+    pc.check_primal_cache(lib, 85, M=4, P=2, T=75, O=6, A=2, hidden=(32, 32), K=1)
+
+
 def test_communicator_moves_to_a_regrown_context(lib):
     a = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)
     a.comm_init(0, 1, _lib.comm_unique_id(lib))
