@@ -45,14 +45,16 @@ struct WorkItem {
 
 // Primal cache.  The R-operator pass at theta on a step's slab recomputes what the gradient pass at the SAME theta on the
 // SAME slab computed moments earlier: the hidden activations and the means.  Both kernels are bound by the matrix pipe
-// while HBM idles (2 % of its bandwidth), so the gradient pass writes them out and the R-operator pass reads them back:
-// 100 of its 688 MFMAs per tile and all 32 tanh per lane disappear for 4 (H1 + H2 + 8) bytes per row each way.
-// One block per 16-row tile, in the R-operator pass's operand order (a lane's four units contiguous):
+// while HBM idles (2 % of its bandwidth), so the gradient pass writes them out and the R-operator pass reads them back,
+// together with the hidden_0 cotangent before its tanh derivative (the product W2 dZ2^T, which the tangent of that
+// derivative needs): 164 of its 688 MFMAs per tile and all 32 tanh per lane disappear for 4 (2 H1 + H2 + 8) bytes per row
+// each way.  One block per 16-row tile, in the R-operator pass's operand order (a lane's four units contiguous):
 //     [c < NC1][sample 16][unit 16]  hidden_0 activations     [c < NC2][sample 16][unit 16]  hidden_1 activations
 //     [sample 16][action 8]          means
+//     [c < NC1][sample 16][unit 16]  W2 dZ2^T, scaled by PROMP_TANH_PRESCALE (the gradient pass's W2 copy carries that factor)
 // The block of tile t of a task starts at "row" row0(task) + 16 t + 16 task: a task's last tile may be partial, the 16
 // spare rows per task keep the next task's first block clear of it without a tile-offset table.
-PROMP_CX int chain_cache_row(int H1, int H2) { return H1 + H2 + 8; }     // floats per row
+PROMP_CX int chain_cache_row(int H1, int H2) { return 2 * H1 + H2 + 8; }     // floats per row
 
 struct ChainSeg {
     int task, tile0, ntiles, pad;   // 16-row tiles [tile0, tile0 + ntiles) of the task; slot = index of the segment
@@ -583,6 +585,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             const float mo0 = a.old_mean[n * A + q0], mo1 = a.old_mean[n * A + q1];
             const float so0 = olsp[q0], so1 = olsp[q1];
 
+            f32x4 cad1[NC1];      // CACHED: W2 dZ2^T of this tile (x PROMP_TANH_PRESCALE), needed at the very end of the tile
+            if (CACHED) {
+                const long long o = (long long)16 * t * HCR + 256 * (NC1 + NC2) + 128;
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) cad1[c] = *(const f32x4*)(hcl + o + 256 * c);
+            }
             // ---- layer 1 and its tangent:  R'z1 = X (-vW1) + (-vb1)
             f32x4 h1[NC1], rh1[NC1];
             {
@@ -899,8 +907,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                             wb[c1] = W2b[(c2 * NC1 + c1) * PROMP_CH_BLK + 4 * r];
                             vb[c1] = W2b[VO + (c2 * NC1 + c1) * PROMP_CH_BLK + 4 * r];
                         }
+                        if (!CACHED) {
 #pragma unroll
-                        for (int c1 = 0; c1 < NC1; ++c1) ad1[c1] = mfma16(wb[c1], dz2[c2][r], ad1[c1]);
+                            for (int c1 = 0; c1 < NC1; ++c1) ad1[c1] = mfma16(wb[c1], dz2[c2][r], ad1[c1]);
+                        }
 #pragma unroll
                         for (int c1 = 0; c1 < NC1; ++c1) qz1[c1] = mfma16(wb[c1], qz2[c2][r], qz1[c1]);
 #pragma unroll
@@ -911,7 +921,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float h = h1[c][r];
-                        qz1[c][r] = qz1[c][r] * (1.f - h * h) - 2.f * ad1[c][r] * h * rh1[c][r];
+                        const float ad2 = CACHED ? (2.f / PROMP_TANH_PRESCALE) * cad1[c][r] : 2.f * ad1[c][r];
+                        qz1[c][r] = qz1[c][r] * (1.f - h * h) - ad2 * h * rh1[c][r];
                     }
             }
             CH_TSTAMP(8);

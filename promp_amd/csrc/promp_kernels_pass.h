@@ -107,8 +107,9 @@ PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
 // distribution epilogue and the partial carries just the two scalars.
 // KS1 > 0: the observation width is known at compile time (ceil(O / 4) == KS1 k-steps in the first layer): the k-loop
 // unrolls and its accumulators stay in place (the runtime loop pays a register copy per accumulator element and step).
-// STORE: the hidden activations and the means of every tile also go to the step's primal cache (chain_cache_row in
-// promp_kernels_chain.h) for the R-operator pass that follows at the same parameters: 36 four-byte stores per lane and tile.
+// STORE: the hidden activations, the means and the hidden_0 cotangent (before its tanh derivative) of every tile also go to
+// the step's primal cache (chain_cache_row in promp_kernels_chain.h) for the R-operator pass that follows at the same
+// parameters: 52 four-byte stores per lane and tile.
 template <int NB1, int NB2, int NW, bool BWD, int KS1 = 0, bool STORE = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
     constexpr int NT = 64 * NW;
@@ -467,6 +468,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
                 for (int r = 0; r < 4; r += 2) {
                     const int idx = (4 * kk + r) * HS + 16 * j + i16;
                     const f32x2 ns = neg_dtanh2(H1w[idx], H1w[idx + HS]);
+                    if (STORE) {
+                        hcb[hoff + 256 * (NC1 + NC2) + 128 + 256 * j + 16 * r] = acc[0][j][r];
+                        hcb[hoff + 256 * (NC1 + NC2) + 128 + 256 * j + 16 * (r + 1)] = acc[0][j][r + 1];
+                    }
                     const float d0 = acc[0][j][r] * -ns[0], d1 = acc[0][j][r + 1] * -ns[1];
                     H1w[idx] = d0;
                     H1w[idx + HS] = d1;
