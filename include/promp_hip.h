@@ -167,11 +167,13 @@ int promp_set_min_std(promp_ctx* ctx, float min_std);
  *   fuse_min_tasks (default 16): from this many local tasks on, the Hessian-vector pass sums each task's partial rows
  *                  inside its own launch (last-arriving workgroup); below, a separate grid-wide reduction follows. */
 int promp_set_schedule(promp_ctx* ctx, int stage_overlap, int fuse_min_tasks);
-/* Primal cache (no reference counterpart; default on; hidden widths from {32, 64} only).  In one evaluation of the
- * meta-gradient (meta_algos/pro_mp.py:113-155) the inner gradient pass and the second-order pass of an adaptation step run at
- * the same parameters on the same slab; with the cache on, the former writes its hidden activations and means to HBM
- * (4 (H1 + H2 + 8) bytes per row) and the latter reads them back instead of recomputing them.  Results agree with the
- * recomputing path to float32 rounding (both evaluate the same tanh network; the two kernels contract in different orders). */
+/* Primal cache (no reference counterpart; hidden widths from {32, 64} only).  In one evaluation of the meta-gradient
+ * (meta_algos/pro_mp.py:113-155) the inner gradient pass and the second-order pass of an adaptation step run at the same
+ * parameters on the same slab; with the cache on, the former writes its hidden activations, means and first-layer
+ * cotangents to HBM (4 (2 H1 + H2 + 8) bytes per row) and the latter reads them back instead of recomputing them.
+ * Results agree with the recomputing path to float32 rounding (both evaluate the same tanh network; the two kernels
+ * contract in different orders).  on = 1 always, 0 never, -1 (default) whenever a step holds at least two rounds of
+ * 16-row tiles per compute unit -- below that the passes are all fixed cost and the stores do not pay. */
 int promp_set_primal_cache(promp_ctx* ctx, int on);
 int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
 int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);

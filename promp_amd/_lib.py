@@ -425,8 +425,9 @@ class Context:
         self._call('promp_set_schedule', int(stage_overlap), int(fuse_min_tasks))
 
     def set_primal_cache(self, on=True):
-        """the second-order pass reads the inner gradient pass's activations back instead of recomputing them (default on)"""
-        self._call('promp_set_primal_cache', int(bool(on)))
+        """the second-order pass reads the inner gradient pass's activations back instead of recomputing them
+        (True / False; None = the default: on for steps with at least two rounds of tiles per compute unit)"""
+        self._call('promp_set_primal_cache', -1 if on is None else int(bool(on)))
 
     def set_min_std(self, min_std):
         self._call('promp_set_min_std', float(min_std))

@@ -151,7 +151,7 @@ struct promp_ctx {
     const float* pass_adv = nullptr;     // launch_pass: per-row weights instead of the step's advantages (DiCE coupling pass)
     float* pass_row_tan = nullptr;       // launch_pass (R-operator pass): where the rows' log-likelihood tangents go
     int pass_cache = 0;                  // launch_pass: 1 = the gradient pass fills the step's primal cache, 2 = the R-operator pass reads it
-    bool primal_cache = true;            // promp_set_primal_cache
+    int primal_cache = -1;               // promp_set_primal_cache: 1 on, 0 off, -1 on from two rounds of tiles per CU on
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
@@ -400,7 +400,10 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         if (join_side(c, c->steps[k])) return -2;
         // the R-operator pass of this step (below) runs at these parameters on this slab: it reads the activations and means
         // back instead of recomputing them (primal cache, promp_kernels_chain.h)
-        const bool cached = want_grad && c->primal_cache && !c->wide && policy_shape_chain(&c->d);
+        // (a small shard's passes are all fixed cost -- staging, one round of tiles, end reduction: the stores then cost more
+        // than the second-order pass gets back: 0.750 vs 0.737 ms per step at 5 tasks, 0.937 vs 0.951 at 10, 1.789 vs 1.894 at 40)
+        const bool worth = c->primal_cache > 0 || (c->primal_cache < 0 && c->steps[k].n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
+        const bool cached = want_grad && worth && !c->wide && policy_shape_chain(&c->d);
         if (cached && !c->steps[k].hcache &&
             dev_alloc(&c->steps[k].hcache, ((size_t)c->d.max_rows + 16 * (size_t)M) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
         c->pass_cache = cached ? 1 : 0;
@@ -1271,7 +1274,7 @@ int promp_set_schedule(promp_ctx* c, int stage_overlap, int fuse_min_tasks) {
 }
 int promp_set_primal_cache(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
-    c->primal_cache = on != 0;
+    c->primal_cache = on < 0 ? -1 : on != 0;
     return 0;
 }
 int promp_set_learn_std(promp_ctx* c, int on) {
