@@ -30,6 +30,14 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('shard-of $n: %d tasks on this GPU, %.4f ms/step' % (d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/shard_timings.txt
 done
 cat $ROOT/$R/shard_timings.txt
+# primal cache on (default rule) / forced off: full batch and shards, same box, back to back
+for n in 0 2 4 8; do for flag in "" "--no-primal-cache"; do
+  sh=""; [ $n -gt 0 ] && sh="--shard-of $n"
+  timeout 300 python $ROOT/bench.py $sh --steps 30 --warmup 3 --no-cpu-baseline --no-roofline $flag 2> /dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-12s %-18s %d tasks on this GPU, %.4f ms/step' % ('$sh' or 'full batch', '$flag' or 'default', d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/primal_cache_ab.txt
+done; done
+cat $ROOT/$R/primal_cache_ab.txt
 # staged uploads: kernel + memory-copy trace of a run fed only by promp_stage_step, and the copy / compute overlap in it
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $ROOT/$R/trace_staged -o staged -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --staged-only > $ROOT/$R/bench_staged.json 2> $ROOT/$R/trace_staged.err; echo "staged trace rc=$?"

@@ -16,16 +16,29 @@ for name, out in [('bench.json', '%s_bench.json'), ('pytest_gpu.log', '%s_pytest
                   ('device.txt', '%s_device.txt'), ('trace/trace_kernel_stats.csv', '%s_rocprofv3_kernel_stats.csv'),
                   ('trace/trace_domain_stats.csv', '%s_rocprofv3_domain_stats.csv'),
                   ('bench_config4.json', '%s_bench_config4.json'), ('bench_config5.json', '%s_bench_config5.json'),
-                  ('shard_timings.txt', '%s_shard_timings.txt'), ('h2d_overlap.txt', '%s_h2d_overlap.txt'), ('bench_staged.json', '%s_bench_staged_uploads.json'), ('timeline.txt', '%s_step_timeline.txt'),
+                  ('shard_timings.txt', '%s_shard_timings.txt'), ('primal_cache_ab.txt', '%s_primal_cache_ab.txt'), ('h2d_overlap.txt', '%s_h2d_overlap.txt'), ('bench_staged.json', '%s_bench_staged_uploads.json'), ('timeline.txt', '%s_step_timeline.txt'),
                   ('trace4/trace4_kernel_stats.csv', '%s_rocprofv3_kernel_stats_config4.csv')]:
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out % tag))
+def short_name(k):
+    """k_fwd_bwd: every gradient-pass launch of a step under one name (the mean over dispatches then weighs the launches that
+    also fill the primal cache by their share, which is what bench.py's per-launch average does), the forward-only instance
+    apart; the cache-filling launches additionally on their own"""
+    base = k.split('(')[0].replace('void ', '')
+    name, _, targs = base.partition('<')
+    targs = [t.strip() for t in targs.rstrip('>').split(',')] if targs else []
+    if name == 'k_fwd_bwd' and len(targs) >= 4 and targs[3] == 'false':
+        return 'k_fwd_bwd<fwd-only>'
+    return name
+
+
 rows = {}
 for i in range(1, 9):
     f = os.path.join(src, 'pmc%d/pmc%d_counter_collection.csv' % (i, i))
     if not os.path.exists(f):
         continue
     df = pd.read_csv(f)
+    df['Kernel_Name'] = df['Kernel_Name'].map(short_name)
     g = df.groupby(['Kernel_Name', 'Counter_Name'])['Counter_Value'].mean().unstack()
     for k, r in g.iterrows():
         rows.setdefault(k, {}).update({c: float(v) for c, v in r.items()})
@@ -35,7 +48,7 @@ pmc.to_csv(os.path.join(dst, '%s_rocprofv3_pmc_per_dispatch_mean.csv' % tag))
 traffic = {}
 for k, r in pmc.iterrows():
     if 'FETCH_SIZE' in r and 'WRITE_SIZE' in r and r['FETCH_SIZE'] == r['FETCH_SIZE']:
-        short = k.split('(')[0].replace('void ', '').split('<')[0]
+        short = k
         traffic[short] = dict(fetch_size_kib=r['FETCH_SIZE'], write_size_kib=r['WRITE_SIZE'],
                               hbm_bytes_per_launch=(2.0 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024.0,
                               note='(2 x FETCH_SIZE + WRITE_SIZE) KiB; separate --pmc passes of bench.py --steps 3; gfx950 FETCH_SIZE x2 correction')
