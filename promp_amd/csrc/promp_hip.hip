@@ -86,6 +86,7 @@ struct StepData {
     hipEvent_t ev_ready = nullptr;     // copy stream: every array of this slab set has arrived
     bool ready_set = false, wait_ready_main = false, wait_ready_side = false, staged = false;
     std::shared_ptr<void> host_tables; // host-side sources of the asynchronous table copies, alive until the next staging
+    std::vector<int> lay_tpo, lay_pro; // the offsets the set's device-side tables were built from (set_step_layout)
 };
 
 // waves per workgroup of k_chain_hvp (one per SIMD: 512 registers per lane)
@@ -709,6 +710,15 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
     if (pro[0] != 0) return fail(-1, "path_row_offsets must start at 0");
     const int R = pro[n_paths];
     if (R < 1 || R > c->d.max_rows) return fail(-1, "rows %d outside [1, max_rows=%d]", R, c->d.max_rows);
+    // Same offsets as the batch this set held before (fixed-horizon environments: every batch): the time indices and the
+    // work tables on the device are already the right ones -- nothing to rebuild on the host (0.3 ms at 160 000 rows), no
+    // table copies to enqueue.  (A set is only ever re-described after its previous table copies have completed.)
+    if ((int)S.lay_tpo.size() == M + 1 && (int)S.lay_pro.size() == n_paths + 1 && S.n_paths == n_paths && S.n_rows == R &&
+        memcmp(S.lay_tpo.data(), tpo, sizeof(int) * (M + 1)) == 0 && memcmp(S.lay_pro.data(), pro, sizeof(int) * (n_paths + 1)) == 0) {
+        S.processed = false; S.has_adv = false; S.has_rew64 = false; S.has_dice = false;
+        return 0;
+    }
+    S.lay_tpo.clear(); S.lay_pro.clear();         // (rebuilt below; stays empty if anything fails half-way)
     std::vector<int> path_task(n_paths), row_t(R), tro(M + 1);
     for (int i = 0; i < M; ++i) {
         if (tpo[i + 1] <= tpo[i]) return fail(-1, "task %d has no paths", i);
@@ -941,6 +951,8 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
     }
     if (async) S.host_tables = keep;
     else HIPCHECK(hipStreamSynchronize(st));  // the sources go out of scope
+    S.lay_tpo.assign(tpo, tpo + M + 1);
+    S.lay_pro.assign(pro, pro + n_paths + 1);
     return 0;
 }
 
