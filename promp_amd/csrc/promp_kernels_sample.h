@@ -166,22 +166,45 @@ __global__ void __launch_bounds__(64 * GramCfg<NBLK>::NW) k_gram(SampleArgs a) {
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = zero4d();
     const int fr = lane >> 2, fc0 = lane & 3;   // feature build: 4 lanes per row, columns fc0, fc0+4, ...
-    for (int base = wk.row_begin + 16 * w; base < wk.row_end; base += 16 * NW) {
-        const int nrows = (wk.row_end - base) < 16 ? (wk.row_end - base) : 16;
+    // A chunk's inputs (this lane's share of the [16][O <= 32] observation rows, a row's return and time index) are
+    // requested one chunk ahead: the wave walks ~5 chunks and would otherwise sit out a memory round trip in each.
+    float xr[8];
+    double tr = 0.0;
+    int ttr = 0;
+    auto request = [&](int base) {
+        const bool live = base < wk.row_end;
+        const int nrows = !live ? 0 : (wk.row_end - base) < 16 ? (wk.row_end - base) : 16;
+        const long long b0 = live ? base : wk.row_begin;          // always a valid row of this work item
         if (a.kind == BASE_LINFEAT) {
             const int lim = nrows * O;
-            for (int e = lane; e < 16 * O; e += 64) {
-                const float x = a.obs[(long long)base * O + (e < lim ? e : 0)];
-                Ob[e] = (e < lim) ? x : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = lane + 64 * u;
+                const float x = a.obs[b0 * O + (e < lim ? e : 0)];
+                xr[u] = (e < lim) ? x : 0.f;
             }
         }
         if (lane < 16) {
             const int r = lane < nrows ? lane : 0;
-            const double t = a.ret64[base + r];
-            const double tau = (double)a.row_t[base + r] / 100.0;
-            Tg[lane] = (lane < nrows) ? t : 0.0;
-            Tau[lane] = (lane < nrows) ? tau : 0.0;
+            tr = a.ret64[b0 + r];
+            ttr = a.row_t[b0 + r];
         }
+    };
+    request(wk.row_begin + 16 * w);
+    for (int base = wk.row_begin + 16 * w; base < wk.row_end; base += 16 * NW) {
+        const int nrows = (wk.row_end - base) < 16 ? (wk.row_end - base) : 16;
+        if (a.kind == BASE_LINFEAT) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = lane + 64 * u;
+                if (e < 16 * O) Ob[e] = xr[u];
+            }
+        }
+        if (lane < 16) {
+            Tg[lane] = (lane < nrows) ? tr : 0.0;
+            Tau[lane] = (lane < nrows) ? (double)ttr / 100.0 : 0.0;
+        }
+        request(base + 16 * NW);
         wave_sync();
         {
             const bool rv = fr < nrows;
@@ -368,6 +391,7 @@ __global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
     double wsol = 0.0;
     for (int attempt = 0; attempt < 5; ++attempt) {
         double W[DT];
+        double rdg = 1.0;         // lane j: 1 / L[j][j] (the reciprocal square root the column step computed anyway)
 #pragma unroll
         for (int k = 0; k < DT; ++k) W[k] = (k < D) ? G[row * DA + k] + ((k == row) ? reg : 0.0) : 0.0;
         // 2. Cholesky of (G[:D,:D] + reg I) carrying the right-hand-side row D along (forward solve for free)
@@ -378,6 +402,7 @@ __global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
                 // kernel's critical path: sqrt followed by a division is two long software sequences, this is one)
                 const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
                 W[j] = (lane == j) ? piv : W[j] * rs;
+                rdg = (lane == j) ? rs : rdg;
 #pragma unroll
                 for (int k = j + 1; k < DT; ++k) W[k] -= W[j] * readlane_f64(W[j], k);      // lane k holds L[k][j] in W[j]
             }
@@ -388,9 +413,9 @@ __global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
             if (k < D && lane < DA) Lm[lane * DA + k] = W[k];
         wave_sync();
         double y = (lane < D) ? Lm[D * DA + lane] : 0.0;
-        const double dg = (lane < D) ? Lm[lane * DA + lane] : 1.0;
+        // (44 dependent steps: a multiplication by the stored reciprocal instead of a float64 division on the chain)
         for (int j = D - 1; j >= 0; --j) {
-            const double wj = readlane_f64(y, j) / readlane_f64(dg, j);
+            const double wj = readlane_f64(y, j) * readlane_f64(rdg, j);
             if (lane == j) wsol = wj;
             if (lane < j) y -= Lm[j * DA + lane] * wj;
         }

@@ -16,10 +16,12 @@ def build(force=False):
     deps.append(os.path.join(ROOT, 'include', 'promp_hip.h'))
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
+    tmp = '%s.%d.tmp' % (OUT, os.getpid())      # two processes may find the library stale at once: each links its own file
     cmd = ['g++', '-std=c++20', '-O1', '-g', '-DPROMP_EMU', '-fPIC', '-shared', '-x', 'c++', SRC,
-           '-I', HERE, '-I', os.path.join(ROOT, 'promp_amd', 'csrc'), '-o', OUT, '-lpthread',
+           '-I', HERE, '-I', os.path.join(ROOT, 'promp_amd', 'csrc'), '-o', tmp, '-lpthread',
            '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-variable', '-Wno-unused-but-set-variable']
     subprocess.check_call(cmd)
+    os.replace(tmp, OUT)                        # atomic: a reader sees the old or the new library, never a partial one
     return OUT
 
 

@@ -71,6 +71,33 @@ def check_sample_processing_oracle(lib, seed, M, P, T, O, ragged, kwargs, baseli
     return out
 
 
+def check_layout_reuse(lib, seed, M=3, P=3, T=40, O=5, order=('X', 'X2', 'Y', 'X', 'Y', 'Y', 'X2')):
+    """one context, one slab set, batches uploaded in the order X, X' (same offsets, other data), Y (other offsets, same
+    capacity), X again: a set described by the offsets it already holds keeps its device-side tables (set_step_layout's
+    early exit), any other description rebuilds them -- every result must equal a fresh context's on the same batch"""
+    from promp_amd import synthetic
+    kwargs = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True, positive_adv=False)
+    rng = np.random.RandomState(seed)
+    theta = synthetic.init_theta(rng, O, (8, 8), 2)
+    X = synthetic.make_paths(rng, theta, M, P, T, O, 2, (8, 8), ragged=True)
+    X2 = {k: [dict(p, observations=p['observations'] + 0.5, rewards=p['rewards'] * 2.0 - 1.0) for p in v] for k, v in X.items()}
+    Y = synthetic.make_paths(rng, theta, M, P, T, O, 2, (8, 8), ragged=True)
+    fls = {name: _lib.flatten_paths(b) for name, b in (('X', X), ('X2', X2), ('Y', Y))}
+    assert np.array_equal(fls['X']['path_row_offsets'], fls['X2']['path_row_offsets'])
+    assert not np.array_equal(fls['X']['path_row_offsets'], fls['Y']['path_row_offsets'])
+    cap_rows = max(len(f['rew']) for f in fls.values())
+    ctx = _lib.Context(M, O, 2, (32, 32), 1, max_rows=cap_rows, max_paths=M * P, lib=lib)
+    for name in order:
+        fl, paths = fls[name], {'X': X, 'X2': X2, 'Y': Y}[name]
+        ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
+        ctx.process_samples(0, baseline_kind=KIND['linear_feature'], **kwargs)
+        got = ctx.download_processed(0)
+        fresh = run_sample_processing(lib, paths, kwargs, 'linear_feature')
+        for key in ('returns', 'advantages', 'coeffs', 'path_returns0'):
+            np.testing.assert_array_equal(got[key], fresh[key], err_msg='%s after %s' % (key, name))
+    ctx.close()
+
+
 def check_float64_rewards(lib, seed, M=2, P=3, T=60, O=4):
     """rewards of large magnitude with small float64 structure (1e4 + N(0,1)): the reference scans the env's float64
     rewards, so returns must match the oracle to float64 accuracy and the raw GAE advantages (differences of large

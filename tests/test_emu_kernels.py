@@ -77,6 +77,10 @@ def test_staged_upload_sequence(lib, two_cus):
     pc.check_staged_upload(lib, 29, M=2, P=1, T=20, O=5, A=3, hidden=(32, 32), iters=2, epochs=1)
 
 
+def test_step_layout_reuse_and_rebuild(lib, two_cus):
+    pc.check_layout_reuse(lib, 61, M=2, P=2, T=24, O=3, order=('X', 'X2', 'Y', 'X'))
+
+
 def test_float64_rewards(lib, two_cus):
     pc.check_float64_rewards(lib, 31, M=2, P=2, T=30, O=3)
 
@@ -87,8 +91,8 @@ def test_fused_and_separate_task_reduction_agree(lib, two_cus):
 
 def test_primal_cache_matches_recomputation(lib, two_cus):
     # ragged tasks (partial last tiles, cache blocks of consecutive tasks 16 spare rows apart), unequal widths, K = 2
-    pc.check_primal_cache(lib, 51, M=3, P=2, T=45, O=7, A=3, hidden=(32, 64), K=1)
-    pc.check_primal_cache(lib, 52, M=2, P=1, T=40, O=20, A=6, hidden=(64, 64), K=2)
+    pc.check_primal_cache(lib, 51, M=3, P=1, T=37, O=7, A=3, hidden=(32, 64), K=1)
+    pc.check_primal_cache(lib, 52, M=1, P=1, T=40, O=20, A=6, hidden=(64, 32), K=2)
 
 
 def test_split_path_equals_fused_launch(lib, two_cus):

@@ -265,6 +265,10 @@ def test_staged_uploads_from_pinned_memory_equal_plain_uploads(lib):
     pc.check_staged_upload(lib, 95, M=6, P=5, T=100, O=20, A=6, hidden=(64, 64), iters=5)
 
 
+def test_step_layout_reuse_and_rebuild(lib):
+    pc.check_layout_reuse(lib, 91, M=6, P=4, T=150, O=20)
+
+
 def test_float64_rewards_stay_float64_on_the_device(lib):
     pc.check_float64_rewards(lib, 97)
 
