@@ -57,6 +57,9 @@ def main():
     ap.add_argument('--no-primal-cache', action='store_true',
                     help='developer switch: the second-order pass recomputes the activations instead of reading the gradient '
                          'pass\'s copies back (promp_set_primal_cache)')
+    ap.add_argument('--schedule', default='', metavar='OVERLAP,FUSE_MIN_TASKS',
+                    help='developer switch: promp_set_schedule(stage_overlap, fuse_min_tasks), e.g. "0,-1" = all sample processing '
+                         'on the main stream (results do not depend on it)')
     ap.add_argument('--staged-only', action='store_true',
                     help='developer switch: feed the timed loop by staged uploads (tools/gpu_round.sh traces the copy / compute overlap with it)')
     args = ap.parse_args()
@@ -85,6 +88,8 @@ def main():
         ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
         if args.no_primal_cache:
             ctx.set_primal_cache(False)
+        if args.schedule:
+            ctx.set_schedule(*[int(x) for x in args.schedule.split(',')])
         if world > 1:
             uid = comm.exchange_unique_id(rank, world, lambda: _lib.comm_unique_id())
             ctx.comm_init(rank, world, uid)

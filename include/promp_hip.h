@@ -164,8 +164,9 @@ int promp_set_min_std(promp_ctx* ctx, float min_std);
  *   stage_overlap  != 0 (default): promp_process_samples of steps >= 1 is enqueued on a second stream, ordered behind the
  *                  last main-stream work on that step's slabs, and joined in front of the first launch that reads its
  *                  outputs -- it then runs under process_samples(0) + the inner step the host enqueued just before.
- *   fuse_min_tasks (default 16): from this many local tasks on, the Hessian-vector pass sums each task's partial rows
- *                  inside its own launch (last-arriving workgroup); below, a separate grid-wide reduction follows. */
+ *   fuse_min_tasks (default: never): from this many local tasks on, the Hessian-vector pass sums each task's partial rows
+ *                  inside its own launch (last-arriving workgroup) instead of leaving it to the grid-wide reduction that
+ *                  otherwise follows the launch (measured slower at every task count since that reduction was tuned). */
 int promp_set_schedule(promp_ctx* ctx, int stage_overlap, int fuse_min_tasks);
 /* Primal cache (no reference counterpart; hidden widths from {32, 64} only).  In one evaluation of the meta-gradient
  * (meta_algos/pro_mp.py:113-155) the inner gradient pass and the second-order pass of an adaptation step run at the same

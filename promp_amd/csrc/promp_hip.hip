@@ -147,7 +147,7 @@ struct promp_ctx {
     int rank = 0, nranks = 1;
     float min_log_std = -13.815510558f;  // log(1e-6): GaussianMLPPolicy's default min_std
     bool learn_std = true;               // false: log_std is neither adapted (step size 0) nor trained (no Adam update)
-    int fuse_min_tasks = 16;             // k_chain_hvp sums a task's partial rows in-launch from this many local tasks on
+    int fuse_min_tasks = 1 << 30;        // k_chain_hvp sums a task's partial rows in-launch from this many local tasks on (default: never)
     int stats_slot = 0;                  // promp_optimize parks the first epoch's statistics in slot 1 (loss_before)
     const float* pass_adv = nullptr;     // launch_pass: per-row weights instead of the step's advantages (DiCE coupling pass)
     float* pass_row_tan = nullptr;       // launch_pass (R-operator pass): where the rows' log-likelihood tangents go
@@ -319,9 +319,11 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.min_log_std = c->min_log_std;   // GaussianMLPPolicy min_std (policies/gaussian_mlp_policy.py:31,35)
     a.kl_weight = klw;
     a.task_counters = c->task_counters; a.task_slot_offsets = S.chain_slot_offsets;
-    // With many tasks the last arrivers' sums hide under the other tasks' tiles (164 us fused vs 187 + 5 us at 40 tasks);
-    // with few, every task finishes at once and one workgroup per task streaming ~50 partial rows is exposed
-    // (66 us vs 46 + 5 us at 5 tasks): there the grid-wide k_reduce_task follows instead.
+    // In-launch reduction (the last-arriving workgroup of a task sums its partial rows) against the grid-wide k_reduce_task
+    // behind the launch: with few tasks every task finishes at once and one workgroup per task streaming ~50 partial rows
+    // is exposed (66 us vs 46 + 5 us at 5 tasks); with 40 tasks the sums partly hide under other tasks' tiles, but since
+    // k_reduce_task keeps eight rows per thread in flight the separate launch wins there too (123 + 5 us vs 137 us with the
+    // primal cache, 147 + 5 vs 162 us without).  The in-launch form stays available (promp_set_schedule).
     a.fuse_reduce = (hvp && !c->wide && c->d.n_tasks >= c->fuse_min_tasks) ? 1 : 0;
     a.red_mode = red_mode; a.step_sizes = c->step_sizes; a.cur = cur; a.cur_task_stride = cur_stride; a.next = next;
     a.lam = c->lam; a.v = c->vbuf; a.scal = scal;
