@@ -7,7 +7,9 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 starts = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_returns') or 'k_returns' in r['Kernel_Name']]
 steps = [i for j, i in enumerate(starts) if j % 2 == 0]
 import os
-sel = int(os.environ.get('TIMELINE_STEP', '-2'))
+# default: a step from the middle of the timed loop of the 10-step runs gpu_trace.sh / gpu_round.sh trace (the list also
+# holds the set-up call, the warm-up steps and, after the timed loop, the upload / staged-upload measurements)
+sel = int(os.environ.get('TIMELINE_STEP', '6'))
 a, b = steps[sel], steps[sel + 1]
 t0 = int(rows[a]['Start_Timestamp']); prev = None; busy = 0
 for r in rows[a:b]:
