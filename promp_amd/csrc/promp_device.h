@@ -37,6 +37,25 @@ PROMP_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma
 // FP64: same A/B lane map as mfma16; D: col = l&15, row = (l>>4) + 4*r.
 PROMP_DEV f64x4 mfma16d(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
+// D[16x16] += A[16x32] * B[32x16] on the BF16 matrix pipe (16 384 FLOP in half the issue time of the FP32 instruction's
+// 2 048).  lane l holds A[i = l & 15][k = 8 (l >> 4) .. + 7] and B[k = 8 (l >> 4) .. + 7][j = l & 15], 8 bf16 each;
+// D as mfma16.  Exact products, float32 accumulation (layout and error: tools/micro/bf16_layout_probe.hip).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+PROMP_DEV f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// Error-compensated split of eight float32 values into three BF16 terms each: x = t0 + t1 + t2 up to 2^-24 |x|
+// (v_cvt_pk_bf16_f32 rounds to nearest even; the residuals are exact in float32).
+PROMP_DEV void bf16_split3(const float (&x)[8], bf16x8 (&t)[3]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h0 = (__bf16)x[e];
+        const float r1 = x[e] - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        t[0][e] = h0;
+        t[1][e] = h1;
+        t[2][e] = (__bf16)r2;
+    }
+}
 PROMP_DEV float shfl_xor_f32(float v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }

@@ -593,14 +593,17 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     {
 #define PROMP_CHAIN_ATTR(N1, N2, KS)                                                                                        \
     {                                                                                                                     \
-        auto c2 = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP>;                                                                   \
+        auto c2 = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP, false>; auto c3 = k_chain_hvp<N1, N2, KS, CHAIN_NW_HVP, true>;     \
         HIPCHECK(hipFuncSetAttribute((const void*)c2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        HIPCHECK(hipFuncSetAttribute((const void*)c3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
     }
         PROMP_CHAIN_ALL(PROMP_CHAIN_ATTR)
 #undef PROMP_CHAIN_ATTR
 #define PROMP_PASS_ATTR(B1, B2, KS)                                                                                          \
     {                                                                                                                     \
         auto c0 = k_fwd_bwd<B1, B2, 8, true, KS>; auto c1 = k_fwd_bwd<B1, B2, 8, false, KS>;                               \
+        auto cs = k_fwd_bwd<B1, B2, 8, true, KS, true>;                                                                    \
+        HIPCHECK(hipFuncSetAttribute((const void*)cs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         HIPCHECK(hipFuncSetAttribute((const void*)c0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         HIPCHECK(hipFuncSetAttribute((const void*)c1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
     }

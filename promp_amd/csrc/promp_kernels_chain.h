@@ -108,9 +108,16 @@ struct PassArgs {
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
 };
 
+// The layer-2 tangent of the cached R-operator pass runs on the BF16 matrix pipe (error-compensated 3-way split of both
+// operands, 6 of the 9 products, float32 accumulation: more accurate than the FP32 MFMA chain).
+#ifndef PROMP_BF16_L2
+#define PROMP_BF16_L2 1
+#endif
+
 struct ChainLds {
     int w1, w2, w3, w3b, b1, b2, b3, dist;   // inside one network block
     int net_stride;
+    int planes, plane_stride;                // BF16 planes of the two networks' hidden_1 kernels, behind both network blocks
     int flag;                                // one int: "this workgroup arrived last"
     int wave0, wave_stride, tb0, tb1, db0, db1;
     int total;
@@ -134,6 +141,13 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP) {
     L.dist = n; n += 48;
     L.net_stride = n;
     o += (hvp ? 2 : 1) * n;
+    // BF16 planes of the hidden_1 kernel for v_mfma_f32_16x16x32_bf16: [term 3][c2][pair of input blocks][lane] x 8 bf16 (16 B):
+    // lane (i16, kk) of chunk (c2, P): W2[16 (2P) + 4 kk + r][16 c2 + i16], r = 0..3, then W2[16 (2P + 1) + 4 kk + r][.]
+    // (behind BOTH network blocks: inside them they would push the second network's float32 fragments past the 64 KB that
+    // a ds_read immediate offset reaches, and every such read would cost an address add: +4.5 us per launch, measured)
+    L.planes = o;
+    L.plane_stride = 3 * NC2 * (NC1 / 2) * 256;
+    o += (hvp && PROMP_BF16_L2 != 0) ? 2 * L.plane_stride : 0;
     L.wave0 = o;
     int q = 0;
     L.tb0 = q; q += 16 * PROMP_CH_TS;
@@ -476,6 +490,7 @@ template <int NC1, int NC2, int KS, int NW, bool CACHED = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     constexpr int NT = 64 * NW, H1 = 16 * NC1, H2 = 16 * NC2, TS = PROMP_CH_TS, DS = PROMP_CH_DS, NOB = KS > 4 ? 2 : 1;
     constexpr int HCR = chain_cache_row(H1, H2);
+    constexpr bool BF16L2 = CACHED && PROMP_BF16_L2 != 0;
     constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0);
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -527,6 +542,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         for (int e = lane; e < 2 * 16 * DS; e += 64) DB0[e] = 0.f;
         CH_STAMP(7);
         __syncthreads();
+        if (BF16L2) {
+            // BF16 planes of both networks' hidden_1 kernels out of the float32 fragments staged above
+            constexpr int NCH = NC2 * (NC1 / 2) * 64;
+            for (int ch = tid; ch < 2 * NCH; ch += NT) {
+                const int ns = ch / NCH, rem = ch - ns * NCH, c2 = rem / ((NC1 / 2) * 64), P = (rem >> 6) % (NC1 / 2), ln = rem & 63;
+                const float* nb = net + ns * VO;
+                float* pl = sm + L.planes + ns * L.plane_stride;
+                const float* src = nb + L.w2 + (ln >> 4) * PROMP_CH_ROW + (ln & 15) * 4;
+                const f32x4 lo = lds4(src + (c2 * NC1 + 2 * P) * PROMP_CH_BLK), hi = lds4(src + (c2 * NC1 + 2 * P + 1) * PROMP_CH_BLK);
+                const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8 t[3];
+                bf16_split3(x, t);
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC2 + c2) * (NC1 / 2) + P) * 64 + ln) * 4) = t[sp];
+            }
+            __syncthreads();
+        }
         CH_STAMP(1);
         const float* dist = net + L.dist;
         const float s0 = dist[CH_LS + q0], s1 = dist[CH_LS + q1], e0 = dist[CH_ES + q0], e1 = dist[CH_ES + q1];
@@ -641,8 +673,35 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     h2[c] = CACHED ? ch2[c] : lds4(B2l + 16 * c);
                     rh2[c] = lds4(B2l + VO + 16 * c);
                 }
+                if (BF16L2) {
+                    // R'z2 += W2^T R'H1 + (-vW2)^T H1 on the BF16 pipe: K = 32 per instruction = two 16-unit input blocks; a
+                    // lane's eight k-slots are its own registers of the two blocks (units 16 c + 4 kk + r), split three ways
+                    const bf16x8* Wp = (const bf16x8*)(sm + L.planes) + lane;
+                    const bf16x8* Vp = (const bf16x8*)(sm + L.planes + L.plane_stride) + lane;
 #pragma unroll
-                for (int c1 = 0; c1 < NC1; ++c1) {
+                    for (int P = 0; P < NC1 / 2; ++P) {
+                        const float xr[8] = {rh1[2 * P][0], rh1[2 * P][1], rh1[2 * P][2], rh1[2 * P][3],
+                                             rh1[2 * P + 1][0], rh1[2 * P + 1][1], rh1[2 * P + 1][2], rh1[2 * P + 1][3]};
+                        const float xh[8] = {h1[2 * P][0], h1[2 * P][1], h1[2 * P][2], h1[2 * P][3],
+                                             h1[2 * P + 1][0], h1[2 * P + 1][1], h1[2 * P + 1][2], h1[2 * P + 1][3]};
+                        bf16x8 rB[3], hB[3];
+                        bf16_split3(xr, rB);
+                        bf16_split3(xh, hB);
+                        // (weight term, activation term), smallest products first; (1,2), (2,1), (2,2) are below 2^-24
+                        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                        for (int p = 0; p < 6; ++p) {
+#pragma unroll
+                            for (int c2 = 0; c2 < NC2; ++c2)
+                                rh2[c2] = mfma16_bf16(Wp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], rB[TB[p]], rh2[c2]);
+#pragma unroll
+                            for (int c2 = 0; c2 < NC2; ++c2)
+                                rh2[c2] = mfma16_bf16(Vp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], hB[TB[p]], rh2[c2]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c1 = 0; c1 < (BF16L2 ? 0 : NC1); ++c1) {
                     f32x4 wf[NC2], vf[NC2];
 #pragma unroll
                     for (int c2 = 0; c2 < NC2; ++c2) {

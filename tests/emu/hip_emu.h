@@ -47,6 +47,7 @@ struct Wave {
     std::barrier<> bar;
     float fa[64], fb[64];
     double da[64], db[64];
+    unsigned short ha[64][8], hb[64][8];
     explicit Wave(int n) : bar(n) {}
 };
 
@@ -143,6 +144,51 @@ inline f32x4 mfma16(float a, float b, f32x4 c) {
         const int i = 4 * g + r;
         float acc = c[r];
         for (int k = 0; k < 4; ++k) acc = fmaf(W.fa[i + 16 * k], W.fb[j + 16 * k], acc);
+        d[r] = acc;
+    }
+    W.bar.arrive_and_wait();
+    return d;
+}
+// BF16 operands of v_mfma_f32_16x16x32_bf16: 8 values per lane and operand (k = 8 (l / 16) .. + 7 of row / column l % 16;
+// layout confirmed on the device by tools/micro/bf16_layout_probe.hip); exact products, float32 accumulation
+struct bf16x8 {
+    unsigned short h[8];
+};
+inline unsigned short emu_f2bf(float x) {              // round to nearest even, as v_cvt_pk_bf16_f32
+    unsigned u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline float emu_bf2f(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+inline void bf16_split3(const float (&x)[8], bf16x8 (&t)[3]) {
+    for (int e = 0; e < 8; ++e) {
+        float r = x[e];
+        for (int s = 0; s < 3; ++s) {
+            t[s].h[e] = emu_f2bf(r);
+            r -= emu_bf2f(t[s].h[e]);
+        }
+    }
+}
+inline f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 15, g = l >> 4;
+    for (int e = 0; e < 8; ++e) {
+        W.ha[l][e] = a.h[e];
+        W.hb[l][e] = b.h[e];
+    }
+    W.bar.arrive_and_wait();
+    f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int kb = 0; kb < 4; ++kb)
+            for (int e = 0; e < 8; ++e) acc += emu_bf2f(W.ha[i + 16 * kb][e]) * emu_bf2f(W.hb[j + 16 * kb][e]);   // (products exact in float32)
         d[r] = acc;
     }
     W.bar.arrive_and_wait();
