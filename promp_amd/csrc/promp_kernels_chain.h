@@ -108,7 +108,7 @@ struct PassArgs {
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
 };
 
-// The layer-2 tangent of the cached R-operator pass runs on the BF16 matrix pipe (error-compensated 3-way split of both
+// Layer 2 of the R-operator pass (tangent, and the primal product where it is not read from the cache) runs on the BF16 matrix pipe (error-compensated 3-way split of both
 // operands, 6 of the 9 products, float32 accumulation: more accurate than the FP32 MFMA chain).
 #ifndef PROMP_BF16_L2
 #define PROMP_BF16_L2 1
@@ -490,7 +490,7 @@ template <int NC1, int NC2, int KS, int NW, bool CACHED = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     constexpr int NT = 64 * NW, H1 = 16 * NC1, H2 = 16 * NC2, TS = PROMP_CH_TS, DS = PROMP_CH_DS, NOB = KS > 4 ? 2 : 1;
     constexpr int HCR = chain_cache_row(H1, H2);
-    constexpr bool BF16L2 = CACHED && PROMP_BF16_L2 != 0;
+    constexpr bool BF16L2 = PROMP_BF16_L2 != 0;
     constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0);
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -691,6 +691,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
                         for (int p = 0; p < 6; ++p) {
+                            if (!CACHED) {        // the primal product z2 = W2^T H1 rides on the same planes and splits
+#pragma unroll
+                                for (int c2 = 0; c2 < NC2; ++c2)
+                                    h2[c2] = mfma16_bf16(Wp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], hB[TB[p]], h2[c2]);
+                            }
 #pragma unroll
                             for (int c2 = 0; c2 < NC2; ++c2)
                                 rh2[c2] = mfma16_bf16(Wp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], rB[TB[p]], rh2[c2]);
