@@ -243,7 +243,10 @@ def main():
                                                              else 'E=%d ProMP epochs + stats' % E),
                    'meta_batch_size': M_global, 'tasks_per_gpu': M, 'rows_per_task_per_step': N,
                    'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
-                   'device': info['name']},
+                   'device': info['name'],
+                   'numerics': 'float32 (exact-FP32 MFMA; sample processing float64); layer 2 of the second-order pass runs as 6 BF16 '
+                               'products of a 3-way error-compensated split with float32 accumulation (error <= the FP32 chain\'s, '
+                               'DESIGN.md 5.2b)'},
     }
 
     # ---- config 5 with the exact constraint Hessian-vector product (promp_constraint_hvp) instead of the reference's finite
