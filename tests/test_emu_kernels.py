@@ -91,8 +91,8 @@ def test_fused_and_separate_task_reduction_agree(lib, two_cus):
 
 def test_primal_cache_matches_recomputation(lib, two_cus):
     # ragged tasks (partial last tiles, cache blocks of consecutive tasks 16 spare rows apart), unequal widths, K = 2
-    pc.check_primal_cache(lib, 51, M=3, P=1, T=37, O=7, A=3, hidden=(32, 64), K=1)
-    pc.check_primal_cache(lib, 52, M=1, P=1, T=40, O=20, A=6, hidden=(64, 32), K=2)
+    # (more shapes, incl. 64/64 and 32/32, in the GPU test of the same name)
+    pc.check_primal_cache(lib, 51, M=2, P=1, T=37, O=7, A=3, hidden=(32, 64), K=2)
 
 
 def test_split_path_equals_fused_launch(lib, two_cus):
