@@ -1383,6 +1383,8 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
 
 // fixed-length layout of a device-side rollout: path p of task i is rows [(i B + p) T, (i B + p + 1) T)
 static int begin_fixed_rollout(promp_ctx* c, int step, int B, int T) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (B < 1 || T < 1) return fail(-1, "envs_per_task and path_length must be positive");
     const int M = c->d.n_tasks;
     const long long rows = (long long)M * B * T;
@@ -1413,6 +1415,7 @@ static int ensure_rollout_buf(promp_ctx* c, size_t need) {
 int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_length, const double* goals,
                             const double* start, const float* noise, const promp_point_env_opts* o) {
     if (!c || !goals || !start || !o) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (c->d.obs_dim != 2 || c->d.act_dim != 2) return fail(-1, "the point environment has obs_dim = act_dim = 2 (context: %d, %d)", c->d.obs_dim, c->d.act_dim);
     if (c->d.hidden1 > 128 || c->d.hidden2 > 128) return fail(-1, "hidden widths above 128 are not supported by the rollout kernels");
     if (o->reward_type < 0 || o->reward_type > 2) return fail(-1, "unknown reward type %d", o->reward_type);

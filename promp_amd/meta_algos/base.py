@@ -40,7 +40,7 @@ class MAMLAlgo(MetaAlgo):
         slot = self.session.resident_slot(samples)
         if slot is None:
             slot = default_slot % (self.num_inner_grad_steps + 1)
-            self.session.upload_samples(slot, samples)
+            self._upload_into(slot, samples)
         return slot
 
     def _place_steps(self, all_samples_data):
@@ -50,8 +50,16 @@ class MAMLAlgo(MetaAlgo):
         if missing:
             self.session.ensure(max(sum(len(d['advantages']) for d in sd) for sd in missing), self.meta_batch_size)
         for k, sd in enumerate(all_samples_data):
-            if self._slot_of(sd, k) != k:             # resident, but in another slot (an extra process_samples call in between)
-                self.session.upload_samples(k, sd)
+            if self.session.resident_slot(sd) != k:   # not resident, or resident in another slot (an extra process_samples call)
+                self._upload_into(k, sd)
+
+    def _upload_into(self, slot, samples):
+        """host copy of `samples` -> `slot`; the samples remember where they now live, so the next call finds them resident
+        instead of uploading again (and instead of displacing the step that owns the slot they used to point at)"""
+        upload = self.session.upload_samples(slot, samples)
+        for i, sd in enumerate(samples):
+            if hasattr(sd, 'device_ref'):
+                sd.device_ref = (self.session.serial, upload, slot, i)
 
     def _adapt(self, samples):
         """MAML inner step for each task; stores the adapted parameters in the policy (base.py:217-242)"""

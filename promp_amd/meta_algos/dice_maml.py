@@ -80,13 +80,14 @@ class DICEMAML(MAMLAlgo):
             for k, flat in todo.items():
                 self._upload_dice(k, all_samples_data[k], flat)
         ctx = self.session.ctx
-        if self.session.world > 1:
-            raise NotImplementedError('DICE-MAML runs on one rank')
         if log: logger.log('Optimizing')
         ctx.optimize(1, self.learning_rate, 0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
         if log: logger.log('Computing statistics')
         # magic_box == 1 in value: the objective is minus the mean adjusted reward of the last step's valid entries
-        loss = float(np.mean([-np.mean(np.asarray(sd['adjusted_rewards']) * np.asarray(sd['mask'])) for sd in all_samples_data[K]]))
+        # (mean over ALL tasks: a task-sharded run sums the ranks' per-task means; the gradient's all-reduce is inside optimize)
+        per_task = [-np.mean(np.asarray(sd['adjusted_rewards']) * np.asarray(sd['mask'])) for sd in all_samples_data[K]]
+        tot, cnt = self.session.allreduce([np.sum(per_task), len(per_task)])
+        loss = float(tot / cnt)
         if log:
             logger.logkv('LossBefore', loss)
             logger.logkv('LossAfter', loss)

@@ -35,8 +35,7 @@ class _DeviceEvaluator(object):
         c = a._explore_coeffs
         tot = np.concatenate([[np.dot(c, l.astype(np.float64))], c.dot(g.astype(np.float64)) if want_grad else []])
         n_global = a.session.M_global
-        if a.session.world > 1:                       # task-sharded run: sum over ranks (64 doubles per call)
-            tot = np.concatenate([ctx.allreduce_f64(tot[i:i + 64]) for i in range(0, tot.size, 64)])
+        tot = a.session.allreduce(tot)                # task-sharded run: sum over the ranks
         return tot[0] / n_global, (tot[1:] / n_global if want_grad else None)
 
     def loss(self):          # -mean_i mean(ratio * adv) at theta'_i   (trpo_maml.py:135,150)

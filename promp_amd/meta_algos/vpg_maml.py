@@ -58,8 +58,7 @@ class VPGMAML(MAMLAlgo):
             def total(want_grad):
                 v, g = self._exploration_term(ctx, coeffs, adv0, want_grad)
                 tot = np.concatenate([[v], g if want_grad else []])
-                if sess.world > 1:
-                    tot = np.concatenate([ctx.allreduce_f64(tot[i:i + 64]) for i in range(0, tot.size, 64)])
+                tot = sess.allreduce(tot)                 # task-sharded run: sum over the ranks
                 return tot[0] / n_global, (tot[1:] if want_grad else None)
             _, st = ctx.meta_grad(0.0, eta, self.inner_kind, _lib.OUTER_LOGLIK)         # sums over the local tasks stay in the buffer
             x_val, x_grad_sum = total(True)

@@ -51,6 +51,10 @@ class SampleProcessor(object):
             self._private_session = p
         return p
 
+    def _stat_session(self):
+        """the session whose ranks share this processor's meta-batch (statistics over all tasks cross it)"""
+        return session_mod.current() or self._private_session or _OneRank
+
     def _process_on_device(self, paths_meta_batch):
         """-> (list[M] of SamplesData, per-path float64 stats) ; mutates the path dicts like the reference."""
         M = len(paths_meta_batch)
@@ -111,13 +115,37 @@ class SampleProcessor(object):
 
     def _log_path_stats(self, out, log=False, log_prefix=''):
         """samplers/base.py:135-149, from the per-path sums the device produced"""
-        und = out['path_undiscounted']
-        if log == 'reward':
-            logger.logkv(log_prefix + 'AverageReturn', np.mean(und))
-        elif log == 'all' or log is True:
-            logger.logkv(log_prefix + 'AverageDiscountedReturn', np.mean(out['path_returns0']))
-            logger.logkv(log_prefix + 'AverageReturn', np.mean(und))
-            logger.logkv(log_prefix + 'NumTrajs', len(und))
-            logger.logkv(log_prefix + 'StdReturn', np.std(und))
-            logger.logkv(log_prefix + 'MaxReturn', np.max(und))
-            logger.logkv(log_prefix + 'MinReturn', np.min(und))
+        _log_return_stats(self._stat_session(), out['path_undiscounted'], out['path_returns0'], log, log_prefix)
+
+
+class _OneRank(object):
+    """stands in for a session when none exists: nothing to reduce over"""
+    world = 1
+
+    @staticmethod
+    def allreduce(values, op='sum'):
+        return np.asarray(values, dtype=np.float64)
+
+
+def _log_return_stats(sess, und, disc, log, log_prefix):
+    """The six path statistics of samplers/base.py:135-149 over ALL paths of the meta-batch.  On one rank they are the NumPy
+    reductions the reference calls; a task-sharded run combines the ranks' counts, sums and extrema."""
+    if not (log == 'reward' or log == 'all' or log is True):
+        return
+    und, disc = np.asarray(und, dtype=np.float64), np.asarray(disc, dtype=np.float64)
+    if sess.world == 1:
+        n, mean, mean_disc, std, hi, lo = len(und), np.mean(und), np.mean(disc), np.std(und), np.max(und), np.min(und)
+    else:
+        n, s1, s2, sd = sess.allreduce([len(und), np.sum(und), np.sum(und * und), np.sum(disc)])
+        hi, neg_lo = sess.allreduce([np.max(und), -np.min(und)], 'max')
+        n, mean, mean_disc, lo = int(round(n)), s1 / n, sd / n, -neg_lo
+        std = np.sqrt(max(s2 / n - mean * mean, 0.0))
+    if log == 'reward':
+        logger.logkv(log_prefix + 'AverageReturn', mean)
+        return
+    logger.logkv(log_prefix + 'AverageDiscountedReturn', mean_disc)
+    logger.logkv(log_prefix + 'AverageReturn', mean)
+    logger.logkv(log_prefix + 'NumTrajs', n)
+    logger.logkv(log_prefix + 'StdReturn', std)
+    logger.logkv(log_prefix + 'MaxReturn', hi)
+    logger.logkv(log_prefix + 'MinReturn', lo)

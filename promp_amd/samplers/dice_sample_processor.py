@@ -16,8 +16,7 @@ from collections import OrderedDict
 import numpy as np
 
 from .. import _lib, session as session_mod
-from ..utils import logger
-from .base import SampleProcessor, _concat_tensor_dict_list
+from .base import SampleProcessor, _concat_tensor_dict_list, _log_return_stats
 
 
 class DiceSamplesData(session_mod.SamplesData):
@@ -26,7 +25,11 @@ class DiceSamplesData(session_mod.SamplesData):
 
 class DiceSampleProcessor(SampleProcessor):
     """Args (dice_sample_processor.py:25-47): baseline, max_path_length, discount=0.99, gae_lambda=1, normalize_adv=True,
-    positive_adv=False, return_baseline=None"""
+    positive_adv=False, return_baseline=None
+
+    Gap: return_baseline (the reference's optional second baseline, fitted on returns to add GAE advantages beside the DiCE
+    rewards, dice_sample_processor.py:113-124) is not built -- DICE-MAML does not read advantages; process_samples raises
+    NotImplementedError when it is given."""
 
     def __init__(self, baseline, max_path_length, discount=0.99, gae_lambda=1, normalize_adv=True, positive_adv=False,
                  return_baseline=None):
@@ -37,6 +40,15 @@ class DiceSampleProcessor(SampleProcessor):
                                                   positive_adv=positive_adv)
         self.max_path_length = max_path_length
         self.return_baseline = return_baseline
+
+    def _baseline_kind(self):
+        """The regression runs on the device, so the baseline must be one the device knows (the `kind` of LinearFeatureBaseline /
+        LinearTimeBaseline / ZeroBaseline).  Anything else would silently act as a zero baseline: refuse it instead."""
+        kind = getattr(self.baseline, 'kind', None)
+        if kind is None:
+            raise TypeError('%s has no device-side `kind`: the DiCE sample processor fits its baseline on the device and takes '
+                            'promp_amd.baselines.{LinearFeatureBaseline, LinearTimeBaseline, ZeroBaseline}' % type(self.baseline).__name__)
+        return kind
 
     # -- padded arrays ---------------------------------------------------------------------------------------------------
     def _pad(self, array, path_length):
@@ -74,7 +86,7 @@ class DiceSampleProcessor(SampleProcessor):
         slot = sess.next_slot()
         upload = sess.upload_flat(slot, fl)
         ctx = sess.ctx
-        kind = getattr(self.baseline, 'kind', _lib.BASELINE_ZERO)
+        kind = self._baseline_kind()
         ctx.process_samples(slot, discount=1.0, gae_lambda=1.0, normalize_adv=False, positive_adv=False, baseline_kind=kind,
                             reg_coeff=getattr(self.baseline, '_reg_coeff', 1e-5))
         if kind != _lib.BASELINE_ZERO:
@@ -123,17 +135,8 @@ class DiceSampleProcessor(SampleProcessor):
 
     def _log_dice_stats(self, paths, log=False, log_prefix=''):
         """dice_sample_processor.py:133-147 ('discounted return' = the sum of a path's discounted rewards)"""
-        disc = [np.sum(p['discounted_rewards']) for p in paths]
-        und = [np.sum(p['rewards']) for p in paths]
-        if log == 'reward':
-            logger.logkv(log_prefix + 'AverageReturn', np.mean(und))
-        elif log == 'all' or log is True:
-            logger.logkv(log_prefix + 'AverageDiscountedReturn', np.mean(disc))
-            logger.logkv(log_prefix + 'AverageReturn', np.mean(und))
-            logger.logkv(log_prefix + 'NumTrajs', len(paths))
-            logger.logkv(log_prefix + 'StdReturn', np.std(und))
-            logger.logkv(log_prefix + 'MaxReturn', np.max(und))
-            logger.logkv(log_prefix + 'MinReturn', np.min(und))
+        _log_return_stats(self._stat_session(), [np.sum(p['rewards']) for p in paths],
+                          [np.sum(p['discounted_rewards']) for p in paths], log, log_prefix)
 
 
 class DiceMetaSampleProcessor(DiceSampleProcessor):
@@ -147,7 +150,13 @@ class DiceMetaSampleProcessor(DiceSampleProcessor):
         samples_data_meta_batch, all_paths = self._process_meta_batch(paths_meta_batch)
         # rewards z-scored over the whole meta-batch (meta_sample_processor.py:40-44), here on the padded reward arrays
         overall = np.concatenate([sd['rewards'].reshape(-1) for sd in samples_data_meta_batch])
-        mean, std = np.mean(overall), np.std(overall)
+        sess = self._stat_session()
+        if sess.world == 1:
+            mean, std = np.mean(overall), np.std(overall)
+        else:           # task-sharded: the padded arrays of the other ranks' tasks enter through their moments
+            n, s1, s2 = sess.allreduce([overall.size, np.sum(overall, dtype=np.float64), np.sum(overall.astype(np.float64) ** 2)])
+            mean = s1 / n
+            std = np.sqrt(max(s2 / n - mean * mean, 0.0))
         for sd in samples_data_meta_batch:
             sd['adj_avg_rewards'] = (sd['rewards'] - mean) / (std + 1e-8)
         self._log_dice_stats(all_paths, log=log, log_prefix=log_prefix)

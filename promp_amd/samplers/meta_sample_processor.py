@@ -16,10 +16,13 @@ class MetaSampleProcessor(SampleProcessor):
         assert isinstance(paths_meta_batch, dict), 'paths must be a dict'
         assert self.baseline, 'baseline must be specified'
         samples_data_meta_batch, out = self._process_on_device(paths_meta_batch)
-        # rewards z-scored over the WHOLE meta-batch (E-MAML's exploration weight), from the per-path sums the device returns
-        n = sum(len(sd['rewards']) for sd in samples_data_meta_batch)
-        mean = np.sum(out['path_undiscounted']) / n
-        std = np.sqrt(max(np.sum(out['path_reward_sumsq']) / n - mean * mean, 0.0))
+        # rewards z-scored over the WHOLE meta-batch (E-MAML's exploration weight; meta_sample_processor.py:40-44 concatenates
+        # every task's rewards), from the per-path sums the device returns.  A task-sharded run holds only this rank's tasks:
+        # the three moments cross the ranks (one small all-reduce per sampling step).
+        n, s1, s2 = self._stat_session().allreduce([sum(len(sd['rewards']) for sd in samples_data_meta_batch),
+                                                    np.sum(out['path_undiscounted']), np.sum(out['path_reward_sumsq'])])
+        mean = s1 / n
+        std = np.sqrt(max(s2 / n - mean * mean, 0.0))
         for sd in samples_data_meta_batch:
             sd['adj_avg_rewards'] = (sd['rewards'] - mean) / (std + 1e-8)
         self._log_path_stats(out, log=log, log_prefix=log_prefix)

@@ -45,7 +45,10 @@ def _graft(tree, key_path, value):
 class _StepTables(object):
     """[environment, time, ...] tables of one rollout, written a column per environment step.
 
-    A table is allocated the first time its key shows up (its per-step shape and dtype are taken from that first value);
+    A table is allocated the first time its key shows up (its per-step shape is taken from that first value).  Its dtype
+    follows NumPy's promotion over everything written so far, as `np.asarray` over the reference's per-step lists does
+    (meta_sampler.py:100-125 appends Python scalars and converts at the end): an environment that returns the int 0 on some
+    steps and floats on others (MetaPointEnvCorner's sparse reward) gets a float table, not a truncating int one.
     `fill[e]` is the length of environment e's episode in progress."""
 
     def __init__(self, n_envs, horizon):
@@ -54,32 +57,37 @@ class _StepTables(object):
         self._tables = {}                       # key path (tuple) -> ndarray [n_envs, horizon, ...]
         self._rows = np.arange(self.n_envs)
 
-    def _table(self, key_path, sample):
+    def _table(self, key_path, column):
+        """the table of `key_path`, wide enough in dtype for `column` ([n_envs, ...])"""
         table = self._tables.get(key_path)
         if table is None:
-            sample = np.asarray(sample)
-            table = np.zeros((self.n_envs, self.horizon) + sample.shape, dtype=sample.dtype)
+            table = np.zeros((self.n_envs, self.horizon) + column.shape[1:], dtype=column.dtype)
             self._tables[key_path] = table
+        elif table.dtype != column.dtype:
+            wide = np.result_type(table.dtype, column.dtype)
+            if wide != table.dtype:
+                table = table.astype(wide)
+                self._tables[key_path] = table
         return table
 
     def put(self, key_path, column):
         """column: one value per environment, for the current time step of each"""
         column = np.asarray(column)
-        self._table(key_path, column[0])[self._rows, self.fill] = column
+        self._table(key_path, column)[self._rows, self.fill] = column
 
     def put_infos(self, group, infos):
         """infos: one (possibly nested, possibly empty) dict per environment"""
         if not infos or not infos[0]:
             return
-        for key_path, first in _leaves(infos[0]):
-            table = self._table((group,) + key_path, first)
+        for key_path, _ in _leaves(infos[0]):
             values = []
             for info in infos:
                 node = info
                 for key in key_path:
                     node = node[key]
                 values.append(node)
-            table[self._rows, self.fill] = np.asarray(values)
+            column = np.asarray(values)
+            self._table((group,) + key_path, column)[self._rows, self.fill] = column
 
     def advance(self):
         self.fill += 1

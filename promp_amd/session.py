@@ -48,7 +48,23 @@ class DeviceSession:
         self.min_std = 1e-6
         self._upload_counter = 0      # never reset: a SamplesData from before a context re-creation can never match a later upload
         self._comm_ready = False      # the RCCL communicator is created once per session and moved across context re-creations
+        # host-side statistics that span the whole meta-batch (reward moments, path statistics, E-MAML sums) cross the ranks
+        # through allreduce(); `collective` replaces the library's RCCL communicator by any callable
+        # (float64 array, 'sum' | 'max') -> array, e.g. a gloo all_reduce (tests, CPU-only launches)
+        self.collective = None
         _current = self
+
+    def allreduce(self, values, op='sum'):
+        """element-wise sum / max over the ranks of a small float64 array (identity on one rank)"""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        if self.world == 1:
+            return values
+        if self.collective is not None:
+            return np.asarray(self.collective(values.copy(), op), dtype=np.float64).reshape(values.shape)
+        ctx = self.ensure()
+        flat = values.reshape(-1)
+        out = np.concatenate([ctx.allreduce_f64(flat[i:i + 64], op) for i in range(0, flat.size, 64)]) if flat.size else flat
+        return out.reshape(values.shape)
 
     def set_num_inner_steps(self, K):
         if K != self.K:
@@ -96,7 +112,7 @@ class DeviceSession:
                 self.ctx.set_adam_state(*self.adam)
             if self.task_thetas is not None:
                 self.ctx.set_task_thetas(self.task_thetas)
-            if self.world > 1 and not self._comm_ready:
+            if self.world > 1 and not self._comm_ready and self.collective is None:
                 from . import comm
                 self.ctx.comm_init(self.rank, self.world, comm.exchange_unique_id(self.rank, self.world, _lib.comm_unique_id))
                 self._comm_ready = True

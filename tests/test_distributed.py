@@ -168,3 +168,99 @@ open(os.path.join(%r, 'ok%%d' %% rank), 'w').write('1')
            '--master-port', '29641', str(script)]
     subprocess.run(cmd, check=True, timeout=600, cwd=ROOT)
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
+
+
+STATS_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+from collections import OrderedDict
+import numpy as np
+import torch, torch.distributed as dist
+from promp_amd import _lib, session
+from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+from promp_amd.samplers.dice_sample_processor import DiceMetaSampleProcessor
+from promp_amd.utils import logger
+from tests import devlib, helpers
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+os.environ['PROMP_EMU_CUS'] = '2'
+_lib.set_library_for_testing(devlib.emu_library())
+meta, paths, g = helpers.load_sample_proc('ragged')
+M = len(paths)
+mine = [i for i in range(M) if i %% world == rank]            # task i -> rank i %% world
+keys = list(paths.keys())
+sub = OrderedDict((j, paths[keys[i]]) for j, i in enumerate(mine))
+first = sub[0][0]
+O, A = first['observations'].shape[1], first['actions'].shape[1]
+
+def gloo(values, op):                                          # stands in for promp_allreduce_f64 (RCCL needs GPUs)
+    t = torch.from_numpy(values)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
+    return t.numpy()
+
+sess = session.DeviceSession(len(mine), O, A, (32, 32), 1, n_tasks_global=M, rank=rank, world=world)
+sess.collective = gloo
+logged = {}
+logger.logkv = lambda k, v: logged.__setitem__(k, v)
+import promp_amd.samplers.base as sb
+sb.logger.logkv = logger.logkv
+proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), **meta['kwargs'])
+out = proc.process_samples(sub, log='all', log_prefix='Step_0-')
+T = max(len(p['rewards']) for pl in paths.values() for p in pl)
+dproc = DiceMetaSampleProcessor(baseline=LinearFeatureBaseline(), max_path_length=T, discount=0.99)
+dlogged = {}
+sb.logger.logkv = lambda k, v: dlogged.__setitem__(k, v)
+dout = dproc.process_samples(OrderedDict((j, [dict(p) for p in paths[keys[i]]]) for j, i in enumerate(mine)), log='all', log_prefix='D-')
+np.savez(os.environ['OUT'] + '.%%d.npz' %% rank, tasks=np.array(mine),
+         adj=np.concatenate([sd['adj_avg_rewards'] for sd in out]),
+         dice_adj=np.concatenate([sd['adj_avg_rewards'].reshape(-1) for sd in dout]),
+         stat_keys=np.array(sorted(logged)), stat_vals=np.array([logged[k] for k in sorted(logged)], dtype=np.float64),
+         dstat_keys=np.array(sorted(dlogged)), dstat_vals=np.array([dlogged[k] for k in sorted(dlogged)], dtype=np.float64))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sample_statistics_span_the_whole_meta_batch(tmp_path):
+    """SURVEY K6 / K7 on two gloo ranks: each rank processes its shard of the tasks (the library's kernels, SIMT-interpreter
+    build); adj_avg_rewards (E-MAML's weight, meta_sample_processor.py:40-44) and the six logged path statistics
+    (samplers/base.py:135-149) must be those of the WHOLE meta-batch -- equal to the reference's outputs in the golden
+    fixture and to a one-process run -- for MetaSampleProcessor and DiceMetaSampleProcessor alike."""
+    from tests import devlib, helpers
+    out = str(tmp_path / 'stats')
+    script = tmp_path / 'worker.py'
+    script.write_text(STATS_WORKER % dict(root=ROOT))
+    devlib.emu_library()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29661', str(script)]
+    subprocess.run(cmd, check=True, env=dict(os.environ, OUT=out, MASTER_ADDR='127.0.0.1'), timeout=900, cwd=ROOT)
+    meta, paths, g = helpers.load_sample_proc('ragged')
+    keys = list(paths.keys())
+    n_rows = [sum(len(p['rewards']) for p in paths[k]) for k in keys]
+    offs = np.concatenate([[0], np.cumsum(n_rows)])
+    # the one-process reference for the logged statistics and the DiCE processor
+    und = np.array([np.sum(np.asarray(p['rewards'], dtype=np.float64)) for k in keys for p in paths[k]])
+    disc = np.array([np.sum(np.asarray(p['rewards'], dtype=np.float64) * 0.99 ** np.arange(len(p['rewards']))) for k in keys for p in paths[k]])
+    T = max(len(p['rewards']) for pl in paths.values() for p in pl)
+    padded = np.concatenate([np.pad(np.asarray(p['rewards'], dtype=np.float64), (0, T - len(p['rewards']))) for k in keys for p in paths[k]])
+    pads_per_task = [len(paths[k]) * T for k in keys]
+    poffs = np.concatenate([[0], np.cumsum(pads_per_task)])
+    dice_ref = (padded - padded.mean()) / (padded.std() + 1e-8)
+    for rank in (0, 1):
+        r = np.load(out + '.%d.npz' % rank)
+        want = np.concatenate([g['adj_avg_rewards'][offs[i]:offs[i + 1]] for i in r['tasks']])
+        np.testing.assert_allclose(r['adj'], want, rtol=1e-4, atol=1e-5)      # (the one-process tolerance: float32 rewards)
+        stats = dict(zip(r['stat_keys'], r['stat_vals']))
+        assert stats['Step_0-NumTrajs'] == len(und)
+        np.testing.assert_allclose(stats['Step_0-AverageReturn'], und.mean(), rtol=1e-10)
+        np.testing.assert_allclose(stats['Step_0-StdReturn'], und.std(), rtol=1e-8)
+        np.testing.assert_allclose(stats['Step_0-MaxReturn'], und.max(), rtol=1e-12)
+        np.testing.assert_allclose(stats['Step_0-MinReturn'], und.min(), rtol=1e-12)
+        disc_ret = np.array([np.sum(np.asarray(p['rewards'], dtype=np.float64) * meta['kwargs'].get('discount', 0.99) ** np.arange(len(p['rewards']))) for k in keys for p in paths[k]])
+        np.testing.assert_allclose(stats['Step_0-AverageDiscountedReturn'], disc_ret.mean(), rtol=1e-9)
+        dwant = np.concatenate([dice_ref[poffs[i]:poffs[i + 1]] for i in r['tasks']])
+        np.testing.assert_allclose(r['dice_adj'], dwant, rtol=1e-9, atol=1e-10)
+        dstats = dict(zip(r['dstat_keys'], r['dstat_vals']))
+        np.testing.assert_allclose(dstats['D-AverageReturn'], und.mean(), rtol=1e-6)      # (path sums of float32 rewards, as the reference's)
+        np.testing.assert_allclose(dstats['D-AverageDiscountedReturn'], disc.mean(), rtol=1e-6)
+        assert dstats['D-NumTrajs'] == len(und)
