@@ -56,7 +56,64 @@ PROMP_DEV void bf16_split3(const float (&x)[8], bf16x8 (&t)[3]) {
         t[2][e] = (__bf16)r2;
     }
 }
+// ---- BF16 fragments as raw 32-bit words ---------------------------------------------------------------------------------
+// The pass kernel moves its BF16 operands around as words of two bf16 (low half = the element with the lower index) and turns
+// them into bf16 vectors only at the MFMA call, by whole-vector bit casts (building a bf16x8 element by element from 16-bit
+// lanes is miscompiled by hipcc 7.2: tools/micro/tr16_wgrad_probe.hip).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+PROMP_DEV f32x4 mfma16_bf16w(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// D[32x32] += A[32x16] * B[16x32] on the BF16 pipe.  lane l holds A[i = l & 31][k = 8 (l >> 5) .. + 7] and
+// B[k = 8 (l >> 5) .. + 7][j = l & 31]; D as mfma32: col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+// (layout confirmed on the device: profiles/r03_tr16_wgrad_probe.txt).
+PROMP_DEV f32x16 mfma32_bf16w(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: every lane of a 16-lane group names an 8-byte chunk (4 bf16); with the 16 chunks read as the rows-major
+// 4 x 16 matrix M[p / 4][4 (p % 4) .. + 3] = chunk of lane p, lane i receives column i: elements M[0..3][i]
+// (= element i % 4 of the chunks of lanes i / 4, 4 + i / 4, 8 + i / 4, 12 + i / 4).  8-byte aligned addresses only.
+PROMP_DEV u32x2 lds_tr16(const void* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+// Error-compensated 3-way BF16 split of two float32 values: word t holds term t of x0 (low half) and of x1 (high half);
+// x = t0 + t1 + t2 up to 2^-24 |x| (round to nearest even, residuals exact in float32).
+PROMP_DEV void bf16_split3_pair(float x0, float x1, unsigned (&w)[3]) {
+    f32x2 r;
+    r[0] = x0;
+    r[1] = x1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const bf16x2 h = __builtin_convertvector(r, bf16x2);
+        w[t] = __builtin_bit_cast(unsigned, h);
+        if (t < 2) r -= __builtin_convertvector(h, f32x2);
+    }
+}
 PROMP_DEV float shfl_xor_f32(float v, int m) { return __shfl_xor(v, m, 64); }
+// Cross-lane sums on the vector ALU (no LDS round trip, unlike ds_bpermute):
+//   fold_groups16: v + the values of the same lane index in the other three 16-lane groups (v_permlane32_swap / v_permlane16_swap:
+//                  the swap of a register with itself leaves the two halves / row pairs side by side)
+//   row16_sum    : the sum over the 16 lanes of a group, in every lane of it (DPP quad permutes and row mirrors)
+PROMP_DEV float fold_groups16(float v) {
+    // (inline assembly: hipcc 7.2 drops the second result of __builtin_amdgcn_permlane{16,32}_swap -- it adds the first one to
+    //  itself; checked on the device.  The s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see here.)
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    const float w = a + b;
+    float c = w, d = w;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c), "+v"(d));
+    return c + d;
+}
+PROMP_DEV float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+    return v;
+}
 PROMP_DEV double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
 PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); }
 PROMP_DEV double shfl_idx_f64(double v, int l) { return __shfl(v, l, 64); }
@@ -119,6 +176,23 @@ PROMP_DEV f32x4 pin_agpr(f32x4 v) {
     asm volatile("" : "+a"(v));
     return v;
 }
+// Pins: zero-instruction pass-throughs the optimiser cannot see through.  A value that went through one exists, in a register of
+// the named file, at that point of the instruction stream; together with sched_fence() they decide which stage of a software
+// pipeline a piece of pure arithmetic belongs to (instruction selection otherwise sinks it to its first use, across any
+// scheduling barrier).  pin_v: vector register; pin_a: accumulator register (MFMA accumulators that live across iterations).
+PROMP_DEV void pin_v(float& x) { asm volatile("" : "+v"(x)); }
+PROMP_DEV void pin_v(unsigned& x) { asm volatile("" : "+v"(x)); }
+PROMP_DEV void pin_v(f32x4& x) { asm volatile("" : "+v"(x)); }
+PROMP_DEV void pin_v(u32x4& x) { asm volatile("" : "+v"(x)); }
+PROMP_DEV void pin_a(f32x4& x) { asm volatile("" : "+a"(x)); }
+PROMP_DEV void pin_a(f32x16& x) { asm volatile("" : "+a"(x)); }
+// Instruction-group pipelines (scheduling hints, no code): the region that holds them is laid out as the sequence of groups the
+// calls name, in call order.  One matrix instruction followed by `n_valu` vector instructions (and a DS read when `ds`): the
+// in-order issue of a single wave then runs the vector work of one instruction stream in the shadow of the other's MFMAs.
+#define PROMP_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define PROMP_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
+#define PROMP_SCHED_DSREAD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define PROMP_SCHED_DSWRITE(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0)
 PROMP_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate: 0..3)
 PROMP_DEV void wave_priority(int p) {

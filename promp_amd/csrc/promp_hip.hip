@@ -2,6 +2,7 @@
 // See include/promp_hip.h for the contract.  gfx950 only; built by __graft_entry__.build():
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC promp_hip.hip -lrccl -o libpromp_hip.so
 #include "promp_kernels_chain.h"
+#include "promp_kernels_pass.h"
 #include "promp_kernels_policy.h"
 #include "promp_kernels_policy_wide.h"
 #include "promp_kernels_sample.h"
@@ -52,8 +53,7 @@ struct StepData {
     int n_paths = 0, n_rows = 0;
     int n_work[2] = {0, 0};            // [0]: one workgroup per CU (wide passes, gram, fit), [1]: two per CU (k_normalize)
     int rollout_B = 0, rollout_T = 0;  // environments per task / horizon of a device-side rollout in progress (promp_begin_rollout)
-    int n_pwork = 0;                   // k_fwd_bwd workgroups (wave-granular PassWork table)
-    int n_chain_wg = 0;                // k_chain_hvp workgroups (segment table)
+    int n_chain_wg = 0;                // workgroups of the register-chained kernels k_pass / k_chain_hvp (segment table)
     bool has_policy = false, processed = false, has_adv = false;
     int ls_per_row = 0;
     int feat_dim = 0;
@@ -70,14 +70,13 @@ struct StepData {
     float* hcache = nullptr;           // primal cache (promp_kernels_chain.h: chain_cache_row), allocated on first use
     int *path_row_offsets = nullptr, *path_task = nullptr, *row_t = nullptr;
     int *task_row_offsets = nullptr, *task_path_offsets = nullptr;
-    int* task_wg_offsets[3] = {nullptr, nullptr, nullptr};   // [2]: partial slots of the k_fwd_bwd table per task
-    ChainSeg* chain_segs = nullptr;                          // segment table of k_chain_hvp
+    int* task_wg_offsets[2] = {nullptr, nullptr};
+    ChainSeg* chain_segs = nullptr;                          // segment table of k_pass / k_chain_hvp
     int* chain_wg_offsets = nullptr;                         // [workgroups+1]
     int* chain_slot_offsets = nullptr;                       // [tasks+1]: partial rows (= segments) of each task
     double *path_ret0 = nullptr, *path_undisc = nullptr, *path_rsq = nullptr, *path_mom = nullptr;
     double* coeffs = nullptr;
     WorkItem* work[2] = {nullptr, nullptr};
-    PassWork* pwork = nullptr;
     // second-stream sample processing (promp_process_samples of steps >= 1, see stage_a_stream):
     hipEvent_t ev_use = nullptr;       // main stream: the last enqueued work that reads or writes this step's slabs
     hipEvent_t ev_done = nullptr;      // side stream: the step's processed outputs are complete
@@ -89,18 +88,12 @@ struct StepData {
     std::vector<int> lay_tpo, lay_pro; // the offsets the set's device-side tables were built from (set_step_layout)
 };
 
-// waves per workgroup of k_chain_hvp (one per SIMD: 512 registers per lane)
+// waves per workgroup of k_pass / k_chain_hvp (one per SIMD: 512 registers per lane)
 constexpr int CHAIN_NW_HVP = 4;
 // layer-1 k-steps k_chain_hvp is instantiated for (4 observation entries per step, zero-padded)
 int chain_ksteps(int obs_dim) { return obs_dim <= 8 ? 2 : obs_dim <= 20 ? 5 : 8; }
-// k_fwd_bwd instances: the first layer's k-steps are a compile-time constant for the widths the BASELINE configs use
-// (17..20 observations: 5 steps); every other width takes the runtime loop (KS = 0)
-#ifdef PROMP_NO_KS1
-int pass_ksteps(int) { return 0; }
-#else
-int pass_ksteps(int obs_dim) { return (obs_dim + 3) / 4 == 5 ? 5 : 0; }
-#endif
-#define PROMP_PASS_ALL(X) X(1, 1, 0) X(1, 2, 0) X(2, 1, 0) X(2, 2, 0) X(1, 1, 5) X(1, 2, 5) X(2, 1, 5) X(2, 2, 5)
+// k_pass instances: (hidden_0 / 16, hidden_1 / 16)
+#define PROMP_PASS_ALL(X) X(2, 2) X(2, 4) X(4, 2) X(4, 4)
 #define PROMP_CHAIN_ALL(X) X(2, 2, 2) X(2, 2, 5) X(2, 2, 8) X(2, 4, 2) X(2, 4, 5) X(2, 4, 8) X(4, 2, 2) X(4, 2, 5) X(4, 2, 8) X(4, 4, 2) X(4, 4, 5) X(4, 4, 8)
 
 struct ProfSlot {
@@ -290,7 +283,7 @@ int prof_collect(promp_ctx* c) {
 // ---- launches ----------------------------------------------------------------------------------
 // One policy pass over a step's slabs plus the per-task reduction that consumes it:
 //   red_mode RED_STEP / RED_OUTER / RED_HVP / RED_PLAIN / RED_SCAL (promp_kernels_chain.h).
-// k_chain_hvp does both in one launch; k_fwd_bwd and the cooperative kernels (hidden 128 / wide observations) are
+// k_chain_hvp can do both in one launch; k_pass and the cooperative kernels (hidden 128 / wide observations) are
 // followed by k_reduce_task.
 int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long long theta_stride, int loss_kind,
                 float clip_eps, int clip_ls, float klw, bool fwd_only, int red_mode, const float* cur, long long cur_stride,
@@ -309,7 +302,6 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
-    a.pwork = S.pwork;
     a.segs = S.chain_segs; a.wg_seg_offsets = S.chain_wg_offsets;
     a.theta = theta; a.theta_task_stride = theta_stride;
     a.vdir = c->vbuf;
@@ -355,12 +347,12 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         HIPCHECK(hipGetLastError());
         if (a.fuse_reduce) return prof_end(c, id);
     } else {
-        const int b1 = c->d.hidden1 / 32, b2 = c->d.hidden2 / 32, ks1 = pass_ksteps(c->d.obs_dim);
-#define PROMP_PASS_CASE(B1, B2, KS)                                                                                                    \
-    if (b1 == B1 && b2 == B2 && ks1 == KS) {                                                                                           \
-        if (fwd_only) { auto k = k_fwd_bwd<B1, B2, 8, false, KS>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
-        else if (cache == 1) { auto k = k_fwd_bwd<B1, B2, 8, true, KS, true>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); } \
-        else { auto k = k_fwd_bwd<B1, B2, 8, true, KS>; PROMP_LAUNCH(k, dim3(S.n_pwork), 512, c->smem_fwd, c->stream, a); }          \
+        const int n1 = c->d.hidden1 / 16, n2 = c->d.hidden2 / 16;
+#define PROMP_PASS_CASE(N1, N2)                                                                                                          \
+    if (n1 == N1 && n2 == N2) {                                                                                                          \
+        if (fwd_only) { auto k = k_pass<N1, N2, CHAIN_NW_HVP, false, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_fwd, c->stream, a); }   \
+        else if (cache == 1) { auto k = k_pass<N1, N2, CHAIN_NW_HVP, true, true>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_fwd, c->stream, a); } \
+        else { auto k = k_pass<N1, N2, CHAIN_NW_HVP, true, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 64 * CHAIN_NW_HVP, c->smem_fwd, c->stream, a); }            \
     }
         PROMP_PASS_ALL(PROMP_PASS_CASE)
 #undef PROMP_PASS_CASE
@@ -369,8 +361,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     if (prof_end(c, id)) return -2;
     ReduceArgs r;
     r.partials = c->partials; r.partial_stride = c->partial_stride;
-    // k_fwd_bwd writes wave-granular slots (table 2), k_chain_hvp one row per segment
-    r.task_wg_offsets = c->wide ? S.task_wg_offsets[0] : hvp ? S.chain_slot_offsets : S.task_wg_offsets[2];
+    // the register-chained kernels write one row per segment
+    r.task_wg_offsets = c->wide ? S.task_wg_offsets[0] : S.chain_slot_offsets;
     r.NP = c->NP;
     r.step_sizes = c->step_sizes; r.mode = red_mode;
     r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
@@ -493,7 +485,7 @@ int upload_eta(promp_ctx* c, const float* eta) {
 
 void free_step(StepData& S) {
     void* ptrs[] = {S.hcache, S.dice_rw, S.dice_c, S.dice_u, S.dice_tmp, S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
-                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.task_wg_offsets[2], S.pwork, S.chain_segs, S.chain_wg_offsets,
+                    S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.chain_segs, S.chain_wg_offsets,
                     S.chain_slot_offsets, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
     for (void* p : ptrs)
@@ -511,7 +503,6 @@ int alloc_step(promp_ctx* c, StepData& S) {
     rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
     rc |= dev_alloc(&S.task_row_offsets, (size_t)M + 1); rc |= dev_alloc(&S.task_path_offsets, (size_t)M + 1);
     rc |= dev_alloc(&S.task_wg_offsets[0], (size_t)M + 1); rc |= dev_alloc(&S.task_wg_offsets[1], (size_t)M + 1);
-    rc |= dev_alloc(&S.task_wg_offsets[2], (size_t)M + 1); rc |= dev_alloc(&S.pwork, (size_t)c->max_work);
     rc |= dev_alloc(&S.chain_segs, (size_t)c->max_work); rc |= dev_alloc(&S.chain_wg_offsets, (size_t)c->max_work + 1);
     rc |= dev_alloc(&S.chain_slot_offsets, (size_t)M + 1);
     rc |= dev_alloc(&S.path_ret0, P); rc |= dev_alloc(&S.path_undisc, P); rc |= dev_alloc(&S.path_rsq, P);
@@ -582,7 +573,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         //  sample processing only -- the policy passes reject them at launch -- and must not fail here on LDS they never use)
         promp_dims pd = *dims;
         if (pd.obs_dim > 32) pd.obs_dim = 32;
-        c->smem_fwd = sizeof(float) * (size_t)make_layout_wave(32, dims->hidden1, dims->hidden2, 8, param_count(&pd)).total;
+        c->smem_fwd = sizeof(float) * (size_t)pass_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, param_count(&pd)).total;
         c->smem_hvp = sizeof(float) * (size_t)chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total;
     }
     if (c->smem_hvp > 160 * 1024 || c->smem_fwd > 160 * 1024) {
@@ -599,10 +590,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     }
         PROMP_CHAIN_ALL(PROMP_CHAIN_ATTR)
 #undef PROMP_CHAIN_ATTR
-#define PROMP_PASS_ATTR(B1, B2, KS)                                                                                          \
+#define PROMP_PASS_ATTR(N1, N2)                                                                                             \
     {                                                                                                                     \
-        auto c0 = k_fwd_bwd<B1, B2, 8, true, KS>; auto c1 = k_fwd_bwd<B1, B2, 8, false, KS>;                               \
-        auto cs = k_fwd_bwd<B1, B2, 8, true, KS, true>;                                                                    \
+        auto c0 = k_pass<N1, N2, CHAIN_NW_HVP, true, false>; auto c1 = k_pass<N1, N2, CHAIN_NW_HVP, false, false>;         \
+        auto cs = k_pass<N1, N2, CHAIN_NW_HVP, true, true>;                                                                \
         HIPCHECK(hipFuncSetAttribute((const void*)cs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         HIPCHECK(hipFuncSetAttribute((const void*)c0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         HIPCHECK(hipFuncSetAttribute((const void*)c1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
@@ -744,7 +735,7 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
     std::vector<WorkItem> work[2];
     std::vector<int> two[2];
     for (int t = 0; t < 2; ++t) {
-        // table 0: k_hvp and k_fwd_bwd (one workgroup per CU: measured faster than two shorter ones, the parameter
+        // table 0: the cooperative pass kernels (one workgroup per CU: measured faster than two shorter ones, the parameter
         // staging and the end-of-kernel reduction amortise over twice the tiles); table 1: the sample-processing kernels
         int target = (t + 1) * c->n_cus;
         two[t].assign(M + 1, 0);
@@ -842,100 +833,19 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
             if (T.slot_off[i + 1] < T.slot_off[i]) T.slot_off[i + 1] = T.slot_off[i];
         if ((int)T.segs.size() > c->max_work) return fail(-5, "internal: segment table overflow (%zu > %d)", T.segs.size(), c->max_work);
     }
-    // k_fwd_bwd: waves (8 per CU-resident workgroup) shared out over tasks in proportion to their tiles, largest remainder;
-    // a workgroup serves at most two tasks, which holds when every task gets >= 8 waves -- otherwise one task per
-    // workgroup (the WorkItem split above, re-expressed wave by wave)
-    std::vector<PassWork> pwork;
-    std::vector<int> slot_off(M + 1, 0);
-    {
-        const int NWV = 8;
-        const long long total_waves = (long long)NWV * c->n_cus;
-        std::vector<long long> nwv(M), rem(M);
-        long long used = 0;
-        bool fine = true;
-        for (int i = 0; i < M; ++i) {
-            const long long num = tiles[i] * total_waves;
-            nwv[i] = num / total_tiles;
-            rem[i] = num % total_tiles;
-            if (nwv[i] > tiles[i]) { nwv[i] = tiles[i]; rem[i] = 0; }
-            used += nwv[i];
-        }
-        while (used < total_waves) {
-            int best = -1;
-            for (int i = 0; i < M; ++i)
-                if (nwv[i] < tiles[i] && rem[i] > 0 && (best < 0 || rem[i] > rem[best])) best = i;
-            if (best < 0) break;
-            nwv[best] += 1;
-            rem[best] = 0;
-            used += 1;
-        }
-        for (int i = 0; i < M; ++i) fine = fine && nwv[i] >= NWV;
-        auto seg_of = [&](PassWork& w, int sg, int task, int wave0, int wstride) {
-            w.task[sg] = task; w.row0[sg] = tro[task]; w.nrows[sg] = tro[task + 1] - tro[task]; w.ntiles[sg] = tiles[task];
-            w.wave0[sg] = wave0; w.wstride[sg] = wstride;
-        };
-        int nslots = 0;
-        if (fine) {
-            // lay the tasks' waves end to end and cut every 8
-            int task = 0, done = 0;   // `done` waves of `task` already placed
-            while (task < M) {
-                PassWork w{};
-                int room = NWV;
-                const int take0 = (int)std::min<long long>(room, nwv[task] - done);
-                seg_of(w, 0, task, done, (int)nwv[task]);
-                w.slot[0] = nslots++;
-                slot_off[task + 1] = nslots;
-                w.nw0 = take0;
-                done += take0; room -= take0;
-                if (done == nwv[task]) { ++task; done = 0; }
-                if (room > 0 && task < M) {
-                    const int take1 = (int)std::min<long long>(room, nwv[task]);   // nwv >= 8 > room: never completes the task
-                    seg_of(w, 1, task, 0, (int)nwv[task]);
-                    w.slot[1] = nslots++;
-                    slot_off[task + 1] = nslots;
-                    done = take1;
-                } else {
-                    // full workgroup, or a short last one: its spare waves form an empty segment with a scratch slot
-                    seg_of(w, 1, w.task[0], 0, 1);
-                    w.ntiles[1] = 0;
-                    w.slot[1] = w.nw0 < NWV ? -1 : w.slot[0];
-                }
-                pwork.push_back(w);
-            }
-            for (auto& w : pwork)
-                if (w.slot[1] < 0) w.slot[1] = nslots;   // one row past every task's range: nobody reads it
-        } else {
-            for (int i = 0; i < M; ++i) {
-                const int wgs = two[0][i + 1] - two[0][i];
-                for (int g = 0; g < wgs; ++g) {
-                    PassWork w{};
-                    seg_of(w, 0, i, NWV * g, NWV * wgs);
-                    seg_of(w, 1, i, 0, 1);
-                    w.ntiles[1] = 0;
-                    w.nw0 = NWV;
-                    w.slot[0] = w.slot[1] = nslots++;
-                    pwork.push_back(w);
-                }
-                slot_off[i + 1] = nslots;
-            }
-        }
-        if ((int)pwork.size() > c->max_work || nslots + 1 > c->max_work)
-            return fail(-5, "internal: pass work table overflow (%zu items, %d slots > %d)", pwork.size(), nslots, c->max_work);
-    }
     S.n_paths = n_paths; S.n_rows = R; S.n_work[0] = (int)work[0].size(); S.n_work[1] = (int)work[1].size();
     S.processed = false; S.has_adv = false; S.has_rew64 = false; S.has_dice = false;
     // every source below lives in `keep` (asynchronous mode: until the set is staged again)
     struct Keep {
-        std::vector<int> pro, tpo, path_task, row_t, tro, wg_off, slot_chain, slot_pass, two[2];
+        std::vector<int> pro, tpo, path_task, row_t, tro, wg_off, slot_chain, two[2];
         std::vector<ChainSeg> segs;
-        std::vector<PassWork> pwork;
         std::vector<WorkItem> work[2];
     };
     auto keep = std::make_shared<Keep>();
     keep->pro.assign(pro, pro + n_paths + 1); keep->tpo.assign(tpo, tpo + M + 1);
     keep->path_task = std::move(path_task); keep->row_t = std::move(row_t); keep->tro = std::move(tro);
-    keep->wg_off = std::move(T.wg_off); keep->slot_chain = std::move(T.slot_off); keep->slot_pass = std::move(slot_off);
-    keep->segs = std::move(T.segs); keep->pwork = std::move(pwork);
+    keep->wg_off = std::move(T.wg_off); keep->slot_chain = std::move(T.slot_off);
+    keep->segs = std::move(T.segs);
     for (int t = 0; t < 2; ++t) { keep->two[t] = std::move(two[t]); keep->work[t] = std::move(work[t]); }
     const Keep& k = *keep;
     HIPCHECK(hipMemcpyAsync(S.path_row_offsets, k.pro.data(), sizeof(int) * (n_paths + 1), hipMemcpyHostToDevice, st));
@@ -944,12 +854,9 @@ static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async
     HIPCHECK(hipMemcpyAsync(S.row_t, k.row_t.data(), sizeof(int) * R, hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.task_row_offsets, k.tro.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
     S.n_chain_wg = (int)k.wg_off.size() - 1;
-    S.n_pwork = (int)k.pwork.size();
     HIPCHECK(hipMemcpyAsync(S.chain_segs, k.segs.data(), sizeof(ChainSeg) * k.segs.size(), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.chain_wg_offsets, k.wg_off.data(), sizeof(int) * k.wg_off.size(), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(S.chain_slot_offsets, k.slot_chain.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[2], k.slot_pass.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipMemcpyAsync(S.pwork, k.pwork.data(), sizeof(PassWork) * k.pwork.size(), hipMemcpyHostToDevice, st));
     for (int t = 0; t < 2; ++t) {
         HIPCHECK(hipMemcpyAsync(S.task_wg_offsets[t], k.two[t].data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice, st));
         HIPCHECK(hipMemcpyAsync(S.work[t], k.work[t].data(), sizeof(WorkItem) * k.work[t].size(), hipMemcpyHostToDevice, st));

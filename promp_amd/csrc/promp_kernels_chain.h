@@ -1,9 +1,9 @@
 // promp_kernels_chain.h -- per-task Gaussian-MLP policy passes for hidden widths <= 64 (reference rows a8-a13).
 //
-//   k_chain_pass : objective + mean KL (+ gradient) of the tasks' slabs                      (K8-K11)
 //   k_chain_hvp  : out = -H v + kl_weight * grad KL, H = Hessian of the inner objective      (K12, K13)
-// both followed, inside the same launch, by the fixed-order sum of a task's partial rows and the update that
-// consumes it (inner SGD step / multiplier update), done by whichever workgroup of the task finishes last.
+// optionally followed, inside the same launch, by the fixed-order sum of a task's partial rows and the update that
+// consumes it (multiplier update), done by whichever workgroup of the task finishes last.
+// (The first-order pass k_pass, promp_kernels_pass.h, shares this file's segment table, primal cache and reductions.)
 //
 // Arithmetic follows oracle/promp.py (which restates meta_algos/pro_mp.py:59-155, meta_algos/base.py:192-215,
 // policies/networks/mlp.py:65-119, policies/distributions/diagonal_gaussian.py:16-109 of the reference).
@@ -51,7 +51,7 @@ struct WorkItem {
 // each way.  One block per 16-row tile, in the R-operator pass's operand order (a lane's four units contiguous):
 //     [c < NC1][sample 16][unit 16]  hidden_0 activations     [c < NC2][sample 16][unit 16]  hidden_1 activations
 //     [sample 16][action 8]          means
-//     [c < NC1][sample 16][unit 16]  W2 dZ2^T, scaled by PROMP_TANH_PRESCALE (the gradient pass's W2 copy carries that factor)
+//     [c < NC1][sample 16][unit 16]  W2 dZ2^T
 // The block of tile t of a task starts at "row" row0(task) + 16 t + 16 task: a task's last tile may be partial, the 16
 // spare rows per task keep the next task's first block clear of it without a tile-offset table.
 PROMP_CX int chain_cache_row(int H1, int H2) { return 2 * H1 + H2 + 8; }     // floats per row
@@ -77,8 +77,7 @@ struct PassArgs {
     int ls_per_row;
     const int* task_row_offsets;  // [tasks+1]
     const WorkItem* work;         // cooperative (wide) kernels: one row range per workgroup
-    const struct PassWork* pwork; // k_fwd_bwd: wave-granular work items
-    const ChainSeg* segs;         // k_chain_hvp
+    const ChainSeg* segs;         // k_pass, k_chain_hvp
     const int* wg_seg_offsets;    // [grid+1]
     const float* theta;           // [Theta] or [tasks][Theta]
     long long theta_task_stride;  // 0 => shared
@@ -104,7 +103,7 @@ struct PassArgs {
     float* v;                       // [tasks][Theta]
     float* scal;                    // [tasks][2]
     float* row_tan;                 // k_chain_hvp, optional [rows]: R'{log pi} of every row = dlogpi_row . (-v)  (DiCE coupling)
-    float* hcache;                  // primal cache of the step (k_fwd_bwd<STORE> writes it, k_chain_hvp<CACHED> reads it), see chain_cache_row
+    float* hcache;                  // primal cache of the step (k_pass<STORE> writes it, k_chain_hvp<CACHED> reads it), see chain_cache_row
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
 };
 
@@ -617,7 +616,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             const float mo0 = a.old_mean[n * A + q0], mo1 = a.old_mean[n * A + q1];
             const float so0 = olsp[q0], so1 = olsp[q1];
 
-            f32x4 cad1[NC1];      // CACHED: W2 dZ2^T of this tile (x PROMP_TANH_PRESCALE), needed at the very end of the tile
+            f32x4 cad1[NC1];      // CACHED: W2 dZ2^T of this tile, needed at the very end of the tile
             if (CACHED) {
                 const long long o = (long long)16 * t * HCR + 256 * (NC1 + NC2) + 128;
 #pragma unroll
@@ -985,7 +984,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float h = h1[c][r];
-                        const float ad2 = CACHED ? (2.f / PROMP_TANH_PRESCALE) * cad1[c][r] : 2.f * ad1[c][r];
+                        const float ad2 = 2.f * (CACHED ? cad1[c][r] : ad1[c][r]);
                         qz1[c][r] = qz1[c][r] * (1.f - h * h) - ad2 * h * rh1[c][r];
                     }
             }

@@ -1,656 +1,843 @@
-// promp_kernels_pass.h -- objective + mean KL (+ gradient) of one task slab for hidden widths <= 64 (reference rows a8-a11):
+// promp_kernels_pass.h -- objective + mean KL (+ gradient) of the tasks' slabs for hidden widths from {32, 64}, obs_dim <= 32
+// (reference rows a8-a11):
 //
-//   k_fwd_bwd : objective (ratio / PPO-clip / log-lik / KL), mean KL and gradient on one slab            (K8-K11)
+//   k_pass : objective (ratio / PPO-clip / log-lik / KL), mean KL and gradient on one step's slabs                 (K8-K11)
 //
 // Arithmetic follows oracle/promp.py (which restates meta_algos/pro_mp.py:59-155, meta_algos/base.py:192-215,
 // policies/networks/mlp.py:65-119, policies/distributions/diagonal_gaussian.py:16-109 of the reference).
 //
-// Work decomposition.  A workgroup of 8 waves (two per SIMD) shares its task's parameters in LDS; each wave walks its own
-// 16-row tiles through the whole chain with private LDS tiles (no workgroup barrier in the tile loop: the two waves of a
-// SIMD drift apart and cover each other's LDS / dependency stalls).  Every GEMM runs on the matrix cores in exact FP32
-// (v_mfma_f32_16x16x4_f32), operands read from LDS: activations as [row][unit] with an odd stride, parameters as
-// [in][out(+1)].  Weight-gradient tiles stay in registers across all tiles of the wave; the waves' tiles are added in a
-// fixed order and written once, as one partial per (workgroup, task); k_reduce_task adds the partials of a task in
-// fixed order (bitwise reproducible).
+// Design.  FP32 is a vector-rate format on gfx950 (v_mfma_f32_16x16x4_f32 = 64 FLOP / clock / SIMD); the BF16 matrix pipe is
+// sixteen times faster.  Every GEMM of this kernel therefore runs on the BF16 pipe in float32-EQUIVALENT arithmetic: both
+// operands are split into three BF16 terms (x = x0 + x1 + x2 up to 2^-24 |x|), the six largest of the nine cross products
+// are accumulated in float32 -- the dropped ones are below 2^-24 relative, the result is at least as accurate as the FP32
+// fma chain (measured: 5.6e-8 against 1.5e-7 of the result's max-norm, profiles/r03_tr16_wgrad_probe.txt).  Six BF16 MFMAs
+// of K = 32 replace eight FP32 MFMAs of K = 4 at half the issue time each: 2.7x less matrix-pipe time, and the BF16
+// instructions leave the vector ALU free for the splits and the tanh / distribution epilogues.
 //
-// The R-operator pass (k_chain_hvp, promp_kernels_chain.h) uses a different, register-chained design: measured on the
-// MI355X it is the faster one where the per-tile state is large (one wave per SIMD, 512 registers), while this
-// two-waves-per-SIMD kernel is the faster one for the plain forward / backward pass.
+//  * Register chain (as k_chain_hvp): a wave owns 16-sample tiles and keeps its activations TRANSPOSED, samples along n.
+//    Lane (i16 = sample, kk) receives units 16 c + 4 kk + r of a layer as its four D registers; the eight k-slots a lane
+//    feeds to v_mfma_f32_16x16x32_bf16 for the input chunk P are its own registers of the blocks 2P and 2P + 1, so a layer's
+//    output becomes the next layer's B operand after a split in registers -- forward and backward alike.  The weights are
+//    split ONCE per segment into BF16 planes in LDS, in fragment order for both orientations (one ds_read_b128 per MFMA
+//    operand, lane-linear: conflict free).
+//  * Weight gradients contract over samples and need both operands with the unit along the lane index.  Each operand's BF16
+//    planes go through a per-wave LDS tile of 8-byte chunks (4 units of one sample) and come back through
+//    ds_read_b64_tr_b16, the 4 x 16 transpose read of gfx950: two reads give a lane the eight samples of its unit.  The
+//    products run on v_mfma_f32_32x32x16_bf16 (K = 16 samples: full utilisation with 16-sample tiles).  The chunk placement
+//    pass_slot() is conflict free for the chain-side ds_write_b64 and for the transpose reads.
+//  * The split terms are computed once per activation and feed both the chain GEMM and the weight-gradient GEMM.
+//  * Only dH2 = W3 dmu^T (K = act_dim <= 8) stays on the FP32 instruction: a K = 32 instruction would be 3/4 padding.
+//
+// Work split: the segment table of k_chain_hvp (16-sample tiles, rounds of NW tiles, cost-balanced shares, one workgroup of
+// NW = 4 waves -- one per SIMD, 512 registers -- per CU).  Every (workgroup, segment) writes one partial row; k_reduce_task
+// adds a task's rows in slot order (bitwise reproducible).
 #pragma once
 #include "promp_device.h"
 #include "promp_kernels_chain.h"
 
-#define PROMP_W3S 17         // row stride of the zero-padded [H2][16] output kernel in LDS
-#define PROMP_MS 17          // row stride of the [64][16] mean / d-mean staging tiles
+// chunk (sample s of 16, unit chunk q = unit / 4) of a transposed tile -> its 8-byte slot.  For the writer (16 lanes = 16
+// samples of one chunk column: ds_write_b64, banks mod 32) the low four bits are a bijection of s; for the transpose read of a
+// 32-unit block (32 lanes = 4 samples x 8 chunks, banks mod 64) the low five bits are a bijection of (s & 3, q & 7).
+PROMP_CX int pass_slot(int s, int q) { return 32 * (4 * (q >> 3) + (q & 3)) + 16 * ((q >> 2) & 1) + 4 * (s & 3) + ((s >> 2) ^ (q & 3)); }
 
-// k_fwd_bwd's work item: the 8 waves of a workgroup are shared out at WAVE granularity, so a workgroup may serve two
-// tasks (waves [0, nw0) segment 0, waves [nw0, 8) segment 1).  With 2048 wave slots and 250 tiles per task (config 3)
-// every wave walks at most 5 tiles; at workgroup granularity (6 or 7 workgroups per task) 60 % of the tasks had waves
-// with 6.  Wave i of a task takes the tiles i, i + wstride, ... of the task's 16-row tiles.
-struct PassWork {
-    int task[2];      // task of each segment (segment 1 unused when nw0 == 8)
-    int row0[2];      // first row of the task
-    int nrows[2];     // rows of the task
-    int ntiles[2];    // 16-row tiles of the task
-    int wave0[2];     // index, among the task's waves, of the segment's first wave
-    int wstride[2];   // waves the task has in total
-    int slot[2];      // partial-sum row the segment writes
-    int nw0, pad;
+// The six products (A-side term ta, B-side term tb) with ta + tb <= 2 are walked by A-side term: (2,0) (1,1) (1,0) (0,2) (0,1) (0,0)
+// -- roughly smallest first, and an A-side fragment is read once and feeds one to three consecutive instructions.
+// (1,2), (2,1), (2,2) are below 2^-24 of the result and dropped.
+
+struct PassLds {                 // offsets in 4-byte words
+    // BF16 planes of the segment's network: [term 3][fragment NG][4 words]; a fragment = one lane's operand of one MFMA.
+    // Fragment order: W1 [c][lane] | W2 forward [c2][P][lane] | W2 backward [c1][P][lane] | W3 forward [P][lane]
+    int wp, plane_stride;
+    int f_w1, f_w2f, f_w2b, f_w3f, n_frag;      // first fragment of each region, fragment count
+    int w3b, b1, b2, b3, dist, n_side;          // float32 side tables (contiguous from w3b: W3 for dH2, biases), their count
+    int wave0, wave_stride, xt, ta, tb, dm;
+    int total;
 };
+#define PROMP_PASS_TPLANE 512    // words per plane of a [16 samples][64 units] bf16 tile
+#define PROMP_PASS_XPLANE 256    // [16][32 observation slots]
+#define PROMP_PASS_DPLANE 160    // [16][16 action slots], rows of 8 words, 32 words of padding between samples 7 and 8
 
-// ---------------------------------------------------------------------------------------------
-// k_fwd_bwd -- wave-private pipelines.
-//
-// The workgroup (4 waves, TWO workgroups resident per CU => 2 waves per SIMD) shares one task's parameters
-// in LDS; every wave walks its own 16-row tiles through the whole forward/backward chain with its own LDS
-// buffers, so there is NO workgroup barrier inside the tile loop: waves drift apart and one wave's VALU /
-// LDS segments overlap the MFMA segments of the other wave on the same SIMD.  All GEMMs are
-// v_mfma_f32_16x16x4_f32 (exact FP32, same FLOP rate as 32x32x2) with up to 16 independent accumulators per
-// GEMM, which also covers the 40-cycle dependent-accumulator latency.  The cotangent tiles dZ2 / dZ1
-// overwrite H2 / H1 in place.  Weight-gradient tiles live in registers across all tiles of the wave; the
-// four waves' tiles are added in a fixed order through LDS at the end (bitwise reproducible).
-// ---------------------------------------------------------------------------------------------
-#define PROMP_WROWS 16
-#define PROMP_XS 33
-
-struct LdsWave {
-    int w1, b1, w2, b2, w3, w3t, b3, ls, lmask, es, sn2;
-    int wave0, wave_stride, x, h1, h2, ms;   // per-wave region: offsets of the private buffers inside it
-    int total, HS, WS, Opad4, XS, copy_stride;
-};
-
-PROMP_HD LdsWave make_layout_wave(int O, int H1, int H2, int nwaves, int NP) {
-    LdsWave L;
-    int o = 0;
-#define PROMP_TAKE(field, n) \
-    L.field = o;             \
-    o += ((n) + 3) & ~3
-    L.Opad4 = (O + 3) & ~3;
-    L.WS = H2 + 1;
-    PROMP_TAKE(w1, L.Opad4 * H1);
-    PROMP_TAKE(b1, H1);
-    PROMP_TAKE(w2, H1 * L.WS);
-    PROMP_TAKE(b2, H2);
-    PROMP_TAKE(w3, H2 * PROMP_W3S);
-    PROMP_TAKE(w3t, 8 * H2);
-    PROMP_TAKE(b3, 16);
-    PROMP_TAKE(ls, 16);
-    PROMP_TAKE(lmask, 16);
-    PROMP_TAKE(es, 16);
-    PROMP_TAKE(sn2, 16);
-    L.copy_stride = o;          // one task's parameter block; a second copy follows for the other segment's task
-    o *= 2;
-    L.HS = (H1 > H2 ? H1 : H2) + 1;
+PROMP_CX PassLds pass_layout(int NC1, int NC2, int nwaves, int NP) {
+    PassLds L{};
+    int o = 4;                                            // [0, 4): spare (the end-of-segment slabs start at 4)
+    L.f_w1 = 0;                                           // W1[obs 8 kk + e][16 c + i16] (x tanh prescale)
+    L.f_w2f = L.f_w1 + NC1 * 64;                          // W2[u(P, kk, e)][16 c2 + i16] (x tanh prescale)
+    L.f_w2b = L.f_w2f + NC2 * (NC1 / 2) * 64;             // W2[16 c1 + i16][u(P, kk, e)]
+    L.f_w3f = L.f_w2b + NC1 * (NC2 / 2) * 64;             // W3[u(P, kk, e)][action of row i16]
+    L.n_frag = L.f_w3f + (NC2 / 2) * 64;
+    L.plane_stride = 4 * L.n_frag;
+    L.wp = o; o += 3 * L.plane_stride;
+    L.w3b = o; o += NC2 * 128;                            // [c][lane][ro]: W3[16 c + i16][2 kk + ro]
+    L.b1 = o; o += 16 * NC1;
+    L.b2 = o; o += 16 * NC2;
+    L.b3 = o; o += 8;
+    L.n_side = o - L.w3b;
+    L.dist = o; o += 48;
     L.wave0 = o;
     int q = 0;
-    // X tile [16][XS]: the hidden_0 gradient reads it transposed with observation indices up to 31; indices >= O land
-    // in the following row / buffer (finite values) and only produce gradient rows >= O, which are never written out
-    L.XS = L.Opad4 + 1;
-    L.x = q;  q += (PROMP_WROWS * L.XS + 3) & ~3;
-    L.h1 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
-    L.h2 = q; q += (PROMP_WROWS * L.HS + 3) & ~3;
-    L.ms = q; q += (PROMP_WROWS * PROMP_MS + 3) & ~3;
+    L.xt = q; q += 3 * PROMP_PASS_XPLANE;
+    L.ta = q; q += 3 * PROMP_PASS_TPLANE;
+    L.tb = q; q += 3 * PROMP_PASS_TPLANE;
+    L.dm = q; q += 3 * PROMP_PASS_DPLANE;
     L.wave_stride = q;
     o += nwaves * q;
-    {   // end-of-kernel: one slab per wave from offset 0 (aliases everything): the hidden_1 kernel with rows padded to
-        // H2 + 4, then the hidden_0 kernel (32 rows padded to H1 + 4) followed by everything else
-        const int nw2 = H1 * (H2 + 4), nr2 = 32 * (H1 + 4) + (NP + 2 - H1 * H2);
-        const int need = nwaves * (nw2 > nr2 ? nw2 : nr2);
+    {   // end of segment: one slab of [NP + 2] floats per wave, from offset 4 (aliases everything else)
+        const int need = 4 + nwaves * ((NP + 2 + 3) & ~3);
         if (o < need) o = need;
     }
-#undef PROMP_TAKE
     L.total = o;
     return L;
 }
 
-// BWD = false: objective and mean KL only (compute_stats / line-search evaluations): the tile loop stops after the
-// distribution epilogue and the partial carries just the two scalars.
-// KS1 > 0: the observation width is known at compile time (ceil(O / 4) == KS1 k-steps in the first layer): the k-loop
-// unrolls and its accumulators stay in place (the runtime loop pays a register copy per accumulator element and step).
-// STORE: the hidden activations, the means and the hidden_0 cotangent (before its tanh derivative) of every tile also go to
-// the step's primal cache (chain_cache_row in promp_kernels_chain.h) for the R-operator pass that follows at the same
-// parameters: 52 four-byte stores per lane and tile.
-template <int NB1, int NB2, int NW, bool BWD, int KS1 = 0, bool STORE = false>
-__global__ void __launch_bounds__(64 * NW, NW / 4) k_fwd_bwd(PassArgs a) {
-    constexpr int NT = 64 * NW;
-    constexpr int H1 = 32 * NB1, H2 = 32 * NB2, NC1 = H1 / 16, NC2 = H2 / 16, MS = PROMP_MS, W3S = PROMP_W3S;
-    constexpr int Q1 = H1 / 4, Q2 = H2 / 4;   // k-slice of lane group kk in the K = H GEMMs: {kk*Q .. kk*Q + Q-1}
-    PROMP_SMEM_DECL;
-    float* sm = (float*)PROMP_SMEM_PTR;
-    const int tid = threadIdx.x, lane = tid & 63, w_ = tid >> 6;
-    const int i16 = lane & 15, kk = lane >> 4;
-    CH_WGSTAMP(0);
-    CH_STAMP(0);
-    const PassWork pw = a.pwork[blockIdx.x];
-    const int w = wave_uniform(w_);
-    const int seg = (w < pw.nw0) ? 0 : 1;      // which of the workgroup's (at most two) tasks this wave serves
-    const int task = pw.task[seg];
-    const int O = a.O, A = a.A;
-    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A,
-              NP = oS + A;
-    // the layout is sized for obs_dim 32 whatever O is: every LDS offset is then a compile-time constant and folds into
-    // the ds_read / ds_write immediates instead of costing address arithmetic in the tile loop
-    const LdsWave L = make_layout_wave(32, H1, H2, NW, 0);
-    const int HS = L.HS, WS = L.WS, Opad4 = (O + 3) & ~3, XS = L.XS;
-    float* wreg = sm + L.wave0 + w * L.wave_stride;
-    float *Xw = wreg + L.x, *H1w = wreg + L.h1, *H2w = wreg + L.h2, *Msw = wreg + L.ms;
-    const float invN = 1.0f / (float)pw.nrows[seg];
+// unit a lane's k-slot e of input chunk P stands for: its own D register (block 2P + e / 4, row e % 4)
+PROMP_CX int pass_unit(int P, int kk, int e) { return 16 * (2 * P + (e >> 2)) + 4 * kk + (e & 3); }
 
-    // ---- stage the parameters of the workgroup's task(s) (shared by the waves of a segment): every global load is
-    //      issued before the first LDS store, so the staging costs one L2 round trip instead of one per loop iteration ----
-    for (int sg = 0; sg < (pw.nw0 < NW ? 2 : 1); ++sg) {
-        float* cp = sm + sg * L.copy_stride;
-        float *W1s = cp + L.w1, *b1s = cp + L.b1, *W2s = cp + L.w2, *b2s = cp + L.b2, *W3s = cp + L.w3, *W3Ts = cp + L.w3t,
-              *b3s = cp + L.b3, *lss = cp + L.ls, *lmask = cp + L.lmask, *ess = cp + L.es, *sn2s = cp + L.sn2;
-        const float* th = a.theta + (long long)pw.task[sg] * a.theta_task_stride;
-        constexpr int N1 = (32 * H1 + NT - 1) / NT, N2 = H1 * H2 / NT, N3 = (H2 * 16 + NT - 1) / NT, N3T = (8 * H2 + NT - 1) / NT;
-        float r1[N1], r2[N2], r3[N3], r3t[N3T];
+PROMP_DEV void sts_w2(float* p, unsigned a, unsigned b) {
+    u32x2 v;
+    v[0] = a;
+    v[1] = b;
+    *(u32x2*)p = v;
+}
+PROMP_DEV void sts_w4(float* p, u32x4 v) { *(u32x4*)p = v; }
+PROMP_DEV u32x4 join_w2(u32x2 lo, u32x2 hi) {
+    u32x4 v;
+    v[0] = lo[0];
+    v[1] = lo[1];
+    v[2] = hi[0];
+    v[3] = hi[1];
+    return v;
+}
+// a lane's eight k-slots of one input chunk (blocks 2P, 2P + 1) -> the three BF16 planes
+PROMP_DEV void pass_split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
+    unsigned w0[3], w1[3], w2[3], w3[3];
+    bf16_split3_pair(lo[0], lo[1], w0);
+    bf16_split3_pair(lo[2], lo[3], w1);
+    bf16_split3_pair(hi[0], hi[1], w2);
+    bf16_split3_pair(hi[2], hi[3], w3);
 #pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int e = tid + i * NT;
-            r1[i] = (e < O * H1) ? PROMP_TANH_PRESCALE * th[e] : 0.f;
-        }
+    for (int t = 0; t < 3; ++t) {
+        pl[t][0] = w0[t];
+        pl[t][1] = w1[t];
+        pl[t][2] = w2[t];
+        pl[t][3] = w3[t];
+    }
+}
+// tanh of a pre-activation that arrives scaled by PROMP_TANH_PRESCALE, and h^2 - 1 (the NEGATED derivative): unpacked float32
+// instructions (packed-f32 VALU beside MFMAs costs more than the issue slot it saves: MI355X_MICROARCH.md)
+PROMP_DEV float pass_tanh(float y) { return __builtin_fmaf(fast_rcp(fast_exp2(y) + 1.f), -2.f, 1.f); }
+PROMP_DEV float pass_neg_dtanh(float h) { return __builtin_fmaf(h, h, -1.f); }
+
+// The segment's network -> BF16 planes (both orientations of the hidden_1 kernel) and float32 side tables in LDS.  A wave
+// stages whole blocks of 64 fragments (one MFMA operand of every lane): the block is wave-uniform, so a fragment's eight source
+// indices are a lane-constant pattern (pass_unit / the observation slots) scaled and shifted by scalars -- no per-element index
+// arithmetic.  All global loads of a wave are issued before its first split (one round trip to L2); padding reads element 0 and
+// is multiplied by 0 (a select would come back as an exec-masked branch around the load).
+template <int NC1, int NC2, int NW>
+PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NP1 = NC1 / 2, NP2 = NC2 / 2, NT = 64 * NW;
+    constexpr PassLds L = pass_layout(NC1, NC2, 1, 0);
+    constexpr int B1 = L.f_w2f / 64, B2 = L.f_w2b / 64, B3 = L.f_w3f / 64, NBLK = L.n_frag / 64, IT = (NBLK + NW - 1) / NW;
+    constexpr int IS = (L.n_side + NT - 1) / NT;
+    const int lane = tid & 63, i16 = lane & 15, kk = lane >> 4, w = wave_uniform(tid >> 6);
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
+    // output row m = i16 of the mean GEMM carries action 2 (m / 4) + m % 4 for m % 4 < 2 (a lane's D registers 0, 1 are then
+    // actions 2 kk, 2 kk + 1: the distribution epilogue keeps all four lane groups busy), nothing otherwise
+    const int aro = i16 & 3, aact = 2 * (i16 >> 2) + aro;
+    const bool aok = aro < 2 && aact < A;
+    float x[IT][8], y[IS];
 #pragma unroll
-        for (int i = 0; i < N2; ++i) r2[i] = PROMP_TANH_PRESCALE * th[oW2 + tid + i * NT];
+    for (int it = 0; it < IT; ++it) {
+        const int b = w + it * NW;                  // wave-uniform
+        if (b < B1) {                               // W1[obs 8 kk + e][16 b + i16], prescaled
 #pragma unroll
-        for (int i = 0; i < N3; ++i) {
-            const int e = tid + i * NT, k = e >> 4, j = e & 15;
-            r3[i] = (e < H2 * 16 && j < A) ? th[oW3 + k * A + j] : 0.f;
-        }
+            for (int e = 0; e < 8; ++e) {
+                const int o = 8 * kk + e;
+                x[it][e] = th[(o < O ? o : 0) * H1 + 16 * b + i16] * (o < O ? PROMP_TANH_PRESCALE : 0.f);
+            }
+        } else if (b < B2) {                        // W2[u(P, kk, e)][16 c2 + i16], prescaled
+            const int c2 = (b - B1) / NP1, P = (b - B1) - c2 * NP1;
 #pragma unroll
-        for (int i = 0; i < N3T; ++i) {
-            const int e = tid + i * NT, aa = e / H2, k = e - aa * H2;
-            r3t[i] = (e < 8 * H2 && aa < A) ? th[oW3 + k * A + aa] : 0.f;
-        }
+            for (int e = 0; e < 8; ++e) x[it][e] = th[oW2 + pass_unit(0, kk, e) * H2 + (32 * P * H2 + 16 * c2) + i16] * PROMP_TANH_PRESCALE;
+        } else if (b < B3) {                        // W2[16 c1 + i16][u(P, kk, e)]
+            const int c1 = (b - B2) / NP2, P = (b - B2) - c1 * NP2;
 #pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int e = tid + i * NT;
-            if (e < Opad4 * H1) W1s[e] = r1[i];
-        }
+            for (int e = 0; e < 8; ++e) x[it][e] = th[oW2 + i16 * H2 + pass_unit(0, kk, e) + (16 * c1 * H2 + 32 * P)];
+        } else if (b < NBLK) {                      // W3[u(P, kk, e)][action of row i16]
+            const int P = b - B3;
 #pragma unroll
-        for (int i = 0; i < N2; ++i) {
-            const int e = tid + i * NT, k = e / H2, j = e - k * H2;
-            W2s[k * WS + j] = r2[i];
-        }
+            for (int e = 0; e < 8; ++e) x[it][e] = th[oW3 + (pass_unit(0, kk, e) + 32 * P) * A + (aok ? aact : 0)] * (aok ? 1.f : 0.f);
+        } else {
 #pragma unroll
-        for (int i = 0; i < N3; ++i) {
-            const int e = tid + i * NT, k = e >> 4, j = e & 15;
-            if (e < H2 * 16) W3s[k * W3S + j] = r3[i];
-        }
-#pragma unroll
-        for (int i = 0; i < N3T; ++i) {
-            const int e = tid + i * NT;
-            if (e < 8 * H2) W3Ts[e] = r3t[i];
-        }
-        if (tid < H1) b1s[tid] = PROMP_TANH_PRESCALE * th[ob1 + tid];
-        if (tid < H2) b2s[tid] = PROMP_TANH_PRESCALE * th[ob2 + tid];
-        if (tid < 16) {
-            b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
-            const float sr = (tid < A) ? th[oS + tid] : 0.f;
-            const bool clipped = a.clip_log_std && (sr < a.min_log_std);   // tf.maximum: gradient iff var >= min
-            const float s = clipped ? a.min_log_std : sr;
-            lss[tid] = s;
-            lmask[tid] = clipped ? 0.f : 1.f;
-            ess[tid] = expf(-s);
-            sn2s[tid] = expf(2.f * s);
+            for (int e = 0; e < 8; ++e) x[it][e] = 0.f;
         }
     }
-    // this wave's view of its task's parameter block
-    float* const cp = sm + seg * L.copy_stride;
-    float *W1s = cp + L.w1, *b1s = cp + L.b1, *W2s = cp + L.w2, *b2s = cp + L.b2, *W3s = cp + L.w3, *W3Ts = cp + L.w3t,
-          *b3s = cp + L.b3, *lss = cp + L.ls, *lmask = cp + L.lmask, *ess = cp + L.es, *sn2s = cp + L.sn2;
-    for (int e = lane; e < L.wave_stride; e += 64) wreg[e] = 0.f;   // pad columns stay zero; over-read cells finite
-    __syncthreads();
-    CH_STAMP(1);
+    // float32 side tables: W3 for dH2 = W3 dmu^T ([c][lane][ro]: W3[16 c + i16][2 kk + ro]), biases (those that feed a tanh prescaled)
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+        const int e = tid + it * NT, wd = L.w3b + e;
+        int idx = 0;
+        float m = 0.f;
+        if (wd < L.b1) {
+            const int c = e >> 7, l = (e >> 1) & 63, aa = 2 * (l >> 4) + (e & 1);
+            idx = oW3 + (16 * c + (l & 15)) * A + (aa < A ? aa : 0);
+            m = aa < A ? 1.f : 0.f;
+        } else if (wd < L.b2) {
+            idx = ob1 + (wd - L.b1);
+            m = PROMP_TANH_PRESCALE;
+        } else if (wd < L.b3) {
+            idx = ob2 + (wd - L.b2);
+            m = PROMP_TANH_PRESCALE;
+        } else if (e < L.n_side) {
+            const int aa = wd - L.b3;
+            idx = ob3 + (aa < A ? aa : 0);
+            m = aa < A ? 1.f : 0.f;
+        }
+        y[it] = th[idx] * m;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int b = w + it * NW;
+        if (b < NBLK) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = x[it][e];
+                hi[e] = x[it][4 + e];
+            }
+            u32x4 pl[3];
+            pass_split8(lo, hi, pl);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+        const int e = tid + it * NT;
+        if (e < L.n_side) sm[L.w3b + e] = y[it];
+    }
+}
 
-    // ---- persistent accumulators of this wave ----
-    f32x4 aw2[NC1][NC2], aw1[2][NC1], aw3[NC2][1];
-#pragma unroll
-    for (int i = 0; i < NC1; ++i)
-#pragma unroll
-        for (int j = 0; j < NC2; ++j) aw2[i][j] = zero4();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NC1; ++j) aw1[i][j] = zero4();
-#pragma unroll
-    for (int j = 0; j < NC2; ++j) aw3[j][0] = zero4();
-    float gb1[NC1], gb2[NC2];
-#pragma unroll
-    for (int j = 0; j < NC1; ++j) gb1[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NC2; ++j) gb2[j] = 0.f;
-    float loss = 0.f, klsum = 0.f, gs0 = 0.f, gs1 = 0.f, gb30 = 0.f, gb31 = 0.f;
-
-    // epilogue role: 4 lanes per row, actions {q, q+4}
-    const int erow = lane >> 2, q = lane & 3;
-    const bool own0 = q < A, own1 = (q + 4) < A;
-    const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;   // clamped action indices for unconditional loads
-    // this lane's share of a [16][O] tile lands at row e / O, column e % O of the padded LDS tile (e = lane + 64 u);
-    // the quotient comes from a float reciprocal (exact for these small integers) instead of 8 live offset registers
-    const float rO = 1.0f / (float)O;
-    // this wave's tiles of its task: wi, wi + wstride, ...
-    const int wi = pw.wave0[seg] + (seg ? w - pw.nw0 : w), wstride = pw.wstride[seg], ntiles = pw.ntiles[seg];
-    const int trow0 = pw.row0[seg], tnrows = pw.nrows[seg];
-    float xr[8];
+// Cross-wave, fixed-order sum of the waves' gradient tiles -> one partial row in global memory (accumulators in the
+// 32x32 / 16x16 result layouts of this kernel).  Every wave stores its tiles to its own LDS slab of [NP + 2] floats (every
+// entry written exactly once), then all threads add the slabs in wave order.
+template <int NC1, int NC2, int NW>
+PROMP_DEV void pass_reduce_to_partial(float* S, float* P, const f32x16 (&aw2)[NC1 / 2][NC2 / 2], const f32x16 (&aw1)[NC1 / 2],
+                                      const f32x4 (&aw3)[NC2], const f32x4 (&gb1)[NC1], const f32x4 (&gb2)[NC2], float gs0,
+                                      float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
+    const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, j32 = lane & 31, kh = lane >> 5;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
+    const int SL = (NP + 2 + 3) & ~3;
+    lds_barrier();                // every wave is done with the parameter planes / transposed tiles
     {
-        const int nr = (tnrows - PROMP_WROWS * wi) < PROMP_WROWS ? (tnrows - PROMP_WROWS * wi) : PROMP_WROWS;
-        const int lim = (wi < ntiles) ? nr * O : 0;
-        const float* src = a.obs + (long long)(trow0 + (wi < ntiles ? PROMP_WROWS * wi : 0)) * O;
+        float* mine = S + w * SL;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = lane + 64 * u;
-            const float x = src[e < lim ? e : 0];      // always a valid address: no exec-masked branch per load
-            xr[u] = (e < lim) ? x : 0.f;
-        }
-    }
-
-    const unsigned hoff = 64 * kk + i16;     // STORE: this lane's offset inside a cache block
-    int tix = 0;
-#ifndef PROMP_NO_TILE_PRIO
-    // The two waves of a SIMD share its issue slots oldest-first, so the older wave runs ahead and the younger one is
-    // left to finish alone (one wave per SIMD pays twice as many issue cycles per VALU / LDS instruction): the wave with
-    // more tiles left gets the higher priority, which keeps the pair within a tile of each other up to the end.
-    const int my_tiles = (wi < ntiles) ? (ntiles - wi + wstride - 1) / wstride : 0;
-#endif
-    for (int t = wi; t < ntiles; t += wstride, ++tix) {
-#ifndef PROMP_NO_TILE_PRIO
-        wave_priority(my_tiles - 1 - tix);
-#endif
-        CH_TSTAMP(0);
-        const int base = trow0 + PROMP_WROWS * t;
-        const int nrows = (tnrows - PROMP_WROWS * t) < PROMP_WROWS ? (tnrows - PROMP_WROWS * t) : PROMP_WROWS;
+        for (int bi = 0; bi < NC1 / 2; ++bi)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = lane + 64 * u;
-            const int r = (int)(((float)e + 0.5f) * rO);
-            if (e < PROMP_WROWS * O) Xw[r * XS + (e - r * O)] = xr[u];
-        }
-        {
-            const int tn = t + wstride;
-            const int nn = (tnrows - PROMP_WROWS * tn) < PROMP_WROWS ? (tnrows - PROMP_WROWS * tn) : PROMP_WROWS;
-            const int lim = (tn < ntiles) ? nn * O : 0;
-            const float* src = a.obs + (long long)(trow0 + (tn < ntiles ? PROMP_WROWS * tn : 0)) * O;
+            for (int bj = 0; bj < NC2 / 2; ++bj)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = lane + 64 * u;
-                const float x = src[e < lim ? e : 0];
-                xr[u] = (e < lim) ? x : 0.f;
+                for (int r = 0; r < 16; ++r)
+                    mine[oW2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + 32 * bj + j32] = aw2[bi][bj][r];
+#pragma unroll
+        for (int bj = 0; bj < NC1 / 2; ++bj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;      // observation index
+                if (row < O) mine[row * H1 + 32 * bj + j32] = aw1[bj][r];
             }
-        }
-        // STORE: this lane's cells of the tile's cache block are sample 4 kk (+ r), unit i16 (+ 16 j) / action i16
-        // (a wave-uniform block address in scalar registers + one constant 32-bit offset per lane)
-        float* const hcb = STORE ? a.hcache + ((long long)base + 16 * task) * chain_cache_row(H1, H2) : nullptr;
-        const bool rvalid = erow < nrows;
-        const long long n = (long long)base + (rvalid ? erow : 0);
-        const float* olsp = a.old_log_std + (a.ls_per_row ? n * A : (long long)task * A);
-        // n is a valid row even for padding lanes; q0/q1 are valid action indices even for lanes that own none:
-        // all loads are unconditional, the selects below discard what is not owned
-        const float advn = rvalid ? a.adv[n] : 0.f;
-        const float ac0 = a.act[n * A + q0], ac1 = a.act[n * A + q1];
-        const float mo0 = a.old_mean[n * A + q0], mo1 = a.old_mean[n * A + q1];
-        const float so0 = olsp[q0], so1 = olsp[q1];
-        wave_sync();
-        // ---- layer 1: H1 = tanh(X W1 + b1)
-        {
-            f32x4 acc[1][NC1];
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) acc[0][j] = splat4(b1s[16 * j + i16]);   // bias rides in the accumulator
-            outer16<1, NC1>(acc, Xw + i16 * XS + kk, 4, 0, W1s + kk * H1 + i16, 4 * H1, 16, KS1 > 0 ? KS1 : Opad4 / 4, 1.f);
-#pragma unroll
-            for (int j = 0; j < NC1; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2 h = tanh2_prescaled(acc[0][j][r], acc[0][j][r + 1]);
-                    H1w[(4 * kk + r) * HS + 16 * j + i16] = h[0];
-                    H1w[(4 * kk + r + 1) * HS + 16 * j + i16] = h[1];
-                    if (STORE) {
-                        hcb[hoff + 256 * j + 16 * r] = h[0];
-                        hcb[hoff + 256 * j + 16 * (r + 1)] = h[1];
-                    }
-                }
-        }
-        wave_sync();
-        CH_TSTAMP(1);
-        // ---- layer 2
-        {
-            f32x4 acc[1][NC2];
-#pragma unroll
-            for (int j = 0; j < NC2; ++j) acc[0][j] = splat4(b2s[16 * j + i16]);
-            outer16<1, NC2>(acc, H1w + i16 * HS + kk * Q1, 1, 0, W2s + kk * Q1 * WS + i16, WS, 16, Q1, 1.f);
-#pragma unroll
-            for (int j = 0; j < NC2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2 h = tanh2_prescaled(acc[0][j][r], acc[0][j][r + 1]);
-                    H2w[(4 * kk + r) * HS + 16 * j + i16] = h[0];
-                    H2w[(4 * kk + r + 1) * HS + 16 * j + i16] = h[1];
-                    if (STORE) {
-                        hcb[hoff + 256 * (NC1 + j) + 16 * r] = h[0];
-                        hcb[hoff + 256 * (NC1 + j) + 16 * (r + 1)] = h[1];
-                    }
-                }
-        }
-        wave_sync();
-        CH_TSTAMP(2);
-        // ---- output layer (16 padded columns)
-        {
-            f32x4 acc[1][1];
-            acc[0][0] = splat4(b3s[i16]);
-            outer16<1, 1>(acc, H2w + i16 * HS + kk * Q2, 1, 0, W3s + kk * Q2 * W3S + i16, W3S, 0, Q2, 1.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Msw[(4 * kk + r) * MS + i16] = acc[0][0][r];
-            if (STORE && i16 < 8) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) hcb[hoff + 256 * (NC1 + NC2) - 32 * kk - (i16 & 8) + 8 * r] = acc[0][0][r];
-            }
-        }
-        wave_sync();
-        CH_TSTAMP(3);
-        // ---- distribution + objective epilogue
-        {
-            float dlp = 0.f, sumz2 = 0.f, sums = 0.f, kl = 0.f;
-            float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f, dklm0 = 0.f, dklm1 = 0.f, dkls0 = 0.f, dkls1 = 0.f;
-            if (own0) {
-                const float s = lss[q], mu = Msw[erow * MS + q];
-                e0 = ess[q];
-                z0 = (ac0 - mu) * e0;
-                const float zo = (ac0 - mo0) * fast_exp(-so0);
-                dlp += (so0 - s) - 0.5f * (z0 * z0 - zo * zo);
-                sumz2 += z0 * z0;
-                sums += s;
-                const float sn2 = sn2s[q], num = (mo0 - mu) * (mo0 - mu) + fast_exp(2.f * so0) - sn2, den = 2.f * sn2 + 1e-8f;
-                const float rden = fast_rcp(den);     // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
-                kl += num * rden + s - so0;
-                dklm0 = -2.f * (mo0 - mu) * rden;
-                dkls0 = (-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f;
-            }
-            if (own1) {
-                const float s = lss[q + 4], mu = Msw[erow * MS + q + 4];
-                e1 = ess[q + 4];
-                z1 = (ac1 - mu) * e1;
-                const float zo = (ac1 - mo1) * fast_exp(-so1);
-                dlp += (so1 - s) - 0.5f * (z1 * z1 - zo * zo);
-                sumz2 += z1 * z1;
-                sums += s;
-                const float sn2 = sn2s[q + 4], num = (mo1 - mu) * (mo1 - mu) + fast_exp(2.f * so1) - sn2, den = 2.f * sn2 + 1e-8f;
-                const float rden = fast_rcp(den);     // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
-                kl += num * rden + s - so1;
-                dklm1 = -2.f * (mo1 - mu) * rden;
-                dkls1 = (-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f;
-            }
-            dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
-            sumz2 += shfl_xor_f32(sumz2, 1);  sumz2 += shfl_xor_f32(sumz2, 2);
-            sums += shfl_xor_f32(sums, 1);  sums += shfl_xor_f32(sums, 2);
-            kl += shfl_xor_f32(kl, 1);  kl += shfl_xor_f32(kl, 2);
-            float c = 0.f, ck = 0.f;   // d loss / d logpi, and the weight of the KL cotangents (LOSS_KL only)
-            if (rvalid) {
-                const float rho = expf(dlp);
-                float lrow;
-                if (a.loss_kind == LOSS_KL) {
-                    lrow = kl * invN;
-                    ck = invN;
-                } else if (a.loss_kind == LOSS_RATIO) {
-                    lrow = -rho * advn * invN;
-                    c = -advn * rho * invN;
-                } else if (a.loss_kind == LOSS_CLIP) {
-                    const float x = rho * advn;
-                    const float y = fminf(fmaxf(rho, 1.f - a.clip_eps), 1.f + a.clip_eps) * advn;
-                    lrow = -fminf(x, y) * invN;
-                    c = (x <= y) ? -advn * rho * invN : 0.f;
-                } else {
-                    const float lp = -sums - 0.5f * sumz2 - 0.5f * (float)A * 1.8378770664093453f;
-                    lrow = -lp * advn * invN;
-                    c = -advn * invN;
-                }
-                if (q == 0) {
-                    loss += lrow;
-                    klsum += kl * invN;
-                }
-            }
-            if (own0) {
-                const float d = c * z0 * e0 + ck * dklm0;
-                Msw[erow * MS + q] = d;
-                gs0 += c * (z0 * z0 - 1.f) + ck * dkls0;
-                gb30 += d;
-            }
-            if (own1) {
-                const float d = c * z1 * e1 + ck * dklm1;
-                Msw[erow * MS + q + 4] = d;
-                gs1 += c * (z1 * z1 - 1.f) + ck * dkls1;
-                gb31 += d;
-            }
-            // columns >= A of Msw already hold exact zeros (zero-padded W3s / b3s)
-        }
-        wave_sync();
-        CH_TSTAMP(4);
-        if (BWD) {
-        // ---- output-kernel gradient (+=); dZ2 = (dmu W3^T) * (1 - H2^2) in place over H2
-        outer16<NC2, 1>(aw3, H2w + kk * HS + i16, 4 * HS, 16, Msw + kk * MS + i16, 4 * MS, 0, PROMP_WROWS / 4, 1.f);
-        sched_fence();
-        CH_TSTAMP(5);
-        {
-            f32x4 acc[1][NC2];
-#pragma unroll
-            for (int j = 0; j < NC2; ++j) acc[0][j] = zero4();
-            outer16<1, NC2>(acc, Msw + i16 * MS + kk, 4, 0, W3Ts + kk * H2 + i16, 4 * H2, 16, 2, 1.f);
-#pragma unroll
-            for (int j = 0; j < NC2; ++j) {
-                float cs = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
-                    const f32x2 ns = neg_dtanh2(H2w[idx], H2w[idx + HS]);
-                    const float d0 = acc[0][j][r] * -ns[0], d1 = acc[0][j][r + 1] * -ns[1];
-                    H2w[idx] = d0;
-                    H2w[idx + HS] = d1;
-                    cs += d0;
-                    cs += d1;
-                }
-                gb2[j] += cs;
-            }
-        }
-        wave_sync();
-        CH_TSTAMP(6);
-        // ---- hidden_1 kernel gradient (+=); dZ1 = (dZ2 W2^T) * (1 - H1^2) in place over H1
-        outer16<NC1, NC2>(aw2, H1w + kk * HS + i16, 4 * HS, 16, H2w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
-        sched_fence();
-        CH_TSTAMP(7);
-        {
-            f32x4 acc[1][NC1];
-#pragma unroll
-            for (int j = 0; j < NC1; ++j) acc[0][j] = zero4();
-            outer16<1, NC1>(acc, H2w + i16 * HS + kk * Q2, 1, 0, W2s + i16 * WS + kk * Q2, 1, 16 * WS, Q2, 1.f);
-#pragma unroll
-            for (int j = 0; j < NC1; ++j) {
-                float cs = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const int idx = (4 * kk + r) * HS + 16 * j + i16;
-                    const f32x2 ns = neg_dtanh2(H1w[idx], H1w[idx + HS]);
-                    if (STORE) {
-                        hcb[hoff + 256 * (NC1 + NC2) + 128 + 256 * j + 16 * r] = acc[0][j][r];
-                        hcb[hoff + 256 * (NC1 + NC2) + 128 + 256 * j + 16 * (r + 1)] = acc[0][j][r + 1];
-                    }
-                    const float d0 = acc[0][j][r] * -ns[0], d1 = acc[0][j][r + 1] * -ns[1];
-                    H1w[idx] = d0;
-                    H1w[idx + HS] = d1;
-                    cs += d0;
-                    cs += d1;
-                }
-                gb1[j] += cs;
-            }
-        }
-        wave_sync();
-        CH_TSTAMP(8);
-        // ---- hidden_0 kernel gradient (+=): rows = observation index (two 16-blocks cover O <= 32)
-        outer16<2, NC1>(aw1, Xw + kk * XS + i16, 4 * XS, 16, H1w + kk * HS + i16, 4 * HS, 16, PROMP_WROWS / 4, 1.f);
-        wave_sync();
-        CH_TSTAMP(9);
-        }
-    }
-    CH_STAMP(2);
-#ifdef PROMP_DEV_STAMPS
-    if (a.dbg != nullptr && blockIdx.x < 4 && lane == 0) { a.dbg[208 + 8 * blockIdx.x + w] = promp_clock(); a.dbg[128 + 8 * blockIdx.x + w] = tix; }
-#endif
-
-    if (BWD) {
-        // the hidden_1 kernel is staged pre-scaled by PROMP_TANH_PRESCALE (so that the forward pass feeds v_exp_f32 without a
-        // multiply); the backward product through it therefore carried that factor into dZ1, i.e. into the hidden_0
-        // kernel / bias gradients, and leaves here
-        constexpr float inv_c = 1.0f / PROMP_TANH_PRESCALE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NC1; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) aw1[i][j][r] *= inv_c;
-#pragma unroll
-        for (int j = 0; j < NC1; ++j) gb1[j] *= inv_c;
-    }
-    const float lmask_reg0 = lmask[lane & 3], lmask_reg1 = lmask[(lane & 3) + 4];
-    // ---- add the four waves' results in wave order, then one coalesced partial ----
-    // bias sums: lanes with equal i16 hold different row groups -> fold kk
-#pragma unroll
-    for (int j = 0; j < NC1; ++j) {
-        gb1[j] += shfl_xor_f32(gb1[j], 16);
-        gb1[j] += shfl_xor_f32(gb1[j], 32);
-    }
-#pragma unroll
-    for (int j = 0; j < NC2; ++j) {
-        gb2[j] += shfl_xor_f32(gb2[j], 16);
-        gb2[j] += shfl_xor_f32(gb2[j], 32);
-    }
-    {   // per-action sums over the rows of this wave: lanes with equal q differ in bits 2..5
-#pragma unroll
-        for (int m = 4; m <= 32; m <<= 1) {
-            gs0 += shfl_xor_f32(gs0, m);  gs1 += shfl_xor_f32(gs1, m);  gb30 += shfl_xor_f32(gb30, m);
-            gb31 += shfl_xor_f32(gb31, m);  loss += shfl_xor_f32(loss, m);  klsum += shfl_xor_f32(klsum, m);
-        }
-    }
-    const bool two = pw.nw0 < NW;                  // the workgroup served two tasks
-    float* P0 = a.partials + (long long)pw.slot[0] * a.partial_stride;
-    float* P1 = a.partials + (long long)pw.slot[two ? 1 : 0] * a.partial_stride;
-    if (!BWD) {   // only the two scalars per segment leave the workgroup
-        float* SC = sm;
-        lds_barrier();
-        if (lane == 0) {
-            SC[2 * w] = loss;
-            SC[2 * w + 1] = klsum;
-        }
-        lds_barrier();
-        if (tid < 2 && (tid == 0 || two)) {
-            float l = 0.f, k = 0.f;
-            const int lo = tid ? pw.nw0 : 0, hi = tid ? NW : pw.nw0;
-            for (int ww = lo; ww < hi; ++ww) {
-                l += SC[2 * ww];
-                k += SC[2 * ww + 1];
-            }
-            float* Pq = tid ? P1 : P0;
-            Pq[NP] = l;
-            Pq[NP + 1] = k;
-        }
-        return;
-    }
-    // Every wave stores its tiles to its own LDS slab (plain stores, no read-modify-write); then all threads add the slabs
-    // in wave order, the waves of segment 0 into the first task's partial and those of segment 1 into the second's.
-    // Two payload rounds because NW x [NP] does not fit in LDS: the hidden_1 kernel, then everything else (compacted).
-    // Slab rows are padded by 4 floats: the four lane groups of an accumulator tile (rows 4 kk + r) then fall into two
-    // bank halves instead of one (a [64]-float row stride puts all four on the same 16 banks).  Every cell of a slab is
-    // written by exactly one lane, so nothing is cleared first.
-    float* S = sm;                                   // whole LDS allocation is free now
-    constexpr int SP2 = H2 + 4, SLAB1 = H1 * SP2;    // round 1: hidden_1 kernel, padded rows
-    constexpr int SP1 = H1 + 4, RESTB = 32 * SP1;    // round 2: hidden_0 kernel rows [0, 32) padded, the rest behind them
-    const int NW2 = H1 * H2;
-    const int NR2 = NP + 2 - NW2;                    // compact index space of round 2
-    const int SLAB2 = RESTB + (NR2 - ob1);
-    CH_STAMP(4);
-    lds_barrier();
-    CH_STAMP(5);
-    {
-        float* mine = S + w * SLAB1;
-#pragma unroll
-        for (int i = 0; i < NC1; ++i)
-#pragma unroll
-            for (int j = 0; j < NC2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * SP2 + 16 * j + i16] = aw2[i][j][r];
-    }
-    lds_barrier();
-    CH_STAMP(6);
-#pragma unroll 2
-    for (int e = tid; e < NW2; e += NT) {
-        const int src = (e / H2) * SP2 + (e % H2);
-        float v[NW];
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SLAB1 + src];      // all slab reads in flight together
-        float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) {
-            if (ww < pw.nw0) t0 += v[ww];
-            else t1 += v[ww];
-        }
-        P0[oW2 + e] = t0;
-        if (two) P1[oW2 + e] = t1;
-    }
-    CH_STAMP(7);
-    lds_barrier();        // (LDS ordering only: the partial-row stores in flight are not waited for)
-    {
-        // round 2: [0, RESTB) hidden_0 kernel rows (padded) | then bias_0 and everything after the hidden_1 kernel, in
-        // parameter order; `rest` maps a parameter index >= ob1 (hidden_1 kernel cut out) to its cell
-        float* mine = S + w * SLAB2;
-        float* rest = mine + RESTB - ob1;            // rest[ob1 + u] = bias_0[u];  rest[p - NW2] for parameters p >= ob2
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NC1; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(16 * i + 4 * kk + r) * SP1 + 16 * j + i16] = aw1[i][j][r];
-#pragma unroll
-        for (int j = 0; j < NC2; ++j)
+        for (int c = 0; c < NC2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (i16 < A) rest[oW3 - NW2 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][0][r];
-        if (kk == 0) {
+                if (i16 < A) mine[oW3 + (16 * c + 4 * kk + r) * A + i16] = aw3[c][r];
+        if (i16 == 0) {           // (bias sums already folded over the 16 sample lanes) units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) rest[ob1 + 16 * j + i16] = gb1[j];
+            for (int c = 0; c < NC1; ++c)
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) rest[ob2 - NW2 + 16 * j + i16] = gb2[j];
-        }
-        if (lane < 4) {   // lane == q
-            if (lane < A) {
-                rest[ob3 - NW2 + lane] = gb30;
-                rest[oS - NW2 + lane] = gs0 * lmask_reg0;
+                for (int r = 0; r < 4; ++r) mine[ob1 + 16 * c + 4 * kk + r] = gb1[c][r];
+#pragma unroll
+            for (int c = 0; c < NC2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[ob2 + 16 * c + 4 * kk + r] = gb2[c][r];
+            if (2 * kk < A) {
+                mine[ob3 + 2 * kk] = gb30;
+                mine[oS + 2 * kk] = gs0;
             }
-            if (lane + 4 < A) {
-                rest[ob3 - NW2 + lane + 4] = gb31;
-                rest[oS - NW2 + lane + 4] = gs1 * lmask_reg1;
+            if (2 * kk + 1 < A) {
+                mine[ob3 + 2 * kk + 1] = gb31;
+                mine[oS + 2 * kk + 1] = gs1;
             }
         }
         if (lane == 0) {
-            rest[NP - NW2] = loss;
-            rest[NP + 1 - NW2] = klsum;
+            mine[NP] = loss;
+            mine[NP + 1] = klsum;
         }
     }
-    CH_STAMP(200);
     lds_barrier();
-    CH_STAMP(201);
-    for (int e = tid; e < NR2; e += NT) {
-        const int dst = e < oW2 ? e : e + NW2;
-        // compact index e: hidden_0 kernel entries [0, ob1) sit in padded rows, the others behind them
-        const int src = e < ob1 ? (e / H1) * SP1 + (e % H1) : RESTB - ob1 + e;
+#pragma unroll 4
+    for (int e = tid; e < NP + 2; e += NT) {
         float v[NW];
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SLAB2 + src];
-        float t0 = 0.f, t1 = 0.f;
+        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SL + e];      // all slab reads in flight together
+        float t = v[0];
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) {
-            if (ww < pw.nw0) t0 += v[ww];
-            else t1 += v[ww];
-        }
-        P0[dst] = t0;
-        if (two) P1[dst] = t1;
+        for (int ww = 1; ww < NW; ++ww) t += v[ww];
+        P[e] = t;
     }
-    CH_STAMP(3);
-    CH_WGSTAMP(1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The tile walk.  One wave per SIMD issues in order and a vector instruction occupies it for four cycles, so the wave is bound
+// by what it issues (1.3 k instructions per tile) plus whatever it waits for.  Measured on the first version of this kernel:
+// a third of all wave cycles parked on s_waitcnt -- every GEMM phase started by loading its operand fragments and waiting.
+// (Running the backward half of one tile against the forward half of the next -- two instruction streams in one basic block,
+// forced together with sched_group_barrier -- was measured too: no faster, the lone wave's issue rate is the limit either way,
+// and the carried planes cost 260 accumulator-register moves per tile.)  The tile is therefore walked front to back in eleven
+// regions separated by scheduling barriers, and every region REQUESTS the operands of the next one: weight fragments one GEMM
+// ahead, the transpose reads of a weight gradient as soon as its tiles are written -- under the GEMM in between.  A lane
+// has 512 registers at one wave per SIMD; about 130 of them hold operands in flight.  Nothing in the loop is a memory
+// barrier: the order of a tile's LDS writes and transpose reads is a memory dependence the compiler keeps (same base,
+// run-time offsets), and the epilogue is branch free.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NC1, int NC2>
+struct PassSums {                // what a wave accumulates over its tiles of a segment
+    f32x16 aw2[NC1 / 2][NC2 / 2], aw1[NC1 / 2];
+    f32x4 aw3[NC2], gb1[NC1], gb2[NC2];
+    float loss, klsum, gs0, gs1, gb30, gb31;
+};
+
+// constants of a wave's walk through a segment
+struct PassWalk {
+    const float *obs, *act, *adv, *old_mean, *old_log_std;
+    float* hcache;
+    int ls_per_row, O, A, task, trow0, tnrows, tend, loss_kind;
+    float invN, clip_eps, sums;
+    float s0, s1, e0, e1, sn20, sn21, rden0, rden1;
+    int q0, q1;
+    bool own0, own1;
+    unsigned long long* dbg;     // developer tooling: cycle stamps (NULL unless a -DPROMP_DEV_STAMPS build asks for them)
+    int tix;
+};
+#ifdef PROMP_DEV_STAMPS
+#define PASS_STAMP(j) do { if (W.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) W.dbg[8 + 16 * (W.tix < 3 ? W.tix : 3) + (j)] = promp_clock(); } while (0)
+#else
+#define PASS_STAMP(j) do { } while (0)
+#endif
+// per-lane addresses (in words) of the transposed tiles
+struct PassTileAddr {
+    int wr, xw0, xw1, rd32_0, rd32_1, rd16_0, rd16_1, dmw, dr0, dr1;
+};
+
+// this lane's eight observation entries of its sample in tile t: obs[row i16][8 kk .. 8 kk + 7] (zeros outside the tile / task)
+PROMP_DEV void pass_load_x(float (&xr)[8], const PassWalk& W, int t, int i16, int kk) {
+    const int nv = (t < W.tend) ? (W.tnrows - 16 * t < 16 ? W.tnrows - 16 * t : 16) : 0;
+    const bool rv = i16 < nv;
+    const float* src = W.obs + ((long long)W.trow0 + (t < W.tend ? 16 * t : 0) + (rv ? i16 : 0)) * W.O;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 8 * kk + e;
+        const bool ok = rv && o < W.O;
+        xr[e] = src[ok ? o : 0] * (ok ? 1.f : 0.f);
+    }
+}
+
+// acc[c] += sum over the six products of (A-side fragments wf[ta][c]) x (B-side planes xb[tb])
+template <int NC>
+PROMP_DEV void pass_gemm16(f32x4 (&acc)[NC], const u32x4 (&wf)[3][NC], const u32x4 (&xb)[3]) {
+#pragma unroll
+    for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+        for (int tb = 2 - ta; tb >= 0; --tb)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = mfma16_bf16w(wf[ta][c], xb[tb], acc[c]);
+}
+// the fragments [term][c] of NC consecutive 64-fragment blocks starting at `first`, stride `cs` blocks between them
+template <int NC>
+PROMP_DEV void pass_load_frags(u32x4 (&wf)[3][NC], const u32x4* F, int PS, int first, int cs) {
+#pragma unroll
+    for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) wf[ta][c] = F[ta * PS + first + c * cs];
+}
+// a chunk pair (blocks 2P, 2P + 1 of sample i16) of three planes -> a transposed tile
+PROMP_DEV void pass_store_planes(float* tile, int plane_words, int off, const u32x4 (&pl)[3]) {
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        sts_w2(tile + tt * plane_words + off, pl[tt][0], pl[tt][1]);
+        sts_w2(tile + tt * plane_words + off + 32, pl[tt][2], pl[tt][3]);
+    }
+}
+// the three planes of a 32-unit (or 16-unit) block as a lane's eight samples: two transpose reads each
+PROMP_DEV void pass_read_tr(u32x4 (&fr)[3], const float* tile, int plane_words, int rd0, int rd1) {
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) fr[tt] = join_w2(lds_tr16(tile + tt * plane_words + rd0), lds_tr16(tile + tt * plane_words + rd1));
+}
+
+// One 16-sample tile, front to back.  `w1f` arrives loaded (layer 1's fragments, requested at the end of the previous tile)
+// and leaves requested for the next tile; `xr` likewise (the observations).
+// One tile's pending hidden_0 kernel gradient: the operand planes (already in registers) of aw1 += X^T dZ1.  Its matrix
+// instructions are issued in the NEXT tile's first tanh / split region, whose vector work runs in their shadow.
+template <int NC1>
+struct PassPending {
+    u32x4 fx[3], fd[NC1 / 2][3];
+};
+template <int NC1, int NC2>
+PROMP_DEV void pass_flush_pending(PassSums<NC1, NC2>& S, const PassPending<NC1>& Q) {
+#pragma unroll
+    for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+        for (int tb = 2 - ta; tb >= 0; --tb)
+#pragma unroll
+            for (int bj = 0; bj < NC1 / 2; ++bj) S.aw1[bj] = mfma32_bf16w(Q.fx[ta], Q.fd[bj][tb], S.aw1[bj]);
+}
+
+template <int NC1, int NC2, bool BWD, bool STORE, bool PENDING>
+PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f)[3][NC1], float (&xr)[8], const PassWalk& W,
+                         const PassTileAddr& T, float* sm, float* wreg, int lane, int t, int tnext) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NP1 = NC1 / 2, NP2 = NC2 / 2, NB1 = NC1 / 2, NB2 = NC2 / 2;
+    constexpr int HCR = chain_cache_row(H1, H2);
+    constexpr int TPL = PROMP_PASS_TPLANE, XPL = PROMP_PASS_XPLANE, DPL = PROMP_PASS_DPLANE;
+    constexpr PassLds L = pass_layout(NC1, NC2, 1, 0);
+    constexpr int PS = L.n_frag;
+    const int i16 = lane & 15, kk = lane >> 4;
+    const u32x4* F = (const u32x4*)(sm + L.wp) + lane;
+    float *XT = wreg + L.xt, *TA = wreg + L.ta, *TB = wreg + L.tb, *DM = wreg + L.dm;
+    const int nrows = (W.tnrows - 16 * t) < 16 ? (W.tnrows - 16 * t) : 16;
+    const long long base = (long long)W.trow0 + 16 * t;
+    const bool rvalid = i16 < nrows;
+    const long long n = base + (rvalid ? i16 : 0);
+    float* const hcb = STORE ? W.hcache + (base + 16 * W.task) * HCR + 16 * i16 + 4 * kk : nullptr;
+
+    // ---- region 0: row data, observation planes, layer 1; requests layer 2's first fragments
+    PASS_STAMP(0);
+    const float* olsp = W.old_log_std + (W.ls_per_row ? n * W.A : (long long)W.task * W.A);
+    const float advn = W.adv[n] * (rvalid ? 1.f : 0.f);
+    const float ac0 = W.act[n * W.A + W.q0], ac1 = W.act[n * W.A + W.q1];
+    const float mo0 = W.old_mean[n * W.A + W.q0], mo1 = W.old_mean[n * W.A + W.q1];
+    const float so0 = olsp[W.q0], so1 = olsp[W.q1];
+    u32x4 xB[3];
+    {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = xr[e];
+            hi[e] = xr[4 + e];
+        }
+        pass_split8(lo, hi, xB);
+    }
+    pass_load_x(xr, W, tnext, i16, kk);
+    if (BWD) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            sts_w2(XT + tt * XPL + T.xw0, xB[tt][0], xB[tt][1]);
+            sts_w2(XT + tt * XPL + T.xw1, xB[tt][2], xB[tt][3]);
+        }
+    }
+    f32x4 h1[NC1], h2[NC2];
+    {
+        const float* B1l = sm + L.b1 + 4 * kk;
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) h1[c] = lds4(B1l + 16 * c);
+    }
+    pass_gemm16<NC1>(h1, w1f, xB);                               // Z1^T = W1^T X^T + b1 (K = 32 observation slots, zero padded)
+    u32x4 w2f[NP1][3][NC2];
+    pass_load_frags<NC2>(w2f[0], F, PS, L.f_w2f, NP1 * 64);      // [c2][P = 0]
+    // (the split first; then layer 1's matrix instructions with the region's address arithmetic and requests in their shadow)
+    PROMP_SCHED_VALU(48);
+#pragma unroll
+    for (int i = 0; i < 6 * NC1; ++i) {
+        PROMP_SCHED_MFMA(1);
+        PROMP_SCHED_VALU(3);
+        PROMP_SCHED_DSREAD(1);
+    }
+    sched_fence();
+    // ---- region 1: tanh, hidden_0 planes (-> first tile); requests the rest of layer 2
+    PASS_STAMP(1);
+    u32x4 hB1[NP1][3];
+#pragma unroll
+    for (int c = 0; c < NC1; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[c][r] = pass_tanh(h1[c][r]);
+        if (STORE) *(f32x4*)(hcb + 256 * c) = h1[c];
+    }
+#pragma unroll
+    for (int P = 0; P < NP1; ++P) {
+        pass_split8(h1[2 * P], h1[2 * P + 1], hB1[P]);
+        if (BWD) pass_store_planes(TA, TPL, T.wr + 256 * P, hB1[P]);
+    }
+#pragma unroll
+    for (int P = 1; P < NP1; ++P) pass_load_frags<NC2>(w2f[P], F, PS, L.f_w2f + P * 64, NP1 * 64);
+    if (BWD && PENDING) {
+        // the previous tile's hidden_0 kernel gradient: 6 NB1 matrix instructions of 32 cycles, this region's vector work in between
+        pass_flush_pending<NC1, NC2>(S, Q);
+#pragma unroll
+        for (int i = 0; i < 6 * NB1; ++i) {
+            PROMP_SCHED_MFMA(1);
+            PROMP_SCHED_VALU(7);
+        }
+    }
+    sched_fence();
+    // ---- region 2: layer 2; requests the output layer's fragments
+    PASS_STAMP(2);
+    {
+        const float* B2l = sm + L.b2 + 4 * kk;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) h2[c] = lds4(B2l + 16 * c);
+    }
+#pragma unroll
+    for (int P = 0; P < NP1; ++P) pass_gemm16<NC2>(h2, w2f[P], hB1[P]);
+    u32x4 w3f[NP2][3][1];
+#pragma unroll
+    for (int P = 0; P < NP2; ++P) pass_load_frags<1>(w3f[P], F, PS, L.f_w3f + P * 64, 0);
+    sched_fence();
+    // ---- region 3: tanh, hidden_1 planes (-> second tile)
+    PASS_STAMP(3);
+    u32x4 hB2[NP2][3];
+#pragma unroll
+    for (int c = 0; c < NC2; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[c][r] = pass_tanh(h2[c][r]);
+        if (STORE) *(f32x4*)(hcb + 256 * (NC1 + c)) = h2[c];
+    }
+#pragma unroll
+    for (int P = 0; P < NP2; ++P) {
+        pass_split8(h2[2 * P], h2[2 * P + 1], hB2[P]);
+        if (BWD) pass_store_planes(TB, TPL, T.wr + 256 * P, hB2[P]);
+    }
+    sched_fence();
+    // ---- region 4: output layer mu^T = W3^T H2^T + b3 (rows of the product: action slots, see pass_stage_net; two accumulators
+    //      in turn), distribution + objective (branch free), mean cotangents (-> their tile); requests the output-kernel
+    //      gradient's operands
+    PASS_STAMP(4);
+    float mu0, mu1;
+    {
+        const float* B3l = sm + L.b3 + 2 * kk;
+        f32x4 m[2] = {zero4(), zero4()};
+        const f32x2 bb = lds2(B3l);
+        m[0][0] = bb[0];
+        m[0][1] = bb[1];
+#pragma unroll
+        for (int P = 0; P < NP2; ++P)
+#pragma unroll
+            for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+                for (int tb = 2 - ta; tb >= 0; --tb)
+                    m[(ta + tb + P) & 1] = mfma16_bf16w(w3f[P][ta][0], hB2[P][tb], m[(ta + tb + P) & 1]);
+        mu0 = m[0][0] + m[1][0];
+        mu1 = m[0][1] + m[1][1];
+        if (STORE) {
+            f32x2 mm;
+            mm[0] = mu0;
+            mm[1] = mu1;
+            *(f32x2*)(W.hcache + (base + 16 * W.task) * HCR + 256 * (NC1 + NC2) + 8 * i16 + 2 * kk) = mm;
+        }
+    }
+    float d0, d1;
+    {   // lane (i16, kk) = sample i16, actions 2 kk and 2 kk + 1
+        const float o0 = W.own0 ? 1.f : 0.f, o1 = W.own1 ? 1.f : 0.f, rv = rvalid ? 1.f : 0.f;
+        const float z0 = (ac0 - mu0) * W.e0, z1 = (ac1 - mu1) * W.e1;
+        const float zo0 = (ac0 - mo0) * fast_exp(-so0), zo1 = (ac1 - mo1) * fast_exp(-so1);
+        const float num0 = (mo0 - mu0) * (mo0 - mu0) + fast_exp(2.f * so0) - W.sn20;
+        const float num1 = (mo1 - mu1) * (mo1 - mu1) + fast_exp(2.f * so1) - W.sn21;
+        const float den0 = 2.f * W.sn20 + 1e-8f, den1 = 2.f * W.sn21 + 1e-8f;
+        float dlp = o0 * ((so0 - W.s0) - 0.5f * (z0 * z0 - zo0 * zo0)) + o1 * ((so1 - W.s1) - 0.5f * (z1 * z1 - zo1 * zo1));
+        float sumz2 = o0 * (z0 * z0) + o1 * (z1 * z1);
+        float kl = o0 * (num0 * W.rden0 + W.s0 - so0) + o1 * (num1 * W.rden1 + W.s1 - so1);
+        dlp = fold_groups16(dlp);          // sums over the row's actions (the four lane groups)
+        sumz2 = fold_groups16(sumz2);
+        kl = fold_groups16(kl);
+        const float rho = expf(rvalid ? dlp : 0.f);        // (padding rows: a finite ratio with zero weight)
+        const float aw = advn * W.invN;
+        const float x = rho * advn, y = fminf(fmaxf(rho, 1.f - W.clip_eps), 1.f + W.clip_eps) * advn;
+        const float lp = -W.sums - 0.5f * sumz2 - 0.5f * (float)W.A * 1.8378770664093453f;
+        const bool is_kl = W.loss_kind == LOSS_KL, is_ratio = W.loss_kind == LOSS_RATIO, is_clip = W.loss_kind == LOSS_CLIP;
+        // d loss / d logpi (c), the weight of the KL cotangents (ck; LOSS_KL only), the row's objective term
+        const float c = is_kl ? 0.f : is_ratio ? -aw * rho : is_clip ? ((x <= y) ? -aw * rho : 0.f) : -aw;
+        const float ck = is_kl ? rv * W.invN : 0.f;
+        const float lrow = is_kl ? kl * W.invN : is_ratio ? -rho * aw : is_clip ? -fminf(x, y) * W.invN : -lp * aw;
+        const float first = (kk == 0) ? rv : 0.f;          // one lane per row carries the row's scalars
+        S.loss += first * lrow;
+        S.klsum += first * (kl * W.invN);
+        const float dklm0 = -2.f * (mo0 - mu0) * W.rden0, dklm1 = -2.f * (mo1 - mu1) * W.rden1;
+        const float dkls0 = (-2.f * W.sn20 * den0 - 4.f * num0 * W.sn20) * (W.rden0 * W.rden0) + 1.f;
+        const float dkls1 = (-2.f * W.sn21 * den1 - 4.f * num1 * W.sn21) * (W.rden1 * W.rden1) + 1.f;
+        d0 = o0 * (c * z0 * W.e0 + ck * dklm0);
+        d1 = o1 * (c * z1 * W.e1 + ck * dklm1);
+        S.gs0 += o0 * (c * (z0 * z0 - 1.f) + ck * dkls0);
+        S.gs1 += o1 * (c * (z1 * z1 - 1.f) + ck * dkls1);
+        S.gb30 += d0;
+        S.gb31 += d1;
+    }
+    if (!BWD) {
+        pass_load_frags<NC1>(w1f, F, PS, L.f_w1, 64);            // the next tile's layer 1
+        sched_fence();
+        return;
+    }
+    {
+        unsigned dw[3];
+        bf16_split3_pair(d0, d1, dw);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) DM[tt * DPL + T.dmw] = __builtin_bit_cast(float, dw[tt]);
+    }
+    u32x4 bD[3], aH[NC2][3];
+    pass_read_tr(bD, DM, DPL, T.dr0, T.dr1);
+#pragma unroll
+    for (int c = 0; c < NC2; ++c) pass_read_tr(aH[c], TB, TPL, T.rd16_0 + 2 * (128 * (c >> 1) + 16 * (c & 1)), T.rd16_1 + 2 * (128 * (c >> 1) + 16 * (c & 1)));
+    f32x2 wb[NC2];
+    {
+        const float* W3b = sm + L.w3b + lane * 2;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) wb[c] = lds2(W3b + c * 128);
+    }
+    sched_fence();
+    // ---- region 5: dH2^T = W3 dmu^T (K = act_dim:
+    //      the exact FP32 instruction, k-step ro <-> actions 2 kk + ro); requests the first backward hidden_1 fragments
+    PASS_STAMP(5);
+    f32x4 dz2[NC2];
+#pragma unroll
+    for (int c = 0; c < NC2; ++c) dz2[c] = mfma16(wb[c][0], d0, zero4());
+#pragma unroll
+    for (int c = 0; c < NC2; ++c) dz2[c] = mfma16(wb[c][1], d1, dz2[c]);
+    u32x4 w2b[NP2][3][NC1];
+    pass_load_frags<NC1>(w2b[0], F, PS, L.f_w2b, NP2 * 64);      // [c1][P = 0]
+    sched_fence();
+    // ---- region 6: dZ2^T = dH2^T * (1 - H2^2), its planes (-> second tile, over the hidden_1 planes)
+    PASS_STAMP(6);
+    u32x4 dB2[NP2][3];
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dz2[c][r] *= -pass_neg_dtanh(h2[c][r]);
+            S.gb2[c][r] += dz2[c][r];
+        }
+#pragma unroll
+    for (int P = 0; P < NP2; ++P) {
+        pass_split8(dz2[2 * P], dz2[2 * P + 1], dB2[P]);
+        pass_store_planes(TB, TPL, T.wr + 256 * P, dB2[P]);      // (after the output-kernel gradient's reads: a memory dependence)
+    }
+    // the output-kernel gradient aw3[unit][action] += sum_s H2[s][unit] dmu[s][action] (operands read in region 4) in this
+    // region's shadow: 6 NC2 matrix instructions of 16 cycles, three vector instructions after each
+#pragma unroll
+    for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+        for (int tb = 2 - ta; tb >= 0; --tb)
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) S.aw3[c] = mfma16_bf16w(aH[c][ta], bD[tb], S.aw3[c]);
+#pragma unroll
+    for (int i = 0; i < 6 * NC2; ++i) {
+        PROMP_SCHED_MFMA(1);
+        PROMP_SCHED_VALU(4);
+        PROMP_SCHED_DSWRITE(1);
+    }
+    sched_fence();
+    // ---- region 7: dH1^T = W2 dZ2^T; requests the rest of its fragments (under its first half) and the planes of the hidden_1
+    //      and hidden_0 kernel gradients (hidden_0 activations, dZ2, observations: their tiles are complete)
+    PASS_STAMP(7);
+#pragma unroll
+    for (int P = 1; P < NP2; ++P) pass_load_frags<NC1>(w2b[P], F, PS, L.f_w2b + P * 64, NP2 * 64);
+    u32x4 fa[NB1][3], fb[NB2][3];
+#pragma unroll
+    for (int b = 0; b < NB1; ++b) pass_read_tr(fa[b], TA, TPL, T.rd32_0 + 256 * b, T.rd32_1 + 256 * b);
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) pass_read_tr(fb[b], TB, TPL, T.rd32_0 + 256 * b, T.rd32_1 + 256 * b);
+    f32x4 ad1[NC1];
+#pragma unroll
+    for (int c = 0; c < NC1; ++c) ad1[c] = zero4();
+#pragma unroll
+    for (int P = 0; P < NP2; ++P) pass_gemm16<NC1>(ad1, w2b[P], dB2[P]);
+    if (STORE) {
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) *(f32x4*)(hcb + 256 * (NC1 + NC2) + 128 + 256 * c) = ad1[c];
+    }
+    u32x4 fx[3];
+    pass_read_tr(fx, XT, XPL, T.rd32_0, T.rd32_1);
+    sched_fence();
+    // ---- region 8: dZ1^T = dH1^T * (1 - H1^2), its planes (-> first tile, over the hidden_0 planes: their reads were issued in
+    //      region 7)
+    PASS_STAMP(8);
+#pragma unroll
+    for (int c = 0; c < NC1; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ad1[c][r] *= -pass_neg_dtanh(h1[c][r]);
+            S.gb1[c][r] += ad1[c][r];
+        }
+#pragma unroll
+    for (int P = 0; P < NP1; ++P) {
+        u32x4 dB1[3];
+        pass_split8(ad1[2 * P], ad1[2 * P + 1], dB1);
+        pass_store_planes(TA, TPL, T.wr + 256 * P, dB1);
+    }
+    // the hidden_1 kernel gradient aw2[u1][u2] += sum_s H1[s][u1] dZ2[s][u2] on 32x32x16 (operands read in regions 5 / 6) in this
+    // region's shadow: 6 NB1 NB2 matrix instructions of 32 cycles, seven vector / LDS instructions after each
+#pragma unroll
+    for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+        for (int tb = 2 - ta; tb >= 0; --tb)
+#pragma unroll
+            for (int bi = 0; bi < NB1; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < NB2; ++bj) S.aw2[bi][bj] = mfma32_bf16w(fa[bi][ta], fb[bj][tb], S.aw2[bi][bj]);
+#pragma unroll
+    for (int i = 0; i < 6 * NB1 * NB2; ++i) {
+        PROMP_SCHED_MFMA(1);
+        PROMP_SCHED_VALU(6);
+        PROMP_SCHED_DSWRITE(1);
+    }
+    sched_fence();
+    // ---- region 9: the hidden_0 kernel gradient aw1[obs][u1] += sum_s X[s][obs] dZ1[s][u1] (one 32-block of observation slots)
+    //      is left pending: its planes are requested here, its matrix instructions run under the next tile's region 1; requests
+    //      the next tile's layer 1
+    PASS_STAMP(9);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) Q.fx[tt] = fx[tt];
+#pragma unroll
+    for (int b = 0; b < NB1; ++b) pass_read_tr(Q.fd[b], TA, TPL, T.rd32_0 + 256 * b, T.rd32_1 + 256 * b);
+    pass_load_frags<NC1>(w1f, F, PS, L.f_w1, 64);
+    sched_fence();
+    PASS_STAMP(10);
+}
+
+// BWD = false: objective and mean KL only (compute_stats / line-search evaluations): the tile walk stops after the
+// distribution epilogue and the partial row carries just the two scalars.
+// STORE: the hidden activations, the means and the hidden_0 cotangent before its tanh derivative (W2 dZ2^T) of every tile also
+// go to the step's primal cache (chain_cache_row in promp_kernels_chain.h) for the R-operator pass that follows at the same
+// parameters; the register-chain layout IS that pass's operand order, so a block is 3 NC1 + NC2 16-byte stores + one 8-byte.
+template <int NC1, int NC2, int NW, bool BWD, bool STORE>
+__global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NB1 = NC1 / 2, NB2 = NC2 / 2;
+    constexpr int DPL = PROMP_PASS_DPLANE;
+    constexpr PassLds L = pass_layout(NC1, NC2, NW, 0);
+    PROMP_SMEM_DECL;
+    float* sm = (float*)PROMP_SMEM_PTR;
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int O = a.O, A = a.A;
+    const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
+    const float* dist = sm + L.dist;
+    float* wreg = sm + L.wave0 + w * L.wave_stride;
+    PassTileAddr T;
+    {
+        const int p16 = lane & 15, g32 = (lane >> 4) & 1, kh = lane >> 5;
+        // where this lane writes (chain side: sample i16, chunk 4 c + kk) ...
+        T.wr = 2 * pass_slot(i16, kk);
+        T.xw0 = 2 * pass_slot(i16, 2 * kk);
+        T.xw1 = 2 * pass_slot(i16, 2 * kk + 1);
+        // ... and reads: 32-unit blocks (v_mfma_f32_32x32x16_bf16 operands): samples 8 kh + 4 t + p16 / 4, chunk 8 b + 4 g32 + p16 % 4
+        T.rd32_0 = 2 * pass_slot(8 * kh + (p16 >> 2), 4 * g32 + (p16 & 3));
+        T.rd32_1 = 2 * pass_slot(8 * kh + 4 + (p16 >> 2), 4 * g32 + (p16 & 3));
+        // 16-unit blocks (A operand of the output-kernel gradient on v_mfma_f32_16x16x32_bf16): samples 8 (kk & 1) + 4 t + p16 / 4
+        // (the k-slots of the lane groups kk >= 2 meet zeros on the B side; they read the same finite data as kk - 2)
+        T.rd16_0 = 2 * pass_slot(8 * (kk & 1) + (p16 >> 2), p16 & 3);
+        T.rd16_1 = 2 * pass_slot(8 * (kk & 1) + 4 + (p16 >> 2), p16 & 3);
+        // cotangent-of-the-mean tile [16 samples][16 action slots]: rows of 8 words, 32 words of padding after sample 7
+        T.dmw = 8 * i16 + 32 * (i16 >> 3) + kk;
+        T.dr0 = (kk < 2) ? 8 * (8 * kk + (p16 >> 2)) + 32 * kk + 2 * (p16 & 3) : 4;     // kk >= 2: a chunk of zeros (actions 8..11 of sample 0)
+        T.dr1 = (kk < 2) ? 8 * (8 * kk + 4 + (p16 >> 2)) + 32 * kk + 2 * (p16 & 3) : 4;
+    }
+    PassWalk W;
+    W.obs = a.obs; W.act = a.act; W.adv = a.adv; W.old_mean = a.old_mean; W.old_log_std = a.old_log_std; W.hcache = a.hcache;
+    W.ls_per_row = a.ls_per_row; W.O = O; W.A = A; W.loss_kind = a.loss_kind; W.clip_eps = a.clip_eps;
+    W.dbg = a.dbg; W.tix = 0;
+    W.own0 = 2 * kk < A; W.own1 = 2 * kk + 1 < A;
+    W.q0 = W.own0 ? 2 * kk : 0; W.q1 = W.own1 ? 2 * kk + 1 : 0;
+
+    const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
+    CH_WGSTAMP(0);
+    for (int sg = sg0; sg < sg1; ++sg) {
+        const ChainSeg seg = a.segs[sg];
+        W.task = seg.task;
+        W.trow0 = a.task_row_offsets[seg.task];
+        W.tnrows = a.task_row_offsets[seg.task + 1] - W.trow0;
+        W.invN = 1.0f / (float)W.tnrows;
+        W.tend = seg.tile0 + seg.ntiles;
+        const float* th = a.theta + (long long)seg.task * a.theta_task_stride;
+        // the first tile's observations are on their way while the network is staged
+        float xr[8];
+        int t = seg.tile0 + w;
+        pass_load_x(xr, W, t, i16, kk);
+        __syncthreads();
+        CH_STAMP(0);
+        pass_stage_net<NC1, NC2, NW>(sm, th, O, A, tid);
+        chain_stage_dist(sm + L.dist, th, nullptr, oS, A, a.clip_log_std, a.min_log_std, tid);
+        // the action slots >= 8 of the cotangent tiles read as zero (the end-of-segment slabs alias them: once per segment)
+        for (int e = lane; e < 3 * DPL; e += 64) wreg[L.dm + e] = 0.f;
+        __syncthreads();
+        CH_STAMP(1);
+        W.s0 = dist[CH_LS + W.q0]; W.s1 = dist[CH_LS + W.q1]; W.e0 = dist[CH_ES + W.q0]; W.e1 = dist[CH_ES + W.q1];
+        W.sn20 = dist[CH_SN2 + W.q0]; W.sn21 = dist[CH_SN2 + W.q1]; W.rden0 = dist[CH_RDEN + W.q0]; W.rden1 = dist[CH_RDEN + W.q1];
+        W.sums = 0.f;                                 // sum of the log standard deviations (log-likelihood objective)
+        for (int aa = 0; aa < A; ++aa) W.sums += dist[CH_LS + aa];
+
+        PassSums<NC1, NC2> S;
+#pragma unroll
+        for (int i = 0; i < NB1; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S.aw1[i][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S.aw2[i][j][r] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) {
+            S.aw3[c] = zero4();
+            S.gb2[c] = zero4();
+        }
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) S.gb1[c] = zero4();
+        S.loss = S.klsum = S.gs0 = S.gs1 = S.gb30 = S.gb31 = 0.f;
+
+        u32x4 w1f[3][NC1];
+        pass_load_frags<NC1>(w1f, (const u32x4*)(sm + L.wp) + lane, L.n_frag, L.f_w1, 64);
+        W.tix = 0;
+        PassPending<NC1> Q;
+        if (t < W.tend) {
+            pass_tile<NC1, NC2, BWD, STORE, false>(S, Q, w1f, xr, W, T, sm, wreg, lane, t, t + NW);
+            for (t += NW; t < W.tend; t += NW) {
+                W.tix += 1;
+                pass_tile<NC1, NC2, BWD, STORE, true>(S, Q, w1f, xr, W, T, sm, wreg, lane, t, t + NW);
+            }
+            if (BWD) pass_flush_pending<NC1, NC2>(S, Q);
+        }
+        CH_STAMP(2);
+
+        float* P = a.partials + (long long)sg * a.partial_stride;
+        float loss = S.loss, klsum = S.klsum, gs0 = S.gs0, gs1 = S.gs1, gb30 = S.gb30, gb31 = S.gb31;
+        // per-action sums: lanes of one kk group differ in the sample; scalars live in the kk = 0 lanes
+        gs0 = row16_sum(gs0);  gs1 = row16_sum(gs1);  gb30 = row16_sum(gb30);
+        gb31 = row16_sum(gb31);  loss = row16_sum(loss);  klsum = row16_sum(klsum);
+        if (!BWD) {   // only the two scalars leave the workgroup
+            lds_barrier();
+            if (lane == 0) {
+                sm[4 + 2 * w] = loss;
+                sm[4 + 2 * w + 1] = klsum;
+            }
+            lds_barrier();
+            if (tid == 0) {
+                float l = 0.f, k = 0.f;
+                for (int ww = 0; ww < NW; ++ww) {
+                    l += sm[4 + 2 * ww];
+                    k += sm[4 + 2 * ww + 1];
+                }
+                P[NP] = l;
+                P[NP + 1] = k;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int c = 0; c < NC1; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S.gb1[c][r] = row16_sum(S.gb1[c][r]);
+#pragma unroll
+        for (int c = 0; c < NC2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S.gb2[c][r] = row16_sum(S.gb2[c][r]);
+        gs0 *= dist[CH_LMASK + W.q0];
+        gs1 *= dist[CH_LMASK + W.q1];
+        pass_reduce_to_partial<NC1, NC2, NW>(sm + 4, P, S.aw2, S.aw1, S.aw3, S.gb1, S.gb2, gs0, gs1, gb30, gb31, loss, klsum, O, A, tid);
+        CH_STAMP(3);
+        CH_WGSTAMP(1 + (sg - sg0 < 2 ? sg - sg0 : 1));
+    }
 }

@@ -1,7 +1,7 @@
 // promp_kernels_policy_wide.h -- the policy passes for obs_dim up to 128 and hidden width 64 or 128
 // (BASELINE config 4: AntRandDirec, obs 111, act 8, 2x128 tanh MLP; also Ant with the reference's default 2x64).
 //
-// Same mathematics, arguments and partial-sum layout as k_fwd_bwd / k_hvp (promp_kernels_policy.h), different
+// Same mathematics, arguments and partial-sum layout as k_pass / k_chain_hvp (promp_kernels_pass.h, promp_kernels_chain.h), different
 // decomposition.  At H = 128 one wave can no longer hold a whole hidden_1 gradient (128x128 = 256 accumulator
 // registers per lane), and theta (137 KB) no longer fits next to the activation tiles in the 160 KB LDS.  So the
 // workgroup turns cooperative:
@@ -146,7 +146,7 @@ PROMP_DEV void wide_load_x(float* Xs, int XS, const float* obs, long long row0, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_wide_fwd_bwd: objective (+ gradient) of one policy pass; PassArgs / partial layout of k_fwd_bwd.
+// k_wide_fwd_bwd: objective (+ gradient) of one policy pass; PassArgs / partial layout of k_pass.
 // grid = work items (table 0), block = 512, one workgroup per CU.
 // ---------------------------------------------------------------------------------------------
 template <int H, int NOB, bool BWD>
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_fwd_bwd(PassArgs a) {
             for (int r = 0; r < 4; ++r) Mss[(16 * w + 4 * kk + r) * MS + i16] = acc[r];
         }
         __syncthreads();
-        // ---- distribution + objective epilogue (same arithmetic as k_fwd_bwd)
+        // ---- distribution + objective epilogue (same arithmetic as k_pass)
         if (epi) {
             const bool rvalid = erow < nrows;
             const long long n = (long long)base + (rvalid ? erow : 0);

@@ -194,6 +194,66 @@ inline f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     W.bar.arrive_and_wait();
     return d;
 }
+// ---- word-packed BF16 fragments (two bf16 per 32-bit word, low half first), see promp_device.h ----
+typedef unsigned u32x4 __attribute__((vector_size(16)));
+typedef unsigned u32x2 __attribute__((vector_size(8)));
+inline unsigned short emu_word_half(const u32x4& v, int e) { return (unsigned short)(v[e >> 1] >> (16 * (e & 1))); }
+inline f32x4 mfma16_bf16w(u32x4 a, u32x4 b, f32x4 c) {
+    bf16x8 x, y;
+    for (int e = 0; e < 8; ++e) {
+        x.h[e] = emu_word_half(a, e);
+        y.h[e] = emu_word_half(b, e);
+    }
+    return mfma16_bf16(x, y, c);
+}
+// v_mfma_f32_32x32x16_bf16: A[i = l & 31][k = 8 (l >> 5) + e], B[k][j = l & 31]; D col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+inline f32x16 mfma32_bf16w(u32x4 a, u32x4 b, f32x16 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 31, h = l >> 5;
+    for (int e = 0; e < 8; ++e) {
+        W.ha[l][e] = emu_word_half(a, e);
+        W.hb[l][e] = emu_word_half(b, e);
+    }
+    W.bar.arrive_and_wait();
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int kb = 0; kb < 2; ++kb)
+            for (int e = 0; e < 8; ++e) acc += emu_bf2f(W.ha[i + 32 * kb][e]) * emu_bf2f(W.hb[j + 32 * kb][e]);
+        d[r] = acc;
+    }
+    W.bar.arrive_and_wait();
+    return d;
+}
+// ds_read_b64_tr_b16 (semantics measured on the device, tools/micro/tr16_wgrad_probe.hip): lane i of a 16-lane group receives
+// element i % 4 of the 8-byte chunks named by the lanes i / 4, 4 + i / 4, 8 + i / 4, 12 + i / 4 of its group
+inline u32x2 lds_tr16(const void* p) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), g = l & ~15, i = l & 15;
+    if (((uintptr_t)p & 7) != 0) { fprintf(stderr, "lds_tr16: address not 8-byte aligned\n"); abort(); }
+    // the hardware executes a wave's LDS instructions in order, so the chunks other lanes stored before this read are there;
+    // here the lanes are free-running threads: wait until every lane has reached the read (= has done its stores)
+    W.bar.arrive_and_wait();
+    memcpy(W.ha[l], p, 8);
+    W.bar.arrive_and_wait();
+    unsigned short v[4];
+    for (int jj = 0; jj < 4; ++jj) v[jj] = W.ha[g + 4 * jj + (i >> 2)][i & 3];
+    W.bar.arrive_and_wait();
+    u32x2 r;
+    r[0] = v[0] | ((unsigned)v[1] << 16);
+    r[1] = v[2] | ((unsigned)v[3] << 16);
+    return r;
+}
+inline void bf16_split3_pair(float x0, float x1, unsigned (&w)[3]) {
+    float r0 = x0, r1 = x1;
+    for (int t = 0; t < 3; ++t) {
+        const unsigned short h0 = emu_f2bf(r0), h1 = emu_f2bf(r1);
+        w[t] = h0 | ((unsigned)h1 << 16);
+        r0 -= emu_bf2f(h0);
+        r1 -= emu_bf2f(h1);
+    }
+}
 inline f64x4 mfma16d(double a, double b, f64x4 c) {
     emu::Wave& W = emu::wave();
     const int l = emu::lane(), j = l & 15, g = l >> 4;
@@ -222,6 +282,15 @@ inline double emu_shfl_f64(double v, int src) {
 }
 inline float shfl_xor_f32(float v, int m) { return (float)emu_shfl_f64((double)v, emu::lane() ^ m); }
 inline double shfl_xor_f64(double v, int m) { return emu_shfl_f64(v, emu::lane() ^ m); }
+inline float fold_groups16(float v) {
+    v += shfl_xor_f32(v, 32);
+    v += shfl_xor_f32(v, 16);
+    return v;
+}
+inline float row16_sum(float v) {
+    for (int m = 1; m <= 8; m <<= 1) v += shfl_xor_f32(v, m);
+    return v;
+}
 inline double shfl_down_f64(double v, int d) { return emu_shfl_f64(v, emu::lane() + d); }
 inline double shfl_idx_f64(double v, int l) { return emu_shfl_f64(v, l); }
 inline double readlane_f64(double v, int l) { return emu_shfl_f64(v, l); }
@@ -241,6 +310,12 @@ inline void sched_fence() {}
 inline int opaque_zero() { return 0; }
 inline f32x4 pin_agpr(f32x4 v) { return v; }
 inline int wave_uniform(int v) { return v; }
+#define PROMP_SCHED_MFMA(n) ((void)0)
+#define PROMP_SCHED_VALU(n) ((void)0)
+#define PROMP_SCHED_DSREAD(n) ((void)0)
+#define PROMP_SCHED_DSWRITE(n) ((void)0)
+template <class T> inline void pin_v(T&) {}
+template <class T> inline void pin_a(T&) {}
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }

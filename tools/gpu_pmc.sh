@@ -20,7 +20,7 @@ for f in glob.glob('gpurun_out/pmc/p*/**/*counter_collection.csv', recursive=Tru
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 with open('gpurun_out/pmc/summary.txt', 'w') as out:
     for k, d in acc.items():
-        if 'chain' not in k and 'wide' not in k: continue
+        if 'chain' not in k and 'wide' not in k and 'k_pass' not in k: continue
         out.write(k + '\n')
         for c, v in sorted(d.items()):
             out.write('   %-28s mean %14.1f  n %d\n' % (c, sum(v) / len(v), len(v)))

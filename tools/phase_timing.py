@@ -1,4 +1,4 @@
-"""Developer tool: cycle stamps of workgroup 0 / thread 0 inside k_chain_hvp on config-3 shapes.
+"""Developer tool: cycle stamps of workgroup 0 / thread 0 inside k_pass / k_chain_hvp on config-3 shapes.
 Needs a library built with -DPROMP_DEV_STAMPS (tools/build_variant.sh stamps -DPROMP_DEV_STAMPS; copy it over
 promp_amd/libpromp_hip.so for the run)."""
 import ctypes as C
@@ -19,7 +19,8 @@ ctx.process_samples(0, normalize_adv=True)
 fn = ctx.lib.cdll.promp_debug_phase_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
-names = ['L1', 'L2', 'L3', 'epi', 'dW3', 'dz2', 'dW2', 'dz1', 'dW1']
+names_hvp = ['L1', 'L2', 'L3', 'epi', 'dW3', 'dz2', 'dW2', 'dz1', 'dW1']
+names_pass = ['0:X,L1', '1:tanh,split|dW1', '2:L2', '3:tanh,split', '4:L3,epi', '5:dH2', '6:dz2,split|dW3', '7:dH1', '8:dz1,split|dW2', '9:requests', '-']
 import os
 for hvp in tuple(int(x) for x in os.environ.get('PROMP_STAMP_KERNELS', '0,1').split(',')):
     for rep in range(3):
@@ -29,11 +30,6 @@ for hvp in tuple(int(x) for x in os.environ.get('PROMP_STAMP_KERNELS', '0,1').sp
     s = buf.astype(np.int64)
     t0 = s[0]
     print('kernel', 'hvp' if hvp else 'pass', ' net1@%d nets@%d zeroed@%d' % (s[5] - t0, s[6] - t0, s[7] - t0), ' staged@%d  loop_end@%d  partial_written@%d  task_reduce_done@%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
-    if not hvp:
-        print('  pass end phase: loop_end@%d  shuffles_done@%d barrier1@%d slab1_written@%d sum1_done@%d slab2_written@%d barrier@%d end@%d' % tuple(int(x - t0) for x in (s[2], s[4], s[5], s[6], s[7], s[200], s[201], s[3])))
-    if not hvp:
-        for b in range(4):
-            print('  wg', b, 'wave loop ends', [int(x - t0) for x in s[208 + 8 * b: 216 + 8 * b]], 'tiles', [int(x) for x in s[128 + 8 * b: 136 + 8 * b]])
     wg = s[256:].reshape(-1, 4)
     wg = wg[wg[:, 0] > 0]
     w0 = wg[:, 0].min()
@@ -44,7 +40,9 @@ for hvp in tuple(int(x) for x in os.environ.get('PROMP_STAMP_KERNELS', '0,1').sp
              np.median((end - w0)[two]) / 100.0 if two.any() else 0, np.median((end - w0)[~two]) / 100.0))
     print('  own duration (us) one-seg median %.1f max %.1f; two-seg median %.1f max %.1f' % (np.median((end - wg[:, 0])[~two]) / 100., ((end - wg[:, 0])[~two]).max() / 100., np.median((end - wg[:, 0])[two]) / 100. if two.any() else 0, ((end - wg[:, 0])[two]).max() / 100. if two.any() else 0))
     for tix in range(4):
-        st = s[8 + 16 * tix: 8 + 16 * tix + 10]
+        st = s[8 + 16 * tix: 8 + 16 * tix + 12]
         if st[0] == 0:
             continue
-        print('  tile', tix, 'start@%d' % (st[0] - t0), ' '.join('%s %d' % (names[i], st[i + 1] - st[i]) for i in range(9)), ' total', st[9] - st[0])
+        names = names_hvp if hvp else names_pass
+        nph = 9 if hvp else 10
+        print('  tile', tix, 'start@%d' % (st[0] - t0), ' '.join('%s %d' % (names[i], st[i + 1] - st[i]) for i in range(nph)), ' total', st[nph] - st[0])
