@@ -125,6 +125,19 @@ PROMP_DEV void pass_split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
 // tanh of a pre-activation that arrives scaled by PROMP_TANH_PRESCALE, and h^2 - 1 (the NEGATED derivative): unpacked float32
 // instructions (packed-f32 VALU beside MFMAs costs more than the issue slot it saves: MI355X_MICROARCH.md)
 PROMP_DEV float pass_tanh(float y) { return __builtin_fmaf(fast_rcp(fast_exp2(y) + 1.f), -2.f, 1.f); }
+// four at a time, stage by stage: a transcendental's result is not consumed by the very next instruction (no hazard s_nop)
+PROMP_DEV f32x4 pass_tanh4(f32x4 y) {
+    f32x4 e, r, h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = fast_exp2(y[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] += 1.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fast_rcp(e[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = __builtin_fmaf(r[i], -2.f, 1.f);
+    return h;
+}
 PROMP_DEV float pass_neg_dtanh(float h) { return __builtin_fmaf(h, h, -1.f); }
 
 // The segment's network -> BF16 planes (both orientations of the hidden_1 kernel) and float32 side tables in LDS.  A wave
@@ -456,8 +469,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     u32x4 hB1[NP1][3];
 #pragma unroll
     for (int c = 0; c < NC1; ++c) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[c][r] = pass_tanh(h1[c][r]);
+        h1[c] = pass_tanh4(h1[c]);
         if (STORE) *(f32x4*)(hcb + 256 * c) = h1[c];
     }
 #pragma unroll
@@ -495,8 +507,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     u32x4 hB2[NP2][3];
 #pragma unroll
     for (int c = 0; c < NC2; ++c) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h2[c][r] = pass_tanh(h2[c][r]);
+        h2[c] = pass_tanh4(h2[c]);
         if (STORE) *(f32x4*)(hcb + 256 * (NC1 + c)) = h2[c];
     }
 #pragma unroll
