@@ -107,11 +107,9 @@ struct PassArgs {
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
 };
 
-// Layer 2 of the R-operator pass (tangent, and the primal product where it is not read from the cache) runs on the BF16 matrix pipe (error-compensated 3-way split of both
-// operands, 6 of the 9 products, float32 accumulation: more accurate than the FP32 MFMA chain).
-#ifndef PROMP_BF16_L2
-#define PROMP_BF16_L2 1
-#endif
+// Layer 2 of the R-operator pass (tangent, and the primal product where it is not read from the cache) runs on the BF16 matrix pipe
+// (error-compensated 3-way split of both operands, 6 of the 9 products, float32 accumulation: at least as accurate as the FP32
+// MFMA chain; guarded by tests/test_gpu_parity.py::test_split_gemm_accuracy_guard).
 
 struct ChainLds {
     int w1, w2, w3, w3b, b1, b2, b3, dist;   // inside one network block
@@ -146,7 +144,7 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP) {
     // a ds_read immediate offset reaches, and every such read would cost an address add: +4.5 us per launch, measured)
     L.planes = o;
     L.plane_stride = 3 * NC2 * (NC1 / 2) * 256;
-    o += (hvp && PROMP_BF16_L2 != 0) ? 2 * L.plane_stride : 0;
+    o += hvp ? 2 * L.plane_stride : 0;
     L.wave0 = o;
     int q = 0;
     L.tb0 = q; q += 16 * PROMP_CH_TS;
@@ -489,7 +487,6 @@ template <int NC1, int NC2, int KS, int NW, bool CACHED = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     constexpr int NT = 64 * NW, H1 = 16 * NC1, H2 = 16 * NC2, TS = PROMP_CH_TS, DS = PROMP_CH_DS, NOB = KS > 4 ? 2 : 1;
     constexpr int HCR = chain_cache_row(H1, H2);
-    constexpr bool BF16L2 = PROMP_BF16_L2 != 0;
     constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0);
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -541,7 +538,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         for (int e = lane; e < 2 * 16 * DS; e += 64) DB0[e] = 0.f;
         CH_STAMP(7);
         __syncthreads();
-        if (BF16L2) {
+        {
             // BF16 planes of both networks' hidden_1 kernels out of the float32 fragments staged above
             constexpr int NCH = NC2 * (NC1 / 2) * 64;
             for (int ch = tid; ch < 2 * NCH; ch += NT) {
@@ -672,7 +669,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     h2[c] = CACHED ? ch2[c] : lds4(B2l + 16 * c);
                     rh2[c] = lds4(B2l + VO + 16 * c);
                 }
-                if (BF16L2) {
+                {
                     // R'z2 += W2^T R'H1 + (-vW2)^T H1 on the BF16 pipe: K = 32 per instruction = two 16-unit input blocks; a
                     // lane's eight k-slots are its own registers of the two blocks (units 16 c + 4 kk + r), split three ways
                     const bf16x8* Wp = (const bf16x8*)(sm + L.planes) + lane;
@@ -702,26 +699,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                             for (int c2 = 0; c2 < NC2; ++c2)
                                 rh2[c2] = mfma16_bf16(Vp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], hB[TB[p]], rh2[c2]);
                         }
-                    }
-                }
-#pragma unroll
-                for (int c1 = 0; c1 < (BF16L2 ? 0 : NC1); ++c1) {
-                    f32x4 wf[NC2], vf[NC2];
-#pragma unroll
-                    for (int c2 = 0; c2 < NC2; ++c2) {
-                        wf[c2] = lds4(W2l + (c2 * NC1 + c1) * PROMP_CH_BLK);
-                        vf[c2] = lds4(W2l + VO + (c2 * NC1 + c1) * PROMP_CH_BLK);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (!CACHED) {
-#pragma unroll
-                            for (int c2 = 0; c2 < NC2; ++c2) h2[c2] = mfma16(wf[c2][r], h1[c1][r], h2[c2]);
-                        }
-#pragma unroll
-                        for (int c2 = 0; c2 < NC2; ++c2) rh2[c2] = mfma16(wf[c2][r], rh1[c1][r], rh2[c2]);
-#pragma unroll
-                        for (int c2 = 0; c2 < NC2; ++c2) rh2[c2] = mfma16(vf[c2][r], h1[c1][r], rh2[c2]);
                     }
                 }
 #pragma unroll

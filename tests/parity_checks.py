@@ -207,6 +207,43 @@ def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False):
     ctx.close()
 
 
+def check_split_accuracy(lib, hidden, O, A, seed=11, M=2, P=2, T=48, tol=2.5e-6):
+    """Guard of the BF16-split GEMMs (k_pass: every GEMM; k_chain_hvp: layer 2): on a small well-conditioned case the gradient,
+    the Hessian-vector product and the meta-gradient must agree with the float64 oracle to float32 rounding.  Measured on the
+    MI355X (profiles/r03_split_accuracy.txt, tools/split_accuracy_gpu.py): six products of the 3-way split 1.7e-7 ... 1.0e-6 of
+    the result's max-norm; the same kernels built with THREE products 5e-6 ... 5e-5.  tol = 2.5e-6 sits between the two: a
+    regression of any GEMM to fewer products (or to plain BF16) fails here, long before the 1e-4 of the functional tests."""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
+    spec = op.PolicySpec(O, A, hidden)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    rng = np.random.RandomState(seed + 1)
+    th = (theta + 0.02 * rng.randn(M, theta.size)).astype(np.float32)
+    ctx.set_task_thetas(th)
+    for kind, name in ((0, 'ratio'), (2, 'loglik')):
+        g, _, _ = ctx.eval_loss_grad(1, kind, clip_eps=0.3, clip_log_std=False)
+        for i in range(M):
+            ref = pm.loss_and_grad(spec, th[i].astype(np.float64), all_slabs[1][i], name, False, clip_eps=0.3)['grad']
+            assert rel_max(g[i], ref) < tol, ('gradient', name, i, rel_max(g[i], ref))
+    v = rng.randn(M, theta.size).astype(np.float32)
+    for kind, name in ((0, 'ratio'), (1, 'loglik')):
+        hv = ctx.eval_hvp(0, v, inner_kind=kind, clip_log_std=True, kl_weight=0.37)
+        for i in range(M):
+            t64 = th[i].astype(np.float64)
+            ref = -pm.hvp(spec, t64, all_slabs[0][i], v[i].astype(np.float64), name, True) + \
+                0.37 * pm.loss_and_grad(spec, t64, all_slabs[0][i], name, True)['grad_kl']
+            assert rel_max(hv[i], ref) < tol, ('hvp', name, i, rel_max(hv[i], ref))
+    alpha, eta = np.full(spec.n_params, 0.1, np.float32), np.array([5e-4], np.float32)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(alpha)
+    r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), all_slabs, alpha.astype(np.float64), eta.astype(np.float64), 0.3)
+    for cache in (0, 1):          # the recomputing and the cached second-order pass
+        ctx.set_primal_cache(cache)
+        g, _ = ctx.meta_grad(0.3, eta)
+        assert rel_max(g, r['grad']) < tol, ('meta-gradient', cache, rel_max(g, r['grad']))
+    ctx.close()
+
+
 def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, compact_log_std=False):
     """meta-objective + exact gradient, _adapt, and E Adam epochs + compute_stats."""
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=ragged)

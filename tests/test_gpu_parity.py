@@ -66,6 +66,11 @@ def test_unequal_hidden_widths(lib, hidden, O, A):
     pc.check_meta(lib, 36, M=3, P=3, T=60, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2)
 
 
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2)])
+def test_split_gemm_accuracy_guard(lib, hidden, O, A):
+    pc.check_split_accuracy(lib, hidden, O, A)
+
+
 def test_unsupported_hidden_widths_are_rejected(lib):
     for hidden, O in (((48, 48), 4), ((64, 128), 4), ((32, 32, 32), 4)):
         with pytest.raises((_lib.PrompError, ValueError, TypeError)):
