@@ -244,9 +244,14 @@ def main():
                    'meta_batch_size': M_global, 'tasks_per_gpu': M, 'rows_per_task_per_step': N,
                    'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
                    'device': info['name'],
-                   'numerics': 'float32 (exact-FP32 MFMA; sample processing float64); layer 2 of the second-order pass runs as 6 BF16 '
-                               'products of a 3-way error-compensated split with float32 accumulation (error <= the FP32 chain\'s, '
-                               'DESIGN.md 5.2b)'},
+                   'numerics': 'float32-equivalent: the first-order passes (k_pass) compute every GEMM, and the second-order pass '
+                               '(k_chain_hvp) its layer 2, as 6 BF16 products of a 3-way error-compensated split with float32 '
+                               'accumulation (measured <= 1.0e-6 of the float64 oracle, the FP32 fma chain\'s own level; a 3-product '
+                               'build measures 5e-6 .. 5e-5; guarded at 2.5e-6 by test_split_gemm_accuracy_guard); the other GEMMs '
+                               'of the second-order pass on the exact-FP32 MFMA; sample processing float64',
+                   'schedule': 'the first Adam epoch takes its first inner pass (theta on step 0) from the _adapt call that just '
+                               'evaluated it instead of repeating it (promp_set_reuse_adapt, default on; bit-identical, '
+                               'test_first_epoch_reuses_the_inner_adapt_pass): 11 instead of 12 first-order passes per step'},
     }
 
     # ---- config 5 with the exact constraint Hessian-vector product (promp_constraint_hvp) instead of the reference's finite
@@ -301,7 +306,7 @@ def main():
         fl = flops_per_row(O, hidden[0], hidden[1], A)
         kern = {}
         hvp_name = 'k_chain_hvp' if (hidden[0] <= 64 and O <= 32) else 'k_wide_hvp'
-        pass_name = 'k_fwd_bwd' if (hidden[0] <= 64 and O <= 32) else 'k_wide_fwd_bwd'
+        pass_name = 'k_pass' if (hidden[0] <= 64 and O <= 32) else 'k_wide_fwd_bwd'
         for name, kid, f in ((pass_name, _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), (hvp_name, _lib.KERNEL_HVP, fl['hvp']),
                              (pass_name + '<fwd-only>', _lib.KERNEL_FWD, fl['fwd'])):
             pr = ctx.prof_read(kid)
@@ -318,6 +323,8 @@ def main():
         traffic = measured_traffic(dom) if args.config == 3 else None   # the committed PMC passes are of config 3
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'], 'peak': FP32_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS,
+                           'peak_note': 'algorithmic float32 FLOPs (SURVEY 8d: matmul only, 2 / MAC) over the FP32 peak of 157.3 TFLOP/s; '
+                                        'k_pass issues them as float32-equivalent BF16 products (6 per float32 product), see config.numerics',
                            'traffic': traffic['bytes'] if traffic else None, 'traffic_source': traffic['source'] if traffic else None,
                            'algorithmic_bytes_per_launch': 4 * (O + 2 * A + 2) * kern[dom]['rows_per_launch'],
                            'avg_launch_ms': kern[dom]['avg_ms'], 'kernels': kern,
@@ -355,10 +362,26 @@ def measured_traffic(kernel):
     if not files:
         return None
     try:
-        t = json.load(open(files[-1])).get(kernel)
+        doc = json.load(open(files[-1]))
+        # the file names the kernel sources it was measured on (tools/summarize_round.py): counters of other sources are not
+        # this run's traffic and are not reported as such
+        if doc.get('_kernel_sources_sha256') != kernel_sources_sha256():
+            return dict(bytes=None, source='%s is of other kernel sources (stale): not reported' % os.path.relpath(files[-1], ROOT))
+        t = doc.get(kernel)
         return dict(bytes=t['hbm_bytes_per_launch'], source=os.path.relpath(files[-1], ROOT)) if t else None
     except Exception:
         return None
+
+
+def kernel_sources_sha256():
+    """content hash of promp_amd/csrc (what the counters of a traffic file were measured on)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'promp_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()
 
 
 def cpu_baseline(cfg, theta0, alpha, eta, opts, E, trpo=False, steps=3, oracle_tasks=8):

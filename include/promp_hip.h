@@ -176,6 +176,18 @@ int promp_set_schedule(promp_ctx* ctx, int stage_overlap, int fuse_min_tasks);
  * contract in different orders).  on = 1 always, 0 never, -1 (default) whenever a step holds at least two rounds of
  * 16-row tiles per compute unit -- below that the passes are all fixed cost and the stores do not pay. */
 int promp_set_primal_cache(promp_ctx* ctx, int on);
+/* The inner step and the first epoch of the optimisation that follows it evaluate the same pass.  MAMLAlgo._adapt
+ * (meta_algos/base.py:217-242) runs the inner gradient step of every task from the meta-parameters; the first thing
+ * ProMP.optimize_policy's graph (pro_mp.py:113-128) then evaluates is that very step again.  With reuse on (default),
+ * promp_inner_adapt(step 0) from the pre-update state also leaves theta', the inner scalars and the primal cache where the
+ * meta-objective's first evaluation looks for them, and that evaluation skips its first pass as long as nothing the pass reads
+ * has changed since (meta-parameters, step-0 slab and advantages, step sizes, inner objective, min_std, learn_std; tracked by
+ * version counters) and no log_std entry is below log(min_std) -- the one place where the two differ (raw log_std in the inner
+ * step, policies/gaussian_mlp_policy.py:182; clipped in the graph's first step, :71,163).  The library knows the smallest
+ * log_std entry from promp_set_theta or from the statistics the last optimisation published; otherwise it does not skip.
+ * Bit-identical results either way.  promp_adapt_passes_skipped counts the skipped passes (for tests / logs). */
+int promp_set_reuse_adapt(promp_ctx* ctx, int on);
+long long promp_adapt_passes_skipped(promp_ctx* ctx);
 int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
 int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);
 /* MetaPolicy.switch_to_pre_update: replicate theta into every task's parameter slot */

@@ -71,6 +71,8 @@ SIGNATURES = {
     'promp_set_step_sizes': (C.c_int, [_P, _F]),
     'promp_set_learn_std': (C.c_int, [_P, C.c_int]),
     'promp_set_primal_cache': (C.c_int, [_P, C.c_int]),
+    'promp_set_reuse_adapt': (C.c_int, [_P, C.c_int]),
+    'promp_adapt_passes_skipped': (C.c_longlong, [_P]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
     'promp_set_rewards_f64': (C.c_int, [_P, C.c_int, _D]),
@@ -428,6 +430,14 @@ class Context:
         """the second-order pass reads the inner gradient pass's activations back instead of recomputing them
         (True / False; None = the default: on for steps with at least two rounds of tiles per compute unit)"""
         self._call('promp_set_primal_cache', -1 if on is None else int(bool(on)))
+
+    def set_reuse_adapt(self, on=True):
+        """the first epoch of an optimisation takes the inner pass promp_inner_adapt just ran instead of repeating it
+        (bit-identical; default on)"""
+        self._call('promp_set_reuse_adapt', int(bool(on)))
+
+    def adapt_passes_skipped(self):
+        return int(self.lib.cdll.promp_adapt_passes_skipped(self._h))
 
     def set_min_std(self, min_std):
         self._call('promp_set_min_std', float(min_std))

@@ -55,6 +55,7 @@ struct StepData {
     int rollout_B = 0, rollout_T = 0;  // environments per task / horizon of a device-side rollout in progress (promp_begin_rollout)
     int n_chain_wg = 0;                // workgroups of the register-chained kernels k_pass / k_chain_hvp (segment table)
     bool has_policy = false, processed = false, has_adv = false;
+    unsigned long long data_version = 0;   // bumped by every entry point that may change what the policy passes read from this step
     int ls_per_row = 0;
     int feat_dim = 0;
     float *obs = nullptr, *act = nullptr, *rew = nullptr, *old_mean = nullptr, *old_ls = nullptr;
@@ -146,6 +147,17 @@ struct promp_ctx {
     float* pass_row_tan = nullptr;       // launch_pass (R-operator pass): where the rows' log-likelihood tangents go
     int pass_cache = 0;                  // launch_pass: 1 = the gradient pass fills the step's primal cache, 2 = the R-operator pass reads it
     int primal_cache = -1;               // promp_set_primal_cache: 1 on, 0 off, -1 on from two rounds of tiles per CU on
+    // promp_inner_adapt(step 0) from the meta-parameters evaluates exactly what the first epoch of the following optimisation
+    // evaluates first (the inner pass at theta on step 0's slab): it leaves theta', the inner scalars and the primal cache
+    // where that epoch expects them, and the epoch skips its pass while nothing it depends on has changed (reuse_adapt).
+    unsigned long long version_counter = 0, theta_version = 0, sizes_version = 0;
+    struct { bool valid = false; unsigned long long theta_version = 0, data_version = 0, sizes_version = 0; int inner_kind = 0; bool cached = false; float min_log_std = 0.f; bool learn_std = true; } adapt0;
+    bool reuse_adapt = true;             // promp_set_reuse_adapt
+    bool ls_known = false;               // ls_min is the smallest log_std entry of the current theta
+    float ls_min = 0.f;
+    float* pass_next2 = nullptr;         // launch_pass: second destinations of the RED_STEP reduction (see adapt0)
+    float* pass_scal2 = nullptr;
+    long long adapt_passes_skipped = 0;
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
@@ -207,7 +219,10 @@ struct StepScope {
     promp_ctx* c;
     StepData& S;
     int rc;
-    StepScope(promp_ctx* c_, StepData& S_) : c(c_), S(S_), rc(join_side(c_, S_) | settle_others(c_, &S_)) {}
+    // writes: the entry point may change what a policy pass reads from the step (slabs, advantages, layout); pure readers say so
+    StepScope(promp_ctx* c_, StepData& S_, bool writes = true) : c(c_), S(S_), rc(join_side(c_, S_) | settle_others(c_, &S_)) {
+        if (writes) S.data_version = ++c->version_counter;
+    }
     ~StepScope() { S.dirty = true; }
 };
 
@@ -367,6 +382,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     r.step_sizes = c->step_sizes; r.mode = red_mode;
     r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
     r.lam = c->lam; r.v = c->vbuf; r.scal = scal;
+    r.next2 = red_mode == RED_STEP ? c->pass_next2 : nullptr; r.scal2 = red_mode == RED_STEP ? c->pass_scal2 : nullptr;
     PROMP_LAUNCH(k_reduce_task, dim3((c->NP + 2 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, r);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -401,6 +417,17 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         const bool cached = want_grad && worth && !c->wide && policy_shape_chain(&c->d);
         if (cached && !c->steps[k].hcache &&
             dev_alloc(&c->steps[k].hcache, ((size_t)c->d.max_rows + 16 * (size_t)M) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
+        // promp_inner_adapt has left exactly this pass's results behind (see there) if nothing it read has changed since and
+        // the clip of log_std at log(min_std) -- the one difference between the two -- is not active
+        const bool reuse = k == 0 && c->reuse_adapt && c->adapt0.valid && c->adapt0.theta_version == c->theta_version &&
+                           c->adapt0.data_version == c->steps[0].data_version && c->adapt0.sizes_version == c->sizes_version &&
+                           c->adapt0.inner_kind == inner_kind && c->adapt0.cached == cached && c->adapt0.min_log_std == c->min_log_std &&
+                           c->adapt0.learn_std == c->learn_std && c->ls_known && c->ls_min >= c->min_log_std && !c->pass_adv;
+        if (reuse) {
+            c->adapt_passes_skipped += 1;
+            filled[k] = cached;
+            continue;
+        }
         c->pass_cache = cached ? 1 : 0;
         const int rc0 = launch_pass(c, c->steps[k], false, th, st, loss_kind_inner(inner_kind), clip_eps, k == 0, 0.f, false, RED_STEP, th, st,
                                     c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2);
@@ -458,7 +485,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     }
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
-    ad.stats = c->stats + (size_t)c->stats_slot * (K + 2); ad.NP = NP; ad.K = K;
+    ad.stats = c->stats + (size_t)c->stats_slot * (K + 2); ad.NP = NP; ad.K = K; ad.A = c->d.act_dim;
     for (int k = 0; k < PROMP_ETA_MAX; ++k) ad.eta[k] = k < K ? eta_host[k] : 0.f;
     ad.host_stats = c->publish_next ? c->stats_host : nullptr; ad.host_seq = c->stats_seq_host; ad.seq = c->stats_seq;
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
@@ -466,6 +493,8 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     ad.n_trainable = c->learn_std ? NP : NP - c->d.act_dim;
     ad.lr_t = 0.f;
     if (do_adam) {
+        c->theta_version = ++c->version_counter;     // (the smallest log_std entry is unknown until the next publication)
+        c->ls_known = false;
         c->adam_t += 1;
         const double t = (double)c->adam_t;
         ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
@@ -645,7 +674,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     rc |= dev_alloc(&c->red64, 64);
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
-    if (hipHostMalloc((void**)&c->stats_host, sizeof(float) * 2 * (K + 2), hipHostMallocDefault) != hipSuccess) rc |= 1;
+    if (hipHostMalloc((void**)&c->stats_host, sizeof(float) * (2 * (K + 2) + 1), hipHostMallocDefault) != hipSuccess) rc |= 1;
     if (hipHostMalloc((void**)&c->stats_seq_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) rc |= 1;
     else *c->stats_seq_host = 0;
     c->steps.resize(K + 1);
@@ -947,6 +976,7 @@ int promp_commit_step(promp_ctx* c, int step) {
     if (mark_use(c, c->steps[step])) return -2;
     std::swap(c->steps[step], c->back[step]);
     c->steps[step].staged = false;
+    c->steps[step].data_version = ++c->version_counter;
     return 0;
 }
 
@@ -1042,7 +1072,7 @@ int promp_download_processed(promp_ctx* c, int step, float* returns, float* adv,
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     if (!S.processed) return fail(-3, "step %d has not been processed", step);
     hipStream_t st = c->stream;
@@ -1066,7 +1096,7 @@ int promp_download_raw(promp_ctx* c, int step, double* ret64, double* adv64) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     if (!S.processed) return fail(-3, "step %d has not been processed", step);
     if (ret64) HIPCHECK(hipMemcpyAsync(ret64, S.ret64, sizeof(double) * S.n_rows, hipMemcpyDeviceToHost, c->stream));
@@ -1096,7 +1126,7 @@ int promp_predict_baseline(promp_ctx* c, int step, int kind, double* out) {
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (kind < 0 || kind > 2) return fail(-1, "unknown baseline kind %d", kind);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     SampleArgs a;
@@ -1169,7 +1199,14 @@ static int copy_out(promp_ctx* c, float* dst, const float* src, size_t n) {
     return 0;
 }
 
-int promp_set_theta(promp_ctx* c, const float* th) { return c ? copy_in(c, c->theta, th, c->NP) : fail(-1, "ctx is NULL"); }
+int promp_set_theta(promp_ctx* c, const float* th) {
+    if (!c || !th) return fail(-1, "NULL argument");
+    c->theta_version = ++c->version_counter;
+    c->ls_min = th[c->NP - c->d.act_dim];
+    for (int i = 1; i < c->d.act_dim; ++i) c->ls_min = std::min(c->ls_min, th[c->NP - c->d.act_dim + i]);
+    c->ls_known = true;
+    return copy_in(c, c->theta, th, c->NP);
+}
 int promp_get_theta(promp_ctx* c, float* th) { return c ? copy_out(c, th, c->theta, c->NP) : fail(-1, "ctx is NULL"); }
 static int mask_log_std_step_sizes(promp_ctx* c) {
     if (c->learn_std) return 0;
@@ -1178,6 +1215,7 @@ static int mask_log_std_step_sizes(promp_ctx* c) {
 }
 int promp_set_step_sizes(promp_ctx* c, const float* s) {
     if (!c) return fail(-1, "ctx is NULL");
+    c->sizes_version = ++c->version_counter;
     if (copy_in(c, c->step_sizes, s, c->NP)) return -2;
     return mask_log_std_step_sizes(c);
 }
@@ -1196,6 +1234,13 @@ int promp_set_schedule(promp_ctx* c, int stage_overlap, int fuse_min_tasks) {
     if (fuse_min_tasks >= 0) c->fuse_min_tasks = fuse_min_tasks;
     return 0;
 }
+int promp_set_reuse_adapt(promp_ctx* c, int on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->reuse_adapt = on != 0;
+    c->adapt0.valid = false;
+    return 0;
+}
+long long promp_adapt_passes_skipped(promp_ctx* c) { return c ? c->adapt_passes_skipped : -1; }
 int promp_set_primal_cache(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
     c->primal_cache = on < 0 ? -1 : on != 0;
@@ -1205,6 +1250,7 @@ int promp_set_learn_std(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
     if (on && !c->learn_std) return fail(-3, "learn_std cannot be switched back on: the log_std step sizes were zeroed (set the step sizes again)");
     c->learn_std = on != 0;
+    c->sizes_version = ++c->version_counter;
     return mask_log_std_step_sizes(c);
 }
 static int tasks_materialize(promp_ctx* c);
@@ -1253,14 +1299,40 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     // pre-update mode: all tasks start from theta itself (stride 0); the step writes every task's row of theta_tasks
     const float* cur = c->tasks_shared ? c->theta : c->theta_tasks;
     const long long st = c->tasks_shared ? 0 : c->NP;
+    // From the meta-parameters on step 0 this IS the first inner pass of the meta-objective (pro_mp.py:113-128 rebuilds what
+    // base.py:217-242 just ran): leave theta', the scalars and the primal cache where the first epoch looks for them.  The two
+    // differ only in log_std entries below log(min_std) (raw here, gaussian_mlp_policy.py:182; clipped there, :71,163), which
+    // enqueue_meta checks before it trusts the result.
+    const bool leave = c->reuse_adapt && c->tasks_shared && step == 0 && !c->wide && policy_shape_chain(&c->d) &&
+                       (inner_kind == PROMP_INNER_RATIO || inner_kind == PROMP_INNER_LOGLIK);
+    if (step == 0) c->adapt0.valid = false;       // (inner steps on later sampling steps touch nothing the record stands for)
+    bool cached = false;
+    if (leave) {
+        const size_t MNP = (size_t)c->d.n_tasks * c->NP;
+        const bool worth = c->primal_cache > 0 || (c->primal_cache < 0 && S.n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
+        cached = worth;
+        if (cached && !S.hcache &&
+            dev_alloc(&S.hcache, ((size_t)c->d.max_rows + 16 * (size_t)c->d.n_tasks) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
+        c->pass_next2 = c->chain + MNP;
+        c->pass_scal2 = c->scal_inner;
+        c->pass_cache = cached ? 1 : 0;
+    }
     c->tasks_shared = false;
-    return launch_pass(c, S, false, cur, st, loss_kind_inner(inner_kind), 0.f, 0, 0.f, false, RED_STEP, cur, st, c->theta_tasks, c->scal_tmp);
+    const int rc = launch_pass(c, S, false, cur, st, loss_kind_inner(inner_kind), 0.f, 0, 0.f, false, RED_STEP, cur, st, c->theta_tasks, c->scal_tmp);
+    c->pass_next2 = nullptr; c->pass_scal2 = nullptr; c->pass_cache = 0;
+    if (rc) return rc;
+    if (leave) {
+        c->adapt0.valid = true; c->adapt0.theta_version = c->theta_version; c->adapt0.data_version = S.data_version;
+        c->adapt0.sizes_version = c->sizes_version; c->adapt0.inner_kind = inner_kind; c->adapt0.cached = cached;
+        c->adapt0.min_log_std = c->min_log_std; c->adapt0.learn_std = c->learn_std;
+    }
+    return 0;
 }
 
 int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_out) {
@@ -1425,7 +1497,7 @@ int promp_download_step(promp_ctx* c, int step, float* obs, float* act, float* r
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     if (S.n_rows == 0) return fail(-3, "step %d has no data", step);
     const size_t R = S.n_rows, O = c->d.obs_dim, A = c->d.act_dim, M = c->d.n_tasks;
@@ -1526,6 +1598,9 @@ int promp_adam_step(promp_ctx* c, float lr) {
     ad.inv_tasks = 1.0f / (float)c->d.n_tasks_global;
     ad.do_update = 1;
     ad.n_trainable = c->learn_std ? c->NP : c->NP - c->d.act_dim;
+    ad.A = c->d.act_dim;
+    c->theta_version = ++c->version_counter;
+    c->ls_known = false;
     c->adam_t += 1;
     const double t = (double)c->adam_t;
     ad.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(0.999, t)) / (1.0 - std::pow(0.9, t)));
@@ -1579,6 +1654,8 @@ int promp_optimize_end(promp_ctx* c, float* loss_before, float* stats_after) {
         }
     }
     const int K = c->d.num_inner_steps;
+    c->ls_min = c->stats_host[2 * (K + 2)];       // theta has not changed since the publishing launch read it
+    c->ls_known = true;
     if (stats_after) memcpy(stats_after, c->stats_host, sizeof(float) * (K + 2));
     if (loss_before) *loss_before = c->opt_epochs > 0 ? c->stats_host[K + 2] : c->stats_host[0];
     return 0;
@@ -1596,7 +1673,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (kind < 0 || kind > 3) return fail(-1, "unknown objective kind %d", kind);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     const int M = c->d.n_tasks;
     if (tasks_materialize(c)) return -2;
@@ -1615,7 +1692,7 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     if (!c || !v || !out) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     const int M = c->d.n_tasks, NP = c->NP;
     if (copy_in(c, c->vbuf, v, (size_t)M * NP)) return -2;
@@ -1710,7 +1787,7 @@ int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long
     if (!c || !out) return fail(-1, "NULL argument");
     if (!PROMP_STAMPS_ON) return fail(-3, "phase stamps need a build with -DPROMP_DEV_STAMPS");
     StepData& S = c->steps[step];
-    StepScope scope_(c, S);
+    StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * (256 + 4 * 1024), c->stream));
     c->dbg_enabled = true;

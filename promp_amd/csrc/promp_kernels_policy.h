@@ -33,6 +33,10 @@ struct ReduceArgs {
     float* lam;                  // [tasks][Theta]
     float* v;                    // [tasks][Theta]
     float* scal;                 // [tasks][2]
+    // mode 0 only, optional: the same step / scalars a second time (promp_inner_adapt leaves its result where the first
+    // epoch of the following optimisation would have computed it: its adaptation chain and inner scalars)
+    float* next2;
+    float* scal2;
 };
 
 __global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
@@ -57,11 +61,14 @@ __global__ void __launch_bounds__(256) k_reduce_task(ReduceArgs a) {
     }
     if (j >= a.NP) {
         a.scal[task * 2 + (j - a.NP)] = g;
+        if (a.scal2 != nullptr) a.scal2[task * 2 + (j - a.NP)] = g;
         return;
     }
     const long long tj = (long long)task * a.NP + j;
     if (a.mode == 0) {
-        a.next[tj] = a.cur[(long long)task * a.cur_task_stride + j] - a.step_sizes[j] * g;
+        const float nx = a.cur[(long long)task * a.cur_task_stride + j] - a.step_sizes[j] * g;
+        a.next[tj] = nx;
+        if (a.next2 != nullptr) a.next2[tj] = nx;
         return;
     }
     float lam = g;
@@ -131,14 +138,14 @@ struct AdamArgs {
     float* grad_mean;  // [NP] task-mean gradient (kept for promp_meta_grad's output)
     float* stats;      // [K+2]
     float eta[PROMP_ETA_MAX];   // inner KL coefficients, by value (K <= PROMP_ETA_MAX): no host -> device copy per optimisation
-    int NP, K;
+    int NP, K, A;
     float inv_tasks;
     float lr_t;        // lr * sqrt(1-b2^t)/(1-b1^t); 0 => no parameter update (stats / grad only)
     int do_update;
     int n_trainable;   // parameters [n_trainable, NP) are left alone (learn_std = False: the trailing log_std entries)
     // promp_optimize_begin's last launch: both statistics slots go straight to page-locked host memory, followed by a
     // sequence number the host polls (no copy operation, no event on the queue)
-    float* host_stats;       // [2 (K + 2)] or NULL
+    float* host_stats;       // [2 (K + 2) + 1] or NULL; the last entry: the smallest log_std entry of theta as it is now
     unsigned* host_seq;
     unsigned seq;
 };
@@ -146,6 +153,11 @@ struct AdamArgs {
 PROMP_DEV void publish_stats(const AdamArgs& a) {
     if (a.host_stats == nullptr) return;
     for (int i = 0; i < 2 * (a.K + 2); ++i) a.host_stats[i] = a.stats[i];
+    {   // (the publishing launch does not update theta: what is read here is what the next inner step will see)
+        float lo = a.theta[a.NP - a.A];
+        for (int i = 1; i < a.A; ++i) lo = fminf(lo, a.theta[a.NP - a.A + i]);
+        a.host_stats[2 * (a.K + 2)] = lo;
+    }
     release_store_system(a.host_seq, a.seq);
 }
 

@@ -431,6 +431,57 @@ def check_schedule_invariance(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, ep
                 np.testing.assert_array_equal(a[key], b[key])
 
 
+def check_adapt_reuse(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, epochs=2):
+    """promp_set_reuse_adapt: the first epoch of an optimisation takes the inner pass promp_inner_adapt just ran (theta', inner
+    scalars, primal cache) instead of repeating it.  Must not change a single bit, must actually skip (one pass per optimisation
+    from the second iteration on AND in the first, where the smallest log_std entry is known from promp_set_theta), and must NOT
+    skip when something the pass reads changed in between or a log_std entry sits below log(min_std)."""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=True)
+    spec = op.PolicySpec(O, A, hidden)
+    eta = np.full(K, 5e-4, np.float32)
+    kwargs = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True, positive_adv=False)
+
+    def run(reuse, cache, disturb=None, min_std=None):
+        ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+        ctx.set_reuse_adapt(reuse)
+        ctx.set_primal_cache(cache)
+        if min_std is not None:
+            ctx.set_min_std(min_std)
+        helpers.upload_slabs(ctx, all_paths, all_slabs)
+        ctx.set_theta(theta)
+        ctx.set_step_sizes(np.full(spec.n_params, 0.1, np.float32))
+        for it in range(iters):
+            ctx.switch_to_pre_update()
+            ctx.process_samples(0, baseline_kind=KIND['linear_feature'], **kwargs)
+            for k in range(K):
+                ctx.inner_adapt(k)
+                ctx.process_samples(k + 1, baseline_kind=KIND['linear_feature'], **kwargs)
+            if disturb == 'advantages' and it == iters - 1:
+                ctx.set_advantages(0, ctx.download_processed(0)['advantages'] * np.float32(1.5))
+            if disturb == 'step_sizes' and it == iters - 1:
+                ctx.set_step_sizes(np.full(spec.n_params, 0.05, np.float32))
+            res = ctx.optimize(epochs, 1e-3, 0.3, eta)
+        g, st = ctx.meta_grad(0.3, eta)
+        out = (ctx.get_theta(), g, res, st, ctx.adapt_passes_skipped())
+        ctx.close()
+        return out
+
+    for cache in (False, True):
+        off, on = run(False, cache), run(True, cache)
+        np.testing.assert_array_equal(off[0], on[0])
+        np.testing.assert_array_equal(off[1], on[1])
+        assert off[2] == pytest_approx_dict(on[2]) and off[3] == pytest_approx_dict(on[3])
+        assert off[4] == 0 and on[4] == iters, (off[4], on[4])          # one pass per optimisation (the trailing meta_grad follows an Adam step)
+        for what in ('advantages', 'step_sizes'):                         # something the pass read has changed: the last optimisation repeats it
+            a, b = run(False, cache, what), run(True, cache, what)
+            np.testing.assert_array_equal(a[0], b[0])
+            assert b[4] == iters - 1, (what, b[4])
+    # a log_std entry below log(min_std): the inner step uses the raw value, the meta-objective's first step the clipped one -- never skipped
+    a, b = run(False, True, min_std=2.0), run(True, True, min_std=2.0)
+    np.testing.assert_array_equal(a[0], b[0])
+    assert b[4] == 0
+
+
 def check_staged_upload(lib, seed, M, P, T, O, A, hidden, iters=4, epochs=2):
     """promp_stage_step / promp_commit_step: two different batches alternate, the next one staged from pinned host arrays
     while the current one is optimised, nothing synchronising the host in between; every iteration's outcome must equal,

@@ -89,6 +89,10 @@ def test_fused_and_separate_task_reduction_agree(lib, two_cus):
     pc.check_schedule_invariance(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), K=1, iters=1, epochs=1)
 
 
+def test_first_epoch_reuses_the_inner_adapt_pass(lib, two_cus):
+    pc.check_adapt_reuse(lib, 63, M=2, P=1, T=20, O=5, A=3, hidden=(32, 32), iters=2, epochs=1)
+
+
 def test_primal_cache_matches_recomputation(lib, two_cus):
     # ragged tasks (partial last tiles, cache blocks of consecutive tasks 16 spare rows apart), unequal widths, K = 2
     # (more shapes, incl. 64/64 and 32/32, in the GPU test of the same name)

@@ -284,6 +284,11 @@ def test_launch_scheduling_does_not_change_results(lib):
     pc.check_schedule_invariance(lib, 82, M=3, P=3, T=60, O=12, A=4, hidden=(64, 32), K=2, iters=2)
 
 
+def test_first_epoch_reuses_the_inner_adapt_pass(lib):
+    pc.check_adapt_reuse(lib, 61, M=5, P=3, T=70, O=20, A=6, hidden=(64, 64))
+    pc.check_adapt_reuse(lib, 62, M=3, P=2, T=40, O=7, A=3, hidden=(32, 64), K=2)
+
+
 def test_primal_cache_matches_recomputation(lib):
     """the second-order pass fed from the gradient pass's cached activations / means vs the recomputing path vs the oracle"""
     pc.check_primal_cache(lib, 83, M=7, P=4, T=110, O=20, A=6, hidden=(64, 64), K=1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# developer tool: cycle stamps of k_fwd_bwd / k_chain_hvp with the -DPROMP_DEV_STAMPS library variant
+# developer tool: cycle stamps of k_pass / k_chain_hvp with the -DPROMP_DEV_STAMPS library variant
 mkdir -p gpurun_out
 cp promp_amd/libpromp_hip.so /tmp/lib_keep.so
 cp tools/ablate/lib_stamps.so promp_amd/libpromp_hip.so

@@ -1,5 +1,5 @@
 """Developer tool: instruction mix of the hottest loop of a kernel in a hipcc -S listing.
-usage: python tools/isa_mix.py /tmp/promp.s _Z9k_fwd_bwdILi2ELi2ELi8ELb1EEv8PassArgs [--all]
+usage: python tools/isa_mix.py /tmp/promp.s _Z6k_passILi4ELi4ELi4ELb1ELb0EEv8PassArgs [--all]
 Finds the loop (label .. backward branch) with the most MFMAs and prints counts per mnemonic class."""
 import collections
 import re

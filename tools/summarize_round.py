@@ -21,14 +21,14 @@ for name, out in [('bench.json', '%s_bench.json'), ('pytest_gpu.log', '%s_pytest
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out % tag))
 def short_name(k):
-    """k_fwd_bwd: every gradient-pass launch of a step under one name (the mean over dispatches then weighs the launches that
+    """k_pass: every gradient-pass launch of a step under one name (the mean over dispatches then weighs the launches that
     also fill the primal cache by their share, which is what bench.py's per-launch average does), the forward-only instance
     apart; the cache-filling launches additionally on their own"""
     base = k.split('(')[0].replace('void ', '')
     name, _, targs = base.partition('<')
     targs = [t.strip() for t in targs.rstrip('>').split(',')] if targs else []
-    if name == 'k_fwd_bwd' and len(targs) >= 4 and targs[3] == 'false':
-        return 'k_fwd_bwd<fwd-only>'
+    if name == 'k_pass' and len(targs) >= 4 and targs[3] == 'false':
+        return 'k_pass<fwd-only>'
     return name
 
 
@@ -52,6 +52,9 @@ for k, r in pmc.iterrows():
         traffic[short] = dict(fetch_size_kib=r['FETCH_SIZE'], write_size_kib=r['WRITE_SIZE'],
                               hbm_bytes_per_launch=(2.0 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024.0,
                               note='(2 x FETCH_SIZE + WRITE_SIZE) KiB; separate --pmc passes of bench.py --steps 3; gfx950 FETCH_SIZE x2 correction')
+sys.path.insert(0, ROOT)
+import bench
+traffic['_kernel_sources_sha256'] = bench.kernel_sources_sha256()    # bench.py reports these counters only for the same sources
 json.dump(traffic, open(os.path.join(dst, '%s_hbm_traffic.json' % tag), 'w'), indent=1)
 print(pmc.loc[[k for k in pmc.index if 'k_' in k]].T.to_string())
-print(json.dumps({k: round(v['hbm_bytes_per_launch'] / 1e6, 2) for k, v in traffic.items()}, indent=1))
+print(json.dumps({k: round(v['hbm_bytes_per_launch'] / 1e6, 2) for k, v in traffic.items() if not k.startswith('_')}, indent=1))
