@@ -31,9 +31,11 @@ from . import sample_processing as sp
 # ---- sample processing --------------------------------------------------------------------------------------------------
 
 def process_samples_dice(paths, max_path_length, baseline_kind=sp.BASELINE_LINEAR_TIME, discount=0.99, normalize_adv=True,
-                         positive_adv=False, reg_coeff=1e-5):
+                         positive_adv=False, reg_coeff=1e-5, return_baseline_kind=None, gae_lambda=1.0):
     """DiceSampleProcessor._compute_samples_data for ONE task (dice_sample_processor.py:96-131).
-    -> dict(mask, observations, actions, rewards, adjusted_rewards, agent_infos) padded to [P, max_path_length, ...]"""
+    -> dict(mask, observations, actions, rewards, adjusted_rewards, agent_infos) padded to [P, max_path_length, ...];
+    with return_baseline_kind also 'advantages': GAE advantages from a second baseline fitted on the returns, padded and
+    normalised / shifted over the padded array (:125-127, 196-238)"""
     T = int(max_path_length)
     disc = np.cumprod(np.concatenate([np.ones(1), np.ones(T - 1) * discount]))                 # :150
     targets = []
@@ -66,6 +68,21 @@ def process_samples_dice(paths, max_path_length, baseline_kind=sp.BASELINE_LINEA
     if positive_adv:
         a = (a - a.min()) + 1e-8
     out['adjusted_rewards'] = a
+    if return_baseline_kind is not None:
+        rews = [np.asarray(p['rewards'], dtype=np.float64) for p in paths]
+        rets = [sp.discount_cumsum(r, discount) for r in rews]                                   # :206
+        if return_baseline_kind == sp.BASELINE_ZERO:
+            base = [np.zeros(len(r)) for r in rews]
+        else:
+            obs = [np.asarray(p['observations']) for p in paths]
+            w, _, _ = sp.fit_linear_baseline(obs, rets, return_baseline_kind, reg_coeff)          # :209-210
+            base = [sp.predict_linear_baseline(o, w, return_baseline_kind) for o in obs]
+        adv = np.stack([pad(sp.compute_advantages(r, b, discount, gae_lambda)) for r, b in zip(rews, base)])   # :213-227
+        if normalize_adv:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        if positive_adv:
+            adv = (adv - adv.min()) + 1e-8
+        out['advantages'] = adv
     return out
 
 
@@ -82,9 +99,12 @@ def to_slab(sd):
     rw = sel(sd['adjusted_rewards']).astype(np.float64) * scale
     off = np.concatenate([[0], np.cumsum(lens)]).astype(int)
     w = np.concatenate([np.cumsum(rw[off[p]:off[p + 1]][::-1])[::-1] for p in range(P)])
-    return dict(observations=sel(sd['observations']), actions=sel(sd['actions']), advantages=w, dice_rw=rw,
-                path_row_offsets=off,
-                agent_infos=dict(mean=sel(sd['agent_infos']['mean']), log_std=sel(sd['agent_infos']['log_std'])))
+    out = dict(observations=sel(sd['observations']), actions=sel(sd['actions']), advantages=w, dice_rw=rw,
+               path_row_offsets=off,
+               agent_infos=dict(mean=sel(sd['agent_infos']['mean']), log_std=sel(sd['agent_infos']['log_std'])))
+    if 'advantages' in sd:      # VPG-DiCE: the outer objective's weights; the mean over the padded array becomes the slab mean
+        out['vpg_advantages'] = sel(sd['advantages']).astype(np.float64) * scale
+    return out
 
 
 # ---- objective ------------------------------------------------------------------------------------------------------------
@@ -142,9 +162,11 @@ def adapt(spec, thetas_tasks, slabs, step_sizes):
             for th, sl in zip(thetas_tasks, slabs)]
 
 
-def meta_objective_and_grad(spec, theta, all_slabs, step_sizes, want_grad=True):
+def meta_objective_and_grad(spec, theta, all_slabs, step_sizes, want_grad=True, outer='dice'):
     """DICEMAML.build_graph (dice_maml.py:84-152) at theta: mean over tasks of the DiCE objective of the last step's samples
-    at the adapted parameters, with its exact gradient through the K adaptation steps."""
+    at the adapted parameters, with its exact gradient through the K adaptation steps.
+    outer='vpg': VPG_DICEMAML.build_graph (vpg_dice_maml.py:35-113) -- the same DiCE inner steps under the outer objective
+    -mean(log pi * advantage * mask) of the last step's samples."""
     K, M = len(all_slabs) - 1, len(all_slabs[0])
     theta = np.asarray(theta, dtype=np.float64)
     loss, grad, adapted = 0.0, np.zeros_like(theta), []
@@ -152,7 +174,11 @@ def meta_objective_and_grad(spec, theta, all_slabs, step_sizes, want_grad=True):
         thetas = [theta]
         for k in range(K):
             thetas.append(thetas[k] - step_sizes * loss_and_grad(spec, thetas[k], all_slabs[k][i], k == 0)['grad'])
-        r = loss_and_grad(spec, thetas[K], all_slabs[K][i], False)
+        if outer == 'vpg':
+            last = all_slabs[K][i]
+            r = pm.loss_and_grad(spec, thetas[K], dict(last, advantages=last['vpg_advantages']), 'loglik', False)
+        else:
+            r = loss_and_grad(spec, thetas[K], all_slabs[K][i], False)
         loss += r['loss']
         adapted.append(thetas[K])
         if want_grad:

@@ -256,15 +256,21 @@ DICE_PROC_CASES = {
     'ragged':   (32, dict(M=3, P=5, T=40, O=4, A=3), 40, dict(discount=0.95, normalize_adv=True), 'linear_feature', True),
     'raw':      (33, dict(M=2, P=4, T=25, O=3, A=2), 32, dict(discount=1.0, normalize_adv=False), 'zero', True),
     'positive': (34, dict(M=2, P=3, T=20, O=3, A=2), 20, dict(discount=0.99, normalize_adv=True, positive_adv=True), 'linear_time', False),
+    # return_baseline given: GAE advantages beside the DiCE rewards (dice_sample_processor.py:113-124, 196-238; VPG-DiCE-MAML reads them)
+    'retbase':  (35, dict(M=3, P=4, T=30, O=5, A=2), 34, dict(discount=0.97, gae_lambda=0.9, normalize_adv=True), 'linear_time', True, 'linear_feature'),
+    'retbase_raw': (36, dict(M=2, P=3, T=22, O=4, A=3), 22, dict(discount=0.99, gae_lambda=1.0, normalize_adv=False), 'linear_feature', False, 'linear_time'),
 }
 
 
-def gen_dice_proc():
+def gen_dice_proc(only=None):
     """inputs + outputs of the reference's own DiceMetaSampleProcessor (samplers/dice_sample_processor.py,
     samplers/meta_sample_processor.py:50-51)"""
     _, baselines, _ = _import_reference()
     from meta_policy_search.samplers.meta_sample_processor import DiceMetaSampleProcessor
-    for name, (seed, dims, tmax, kw, bname, ragged) in DICE_PROC_CASES.items():
+    for name, case in DICE_PROC_CASES.items():
+        if only is not None and name not in only:
+            continue
+        (seed, dims, tmax, kw, bname, ragged), rbname = case[:6], (case[6] if len(case) > 6 else None)
         paths = make_sample_proc_inputs(seed, dims, dict(ragged=ragged))
         lens = np.array([[len(p['rewards']) for p in plist] for plist in paths.values()], dtype=np.int32)
         obs = np.concatenate([p['observations'] for plist in paths.values() for p in plist])
@@ -272,13 +278,15 @@ def gen_dice_proc():
         rew = np.concatenate([p['rewards'] for plist in paths.values() for p in plist])
         mean = np.concatenate([p['agent_infos']['mean'] for plist in paths.values() for p in plist])
         lstd = np.concatenate([p['agent_infos']['log_std'] for plist in paths.values() for p in plist])
-        proc = DiceMetaSampleProcessor(baselines[bname](), max_path_length=tmax, **kw)
+        extra = dict(return_baseline=baselines[rbname]()) if rbname else {}
+        proc = DiceMetaSampleProcessor(baselines[bname](), max_path_length=tmax, **extra, **kw)
         out = proc.process_samples(paths, log=False)
+        more = dict(advantages=np.stack([sd['advantages'] for sd in out])) if rbname else {}
         np.savez_compressed(
             os.path.join(GOLDEN, 'dice_proc_%s.npz' % name),
             meta=json.dumps(dict(seed=seed, dims=dims, max_path_length=tmax, kwargs=kw, baseline=bname, ragged=ragged,
-                                 keys=sorted(out[0].keys()))),
-            path_lengths=lens, observations=obs, actions=act, rewards=rew, agent_mean=mean, agent_log_std=lstd,
+                                 return_baseline=rbname, keys=sorted(out[0].keys()))),
+            path_lengths=lens, observations=obs, actions=act, rewards=rew, agent_mean=mean, agent_log_std=lstd, **more,
             mask=np.stack([sd['mask'] for sd in out]),
             adjusted_rewards=np.stack([sd['adjusted_rewards'] for sd in out]),
             padded_rewards=np.stack([sd['rewards'] for sd in out]),
@@ -320,7 +328,7 @@ def make_dice_inputs(c):
     return theta, all_samples
 
 
-def torch_dice_meta_objective(theta, all_samples, c, min_log_std=float(np.log(1e-6))):
+def torch_dice_meta_objective(theta, all_samples, c, min_log_std=float(np.log(1e-6)), outer='dice'):
     """Direct transcription of DICEMAML.build_graph's forward arithmetic (meta_algos/dice_maml.py:39-45, 84-152, 245-258) on
     the PADDED [P, Tmax] arrays in torch float64: cumulative log-likelihoods, magic box, mask; gradients by torch.autograd."""
     import torch
@@ -337,7 +345,7 @@ def torch_dice_meta_objective(theta, all_samples, c, min_log_std=float(np.log(1e
         parts.append(t[off:off + A])
         return parts
 
-    def dice_obj(t, sd, clip):
+    def dice_obj(t, sd, clip, vpg=False):
         T = lambda x: torch.tensor(np.asarray(x, dtype=np.float64))
         p = split(t)
         P_, Tm = sd['mask'].shape
@@ -352,6 +360,8 @@ def torch_dice_meta_objective(theta, all_samples, c, min_log_std=float(np.log(1e
         a = T(sd['actions']).reshape(P_ * Tm, A)
         z = (a - x) / torch.exp(s)
         ll = (-(s * torch.ones_like(x)).sum(-1) - 0.5 * (z ** 2).sum(-1) - 0.5 * A * np.log(2 * np.pi)).reshape(P_, Tm)
+        if vpg:         # VPG_DICEMAML's outer objective (vpg_dice_maml.py:98-104): log-likelihood times advantage, masked mean
+            return -(ll * T(sd['advantages']) * T(sd['mask'])).mean()
         tau = torch.cumsum(ll, dim=1)
         box = torch.exp(tau - tau.detach())
         return -(box * T(sd['adjusted_rewards']) * T(sd['mask'])).mean()
@@ -364,7 +374,7 @@ def torch_dice_meta_objective(theta, all_samples, c, min_log_std=float(np.log(1e
             inner = dice_obj(cur, all_samples[k][i], clip)
             g, = torch.autograd.grad(inner, cur, create_graph=True)
             cur, clip = cur - c['alpha'] * g, False
-        objs.append(dice_obj(cur, all_samples[K][i], False))
+        objs.append(dice_obj(cur, all_samples[K][i], False, vpg=(outer == 'vpg')))
     loss = torch.stack(objs).mean()
     grad, = torch.autograd.grad(loss, th)
     return float(loss.detach()), grad.numpy()
@@ -383,6 +393,32 @@ def gen_dice():
         np.savez_compressed(os.path.join(GOLDEN, 'dice_autograd_%s.npz' % name), meta=json.dumps(c), theta=theta, loss=loss,
                             grad=grad, **flat)
         print('wrote dice_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
+
+
+VPG_DICE_CASES = {
+    'k1_ragged': dict(seed=211, M=2, P=3, T=12, Tmax=14, O=4, A=2, hidden=(32, 32), K=1, alpha=0.1, ragged=True),
+    'k2_small': dict(seed=212, M=2, P=2, T=8, Tmax=8, O=5, A=3, hidden=(32, 64), K=2, alpha=0.05, ragged=False),
+}
+
+
+def gen_vpg_dice():
+    """VPG_DICEMAML.build_graph (meta_algos/vpg_dice_maml.py:35-113): DiCE inner steps, log-likelihood x advantage outer objective"""
+    for name, c in VPG_DICE_CASES.items():
+        theta, all_samples = make_dice_inputs(c)
+        rng = np.random.RandomState(c['seed'] + 1000)
+        for sd in all_samples[c['K']]:
+            sd['advantages'] = rng.randn(*sd['mask'].shape)
+        loss, grad = torch_dice_meta_objective(theta, all_samples, c, outer='vpg')
+        flat = {}
+        for k, step in enumerate(all_samples):
+            for key in ('mask', 'observations', 'actions', 'adjusted_rewards'):
+                flat['step%d_%s' % (k, key)] = np.stack([sd[key] for sd in step])
+            flat['step%d_mean' % k] = np.stack([sd['agent_infos']['mean'] for sd in step])
+            flat['step%d_log_std' % k] = np.stack([sd['agent_infos']['log_std'] for sd in step])
+        flat['step%d_advantages' % c['K']] = np.stack([sd['advantages'] for sd in all_samples[c['K']]])
+        np.savez_compressed(os.path.join(GOLDEN, 'vpgdice_autograd_%s.npz' % name), meta=json.dumps(c), theta=theta, loss=loss,
+                            grad=grad, **flat)
+        print('wrote vpgdice_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
 
 
 def gen_point_env():
@@ -479,6 +515,11 @@ if __name__ == '__main__':
     if '--dice-only' in sys.argv:
         gen_dice_proc()
         gen_dice()
+        gen_vpg_dice()
+        sys.exit(0)
+    if '--vpg-dice-only' in sys.argv:       # (round 3 additions only: the other fixtures stay byte-identical)
+        gen_dice_proc(only=('retbase', 'retbase_raw'))
+        gen_vpg_dice()
         sys.exit(0)
     if '--dist-only' not in sys.argv:
         gen_sample_proc()
@@ -487,3 +528,4 @@ if __name__ == '__main__':
     gen_point_env()
     gen_dice_proc()
     gen_dice()
+    gen_vpg_dice()

@@ -391,6 +391,12 @@ class Context:
         return out
 
     def set_rewards(self, step, rewards):
+        """float64 rewards stay float64 on the device (the returns / GAE scans read them), anything else goes as float32"""
+        if np.asarray(rewards).dtype == np.float64:
+            r = np.ascontiguousarray(rewards, dtype=np.float64).reshape(-1)
+            assert r.size == self.step_rows[step]
+            self._call('promp_set_rewards_f64', int(step), _ptr(r, C.c_double))
+            return
         r = _f32(rewards).reshape(-1)
         assert r.size == self.step_rows[step]
         self._call('promp_set_rewards', int(step), _ptr(r, C.c_float))

@@ -65,10 +65,8 @@ class DICEMAML(MAMLAlgo):
             self._upload_dice(slot, samples)
         return slot
 
-    def optimize_policy(self, all_samples_data, log=True):
-        """MAML outer step (dice_maml.py:154-178)"""
-        K = self.num_inner_grad_steps
-        assert len(all_samples_data) == K + 1
+    def _place_dice_steps(self, all_samples_data):
+        """sampling step k into slot k with its DiCE rewards, for every k"""
         # steps that are not resident in their own slot are flattened first, so that the context is sized for the largest of
         # them before anything is uploaded (a context that grows in between would drop the slabs uploaded so far)
         todo = {k: self._flatten_dice(sd) for k, sd in enumerate(all_samples_data) if self.session.resident_slot(sd) != k}
@@ -79,6 +77,12 @@ class DICEMAML(MAMLAlgo):
                 todo = {k: self._flatten_dice(sd) for k, sd in enumerate(all_samples_data)}     # the context was re-created
             for k, flat in todo.items():
                 self._upload_dice(k, all_samples_data[k], flat)
+
+    def optimize_policy(self, all_samples_data, log=True):
+        """MAML outer step (dice_maml.py:154-178)"""
+        K = self.num_inner_grad_steps
+        assert len(all_samples_data) == K + 1
+        self._place_dice_steps(all_samples_data)
         ctx = self.session.ctx
         if log: logger.log('Optimizing')
         ctx.optimize(1, self.learning_rate, 0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)

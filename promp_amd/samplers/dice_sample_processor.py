@@ -27,9 +27,9 @@ class DiceSampleProcessor(SampleProcessor):
     """Args (dice_sample_processor.py:25-47): baseline, max_path_length, discount=0.99, gae_lambda=1, normalize_adv=True,
     positive_adv=False, return_baseline=None
 
-    Gap: return_baseline (the reference's optional second baseline, fitted on returns to add GAE advantages beside the DiCE
-    rewards, dice_sample_processor.py:113-124) is not built -- DICE-MAML does not read advantages; process_samples raises
-    NotImplementedError when it is given."""
+    return_baseline (dice_sample_processor.py:113-124, 196-238): a second baseline, fitted on the returns, adds GAE
+    'advantages' (padded, normalised / shifted over the padded array) beside the DiCE rewards -- what VPG_DICEMAML's outer
+    objective reads.  Its regression and the GAE scan are a second run of the device pipeline on the same resident slab."""
 
     def __init__(self, baseline, max_path_length, discount=0.99, gae_lambda=1, normalize_adv=True, positive_adv=False,
                  return_baseline=None):
@@ -39,6 +39,8 @@ class DiceSampleProcessor(SampleProcessor):
         super(DiceSampleProcessor, self).__init__(baseline, discount=discount, gae_lambda=gae_lambda, normalize_adv=normalize_adv,
                                                   positive_adv=positive_adv)
         self.max_path_length = max_path_length
+        if return_baseline is not None:
+            assert hasattr(return_baseline, 'fit') and hasattr(return_baseline, 'predict')
         self.return_baseline = return_baseline
 
     def _baseline_kind(self):
@@ -93,6 +95,24 @@ class DiceSampleProcessor(SampleProcessor):
             self.baseline._coeffs = ctx.download_processed(slot, kind)['coeffs'][-1].copy()
         base = ctx.predict_baseline(slot, kind)                    # Phi . w per valid row, float64
         pro, tpo = fl['path_row_offsets'], fl['task_path_offsets']
+        gae = None
+        if self.return_baseline is not None:
+            # GAE advantages from a baseline fitted on the returns: the ordinary pipeline (returns, fit, predict, GAE) on the true
+            # rewards of the same slab; normalisation happens below, over the padded array
+            rkind = getattr(self.return_baseline, 'kind', None)
+            if rkind is None:
+                raise TypeError('%s has no device-side `kind`' % type(self.return_baseline).__name__)
+            true_rewards = np.concatenate([np.asarray(p['rewards'], dtype=np.float64) for plist in paths_meta_batch.values() for p in plist])
+            ctx.set_rewards(slot, true_rewards)
+            ctx.process_samples(slot, discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=False, positive_adv=False,
+                                baseline_kind=rkind, reg_coeff=getattr(self.return_baseline, '_reg_coeff', 1e-5))
+            if rkind != _lib.BASELINE_ZERO:
+                self.return_baseline._coeffs = ctx.download_processed(slot, rkind)['coeffs'][-1].copy()
+            ret64, gae = ctx.download_raw(slot)
+            for i, (_, plist) in enumerate(paths_meta_batch.items()):
+                for j, p in enumerate(plist):
+                    a, b = pro[tpo[i] + j], pro[tpo[i] + j + 1]
+                    p['returns'], p['advantages'] = ret64[a:b], gae[a:b]
         result, rw_rows = [], []
         for i, (_, plist) in enumerate(paths_meta_batch.items()):
             for j, p in enumerate(plist):
@@ -111,6 +131,13 @@ class DiceSampleProcessor(SampleProcessor):
                 env_infos={k: self._stack_padded(plist, 'env_infos', k) for k in plist[0].get('env_infos', {})},
                 agent_infos={k: self._stack_padded(plist, 'agent_infos', k) for k in plist[0].get('agent_infos', {})},
                 adjusted_rewards=adj)
+            if gae is not None:
+                adv = self._stack_padded(plist, 'advantages')
+                if self.normalize_adv:
+                    adv = (adv - np.mean(adv)) / (np.std(adv) + 1e-8)
+                if self.positive_adv:
+                    adv = (adv - np.min(adv)) + 1e-8
+                sd['advantages'] = adv
             sd.device_ref = (sess.serial, upload, slot, i)
             result.append(sd)
             rows = sum(len(p['rewards']) for p in plist)
@@ -125,8 +152,6 @@ class DiceSampleProcessor(SampleProcessor):
         assert type(paths) == list, 'paths must be a list'
         assert paths[0].keys() >= {'observations', 'actions', 'rewards'}
         assert self.baseline, 'baseline must be specified - use self.build_sample_processor(baseline_obj)'
-        if self.return_baseline is not None:
-            raise NotImplementedError('return_baseline (GAE advantages beside the DiCE rewards) is not part of the DICE-MAML path')
         result, all_paths = self._process_meta_batch(OrderedDict([(0, paths)]))
         self._log_dice_stats(all_paths, log=log, log_prefix='')   # the reference drops log_prefix here (:87)
         sd = dict(result[0])
@@ -145,8 +170,6 @@ class DiceMetaSampleProcessor(DiceSampleProcessor):
     def process_samples(self, paths_meta_batch, log=False, log_prefix=''):
         assert isinstance(paths_meta_batch, dict), 'paths must be a dict'
         assert self.baseline, 'baseline must be specified'
-        if self.return_baseline is not None:
-            raise NotImplementedError('return_baseline (GAE advantages beside the DiCE rewards) is not part of the DICE-MAML path')
         samples_data_meta_batch, all_paths = self._process_meta_batch(paths_meta_batch)
         # rewards z-scored over the whole meta-batch (meta_sample_processor.py:40-44), here on the padded reward arrays
         overall = np.concatenate([sd['rewards'].reshape(-1) for sd in samples_data_meta_batch])

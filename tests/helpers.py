@@ -125,6 +125,8 @@ def dice_case_from_golden(g):
             sd = dict(mask=g['step%d_mask' % k][i], observations=g['step%d_observations' % k][i], actions=g['step%d_actions' % k][i],
                       adjusted_rewards=g['step%d_adjusted_rewards' % k][i],
                       agent_infos=dict(mean=g['step%d_mean' % k][i], log_std=g['step%d_log_std' % k][i]))
+            if 'step%d_advantages' % k in g:       # VPG-DiCE fixtures: the last step's advantages
+                sd['advantages'] = g['step%d_advantages' % k][i]
             slab = dice.to_slab(sd)
             slab['padded'] = sd
             step.append(slab)

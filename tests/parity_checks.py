@@ -708,3 +708,33 @@ def check_dice(lib, name, tol=1e-4):
     grad_ll, _ = ctx.meta_grad(0.0, np.zeros(K, np.float32), _lib.INNER_LOGLIK, _lib.OUTER_LOGLIK)
     assert rel_max(grad_ll, r['grad']) > 10 * tol
     ctx.close()
+
+
+def check_vpg_dice(lib, name, tol=1e-4):
+    """VPG-DiCE-MAML on the device: DiCE inner steps (PROMP_INNER_DICE), log-likelihood x advantage outer objective
+    (PROMP_OUTER_LOGLIK with the last step's weights set to the advantages) against the oracle and, through the committed
+    fixture, against torch.autograd on a transcription of VPG_DICEMAML's graph (vpg_dice_maml.py:35-113)."""
+    from oracle import dice
+    g = np.load(os.path.join(helpers.GOLDEN, 'vpgdice_autograd_%s.npz' % name))
+    c, t64, all_slabs = helpers.dice_case_from_golden(g)
+    spec = op.PolicySpec(c['O'], c['A'], c['hidden'])
+    M, K = c['M'], c['K']
+    R = max(sum(len(sl['dice_rw']) for sl in step) for step in all_slabs)
+    NPaths = max(sum(len(sl['path_row_offsets']) - 1 for sl in step) for step in all_slabs)
+    ctx = _lib.Context(M, c['O'], c['A'], c['hidden'], K, max_rows=R, max_paths=NPaths, lib=lib)
+    upload_dice_slabs(ctx, all_slabs)
+    ctx.set_advantages(K, np.concatenate([sl['vpg_advantages'] for sl in all_slabs[K]]).astype(np.float32))
+    alpha = np.full(spec.n_params, c['alpha'], np.float32)
+    ctx.set_theta(t64.astype(np.float32))
+    ctx.set_step_sizes(alpha)
+    grad, st = ctx.meta_grad(0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
+    r = dice.meta_objective_and_grad(spec, t64, all_slabs, alpha.astype(np.float64), outer='vpg')
+    np.testing.assert_allclose(st['loss'], r['loss'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st['loss'], float(g['loss']), rtol=1e-4, atol=1e-6)
+    assert rel_max(grad, r['grad']) < tol
+    assert rel_max(grad, g['grad']) < tol                      # torch.autograd on the padded graph
+    # the DiCE outer objective on the same samples gives a measurably different gradient (the check above is not vacuous)
+    ctx.set_dice_rewards(K, np.concatenate([sl['dice_rw'] for sl in all_slabs[K]]).astype(np.float32))
+    grad_dice, _ = ctx.meta_grad(0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
+    assert rel_max(grad_dice, r['grad']) > 10 * tol
+    ctx.close()

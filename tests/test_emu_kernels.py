@@ -136,6 +136,10 @@ def test_dice_maml_gradient(lib, two_cus, name):
     pc.check_dice(lib, name)
 
 
+def test_vpg_dice_maml_gradient(lib, two_cus):
+    pc.check_vpg_dice(lib, 'k1_ragged')
+
+
 def test_loss_grad_h32_wide_obs(lib):
     # O=31, A=8, H=32: the compact (non hidden_1) part of the gradient is larger than the hidden_1 kernel
     pc.check_loss_grad(lib, 14, M=1, P=1, T=40, O=31, A=8, hidden=(32, 32))

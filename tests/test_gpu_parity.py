@@ -338,3 +338,9 @@ def test_dice_maml_gradient_vs_oracle_and_autograd(lib, name):
     """PROMP_INNER_DICE: exact meta-gradient of the DiCE objective (path-coupled second-order term) against the float64 oracle
     and torch.autograd on the reference's padded magic-box graph (tests/golden/dice_autograd_*.npz)"""
     pc.check_dice(lib, name)
+
+
+@pytest.mark.parametrize('name', ['k1_ragged', 'k2_small'])
+def test_vpg_dice_maml_gradient_vs_oracle_and_autograd(lib, name):
+    """VPG_DICEMAML (vpg_dice_maml.py:35-113): DiCE inner steps, log-likelihood x advantage outer objective"""
+    pc.check_vpg_dice(lib, name)

@@ -94,7 +94,7 @@ def test_baseline_fit_predict_on_device():
     scen.run_baseline_fit_predict_scenario()
 
 
-@pytest.mark.parametrize('name', ['default', 'ragged', 'raw', 'positive'])
+@pytest.mark.parametrize('name', ['default', 'ragged', 'raw', 'positive', 'retbase', 'retbase_raw'])
 def test_dice_sample_processor_vs_reference_outputs(name):
     scen.run_dice_processor_scenario(name)
 
@@ -102,3 +102,8 @@ def test_dice_sample_processor_vs_reference_outputs(name):
 @pytest.mark.parametrize('name', ['k1_small', 'k1_ragged', 'k2_small', 'k1_hc', 'k1_long'])
 def test_dice_maml_plugin(name):
     scen.run_dice_maml_scenario(name)
+
+
+@pytest.mark.parametrize('name', ['k1_ragged', 'k2_small'])
+def test_vpg_dice_maml_plugin(name):
+    scen.run_vpg_dice_maml_scenario(name)

@@ -28,6 +28,30 @@ def test_dice_sample_processor_matches_reference_outputs(name):
         np.testing.assert_array_equal(out['observations'], g['padded_observations'][i])
 
 
+@pytest.mark.parametrize('name', ['retbase', 'retbase_raw'])
+def test_dice_sample_processor_with_return_baseline_matches_reference_outputs(name):
+    """return_baseline given (dice_sample_processor.py:113-124, 196-238): GAE advantages beside the DiCE rewards"""
+    g = np.load(os.path.join(GOLDEN, 'dice_proc_%s.npz' % name))
+    meta = json.loads(str(g['meta']))
+    kw = meta['kwargs']
+    for i, plist in enumerate(helpers.dice_paths_from_golden(g).values()):
+        out = dice.process_samples_dice(plist, meta['max_path_length'], KIND[meta['baseline']], kw['discount'],
+                                        kw.get('normalize_adv', True), kw.get('positive_adv', False),
+                                        return_baseline_kind=KIND[meta['return_baseline']], gae_lambda=kw.get('gae_lambda', 1.0))
+        np.testing.assert_allclose(out['adjusted_rewards'], g['adjusted_rewards'][i], rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(out['advantages'], g['advantages'][i], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['k1_ragged', 'k2_small'])
+def test_vpg_dice_meta_gradient_matches_torch_autograd(name):
+    g = np.load(os.path.join(GOLDEN, 'vpgdice_autograd_%s.npz' % name))
+    c, theta, all_slabs = helpers.dice_case_from_golden(g)
+    spec = op.PolicySpec(c['O'], c['A'], c['hidden'])
+    r = dice.meta_objective_and_grad(spec, theta, all_slabs, np.full(spec.n_params, c['alpha']), outer='vpg')
+    assert abs(r['loss'] - float(g['loss'])) < 1e-10
+    np.testing.assert_allclose(r['grad'], g['grad'], rtol=1e-7, atol=1e-9 * np.abs(g['grad']).max())
+
+
 @pytest.mark.parametrize('name', ['k1_small', 'k1_ragged', 'k2_small', 'k1_hc', 'k1_long'])
 def test_dice_meta_gradient_matches_torch_autograd(name):
     g = np.load(os.path.join(GOLDEN, 'dice_autograd_%s.npz' % name))

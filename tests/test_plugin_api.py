@@ -319,8 +319,10 @@ def run_dice_processor_scenario(name='ragged'):
     g = np.load(os.path.join(helpers.GOLDEN, 'dice_proc_%s.npz' % name))
     meta = json.loads(str(g['meta']))
     paths = helpers.dice_paths_from_golden(g)
-    base = dict(zero=ZeroBaseline, linear_feature=LinearFeatureBaseline, linear_time=LinearTimeBaseline)[meta['baseline']]()
-    proc = DiceMetaSampleProcessor(base, max_path_length=meta['max_path_length'], **meta['kwargs'])
+    kinds = dict(zero=ZeroBaseline, linear_feature=LinearFeatureBaseline, linear_time=LinearTimeBaseline)
+    base = kinds[meta['baseline']]()
+    extra = dict(return_baseline=kinds[meta['return_baseline']]()) if meta.get('return_baseline') else {}
+    proc = DiceMetaSampleProcessor(base, max_path_length=meta['max_path_length'], **extra, **meta['kwargs'])
     with pytest.raises(AssertionError):
         proc.process_samples(list(paths.values()))
     out = proc.process_samples(paths, log=False)
@@ -331,7 +333,41 @@ def run_dice_processor_scenario(name='ragged'):
         np.testing.assert_array_equal(sd['rewards'], g['padded_rewards'][i])
         np.testing.assert_array_equal(sd['observations'], g['padded_observations'][i])
         np.testing.assert_allclose(sd['adjusted_rewards'], g['adjusted_rewards'][i], rtol=1e-5, atol=1e-6)
+        if extra:      # return_baseline: GAE advantages beside the DiCE rewards (dice_sample_processor.py:113-124, 196-238)
+            np.testing.assert_allclose(sd['advantages'], g['advantages'][i], rtol=1e-4, atol=1e-5)
     return proc, out
+
+
+def run_vpg_dice_maml_scenario(name='k1_ragged'):
+    """VPG_DICEMAML._adapt + optimize_policy (one Adam step on the exact meta-gradient) against the oracle / torch.autograd fixture"""
+    from oracle import dice, policy as op, promp as pm
+    from promp_amd.meta_algos.vpg_dice_maml import VPG_DICEMAML
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.utils import logger
+    logger.configure(quiet=True)
+    g = np.load(os.path.join(helpers.GOLDEN, 'vpgdice_autograd_%s.npz' % name))
+    c, t64, all_slabs = helpers.dice_case_from_golden(g)
+    spec = op.PolicySpec(c['O'], c['A'], c['hidden'])
+    theta = t64.astype(np.float32)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=c['O'], action_dim=c['A'], meta_batch_size=c['M'], hidden_sizes=c['hidden'])
+    policy.set_params(spec.to_ordered_dict(theta))
+    algo = VPG_DICEMAML(c['Tmax'], policy=policy, learning_rate=1e-3, inner_lr=c['alpha'], meta_batch_size=c['M'],
+                        num_inner_grad_steps=c['K'])
+    assert algo.name == 'vpg_dice_maml' and 'advantages' in algo._optimization_keys
+    samples = [[sl['padded'] for sl in step] for step in all_slabs]
+    alpha = np.full(spec.n_params, c['alpha'])
+    with pytest.raises(AssertionError):          # the last step's samples must carry the advantages
+        algo.optimize_policy([[{k: v for k, v in sd.items() if k != 'advantages'} for sd in step] for step in samples], log=False)
+    algo.optimize_policy(samples, log=False)
+    r = dice.meta_objective_and_grad(spec, t64, all_slabs, alpha, outer='vpg')
+    th_ref = pm.adam_step(t64, r['grad'], pm.AdamState(spec.n_params), 1e-3)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], r['loss'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(algo.last_stats['loss_before'], float(g['loss']), rtol=1e-4, atol=1e-6)
+    after = dice.meta_objective_and_grad(spec, th_ref, all_slabs, alpha, want_grad=False, outer='vpg')
+    np.testing.assert_allclose(algo.last_stats['loss_after'], after['loss'], rtol=5e-4, atol=1e-5)
+    got = spec.from_ordered_dict(policy.get_param_values())
+    d_dev, d_ref = got - theta, th_ref - t64
+    assert np.mean(np.sign(d_dev) == np.sign(d_ref)) > 0.98 and np.max(np.abs(d_dev)) < 1.01e-3
 
 
 def run_dice_maml_scenario(name='k1_ragged'):
@@ -375,6 +411,14 @@ def test_dice_sample_processor(emu):
 
 def test_dice_maml(emu):
     run_dice_maml_scenario('k1_ragged')
+
+
+def test_dice_sample_processor_with_return_baseline(emu):
+    run_dice_processor_scenario('retbase')
+
+
+def test_vpg_dice_maml(emu):
+    run_vpg_dice_maml_scenario('k1_ragged')
 
 
 def test_vpg_maml(emu):
