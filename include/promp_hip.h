@@ -221,6 +221,18 @@ int promp_policy_forward(promp_ctx* ctx, const float* obs, int batch, float* mea
  *     clip_infos != 0: the log_std recorded for agent_infos is max(log_std, log 1e-6) (pre-update policy,
  *     policies/gaussian_mlp_policy.py:71); the noise scale always uses the raw value (:74). */
 int promp_begin_rollout(promp_ctx* ctx, int step, int envs_per_task, int path_length);
+/* (a') the same for environments whose episodes end early (samplers/meta_sampler.py:100-125: an environment that reports
+ *     `done` is reset and keeps collecting; gym-style termination, e.g. envs/mujoco_envs/ant_rand_direc.py:32-46).  The slab
+ *     cannot be laid out before the episode lengths are known, so promp_policy_step files the rows of vectorised step
+ *     s = 0 .. max_steps-1 (its `t` argument) under (s, environment) in a staging area -- the Philox counter is that staging
+ *     row, s * n_tasks * envs_per_task + environment -- and promp_end_collection copies the FINISHED episodes into the slab in
+ *     path order once the host knows them: path p = steps [path_start[p], path_start[p] + path_len[p]) of environment
+ *     path_env[p] (= task * envs_per_task + b); task_path_offsets [n_tasks + 1] as in promp_upload_step; rewards [rows] in path
+ *     order.  Unfinished episodes are simply not listed (meta_sampler.py:114-125 drops them too).  2 * max_path_length - 1
+ *     vectorised steps always suffice to finish n_tasks * envs_per_task * max_path_length environment steps. */
+int promp_begin_collection(promp_ctx* ctx, int step, int envs_per_task, int max_steps);
+int promp_end_collection(promp_ctx* ctx, int step, int n_paths, const int32_t* task_path_offsets, const int32_t* path_env,
+                         const int32_t* path_start, const int32_t* path_len, const float* rewards);
 int promp_policy_step(promp_ctx* ctx, int step, int t, const float* obs, uint64_t seed, int clip_infos, float* actions_out);
 int promp_set_rewards(promp_ctx* ctx, int step, const float* rewards);
 /* The same in the environment's float64: the reference scans float64 rewards (utils/utils.py:74-81 on the arrays the env

@@ -91,6 +91,8 @@ SIGNATURES = {
     'promp_policy_forward': (C.c_int, [_P, _F, C.c_int, _F]),
     'promp_rollout_point_env': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D, _D, _F, C.POINTER(PointEnvOpts)]),
     'promp_begin_rollout': (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    'promp_begin_collection': (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    'promp_end_collection': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _F]),
     'promp_policy_step': (C.c_int, [_P, C.c_int, C.c_int, _F, C.c_uint64, C.c_int, _F]),
     'promp_set_rewards': (C.c_int, [_P, C.c_int, _F]),
     'promp_download_step': (C.c_int, [_P, C.c_int, _F, _F, _F, _F, _F]),
@@ -380,6 +382,23 @@ class Context:
         self.step_rows[step] = self.n_tasks * envs_per_task * path_length
         self.step_paths[step] = self.n_tasks * envs_per_task
         self.step_ls_rows[step] = self.n_tasks
+
+    def begin_collection(self, step, envs_per_task, max_steps):
+        """ragged collection: policy_step files vectorised step s under (s, environment) in a staging area until
+        end_collection copies the finished episodes into the slab"""
+        self._call('promp_begin_collection', int(step), int(envs_per_task), int(max_steps))
+        self._rollout_shape = (int(envs_per_task), int(max_steps))
+
+    def end_collection(self, step, task_path_offsets, path_env, path_start, path_len, rewards):
+        """the finished episodes, in path order: path p = steps [path_start[p], path_start[p] + path_len[p]) of environment
+        path_env[p]; rewards [rows] in path order"""
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        tpo, env, start, ln = i32(task_path_offsets), i32(path_env), i32(path_start), i32(path_len)
+        rew = _f32(rewards).reshape(-1)
+        assert tpo.shape == (self.n_tasks + 1,) and env.shape == start.shape == ln.shape and rew.size == int(ln.sum())
+        self._call('promp_end_collection', int(step), int(env.size), tpo.ctypes.data_as(C.c_void_p), env.ctypes.data_as(C.c_void_p),
+                   start.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), _ptr(rew, C.c_float))
+        self.step_rows[step], self.step_paths[step], self.step_ls_rows[step] = int(ln.sum()), int(env.size), self.n_tasks
 
     def policy_step(self, step, t, obs, seed=0, clip_infos=True):
         """obs [M, B, O] -> actions [M, B, A]; observation, action and mean land in the slab at row (task, env, t)"""

@@ -53,6 +53,7 @@ struct StepData {
     int n_paths = 0, n_rows = 0;
     int n_work[2] = {0, 0};            // [0]: one workgroup per CU (wide passes, gram, fit), [1]: two per CU (k_normalize)
     int rollout_B = 0, rollout_T = 0;  // environments per task / horizon of a device-side rollout in progress (promp_begin_rollout)
+    bool rollout_ragged = false;       // promp_begin_collection: rows go to the staging area, rollout_T = its capacity in vectorised steps
     int n_chain_wg = 0;                // workgroups of the register-chained kernels k_pass / k_chain_hvp (segment table)
     bool has_policy = false, processed = false, has_adv = false;
     unsigned long long data_version = 0;   // bumped by every entry point that may change what the policy passes read from this step
@@ -128,6 +129,8 @@ struct promp_ctx {
     float eta_last[PROMP_ETA_MAX] = {};
     double *gram_partials = nullptr, *red64 = nullptr;
     void* rollout_buf = nullptr;         // goals, start states and noise of a device rollout
+    float* stage_rows = nullptr;         // promp_begin_collection: staging rows [steps][tasks * B] of observations | actions | means
+    size_t stage_capacity = 0;           // floats
     size_t rollout_capacity = 0;
     double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
     size_t smem_fwd = 0, smem_hvp = 0;
@@ -702,7 +705,7 @@ void promp_ctx_destroy(promp_ctx* c) {
         }
     void* ptrs[] = {c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
-                    c->gram_partials, c->red64, c->fwd_buf, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
+                    c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
@@ -1429,7 +1432,68 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
 int promp_begin_rollout(promp_ctx* c, int step, int envs_per_task, int path_length) {
     if (!c) return fail(-1, "ctx is NULL");
     if (c->d.hidden1 > 128 || c->d.hidden2 > 128 || c->d.act_dim > 8) return fail(-1, "shape not supported by the rollout kernels");
-    return begin_fixed_rollout(c, step, envs_per_task, path_length);
+    if (begin_fixed_rollout(c, step, envs_per_task, path_length)) return -2;
+    c->steps[step].rollout_ragged = false;
+    return 0;
+}
+
+int promp_begin_collection(promp_ctx* c, int step, int envs_per_task, int max_steps) {
+    if (!c) return fail(-1, "ctx is NULL");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    if (c->d.hidden1 > 128 || c->d.hidden2 > 128 || c->d.act_dim > 8) return fail(-1, "shape not supported by the rollout kernels");
+    if (envs_per_task < 1 || max_steps < 1) return fail(-1, "envs_per_task and max_steps must be positive");
+    StepData& S = c->steps[step];
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
+    const size_t need = (size_t)max_steps * c->d.n_tasks * envs_per_task * (c->d.obs_dim + 2 * c->d.act_dim);
+    if (need > c->stage_capacity) {
+        if (c->stage_rows) (void)hipFree(c->stage_rows);
+        c->stage_rows = nullptr;
+        c->stage_capacity = need;
+        HIPCHECK(hipMalloc((void**)&c->stage_rows, sizeof(float) * need));
+    }
+    S.rollout_B = envs_per_task; S.rollout_T = max_steps; S.rollout_ragged = true;
+    S.has_policy = false; S.processed = false; S.has_adv = false;
+    return 0;
+}
+
+int promp_end_collection(promp_ctx* c, int step, int n_paths, const int32_t* task_path_offsets, const int32_t* path_env,
+                         const int32_t* path_start, const int32_t* path_len, const float* rewards) {
+    if (!c || !task_path_offsets || !path_env || !path_start || !path_len || !rewards) return fail(-1, "NULL argument");
+    if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
+    StepData& S = c->steps[step];
+    if (!S.rollout_ragged || S.rollout_B < 1) return fail(-3, "promp_begin_collection has not been called for step %d", step);
+    const int M = c->d.n_tasks, B = S.rollout_B, O = c->d.obs_dim, A = c->d.act_dim;
+    if (n_paths < 1 || n_paths > c->d.max_paths) return fail(-1, "%d paths outside [1, max_paths = %d]", n_paths, c->d.max_paths);
+    std::vector<int32_t> pro((size_t)n_paths + 1, 0);
+    for (int p = 0; p < n_paths; ++p) {
+        if (path_len[p] < 1 || path_start[p] < 0 || path_start[p] + path_len[p] > S.rollout_T || path_env[p] < 0 || path_env[p] >= M * B)
+            return fail(-1, "path %d (environment %d, steps [%d, %d)) lies outside the collection", p, path_env[p], path_start[p], path_start[p] + path_len[p]);
+        pro[p + 1] = pro[p] + path_len[p];
+    }
+    if (pro[n_paths] > c->d.max_rows) return fail(-1, "%d collected rows exceed max_rows = %d", pro[n_paths], c->d.max_rows);
+    StepScope scope_(c, S);
+    if (scope_.rc) return -2;
+    if (set_step_layout(c, S, c->stream, false, n_paths, task_path_offsets, pro.data())) return -2;
+    // the finished episodes: staging rows -> slab rows in path order
+    if (ensure_rollout_buf(c, sizeof(int32_t) * 2 * (size_t)n_paths)) return -2;
+    int32_t* d_env = (int32_t*)c->rollout_buf;
+    int32_t* d_start = d_env + n_paths;
+    HIPCHECK(hipMemcpyAsync(d_env, path_env, sizeof(int32_t) * n_paths, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(d_start, path_start, sizeof(int32_t) * n_paths, hipMemcpyHostToDevice, c->stream));
+    GatherPathsArgs g;
+    const size_t n_rows = (size_t)S.rollout_T * M * B;
+    g.obs_in = c->stage_rows; g.act_in = c->stage_rows + n_rows * O; g.mean_in = g.act_in + n_rows * A;
+    g.obs = S.obs; g.act = S.act; g.mean = S.old_mean;
+    g.path_env = d_env; g.path_start = d_start; g.path_row_offsets = S.path_row_offsets;
+    g.n_envs = M * B; g.O = O; g.A = A;
+    PROMP_LAUNCH(k_gather_paths, dim3(n_paths), 256, 0, c->stream, g);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(S.rew, rewards, sizeof(float) * pro[n_paths], hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    S.has_policy = true; S.ls_per_row = 0; S.has_rew64 = false; S.processed = false; S.has_adv = false;
+    S.rollout_ragged = false; S.rollout_B = 0;
+    return 0;
 }
 
 int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t seed, int clip_infos, float* actions_out) {
@@ -1451,6 +1515,12 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     if (tasks_materialize(c)) return -2;
     a.obs_in = d_obs; a.theta_tasks = c->theta_tasks;
     a.obs = S.obs; a.act = S.act; a.mean = S.old_mean; a.old_ls = S.old_ls; a.actions_out = d_act;
+    a.row_env_stride = T; a.row_t_stride = 1;
+    if (S.rollout_ragged) {       // (s, env) rows of the staging area
+        const size_t n_rows = (size_t)T * M * B;
+        a.obs = c->stage_rows; a.act = c->stage_rows + n_rows * O; a.mean = a.act + n_rows * A;
+        a.row_env_stride = 1; a.row_t_stride = (long long)M * B;
+    }
     a.B = B; a.T = T; a.t = t; a.O = O; a.A = A; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2; a.NP = c->NP;
     a.clip_infos = clip_infos; a.min_log_std = c->min_log_std;
     a.seed = seed; a.stream = (unsigned)step;

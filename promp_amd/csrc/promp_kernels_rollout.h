@@ -79,7 +79,8 @@ PROMP_DEV void mlp_mean(const float* th, const float* x, int O, int A, int H1, i
 struct PolicyStepArgs {
     const float* obs_in;        // [tasks][B][O] observations of this environment step
     const float* theta_tasks;   // [tasks][Theta]
-    float *obs, *act, *mean;    // slab of the sampling step: row (task * B + b) * T + t
+    float *obs, *act, *mean;    // where the rows go: row = env * row_env_stride + t * row_t_stride, env = task * B + b
+    long long row_env_stride, row_t_stride;   // fixed-length rollout: (T, 1) into the slab; ragged collection: (1, tasks * B) into the staging rows
     float* old_ls;              // [tasks][A] log_std reported in agent_infos (written at t = 0)
     float* actions_out;         // [tasks][B][A]
     int B, T, t, O, A, H1, H2, NP;
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(64) k_policy_step(PolicyStepArgs a) {
         a.old_ls[task * a.A + threadIdx.x] = a.clip_infos ? fmaxf(ls, a.min_log_std) : ls;
     }
     if (b >= a.B) return;
-    const long long env = (long long)task * a.B + b, row = env * a.T + a.t;
+    const long long env = (long long)task * a.B + b, row = env * a.row_env_stride + a.t * a.row_t_stride;
     const float* x = a.obs_in + env * a.O;
     float mean[8];
     mlp_mean(th, x, a.O, a.A, a.H1, a.H2, mean);
@@ -117,6 +118,28 @@ __global__ void __launch_bounds__(64) k_policy_step(PolicyStepArgs a) {
             a.act[row * a.A + j + 1] = a1;
             a.actions_out[env * a.A + j + 1] = a1;
         }
+    }
+}
+
+// Ragged collection (samplers/meta_sampler.py:100-125: an environment that reports `done` starts its next episode at once):
+// promp_policy_step files the rows of vectorised step s under (s, env) in a staging area; when the host knows the episodes, the
+// finished ones are copied into the step's slab in path order: path p = staging rows (start[p] + t, env[p]), t < len[p].
+struct GatherPathsArgs {
+    const float *obs_in, *act_in, *mean_in;   // staging rows [steps][n_envs]
+    float *obs, *act, *mean;                  // the slab
+    const int *path_env, *path_start, *path_row_offsets;
+    int n_envs, O, A;
+};
+// grid = paths, block = 256
+__global__ void __launch_bounds__(256) k_gather_paths(GatherPathsArgs a) {
+    const int p = blockIdx.x, env = a.path_env[p], s0 = a.path_start[p], r0 = a.path_row_offsets[p], n = a.path_row_offsets[p + 1] - r0;
+    const int W = a.O + 2 * a.A;
+    for (int e = threadIdx.x; e < n * W; e += 256) {
+        const int t = e / W, k = e - t * W;
+        const long long src = (long long)(s0 + t) * a.n_envs + env, dst = r0 + t;
+        if (k < a.O) a.obs[dst * a.O + k] = a.obs_in[src * a.O + k];
+        else if (k < a.O + a.A) a.act[dst * a.A + (k - a.O)] = a.act_in[src * a.A + (k - a.O)];
+        else a.mean[dst * a.A + (k - a.O - a.A)] = a.mean_in[src * a.A + (k - a.O - a.A)];
     }
 }
 

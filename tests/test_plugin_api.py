@@ -245,7 +245,10 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
     cat = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths[i]])
     obs = cat('observations')
     mean = op.forward(spec, theta, obs.astype(np.float64), False)[0]
-    noise = philox.action_noise(seed, np.arange(M * B * T), A, stream=0)          # slab row -> counter; sampling step 0 -> stream
+    # Philox counter = the staging row (vectorised step s, environment); sampling step 0 -> stream.  Fixed-length episodes: the
+    # row of path (task i, env b) at time t is t * M * B + i * B + b
+    counters = np.concatenate([np.arange(T) * (M * B) + env for env in range(M * B)])
+    noise = philox.action_noise(seed, counters, A, stream=0)
     np.testing.assert_allclose(cat('agent_infos', 'mean'), mean, atol=2e-6)
     np.testing.assert_allclose(cat('actions'), mean + np.exp(theta[-A:]) * noise, atol=5e-6)
     act = cat('actions')
@@ -262,13 +265,61 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
     before = list(policy.session.upload_serial)
     sd = proc.process_samples(paths)
     assert policy.session.upload_serial == before and len(sd) == M
-    # ragged episodes: the sampling step is collected by the host-side logic instead
-    sampler2 = DeviceSlabSampler(env=DriftEnv(stop_at=3), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
-    sampler2.update_tasks()
+    # ---- episodes that end early (meta_sampler.py:100-125): same device path, no host fallback.  An environment whose
+    # trajectory does not depend on the actions makes the result comparable with the host-side MetaSampler field by field
+    # (the two draw different exploration noise): same paths per task in the same order, same lengths, observations, rewards, infos
+    class ClockEnv(object):
+        """episode e of task k lasts 2 + (k + e) % 4 steps; observations / rewards are functions of (task, episode, t)"""
+        def __init__(self):
+            self.task, self.episode, self.t = 0, -1, 0
+        def sample_tasks(self, n): return list(range(n))
+        def set_task(self, task): self.task = task
+        def log_diagnostics(self, *a, **k): pass
+        def _obs(self):
+            return np.array([self.task, self.episode, self.t] + [0.5] * (O - 3), dtype=np.float32)[:O]
+        def reset(self):
+            self.episode += 1
+            self.t = 0
+            return self._obs()
+        def step(self, a):
+            self.t += 1
+            done = self.t >= 2 + (self.task + self.episode) % 4
+            return self._obs(), float(10 * self.task + self.episode + 0.25 * self.t), done, dict(t=self.t)
+
+    from promp_amd.samplers.meta_sampler import MetaSampler
+    sampler2 = DeviceSlabSampler(env=ClockEnv(), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
+    host = MetaSampler(env=ClockEnv(), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
+    for smp in (sampler2, host):
+        smp.update_tasks()
     policy.switch_to_pre_update()
+    state = np.random.get_state()
     paths2 = sampler2.obtain_samples()
-    assert sampler2.host_fallbacks == 1 and all(len(p['rewards']) == 3 for i in range(M) for p in paths2[i])
-    assert len(proc.process_samples(paths2)) == M
+    np.random.set_state(state)
+    seed2 = int(np.random.randint(0, 2 ** 31 - 1))
+    ref2 = host.obtain_samples()
+    assert sampler2.host_fallbacks == 0
+    assert [len(paths2[i]) for i in range(M)] == [len(ref2[i]) for i in range(M)]
+    lengths = set()
+    for i in range(M):
+        for p, q in zip(paths2[i], ref2[i]):
+            lengths.add(len(p['rewards']))
+            np.testing.assert_array_equal(p['observations'], np.asarray(q['observations'], dtype=np.float32))
+            np.testing.assert_array_equal(p['rewards'], np.asarray(q['rewards'], dtype=np.float32))
+            np.testing.assert_array_equal(p['env_infos']['t'], q['env_infos']['t'])
+            assert p['actions'].shape == (len(p['rewards']), A) and p['agent_infos']['log_std'].shape == p['actions'].shape
+    assert len(lengths) > 1 and max(lengths) < T                  # really ragged, really early
+    # the rows of every path are the network's output on its observations plus the staging row's noise
+    cat2 = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths2[i]])
+    mean2 = op.forward(spec, theta, cat2('observations').astype(np.float64), False)[0]
+    np.testing.assert_allclose(cat2('agent_infos', 'mean'), mean2, atol=2e-6)
+    fl = paths2.flat
+    counters2 = np.concatenate([(st + np.arange(n)) * (M * B) + e for e, st, n in
+                                zip(fl['path_env'], fl['path_start'], np.diff(fl['path_row_offsets']))])
+    noise2 = philox.action_noise(seed2, counters2, A, stream=policy.session.upload_serial.index(paths2.device_ref[1]))
+    np.testing.assert_allclose(cat2('actions'), mean2 + np.exp(theta[-A:]) * noise2, atol=5e-6)
+    sd2 = proc.process_samples(paths2)
+    assert len(sd2) == M and policy.session.resident_slot(sd2) is not None       # processed where it was collected: no upload
+    assert sum(len(d['rewards']) for d in sd2) == sum(len(p['rewards']) for i in range(M) for p in paths2[i])
 
 
 def run_vpg_scenario(M=3, P=3, T=30, O=5, A=3, hidden=(32, 32), inner_type='log_likelihood', exploration=False):
