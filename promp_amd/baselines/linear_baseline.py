@@ -10,6 +10,24 @@ import numpy as np
 from .. import _lib
 from .base import Baseline
 
+# Standalone fit / predict run on a one-task context of their own.  Creating a context costs ~40 device allocations, three
+# streams and their events -- far more than the one small solve it is created for -- so one is kept per observation width
+# and grown geometrically (a baseline is typically asked to predict path after path).
+_standalone = {}
+
+
+def _standalone_context(obs_dim, rows, paths):
+    lib = _lib.get_library()
+    key = (id(lib), obs_dim)
+    ctx = _standalone.get(key)
+    if ctx is None or ctx.dims.max_rows < rows or ctx.dims.max_paths < paths:
+        cap = (max(rows, 2 * ctx.dims.max_rows), max(paths, 2 * ctx.dims.max_paths)) if ctx is not None else (max(rows, 1024), max(paths, 16))
+        if ctx is not None:
+            ctx.close()
+        ctx = _lib.Context(1, obs_dim, 1, (32, 32), 1, max_rows=cap[0], max_paths=cap[1])
+        _standalone[key] = ctx
+    return ctx
+
 
 class LinearBaseline(Baseline):
     kind = None
@@ -36,11 +54,10 @@ class LinearBaseline(Baseline):
             r = y - np.append(y[1:], 0.0)
             shadow.append(dict(observations=p['observations'], rewards=r))
         fl = _lib.flatten_paths(OrderedDict([(0, shadow)]))
-        ctx = _lib.Context(1, fl['obs'].shape[1], 1, (32, 32), 1, max_rows=len(fl['rew']), max_paths=len(paths))
+        ctx = _standalone_context(fl['obs'].shape[1], len(fl['rew']), len(paths))
         ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
         ctx.process_samples(0, discount=1.0, gae_lambda=1.0, baseline_kind=self.kind, reg_coeff=self._reg_coeff)
-        self._coeffs = ctx.download_processed(0)['coeffs'][0]
-        ctx.close()
+        self._coeffs = ctx.download_processed(0)['coeffs'][0].copy()
 
     def predict(self, path):
         """Phi . w for one path, evaluated on the device (zeros when unfit, linear_baseline.py:31-32)."""
@@ -49,12 +66,10 @@ class LinearBaseline(Baseline):
             return np.zeros(n)
         from collections import OrderedDict
         fl = _lib.flatten_paths(OrderedDict([(0, [dict(observations=path['observations'], rewards=np.zeros(n))])]))
-        ctx = _lib.Context(1, fl['obs'].shape[1], 1, (32, 32), 1, max_rows=n, max_paths=1)
+        ctx = _standalone_context(fl['obs'].shape[1], n, 1)
         ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
         ctx.set_coeffs(0, self.kind, np.asarray(self._coeffs, dtype=np.float64).reshape(1, -1))
-        out = ctx.predict_baseline(0, self.kind)
-        ctx.close()
-        return out
+        return ctx.predict_baseline(0, self.kind)
 
     def log_diagnostics(self, paths, prefix):
         pass
