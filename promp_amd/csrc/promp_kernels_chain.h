@@ -186,84 +186,144 @@ PROMP_DEV f32x2 lds2(const float* p) { return *(const f32x2*)p; }
 PROMP_DEV void sts4(float* p, f32x4 v) { *(f32x4*)p = v; }
 PROMP_DEV void sts2(float* p, f32x2 v) { *(f32x2*)p = v; }
 
-// The networks of a segment (theta, and for the R-operator pass the direction, negated) -> fragment order in LDS.
-// All global loads of all regions of all networks are issued before the first LDS store: the staging costs ONE round trip
-// to L2 / memory (the parameters were written by another CU's reduction moments ago and are nowhere near this CU).
-// Invalid elements (padding) load a clamped valid weight and are multiplied by a zero mask: a select on the loaded value
-// would be turned back into an exec-masked branch around the load and serialise the loads.
-template <int NC1, int NC2, int NT, int NNETS>
-PROMP_DEV void chain_stage_nets(float* blk0, const float* src0, const float* src1, int O, int A, int tid_) {
-    constexpr int H1 = 16 * NC1, H2 = 16 * NC2;
-    constexpr ChainLds L = chain_layout(NC1, NC2, 1, false, 0);
-    constexpr int N1 = NC1 * 512, N2 = NC1 * NC2 * 256, N3 = NC2 * 256, N4 = NC2 * 128, N5 = H1 + H2 + 8;
-    constexpr int E1 = N1, E2 = E1 + N2, E3 = E2 + N3, E4 = E3 + N4, NTOT = E4 + N5, IT = (NTOT + NT - 1) / NT;
-    const int tid = tid_ + opaque_zero();      // (keeps the index arithmetic inside the segment loop: hoisted, it would occupy registers for the whole kernel)
+// The networks of a segment (theta, and the direction, negated) -> fragment order in LDS, plus the BF16 planes of both
+// hidden_1 kernels.  A wave stages whole blocks of 64 four-float fragments (the block is wave-uniform, so a fragment's source
+// indices are a lane-constant pattern shifted by scalars: no per-element index arithmetic, one ds_write_b128 per fragment);
+// the hidden_1 blocks come in pairs (input blocks 2P, 2P + 1 of one output block): the pair IS a lane's eight k-slots of the
+// BF16 instruction, so the three planes are split from the registers that were just loaded.  All global loads of a wave
+// are issued before its first store (one round trip to L2 / memory: the parameters were written by another CU's reduction
+// moments ago): nothing in the load phase USES a loaded value or branches (otherwise the blocks' round trips add up: 13 k cycles
+// instead of 3 k, measured).  Padding reads a clamped valid element; signs and the zero masks of the padding are applied in the
+// store phase.
+//   blocks, per network:  [0, 2 NC1)                       hidden_0: (c, t4)   W1[4 (4 t4 + r) + kk][16 c + i16], obs padded to 32
+//                         [.., + NC2 NC1 / 2)              hidden_1 pairs: (c2, P)  W2[16 (2P + h) + 4 kk + r][16 c2 + i16], h = 0, 1
+//                         [.., + NC2)                      output: (c)  W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
+//                                                          and its [c][lane][ro] copy W3[16 c + i16][2 kk + ro]; the last block
+//                                                          also carries the biases
+template <int NC1, int NC2, int NW>
+PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1, int O, int A, int tid) {
+    constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
+    constexpr ChainLds L = chain_layout(NC1, NC2, 1, true, 0);
+    constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2;
+    constexpr int IT1 = (NB1 + NW - 1) / NW, IT2 = (NB2 + NW - 1) / NW, IT3 = (NB3 + NW - 1) / NW;
+    constexpr int N5 = H1 + H2 + 8, IS = (N5 + NT - 1) / NT;
+    const int lane = tid & 63, i16 = lane & 15, kk = lane >> 4, w = wave_uniform(tid >> 6);
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
-    float r[NNETS][IT];
-    int off[IT];
+    const int mm = i16, ro3 = mm & 3, aa3 = 2 * (mm >> 2) + ro3;          // output block: action of row i16
+    const bool ok3 = ro3 < 2 && aa3 < A;
+    // One loop per block kind with a compile-time trip count; a wave whose block index runs past the end of a kind loads and
+    // stores the kind's last block a second time (same values, same addresses): no branch anywhere (loads inside a block-kind
+    // branch make the compiler wait, at the head of the next branch, for loads it believes may still target the registers it
+    // reuses; a guarded store invites it to sink the block's loads into the guard).
+    float x1[2][IT1][4], x2[2][IT2][8], x3[2][IT3][4], y3[2][IT3][2], z[2][IS];
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int e = tid + i * NT;
-        int idx = 0;
-        float m = 0.f;
-        off[i] = -1;
-        if (e < E1) {
-            const int d = e, c = d >> 9, t4 = (d >> 8) & 1, l = (d >> 2) & 63, rr = d & 3;
-            const int o = 4 * (4 * t4 + rr) + (l >> 4);
-            off[i] = L.w1 + d;
-            idx = (o < O ? o : O - 1) * H1 + 16 * c + (l & 15);
-            m = o < O ? 1.f : 0.f;
-        } else if (e < E2) {                       // (the 4 pad floats of a fragment row are never read)
-            const int d = e - E1, b = d >> 8, kk = (d >> 6) & 3, jl = (d >> 2) & 15, rr = d & 3;
-            const int c2 = b / NC1, c1 = b - c2 * NC1;
-            off[i] = L.w2 + b * PROMP_CH_BLK + kk * PROMP_CH_ROW + jl * 4 + rr;
-            idx = oW2 + (16 * c1 + 4 * kk + rr) * H2 + 16 * c2 + jl;
-            m = 1.f;
-        } else if (e < E3) {
-            const int d = e - E2, c = d >> 8, l = (d >> 2) & 63, rr = d & 3;
-            const int mm = l & 15, ro = mm & 3, aa = 2 * (mm >> 2) + ro;
-            off[i] = L.w3 + d;
-            idx = oW3 + (16 * c + 4 * (l >> 4) + rr) * A + (aa < A ? aa : A - 1);
-            m = (ro < 2 && aa < A) ? 1.f : 0.f;
-        } else if (e < E4) {
-            const int d = e - E3, c = d >> 7, l = (d >> 1) & 63, ro = d & 1;
-            const int aa = 2 * (l >> 4) + ro;
-            off[i] = L.w3b + d;
-            idx = oW3 + (16 * c + (l & 15)) * A + (aa < A ? aa : A - 1);
-            m = aa < A ? 1.f : 0.f;
-        } else if (e < NTOT) {
-            const int d = e - E4;
-            if (d < H1) {
-                off[i] = L.b1 + d;
-                idx = ob1 + d;
-                m = 1.f;
-            } else if (d < H1 + H2) {
-                off[i] = L.b2 + d - H1;
-                idx = ob2 + d - H1;
-                m = 1.f;
-            } else {
-                const int aa = d - H1 - H2;
-                off[i] = L.b3 + aa;
-                idx = ob3 + (aa < A ? aa : A - 1);
-                m = aa < A ? 1.f : 0.f;
+    for (int n = 0; n < 2; ++n) {
+        const float* src = n ? src1 : src0;
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, c = b >> 1, t4 = b & 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * (4 * t4 + r) + kk;
+                x1[n][it][r] = src[(o < O ? o : O - 1) * H1 + 16 * c + i16];
             }
         }
-        r[0][i] = src0[idx] * m;
-        if (NNETS > 1) r[NNETS - 1][i] = src1[idx] * -m;
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const int bj = w + it * NW, b = bj < NB2 ? bj : NB2 - 1, c2 = b / (NC1 / 2), P = b - c2 * (NC1 / 2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x2[n][it][e] = src[oW2 + (16 * (2 * P + (e >> 2)) + 4 * kk + (e & 3)) * H2 + 16 * c2 + i16];
+        }
+#pragma unroll
+        for (int it = 0; it < IT3; ++it) {
+            const int bj = w + it * NW, c = bj < NB3 ? bj : NB3 - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x3[n][it][r] = src[oW3 + (16 * c + 4 * kk + r) * A + (ok3 ? aa3 : 0)];
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro) {
+                const int aa = 2 * kk + ro;
+                y3[n][it][ro] = src[oW3 + (16 * c + i16) * A + (aa < A ? aa : 0)];
+            }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < IT; ++i)
-        if (off[i] >= 0) {
-            blk0[off[i]] = r[0][i];
-            if (NNETS > 1) blk0[L.net_stride + off[i]] = r[NNETS - 1][i];
+    for (int it = 0; it < IS; ++it) {
+        const int dj = tid + it * NT, d = dj < N5 ? dj : N5 - 1;
+        const int aa = d - H1 - H2;
+        const int idx = d < H1 ? ob1 + d : d < H1 + H2 ? ob2 + d - H1 : ob3 + (aa < A ? aa : 0);
+        z[0][it] = src0[idx];
+        z[1][it] = src1[idx];
+    }
+    sched_fence();       // every load is issued before the first store (the scheduler would interleave them in batches: several round trips)
+    float* net0 = sm + 4;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float* nb = net0 + n * L.net_stride;
+        const float sg = n ? -1.f : 1.f;         // the direction is staged negated
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, t4 = b & 1;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = x1[n][it][r] * (4 * (4 * t4 + r) + kk < O ? sg : 0.f);
+            sts4(nb + L.w1 + b * 256 + lane * 4, v);
         }
+#pragma unroll
+        for (int it = 0; it < IT2; ++it) {
+            const int bj = w + it * NW, b = bj < NB2 ? bj : NB2 - 1, c2 = b / (NC1 / 2), P = b - c2 * (NC1 / 2);
+            f32x4 lo, hi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] = x2[n][it][r] * sg;
+                hi[r] = x2[n][it][4 + r] * sg;
+            }
+            // the pair is this lane's eight k-slots of the BF16 instruction: the three planes [term][c2][P][lane] x 8 bf16
+            const float xs[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bf16x8 t[3];
+            bf16_split3(xs, t);
+            sts4(nb + L.w2 + (c2 * NC1 + 2 * P) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, lo);
+            sts4(nb + L.w2 + (c2 * NC1 + 2 * P + 1) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, hi);
+            float* pl = sm + L.planes + n * L.plane_stride;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC2 + c2) * (NC1 / 2) + P) * 64 + lane) * 4) = t[sp];
+        }
+#pragma unroll
+        for (int it = 0; it < IT3; ++it) {
+            const int cj = w + it * NW, c = cj < NB3 ? cj : NB3 - 1;
+            f32x4 v;
+            f32x2 u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = x3[n][it][r] * (ok3 ? sg : 0.f);
+            u[0] = y3[n][it][0] * (2 * kk < A ? sg : 0.f);
+            u[1] = y3[n][it][1] * (2 * kk + 1 < A ? sg : 0.f);
+            sts4(nb + L.w3 + c * 256 + lane * 4, v);
+            sts2(nb + L.w3b + c * 128 + lane * 2, u);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IS; ++it) {
+        const int dj = tid + it * NT, d = dj < N5 ? dj : N5 - 1;
+        const int off = d < H1 ? L.b1 + d : d < H1 + H2 ? L.b2 + d - H1 : L.b3 + d - H1 - H2;
+        const float m = d < H1 + H2 || d - H1 - H2 < A ? 1.f : 0.f;
+        net0[off] = z[0][it] * m;
+        net0[L.net_stride + off] = z[1][it] * -m;
+    }
 }
 
-// distribution constants of the theta network: s (clipped), exp(-s), exp(2 s), gradient mask, R{s}, 1 / (2 exp(2 s) + 1e-8)
-PROMP_DEV void chain_stage_dist(float* dist, const float* th, const float* v, int oS, int A, int clip_log_std, float min_log_std,
-                                int tid) {
+// distribution constants of the theta network: s (clipped), exp(-s), exp(2 s), gradient mask, R{s}, 1 / (2 exp(2 s) + 1e-8).
+// The two global reads are issued by chain_dist_load BEFORE the networks are staged (their round trip to L2 hides behind the
+// staging loads instead of following them).
+struct ChainDistRaw { float s, v; };
+PROMP_DEV ChainDistRaw chain_dist_load(const float* th, const float* v, int oS, int A, int tid) {
+    ChainDistRaw r;
+    const int q = (tid < A) ? tid : 0;
+    r.s = th[oS + q];
+    r.v = (v != nullptr) ? v[oS + q] : 0.f;
+    return r;
+}
+PROMP_DEV void chain_stage_dist(float* dist, ChainDistRaw raw, int A, int clip_log_std, float min_log_std, int tid) {
     if (tid < 8) {
-        const float sr = (tid < A) ? th[oS + tid] : 0.f;
+        const float sr = (tid < A) ? raw.s : 0.f;
         const bool clipped = clip_log_std && (sr < min_log_std);   // tf.maximum: gradient iff var >= min
         const float s = clipped ? min_log_std : sr;
         const float sn2 = expf(2.f * s);
@@ -271,7 +331,7 @@ PROMP_DEV void chain_stage_dist(float* dist, const float* th, const float* v, in
         dist[CH_ES + tid] = expf(-s);
         dist[CH_SN2 + tid] = sn2;
         dist[CH_LMASK + tid] = clipped ? 0.f : 1.f;
-        dist[CH_VLS + tid] = (v != nullptr && tid < A && !clipped) ? -v[oS + tid] : 0.f;   // tangent along -v
+        dist[CH_VLS + tid] = (tid < A && !clipped) ? -raw.v : 0.f;   // tangent along -v
         dist[CH_RDEN + tid] = fast_rcp(2.f * sn2 + 1e-8f);      // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
     }
 }
@@ -527,34 +587,41 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         const float invN = 1.0f / (float)tnrows;
         const float* th = a.theta + (long long)task * a.theta_task_stride;
         const float* v = a.vdir + (long long)task * NP;
+        // on their way while the networks are staged: the distribution's raw parameters, the first tile's observations and
+        // (CACHED) its cache block
+        const ChainDistRaw draw = chain_dist_load(th, v, oS, A, tid);
+        const int tend = seg.tile0 + seg.ntiles;
+        float xT[KS];
+        {
+            const int t = seg.tile0 + w;
+            const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
+            chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
+        }
+        // CACHED: this lane's share of a tile's cache block (sample i16, units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1)
+        f32x4 ch1[NC1], ch2[NC2];
+        f32x2 cmu;
+        const float* hcl = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + i16 * 16 + 4 * kk : nullptr;
+        const float* hcm = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + 256 * (NC1 + NC2) + i16 * 8 + 2 * kk : nullptr;
+        if (CACHED) {
+            const int t = seg.tile0 + w;
+            const long long o = (long long)(t < tend ? 16 * t : 16 * seg.tile0) * HCR;     // always a block of this segment
+#pragma unroll
+            for (int c = 0; c < NC1; ++c) ch1[c] = *(const f32x4*)(hcl + o + 256 * c);
+#pragma unroll
+            for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
+            cmu = *(const f32x2*)(hcm + o);
+        }
         __syncthreads();
         CH_STAMP(0);
-        chain_stage_nets<NC1, NC2, NT, 2>(net, th, v, O, A, tid);
+        chain_stage_nets<NC1, NC2, NW>(sm, th, v, O, A, tid);
         CH_STAMP(5);
-        chain_stage_dist(net + L.dist, th, v, oS, A, a.clip_log_std, a.min_log_std, tid);
+        chain_stage_dist(net + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         CH_STAMP(6);
         // action slots >= 8 of the cotangent tiles must read as zero (slots < 8 and the transpose tiles are rewritten by
         // every tile before they are read); the end-of-segment slabs alias them, so once per segment
         for (int e = lane; e < 2 * 16 * DS; e += 64) DB0[e] = 0.f;
         CH_STAMP(7);
         __syncthreads();
-        {
-            // BF16 planes of both networks' hidden_1 kernels out of the float32 fragments staged above
-            constexpr int NCH = NC2 * (NC1 / 2) * 64;
-            for (int ch = tid; ch < 2 * NCH; ch += NT) {
-                const int ns = ch / NCH, rem = ch - ns * NCH, c2 = rem / ((NC1 / 2) * 64), P = (rem >> 6) % (NC1 / 2), ln = rem & 63;
-                const float* nb = net + ns * VO;
-                float* pl = sm + L.planes + ns * L.plane_stride;
-                const float* src = nb + L.w2 + (ln >> 4) * PROMP_CH_ROW + (ln & 15) * 4;
-                const f32x4 lo = lds4(src + (c2 * NC1 + 2 * P) * PROMP_CH_BLK), hi = lds4(src + (c2 * NC1 + 2 * P + 1) * PROMP_CH_BLK);
-                const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                bf16x8 t[3];
-                bf16_split3(x, t);
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC2 + c2) * (NC1 / 2) + P) * 64 + ln) * 4) = t[sp];
-            }
-            __syncthreads();
-        }
         CH_STAMP(1);
         const float* dist = net + L.dist;
         const float s0 = dist[CH_LS + q0], s1 = dist[CH_LS + q1], e0 = dist[CH_ES + q0], e1 = dist[CH_ES + q1];
@@ -579,27 +646,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         for (int j = 0; j < NC2; ++j) ob2acc[j] = 0.f;
         float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
 
-        const int tend = seg.tile0 + seg.ntiles;
-        float xT[KS];
-        {
-            const int t = seg.tile0 + w;
-            const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
-            chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
-        }
-        // CACHED: this lane's share of a tile's cache block (sample i16, units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1)
-        f32x4 ch1[NC1], ch2[NC2];
-        f32x2 cmu;
-        const float* hcl = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + i16 * 16 + 4 * kk : nullptr;
-        const float* hcm = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + 256 * (NC1 + NC2) + i16 * 8 + 2 * kk : nullptr;
-        if (CACHED) {
-            const int t = seg.tile0 + w;
-            const long long o = (long long)(t < tend ? 16 * t : 16 * seg.tile0) * HCR;     // always a block of this segment
-#pragma unroll
-            for (int c = 0; c < NC1; ++c) ch1[c] = *(const f32x4*)(hcl + o + 256 * c);
-#pragma unroll
-            for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
-            cmu = *(const f32x2*)(hcm + o);
-        }
         int tix = 0;
         for (int t = seg.tile0 + w; t < tend; t += NW, ++tix) {
             CH_TSTAMP(0);
@@ -761,9 +807,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 float dlp = (own0 ? (so0 - s0) - 0.5f * (z0 * z0 - zo0 * zo0) : 0.f) + (own1 ? (so1 - s1) - 0.5f * (z1 * z1 - zo1 * zo1) : 0.f);
                 float Rlp = (own0 ? z0 * e0 * Rmu0 + (z0 * z0 - 1.f) * Rs0 : 0.f) + (own1 ? z1 * e1 * Rmu1 + (z1 * z1 - 1.f) * Rs1 : 0.f);
                 float kl = (own0 ? num0 * rden0 + s0 - so0 : 0.f) + (own1 ? num1 * rden1 + s1 - so1 : 0.f);
-                dlp += shfl_xor_f32(dlp, 16);  dlp += shfl_xor_f32(dlp, 32);
-                Rlp += shfl_xor_f32(Rlp, 16);  Rlp += shfl_xor_f32(Rlp, 32);
-                kl += shfl_xor_f32(kl, 16);    kl += shfl_xor_f32(kl, 32);
+                dlp = fold_groups16(dlp);      // sums over the row's actions (the four lane groups): lane swaps, no LDS round trip
+                Rlp = fold_groups16(Rlp);
+                kl = fold_groups16(kl);
                 if (a.row_tan != nullptr && rvalid && kk == 0) a.row_tan[n] = Rlp;
                 float c = 0.f, Rc = 0.f, km = 0.f;
                 if (rvalid) {
@@ -988,21 +1034,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         }
         CH_STAMP(2);
 
+        outs0 = row16_sum(outs0);  outs1 = row16_sum(outs1);  outb30 = row16_sum(outb30);
+        outb31 = row16_sum(outb31);  klsum = row16_sum(klsum);
 #pragma unroll
-        for (int m = 1; m <= 8; m <<= 1) {
-            outs0 += shfl_xor_f32(outs0, m);  outs1 += shfl_xor_f32(outs1, m);  outb30 += shfl_xor_f32(outb30, m);
-            outb31 += shfl_xor_f32(outb31, m);  klsum += shfl_xor_f32(klsum, m);
-        }
+        for (int j = 0; j < NC1; ++j) ob1acc[j] = fold_groups16(ob1acc[j]);
 #pragma unroll
-        for (int j = 0; j < NC1; ++j) {
-            ob1acc[j] += shfl_xor_f32(ob1acc[j], 16);
-            ob1acc[j] += shfl_xor_f32(ob1acc[j], 32);
-        }
-#pragma unroll
-        for (int j = 0; j < NC2; ++j) {
-            ob2acc[j] += shfl_xor_f32(ob2acc[j], 16);
-            ob2acc[j] += shfl_xor_f32(ob2acc[j], 32);
-        }
+        for (int j = 0; j < NC2; ++j) ob2acc[j] = fold_groups16(ob2acc[j]);
         outs0 *= dist[CH_LMASK + q0];
         outs1 *= dist[CH_LMASK + q1];
         float* P = a.partials + (long long)sg * a.partial_stride;

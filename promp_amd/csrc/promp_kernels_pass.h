@@ -149,7 +149,7 @@ template <int NC1, int NC2, int NW>
 PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NP1 = NC1 / 2, NP2 = NC2 / 2, NT = 64 * NW;
     constexpr PassLds L = pass_layout(NC1, NC2, 1, 0);
-    constexpr int B1 = L.f_w2f / 64, B2 = L.f_w2b / 64, B3 = L.f_w3f / 64, NBLK = L.n_frag / 64, IT = (NBLK + NW - 1) / NW;
+    constexpr int B1 = L.f_w2f / 64, B2 = L.f_w2b / 64, B3 = L.f_w3f / 64, NBLK = L.n_frag / 64;
     constexpr int IS = (L.n_side + NT - 1) / NT;
     const int lane = tid & 63, i16 = lane & 15, kk = lane >> 4, w = wave_uniform(tid >> 6);
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
@@ -157,37 +157,44 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid)
     // actions 2 kk, 2 kk + 1: the distribution epilogue keeps all four lane groups busy), nothing otherwise
     const int aro = i16 & 3, aact = 2 * (i16 >> 2) + aro;
     const bool aok = aro < 2 && aact < A;
-    float x[IT][8], y[IS];
+    // One loop per block kind with a compile-time trip count; a wave whose block index runs past the end of a kind loads the
+    // kind's last block again and skips the store.  The load phase neither branches nor uses a loaded value: all loads of the
+    // wave are in flight together (with a branch per block kind the compiler waits, at the head of the next branch, for loads it
+    // believes may still target the registers it reuses, and the round trips to L2 add up).
+    constexpr int NK1 = B1, NK2 = B2 - B1, NK3 = B3 - B2, NK4 = NBLK - B3;
+    constexpr int IT1 = (NK1 + NW - 1) / NW, IT2 = (NK2 + NW - 1) / NW, IT3 = (NK3 + NW - 1) / NW, IT4 = (NK4 + NW - 1) / NW;
+    float x1[IT1][8], x2[IT2][8], x3[IT3][8], x4[IT4][8], y[IS];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int b = w + it * NW;                  // wave-uniform
-        if (b < B1) {                               // W1[obs 8 kk + e][16 b + i16], prescaled
+    for (int it = 0; it < IT1; ++it) {              // W1[obs 8 kk + e][16 b + i16]
+        const int bj = w + it * NW, b = bj < NK1 ? bj : NK1 - 1;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int o = 8 * kk + e;
-                x[it][e] = th[(o < O ? o : 0) * H1 + 16 * b + i16] * (o < O ? PROMP_TANH_PRESCALE : 0.f);
-            }
-        } else if (b < B2) {                        // W2[u(P, kk, e)][16 c2 + i16], prescaled
-            const int c2 = (b - B1) / NP1, P = (b - B1) - c2 * NP1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[it][e] = th[oW2 + pass_unit(0, kk, e) * H2 + (32 * P * H2 + 16 * c2) + i16] * PROMP_TANH_PRESCALE;
-        } else if (b < B3) {                        // W2[16 c1 + i16][u(P, kk, e)]
-            const int c1 = (b - B2) / NP2, P = (b - B2) - c1 * NP2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[it][e] = th[oW2 + i16 * H2 + pass_unit(0, kk, e) + (16 * c1 * H2 + 32 * P)];
-        } else if (b < NBLK) {                      // W3[u(P, kk, e)][action of row i16]
-            const int P = b - B3;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[it][e] = th[oW3 + (pass_unit(0, kk, e) + 32 * P) * A + (aok ? aact : 0)] * (aok ? 1.f : 0.f);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[it][e] = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const int o = 8 * kk + e;
+            x1[it][e] = th[(o < O ? o : 0) * H1 + 16 * b + i16];
         }
+    }
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {              // W2[u(P, kk, e)][16 c2 + i16]
+        const int bj = w + it * NW, b = bj < NK2 ? bj : NK2 - 1, c2 = b / NP1, P = b - c2 * NP1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x2[it][e] = th[oW2 + pass_unit(0, kk, e) * H2 + (32 * P * H2 + 16 * c2) + i16];
+    }
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) {              // W2[16 c1 + i16][u(P, kk, e)]
+        const int bj = w + it * NW, b = bj < NK3 ? bj : NK3 - 1, c1 = b / NP2, P = b - c1 * NP2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x3[it][e] = th[oW2 + i16 * H2 + pass_unit(0, kk, e) + (16 * c1 * H2 + 32 * P)];
+    }
+#pragma unroll
+    for (int it = 0; it < IT4; ++it) {              // W3[u(P, kk, e)][action of row i16]
+        const int bj = w + it * NW, P = bj < NK4 ? bj : NK4 - 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x4[it][e] = th[oW3 + (pass_unit(0, kk, e) + 32 * P) * A + (aok ? aact : 0)];
     }
     // float32 side tables: W3 for dH2 = W3 dmu^T ([c][lane][ro]: W3[16 c + i16][2 kk + ro]), biases (those that feed a tanh prescaled)
 #pragma unroll
     for (int it = 0; it < IS; ++it) {
-        const int e = tid + it * NT, wd = L.w3b + e;
+        const int ej = tid + it * NT, e = ej < L.n_side ? ej : L.n_side - 1, wd = L.w3b + e;      // (past the end: the last entry again)
         int idx = 0;
         float m = 0.f;
         if (wd < L.b1) {
@@ -200,33 +207,62 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid)
         } else if (wd < L.b3) {
             idx = ob2 + (wd - L.b2);
             m = PROMP_TANH_PRESCALE;
-        } else if (e < L.n_side) {
+        } else {
             const int aa = wd - L.b3;
             idx = ob3 + (aa < A ? aa : 0);
             m = aa < A ? 1.f : 0.f;
         }
         y[it] = th[idx] * m;
     }
+    sched_fence();       // every load is issued before the first store
+    // scales (the kernels that feed a tanh are prescaled) and the zero masks of the padding are applied here
+    auto put = [&](const float (&x)[8], int b, float m0, float m1) {
+        f32x4 lo, hi;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int b = w + it * NW;
-        if (b < NBLK) {
-            f32x4 lo, hi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lo[e] = x[it][e];
-                hi[e] = x[it][4 + e];
-            }
-            u32x4 pl[3];
-            pass_split8(lo, hi, pl);
-#pragma unroll
-            for (int t = 0; t < 3; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = x[e] * m0;
+            hi[e] = x[4 + e] * m1;
         }
+        u32x4 pl[3];
+        pass_split8(lo, hi, pl);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
+    };
+    // (a wave past the end of a kind stores the kind's last block a second time: same values, same addresses, no branch -- a
+    //  guarded store invites the compiler to sink the block's loads into the guard, one more round trip)
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int bj = w + it * NW, b = bj < NK1 ? bj : NK1 - 1;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = x1[it][e] * (8 * kk + e < O ? PROMP_TANH_PRESCALE : 0.f);
+            hi[e] = x1[it][4 + e] * (8 * kk + 4 + e < O ? PROMP_TANH_PRESCALE : 0.f);
+        }
+        u32x4 pl[3];
+        pass_split8(lo, hi, pl);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
+    }
+#pragma unroll
+    for (int it = 0; it < IT2; ++it) {
+        const int bj = w + it * NW;
+        put(x2[it], B1 + (bj < NK2 ? bj : NK2 - 1), PROMP_TANH_PRESCALE, PROMP_TANH_PRESCALE);
+    }
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) {
+        const int bj = w + it * NW;
+        put(x3[it], B2 + (bj < NK3 ? bj : NK3 - 1), 1.f, 1.f);
+    }
+#pragma unroll
+    for (int it = 0; it < IT4; ++it) {
+        const int bj = w + it * NW;
+        put(x4[it], B3 + (bj < NK4 ? bj : NK4 - 1), aok ? 1.f : 0.f, aok ? 1.f : 0.f);
     }
 #pragma unroll
     for (int it = 0; it < IS; ++it) {
-        const int e = tid + it * NT;
-        if (e < L.n_side) sm[L.w3b + e] = y[it];
+        const int ej = tid + it * NT, e = ej < L.n_side ? ej : L.n_side - 1;
+        sm[L.w3b + e] = y[it];
     }
 }
 
@@ -768,10 +804,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
         float xr[8];
         int t = seg.tile0 + w;
         pass_load_x(xr, W, t, i16, kk);
+        const ChainDistRaw draw = chain_dist_load(th, nullptr, oS, A, tid);
         __syncthreads();
         CH_STAMP(0);
         pass_stage_net<NC1, NC2, NW>(sm, th, O, A, tid);
-        chain_stage_dist(sm + L.dist, th, nullptr, oS, A, a.clip_log_std, a.min_log_std, tid);
+        chain_stage_dist(sm + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         // the action slots >= 8 of the cotangent tiles read as zero (the end-of-segment slabs alias them: once per segment)
         for (int e = lane; e < 3 * DPL; e += 64) wreg[L.dm + e] = 0.f;
         __syncthreads();

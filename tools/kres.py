@@ -3,7 +3,7 @@ usage: python tools/kres.py [substring ...]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pats = sys.argv[1:] or ['k_chain']
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form',
+cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-slp-vectorize',
        '-shared', '-fPIC', os.path.join(ROOT, 'promp_amd/csrc/promp_hip.hip'), '-o', os.path.join(ROOT, 'promp_amd/libpromp_hip.so'),
        '-lrccl', '-Wno-pass-failed', '-Rpass-analysis=kernel-resource-usage'] + os.environ.get('PROMP_EXTRA_FLAGS', '').split()
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
