@@ -188,6 +188,15 @@ int promp_set_primal_cache(promp_ctx* ctx, int on);
  * Bit-identical results either way.  promp_adapt_passes_skipped counts the skipped passes (for tests / logs). */
 int promp_set_reuse_adapt(promp_ctx* ctx, int on);
 long long promp_adapt_passes_skipped(promp_ctx* ctx);
+/* R-operator passes of promp_constraint_hvp that read a step's primal cache instead of recomputing layers 1 and 2 (the
+ * products of one conjugate-gradient solve run at the same parameters on the same slabs: the passes that refresh the chain
+ * store, every pass of every product reads; governed by promp_set_primal_cache; for tests / logs) */
+long long promp_constraint_hvp_cached_passes(promp_ctx* ctx);
+/* A counter that moves whenever something an evaluation of the objectives depends on is replaced: the parameters (set /
+ * Adam update), the inner step sizes, min_std / learn_std, a step's slabs or advantages.  Equal values before two evaluations
+ * with the same arguments mean equal results: the host side uses it to answer TRPO's separate loss / constraint queries at
+ * one parameter vector (optimizers/conjugate_gradient_optimizer.py:227-236 evaluates them one after the other) from one pass. */
+long long promp_state_version(promp_ctx* ctx);
 int promp_set_adam_state(promp_ctx* ctx, const float* m, const float* v, int64_t t);
 int promp_get_adam_state(promp_ctx* ctx, float* m, float* v, int64_t* t);
 /* MetaPolicy.switch_to_pre_update: replicate theta into every task's parameter slot */

@@ -73,6 +73,8 @@ SIGNATURES = {
     'promp_set_primal_cache': (C.c_int, [_P, C.c_int]),
     'promp_set_reuse_adapt': (C.c_int, [_P, C.c_int]),
     'promp_adapt_passes_skipped': (C.c_longlong, [_P]),
+    'promp_constraint_hvp_cached_passes': (C.c_longlong, [_P]),
+    'promp_state_version': (C.c_longlong, [_P]),
     'promp_set_min_std': (C.c_int, [_P, C.c_float]),
     'promp_set_schedule': (C.c_int, [_P, C.c_int, C.c_int]),
     'promp_set_rewards_f64': (C.c_int, [_P, C.c_int, _D]),
@@ -463,6 +465,13 @@ class Context:
 
     def adapt_passes_skipped(self):
         return int(self.lib.cdll.promp_adapt_passes_skipped(self._h))
+
+    def state_version(self):
+        """moves whenever parameters, step sizes, min_std / learn_std or a step's data are replaced (promp_state_version)"""
+        return int(self.lib.cdll.promp_state_version(self._h))
+
+    def constraint_hvp_cached_passes(self):
+        return int(self.lib.cdll.promp_constraint_hvp_cached_passes(self._h))
 
     def set_min_std(self, min_std):
         self._call('promp_set_min_std', float(min_std))

@@ -57,6 +57,7 @@ struct StepData {
     int n_chain_wg = 0;                // workgroups of the register-chained kernels k_pass / k_chain_hvp (segment table)
     bool has_policy = false, processed = false, has_adv = false;
     unsigned long long data_version = 0;   // bumped by every entry point that may change what the policy passes read from this step
+    unsigned long long cache_tag = 0;      // identity of the primal cache's contents (every storing pass draws a new one)
     int ls_per_row = 0;
     int feat_dim = 0;
     float *obs = nullptr, *act = nullptr, *rew = nullptr, *old_mean = nullptr, *old_ls = nullptr;
@@ -158,6 +159,11 @@ struct promp_ctx {
     bool reuse_adapt = true;             // promp_set_reuse_adapt
     bool ls_known = false;               // ls_min is the smallest log_std entry of the current theta
     float ls_min = 0.f;
+    // promp_constraint_hvp: what its primal caches (one per step) were filled at; the products of one conjugate-gradient solve run
+    // at the same parameters on the same slabs, so the 2K + 1 R-operator passes of every product after the first read them back
+    struct { bool valid = false; unsigned long long theta_version = 0, sizes_version = 0, data_version[PROMP_ETA_MAX + 1] = {},
+             tag[PROMP_ETA_MAX + 1] = {}; int inner_kind = 0; float min_log_std = 0.f; } chvp;
+    long long chvp_cached_passes = 0;          // R-operator passes of promp_constraint_hvp that read a primal cache (tests, tools)
     float* pass_next2 = nullptr;         // launch_pass: second destinations of the RED_STEP reduction (see adapt0)
     float* pass_scal2 = nullptr;
     long long adapt_passes_skipped = 0;
@@ -317,6 +323,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.row_tan = hvp ? c->pass_row_tan : nullptr;
     const int cache = (c->wide || fwd_only || !S.hcache) ? 0 : c->pass_cache;
     a.hcache = cache ? S.hcache : nullptr;
+    if (cache == 1) S.cache_tag = ++c->version_counter;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
@@ -398,6 +405,15 @@ int loss_kind_outer(int outer_kind) {
            : outer_kind == PROMP_OUTER_LOGLIK ? LOSS_LOGLIK : LOSS_CLIP;
 }
 
+// promp_inner_adapt has left the first inner pass's results behind (theta' in chain[1], its scalars, the primal cache) and nothing
+// it read has changed since; the clip of log_std at log(min_std) -- the one difference between the two -- is not active
+static bool adapt0_stands(const promp_ctx* c, int inner_kind, bool cached) {
+    return c->reuse_adapt && c->adapt0.valid && c->adapt0.theta_version == c->theta_version &&
+           c->adapt0.data_version == c->steps[0].data_version && c->adapt0.sizes_version == c->sizes_version &&
+           c->adapt0.inner_kind == inner_kind && c->adapt0.cached == cached && c->adapt0.min_log_std == c->min_log_std &&
+           c->adapt0.learn_std == c->learn_std && c->ls_known && c->ls_min >= c->min_log_std && !c->pass_adv;
+}
+
 // One evaluation of the meta-objective (+ gradient, + Adam) enqueued on the stream.
 int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_kind, int outer_kind, bool want_grad,
                  bool do_adam, float lr) {
@@ -422,10 +438,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
             dev_alloc(&c->steps[k].hcache, ((size_t)c->d.max_rows + 16 * (size_t)M) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
         // promp_inner_adapt has left exactly this pass's results behind (see there) if nothing it read has changed since and
         // the clip of log_std at log(min_std) -- the one difference between the two -- is not active
-        const bool reuse = k == 0 && c->reuse_adapt && c->adapt0.valid && c->adapt0.theta_version == c->theta_version &&
-                           c->adapt0.data_version == c->steps[0].data_version && c->adapt0.sizes_version == c->sizes_version &&
-                           c->adapt0.inner_kind == inner_kind && c->adapt0.cached == cached && c->adapt0.min_log_std == c->min_log_std &&
-                           c->adapt0.learn_std == c->learn_std && c->ls_known && c->ls_min >= c->min_log_std && !c->pass_adv;
+        const bool reuse = k == 0 && adapt0_stands(c, inner_kind, cached);
         if (reuse) {
             c->adapt_passes_skipped += 1;
             filled[k] = cached;
@@ -1226,6 +1239,7 @@ int promp_set_min_std(promp_ctx* c, float min_std) {
     if (!c) return fail(-1, "ctx is NULL");
     if (!(min_std > 0.f)) return fail(-1, "min_std must be positive");
     c->min_log_std = logf(min_std);
+    c->version_counter += 1;
     return 0;
 }
 int promp_set_schedule(promp_ctx* c, int stage_overlap, int fuse_min_tasks) {
@@ -1244,6 +1258,8 @@ int promp_set_reuse_adapt(promp_ctx* c, int on) {
     return 0;
 }
 long long promp_adapt_passes_skipped(promp_ctx* c) { return c ? c->adapt_passes_skipped : -1; }
+long long promp_constraint_hvp_cached_passes(promp_ctx* c) { return c ? c->chvp_cached_passes : -1; }
+long long promp_state_version(promp_ctx* c) { return c ? (long long)c->version_counter : -1; }
 int promp_set_primal_cache(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
     c->primal_cache = on < 0 ? -1 : on != 0;
@@ -1615,18 +1631,60 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     };
     const int lk = loss_kind_inner(inner_kind);
     long long st = 0;
-    if (refresh_chain)
+    // Primal caches: the products of one conjugate-gradient solve all run at the same parameters on the same slabs, so the
+    // passes that refresh the chain store their activations (and one extra storing pass with the KL objective covers step K);
+    // every R-operator pass below then reads them back instead of recomputing layers 1 and 2.  Same worth-it rule as the
+    // meta-objective's cache (enqueue_meta).
+    bool use_cache = policy_shape_chain(&c->d);
+    for (int k = 0; k <= K && use_cache; ++k)
+        use_cache = c->primal_cache > 0 || (c->primal_cache < 0 && c->steps[k].n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
+    if (refresh_chain) {
+        c->chvp.valid = false;
+        for (int k = 0; k <= K && use_cache; ++k)
+            if (!c->steps[k].hcache &&
+                dev_alloc(&c->steps[k].hcache, ((size_t)c->d.max_rows + 16 * (size_t)M) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
         for (int k = 0; k < K; ++k) {
             const float* th = theta_of(k, &st);
-            if (launch_pass(c, c->steps[k], false, th, st, lk, 0.f, k == 0, 0.f, false, RED_STEP, th, st,
-                            c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2)) return -2;
+            if (k == 0 && adapt0_stands(c, inner_kind, use_cache)) {       // promp_inner_adapt has just run exactly this pass
+                c->adapt_passes_skipped += 1;
+                continue;
+            }
+            c->pass_cache = use_cache ? 1 : 0;
+            const int rc = launch_pass(c, c->steps[k], false, th, st, lk, 0.f, k == 0, 0.f, false, RED_STEP, th, st,
+                                       c->chain + (size_t)(k + 1) * MNP, c->scal_inner + (size_t)k * M * 2);
+            c->pass_cache = 0;
+            if (rc) return -2;
         }
+        if (use_cache) {
+            const float* th = theta_of(K, &st);
+            c->pass_cache = 1;
+            const int rc = launch_pass(c, c->steps[K], false, th, st, LOSS_KL, 0.f, K == 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
+            c->pass_cache = 0;
+            if (rc) return -2;
+            c->chvp.valid = true; c->chvp.theta_version = c->theta_version; c->chvp.sizes_version = c->sizes_version;
+            c->chvp.inner_kind = inner_kind; c->chvp.min_log_std = c->min_log_std;
+            for (int k = 0; k <= K; ++k) {
+                c->chvp.data_version[k] = c->steps[k].data_version;
+                c->chvp.tag[k] = c->steps[k].cache_tag;
+            }
+        }
+    }
+    const bool rec_ok = use_cache && c->chvp.valid && c->chvp.theta_version == c->theta_version && c->chvp.sizes_version == c->sizes_version &&
+                        c->chvp.inner_kind == inner_kind && c->chvp.min_log_std == c->min_log_std;
+    auto cache_ok = [&](int k) {
+        return rec_ok && c->steps[k].hcache && c->chvp.data_version[k] == c->steps[k].data_version && c->chvp.tag[k] == c->steps[k].cache_tag;
+    };
     HIPCHECK(hipMemcpyAsync(c->grad_mean, v, sizeof(float) * NP, hipMemcpyHostToDevice, c->stream));
     PROMP_LAUNCH(k_replicate, dim3((NP + 255) / 256), 256, 0, c->stream, c->vbuf, c->grad_mean, NP, M);
     const dim3 eg((NP + 255) / 256, M);
     auto pass = [&](int k, int kind) -> int {
         const float* th = theta_of(k, &st);
-        return launch_pass(c, c->steps[k], true, th, st, kind, 0.f, k == 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
+        const bool cached = cache_ok(k);
+        c->pass_cache = cached ? 2 : 0;
+        c->chvp_cached_passes += cached ? 1 : 0;
+        const int rc = launch_pass(c, c->steps[k], true, th, st, kind, 0.f, k == 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
+        c->pass_cache = 0;
+        return rc;
     };
     for (int k = 0; k < K; ++k) {                      // u = J_{K-1} ... J_0 v
         if (pass(k, lk)) return -2;

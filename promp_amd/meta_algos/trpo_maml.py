@@ -13,6 +13,7 @@ class _DeviceEvaluator(object):
 
     def __init__(self, algo):
         self.algo = algo
+        self._memo = None
 
     @property
     def ctx(self):
@@ -38,12 +39,24 @@ class _DeviceEvaluator(object):
         tot = a.session.allreduce(tot)                # task-sharded run: sum over the ranks
         return tot[0] / n_global, (tot[1:] / n_global if want_grad else None)
 
+    def _objectives(self):
+        """One forward evaluation of the meta-objective yields both the surrogate loss and the mean KL.  The optimizer asks for
+        them one after the other at every parameter vector it visits (KL before / loss before, every line-search trial, loss
+        after / KL after: conjugate_gradient_optimizer.py:227-236, trpo_maml.py:170-191); the second question is answered from
+        the first one's pass as long as nothing the evaluation reads has been replaced (promp_state_version)."""
+        ctx = self.ctx
+        key = (id(ctx), ctx.state_version(), self.algo.inner_kind)
+        if self._memo is None or self._memo[0] != key:
+            r = ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)
+            self._memo = ((id(ctx), ctx.state_version(), self.algo.inner_kind), r)
+        return self._memo[1]
+
     def loss(self):          # -mean_i mean(ratio * adv) at theta'_i   (trpo_maml.py:135,150)
-        v = self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['loss']
+        v = self._objectives()['loss']
         return v + self._exploration(False)[0] if self.algo.exploration else v
 
     def constraint_val(self):   # mean_i mean KL(old || pi_theta'_i)   (trpo_maml.py:133,147)
-        return self.ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)['outer_kl']
+        return self._objectives()['outer_kl']
 
     def gradient(self):
         g = self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0]

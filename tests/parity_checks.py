@@ -386,9 +386,23 @@ def check_exact_constraint_hvp(lib, seed, M, P, T, O, A, hidden, K=1, inner='log
         assert float(np.dot(x, hv)) > 0                               # positive semi-definite (J^T H_KL J), strictly here
     # symmetry: <y, H x> == <x, H y>
     x, y = rng.randn(spec.n_params).astype(np.float32), rng.randn(spec.n_params).astype(np.float32)
-    a = float(np.dot(y, ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=False)))
+    hx = ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=False)
+    a = float(np.dot(y, hx))
     b = float(np.dot(x, ctx.constraint_hvp(y, inner_kind=kind, refresh_chain=False)))
     assert abs(a - b) <= 1e-3 * max(abs(a), abs(b))
+    if tuple(hidden) in ((32, 32), (64, 64), (32, 64), (64, 32)) and O <= 32:
+        # primal caches: the chain-refreshing passes store, all 2K + 1 R-operator passes of every product read; equal to the
+        # recomputing passes to rounding, and nothing stale survives new parameters / a refresh
+        assert ctx.constraint_hvp_cached_passes() == 0               # (these shapes are below the worth-it threshold)
+        ctx.set_primal_cache(True)
+        h1 = ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=True)
+        h2 = ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=False)
+        assert ctx.constraint_hvp_cached_passes() == 2 * (2 * K + 1)
+        assert rel_max(h1, hx) < 5e-6 and np.array_equal(h1, h2), rel_max(h1, hx)
+        ctx.set_theta(theta * np.float32(1.01))                      # new parameters without a refresh: the caches must not be read
+        n0 = ctx.constraint_hvp_cached_passes()
+        ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=False)
+        assert ctx.constraint_hvp_cached_passes() == n0
     ctx.close()
 
 
