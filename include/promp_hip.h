@@ -287,7 +287,8 @@ int promp_meta_grad(promp_ctx* ctx, float clip_eps, const float* inner_kl_coeff,
  * distribution is the adapted policy's, i.e. at the parameters TRPO evaluates it).  The mean is over the GLOBAL
  * meta-batch (all-reduce when a communicator is attached).  refresh_chain != 0 recomputes the adapted parameters
  * theta_k from the current theta first (needed once per theta).  No reg_coeff term: the caller adds reg_coeff * v.
- * Register-chained kernels only (hidden sizes from {32,64}, obs_dim <= 32); other shapes fail with -1. */
+ * Every supported policy shape (register-chained and cooperative kernels); the register-chained ones keep primal caches
+ * over the products of one solve (promp_set_primal_cache, promp_constraint_hvp_cached_passes). */
 int promp_constraint_hvp(promp_ctx* ctx, int inner_kind, const float* v, int refresh_chain, float* out);
 /* tf.train.AdamOptimizer step on theta with the gradient left by promp_meta_grad
  * (optimizers/maml_first_order_optimizer.py:24,64; b1=.9 b2=.999 eps=1e-8, bias-corrected lr). */

@@ -1616,8 +1616,6 @@ int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_ki
 // product: at the parameters the samples were drawn with (old distribution == adapted policy).  2K + 1 R-operator passes.
 int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refresh_chain, float* out) {
     if (!c || !v || !out) return fail(-1, "NULL argument");
-    if (c->wide) return fail(-1, "the exact constraint Hessian-vector product runs on the register-chained pass kernels "
-                                 "(hidden sizes from {32, 64}, obs_dim <= 32); use the finite-difference product for this shape");
     const int K = c->d.num_inner_steps, M = c->d.n_tasks, NP = c->NP;
     const size_t MNP = (size_t)M * NP;
     for (int k = 0; k <= K; ++k) {
@@ -1635,7 +1633,7 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     // passes that refresh the chain store their activations (and one extra storing pass with the KL objective covers step K);
     // every R-operator pass below then reads them back instead of recomputing layers 1 and 2.  Same worth-it rule as the
     // meta-objective's cache (enqueue_meta).
-    bool use_cache = policy_shape_chain(&c->d);
+    bool use_cache = !c->wide && policy_shape_chain(&c->d);      // (the cooperative kernels keep no primal cache)
     for (int k = 0; k <= K && use_cache; ++k)
         use_cache = c->primal_cache > 0 || (c->primal_cache < 0 && c->steps[k].n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
     if (refresh_chain) {

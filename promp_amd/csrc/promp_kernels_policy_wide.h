@@ -610,6 +610,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
             float dlp = 0.f, Rlp = 0.f, kl = 0.f;
             float z0 = 0.f, z1 = 0.f, e0 = 0.f, e1 = 0.f, Rmu0 = 0.f, Rmu1 = 0.f, dklm0 = 0.f, dklm1 = 0.f, dkls0 = 0.f,
                   dkls1 = 0.f, Rs0 = 0.f, Rs1 = 0.f;
+            // objective = the mean KL itself (the TRPO constraint, LOSS_KL): R{dKL/dmu}, R{dKL/ds} along v (formulas: k_chain_hvp)
+            float kRdm0 = 0.f, kRdm1 = 0.f, kRds0 = 0.f, kRds1 = 0.f;
             if (own0) {
                 const float s = lss[q], mu = Mss[erow * MS + q];
                 Rmu0 = Ms2s[erow * MS + q];
@@ -624,6 +626,10 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
                 kl += num * rden + s - so0;
                 dklm0 = -2.f * (mo0 - mu) * rden * invN;
                 dkls0 = ((-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f) * invN;
+                const float D = mo0 - mu, Pk = sn2 * (den + 2.f * num);
+                const float RP = 2.f * sn2 * Rs0 * (den + 2.f * num) - 4.f * sn2 * D * Rmu0;
+                kRdm0 = (2.f * Rmu0 * rden + 8.f * D * sn2 * Rs0 * (rden * rden)) * invN;
+                kRds0 = (-2.f * RP + 16.f * Pk * sn2 * Rs0 * rden) * (rden * rden) * invN;
             }
             if (own1) {
                 const float s = lss[q + 4], mu = Mss[erow * MS + q + 4];
@@ -639,6 +645,10 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
                 kl += num * rden + s - so1;
                 dklm1 = -2.f * (mo1 - mu) * rden * invN;
                 dkls1 = ((-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f) * invN;
+                const float D = mo1 - mu, Pk = sn2 * (den + 2.f * num);
+                const float RP = 2.f * sn2 * Rs1 * (den + 2.f * num) - 4.f * sn2 * D * Rmu1;
+                kRdm1 = (2.f * Rmu1 * rden + 8.f * D * sn2 * Rs1 * (rden * rden)) * invN;
+                kRds1 = (-2.f * RP + 16.f * Pk * sn2 * Rs1 * rden) * (rden * rden) * invN;
             }
             dlp += shfl_xor_f32(dlp, 1);  dlp += shfl_xor_f32(dlp, 2);
             Rlp += shfl_xor_f32(Rlp, 1);  Rlp += shfl_xor_f32(Rlp, 2);
@@ -654,26 +664,27 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
                 }
                 if (q == 0) klsum += kl * invN;
             }
+            const bool klobj = a.loss_kind == LOSS_KL;      // the outputs are MINUS the tangent of the gradient (see the header)
             if (own0) {
                 const float Rz = -Rmu0 * e0 - z0 * Rs0;
-                const float d = c * z0 * e0;
                 const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
                 const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
-                const float qm = km * (-Rd + klw * dklm0);
+                const float d = klobj ? km * dklm0 : c * z0 * e0;
+                const float qm = klobj ? -km * kRdm0 : km * (-Rd + klw * dklm0);
                 Mss[erow * MS + q] = d;
                 Ms2s[erow * MS + q] = qm;
-                outs0 += km * (-Rds + klw * dkls0);
+                outs0 += klobj ? -km * kRds0 : km * (-Rds + klw * dkls0);
                 outb30 += qm;
             }
             if (own1) {
                 const float Rz = -Rmu1 * e1 - z1 * Rs1;
-                const float d = c * z1 * e1;
                 const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
                 const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
-                const float qm = km * (-Rd + klw * dklm1);
+                const float d = klobj ? km * dklm1 : c * z1 * e1;
+                const float qm = klobj ? -km * kRdm1 : km * (-Rd + klw * dklm1);
                 Mss[erow * MS + q + 4] = d;
                 Ms2s[erow * MS + q + 4] = qm;
-                outs1 += km * (-Rds + klw * dkls1);
+                outs1 += klobj ? -km * kRds1 : km * (-Rds + klw * dkls1);
                 outb31 += qm;
             }
         }

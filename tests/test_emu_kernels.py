@@ -162,6 +162,11 @@ def test_wide_hvp_h128_narrow_obs(lib):
     pc.check_hvp(lib, 25, M=1, P=2, T=20, O=20, A=6, hidden=(128, 128), ragged=True)
 
 
+def test_wide_exact_constraint_hvp_h128(lib):
+    # the TRPO constraint product through the cooperative kernels (KL objective in k_wide_hvp)
+    pc.check_exact_constraint_hvp(lib, 26, M=1, P=2, T=20, O=20, A=6, hidden=(128, 128), K=1)
+
+
 def test_wide_loss_grad_h64_wide_obs(lib):
     pc.check_loss_grad(lib, 21, M=1, P=1, T=40, O=40, A=8, hidden=(64, 64))
 

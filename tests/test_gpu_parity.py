@@ -264,6 +264,9 @@ def test_exact_constraint_hvp_through_the_adaptation(lib):
     pc.check_exact_constraint_hvp(lib, 91, M=4, P=4, T=80, O=20, A=6, hidden=(64, 64), K=1)
     pc.check_exact_constraint_hvp(lib, 92, M=3, P=3, T=50, O=11, A=3, hidden=(64, 32), K=2, inner='ratio')
     pc.check_exact_constraint_hvp(lib, 93, M=20, P=2, T=60, O=20, A=6, hidden=(64, 64), K=1)     # fused in-launch task reduction
+    # cooperative kernels (Ant shapes, hidden 128): KL objective in k_wide_hvp
+    pc.check_exact_constraint_hvp(lib, 94, M=3, P=2, T=70, O=111, A=8, hidden=(128, 128), K=1)
+    pc.check_exact_constraint_hvp(lib, 95, M=2, P=3, T=40, O=20, A=6, hidden=(128, 128), K=2, inner='ratio')
 
 
 def test_staged_uploads_from_pinned_memory_equal_plain_uploads(lib):
