@@ -427,15 +427,18 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
         }
     }
     lds_barrier();
-#pragma unroll 4
-    for (int e = tid; e < NP + 2; e += NT) {
-        float v[NW];
+    // four entries per thread and trip (16-byte LDS reads and one 16-byte store: a quarter of the instructions of the
+    // entry-by-entry loop, 4.6 k -> measured cycles per segment); the slabs and the partial row are padded to SL floats, the pad is
+    // summed and stored like the rest and never read
+#pragma unroll 2
+    for (int e = 4 * tid; e < SL; e += 4 * NT) {
+        f32x4 v[NW];
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v[ww] = S[ww * SL + e];      // all slab reads in flight together
-        float t = v[0];
+        for (int ww = 0; ww < NW; ++ww) v[ww] = *(const f32x4*)(S + ww * SL + e);      // all slab reads in flight together
+        f32x4 t = v[0];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) t += v[ww];
-        P[e] = t;
+        *(f32x4*)(P + e) = t;
     }
 }
 

@@ -445,7 +445,7 @@ def check_schedule_invariance(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, ep
                 np.testing.assert_array_equal(a[key], b[key])
 
 
-def check_adapt_reuse(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, epochs=2):
+def check_adapt_reuse(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, epochs=2, light=False):
     """promp_set_reuse_adapt: the first epoch of an optimisation takes the inner pass promp_inner_adapt just ran (theta', inner
     scalars, primal cache) instead of repeating it.  Must not change a single bit, must actually skip (one pass per optimisation
     from the second iteration on AND in the first, where the smallest log_std entry is known from promp_set_theta), and must NOT
@@ -480,13 +480,14 @@ def check_adapt_reuse(lib, seed, M, P, T, O, A, hidden, K=1, iters=3, epochs=2):
         ctx.close()
         return out
 
-    for cache in (False, True):
+    # (light: the emulated run keeps the cache-filling variant and one kind of disturbance; the GPU test runs everything)
+    for cache in ((True,) if light else (False, True)):
         off, on = run(False, cache), run(True, cache)
         np.testing.assert_array_equal(off[0], on[0])
         np.testing.assert_array_equal(off[1], on[1])
         assert off[2] == pytest_approx_dict(on[2]) and off[3] == pytest_approx_dict(on[3])
         assert off[4] == 0 and on[4] == iters, (off[4], on[4])          # one pass per optimisation (the trailing meta_grad follows an Adam step)
-        for what in ('advantages', 'step_sizes'):                         # something the pass read has changed: the last optimisation repeats it
+        for what in (('advantages',) if light else ('advantages', 'step_sizes')):      # something the pass read has changed: the last optimisation repeats it
             a, b = run(False, cache, what), run(True, cache, what)
             np.testing.assert_array_equal(a[0], b[0])
             assert b[4] == iters - 1, (what, b[4])

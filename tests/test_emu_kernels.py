@@ -90,7 +90,7 @@ def test_fused_and_separate_task_reduction_agree(lib, two_cus):
 
 
 def test_first_epoch_reuses_the_inner_adapt_pass(lib, two_cus):
-    pc.check_adapt_reuse(lib, 63, M=2, P=1, T=20, O=5, A=3, hidden=(32, 32), iters=2, epochs=1)
+    pc.check_adapt_reuse(lib, 63, M=2, P=1, T=20, O=5, A=3, hidden=(32, 32), iters=2, epochs=1, light=True)
 
 
 def test_primal_cache_matches_recomputation(lib, two_cus):
