@@ -619,7 +619,9 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
         promp_dims pd = *dims;
         if (pd.obs_dim > 32) pd.obs_dim = 32;
         c->smem_fwd = sizeof(float) * (size_t)pass_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, param_count(&pd)).total;
-        c->smem_hvp = sizeof(float) * (size_t)chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total;
+        // (one size for both instances: the cache-reading one lays LDS out with the backward planes)
+        c->smem_hvp = sizeof(float) * (size_t)std::max(chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total,
+                                                       chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd), true).total);
     }
     if (c->smem_hvp > 160 * 1024 || c->smem_fwd > 160 * 1024) {
         const size_t need = c->smem_hvp > c->smem_fwd ? c->smem_hvp : c->smem_fwd;

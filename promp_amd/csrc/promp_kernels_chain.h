@@ -115,6 +115,7 @@ struct ChainLds {
     int w1, w2, w3, w3b, b1, b2, b3, dist;   // inside one network block
     int net_stride;
     int planes, plane_stride;                // BF16 planes of the two networks' hidden_1 kernels, behind both network blocks
+    int bplanes, bplane_stride;              // (bwdp) the same kernels' planes in the orientation of the backward product
     int flag;                                // one int: "this workgroup arrived last"
     int wave0, wave_stride, tb0, tb1, db0, db1;
     int total;
@@ -123,14 +124,21 @@ struct ChainLds {
 // dist block of the theta network: 6 x 8 floats
 enum { CH_LS = 0, CH_ES = 8, CH_SN2 = 16, CH_LMASK = 24, CH_VLS = 32, CH_RDEN = 40 };
 
-PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP) {
+// bwdp (the cache-reading R-operator pass): the backward product W2 qZ2^T + (-vW2) dZ2^T runs on the BF16 pipe too and needs both
+// networks' hidden_1 planes in the second orientation (48 KB at 64/64).  LDS pays for them with what that pass no longer reads:
+// the float32 hidden_1 fragments of both networks (every product with W2 is on planes now), theta's hidden_0 fragments (h1 comes
+// from the cache), and the padding lanes of the output kernel's fragments (stored by action instead of by action slot).
+PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, bool bwdp = false) {
     ChainLds L{};
     int o = 4;                    // [0, 4): flag
     L.flag = 0;
     int n = 0;
-    L.w1 = n;  n += NC1 * 512;                      // [c][t4][lane][4]: W1[4 (4 t4 + r) + kk][16 c + i16], obs padded to 32
-    L.w2 = n;  n += NC2 * NC1 * PROMP_CH_BLK;       // [c2][c1][kk][i16][r]: W2[16 c1 + 4 kk + r][16 c2 + i16]
-    L.w3 = n;  n += NC2 * 256;                      // [c][lane][r]: W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
+    if (!bwdp) {
+        L.w1 = n;  n += NC1 * 512;                  // [c][t4][lane][4]: W1[4 (4 t4 + r) + kk][16 c + i16], obs padded to 32
+        L.w2 = n;  n += NC2 * NC1 * PROMP_CH_BLK;   // [c2][c1][kk][i16][r]: W2[16 c1 + 4 kk + r][16 c2 + i16]
+    }
+    L.w3 = n;  n += bwdp ? NC2 * 128 : NC2 * 256;   // [c][lane][r]: W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
+                                                    // bwdp: [c][kk][action 0..7][r]: W3[16 c + 4 kk + r][action]
     L.w3b = n; n += NC2 * 128;                      // [c][lane][ro]: W3[16 c + i16][2 kk + ro]
     L.b1 = n;  n += 16 * NC1;
     L.b2 = n;  n += 16 * NC2;
@@ -138,6 +146,11 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP) {
     L.dist = n; n += 48;
     L.net_stride = n;
     o += (hvp ? 2 : 1) * n;
+    if (bwdp) {                   // the direction's hidden_0 fragments alone: (network block 0) + L.w1 + net_stride lands here
+        L.w1 = (o - 4) - n;
+        L.w2 = 0;
+        o += NC1 * 512;
+    }
     // BF16 planes of the hidden_1 kernel for v_mfma_f32_16x16x32_bf16: [term 3][c2][pair of input blocks][lane] x 8 bf16 (16 B):
     // lane (i16, kk) of chunk (c2, P): W2[16 (2P) + 4 kk + r][16 c2 + i16], r = 0..3, then W2[16 (2P + 1) + 4 kk + r][.]
     // (behind BOTH network blocks: inside them they would push the second network's float32 fragments past the 64 KB that
@@ -145,6 +158,11 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP) {
     L.planes = o;
     L.plane_stride = 3 * NC2 * (NC1 / 2) * 256;
     o += hvp ? 2 * L.plane_stride : 0;
+    // bwdp: [term 3][c1][pair of hidden_1 OUTPUT blocks P][lane] x 8 bf16: lane (i16, kk) of chunk (c1, P):
+    // W2[16 c1 + i16][16 (2P) + 4 kk + r], r = 0..3, then W2[16 c1 + i16][16 (2P + 1) + 4 kk + r]
+    L.bplanes = o;
+    L.bplane_stride = 3 * NC1 * (NC2 / 2) * 256;
+    o += bwdp ? 2 * L.bplane_stride : 0;
     L.wave0 = o;
     int q = 0;
     L.tb0 = q; q += 16 * PROMP_CH_TS;
@@ -200,32 +218,36 @@ PROMP_DEV void sts2(float* p, f32x2 v) { *(f32x2*)p = v; }
 //                         [.., + NC2)                      output: (c)  W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
 //                                                          and its [c][lane][ro] copy W3[16 c + i16][2 kk + ro]; the last block
 //                                                          also carries the biases
-template <int NC1, int NC2, int NW>
+template <int NC1, int NC2, int NW, bool BWDP>
 PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1, int O, int A, int tid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
-    constexpr ChainLds L = chain_layout(NC1, NC2, 1, true, 0);
-    constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2;
-    constexpr int IT1 = (NB1 + NW - 1) / NW, IT2 = (NB2 + NW - 1) / NW, IT3 = (NB3 + NW - 1) / NW;
+    constexpr ChainLds L = chain_layout(NC1, NC2, 1, true, 0, BWDP);
+    constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2, NB4 = BWDP ? NC1 * (NC2 / 2) : 0;
+    constexpr int IT1 = (NB1 + NW - 1) / NW, IT2 = (NB2 + NW - 1) / NW, IT3 = (NB3 + NW - 1) / NW, IT4 = (NB4 + NW - 1) / NW;
     constexpr int N5 = H1 + H2 + 8, IS = (N5 + NT - 1) / NT;
     const int lane = tid & 63, i16 = lane & 15, kk = lane >> 4, w = wave_uniform(tid >> 6);
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
-    const int mm = i16, ro3 = mm & 3, aa3 = 2 * (mm >> 2) + ro3;          // output block: action of row i16
-    const bool ok3 = ro3 < 2 && aa3 < A;
+    // output block: the action of row i16.  Fragment order by action SLOT (slot 4 ko + ro <-> action 2 ko + ro, ro < 2; the other
+    // lanes hold zeros), or -- BWDP -- by action: lanes i16 and i16 + 8 both stage action i16 & 7 (same values, same addresses)
+    const int mm = i16, ro3 = mm & 3, aa3 = BWDP ? (mm & 7) : 2 * (mm >> 2) + ro3;
+    const bool ok3 = (BWDP || ro3 < 2) && aa3 < A;
     // One loop per block kind with a compile-time trip count; a wave whose block index runs past the end of a kind loads and
     // stores the kind's last block a second time (same values, same addresses): no branch anywhere (loads inside a block-kind
     // branch make the compiler wait, at the head of the next branch, for loads it believes may still target the registers it
     // reuses; a guarded store invites it to sink the block's loads into the guard).
-    float x1[2][IT1][4], x2[2][IT2][8], x3[2][IT3][4], y3[2][IT3][2], z[2][IS];
+    float x1[2][IT1][4], x2[2][IT2][8], x3[2][IT3][4], y3[2][IT3][2], x4[2][IT4 ? IT4 : 1][8], z[2][IS];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const float* src = n ? src1 : src0;
+        if (!BWDP || n == 1) {
 #pragma unroll
-        for (int it = 0; it < IT1; ++it) {
-            const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, c = b >> 1, t4 = b & 1;
+            for (int it = 0; it < IT1; ++it) {
+                const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, c = b >> 1, t4 = b & 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 4 * (4 * t4 + r) + kk;
-                x1[n][it][r] = src[(o < O ? o : O - 1) * H1 + 16 * c + i16];
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 4 * (4 * t4 + r) + kk;
+                    x1[n][it][r] = src[(o < O ? o : O - 1) * H1 + 16 * c + i16];
+                }
             }
         }
 #pragma unroll
@@ -233,6 +255,12 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
             const int bj = w + it * NW, b = bj < NB2 ? bj : NB2 - 1, c2 = b / (NC1 / 2), P = b - c2 * (NC1 / 2);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x2[n][it][e] = src[oW2 + (16 * (2 * P + (e >> 2)) + 4 * kk + (e & 3)) * H2 + 16 * c2 + i16];
+        }
+#pragma unroll
+        for (int it = 0; it < IT4; ++it) {
+            const int bj = w + it * NW, b = bj < NB4 ? bj : NB4 - 1, c1 = b / (NC2 / 2), P = b - c1 * (NC2 / 2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x4[n][it][e] = src[oW2 + (16 * c1 + i16) * H2 + 16 * (2 * P + (e >> 2)) + 4 * kk + (e & 3)];
         }
 #pragma unroll
         for (int it = 0; it < IT3; ++it) {
@@ -260,13 +288,15 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
     for (int n = 0; n < 2; ++n) {
         float* nb = net0 + n * L.net_stride;
         const float sg = n ? -1.f : 1.f;         // the direction is staged negated
+        if (!BWDP || n == 1) {
 #pragma unroll
-        for (int it = 0; it < IT1; ++it) {
-            const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, t4 = b & 1;
-            f32x4 v;
+            for (int it = 0; it < IT1; ++it) {
+                const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, t4 = b & 1;
+                f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = x1[n][it][r] * (4 * (4 * t4 + r) + kk < O ? sg : 0.f);
-            sts4(nb + L.w1 + b * 256 + lane * 4, v);
+                for (int r = 0; r < 4; ++r) v[r] = x1[n][it][r] * (4 * (4 * t4 + r) + kk < O ? sg : 0.f);
+                sts4(nb + L.w1 + b * 256 + lane * 4, v);
+            }
         }
 #pragma unroll
         for (int it = 0; it < IT2; ++it) {
@@ -281,11 +311,25 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
             const float xs[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             bf16x8 t[3];
             bf16_split3(xs, t);
-            sts4(nb + L.w2 + (c2 * NC1 + 2 * P) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, lo);
-            sts4(nb + L.w2 + (c2 * NC1 + 2 * P + 1) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, hi);
+            if (!BWDP) {
+                sts4(nb + L.w2 + (c2 * NC1 + 2 * P) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, lo);
+                sts4(nb + L.w2 + (c2 * NC1 + 2 * P + 1) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, hi);
+            }
             float* pl = sm + L.planes + n * L.plane_stride;
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC2 + c2) * (NC1 / 2) + P) * 64 + lane) * 4) = t[sp];
+        }
+#pragma unroll
+        for (int it = 0; it < IT4; ++it) {       // (BWDP) the planes of the backward product: [term][c1][P][lane] x 8 bf16
+            const int bj = w + it * NW, b = bj < NB4 ? bj : NB4 - 1, c1 = b / (NC2 / 2), P = b - c1 * (NC2 / 2);
+            float xs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xs[e] = x4[n][it][e] * sg;
+            bf16x8 t[3];
+            bf16_split3(xs, t);
+            float* pl = sm + L.bplanes + n * L.bplane_stride;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC1 + c1) * (NC2 / 2) + P) * 64 + lane) * 4) = t[sp];
         }
 #pragma unroll
         for (int it = 0; it < IT3; ++it) {
@@ -296,7 +340,8 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
             for (int r = 0; r < 4; ++r) v[r] = x3[n][it][r] * (ok3 ? sg : 0.f);
             u[0] = y3[n][it][0] * (2 * kk < A ? sg : 0.f);
             u[1] = y3[n][it][1] * (2 * kk + 1 < A ? sg : 0.f);
-            sts4(nb + L.w3 + c * 256 + lane * 4, v);
+            if (BWDP) sts4(nb + L.w3 + c * 128 + (kk * 8 + (i16 & 7)) * 4, v);
+            else sts4(nb + L.w3 + c * 256 + lane * 4, v);
             sts2(nb + L.w3b + c * 128 + lane * 2, u);
         }
     }
@@ -550,7 +595,7 @@ template <int NC1, int NC2, int KS, int NW, bool CACHED = false>
 __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     constexpr int NT = 64 * NW, H1 = 16 * NC1, H2 = 16 * NC2, TS = PROMP_CH_TS, DS = PROMP_CH_DS, NOB = KS > 4 ? 2 : 1;
     constexpr int HCR = chain_cache_row(H1, H2);
-    constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0);
+    constexpr ChainLds L = chain_layout(NC1, NC2, NW, true, 0, CACHED);      // CACHED: the layout with backward planes
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
@@ -565,7 +610,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     const float* W1l = net + L.w1 + lane * 4;
     const float* W2l = net + L.w2 + kk * PROMP_CH_ROW + i16 * 4;
     const float* W2b = net + L.w2 + (i16 >> 2) * PROMP_CH_ROW + (i16 & 3) + 16 * kk;
-    const float* W3l = net + L.w3 + lane * 4;
+    // output kernel fragments: by action slot (one per lane), or -- CACHED -- by action: lanes of a padding slot read a valid
+    // fragment and multiply it by zero
+    constexpr int W3C = CACHED ? 128 : 256;
+    const float w3m = (!CACHED || (i16 & 3) < 2) ? 1.f : 0.f;
+    const float* W3l = net + L.w3 + (CACHED ? (kk * 8 + 2 * (i16 >> 2) + (i16 & 1)) * 4 : lane * 4);
     const float* W3b = net + L.w3b + lane * 2;
     const float *B1l = net + L.b1 + 4 * kk, *B2l = net + L.b2 + 4 * kk, *B3l = net + L.b3 + 2 * kk;
     float* TB0w = TB0 + i16 * TS + 4 * kk;
@@ -616,7 +665,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         }
         __syncthreads();
         CH_STAMP(0);
-        chain_stage_nets<NC1, NC2, NW>(sm, th, v, O, A, tid);
+        chain_stage_nets<NC1, NC2, NW, CACHED>(sm, th, v, O, A, tid);
         CH_STAMP(5);
         chain_stage_dist(net + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         CH_STAMP(6);
@@ -778,8 +827,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 f32x4 wf[NC2], vf[NC2];
 #pragma unroll
                 for (int c = 0; c < NC2; ++c) {
-                    wf[c] = lds4(W3l + c * 256);
-                    vf[c] = lds4(W3l + VO + c * 256);
+                    wf[c] = lds4(W3l + c * W3C);
+                    vf[c] = lds4(W3l + VO + c * W3C);
+                    if (CACHED) {
+                        wf[c] *= w3m;
+                        vf[c] *= w3m;
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < NC2; ++c) {
@@ -986,9 +1039,36 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     ad1[c] = zero4();
                     qz1[c] = zero4();
                 }
+                if (CACHED) {
+                    // On the BF16 pipe (round 3): K = 32 hidden_1 output units per instruction = two 16-unit blocks, a lane's eight
+                    // k-slots are its own registers of the two blocks, split three ways; the planes of the second orientation
+                    // come from LDS (chain_layout, bwdp).  6 of the 9 term products, smallest first, as in layer 2.
+                    const bf16x8* Wq = (const bf16x8*)(sm + L.bplanes) + lane;
+                    const bf16x8* Vq = (const bf16x8*)(sm + L.bplanes + L.bplane_stride) + lane;
+                    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                    for (int P = 0; P < NC2 / 2; ++P) {
+                        const float xd[8] = {dz2[2 * P][0], dz2[2 * P][1], dz2[2 * P][2], dz2[2 * P][3],
+                                             dz2[2 * P + 1][0], dz2[2 * P + 1][1], dz2[2 * P + 1][2], dz2[2 * P + 1][3]};
+                        const float xq[8] = {qz2[2 * P][0], qz2[2 * P][1], qz2[2 * P][2], qz2[2 * P][3],
+                                             qz2[2 * P + 1][0], qz2[2 * P + 1][1], qz2[2 * P + 1][2], qz2[2 * P + 1][3]};
+                        bf16x8 dB[3], qB[3];
+                        bf16_split3(xd, dB);
+                        bf16_split3(xq, qB);
+#pragma unroll
+                        for (int p = 0; p < 6; ++p) {
+#pragma unroll
+                            for (int c1 = 0; c1 < NC1; ++c1)
+                                qz1[c1] = mfma16_bf16(Wq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], qB[TB[p]], qz1[c1]);
+#pragma unroll
+                            for (int c1 = 0; c1 < NC1; ++c1)
+                                qz1[c1] = mfma16_bf16(Vq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], dB[TB[p]], qz1[c1]);
+                        }
+                    }
+                } else {
                 // the operands of k-group g + 1 are requested before the products of group g are issued (a fence per group keeps
                 // that order): left alone the compiler reads each operand right in front of its product, and the single wave of
-                // a SIMD then sits out one LDS latency per product (7.7 k cycles per tile for 4.1 k of matrix work, measured)
+                // a SIMD then sits out one LDS latency per product
                 float wb[2][NC1], vb[2][NC1];
 #pragma unroll
                 for (int c1 = 0; c1 < NC1; ++c1) {
@@ -1007,18 +1087,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                             vb[nxt][c1] = W2b[VO + (c2n * NC1 + c1) * PROMP_CH_BLK + 4 * rn];
                         }
                     }
-                    if (!CACHED) {
 #pragma unroll
-                        for (int c1 = 0; c1 < NC1; ++c1) ad1[c1] = mfma16(wb[cur][c1], dz2[c2][r], ad1[c1]);
-                    }
+                    for (int c1 = 0; c1 < NC1; ++c1) ad1[c1] = mfma16(wb[cur][c1], dz2[c2][r], ad1[c1]);
 #pragma unroll
                     for (int c1 = 0; c1 < NC1; ++c1) qz1[c1] = mfma16(wb[cur][c1], qz2[c2][r], qz1[c1]);
 #pragma unroll
                     for (int c1 = 0; c1 < NC1; ++c1) qz1[c1] = mfma16(vb[cur][c1], dz2[c2][r], qz1[c1]);
                     if (g + 1 < 4 * NC2) PROMP_SCHED_DSREAD(2 * NC1);      // the requests first, then the products
-                    PROMP_SCHED_MFMA((CACHED ? 2 : 3) * NC1);
+                    PROMP_SCHED_MFMA(3 * NC1);
                 }
                 sched_fence();
+                }
 #pragma unroll
                 for (int c = 0; c < NC1; ++c)
 #pragma unroll
