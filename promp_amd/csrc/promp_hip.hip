@@ -1917,10 +1917,20 @@ int promp_debug_phase_stamps(promp_ctx* c, int step, int hvp, unsigned long long
     StepData& S = c->steps[step];
     StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
+    if (tasks_materialize(c)) return -2;
+    if (hvp == 2) {               // the cache-reading R-operator pass: fill the step's primal cache first (unstamped)
+        if (c->wide || !policy_shape_chain(&c->d)) return fail(-1, "no primal cache for this shape");
+        if (!S.hcache && dev_alloc(&S.hcache, ((size_t)c->d.max_rows + 16 * (size_t)c->d.n_tasks) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
+        c->pass_cache = 1;
+        const int rc0 = launch_pass(c, S, false, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
+        c->pass_cache = 0;
+        if (rc0) return rc0;
+    }
     HIPCHECK(hipMemsetAsync(c->dbg, 0, sizeof(unsigned long long) * (256 + 4 * 1024), c->stream));
     c->dbg_enabled = true;
-    if (tasks_materialize(c)) return -2;
+    c->pass_cache = hvp == 2 ? 2 : 0;
     const int rc = launch_pass(c, S, hvp != 0, c->theta_tasks, c->NP, LOSS_RATIO, 0.3f, 0, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp);
+    c->pass_cache = 0;
     c->dbg_enabled = false;
     if (rc) return rc;
     HIPCHECK(hipMemcpyAsync(out, c->dbg, sizeof(unsigned long long) * (256 + 4 * 1024), hipMemcpyDeviceToHost, c->stream));

@@ -29,7 +29,7 @@ for hvp in tuple(int(x) for x in os.environ.get('PROMP_STAMP_KERNELS', '0,1').sp
         assert rc == 0, ctx.lib.cdll.promp_last_error()
     s = buf.astype(np.int64)
     t0 = s[0]
-    print('kernel', 'hvp' if hvp else 'pass', ' net1@%d nets@%d zeroed@%d' % (s[5] - t0, s[6] - t0, s[7] - t0), ' staged@%d  loop_end@%d  partial_written@%d  task_reduce_done@%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
+    print('kernel', ('pass', 'hvp', 'hvp<CACHED>')[hvp], ' net1@%d nets@%d zeroed@%d' % (s[5] - t0, s[6] - t0, s[7] - t0), ' staged@%d  loop_end@%d  partial_written@%d  task_reduce_done@%d' % (s[1] - t0, s[2] - t0, s[3] - t0, s[4] - t0))
     wg = s[256:].reshape(-1, 4)
     wg = wg[wg[:, 0] > 0]
     w0 = wg[:, 0].min()
