@@ -369,9 +369,20 @@ __global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
     // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
     const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
     for (int e = threadIdx.x; e < NPAIR * 256; e += 256) {
+        // eight partial blocks per trip, all requested before the first is added (indices past the task's last workgroup read
+        // that workgroup again and add nothing): the trip count is a run-time value, and the remainder loop of a plain unrolled
+        // loop issues load -> add -> load, one round trip to L2 per partial block (28 k of this kernel's 78 k cycles, measured)
         double s = 0.0;
-#pragma unroll 8
-        for (int wg = wg0; wg < wg1; ++wg) s += a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+        for (int base = wg0; base < wg1; base += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int wg = base + u < wg1 ? base + u : wg1 - 1;
+                v[u] = a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (base + u < wg1) ? v[u] : 0.0;
+        }
         int p = e >> 8, bi = 0, rem = p;
         while (rem >= NBLK - bi) {
             rem -= NBLK - bi;
@@ -413,11 +424,18 @@ __global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
             if (k < D && lane < DA) Lm[lane * DA + k] = W[k];
         wave_sync();
         double y = (lane < D) ? Lm[D * DA + lane] : 0.0;
-        // (44 dependent steps: a multiplication by the stored reciprocal instead of a float64 division on the chain)
-        for (int j = D - 1; j >= 0; --j) {
-            const double wj = readlane_f64(y, j) * readlane_f64(rdg, j);
-            if (lane == j) wsol = wj;
-            if (lane < j) y -= Lm[j * DA + lane] * wj;
+        // lane t's column of the transposed factor goes back into the registers the factorisation has just freed: the 44
+        // dependent steps below then contain no memory access (each used to wait for its own LDS read: 310 cycles per step)
+#pragma unroll
+        for (int k = 0; k < DT; ++k) W[k] = (k < D) ? Lm[k * DA + row] : 0.0;
+        // (a multiplication by the stored reciprocal instead of a float64 division on the chain)
+#pragma unroll
+        for (int j = DT - 1; j >= 0; --j) {
+            if (j < D) {
+                const double wj = readlane_f64(y, j) * readlane_f64(rdg, j);
+                if (lane == j) wsol = wj;
+                if (lane < j) y -= W[j] * wj;
+            }
         }
         wave_sync();
         if (!wave_any(lane < D && wsol != wsol)) break;      // NaN => reg *= 10, at most 5 tries (linear_baseline.py:68-77)
