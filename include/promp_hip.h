@@ -342,7 +342,7 @@ int promp_eval_hvp(promp_ctx* ctx, int step, int inner_kind, int clip_log_std, f
                    const float* v, float* out);
 
 /* ---- measurement: HIP-event timing of the pass kernels on the context's stream ------------- */
-enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PROMP_KERNEL_FWD = 3 /* forward-only k_fwd_bwd */,
+enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PROMP_KERNEL_FWD = 3 /* forward-only k_pass */,
        PROMP_KERNEL_COUNT = 4 };
 int promp_prof_enable(promp_ctx* ctx, int on);
 int promp_prof_read(promp_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches, int64_t* rows);

@@ -651,6 +651,22 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
             assert np.abs(ev.constraint_gradient()).max() < 1e-4 and np.abs(r_kl['grad']).max() < 1e-4
         else:
             assert rel_max(ev.constraint_gradient(), r_kl['grad']) < 1e-4
+        # the optimizer's back-to-back loss / constraint queries at one parameter vector share ONE device evaluation, and a new
+        # parameter vector (or anything else the evaluation reads) ends the sharing
+        ctx, calls = algo.session.ctx, []
+        orig = ctx.meta_eval
+        ctx.meta_eval = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            ev._memo = None
+            l0, k0 = ev.loss(), ev.constraint_val()
+            assert len(calls) == 1 + (1 if exploration else 0), len(calls)      # (the exploration term replaces step 0's advantages for a moment)
+            ev.set_theta(theta * np.float32(1.01))
+            l1 = ev.loss()
+            assert len(calls) == 2 + (1 if exploration else 0) and l1 != l0
+            ev.set_theta(theta)
+            assert ev.loss() == l0 and ev.constraint_val() == k0
+        finally:
+            ctx.meta_eval = orig
         # (2) the step
         algo.optimize_policy(samples, log=False)
         st, last = algo.last_stats, algo.optimizer.last

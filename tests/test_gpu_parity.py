@@ -117,7 +117,7 @@ def test_shape_sweep_loss_grad_and_hvp(lib, H, O, A, M, P, T):
 @pytest.mark.parametrize('M,P,T', [(1, 3, 50), (2, 20, 200), (3, 7, 90), (5, 20, 200), (7, 3, 40), (13, 9, 77), (29, 6, 130),
                                    (41, 2, 60), (57, 3, 50), (8, 1, 10)])
 def test_loss_grad_task_count_sweep(lib, M, P, T):
-    # the wave-granular work split of k_fwd_bwd over 2048 wave slots: tasks with fewer tiles than waves, workgroups that
+    # the wave-granular work split of the first-order pass over 2048 wave slots: tasks with fewer tiles than waves, workgroups that
     # straddle two tasks, short last workgroups, and the one-task-per-workgroup fallback (tasks with < 8 waves)
     pc.check_loss_grad(lib, 500 + M, M=M, P=P, T=T, O=11, A=5, hidden=(64, 64), ragged=True)
     pc.check_hvp(lib, 600 + M, M=M, P=P, T=T, O=11, A=5, hidden=(64, 64), ragged=True)
