@@ -39,7 +39,10 @@ typedef struct promp_dims {
     int32_t n_tasks_global;     /* meta_batch_size over all ranks: the task-mean divides by this   */
     int32_t obs_dim;            /* O, 1..128 (policy passes with O > 32 need hidden sizes 64 or 128)  */
     int32_t act_dim;            /* A  (<= 8)                                                       */
-    int32_t hidden1, hidden2;   /* hidden_sizes: (32,32), (64,64) or (128,128)                      */
+    int32_t hidden1, hidden2;   /* hidden_sizes: any two widths in 1..128 (policies/networks/mlp.py:5-62).  The kernels are
+                                 * instantiated for {32,64} x {32,64} (obs_dim <= 32) and (64,64) / (128,128); other widths
+                                 * run zero-padded on the next of those -- every parameter vector still crosses this ABI in the
+                                 * caller's layout (promp_param_count floats, policies/base.py:271-277 order)             */
     int32_t num_inner_steps;    /* K = num_inner_grad_steps (>= 1)                                 */
     int32_t max_rows;           /* capacity: rows (env steps) per sampling step over local tasks   */
     int32_t max_paths;          /* capacity: paths per sampling step over local tasks              */

@@ -113,6 +113,9 @@ struct promp_ctx {
     int device = 0, n_cus = 256, clock_mhz = 0;
     char dev_name[256];
     int NP = 0, Dmax = 0, coeff_stride = 0, max_work = 0, partial_stride = 0, gram_stride = 0;
+    promp_dims du;                       // the caller's dims (d holds the instantiated, possibly zero-padded hidden widths)
+    int NPu = 0;                         // parameter count in the caller's layout
+    bool padded = false;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // sample processing of steps >= 1 runs here, under the main stream's step-0 work
     hipStream_t copy = nullptr;          // promp_stage_step: host -> device copies of the NEXT batch, under the current one's compute
@@ -248,9 +251,9 @@ int check_dims(const promp_dims* d) {
     if (d->n_tasks < 1 || d->n_tasks_global < d->n_tasks) return fail(-1, "bad task counts (%d local, %d global)", d->n_tasks, d->n_tasks_global);
     if (d->obs_dim < 1 || d->obs_dim > 128) return fail(-1, "obs_dim %d unsupported (1..128)", d->obs_dim);
     if (d->act_dim < 1 || d->act_dim > 8) return fail(-1, "act_dim %d unsupported (1..8)", d->act_dim);
-    if (!policy_shape_chain(d) && !policy_shape_coop(d) && !((d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64)))
-        return fail(-1, "hidden sizes (%d,%d) unsupported: this build instantiates every combination of {32, 64} (obs_dim <= 32) "
-                    "and (64,64) / (128,128) (obs_dim <= 128)", d->hidden1, d->hidden2);
+    if (d->hidden1 < 1 || d->hidden2 < 1 || d->hidden1 > 128 || d->hidden2 > 128)
+        return fail(-1, "hidden sizes (%d,%d) unsupported: two tanh layers of 1..128 units each (narrower layers run zero-padded on the "
+                    "instantiated widths: every combination of {32, 64} for obs_dim <= 32, (64,64) / (128,128) otherwise)", d->hidden1, d->hidden2);
     if (d->num_inner_steps < 1 || d->num_inner_steps > PROMP_ETA_MAX) return fail(-1, "num_inner_steps must be in [1, %d]", PROMP_ETA_MAX);
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
@@ -566,6 +569,42 @@ extern "C" {
 const char* promp_last_error(void) { return g_err.c_str(); }
 int promp_abi_version(void) { return 2; }
 
+// The kernels are instantiated for hidden widths from {32, 64} in any combination (obs_dim <= 32) and for (64,64) / (128,128).
+// Any other pair of widths up to 128 runs EMBEDDED in the next instantiated shape: the extra hidden units have zero incoming and
+// outgoing weights and zero bias, so they output tanh(0) = 0, receive a zero cotangent, and every gradient / Hessian-vector entry
+// that belongs to them is exactly zero -- they stay zero under the inner steps and under Adam.  Parameter vectors cross the C ABI in
+// the caller's (unpadded) layout (policies/networks/mlp.py:5-62 takes any hidden_sizes; policies/base.py:271-277 fixes the order).
+static void pad_dims(const promp_dims* u, promp_dims* p) {
+    *p = *u;
+    auto up = [](int h) { return h <= 32 ? 32 : h <= 64 ? 64 : 128; };
+    int a = up(u->hidden1), b = up(u->hidden2);
+    if (u->obs_dim > 32) a = b = std::max(std::max(a, b), 64);
+    else if (a == 128 || b == 128) a = b = 128;
+    p->hidden1 = a;
+    p->hidden2 = b;
+}
+// one parameter vector between the caller's layout (du) and the padded one (dp); to_padded: dst must arrive zeroed
+static void remap_params(const promp_dims& du, const promp_dims& dp, const float* src, float* dst, bool to_padded) {
+    const int O = du.obs_dim, A = du.act_dim, h1 = du.hidden1, h2 = du.hidden2, H1 = dp.hidden1, H2 = dp.hidden2;
+    size_t ou = 0, op = 0;
+    auto rows = [&](int nrows_u, int nrows_p, int cols_u, int cols_p) {
+        for (int r = 0; r < nrows_u; ++r)
+            for (int cc = 0; cc < cols_u; ++cc) {
+                if (to_padded) dst[op + (size_t)r * cols_p + cc] = src[ou + (size_t)r * cols_u + cc];
+                else dst[ou + (size_t)r * cols_u + cc] = src[op + (size_t)r * cols_p + cc];
+            }
+        ou += (size_t)nrows_u * cols_u;
+        op += (size_t)nrows_p * cols_p;
+    };
+    rows(O, O, h1, H1);      // hidden_0/kernel
+    rows(1, 1, h1, H1);      // hidden_0/bias
+    rows(h1, H1, h2, H2);    // hidden_1/kernel
+    rows(1, 1, h2, H2);      // hidden_1/bias
+    rows(h2, H2, A, A);      // output/kernel
+    rows(1, 1, A, A);        // output/bias
+    rows(1, 1, A, A);        // log_std
+}
+
 int promp_param_count(const promp_dims* d) {
     if (!d) return fail(-1, "dims is NULL");
     return param_count(d);
@@ -575,10 +614,13 @@ int promp_feature_dim(const promp_dims* d, int kind) {
     return feature_dim(d, kind);
 }
 
-int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
+int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims) {
     if (!out) return fail(-1, "out is NULL");
     *out = nullptr;
-    if (check_dims(dims)) return -1;
+    if (check_dims(user_dims)) return -1;
+    promp_dims padded_dims;
+    pad_dims(user_dims, &padded_dims);
+    const promp_dims* dims = &padded_dims;        // everything below sees the instantiated shape
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev < 1)
@@ -587,6 +629,9 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims) {
     HIPCHECK(hipSetDevice(device_id));
     promp_ctx* c = new promp_ctx();
     c->d = *dims;
+    c->du = *user_dims;
+    c->NPu = param_count(user_dims);
+    c->padded = c->NPu != param_count(dims);
     c->device = device_id;
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, device_id));
@@ -1217,15 +1262,32 @@ static int copy_out(promp_ctx* c, float* dst, const float* src, size_t n) {
     return 0;
 }
 
+// nvec parameter vectors in the caller's layout <-> device buffers in the instantiated (zero-padded) layout
+static int params_in(promp_ctx* c, float* dst, const float* src, size_t nvec) {
+    if (!c || !src) return fail(-1, "NULL argument");
+    if (!c->padded) return copy_in(c, dst, src, nvec * (size_t)c->NP);
+    std::vector<float> tmp(nvec * (size_t)c->NP, 0.f);
+    for (size_t i = 0; i < nvec; ++i) remap_params(c->du, c->d, src + i * (size_t)c->NPu, tmp.data() + i * (size_t)c->NP, true);
+    return copy_in(c, dst, tmp.data(), tmp.size());
+}
+static int params_out(promp_ctx* c, float* dst, const float* src, size_t nvec) {
+    if (!c || !dst) return fail(-1, "NULL argument");
+    if (!c->padded) return copy_out(c, dst, src, nvec * (size_t)c->NP);
+    std::vector<float> tmp(nvec * (size_t)c->NP);
+    if (copy_out(c, tmp.data(), src, tmp.size())) return -2;
+    for (size_t i = 0; i < nvec; ++i) remap_params(c->du, c->d, tmp.data() + i * (size_t)c->NP, dst + i * (size_t)c->NPu, false);
+    return 0;
+}
+
 int promp_set_theta(promp_ctx* c, const float* th) {
     if (!c || !th) return fail(-1, "NULL argument");
     c->theta_version = ++c->version_counter;
-    c->ls_min = th[c->NP - c->d.act_dim];
-    for (int i = 1; i < c->d.act_dim; ++i) c->ls_min = std::min(c->ls_min, th[c->NP - c->d.act_dim + i]);
+    c->ls_min = th[c->NPu - c->d.act_dim];
+    for (int i = 1; i < c->d.act_dim; ++i) c->ls_min = std::min(c->ls_min, th[c->NPu - c->d.act_dim + i]);
     c->ls_known = true;
-    return copy_in(c, c->theta, th, c->NP);
+    return params_in(c, c->theta, th, 1);
 }
-int promp_get_theta(promp_ctx* c, float* th) { return c ? copy_out(c, th, c->theta, c->NP) : fail(-1, "ctx is NULL"); }
+int promp_get_theta(promp_ctx* c, float* th) { return c ? params_out(c, th, c->theta, 1) : fail(-1, "ctx is NULL"); }
 static int mask_log_std_step_sizes(promp_ctx* c) {
     if (c->learn_std) return 0;
     HIPCHECK(hipMemsetAsync(c->step_sizes + (c->NP - c->d.act_dim), 0, sizeof(float) * c->d.act_dim, c->stream));
@@ -1234,7 +1296,7 @@ static int mask_log_std_step_sizes(promp_ctx* c) {
 int promp_set_step_sizes(promp_ctx* c, const float* s) {
     if (!c) return fail(-1, "ctx is NULL");
     c->sizes_version = ++c->version_counter;
-    if (copy_in(c, c->step_sizes, s, c->NP)) return -2;
+    if (params_in(c, c->step_sizes, s, 1)) return -2;
     return mask_log_std_step_sizes(c);
 }
 int promp_set_min_std(promp_ctx* c, float min_std) {
@@ -1278,24 +1340,24 @@ static int tasks_materialize(promp_ctx* c);
 int promp_set_task_thetas(promp_ctx* c, const float* t) {
     if (!c) return fail(-1, "ctx is NULL");
     c->tasks_shared = false;
-    return copy_in(c, c->theta_tasks, t, (size_t)c->d.n_tasks * c->NP);
+    return params_in(c, c->theta_tasks, t, (size_t)c->d.n_tasks);
 }
 int promp_get_task_thetas(promp_ctx* c, float* t) {
     if (!c) return fail(-1, "ctx is NULL");
     if (tasks_materialize(c)) return -2;
-    return copy_out(c, t, c->theta_tasks, (size_t)c->d.n_tasks * c->NP);
+    return params_out(c, t, c->theta_tasks, (size_t)c->d.n_tasks);
 }
 
 int promp_set_adam_state(promp_ctx* c, const float* m, const float* v, int64_t t) {
     if (!c) return fail(-1, "ctx is NULL");
-    if (copy_in(c, c->adam_m, m, c->NP) || copy_in(c, c->adam_v, v, c->NP)) return -2;
+    if (params_in(c, c->adam_m, m, 1) || params_in(c, c->adam_v, v, 1)) return -2;
     c->adam_t = t;
     return 0;
 }
 int promp_get_adam_state(promp_ctx* c, float* m, float* v, int64_t* t) {
     if (!c) return fail(-1, "ctx is NULL");
-    if (m && copy_out(c, m, c->adam_m, c->NP)) return -2;
-    if (v && copy_out(c, v, c->adam_v, c->NP)) return -2;
+    if (m && params_out(c, m, c->adam_m, 1)) return -2;
+    if (v && params_out(c, v, c->adam_v, 1)) return -2;
     if (t) *t = c->adam_t;
     return 0;
 }
@@ -1605,7 +1667,7 @@ int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_ki
     if (!c || !eta) return fail(-1, "NULL argument");
     if (upload_eta(c, eta)) return -2;
     if (enqueue_meta(c, clip_eps, eta, inner_kind, outer_kind, true, false, 0.f)) return -2;
-    if (grad_out && copy_out(c, grad_out, c->grad_mean, c->NP)) return -2;
+    if (grad_out && params_out(c, grad_out, c->grad_mean, 1)) return -2;
     if (stats_out && copy_out(c, stats_out, c->stats, c->d.num_inner_steps + 2)) return -2;
     HIPCHECK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1674,7 +1736,7 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     auto cache_ok = [&](int k) {
         return rec_ok && c->steps[k].hcache && c->chvp.data_version[k] == c->steps[k].data_version && c->chvp.tag[k] == c->steps[k].cache_tag;
     };
-    HIPCHECK(hipMemcpyAsync(c->grad_mean, v, sizeof(float) * NP, hipMemcpyHostToDevice, c->stream));
+    if (params_in(c, c->grad_mean, v, 1)) return -2;
     PROMP_LAUNCH(k_replicate, dim3((NP + 255) / 256), 256, 0, c->stream, c->vbuf, c->grad_mean, NP, M);
     const dim3 eg((NP + 255) / 256, M);
     auto pass = [&](int k, int kind) -> int {
@@ -1708,9 +1770,9 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
         if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
     }
 #endif
-    if (copy_out(c, out, c->red, NP)) return -2;
+    if (params_out(c, out, c->red, 1)) return -2;
     const float inv = 1.0f / (float)c->d.n_tasks_global;
-    for (int j = 0; j < NP; ++j) out[j] *= inv;
+    for (int j = 0; j < c->NPu; ++j) out[j] *= inv;
     for (int k = 0; k <= K; ++k) c->steps[k].dirty = true;
     return 0;
 }
@@ -1806,7 +1868,7 @@ int promp_eval_loss_grad(promp_ctx* c, int step, int kind, float clip_eps, int c
     const int M = c->d.n_tasks;
     if (tasks_materialize(c)) return -2;
     if (launch_pass(c, S, false, c->theta_tasks, c->NP, kind, clip_eps, clip_ls, 0.f, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
-    if (grads_out && copy_out(c, grads_out, c->lam, (size_t)M * c->NP)) return -2;
+    if (grads_out && params_out(c, grads_out, c->lam, (size_t)M)) return -2;
     std::vector<float> sc((size_t)M * 2);
     if (copy_out(c, sc.data(), c->scal_tmp, sc.size())) return -2;
     for (int i = 0; i < M; ++i) {
@@ -1823,11 +1885,11 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
     StepScope scope_(c, S, false);
     if (scope_.rc) return -2;
     const int M = c->d.n_tasks, NP = c->NP;
-    if (copy_in(c, c->vbuf, v, (size_t)M * NP)) return -2;
+    if (params_in(c, c->vbuf, v, (size_t)M)) return -2;
     HIPCHECK(hipMemsetAsync(c->lam, 0, sizeof(float) * (size_t)M * NP, c->stream));
     if (tasks_materialize(c)) return -2;
     if (launch_pass(c, S, true, c->theta_tasks, NP, loss_kind_inner(inner_kind), 0.f, clip_ls, klw, false, RED_PLAIN, nullptr, 0, nullptr, c->scal_tmp)) return -2;
-    return copy_out(c, out, c->lam, (size_t)M * NP);
+    return params_out(c, out, c->lam, (size_t)M);
 }
 
 int promp_comm_unique_id(void* id_out, size_t id_bytes) {
@@ -1888,11 +1950,14 @@ int promp_comm_move(promp_ctx* dst, promp_ctx* src) {
 
 int promp_reduced_get(promp_ctx* c, float* out) {
     if (!c || !out) return fail(-1, "NULL argument");
-    return copy_out(c, out, c->red, (size_t)c->NP + c->d.num_inner_steps + 2);
+    // [grad Theta | K + 2 scalars]: the gradient part in the caller's layout, like every parameter vector that crosses the ABI
+    if (params_out(c, out, c->red, 1)) return -2;
+    return copy_out(c, out + c->NPu, c->red + c->NP, (size_t)c->d.num_inner_steps + 2);
 }
 int promp_reduced_set(promp_ctx* c, const float* in) {
     if (!c || !in) return fail(-1, "NULL argument");
-    return copy_in(c, c->red, in, (size_t)c->NP + c->d.num_inner_steps + 2);
+    if (params_in(c, c->red, in, 1)) return -2;
+    return copy_in(c, c->red + c->NP, in + c->NPu, (size_t)c->d.num_inner_steps + 2);
 }
 
 int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {

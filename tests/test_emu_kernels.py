@@ -123,6 +123,11 @@ def test_hvp_h32_odd_obs(lib):
     pc.check_hvp(lib, 11, M=1, P=2, T=50, O=5, A=3, hidden=(32, 32), ragged=True)
 
 
+def test_hidden_widths_between_the_instantiated_ones_run_zero_padded(lib, two_cus):
+    # (24, 40) on the (32, 64) kernels: parameter vectors in the caller's layout on both sides of the ABI
+    pc.check_meta(lib, 14, M=2, P=1, T=30, O=6, A=3, hidden=(24, 40), K=1, ragged=True, epochs=1)
+
+
 def test_meta_k1_h64(lib, two_cus):
     pc.check_meta(lib, 12, M=2, P=1, T=40, O=20, A=6, hidden=(64, 64), K=1, ragged=True, epochs=1)
 

@@ -72,9 +72,19 @@ def test_split_gemm_accuracy_guard(lib, hidden, O, A):
 
 
 def test_unsupported_hidden_widths_are_rejected(lib):
-    for hidden, O in (((48, 48), 4), ((64, 128), 4), ((32, 32, 32), 4)):
+    for hidden, O in (((256, 256), 4), ((64, 129), 4), ((0, 32), 4), ((32, 32, 32), 4)):
         with pytest.raises((_lib.PrompError, ValueError, TypeError)):
             _lib.Context(2, O, 2, hidden, 1, max_rows=10, max_paths=2, lib=lib)
+
+
+@pytest.mark.parametrize('hidden,O,A', [((100, 100), 20, 6), ((48, 20), 11, 3), ((64, 128), 20, 6), ((100, 100), 111, 8), ((24, 40), 50, 4)])
+def test_any_hidden_widths_up_to_128(lib, hidden, O, A):
+    """mlp.py:5-62 takes any hidden_sizes: widths the kernels are not instantiated for run zero-padded on the next instantiated
+    shape, parameter vectors cross the ABI in the caller's layout -- objective, gradient, Hessian-vector product, _adapt, the Adam
+    epochs and the Adam state against the float64 oracle of the UNPADDED network"""
+    pc.check_loss_grad(lib, 71, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_hvp(lib, 72, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_meta(lib, 73, M=3, P=2, T=50, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2)
 
 
 def test_loss_grad_clipped_log_std(lib):

@@ -31,6 +31,11 @@ def test_policy_algo_api_two_inner_steps():
     scen.run_algo_scenario(M=3, P=4, T=50, O=5, A=3, hidden=(32, 32), K=2, epochs=3)
 
 
+def test_policy_algo_api_hidden_sizes_100():
+    # the reference's other common policy size (hidden_sizes=(100, 100)): runs zero-padded on the (128, 128) kernels
+    scen.run_algo_scenario(M=4, P=4, T=60, O=20, A=6, hidden=(100, 100), K=1, epochs=3)
+
+
 def test_trainer_end_to_end_point_env():
     scen.run_trainer_scenario(n_itr=3)
 
