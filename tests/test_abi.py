@@ -51,7 +51,8 @@ def test_argument_errors_are_reported():
     with pytest.raises(_lib.PrompError, match='hidden'):
         _lib.Context(2, 4, 2, (256, 256), 1, max_rows=10, max_paths=2, lib=lib)
     with pytest.raises(_lib.PrompError, match='hidden'):
-        _lib.Context(2, 4, 2, (64, 128), 1, max_rows=10, max_paths=2, lib=lib)
+        _lib.Context(2, 4, 2, (64, 129), 1, max_rows=10, max_paths=2, lib=lib)
+    _lib.Context(2, 4, 2, (64, 128), 1, max_rows=10, max_paths=2, lib=lib).close()     # runs zero-padded on (128, 128)
     _lib.Context(2, 4, 2, (64, 32), 1, max_rows=10, max_paths=2, lib=lib).close()      # every combination of {32, 64}
     ctx = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)
     with pytest.raises(_lib.PrompError, match='no data'):
