@@ -1392,14 +1392,14 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     // base.py:217-242 just ran): leave theta', the scalars and the primal cache where the first epoch looks for them.  The two
     // differ only in log_std entries below log(min_std) (raw here, gaussian_mlp_policy.py:182; clipped there, :71,163), which
     // enqueue_meta checks before it trusts the result.
-    const bool leave = c->reuse_adapt && c->tasks_shared && step == 0 && !c->wide && policy_shape_chain(&c->d) &&
+    const bool leave = c->reuse_adapt && c->tasks_shared && step == 0 &&
                        (inner_kind == PROMP_INNER_RATIO || inner_kind == PROMP_INNER_LOGLIK);
     if (step == 0) c->adapt0.valid = false;       // (inner steps on later sampling steps touch nothing the record stands for)
     bool cached = false;
     if (leave) {
         const size_t MNP = (size_t)c->d.n_tasks * c->NP;
         const bool worth = c->primal_cache > 0 || (c->primal_cache < 0 && S.n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
-        cached = worth;
+        cached = worth && !c->wide && policy_shape_chain(&c->d);      // (the cooperative kernels keep no primal cache: theta' and the scalars only)
         if (cached && !S.hcache &&
             dev_alloc(&S.hcache, ((size_t)c->d.max_rows + 16 * (size_t)c->d.n_tasks) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
         c->pass_next2 = c->chain + MNP;

@@ -300,6 +300,8 @@ def test_launch_scheduling_does_not_change_results(lib):
 def test_first_epoch_reuses_the_inner_adapt_pass(lib):
     pc.check_adapt_reuse(lib, 61, M=5, P=3, T=70, O=20, A=6, hidden=(64, 64))
     pc.check_adapt_reuse(lib, 62, M=3, P=2, T=40, O=7, A=3, hidden=(32, 64), K=2)
+    pc.check_adapt_reuse(lib, 64, M=3, P=2, T=70, O=40, A=8, hidden=(128, 128))      # cooperative kernels: theta' and the scalars (no cache)
+    pc.check_adapt_reuse(lib, 65, M=2, P=2, T=50, O=111, A=8, hidden=(100, 100), K=2)  # ... zero-padded widths, two inner steps
 
 
 def test_primal_cache_matches_recomputation(lib):
