@@ -76,6 +76,9 @@ typedef struct promp_proc_opts {
 int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims);
 void promp_ctx_destroy(promp_ctx* ctx);
 const char* promp_last_error(void);
+/* 2.  The version moves when an existing entry point changes its meaning or signature; entry points added since (round 3:
+ * promp_set_reuse_adapt, promp_begin_collection / promp_end_collection, promp_state_version, the two pass counters) and the wider
+ * range of hidden sizes are additions a binding built against the first v2 header keeps working with. */
 int promp_abi_version(void);
 /* Theta = O*H1+H1 + H1*H2+H2 + H2*A+A + A */
 int promp_param_count(const promp_dims* dims);
