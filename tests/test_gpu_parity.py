@@ -261,12 +261,17 @@ def test_split_reduce_allreduce_adam_equals_fused_launch(lib):
     # the N>1 kernels (k_reduce_final, ncclAllReduce enqueue, k_mean_adam) on hardware, one-rank communicator
     pc.check_split_path_equals_fused(lib, 71, M=5, P=4, T=90, O=20, A=6, hidden=(64, 64), attach_comm=True)
     pc.check_split_path_equals_fused(lib, 72, M=3, P=3, T=50, O=111, A=8, hidden=(128, 128), epochs=2, attach_comm=False)
+    # zero-padded widths: the reduced buffer crosses the ABI in the caller's layout like every parameter vector
+    pc.check_split_path_equals_fused(lib, 73, M=3, P=3, T=50, O=20, A=6, hidden=(48, 20), epochs=2, attach_comm=True)
 
 
 def test_trpo_maml_step_with_exact_constraint_hvp(lib):
     """the plugin with hvp_approach='exact': with the finite-difference noise gone, the float32 step tracks the float64 oracle"""
     pc.check_trpo(lib, 66, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood', hvp_approach='exact', on_policy=True)
     pc.check_trpo(lib, 67, M=3, P=4, T=60, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio', hvp_approach='exact', on_policy=True)
+    # Ant shapes (cooperative kernels, KL objective in k_wide_hvp) and a zero-padded policy
+    pc.check_trpo(lib, 68, M=3, P=4, T=80, O=111, A=8, hidden=(128, 128), inner_type='log_likelihood', hvp_approach='exact', on_policy=True)
+    pc.check_trpo(lib, 69, M=3, P=4, T=60, O=20, A=6, hidden=(100, 100), inner_type='log_likelihood', hvp_approach='exact', on_policy=True)
 
 
 def test_exact_constraint_hvp_through_the_adaptation(lib):
