@@ -54,6 +54,8 @@ def main():
                          '(M/N tasks, no collective) to study the per-rank step time of strong scaling')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-primal-cache', action='store_true',
+                    help='developer switch: promp_set_primal_cache(1) whatever the size of the shard (default: on from two rounds of tiles per compute unit)')
     ap.add_argument('--no-primal-cache', action='store_true',
                     help='developer switch: the second-order pass recomputes the activations instead of reading the gradient '
                          'pass\'s copies back (promp_set_primal_cache)')
@@ -88,6 +90,8 @@ def main():
         ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
         if args.no_primal_cache:
             ctx.set_primal_cache(False)
+        if args.force_primal_cache:
+            ctx.set_primal_cache(True)
         if args.schedule:
             ctx.set_schedule(*[int(x) for x in args.schedule.split(',')])
         if world > 1:
