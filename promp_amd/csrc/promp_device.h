@@ -193,6 +193,18 @@ PROMP_DEV void pin_a(f32x16& x) { asm volatile("" : "+a"(x)); }
 #define PROMP_SCHED_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, n, 0)
 #define PROMP_SCHED_DSREAD(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
 #define PROMP_SCHED_DSWRITE(n) __builtin_amdgcn_sched_group_barrier(0x200, n, 0)
+// XCD-aware work-item index.  The dispatcher places block b on XCD b % 8 (observed, not a contract: a performance tool only), and
+// every XCD has its own 4 MB L2.  Work tables are ordered by task, so with the identity mapping the workgroups of one task are
+// spread over all eight L2s and each L2 sees every task's parameters.  This bijection hands XCD x the x-th contiguous eighth of
+// the table: the workgroups that share a task's parameters share an L2 (k_wide_hvp re-reads theta and the direction once per
+// 64-row round: 755 MB per launch through the fabric with the identity mapping, measured).
+PROMP_DEV int xcd_item(int b, int G) {
+    const int x = b & 7;
+    int off = 0;
+#pragma unroll
+    for (int y = 0; y < 7; ++y) off += (y < x) ? ((G - y + 7) >> 3) : 0;
+    return off + (b >> 3);
+}
 PROMP_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate: 0..3)
 PROMP_DEV void wave_priority(int p) {

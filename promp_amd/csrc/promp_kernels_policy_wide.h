@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_fwd_bwd(PassArgs a) {
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i16_ = lane & 15, kk_ = lane >> 4;
-    const WorkItem wk = a.work[blockIdx.x];
+    const int wi = xcd_item(blockIdx.x, gridDim.x);       // which work item (and partial row) this workgroup takes
+    const WorkItem wk = a.work[wi];
     const int task = wk.task;
     const int O = a.O, A = a.A;
     const int ob1 = O * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H, ob3 = oW3 + H * A, oS = ob3 + A, NP = oS + A;
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_fwd_bwd(PassArgs a) {
 
     // ---- results: scalars through LDS in wave order, gradient slices straight from their owners ----
     const int i16 = i16_, kk = kk_, col = col_;
-    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    float* P = a.partials + (long long)wi * a.partial_stride;
 #pragma unroll
     for (int m = 4; m <= 32; m <<= 1) {
         gs0 += shfl_xor_f32(gs0, m);  gs1 += shfl_xor_f32(gs1, m);  gb30 += shfl_xor_f32(gb30, m);
@@ -470,7 +471,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
     float* sm = (float*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i16_ = lane & 15, kk_ = lane >> 4;
-    const WorkItem wk = a.work[blockIdx.x];
+    const int wi = xcd_item(blockIdx.x, gridDim.x);       // which work item (and partial row) this workgroup takes
+    const WorkItem wk = a.work[wi];
     const int task = wk.task;
     const int O = a.O, A = a.A;
     const int ob1 = O * H, oW2 = ob1 + H, ob2 = oW2 + H * H, oW3 = ob2 + H, ob3 = oW3 + H * A, oS = ob3 + A, NP = oS + A;
@@ -772,7 +774,7 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
     }
 
     const int i16 = i16_, kk = kk_, col = col_;
-    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    float* P = a.partials + (long long)wi * a.partial_stride;
 #pragma unroll
     for (int m = 4; m <= 32; m <<= 1) {
         outs0 += shfl_xor_f32(outs0, m);  outs1 += shfl_xor_f32(outs1, m);  outb30 += shfl_xor_f32(outb30, m);

@@ -310,6 +310,13 @@ inline void sched_fence() {}
 inline int opaque_zero() { return 0; }
 inline f32x4 pin_agpr(f32x4 v) { return v; }
 inline int wave_uniform(int v) { return v; }
+// the product's XCD-aware work-item bijection (promp_device.h), so that the emulated kernels take the same items
+inline int xcd_item(int b, int G) {
+    const int x = b & 7;
+    int off = 0;
+    for (int y = 0; y < 7; ++y) off += (y < x) ? ((G - y + 7) >> 3) : 0;
+    return off + (b >> 3);
+}
 #define PROMP_SCHED_MFMA(n) ((void)0)
 #define PROMP_SCHED_VALU(n) ((void)0)
 #define PROMP_SCHED_DSREAD(n) ((void)0)
