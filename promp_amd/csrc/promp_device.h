@@ -142,6 +142,18 @@ PROMP_DEV void wave_fence() {
 // Workgroup barrier that orders LDS traffic only: global stores in flight (partial rows on their way to L2) are not
 // waited for, unlike __syncthreads().
 PROMP_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Two-wave rendezvous through a pair of LDS words (gfx950 has no named barriers, and s_barrier is the whole workgroup's).
+// LDS executes one wave's instructions in issue order, so a flag stored after data is seen after the data; the waiting side
+// polls the partner's word (one broadcast read) and sleeps in between.  pair_post also waits for this wave's own LDS reads: the
+// partner may overwrite what they read once it has seen the flag.
+PROMP_DEV void pair_post(float* flags, int mine, int seq, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) ((volatile int*)flags)[mine] = seq;
+}
+PROMP_DEV void pair_wait(float* flags, int other, int seq) {
+    while (__builtin_amdgcn_readfirstlane(((volatile int*)flags)[other]) < seq) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
 // Agent-scope hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility): the producer writes its
 // data, releases (L2 write-back + drain), then bumps a counter with a relaxed agent-scope atomic; the workgroup that
 // reads the final count acquires (L1 invalidate) before it loads the others' data.
@@ -182,6 +194,8 @@ PROMP_DEV f32x4 pin_agpr(f32x4 v) {
 // scheduling barrier).  pin_v: vector register; pin_a: accumulator register (MFMA accumulators that live across iterations).
 PROMP_DEV void pin_v(float& x) { asm volatile("" : "+v"(x)); }
 PROMP_DEV void pin_v(unsigned& x) { asm volatile("" : "+v"(x)); }
+PROMP_DEV void pin_v(int& x) { asm volatile("" : "+v"(x)); }
+PROMP_DEV void pin_s(unsigned& x) { asm volatile("" : "+s"(x)); }
 PROMP_DEV void pin_v(f32x4& x) { asm volatile("" : "+v"(x)); }
 PROMP_DEV void pin_v(u32x4& x) { asm volatile("" : "+v"(x)); }
 PROMP_DEV void pin_a(f32x4& x) { asm volatile("" : "+a"(x)); }

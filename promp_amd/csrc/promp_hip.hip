@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC promp_hip.hip -lrccl -o libpromp_hip.so
 #include "promp_kernels_chain.h"
 #include "promp_kernels_pass.h"
+#include "promp_kernels_pass2.h"
 #include "promp_kernels_policy.h"
 #include "promp_kernels_policy_wide.h"
 #include "promp_kernels_sample.h"
@@ -138,6 +139,7 @@ struct promp_ctx {
     size_t rollout_capacity = 0;
     double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
     size_t smem_fwd = 0, smem_hvp = 0;
+    size_t smem_pair = 0;              // k_pass_pair (the (64, 64) first-order pass at two waves per SIMD); 0: not this shape
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
     unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
     bool dbg_enabled = false;
@@ -374,6 +376,12 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
 #undef PROMP_CHAIN_CASE
         HIPCHECK(hipGetLastError());
         if (a.fuse_reduce) return prof_end(c, id);
+    } else if (c->smem_pair) {
+        // (64, 64): pairs of waves share a tile, two waves per SIMD (promp_kernels_pass2.h); segment table, partial rows and
+        // primal-cache blocks are k_pass's
+        if (fwd_only) { auto k = k_pass_pair<false, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 512, c->smem_pair, c->stream, a); }
+        else if (cache == 1) { auto k = k_pass_pair<true, true>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 512, c->smem_pair, c->stream, a); }
+        else { auto k = k_pass_pair<true, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 512, c->smem_pair, c->stream, a); }
     } else {
         const int n1 = c->d.hidden1 / 16, n2 = c->d.hidden2 / 16;
 #define PROMP_PASS_CASE(N1, N2)                                                                                                          \
@@ -668,6 +676,15 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         c->smem_hvp = sizeof(float) * (size_t)std::max(chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total,
                                                        chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd), true).total);
     }
+#ifndef PROMP_PASS_PAIR
+#define PROMP_PASS_PAIR 1          // developer switch: -DPROMP_PASS_PAIR=0 keeps k_pass for the (64, 64) network as well
+#endif
+    if (PROMP_PASS_PAIR && !c->wide && dims->hidden1 == 64 && dims->hidden2 == 64) {
+        promp_dims pd = *dims;
+        if (pd.obs_dim > 32) pd.obs_dim = 32;
+        c->smem_pair = sizeof(float) * (size_t)pass2_layout(param_count(&pd)).total;
+        if (c->smem_pair > 160 * 1024) c->smem_pair = 0;
+    }
     if (c->smem_hvp > 160 * 1024 || c->smem_fwd > 160 * 1024) {
         const size_t need = c->smem_hvp > c->smem_fwd ? c->smem_hvp : c->smem_fwd;
         promp_ctx_destroy(c);
@@ -692,6 +709,12 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     }
         PROMP_PASS_ALL(PROMP_PASS_ATTR)
 #undef PROMP_PASS_ATTR
+        {
+            auto p0 = k_pass_pair<true, false>; auto p1 = k_pass_pair<false, false>; auto p2 = k_pass_pair<true, true>;
+            HIPCHECK(hipFuncSetAttribute((const void*)p0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)p2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
 #define PROMP_WIDE_ATTR(HH, NOB)                                                                                          \
     {                                                                                                                     \
         auto w0 = k_wide_fwd_bwd<HH, NOB, true>; auto w1 = k_wide_fwd_bwd<HH, NOB, false>; auto w2 = k_wide_hvp<HH, NOB>;   \

@@ -302,6 +302,16 @@ inline bool wave_any(bool p) {
 inline void wave_sync() { emu::wave().bar.arrive_and_wait(); }
 inline void lds_barrier() { emu::tl.blk->bar.arrive_and_wait(); }
 inline void wave_fence() { emu::wave().bar.arrive_and_wait(); }
+// two-wave rendezvous through LDS words (promp_device.h): every lane of the posting wave has done its LDS traffic before lane 0
+// raises the flag; the waiting lanes spin on it
+inline void pair_post(float* flags, int mine, int seq, int lane) {
+    emu::wave().bar.arrive_and_wait();
+    if (lane == 0) __atomic_store_n((int*)flags + mine, seq, __ATOMIC_SEQ_CST);
+}
+inline void pair_wait(float* flags, int other, int seq) {
+    while (__atomic_load_n((int*)flags + other, __ATOMIC_SEQ_CST) < seq) std::this_thread::yield();
+    emu::wave().bar.arrive_and_wait();
+}
 inline void fence_release_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void fence_acquire_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
@@ -323,6 +333,7 @@ inline int xcd_item(int b, int G) {
 #define PROMP_SCHED_DSWRITE(n) ((void)0)
 template <class T> inline void pin_v(T&) {}
 template <class T> inline void pin_a(T&) {}
+template <class T> inline void pin_s(T&) {}
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }

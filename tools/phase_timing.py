@@ -20,7 +20,7 @@ fn = ctx.lib.cdll.promp_debug_phase_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
 names_hvp = ['L1', 'L2', 'L3', 'epi', 'dW3', 'dz2', 'dW2', 'dz1', 'dW1']
-names_pass = ['0:X,L1', '1:tanh,split|dW1', '2:L2', '3:tanh,split', '4:L3,epi', '5:dH2', '6:dz2,split|dW3', '7:dH1', '8:dz1,split|dW2', '9:requests', '-']
+names_pass = ['0:X,L1', '1:tanh,split,L2own..B1', '2:L2oth', '3:tanh,split', '4:L3..B2', '5:epi', '6:dH2,dW3', '7:dz2,dW2,dH1own..B3', '8:dH1oth', '9:dz1,dW1', '-']  # k_pass_pair
 import os
 for hvp in tuple(int(x) for x in os.environ.get('PROMP_STAMP_KERNELS', '0,1').split(',')):
     for rep in range(3):
