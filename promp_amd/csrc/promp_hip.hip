@@ -676,10 +676,15 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         c->smem_hvp = sizeof(float) * (size_t)std::max(chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total,
                                                        chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd), true).total);
     }
+    // k_pass_pair (promp_kernels_pass2.h: the (64, 64) first-order pass at two waves per SIMD) is the MEASURED-SLOWER alternative
+    // (65 vs 62 us per launch); it stays selectable -- environment PROMP_PASS_PAIR=1 when the context is created,
+    // or a -DPROMP_PASS_PAIR=1 build -- and is covered by the parity tests
 #ifndef PROMP_PASS_PAIR
-#define PROMP_PASS_PAIR 1          // developer switch: -DPROMP_PASS_PAIR=0 keeps k_pass for the (64, 64) network as well
+#define PROMP_PASS_PAIR 0
 #endif
-    if (PROMP_PASS_PAIR && !c->wide && dims->hidden1 == 64 && dims->hidden2 == 64) {
+    const char* pair_env = getenv("PROMP_PASS_PAIR");
+    const bool want_pair = pair_env ? atoi(pair_env) != 0 : PROMP_PASS_PAIR != 0;
+    if (want_pair && !c->wide && dims->hidden1 == 64 && dims->hidden2 == 64) {
         promp_dims pd = *dims;
         if (pd.obs_dim > 32) pd.obs_dim = 32;
         c->smem_pair = sizeof(float) * (size_t)pass2_layout(param_count(&pd)).total;

@@ -484,6 +484,9 @@ __global__ void __launch_bounds__(512, 2) k_pass_pair(PassArgs a) {
     W.q0 = W.own0 ? 2 * kk : 0; W.q1 = W.own1 ? 2 * kk + 1 : 0;
     W.s0 = W.s1 = W.e0 = W.e1 = W.sn20 = W.sn21 = W.rden0 = W.rden1 = 0.f;      // (read from the table once per tile)
 
+#ifdef PROMP_PAIR_PRIO
+    if (w >= 4) wave_priority(1);          // developer switch: the later-placed half of the waves loses every issue arbitration otherwise
+#endif
     const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
     CH_WGSTAMP(0);
     for (int sg = sg0; sg < sg1; ++sg) {

@@ -71,6 +71,25 @@ def test_split_gemm_accuracy_guard(lib, hidden, O, A):
     pc.check_split_accuracy(lib, hidden, O, A)
 
 
+@pytest.fixture
+def pair_kernel(monkeypatch):
+    """contexts created inside the test run the (64, 64) first-order pass on k_pass_pair (two waves per SIMD; the measured-slower
+    alternative of k_pass, promp_kernels_pass2.h) -- read from the environment when a context is created"""
+    monkeypatch.setenv('PROMP_PASS_PAIR', '1')
+
+
+def test_pair_kernel_parity(lib, pair_kernel):
+    # objective / KL / gradient of every objective kind (ragged tasks, partial and null tiles, compact log_std), the whole
+    # meta-gradient + Adam epochs, the primal cache it fills for the second-order pass, the 2.5e-6 accuracy guard
+    pc.check_loss_grad(lib, 31, M=5, P=6, T=150, O=20, A=6, hidden=(64, 64), ragged=True)
+    pc.check_loss_grad(lib, 32, M=3, P=4, T=100, O=17, A=6, hidden=(64, 64), compact_log_std=True)
+    pc.check_loss_grad(lib, 33, M=2, P=3, T=90, O=32, A=8, hidden=(64, 64), ragged=True)
+    pc.check_meta(lib, 34, M=6, P=5, T=120, O=20, A=6, hidden=(64, 64), K=1, ragged=True)
+    pc.check_primal_cache(lib, 83, M=7, P=4, T=110, O=20, A=6, hidden=(64, 64), K=1)
+    pc.check_adapt_reuse(lib, 61, M=5, P=3, T=70, O=20, A=6, hidden=(64, 64))
+    pc.check_split_accuracy(lib, (64, 64), 20, 6)
+
+
 def test_unsupported_hidden_widths_are_rejected(lib):
     for hidden, O in (((256, 256), 4), ((64, 129), 4), ((0, 32), 4), ((32, 32, 32), 4)):
         with pytest.raises((_lib.PrompError, ValueError, TypeError)):
