@@ -52,6 +52,10 @@ def main():
     ap.add_argument('--shard-of', type=int, default=0, metavar='N',
                     help='developer option: with --gpus 1, run only the shard rank 0 of an N-GPU job would hold '
                          '(M/N tasks, no collective) to study the per-rank step time of strong scaling')
+    ap.add_argument('--repeats', type=int, default=0,
+                    help='timed loops of exactly --steps steps each; `value` is the MEDIAN loop (default: 5 when one loop is '
+                         'shorter than half a second, else 1)')
+    ap.add_argument('--no-plugin-path', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-primal-cache', action='store_true',
@@ -231,6 +235,17 @@ def main():
         ctx.stage_wait()
     else:
         elapsed, res = run_timed(ctx, iteration, args.warmup, args.steps)
+    # A loop of K steps is tens of milliseconds at config 3: one loop is one sample of the box's clocks.  Every repeat is the
+    # contract's measurement again -- exactly K steps between barrier + device sync, max over ranks -- and `value` is the median
+    # loop (all of them are listed).  The number of repeats is agreed on by the ranks (rank-local clocks differ).
+    loops = [elapsed]
+    n_rep = args.repeats if args.repeats > 0 else (5 if ctx.allreduce_f64([elapsed], op='max')[0] < 0.5 else 1)
+    if not args.staged_only:
+        for _ in range(n_rep - 1):
+            el, r = run_timed(ctx, iteration, 0, args.steps)
+            loops.append(el)
+            res = r if r is not None else res
+        elapsed = float(np.median(loops))
     if not np.isfinite(res['loss_after']):
         raise SystemExit('bench: non-finite loss')
     env_steps = M_global * N * (K + 1) * args.steps
@@ -240,6 +255,7 @@ def main():
         'metric': 'env-steps/sec through GAE+inner+outer update', 'value': value, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'timed_loops_ms_per_step': [1e3 * e / args.steps for e in loops],
         'config': {'workload': 'BASELINE config %d: %d-task %s shapes (obs=%d, act=%d, 2x%d tanh MLP, H=%d, '
                                'P=%d paths/task, K=1 inner step, %s); process_samples x2 + _adapt + '
                                'optimize_policy per step' % (args.config, M_global, ENV_NAMES[args.config], O, A, hidden[0], T, P,
@@ -335,6 +351,32 @@ def main():
                            'end_to_end_tflops_per_gpu': None if trpo else value * ((fl['fwd_bwd'] + E * (2 * fl['fwd'] + 3 * fl['bwd'] + fl['hvp'])
                                                                                            + 2 * fl['fwd'] + fl['bwd']) / 2.0) / 1e12 / world}
 
+    # ---- Stage A alone (the scan / fit / normalise chain against HBM): process_samples on the stream, nothing else ----
+    if not args.no_roofline and rank == 0 and world == 1:
+        n_a = 50
+        ctx.switch_to_pre_update()
+        for _ in range(5):
+            ctx.process_samples(0, **opts)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(n_a):
+            ctx.process_samples(0, **opts)
+        ctx.sync()
+        ms_a = 1e3 * (time.perf_counter() - t0) / n_a
+        bytes_a = (4 * (O + 1) + 8) * M * N
+        out['roofline']['stage_a'] = {'ms': ms_a, 'rows': M * N, 'algorithmic_bytes': bytes_a, 'GB_per_s': bytes_a / (ms_a * 1e-3) / 1e9,
+                                      'peak_GB_per_s': HBM_PEAK_GBS, 'frac': bytes_a / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      'note': 'process_samples of one sampling step, back to back on the stream (returns scan, feature Gram '
+                                              'matrix on FP64 MFMA, Cholesky fit, GAE scan, normalisation): %d B per row of algorithmic '
+                                              'traffic (SURVEY 8d); latency-bound -- five dependent launches over %d rows' % (4 * (O + 1) + 8, M * N)}
+
+    # ---- the same step through the plugin classes (what a user who swaps the imports runs: meta_trainer.py:96-142) ----
+    if rank == 0 and world == 1 and not trpo and not args.no_plugin_path and not args.staged_only:
+        try:
+            out['plugin_path'] = plugin_path(cfg, theta0, E, eta, opts, value, out.get('h2d', {}).get('upload_ms_per_step'))
+        except Exception as e:          # the secondary measurement must never cost the primary line
+            print('bench.py: plugin-path measurement skipped: %r' % (e,), file=sys.stderr)
+
     # ---- CPU baseline: the C + OpenMP restatement ("port") on the host cores, rank 0, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg, theta0, alpha, eta, opts, E, trpo=trpo, steps=3 if args.config != 4 else 1,
@@ -356,6 +398,87 @@ def main():
             print('bench.py: %s-scaling measurement skipped: %r' % (other, e), file=sys.stderr)
     if rank == 0:
         print(json.dumps(out))
+
+
+def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
+    """Trainer.train()'s timed stages through the plugin classes, on the benchmark's own batch:
+        MetaSampleProcessor.process_samples (step 0) -> ProMP._adapt -> process_samples (step 1) -> ProMP.optimize_policy
+    (a) host_paths: the path dicts MetaSampler.obtain_samples returns, in host memory -- every step flattens and uploads them
+        (PCIe, pageable), downloads returns / advantages, builds the per-task dicts;
+    (b) device_resident: the same batch as a device sampler leaves it (DeviceSlabSampler / DevicePointEnvSampler: slabs already
+        in HBM, DevicePaths.device_ref) -- no upload, the downloads and the dicts remain.
+    Both hand the reference's return values to the caller; neither is `value`."""
+    from collections import OrderedDict
+    from promp_amd import session as session_mod
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.meta_algos.pro_mp import ProMP
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.device_point_sampler import DevicePaths
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    from promp_amd.utils import logger as plog
+    plog.configure(quiet=True)
+    M, P, T, O, A, hidden = cfg['M'], cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
+    keep = session_mod.current()
+    policy = MetaGaussianMLPPolicy(name='bench-policy', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden,
+                                   rank=0, world=1, device_id=0)
+    policy.set_params(policy._unflatten(np.asarray(theta0, np.float32)))
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=opts['discount'], gae_lambda=opts['gae_lambda'],
+                               normalize_adv=opts['normalize_adv'])
+    algo = ProMP(policy=policy, inner_lr=0.1, meta_batch_size=M, num_inner_grad_steps=1, learning_rate=1e-3, num_ppo_steps=E,
+                 clip_eps=0.3, target_inner_step=0.01, init_inner_kl_penalty=float(eta[0]), adaptive_inner_kl_penalty=True)
+    rng = np.random.RandomState(4321)
+    p0 = synthetic.make_paths(rng, theta0, M, P, T, O, A, hidden)
+    policy.switch_to_pre_update()
+    sd0 = proc.process_samples(p0, log=False)
+    algo._adapt(sd0)
+    th1 = np.stack([np.concatenate([v.reshape(-1) for v in d.values()]) for d in policy.policies_params_vals]).astype(np.float32)
+    p1 = synthetic.make_paths(rng, th1, M, P, T, O, A, hidden)
+
+    def step(b0, b1):
+        policy.switch_to_pre_update()                          # meta_trainer.py:85
+        s0 = proc.process_samples(b0, log=False)               # :105
+        algo._adapt(s0)                                        # :116
+        s1 = proc.process_samples(b1, log=False)               # :105
+        algo.optimize_policy([s0, s1], log=False)              # :128
+
+    def timed(b0, b1, n):
+        for _ in range(2):
+            step(b0, b1)
+        policy.session.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(b0, b1)
+        policy.session.ctx.sync()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    n = 10
+    ms_host = timed(p0, p1, n)
+    # (b) the batch as a device sampler leaves it: slot k holds step k, the path dicts are views of the downloaded slab
+    sess = policy.session
+    dev = []
+    for slot, paths in ((0, p0), (1, p1)):
+        fl = _lib.flatten_paths(paths)
+        sess.upload_flat(slot, fl)
+        dp = DevicePaths(paths)
+        dp.device_ref = (sess.serial, sess.upload_serial[slot], slot)
+        dp.flat = fl
+        dev.append(dp)
+    ms_dev = timed(dev[0], dev[1], n)
+    env_steps = 2 * M * P * T
+    res = {'steps': n,
+           'host_paths': {'ms_per_step': ms_host, 'value': env_steps / (ms_host * 1e-3),
+                          'pcie_upload_ms_per_step': upload_ms,
+                          'pcie_share': (upload_ms / ms_host) if upload_ms else None,
+                          'note': 'path dicts in host memory: flatten (800 paths x 5 arrays) + promp_upload_step from pageable memory + '
+                                  'downloads + per-task dicts, twice per step'},
+           'device_resident': {'ms_per_step': ms_dev, 'value': env_steps / (ms_dev * 1e-3),
+                               'ratio_to_value': (env_steps / (ms_dev * 1e-3)) / device_value,
+                               'note': 'DevicePaths with a valid device_ref (what DeviceSlabSampler / DevicePointEnvSampler return): '
+                                       'no upload; per step 2 x (returns + raw advantages float64, advantages float32) come back '
+                                       'over PCIe and 2 x %d path dicts receive their views' % (M * P)}}
+    policy.session._drop()
+    session_mod._current = keep
+    return res
 
 
 def measured_traffic(kernel):
@@ -443,6 +566,19 @@ def cpu_baseline(cfg, theta0, alpha, eta, opts, E, trpo=False, steps=3, oracle_t
     out = {'value': M * P * T * 2 * steps / dt, 'unit': 'env-steps/s', 'cores': min(port.threads(), M), 'kind': 'port',
            'sample': 'oracle/promp_cpu.c (C + OpenMP restatement, one thread per task: %d busy threads on %d host cores), the whole '
                      '%d-task batch, %d full steps, %.1f s' % (min(port.threads(), M), os.cpu_count() or 1, M, steps, dt)}
+    if not trpo:
+        # the same port on ONE thread, a sample of the tasks, one full step (BASELINE.md 3.2-3.3 asks for both figures)
+        Ms = max(1, min(4, M))
+        port1 = cpu_port.CpuPort(Ms, P, T, O, A, hidden)
+        port1.set_threads(1)
+        sub = lambda r: {k: (v[:Ms * P * T] if k != 'old_log_std' else v[:Ms]) for k, v in r.items()}
+        r0s, r1s = sub(raw0), sub(raw1)
+        t1 = time.perf_counter()
+        port1.promp_step(np.array(theta0, np.float32), alpha, float(eta[0]), 0.3, 1e-3, E, r0s, r1s, opts)
+        dt1 = time.perf_counter() - t1
+        port1.set_threads(os.cpu_count() or 1)
+        out['single_thread'] = {'value': Ms * P * T * 2 / dt1, 'unit': 'env-steps/s', 'cores': 1,
+                                'sample': 'the same C port on one thread, one full step on %d of the %d tasks, %.1f s' % (Ms, M, dt1)}
     if not trpo and oracle_tasks:
         # the float64 NumPy oracle on a sample of the tasks, one full step
         Ms = min(oracle_tasks, M)

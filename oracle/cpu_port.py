@@ -43,6 +43,9 @@ class CpuPort(object):
     def threads(self):
         return int(self.lib.pc_threads())
 
+    def set_threads(self, n):
+        self.lib.pc_set_threads(int(n))
+
     def process_samples(self, obs, rew, discount=0.99, gae_lambda=1.0, reg=1e-5, normalize_adv=True):
         obs, rew = np.ascontiguousarray(obs, np.float32), np.ascontiguousarray(rew, np.float32)
         adv = np.empty(self.M * self.N, np.float32)

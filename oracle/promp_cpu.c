@@ -32,6 +32,13 @@ enum { PC_RATIO = 0, PC_CLIP = 1, PC_LOGLIK = 2, PC_KL = 3 };
 #define PC_MAXA 8
 #define PC_LOG_2PI 1.8378770664093453f
 
+void pc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
 int pc_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

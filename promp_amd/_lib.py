@@ -176,6 +176,54 @@ def pinned_empty(lib, shape, dtype=np.float32):
     return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape)
 
 
+class _HostPool(object):
+    """Large host arrays for the plugin path's uploads and downloads, recycled once nobody else references them.
+
+    The plugin API hands NumPy arrays to the caller (flattened observations, returns, advantages ...) and the caller may keep
+    them, so a buffer is reused only when its reference count says that no view of it is alive any more.  Fresh allocations
+    of this size (3 - 13 MB) cost more in page faults than the copy they receive; with a library at hand the buffers are
+    page-locked (promp_host_alloc): the copies to and from the device then run at PCIe speed instead of through the
+    runtime's bounce buffers."""
+
+    def __init__(self, keep=8):
+        self._owners, self._keep = {}, keep
+
+    def get(self, shape, dtype, lib=None):
+        import sys
+        shape = tuple(int(x) for x in shape)
+        dt = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape)) * dt.itemsize, 1)
+        key = (nbytes, lib is not None)
+        lst = self._owners.setdefault(key, [])
+        owner = None
+        for cand in lst:
+            if sys.getrefcount(cand) == 3:       # the list, `cand`, getrefcount's argument: no view outside
+                owner = cand
+                break
+        if owner is None:
+            owner = self._new_owner(nbytes, lib)
+            if len(lst) < self._keep:
+                lst.append(owner)
+        return owner[:int(np.prod(shape)) * dt.itemsize].view(dt).reshape(shape)
+
+    @staticmethod
+    def _new_owner(nbytes, lib):
+        if lib is not None:
+            try:
+                import weakref
+                ptr = lib.cdll.promp_host_alloc(C.c_size_t(nbytes))
+                if ptr:
+                    raw = (C.c_char * nbytes).from_address(ptr)
+                    weakref.finalize(raw, lib.cdll.promp_host_free, C.c_void_p(ptr))
+                    return np.frombuffer(raw, dtype=np.uint8, count=nbytes)      # views collapse their .base onto this array
+            except Exception:
+                pass
+        return np.empty(nbytes, np.uint8)
+
+
+host_pool = _HostPool()
+
+
 class Context:
     """One promp_ctx (one GPU).  Thin, NumPy-in / NumPy-out."""
 
@@ -271,11 +319,12 @@ class Context:
         self._call('promp_process_samples', int(step), C.byref(o))
         self._last_kind = int(baseline_kind)
 
-    def download_processed(self, step, baseline_kind=None):
+    def download_processed(self, step, baseline_kind=None, want_returns32=True):
         R, P = self.step_rows[step], self.step_paths[step]
         kind = self._last_kind if baseline_kind is None else baseline_kind
         D = self.lib.cdll.promp_feature_dim(C.byref(self.dims), int(kind))
-        out = dict(returns=np.empty(R, np.float32), advantages=np.empty(R, np.float32),
+        out = dict(returns=host_pool.get((R,), np.float32, self.lib) if want_returns32 else None,
+                   advantages=host_pool.get((R,), np.float32, self.lib),
                    coeffs=np.zeros((self.n_tasks, D), np.float64), path_returns0=np.empty(P, np.float64),
                    path_undiscounted=np.empty(P, np.float64), path_reward_sumsq=np.empty(P, np.float64))
         self._call('promp_download_processed', int(step), _ptr(out['returns'], C.c_float),
@@ -286,7 +335,7 @@ class Context:
 
     def download_raw(self, step):
         R = self.step_rows[step]
-        ret, adv = np.empty(R, np.float64), np.empty(R, np.float64)
+        ret, adv = host_pool.get((R,), np.float64, self.lib), host_pool.get((R,), np.float64, self.lib)
         self._call('promp_download_raw', int(step), _ptr(ret, C.c_double), _ptr(adv, C.c_double))
         return ret, adv
 
@@ -580,27 +629,39 @@ def comm_unique_id(lib=None):
     return bytes(buf.raw)
 
 
-def flatten_paths(paths_meta_batch):
-    """OrderedDict{task -> [path dicts]} (MetaSampler.obtain_samples' return value) -> flat arrays + CSR offsets."""
-    tpo, pro = [0], [0]
-    obs, act, rew, mean, ls = [], [], [], [], []
-    has_policy = True
-    for _, plist in paths_meta_batch.items():
-        for p in plist:
-            n = len(p['rewards'])
-            pro.append(pro[-1] + n)
-            obs.append(np.asarray(p['observations'], dtype=np.float32).reshape(n, -1))
-            r = np.asarray(p['rewards'])
-            rew.append(r.reshape(n) if r.dtype == np.float64 else r.astype(np.float32).reshape(n))
-            if 'actions' in p and 'agent_infos' in p and p['agent_infos'] and 'mean' in p['agent_infos']:
-                act.append(np.asarray(p['actions'], dtype=np.float32).reshape(n, -1))
-                mean.append(np.asarray(p['agent_infos']['mean'], dtype=np.float32).reshape(n, -1))
-                ls.append(np.asarray(p['agent_infos']['log_std'], dtype=np.float32).reshape(n, -1))
-            else:
-                has_policy = False
-        tpo.append(len(pro) - 1)
-    out = dict(task_path_offsets=np.array(tpo, np.int32), path_row_offsets=np.array(pro, np.int32),
-               obs=np.concatenate(obs), rew=np.concatenate(rew), act=None, old_mean=None, old_log_std=None)
-    if has_policy:
-        out.update(act=np.concatenate(act), old_mean=np.concatenate(mean), old_log_std=np.concatenate(ls))
+def flatten_paths(paths_meta_batch, lib=None):
+    """OrderedDict{task -> [path dicts]} (MetaSampler.obtain_samples' return value) -> flat arrays + CSR offsets.
+    One concatenation per field over all paths of all tasks, straight into recycled (page-locked, when `lib` is given) host
+    buffers: no per-path conversions (at 800 paths they cost more than the copy), no page faults of a fresh allocation.
+    Observations / actions / agent_infos as float32 [rows, dim], rewards float64 if the environment's are, else float32."""
+    plists = list(paths_meta_batch.values())
+    flat = [p for plist in plists for p in plist]
+    lens = [len(p['rewards']) for p in flat]
+    pro = np.zeros(len(flat) + 1, np.int32)
+    np.cumsum(lens, out=pro[1:])
+    tpo = np.zeros(len(plists) + 1, np.int32)
+    np.cumsum([len(plist) for plist in plists], out=tpo[1:])
+    rows = int(pro[-1])
+
+    def cat2d(get):
+        parts = [get(p) for p in flat]
+        first = parts[0]
+        if isinstance(first, np.ndarray) and first.ndim == 2:
+            out = host_pool.get((rows, first.shape[1]), np.float32, lib)
+            try:
+                return np.concatenate(parts, out=out, casting='unsafe')
+            except (ValueError, TypeError):
+                pass                                             # ragged trailing shapes / non-array entries: the general way below
+        a = np.concatenate([np.asarray(x).reshape(n, -1) for x, n in zip(parts, lens)])
+        return np.ascontiguousarray(a, dtype=np.float32)
+    rparts = [p['rewards'] for p in flat]
+    if not (isinstance(rparts[0], np.ndarray) and rparts[0].ndim == 1):
+        rparts = [np.asarray(r).reshape(-1) for r in rparts]
+    is64 = any(r.dtype == np.float64 for r in rparts)
+    rew = np.concatenate(rparts, out=host_pool.get((rows,), np.float64 if is64 else np.float32, lib), casting='unsafe')
+    out = dict(task_path_offsets=tpo, path_row_offsets=pro, obs=cat2d(lambda p: p['observations']), rew=rew,
+               act=None, old_mean=None, old_log_std=None)
+    if all('actions' in p and p.get('agent_infos') and 'mean' in p['agent_infos'] for p in flat):
+        out.update(act=cat2d(lambda p: p['actions']), old_mean=cat2d(lambda p: p['agent_infos']['mean']),
+                   old_log_std=cat2d(lambda p: p['agent_infos']['log_std']))
     return out

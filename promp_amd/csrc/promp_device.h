@@ -13,6 +13,7 @@
 #include "hip_emu.h"
 #else
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #define PROMP_DEV __device__ __forceinline__
 #define PROMP_DEV_NOINLINE __device__ __attribute__((noinline))

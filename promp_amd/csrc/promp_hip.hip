@@ -10,10 +10,6 @@
 #include "promp_kernels_rollout.h"
 #include "../../include/promp_hip.h"
 
-#ifndef PROMP_EMU
-#include <rccl/rccl.h>
-#endif
-
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -24,11 +20,7 @@
 #include <string>
 #include <vector>
 
-#ifdef PROMP_EMU
-#define PROMP_ARCH_NAME(prop) "emulator"
-#else
 #define PROMP_ARCH_NAME(prop) (prop).gcnArchName
-#endif
 
 namespace {
 
@@ -144,9 +136,7 @@ struct promp_ctx {
     unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
     bool dbg_enabled = false;
     int* task_counters = nullptr;        // [tasks] arrival counters of the chain kernels' fused reductions (zero between launches)
-#ifndef PROMP_EMU
     ncclComm_t comm = nullptr;
-#endif
     int rank = 0, nranks = 1;
     float min_log_std = -13.815510558f;  // log(1e-6): GaussianMLPPolicy's default min_std
     bool learn_std = true;               // false: log_std is neither adapted (step size 0) nor trained (no Adam update)
@@ -160,6 +150,9 @@ struct promp_ctx {
     // evaluates first (the inner pass at theta on step 0's slab): it leaves theta', the inner scalars and the primal cache
     // where that epoch expects them, and the epoch skips its pass while nothing it depends on has changed (reuse_adapt).
     unsigned long long version_counter = 0, theta_version = 0, sizes_version = 0;
+    unsigned long long cache_counter = 0;   // tags of primal-cache fills: their own counter (whether a rank fills a cache depends on
+                                            // its shard; promp_state_version must move alike on every rank)
+    unsigned long long opt_theta_version = 0;   // theta_version when promp_optimize_begin returned (promp_optimize_end: ls_min)
     struct { bool valid = false; unsigned long long theta_version = 0, data_version = 0, sizes_version = 0; int inner_kind = 0; bool cached = false; float min_log_std = 0.f; bool learn_std = true; } adapt0;
     bool reuse_adapt = true;             // promp_set_reuse_adapt
     bool ls_known = false;               // ls_min is the smallest log_std entry of the current theta
@@ -328,7 +321,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.row_tan = hvp ? c->pass_row_tan : nullptr;
     const int cache = (c->wide || fwd_only || !S.hcache) ? 0 : c->pass_cache;
     a.hcache = cache ? S.hcache : nullptr;
-    if (cache == 1) S.cache_tag = ++c->version_counter;
+    if (cache == 1) S.cache_tag = ++c->cache_counter;
     a.ls_per_row = S.ls_per_row;
     a.task_row_offsets = S.task_row_offsets;
     a.work = S.work[0];
@@ -425,6 +418,11 @@ static bool adapt0_stands(const promp_ctx* c, int inner_kind, bool cached) {
            c->adapt0.learn_std == c->learn_std && c->ls_known && c->ls_min >= c->min_log_std && !c->pass_adv;
 }
 
+// A context that holds a shard of the meta-batch (n_tasks_global > n_tasks) but no communicator: the external-collective mode.
+// Its entry points return this rank's SHARE of a mean (promp_meta_grad: local sums / n_tasks_global, the sums themselves in the
+// exchange buffer); the ones that would go on to USE a mean (an Adam step, a conjugate-gradient product) refuse instead.
+static bool sharded_without_comm(const promp_ctx* c) { return c->d.n_tasks_global > c->d.n_tasks && c->comm == nullptr; }
+
 // One evaluation of the meta-objective (+ gradient, + Adam) enqueued on the stream.
 int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_kind, int outer_kind, bool want_grad,
                  bool do_adam, float lr) {
@@ -503,12 +501,10 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     if (split) {
         PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
         HIPCHECK(hipGetLastError());
-#ifndef PROMP_EMU
         if (c->comm) {
             ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)(NP + K + 2), ncclFloat, ncclSum, c->comm, c->stream);
             if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
         }
-#endif
     }
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
@@ -781,9 +777,7 @@ void promp_ctx_destroy(promp_ctx* c) {
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-#ifndef PROMP_EMU
     if (c->comm) ncclCommDestroy(c->comm);
-#endif
     for (auto* set : {&c->steps, &c->back})
         for (auto& S : *set) {
             free_step(S);
@@ -1708,6 +1702,9 @@ int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_ki
 // product: at the parameters the samples were drawn with (old distribution == adapted policy).  2K + 1 R-operator passes.
 int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refresh_chain, float* out) {
     if (!c || !v || !out) return fail(-1, "NULL argument");
+    if (sharded_without_comm(c))
+        return fail(-3, "this context holds %d of %d tasks and has no communicator: the product would be this rank's share only "
+                        "(promp_comm_init first)", c->d.n_tasks, c->d.n_tasks_global);
     const int K = c->d.num_inner_steps, M = c->d.n_tasks, NP = c->NP;
     const size_t MNP = (size_t)M * NP;
     for (int k = 0; k <= K; ++k) {
@@ -1792,12 +1789,10 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = 1;
     PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
     HIPCHECK(hipGetLastError());
-#ifndef PROMP_EMU
     if (c->comm) {
         ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)NP, ncclFloat, ncclSum, c->comm, c->stream);
         if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
     }
-#endif
     if (params_out(c, out, c->red, 1)) return -2;
     const float inv = 1.0f / (float)c->d.n_tasks_global;
     for (int j = 0; j < c->NPu; ++j) out[j] *= inv;
@@ -1831,6 +1826,10 @@ int promp_optimize_begin(promp_ctx* c, int num_epochs, float lr, float clip_eps,
     if (!c || !eta) return fail(-1, "NULL argument");
     if (num_epochs < 0) return fail(-1, "num_epochs must be >= 0");
     if (c->opt_pending) return fail(-1, "promp_optimize_begin: the previous optimisation has not been collected (promp_optimize_end)");
+    if (sharded_without_comm(c))
+        return fail(-3, "this context holds %d of %d tasks and has no communicator: promp_optimize would apply this rank's sums as if they "
+                        "were the meta-batch's.  Attach one (promp_comm_init), or run the exchange yourself: promp_meta_grad -> "
+                        "promp_reduced_get -> all-reduce -> promp_reduced_set -> promp_adam_step", c->d.n_tasks, c->d.n_tasks_global);
     if (upload_eta(c, eta)) return -2;
     const int K = c->d.num_inner_steps;
     for (int e = 0; e < num_epochs; ++e) {
@@ -1852,6 +1851,7 @@ int promp_optimize_begin(promp_ctx* c, int num_epochs, float lr, float clip_eps,
     (void)K;
     c->opt_pending = true;
     c->opt_epochs = num_epochs;
+    c->opt_theta_version = c->theta_version;
     return 0;
 }
 
@@ -1872,8 +1872,12 @@ int promp_optimize_end(promp_ctx* c, float* loss_before, float* stats_after) {
         }
     }
     const int K = c->d.num_inner_steps;
-    c->ls_min = c->stats_host[2 * (K + 2)];       // theta has not changed since the publishing launch read it
-    c->ls_known = true;
+    // the smallest log_std entry the publishing launch saw: current only if nothing replaced theta between begin and end
+    // (promp_set_theta / promp_adam_step in the window leave it unknown, as they do anywhere else)
+    if (c->theta_version == c->opt_theta_version) {
+        c->ls_min = c->stats_host[2 * (K + 2)];
+        c->ls_known = true;
+    }
     if (stats_after) memcpy(stats_after, c->stats_host, sizeof(float) * (K + 2));
     if (loss_before) *loss_before = c->opt_epochs > 0 ? c->stats_host[K + 2] : c->stats_host[0];
     return 0;
@@ -1921,7 +1925,6 @@ int promp_eval_hvp(promp_ctx* c, int step, int inner_kind, int clip_ls, float kl
 }
 
 int promp_comm_unique_id(void* id_out, size_t id_bytes) {
-#ifndef PROMP_EMU
     if (!id_out || id_bytes < sizeof(ncclUniqueId)) return fail(-1, "id buffer must hold %zu bytes", sizeof(ncclUniqueId));
     ncclUniqueId id;
     ncclResult_t r = ncclGetUniqueId(&id);
@@ -1929,16 +1932,11 @@ int promp_comm_unique_id(void* id_out, size_t id_bytes) {
     memset(id_out, 0, id_bytes);
     memcpy(id_out, &id, sizeof id);
     return 0;
-#else
-    (void)id_out; (void)id_bytes;
-    return fail(-4, "no communicator in the kernel-emulation build");
-#endif
 }
 
 int promp_comm_init(promp_ctx* c, int rank, int nranks, const void* id, size_t id_bytes) {
     if (!c) return fail(-1, "ctx is NULL");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "bad rank %d / nranks %d", rank, nranks);
-#ifndef PROMP_EMU
     if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(-1, "id buffer must hold %zu bytes", sizeof(ncclUniqueId));
     HIPCHECK(hipSetDevice(c->device));
     ncclUniqueId uid;
@@ -1948,11 +1946,6 @@ int promp_comm_init(promp_ctx* c, int rank, int nranks, const void* id, size_t i
     c->rank = rank;
     c->nranks = nranks;
     return 0;
-#else
-    (void)id; (void)id_bytes;
-    if (nranks != 1) return fail(-4, "no communicator in the kernel-emulation build");
-    return 0;
-#endif
 }
 
 int promp_comm_split_path(promp_ctx* c, int on) {
@@ -1964,13 +1957,11 @@ int promp_comm_split_path(promp_ctx* c, int on) {
 int promp_comm_move(promp_ctx* dst, promp_ctx* src) {
     if (!dst || !src) return fail(-1, "ctx is NULL");
     if (dst == src) return 0;
-#ifndef PROMP_EMU
     if (dst->comm) return fail(-3, "destination context already holds a communicator");
     if (dst->device != src->device) return fail(-1, "contexts live on different devices (%d, %d)", dst->device, src->device);
     HIPCHECK(hipStreamSynchronize(src->stream));    // nothing of the old context may still be using it
     dst->comm = src->comm;
     src->comm = nullptr;
-#endif
     dst->rank = src->rank; dst->nranks = src->nranks;
     src->rank = 0; src->nranks = 1;
     return 0;
@@ -1992,13 +1983,11 @@ int promp_allreduce_f64(promp_ctx* c, double* buf, int n, int op) {
     if (!c || !buf) return fail(-1, "NULL argument");
     if (n < 1 || n > 64) return fail(-1, "n must be in [1,64]");
     if (c->nranks == 1) return 0;
-#ifndef PROMP_EMU
     HIPCHECK(hipMemcpyAsync(c->red64, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     ncclResult_t r = ncclAllReduce(c->red64, c->red64, (size_t)n, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream);
     if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
     HIPCHECK(hipMemcpyAsync(buf, c->red64, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-#endif
     return 0;
 }
 

@@ -85,7 +85,7 @@ class DICEMAML(MAMLAlgo):
         self._place_dice_steps(all_samples_data)
         ctx = self.session.ctx
         if log: logger.log('Optimizing')
-        ctx.optimize(1, self.learning_rate, 0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
+        self.session.optimize(1, self.learning_rate, 0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
         if log: logger.log('Computing statistics')
         # magic_box == 1 in value: the objective is minus the mean adjusted reward of the last step's valid entries
         # (mean over ALL tasks: a task-sharded run sums the ranks' per-task means; the gradient's all-reduce is inside optimize)

@@ -37,7 +37,7 @@ class ProMP(MAMLAlgo):
         assert len(all_samples_data) == self.num_inner_grad_steps + 1
         self._place_steps(all_samples_data)           # sampling step k must sit in slot k
         if log: logger.log('Optimizing')
-        res = self.session.ctx.optimize(self.num_ppo_steps, self.learning_rate, self.clip_eps, self.inner_kl_coeff,
+        res = self.session.optimize(self.num_ppo_steps, self.learning_rate, self.clip_eps, self.inner_kl_coeff,
                                         self.inner_kind, self.outer_kind)
         if log: logger.log('Computing statistics')
         loss_before, loss_after, inner_kls = res['loss_before'], res['loss_after'], res['inner_kl']

@@ -22,6 +22,12 @@ class _DeviceEvaluator(object):
     def _eta(self):
         return np.zeros(self.algo.num_inner_grad_steps, np.float32)
 
+    def _whole_batch(self, g):
+        """a gradient promp_meta_grad returned: the meta-batch's mean -- or, on ranks that exchange through the session's
+        `collective` (no communicator in the context), this rank's share of it, summed here"""
+        sess = self.algo.session
+        return np.asarray(sess.collective(np.asarray(g, dtype=np.float64), 'sum'), dtype=np.float32) if sess.external() else g
+
     def _exploration(self, want_grad):
         """E-MAML term (trpo_maml.py:137-144): mean_i [ -mean(adj_avg_rewards_i) * mean_n log pi_theta(a0_n | s0_n) ], the
         log-likelihood of the INITIAL (step-0) actions under the pre-update parameters.  On the device that is the
@@ -47,7 +53,7 @@ class _DeviceEvaluator(object):
         ctx = self.ctx
         key = (id(ctx), ctx.state_version(), self.algo.inner_kind)
         if self._memo is None or self._memo[0] != key:
-            r = ctx.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)
+            r = self.algo.session.meta_eval(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)
             self._memo = ((id(ctx), ctx.state_version(), self.algo.inner_kind), r)
         return self._memo[1]
 
@@ -59,11 +65,11 @@ class _DeviceEvaluator(object):
         return self._objectives()['outer_kl']
 
     def gradient(self):
-        g = self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0]
+        g = self._whole_batch(self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0])
         return (g + self._exploration(True)[1]).astype(np.float32) if self.algo.exploration else g
 
     def constraint_gradient(self):
-        return self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_KL)[0]
+        return self._whole_batch(self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_KL)[0])
 
     def constraint_hvp(self, x, refresh_chain=True):   # exact (d2 constraint / d theta2) x on the device
         return self.ctx.constraint_hvp(np.asarray(x, dtype=np.float32), self.algo.inner_kind, refresh_chain)

@@ -42,7 +42,11 @@ class VPG_DICEMAML(DICEMAML):
             adv.append(np.concatenate([a[p, :n[p]] for p in range(len(n))]) * (n.sum() / float(m.size)))
         ctx.set_advantages(K, np.concatenate(adv).astype(np.float32))
         if log: logger.log('Optimizing')
-        res = ctx.optimize(1, self.learning_rate, 0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
+        res = self.session.optimize(1, self.learning_rate, 0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
+        # slot K's weights are the GAE advantages now, not the DiCE suffix sums promp_set_dice_rewards wrote: the samples are no
+        # longer "resident" as DiCE data (a later DiCE use of the same samples re-uploads instead of differentiating the wrong
+        # objective)
+        self.session.upload_serial[K] = -1
         if log: logger.log('Computing statistics')
         if log:
             logger.logkv('LossBefore', res['loss_before'])

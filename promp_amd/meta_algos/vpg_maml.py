@@ -48,7 +48,7 @@ class VPGMAML(MAMLAlgo):
         eta = np.zeros(K, np.float32)
         if log: logger.log('Optimizing')
         if not self.exploration:
-            res = ctx.optimize(1, self.learning_rate, 0.0, eta, self.inner_kind, _lib.OUTER_LOGLIK)
+            res = sess.optimize(1, self.learning_rate, 0.0, eta, self.inner_kind, _lib.OUTER_LOGLIK)
             loss_before, loss_after = res['loss_before'], res['loss_after']
         else:
             coeffs = np.array([np.mean(np.asarray(d['adj_avg_rewards'], dtype=np.float32)) for d in all_samples_data[K]], np.float64)
@@ -68,7 +68,7 @@ class VPGMAML(MAMLAlgo):
             ctx.reduced_set(red)
             ctx.adam_step(self.learning_rate)
             if log: logger.log('Computing statistics')
-            loss_after = ctx.meta_eval(0.0, eta, self.inner_kind, _lib.OUTER_LOGLIK)['loss'] + total(False)[0]
+            loss_after = sess.meta_eval(0.0, eta, self.inner_kind, _lib.OUTER_LOGLIK)['loss'] + total(False)[0]
         if log:
             logger.logkv('LossBefore', loss_before)
             logger.logkv('LossAfter', loss_after)

@@ -20,6 +20,18 @@ def _concat_tensor_dict_list(dict_list):
     return out
 
 
+def _shared_storage(fl, first):
+    """True when per-task slices of the flat arrays `fl` equal what concatenating the path dicts' arrays would give, dtype and
+    shape included (flatten_paths casts to float32 and reshapes to [n, dim]; anything it changed is concatenated the old way)"""
+    if fl.get('obs') is None or fl.get('act') is None or fl.get('old_mean') is None or fl.get('rew') is None:
+        return False
+    if 'agent_infos' not in first or not first['agent_infos'] or 'mean' not in first['agent_infos']:
+        return False
+    same = lambda a, ref: isinstance(a, np.ndarray) and a.dtype == ref.dtype and a.ndim == ref.ndim and a.shape[1:] == ref.shape[1:]
+    return same(first['observations'], fl['obs']) and same(first['actions'], fl['act']) and same(first['rewards'], fl['rew']) \
+        and same(first['agent_infos']['mean'], fl['old_mean']) and same(first['agent_infos']['log_std'], fl['old_mean'])
+
+
 class SampleProcessor(object):
     """
     - fits a reward baseline, - performs GAE, - stacks the path data, - logs path statistics
@@ -56,7 +68,13 @@ class SampleProcessor(object):
         return session_mod.current() or self._private_session or _OneRank
 
     def _process_on_device(self, paths_meta_batch):
-        """-> (list[M] of SamplesData, per-path float64 stats) ; mutates the path dicts like the reference."""
+        """-> (list[M] of SamplesData, per-path float64 stats) ; mutates the path dicts like the reference.
+
+        Host work is kept off the per-path / per-task level where the API allows it: the flat arrays that went to the device
+        (or came from it) are the storage of every task's observations / actions / rewards / agent_infos -- the per-task
+        entries are VIEWS of them, not fresh concatenations (the reference concatenates, samplers/base.py:165-173; the values
+        are the same) -- and the per-path 'returns' / 'advantages' the reference leaves in the path dicts (base.py:104,159) are
+        views of the two downloaded float64 arrays."""
         M = len(paths_meta_batch)
         sess, ref = session_mod.current(), getattr(paths_meta_batch, 'device_ref', None)
         if ref is not None and sess is not None and sess.ctx is not None and ref[0] == sess.serial \
@@ -64,7 +82,7 @@ class SampleProcessor(object):
             # a device rollout (samplers/device_point_sampler.py): the slab is already resident, nothing to upload
             fl, upload, slot = paths_meta_batch.flat, ref[1], ref[2]
         else:
-            fl = _lib.flatten_paths(paths_meta_batch)
+            fl = _lib.flatten_paths(paths_meta_batch, _lib.get_library())
             O = fl['obs'].shape[1]
             first = next(iter(paths_meta_batch.values()))[0]
             A = int(np.asarray(first['actions']).reshape(len(first['rewards']), -1).shape[1]) if 'actions' in first else 1
@@ -76,26 +94,44 @@ class SampleProcessor(object):
         ctx.process_samples(slot, discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=self.normalize_adv,
                             positive_adv=self.positive_adv, baseline_kind=kind,
                             reg_coeff=getattr(self.baseline, '_reg_coeff', 1e-5))
-        out = ctx.download_processed(slot, kind)
+        out = ctx.download_processed(slot, kind, want_returns32=False)     # (the float64 returns below are what the API hands out)
         ret64, raw_adv64 = ctx.download_raw(slot)
         if kind != _lib.BASELINE_ZERO:
             self.baseline._coeffs = out['coeffs'][-1].copy()      # the shared baseline ends on the last task's fit
         pro, tpo = fl['path_row_offsets'], fl['task_path_offsets']
+        # side effect of samplers/base.py:104,159: two views and two dict stores per path (plain slices on Python ints: np.split
+        # costs ten times as much per piece)
+        flat_paths = [p for plist in paths_meta_batch.values() for p in plist]
+        ends = pro.tolist()
+        a = ends[0]
+        for p, b in zip(flat_paths, ends[1:]):
+            p['returns'] = ret64[a:b]
+            p['advantages'] = raw_adv64[a:b]
+            a = b
+        first = flat_paths[0]
+        shared = _shared_storage(fl, first)       # the flat arrays hold exactly what the path dicts hold (dtype and all)
+        row0 = pro[tpo].tolist()
         result = []
-        for i, (_, plist) in enumerate(paths_meta_batch.items()):
-            r0, r1 = pro[tpo[i]], pro[tpo[i + 1]]
-            for j, p in enumerate(plist):                        # side effect of samplers/base.py:104,159
-                a, b = pro[tpo[i] + j], pro[tpo[i] + j + 1]
-                p['returns'] = ret64[a:b]
-                p['advantages'] = raw_adv64[a:b]
+        for i, plist in enumerate(paths_meta_batch.values()):
+            r0, r1 = row0[i], row0[i + 1]
+            if shared:
+                ls = fl['old_log_std']
+                infos = dict(mean=fl['old_mean'][r0:r1],
+                             log_std=ls[r0:r1] if len(ls) == len(fl['obs']) else np.broadcast_to(ls[i], (r1 - r0, ls.shape[1])))
+                extra = [k for k in first['agent_infos'] if k not in ('mean', 'log_std')]
+                if extra:
+                    more = _concat_tensor_dict_list([{k: p['agent_infos'][k] for k in extra} for p in plist])
+                    infos.update(more)
+                obs, act, rew = fl['obs'][r0:r1], fl['act'][r0:r1], fl['rew'][r0:r1]
+            else:
+                obs = np.concatenate([p['observations'] for p in plist])
+                act = np.concatenate([p['actions'] for p in plist])
+                rew = np.concatenate([p['rewards'] for p in plist])
+                infos = _concat_tensor_dict_list([p.get('agent_infos', {}) for p in plist])
             sd = session_mod.SamplesData(
-                observations=np.concatenate([p['observations'] for p in plist]),
-                actions=np.concatenate([p['actions'] for p in plist]),
-                rewards=np.concatenate([p['rewards'] for p in plist]),
-                returns=ret64[r0:r1],
-                advantages=out['advantages'][r0:r1],
-                env_infos=_concat_tensor_dict_list([p.get('env_infos', {}) for p in plist]),
-                agent_infos=_concat_tensor_dict_list([p.get('agent_infos', {}) for p in plist]),
+                observations=obs, actions=act, rewards=rew, returns=ret64[r0:r1], advantages=out['advantages'][r0:r1],
+                env_infos=_concat_tensor_dict_list([p.get('env_infos', {}) for p in plist]) if first.get('env_infos') else {},
+                agent_infos=infos,
             )
             sd.device_ref = (sess.serial, upload, slot, i)
             result.append(sd)

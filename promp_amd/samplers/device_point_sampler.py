@@ -91,7 +91,8 @@ class DevicePointEnvSampler(object):
                                      agent_infos=dict(mean=slab['old_mean'][rows], log_std=log_std)))
         paths.device_ref = (sess.serial, sess.upload_serial[slot], slot)
         paths.flat = dict(task_path_offsets=np.arange(M + 1, dtype=np.int32) * B,
-                          path_row_offsets=np.arange(M * B + 1, dtype=np.int32) * T)
+                          path_row_offsets=np.arange(M * B + 1, dtype=np.int32) * T,
+                          obs=slab['obs'], act=slab['act'], rew=slab['rew'], old_mean=slab['old_mean'], old_log_std=slab['old_log_std'])
         self.total_timesteps_sampled += M * B * T
         if log:
             logger.logkv(log_prefix + 'PolicyExecTime', 0.0)

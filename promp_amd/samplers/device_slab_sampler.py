@@ -74,6 +74,14 @@ class DeviceSlabSampler(MetaSampler):
                 collected += n
                 started_at[env] = s + 1
             s += 1
+        empty = [i for i, tp in enumerate(done_paths) if not tp]
+        if empty:
+            # (the reference's sampler would hand such a task an empty path list and fail later, in the sample processor;
+            #  typical cause: envs_per_task above rollouts_per_meta_task, so total_samples is reached before every task's
+            #  environments have finished an episode)
+            raise RuntimeError('DeviceSlabSampler: no finished episode for task(s) %s within total_samples = %d '
+                               '(envs_per_task = %d, rollouts_per_meta_task = %d, max_path_length = %d)'
+                               % (empty, self.total_samples, B, self.batch_size, T))
         flat = [p for task_paths in done_paths for p in task_paths]
         tpo = np.concatenate([[0], np.cumsum([len(tp) for tp in done_paths])]).astype(np.int32)
         env_of = np.array([p[0] for p in flat], dtype=np.int32)
@@ -94,7 +102,10 @@ class DeviceSlabSampler(MetaSampler):
                                      env_infos=flat[p][3],
                                      agent_infos=dict(mean=slab['old_mean'][rows], log_std=np.tile(slab['old_log_std'][i], (len_of[p], 1)))))
         paths.device_ref = (sess.serial, sess.upload_serial[slot], slot)
-        paths.flat = dict(task_path_offsets=tpo, path_row_offsets=pro, path_env=env_of, path_start=start_of)
+        # (the downloaded slab arrays ride along: the sample processor hands out per-task views of them instead of concatenating
+        #  the path dicts' slices again)
+        paths.flat = dict(task_path_offsets=tpo, path_row_offsets=pro, path_env=env_of, path_start=start_of,
+                          obs=slab['obs'], act=slab['act'], rew=slab['rew'], old_mean=slab['old_mean'], old_log_std=slab['old_log_std'])
         self.total_timesteps_sampled += self.total_samples
         if log:
             logger.logkv(log_prefix + 'PolicyExecTime', policy_seconds)

@@ -66,6 +66,44 @@ class DeviceSession:
         out = np.concatenate([ctx.allreduce_f64(flat[i:i + 64], op) for i in range(0, flat.size, 64)]) if flat.size else flat
         return out.reshape(values.shape)
 
+    def external(self):
+        """True when the meta-batch is sharded over ranks that exchange through `collective` (the context then holds no
+        communicator and refuses promp_optimize / promp_constraint_hvp: its sums are one rank's)"""
+        return self.world > 1 and self.collective is not None
+
+    def _meta_eval_shares(self, ctx, clip_eps, eta, inner_kind, outer_kind):
+        """one evaluation whose per-rank shares have been summed: (grad mean buffer applied?, stats dict)"""
+        _, st = ctx.meta_grad(clip_eps, eta, inner_kind, outer_kind)       # local SUMS stay in the exchange buffer
+        red = ctx.reduced_get()
+        red = np.asarray(self.collective(red.astype(np.float64), 'sum'), dtype=np.float32)
+        ctx.reduced_set(red)                                                # every rank now holds the meta-batch's sums
+        K, n = self.K, float(self.M_global)
+        eta = np.asarray(eta, dtype=np.float64)
+        J, kls, okl = red[-(K + 2)] / n, red[-(K + 1):-1].astype(np.float64) / n, red[-1] / n
+        return dict(loss=float(J + np.mean(eta * kls)), inner_kl=kls.astype(np.float32), outer_kl=float(okl))
+
+    def optimize(self, num_epochs, lr, clip_eps, inner_kl_coeff, inner_kind=_lib.INNER_RATIO, outer_kind=_lib.OUTER_CLIP):
+        """ProMP.optimize_policy's numerical core on this session: promp_optimize, or -- ranks that exchange through
+        `collective` -- the same epochs with the [Theta + K + 2] buffer crossing the ranks on the host
+        (promp_meta_grad -> promp_reduced_get -> collective -> promp_reduced_set -> promp_adam_step)."""
+        ctx = self.ensure()
+        if not self.external():
+            return ctx.optimize(num_epochs, lr, clip_eps, inner_kl_coeff, inner_kind, outer_kind)
+        eta = np.asarray(inner_kl_coeff, dtype=np.float32)
+        loss_before = None
+        for _ in range(int(num_epochs)):
+            st = self._meta_eval_shares(ctx, clip_eps, eta, inner_kind, outer_kind)
+            if loss_before is None:
+                loss_before = st['loss']
+            ctx.adam_step(lr)
+        st = self._meta_eval_shares(ctx, clip_eps, eta, inner_kind, outer_kind)        # compute_stats
+        return dict(loss_before=st['loss'] if loss_before is None else loss_before, loss_after=st['loss'],
+                    inner_kl=st['inner_kl'], outer_kl=st['outer_kl'])
+
+    def meta_eval(self, clip_eps, inner_kl_coeff, inner_kind=_lib.INNER_RATIO, outer_kind=_lib.OUTER_CLIP):
+        r = self.optimize(0, 0.0, clip_eps, inner_kl_coeff, inner_kind, outer_kind)
+        return dict(loss=r['loss_after'], inner_kl=r['inner_kl'], outer_kl=r['outer_kl'])
+
     def set_num_inner_steps(self, K):
         if K != self.K:
             self.K = int(K)

@@ -354,11 +354,12 @@ struct EmuEvent { std::chrono::steady_clock::time_point t; };
 typedef EmuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-struct hipDeviceProp_t { char name[256]; int multiProcessorCount; int clockRate; };
+struct hipDeviceProp_t { char name[256]; char gcnArchName[64]; int multiProcessorCount; int clockRate; };
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     snprintf(p->name, sizeof p->name, "kernel-emulator (tests only)");
+    snprintf(p->gcnArchName, sizeof p->gcnArchName, "emulator");
     const char* e = getenv("PROMP_EMU_CUS");
     p->multiProcessorCount = e ? atoi(e) : 4;
     p->clockRate = 1000;
@@ -390,4 +391,28 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return 0;
+}
+
+// ---- RCCL shim ------------------------------------------------------------------------------------
+// The host code calls RCCL unconditionally (same sequence as the product); here a communicator exists for ONE rank only
+// (all-reduce = identity), anything wider fails like an RCCL error would.  Multi-rank tests of the emulated library exchange the
+// reduction buffer themselves (promp_reduced_get / _set over gloo).
+typedef struct EmuComm* ncclComm_t;
+struct EmuComm { int nranks; };
+struct ncclUniqueId { char internal[128]; };
+typedef int ncclResult_t;
+enum { ncclSuccess = 0, ncclInvalidUsage = 5 };
+enum ncclDataType_t { ncclFloat, ncclDouble };
+enum ncclRedOp_t { ncclSum, ncclMax };
+inline const char* ncclGetErrorString(ncclResult_t) { return "no multi-rank communicator in the kernel-emulation build"; }
+inline ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { memset(id, 0, sizeof *id); return ncclSuccess; }
+inline ncclResult_t ncclCommInitRank(ncclComm_t* c, int nranks, ncclUniqueId, int) {
+    if (nranks != 1) return ncclInvalidUsage;
+    *c = new EmuComm{1};
+    return ncclSuccess;
+}
+inline ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
+inline ncclResult_t ncclAllReduce(const void* in, void* out, size_t n, ncclDataType_t t, ncclRedOp_t, ncclComm_t, hipStream_t) {
+    if (in != out) memcpy(out, in, n * (t == ncclDouble ? 8 : 4));
+    return ncclSuccess;
 }

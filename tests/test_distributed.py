@@ -264,3 +264,101 @@ def test_two_rank_sample_statistics_span_the_whole_meta_batch(tmp_path):
         np.testing.assert_allclose(dstats['D-AverageReturn'], und.mean(), rtol=1e-6)      # (path sums of float32 rewards, as the reference's)
         np.testing.assert_allclose(dstats['D-AverageDiscountedReturn'], disc.mean(), rtol=1e-6)
         assert dstats['D-NumTrajs'] == len(und)
+
+
+OPT_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+from promp_amd import _lib, synthetic
+from tests import devlib
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+os.environ['PROMP_EMU_CUS'] = '2'
+_lib.set_library_for_testing(devlib.emu_library())
+from tests.test_distributed import run_promp_iteration
+
+def gloo(values, op):                                          # stands in for the RCCL all-reduce (no GPUs here)
+    t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
+    return t.numpy()
+
+M = 4
+mine = [i for i in range(M) if i %% world == rank]
+theta, stats = run_promp_iteration(mine, M, rank, world, gloo)
+ths = [torch.zeros(theta.size) for _ in range(world)]
+dist.all_gather(ths, torch.from_numpy(theta))
+assert all(torch.equal(ths[0], t) for t in ths), 'replicated parameters diverged'
+np.savez(os.environ['OUT'] + '.%%d.npz' %% rank, theta=theta, loss_before=stats['loss_before'], loss_after=stats['loss_after'],
+         inner_kl=stats['inner_kl'])
+dist.destroy_process_group()
+'''
+
+
+def run_promp_iteration(task_ids, M_global, rank, world, collective, epochs=2):
+    """one ProMP iteration through the plugin classes (process_samples x2, _adapt, optimize_policy) on the tasks `task_ids`
+    of an M_global-task meta-batch; every task's paths come from its own seed, so a shard is exactly its part of the batch"""
+    from promp_amd import synthetic
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.meta_algos.pro_mp import ProMP
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    O, A, hidden, P, T = 5, 3, (32, 32), 2, 24
+    np.random.seed(11)                                   # identical initial parameters on every rank
+    policy = MetaGaussianMLPPolicy(name='meta-policy', obs_dim=O, action_dim=A, meta_batch_size=len(task_ids), hidden_sizes=hidden,
+                                   n_tasks_global=M_global, rank=rank, world=world, device_id=0)
+    policy.session.collective = collective
+    proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
+    algo = ProMP(policy=policy, inner_lr=0.1, meta_batch_size=len(task_ids), num_inner_grad_steps=1, learning_rate=1e-3,
+                 num_ppo_steps=epochs, clip_eps=0.3, target_inner_step=0.01, init_inner_kl_penalty=5e-4, adaptive_inner_kl_penalty=False)
+    policy.switch_to_pre_update()
+    samples = []
+    for step in range(2):
+        th = np.stack([np.concatenate([v.reshape(-1) for v in d.values()]) for d in policy.policies_params_vals])
+        paths = synthetic.make_paths_for_tasks(900 + step, task_ids, th, P, T, O, A, hidden)
+        samples.append(proc.process_samples(paths, log=False))
+        if step == 0:
+            algo._adapt(samples[0])
+    algo.optimize_policy(samples, log=False)
+    theta = np.concatenate([v.reshape(-1) for v in policy.get_param_values().values()]).astype(np.float32)
+    return theta, algo.last_stats
+
+
+def test_two_rank_promp_optimize_policy_through_the_collective_hook(tmp_path, monkeypatch):
+    """ProMP.optimize_policy end to end on two gloo ranks whose session exchanges through `collective` (no communicator in
+    the contexts): the Adam epochs must use the WHOLE meta-batch's gradient -- equal to the one-process run over all four
+    tasks, identical on both ranks.  (Before the fix the ranks applied their local sums and drifted apart silently; the
+    library now also refuses promp_optimize on a sharded context without a communicator.)"""
+    from promp_amd import _lib
+    from tests import devlib
+    out = str(tmp_path / 'opt')
+    script = tmp_path / 'worker.py'
+    script.write_text(OPT_WORKER % dict(root=ROOT))
+    devlib.emu_library()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29671', str(script)]
+    subprocess.run(cmd, check=True, env=dict(os.environ, OUT=out, MASTER_ADDR='127.0.0.1'), timeout=900, cwd=ROOT)
+    monkeypatch.setenv('PROMP_EMU_CUS', '2')
+    _lib.set_library_for_testing(devlib.emu_library())
+    try:
+        ref_theta, ref_stats = run_promp_iteration([0, 1, 2, 3], 4, 0, 1, None)
+        # a sharded context without a communicator refuses the calls that would use a mean it does not have
+        ctx = _lib.Context(2, 5, 3, (32, 32), 1, max_rows=64, max_paths=4, lib=devlib.emu_library(), n_tasks_global=4)
+        for call in (lambda: ctx.optimize(1, 1e-3, 0.3, np.array([5e-4], np.float32)),
+                     lambda: ctx.constraint_hvp(np.zeros(ctx.n_params, np.float32))):
+            try:
+                call()
+                raise AssertionError('a sharded context without a communicator must refuse')
+            except _lib.PrompError as e:
+                assert 'no communicator' in str(e)
+        ctx.close()
+    finally:
+        _lib.set_library_for_testing(None)
+    r0, r1 = np.load(out + '.0.npz'), np.load(out + '.1.npz')
+    assert np.array_equal(r0['theta'], r1['theta'])
+    # float32 sums in another task order (rank-major): Adam steps are ~lr per element
+    assert np.max(np.abs(r0['theta'] - ref_theta)) < 2e-5 and np.mean(np.abs(r0['theta'] - ref_theta)) < 2e-6
+    np.testing.assert_allclose(r0['loss_before'], ref_stats['loss_before'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r0['loss_after'], ref_stats['loss_after'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r0['inner_kl'], ref_stats['inner_kl'], rtol=1e-3, atol=1e-7)
