@@ -249,6 +249,47 @@ def gen_promp():
         print('wrote promp_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
 
 
+# ---- E Adam epochs on the autograd gradient (tf.train.AdamOptimizer's update, transcribed) -------------------------------
+# optimizers/maml_first_order_optimizer.py:22-46,82-115: AdamOptimizer(lr).minimize(loss); E full-batch steps.  TF-1's update
+# (python/training/adam.py, _apply_dense): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); m += (1 - b1)(g - m); v += (1 - b2)(g^2 - v);
+# theta -= lr_t m / (sqrt(v) + eps) -- eps OUTSIDE the root, no separate bias-corrected m-hat / v-hat.
+ADAM_CASES = {
+    # BASELINE config 3's and config 4's network shapes, small batches (the gradient comes from torch.autograd each epoch)
+    'hc':  dict(seed=111, M=3, P=2, T=40, O=20, A=6, hidden=(64, 64), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1, lr=1e-3, epochs=5),
+    'ant': dict(seed=112, M=2, P=2, T=30, O=111, A=8, hidden=(128, 128), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1, lr=1e-3, epochs=5),
+}
+
+
+def gen_promp_adam():
+    for name, c in ADAM_CASES.items():
+        theta0, all_slabs = make_promp_inputs(c)
+        th = theta0.astype(np.float64)
+        m, v = np.zeros_like(th), np.zeros_like(th)
+        b1, b2, eps, lr = 0.9, 0.999, 1e-8, c['lr']
+        losses, grads = [], []
+        for t in range(1, c['epochs'] + 1):
+            loss, _, _, g = torch_meta_objective(th, all_slabs, c)
+            losses.append(loss)
+            grads.append(g)
+            lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            m = m + (1.0 - b1) * (g - m)
+            v = v + (1.0 - b2) * (g * g - v)
+            th = th - lr_t * m / (np.sqrt(v) + eps)
+        loss_after, ikl, okl, _ = torch_meta_objective(th, all_slabs, c)
+        flat = {}
+        for k, slabs in enumerate(all_slabs):
+            for key in ('observations', 'actions', 'advantages'):
+                flat['step%d_%s' % (k, key)] = np.stack([s[key] for s in slabs])
+            flat['step%d_mean' % k] = np.stack([s['agent_infos']['mean'] for s in slabs])
+            flat['step%d_log_std' % k] = np.stack([s['agent_infos']['log_std'] for s in slabs])
+        np.savez_compressed(os.path.join(GOLDEN, 'promp_adam_%s.npz' % name), meta=json.dumps(c), theta=theta0,
+                            theta_after=th, adam_m=m.astype(np.float32), adam_v=v.astype(np.float32), losses=np.array(losses),
+                            grad_min_abs=np.min(np.abs(np.stack(grads)), axis=0).astype(np.float32),      # per entry, over the epochs
+                            grad_max_norm=np.array([np.max(np.abs(g)) for g in grads]),                   # per epoch
+                            loss_after=loss_after, inner_kl_after=ikl, outer_kl_after=okl, **flat)
+        print('wrote promp_adam_%s.npz  loss %.6f -> %.6f  max|dtheta| %.3e' % (name, losses[0], loss_after, np.max(np.abs(th - theta0))))
+
+
 # --------------------------------------------------------------------------------------------------
 DICE_PROC_CASES = {
     # name: (seed, dims, max_path_length, processor kwargs, baseline, ragged)
@@ -521,9 +562,13 @@ if __name__ == '__main__':
         gen_dice_proc(only=('retbase', 'retbase_raw'))
         gen_vpg_dice()
         sys.exit(0)
+    if '--adam-only' in sys.argv:            # (round 4 additions only: the other fixtures stay byte-identical)
+        gen_promp_adam()
+        sys.exit(0)
     if '--dist-only' not in sys.argv:
         gen_sample_proc()
         gen_promp()
+        gen_promp_adam()
     gen_dist_reference()
     gen_point_env()
     gen_dice_proc()

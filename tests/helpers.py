@@ -53,6 +53,24 @@ def load_promp(name):
     return c, g['theta'], all_slabs, g
 
 
+def promp_adam_cases():
+    return sorted(os.path.basename(p)[len('promp_adam_'):-4] for p in glob.glob(os.path.join(GOLDEN, 'promp_adam_*.npz')))
+
+
+def load_promp_adam(name):
+    """-> (case dict, theta float32, all_slabs, golden npz): inputs as load_promp, results after E Adam epochs (torch.autograd
+    gradient each epoch, tf.train.AdamOptimizer's update transcribed: oracle/gen_golden.py:gen_promp_adam)."""
+    g = np.load(os.path.join(GOLDEN, 'promp_adam_%s.npz' % name))
+    c = json.loads(str(g['meta']))
+    all_slabs = []
+    for k in range(c['K'] + 1):
+        all_slabs.append([dict(observations=g['step%d_observations' % k][i], actions=g['step%d_actions' % k][i],
+                               advantages=g['step%d_advantages' % k][i],
+                               agent_infos=dict(mean=g['step%d_mean' % k][i], log_std=g['step%d_log_std' % k][i]))
+                          for i in range(c['M'])])
+    return c, g['theta'], all_slabs, g
+
+
 def make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=False, low_log_std=False, per_task_log_std=False, min_std=1e-6):
     """Seeded slabs for steps 0..K (same recipe as oracle/gen_golden.py:make_promp_inputs): the 'old' policy
     differs from theta so that ratio != 1 and the PPO clip is active on some rows."""

@@ -134,6 +134,30 @@ def test_two_rank_library_kernels_with_external_collective(tmp_path):
     assert np.max(np.abs(ref - theta)) > 5e-4
 
 
+def test_launcher_and_socket_rendezvous_without_torch(tmp_path):
+    """python -m promp_amd.launch (no PyTorch anywhere): three ranks, two exchanges each through rank 0's socket server;
+    torch must not have been imported by the package; a failing rank takes the job down with its exit code."""
+    script = tmp_path / 'rdzv.py'
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r)
+from promp_amd import comm
+rank, world, local = comm.env_world()
+assert world == 3 and local == rank
+for k in (3, 11):
+    uid = comm.exchange_unique_id(rank, world, lambda: bytes((k * i + rank) %% 256 for i in range(128)))
+    assert uid == bytes((k * i) %% 256 for i in range(128)), uid[:8]
+assert 'torch' not in sys.modules
+open(os.path.join(%r, 'ok%%d' %% rank), 'w').write('1')
+if len(sys.argv) > 1 and rank == 1:
+    sys.exit(7)
+''' % (ROOT, str(tmp_path)))
+    cmd = [sys.executable, '-m', 'promp_amd.launch', '--nproc', '3', '--master-port', '29741', str(script)]
+    assert subprocess.run(cmd, timeout=300, cwd=ROOT).returncode == 0
+    assert all(os.path.exists(tmp_path / ('ok%d' % r)) for r in range(3))
+    assert subprocess.run(cmd[:-1] + ['--master-port', '29751', str(script), 'fail'], timeout=300, cwd=ROOT).returncode == 7
+
+
 def test_rendezvous_socket_fallback_two_processes(tmp_path):
     """promp_amd.comm.exchange_unique_id without torch: rank 0 serves the 128-byte id over a socket."""
     code = r'''
@@ -150,7 +174,8 @@ assert uid == bytes(range(128))
 
 def test_rendezvous_under_torchrun_agent_store(tmp_path):
     """The launch the driver uses for N>1: python -m torch.distributed.run --master-addr/--master-port ... bench.py.
-    promp_amd.comm.exchange_unique_id must hand rank 0's 128-byte id to every rank through the agent's TCPStore."""
+    promp_amd.comm.exchange_unique_id must hand rank 0's 128-byte id to every rank: by default over its own socket next to
+    the agent's store (MASTER_PORT + 1), and -- PROMP_RDZV=torch -- through the agent's TCPStore."""
     script = tmp_path / 'rdzv.py'
     script.write_text(r'''
 import os, sys
@@ -167,6 +192,10 @@ open(os.path.join(%r, 'ok%%d' %% rank), 'w').write('1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29641', str(script)]
     subprocess.run(cmd, check=True, timeout=600, cwd=ROOT)
+    assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
+    os.remove(tmp_path / 'ok0'), os.remove(tmp_path / 'ok1')
+    cmd[cmd.index('29641')] = '29645'
+    subprocess.run(cmd, check=True, timeout=600, cwd=ROOT, env=dict(os.environ, PROMP_RDZV='torch'))
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')
 
 

@@ -134,6 +134,10 @@ def test_hidden_widths_between_the_instantiated_ones_run_zero_padded(lib, two_cu
     pc.check_meta(lib, 14, M=2, P=1, T=30, O=6, A=3, hidden=(24, 40), K=1, ragged=True, epochs=1)
 
 
+def test_adam_epochs_vs_torch_autograd_golden_h64(lib, two_cus):
+    pc.check_adam_golden(lib, 'hc')
+
+
 def test_meta_k1_h64(lib, two_cus):
     pc.check_meta(lib, 12, M=2, P=1, T=40, O=20, A=6, hidden=(64, 64), K=1, ragged=True, epochs=1)
 

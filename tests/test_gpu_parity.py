@@ -192,6 +192,14 @@ def test_meta_gradient_vs_torch_autograd_golden(lib, name):
     ctx.close()
 
 
+@pytest.mark.parametrize('name', helpers.promp_adam_cases())
+def test_adam_epochs_vs_torch_autograd_golden(lib, name):
+    """E = 5 Adam epochs at config 3's / config 4's network shapes against the torch.autograd + tf.train.Adam transcription:
+    per-element bound on the parameters (entries with |g| under a stated floor excluded), both moments, the losses"""
+    worst, excluded = pc.check_adam_golden(lib, name)
+    print('adam golden %s: worst judged entry %.2e of one step, %.2f %% of the entries under the gradient floor' % (name, worst, 100 * excluded))
+
+
 # ---- full BASELINE configs 3 (M=40, P=20, T=200, O=20, A=6, 2x64) and 4 (Ant: O=111, A=8, 2x128):
 #      size-independent properties + one oracle comparison each ----
 @pytest.fixture(scope='module', params=[3, 4], ids=['config3', 'config4'])

@@ -32,6 +32,23 @@ def test_meta_gradient_matches_torch_autograd(name):
     np.testing.assert_allclose(r['grad'], g['grad'], rtol=1e-7, atol=1e-9 * scale)
 
 
+@pytest.mark.parametrize('name', helpers.promp_adam_cases())
+def test_adam_epochs_match_torch_autograd_trajectory(name):
+    """the oracle's optimize_policy (hand-derived gradient + its Adam) against E epochs of torch.autograd gradients through a
+    transcription of tf.train.AdamOptimizer's update (bias-corrected lr_t, epsilon outside the root), at the network shapes of
+    BASELINE configs 3 and 4"""
+    c, theta, all_slabs, g = helpers.load_promp_adam(name)
+    spec = _spec(c)
+    adam = pm.AdamState(spec.n_params)
+    th, ref = pm.optimize_policy(spec, theta.astype(np.float64), all_slabs, np.full(spec.n_params, c['alpha']), np.array(c['eta']),
+                                 c['clip_eps'], adam, c['lr'], c['epochs'])
+    assert ref['loss_before'] == pytest.approx(float(g['losses'][0]), rel=1e-10)
+    assert ref['loss_after'] == pytest.approx(float(g['loss_after']), rel=1e-8)
+    np.testing.assert_allclose(th, g['theta_after'], rtol=0, atol=1e-9)           # (steps are ~1e-3 per epoch)
+    np.testing.assert_allclose(adam.m, g['adam_m'], rtol=1e-5, atol=1e-7 * float(g['grad_max_norm'].max()))
+    np.testing.assert_allclose(adam.v, g['adam_v'], rtol=1e-5, atol=1e-7 * float(g['grad_max_norm'].max()) ** 2)
+
+
 def test_hvp_matches_finite_differences():
     c, theta, all_slabs, _ = helpers.load_promp('k1_small')
     spec = _spec(c)
