@@ -77,8 +77,9 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims);
 void promp_ctx_destroy(promp_ctx* ctx);
 const char* promp_last_error(void);
 /* 2.  The version moves when an existing entry point changes its meaning or signature; entry points added since (round 3:
- * promp_set_reuse_adapt, promp_begin_collection / promp_end_collection, promp_state_version, the two pass counters) and the wider
- * range of hidden sizes are additions a binding built against the first v2 header keeps working with. */
+ * promp_set_reuse_adapt, promp_begin_collection / promp_end_collection, promp_state_version, the two pass counters; round 4:
+ * promp_comm_fixed_order) and the wider range of hidden sizes are additions a binding built against the first v2 header
+ * keeps working with. */
 int promp_abi_version(void);
 /* Theta = O*H1+H1 + H1*H2+H2 + H2*A+A + A */
 int promp_param_count(const promp_dims* dims);
@@ -328,6 +329,11 @@ int promp_comm_move(promp_ctx* dst, promp_ctx* src);
 /* Take the several-rank launch sequence (per-rank sums -> [all-reduce] -> mean + Adam as separate launches) even on
  * one rank; numerically identical to the fused single-rank launch (the parity tests assert bitwise equality). */
 int promp_comm_split_path(promp_ctx* ctx, int on);
+/* The exchange as ncclAllGather + a sum in rank order (0, 1, ...) on every rank instead of ncclAllReduce: the replicas'
+ * parameters are bitwise identical by construction -- not by the grace of RCCL choosing the same reduction order on every
+ * rank -- and equal to one process adding the ranks' shards in that order.  The buffer is ~6 k floats:
+ * the gather moves nranks x 24 KB, latency as the all-reduce's.  Set it the same on every rank; default off. */
+int promp_comm_fixed_order(promp_ctx* ctx, int on);
 /* The buffer the all-reduce acts on, [Theta + K + 2] floats = { grad sums | J sum | inner-KL sums [K] | outer-KL sum }
  * over the LOCAL tasks after promp_meta_grad (when n_tasks_global > n_tasks and no communicator is attached, the
  * exchange is the caller's: get, reduce over ranks with any collective, set, then promp_adam_step -- which divides by

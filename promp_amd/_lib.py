@@ -108,6 +108,7 @@ SIGNATURES = {
     'promp_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     'promp_comm_move': (C.c_int, [_P, _P]),
     'promp_comm_split_path': (C.c_int, [_P, C.c_int]),
+    'promp_comm_fixed_order': (C.c_int, [_P, C.c_int]),
     'promp_reduced_get': (C.c_int, [_P, _F]),
     'promp_reduced_set': (C.c_int, [_P, _F]),
     'promp_allreduce_f64': (C.c_int, [_P, _D, C.c_int, C.c_int]),
@@ -585,6 +586,10 @@ class Context:
     def comm_move_from(self, other):
         """take over `other`'s communicator (a context re-created with more capacity keeps it: no new rendezvous)"""
         self.lib.check(self.lib.cdll.promp_comm_move(self._h, other._h))
+
+    def comm_fixed_order(self, on=True):
+        """exchange = ncclAllGather + sum in rank order instead of ncclAllReduce: bitwise-identical replicas by construction"""
+        self._call('promp_comm_fixed_order', int(bool(on)))
 
     def comm_split_path(self, on=True):
         self._call('promp_comm_split_path', int(bool(on)))

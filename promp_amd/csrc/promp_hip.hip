@@ -166,6 +166,9 @@ struct promp_ctx {
     float* pass_scal2 = nullptr;
     long long adapt_passes_skipped = 0;
     bool force_split = false;            // take the multi-rank launch sequence (reduce / all-reduce / Adam) on one rank too
+    bool fixed_order = false;            // exchange = ncclAllGather + sum in rank order (bitwise-identical replicas) instead of ncclAllReduce
+    float* gather = nullptr;             // [nranks][Theta + K + 2]: every rank's sums side by side (fixed_order)
+    size_t gather_len = 0;
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
     float* stats_host = nullptr;         // pinned: promp_optimize_begin parks both statistics slots here (async copy)
@@ -418,6 +421,33 @@ static bool adapt0_stands(const promp_ctx* c, int inner_kind, bool cached) {
            c->adapt0.learn_std == c->learn_std && c->ls_known && c->ls_min >= c->min_log_std && !c->pass_adv;
 }
 
+// The one exchange of the path (meta_algos/pro_mp.py:122,151,155: the mean over tasks): the ranks' sums of n floats, in place.
+//   default      ncclAllReduce -- the result is the same on every rank for a given algorithm / topology, but the ORDER of the
+//                additions is RCCL's;
+//   fixed_order  ncclAllGather of the ranks' vectors + k_sum_ranks adding them in rank order 0, 1, ... on every rank: replicas
+//                bitwise identical by construction, and equal to what one process adding its shards in that order computes
+//                (the fixed-order one-shot variant; n is ~6 k floats, the gather moves nranks x 24 KB).
+static int exchange_sums(promp_ctx* c, float* buf, size_t n) {
+    if (!c->comm) return 0;
+    if (c->fixed_order) {
+        const size_t need = (size_t)c->nranks * n;
+        if (c->gather_len < need) {
+            if (c->gather) HIPCHECK(hipFree(c->gather));
+            c->gather = nullptr;
+            HIPCHECK(hipMalloc((void**)&c->gather, sizeof(float) * need));
+            c->gather_len = need;
+        }
+        ncclResult_t r = ncclAllGather(buf, c->gather, n, ncclFloat, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(-4, "ncclAllGather failed: %s", ncclGetErrorString(r));
+        PROMP_LAUNCH(k_sum_ranks, dim3((unsigned)((n + 255) / 256)), 256, 0, c->stream, (const float*)c->gather, buf, (int)n, c->nranks);
+        HIPCHECK(hipGetLastError());
+        return 0;
+    }
+    ncclResult_t r = ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    return 0;
+}
+
 // A context that holds a shard of the meta-batch (n_tasks_global > n_tasks) but no communicator: the external-collective mode.
 // Its entry points return this rank's SHARE of a mean (promp_meta_grad: local sums / n_tasks_global, the sums themselves in the
 // exchange buffer); the ones that would go on to USE a mean (an Adam step, a conjugate-gradient product) refuse instead.
@@ -501,10 +531,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
     if (split) {
         PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
         HIPCHECK(hipGetLastError());
-        if (c->comm) {
-            ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)(NP + K + 2), ncclFloat, ncclSum, c->comm, c->stream);
-            if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
-        }
+        if (exchange_sums(c, c->red, (size_t)(NP + K + 2))) return -4;
     }
     AdamArgs ad;
     ad.theta = c->theta; ad.m = c->adam_m; ad.v = c->adam_v; ad.red = c->red; ad.grad_mean = c->grad_mean;
@@ -778,6 +805,7 @@ void promp_ctx_destroy(promp_ctx* c) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->gather) (void)hipFree(c->gather);
     for (auto* set : {&c->steps, &c->back})
         for (auto& S : *set) {
             free_step(S);
@@ -1789,10 +1817,7 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     f.scal_inner = c->scal_inner; f.scal_outer = c->scal_outer; f.red = c->red; f.want_grad = 1;
     PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
     HIPCHECK(hipGetLastError());
-    if (c->comm) {
-        ncclResult_t r = ncclAllReduce(c->red, c->red, (size_t)NP, ncclFloat, ncclSum, c->comm, c->stream);
-        if (r != ncclSuccess) return fail(-4, "ncclAllReduce failed: %s", ncclGetErrorString(r));
-    }
+    if (exchange_sums(c, c->red, (size_t)NP)) return -4;
     if (params_out(c, out, c->red, 1)) return -2;
     const float inv = 1.0f / (float)c->d.n_tasks_global;
     for (int j = 0; j < c->NPu; ++j) out[j] *= inv;
@@ -1948,6 +1973,12 @@ int promp_comm_init(promp_ctx* c, int rank, int nranks, const void* id, size_t i
     return 0;
 }
 
+int promp_comm_fixed_order(promp_ctx* c, int on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->fixed_order = on != 0;
+    return 0;
+}
+
 int promp_comm_split_path(promp_ctx* c, int on) {
     if (!c) return fail(-1, "ctx is NULL");
     c->force_split = on != 0;
@@ -1962,6 +1993,7 @@ int promp_comm_move(promp_ctx* dst, promp_ctx* src) {
     HIPCHECK(hipStreamSynchronize(src->stream));    // nothing of the old context may still be using it
     dst->comm = src->comm;
     src->comm = nullptr;
+    dst->fixed_order = src->fixed_order;
     dst->rank = src->rank; dst->nranks = src->nranks;
     src->rank = 0; src->nranks = 1;
     return 0;

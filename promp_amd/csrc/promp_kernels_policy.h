@@ -186,6 +186,16 @@ __global__ void __launch_bounds__(256) k_mean_adam(AdamArgs a) {
     }
 }
 
+// Fixed-order exchange: the ranks' vectors side by side ([nranks][n], ncclAllGather) added in rank order -- the same additions in
+// the same order on every rank.
+__global__ void __launch_bounds__(256) k_sum_ranks(const float* gathered, float* out, int n, int nranks) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float s = gathered[j];
+    for (int r = 1; r < nranks; ++r) s += gathered[(long long)r * n + j];
+    out[j] = s;
+}
+
 // k_reduce_final + k_mean_adam in one launch, for the single-rank case (no all-reduce in between).  Column sums in the
 // same order as k_reduce_final (bitwise the same red[]); the thread that finishes a parameter column applies its Adam
 // update; one extra workgroup re-sums the K + 2 scalar columns and writes the statistics.

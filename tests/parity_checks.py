@@ -245,7 +245,7 @@ def check_split_accuracy(lib, hidden, O, A, seed=11, M=2, P=2, T=48, tol=2.5e-6)
 
 
 ADAM_GRAD_FLOOR = 1e-3      # entries whose |g| stays above this fraction of the gradient's max-norm in EVERY epoch are compared
-ADAM_STEP_TOL = 2e-2        # ... to this fraction of ONE Adam step (lr) over the whole trajectory
+ADAM_STEP_TOL = 5e-3        # ... to this fraction of ONE Adam step (lr) over the whole trajectory (measured on the MI355X: 5e-5 .. 2.5e-4)
 ADAM_MAX_EXCLUDED = 0.25    # and they must be most of the vector
 
 
@@ -374,7 +374,7 @@ def check_primal_cache(lib, seed, M, P, T, O, A, hidden, K=1, ragged=True):
     assert rel_max(g_off, r['grad']) < 1e-4
 
 
-def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, attach_comm=False):
+def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, attach_comm=False, fixed_order=False):
     """the several-rank launch sequence (k_reduce_final -> [ncclAllReduce] -> k_mean_adam) on ONE rank must reproduce the
     fused single-rank launch (k_final_adam) bit for bit: same column sums in the same order, same Adam arithmetic"""
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=True)
@@ -389,6 +389,7 @@ def check_split_path_equals_fused(lib, seed, M, P, T, O, A, hidden, epochs=3, at
         if split:
             if attach_comm:
                 ctx.comm_init(0, 1, _lib.comm_unique_id(lib))      # a real (one-rank) RCCL communicator: the all-reduce is enqueued
+                ctx.comm_fixed_order(fixed_order)                  # ... or ncclAllGather + k_sum_ranks
             ctx.comm_split_path(True)
         res = ctx.optimize(epochs, 1e-3, 0.3, eta)
         g, st = ctx.meta_grad(0.3, eta)
@@ -717,8 +718,8 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
         # the optimizer's back-to-back loss / constraint queries at one parameter vector share ONE device evaluation, and a new
         # parameter vector (or anything else the evaluation reads) ends the sharing
         ctx, calls = algo.session.ctx, []
-        orig = ctx.meta_eval
-        ctx.meta_eval = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        orig = ctx.optimize              # (a forward evaluation is promp_optimize with zero epochs: DeviceSession.meta_eval)
+        ctx.optimize = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
         try:
             ev._memo = None
             l0, k0 = ev.loss(), ev.constraint_val()
@@ -729,7 +730,7 @@ def check_trpo(lib, seed, M, P, T, O, A, hidden, inner_type='log_likelihood', cg
             ev.set_theta(theta)
             assert ev.loss() == l0 and ev.constraint_val() == k0
         finally:
-            ctx.meta_eval = orig
+            ctx.optimize = orig
         # (2) the step
         algo.optimize_policy(samples, log=False)
         st, last = algo.last_stats, algo.optimizer.last

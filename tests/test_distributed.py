@@ -308,10 +308,18 @@ os.environ['PROMP_EMU_CUS'] = '2'
 _lib.set_library_for_testing(devlib.emu_library())
 from tests.test_distributed import run_promp_iteration
 
-def gloo(values, op):                                          # stands in for the RCCL all-reduce (no GPUs here)
+def gloo(values, op):                                          # stands in for the RCCL exchange (no GPUs here)
     t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
-    return t.numpy()
+    if op == 'max':
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.numpy()
+    # the fixed-order form (promp_comm_fixed_order's: all-gather, then every rank adds the vectors in rank order)
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    out = parts[0].clone()
+    for p in parts[1:]:
+        out += p
+    return out.numpy()
 
 M = 4
 mine = [i for i in range(M) if i %% world == rank]

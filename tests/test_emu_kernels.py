@@ -107,6 +107,10 @@ def test_primal_cache_matches_recomputation(lib, two_cus):
 
 def test_split_path_equals_fused_launch(lib, two_cus):
     pc.check_split_path_equals_fused(lib, 18, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), epochs=2)
+    # the host sequence with a communicator attached (the emulated build's one-rank RCCL shim): all-reduce, and the fixed-order
+    # exchange (all-gather + k_sum_ranks)
+    pc.check_split_path_equals_fused(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), epochs=2, attach_comm=True)
+    pc.check_split_path_equals_fused(lib, 19, M=2, P=1, T=30, O=5, A=3, hidden=(32, 32), epochs=2, attach_comm=True, fixed_order=True)
 
 
 def test_learn_std_false(lib, two_cus):

@@ -290,6 +290,8 @@ def test_split_reduce_allreduce_adam_equals_fused_launch(lib):
     pc.check_split_path_equals_fused(lib, 72, M=3, P=3, T=50, O=111, A=8, hidden=(128, 128), epochs=2, attach_comm=False)
     # zero-padded widths: the reduced buffer crosses the ABI in the caller's layout like every parameter vector
     pc.check_split_path_equals_fused(lib, 73, M=3, P=3, T=50, O=20, A=6, hidden=(48, 20), epochs=2, attach_comm=True)
+    # the fixed-order exchange (ncclAllGather on the one-rank communicator + k_sum_ranks): the same bits again
+    pc.check_split_path_equals_fused(lib, 74, M=5, P=4, T=90, O=20, A=6, hidden=(64, 64), attach_comm=True, fixed_order=True)
 
 
 def test_trpo_maml_step_with_exact_constraint_hvp(lib):
