@@ -1149,7 +1149,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<5>::NW, GramCfg<5>::SMEM_BYTES, st, a); } break;
             default:
                 if (nblk > 17) return fail(-1, "feature dim %d unsupported in this build", a.D);
-                PROMP_LAUNCH(k_gram_wide, dim3(S.n_work[0]), 512, gramw_smem(nblk, a.O), st, a, nblk);
+                PROMP_LAUNCH(k_gram_wide, dim3(S.n_work[0]), 512, gramw_smem(nblk, a.O, gramw_rows(nblk, a.O)), st, a, nblk, gramw_rows(nblk, a.O));
         }
         HIPCHECK(hipGetLastError());
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
@@ -1162,7 +1162,9 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             else if (DA <= 64) { auto k = k_fit_wave<64>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
             else PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         } else {
-            PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), 1024, fitw_smem(a.D), st, a, nblk, fit_scratch);
+            PROMP_LAUNCH(k_gram_sum_wide, dim3(c->d.n_tasks * FITW_SUM_SPLIT), 256, 0, st, a, nblk, fit_scratch);
+            HIPCHECK(hipGetLastError());
+            PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D), st, a, nblk, fit_scratch);
         }
         HIPCHECK(hipGetLastError());
     }

@@ -546,20 +546,20 @@ __global__ void __launch_bounds__(256) k_normalize(SampleArgs a) {
 // observation rows of at most 32 floats per wave and k_fit keeps two (D+1)^2 matrices in LDS; beyond that:
 //
 // k_gram_wide: the upper-triangular 16x16 block pairs of [Phi R]^T [Phi R] no longer fit one wave's registers
-// (120 pairs at D = 226), so the workgroup shares the feature tile: 8 waves, wave w owns the pairs p = w, w+8, ...
+// (120 pairs at D = 226), so the workgroup shares the feature tile: 8 waves, wave w owns a contiguous eighth of the pair list
 // (<= GRAMW_PPW of them) over ALL rows of the work item -- no cross-wave reduction, each partial block is written by
-// its owner.  Rounds of 32 rows; same partial layout as k_gram ([NPAIR][256] doubles per work item).
-// grid = work items (table 0), block = 512.  smem: 32 * FS doubles + raw obs [32][O] floats + 2 * 32 doubles.
+// its owner.  Rounds of GRAMW_ROWS rows; same partial layout as k_gram ([NPAIR][256] doubles per work item).
+// grid = work items (table 0), block = 512.  smem: ROWS * FS doubles + raw obs [ROWS][O] floats + 2 * ROWS doubles.
 // ---------------------------------------------------------------------------------------------
 #define GRAMW_PPW 20     // pairs per wave: 8 * 20 >= 17 * 18 / 2 (NBLK <= 17, D <= 271)
-#define GRAMW_ROWS 32
-
 PROMP_HD int gramw_fs(int NBLK) { return (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16; }
-PROMP_HD size_t gramw_smem(int NBLK, int O) {
-    return sizeof(double) * (size_t)(GRAMW_ROWS * gramw_fs(NBLK) + 2 * GRAMW_ROWS) + sizeof(float) * (size_t)(GRAMW_ROWS * O);
+PROMP_HD size_t gramw_smem(int NBLK, int O, int rows) {
+    return sizeof(double) * (size_t)(rows * gramw_fs(NBLK) + 2 * rows) + sizeof(float) * (size_t)(rows * O);
 }
+// rows per round: 64 where the feature tile + raw observations fit the 160 KB of LDS (Ant: 151 KB), else 32
+PROMP_HD int gramw_rows(int NBLK, int O) { return gramw_smem(NBLK, O, 64) <= 160 * 1024 ? 64 : 32; }
 
-__global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
+__global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, int GRAMW_ROWS) {
     PROMP_SMEM_DECL;
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), i16 = lane & 15, kk = lane >> 4;
     const int FS = gramw_fs(NBLK), NPAIR = NBLK * (NBLK + 1) / 2, NC = 16 * NBLK;
@@ -569,12 +569,14 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
     float* Ob = (float*)(Tau + GRAMW_ROWS);
     const WorkItem wk = a.work[blockIdx.x];
     const int O = a.O, D = a.D;
-    // this wave's pairs: offsets of the two 16-column blocks inside a feature row (wave-uniform: scalar registers)
+    // this wave's pairs: a contiguous range of the row-major list (bi, bj >= bi); offsets of the two 16-column blocks inside a
+    // feature row (wave-uniform)
+    const int ppw = (NPAIR + 7) / 8, p0 = w * ppw;
     int ca[GRAMW_PPW], cb[GRAMW_PPW];
 #pragma unroll
     for (int j = 0; j < GRAMW_PPW; ++j) {
-        const int p = w + 8 * j;
-        int bi = 0, rem = p < NPAIR ? p : 0;
+        const int p = p0 + j;
+        int bi = 0, rem = (j < ppw && p < NPAIR) ? p : 0;
         while (rem >= NBLK - bi) {
             rem -= NBLK - bi;
             ++bi;
@@ -603,8 +605,8 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
             Tau[tid] = (tid < nrows) ? tau : 0.0;
         }
         __syncthreads();
-        {   // features: 16 threads per row, columns fc0, fc0 + 16, ...
-            const int fr = tid >> 4, fc0 = tid & 15;
+        for (int fr = tid >> 4; fr < GRAMW_ROWS; fr += 32) {   // features: 16 threads per row, columns fc0, fc0 + 16, ...
+            const int fc0 = tid & 15;
             const bool rv = fr < nrows;
             const double tau = Tau[fr];
             for (int c = fc0; c < NC; c += 16) {
@@ -632,59 +634,108 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK) {
             }
         }
         __syncthreads();
-#pragma unroll 1
-        for (int s = 0; s < GRAMW_ROWS / 4; ++s) {
-            const double* row = Phi + (4 * s + kk) * FS + i16;
+        // The products, software-pipelined: the operands of the NEXT group of four pairs are requested before the current group's
+        // four matrix instructions issue (4 x 64 cycles of FP64 MFMA cover the LDS round trip).  Loading a group, waiting, then
+        // issuing its products left the matrix pipe idle two thirds of the time (PMC: SQ_VALU_MFMA_BUSY_CYCLES 33 % of the
+        // kernel, SQ_WAIT_ANY 50 % of the wave cycles).  Pairs beyond the wave's share read a valid address and are not issued.
+        {
+            constexpr int NG = GRAMW_PPW / 4;
+            const int nsteps = GRAMW_ROWS / 4;
+            double xa[4], xb[4];
+            const double* row = Phi + kk * FS + i16;
 #pragma unroll
-            for (int j = 0; j < GRAMW_PPW; ++j) {
-                if (w + 8 * j < NPAIR) acc[j] = mfma16d(row[ca[j]], row[cb[j]], acc[j]);
-                if ((j & 3) == 3) sched_fence();       // at most 4 pairs' operands in flight: the pairs own the registers
+            for (int u = 0; u < 4; ++u) {
+                xa[u] = row[ca[u]];
+                xb[u] = row[cb[u]];
+            }
+#pragma unroll 1
+            for (int st = 0; st < nsteps; ++st) {
+                const double* rnext = Phi + (4 * (st + 1 < nsteps ? st + 1 : st) + kk) * FS + i16;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    double na[4], nb[4];
+                    const double* src = (g + 1 < NG) ? row : rnext;
+                    const int gn = (g + 1 < NG) ? g + 1 : 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        na[u] = src[ca[4 * gn + u]];
+                        nb[u] = src[cb[4 * gn + u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = 4 * g + u;
+                        if (j < ppw && p0 + j < NPAIR) acc[j] = mfma16d(xa[u], xb[u], acc[j]);      // (wave-uniform)
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xa[u] = na[u];
+                        xb[u] = nb[u];
+                    }
+                    sched_fence();
+                }
+                row = rnext;
             }
         }
     }
     double* out = a.gram_partials + (long long)blockIdx.x * (NPAIR * 256);
 #pragma unroll
     for (int j = 0; j < GRAMW_PPW; ++j) {
-        const int p = w + 8 * j;
-        if (p < NPAIR)
+        const int p = p0 + j;
+        if (j < ppw && p < NPAIR)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[p * 256 + (kk + 4 * r) * 16 + i16] = acc[j][r];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fit_wide: the same solve as k_fit when the (D+1)^2 matrices do not fit in LDS.  G and the work matrix live in
-// global memory (L2-resident, 0.4 MB per task); a right-looking blocked Cholesky brings one 32-column panel at a time
-// into LDS, factors it there (carrying the right-hand-side row D along, as k_fit does), and applies its rank-32
-// update to the trailing matrix; the back substitution walks 32-row blocks of L through LDS.
-// grid = tasks, block = 1024.  smem: (D+1) * 33 + 3 * (D+1) + 2 doubles.
+// k_fit_wide: the same solve as k_fit when the (D+1)^2 matrices do not fit in LDS (Ant: D = 226).  G and the work matrix live in
+// global memory (L2-resident, 0.4 MB per task).  Right-looking blocked Cholesky, 32-column panels through LDS, the right-hand
+// side carried along as row D (k_fit's forward solve for free):
+//   1. the panel's 32 x 32 diagonal block is factorised by ONE wave in registers (a row per lane, pivots and multipliers by
+//      v_readlane: k_fit_wave's column step -- 32 dependent steps with no barrier and no memory access on the chain);
+//   2. the rows below it (and the right-hand-side row) are solved against that block one row per thread (independent rows);
+//   3. the rank-32 update of the trailing matrix runs on the FP64 matrix cores: v_mfma_f64_16x16x4_f64 over the 16 x 16 tiles of
+//      the lower triangle, all waves, operands straight from the panel in LDS.
+// The back substitution walks the factor in 32-row blocks: one wave solves the block's triangle in registers, all threads apply
+// its 32 solved entries to the rows above.  Round 3's version took two workgroup barriers per COLUMN (226 x 2, plus 226 in the
+// back substitution) and updated the trailing matrix with scalar FMAs: 676 us per launch at Ant's size; this one takes four
+// barriers per PANEL.  Same elimination order and arithmetic as k_fit up to the reciprocal square root k_fit_wave also uses
+// (results agree to rounding, not bit for bit).
+// grid = tasks, block = FITW_NT.  smem: fitw_smem(D).
 // ---------------------------------------------------------------------------------------------
 #define FITW_NB 32
 #define FITW_PS (FITW_NB + 1)
+#define FITW_NT 512        // 8 waves: two per SIMD, 256 registers each (a row of the diagonal block / of the solve lives in 64 of them)
 PROMP_HD size_t fitw_smem(int D) {
-    const size_t DA = D + 1, panel = DA * FITW_PS, blk = FITW_NB * (DA + 1);
-    return sizeof(double) * ((panel > blk ? panel : blk) + 3 * DA + 2);
+    const size_t DA = D + 1, panel = (DA + 16) * FITW_PS;       // (16 spare rows: the last 16-row tile of the update reads zeros)
+    return sizeof(double) * (panel + 3 * DA + FITW_NB + 2);
 }
 
-__global__ void __launch_bounds__(1024) k_fit_wide(SampleArgs a, int NBLK, double* scratch) {
-    PROMP_SMEM_DECL;
-    const int D = a.D, DA = D + 1, NT = 1024;
-    const int tid = threadIdx.x, task = blockIdx.x;
-    const size_t region = (size_t)DA * FITW_PS > (size_t)FITW_NB * (DA + 1) ? (size_t)DA * FITW_PS : (size_t)FITW_NB * (DA + 1);
-    double* Pn = (double*)PROMP_SMEM_PTR;     // panel [DA - k0][33]  /  back-substitution block [32][DA + 1]
-    double* yv = Pn + region;
-    double* wv = yv + DA;
-    double* dg = wv + DA;
-    int* flag = (int*)(dg + DA);
+// The task's partial Gram blocks summed in workgroup order and scattered into the symmetric matrix G -- and G + reg I into the
+// work matrix of the first factorisation attempt -- by the WHOLE chip (grid = tasks x FITW_SUM_SPLIT): inside k_fit_wide the sum
+// ran on one compute unit per task (40 of 256 busy, a quarter of that kernel's time at Ant's size).
+// scratch: [tasks][2][(D+1)^2].  block = 256.
+#define FITW_SUM_SPLIT 8
+__global__ void __launch_bounds__(256) k_gram_sum_wide(SampleArgs a, int NBLK, double* scratch) {
+    const int D = a.D, DA = D + 1;
+    const int task = blockIdx.x / FITW_SUM_SPLIT, part = blockIdx.x % FITW_SUM_SPLIT;
     double* G = scratch + (size_t)task * 2 * DA * DA;
     double* Wm = G + (size_t)DA * DA;
     const int NPAIR = NBLK * (NBLK + 1) / 2;
-    // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
     const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
-    for (int e = tid; e < NPAIR * 256; e += NT) {
+    for (int e = part * 256 + threadIdx.x; e < NPAIR * 256; e += 256 * FITW_SUM_SPLIT) {
+        // eight partial blocks per trip, all requested before the first is added (as k_fit_wave)
         double s = 0.0;
-#pragma unroll 4
-        for (int wg = wg0; wg < wg1; ++wg) s += a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+        for (int base = wg0; base < wg1; base += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int wg = base + u < wg1 ? base + u : wg1 - 1;
+                v[u] = a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (base + u < wg1) ? v[u] : 0.0;
+        }
         int p = e >> 8, bi = 0, rem = p;
         while (rem >= NBLK - bi) {
             rem -= NBLK - bi;
@@ -693,87 +744,184 @@ __global__ void __launch_bounds__(1024) k_fit_wide(SampleArgs a, int NBLK, doubl
         const int bj = bi + rem;
         const int row = 16 * bi + ((e & 255) >> 4), col = 16 * bj + (e & 15);
         if (row < DA && col < DA) {
+            const double diag = (row == col && row < D) ? a.reg : 0.0;
             G[(size_t)row * DA + col] = s;
-            if (bi != bj) G[(size_t)col * DA + row] = s;
+            Wm[(size_t)row * DA + col] = s + diag;
+            if (bi != bj) {
+                G[(size_t)col * DA + row] = s;
+                Wm[(size_t)col * DA + row] = s;
+            }
         }
     }
-    __syncthreads();
+}
+
+__global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, double* scratch) {
+    PROMP_SMEM_DECL;
+#ifdef PROMP_DEV_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = promp_clock();
+#define FITW_PHASE(i) do { const unsigned long long now_ = promp_clock(); ph[i] += now_ - tph; tph = now_; } while (0)
+#else
+#define FITW_PHASE(i) do { } while (0)
+#endif
+    const int D = a.D, DA = D + 1, NT = FITW_NT;
+    const int tid = threadIdx.x, task = blockIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    double* Pn = (double*)PROMP_SMEM_PTR;     // panel [DA - k0 (+ 16)][33]
+    double* yv = Pn + (size_t)(DA + 16) * FITW_PS;
+    double* wv = yv + DA;
+    double* dg = wv + DA;
+    double* rdp = dg + DA;                    // 1 / L[c][c] of the current panel's diagonal block
+    int* flag = (int*)(rdp + FITW_NB);
+    double* G = scratch + (size_t)task * 2 * DA * DA;
+    double* Wm = G + (size_t)DA * DA;
+    // (G, and G + reg I as the work matrix of the first attempt, were written by k_gram_sum_wide)
     const float rDA = 1.0f / (float)DA;
     double reg = a.reg;
     for (int attempt = 0; attempt < 5; ++attempt) {
-        for (int e = tid; e < DA * DA; e += NT) {
-            const int i = (int)(((float)e + 0.5f) * rDA), j = e - i * DA;
-            Wm[e] = G[e] + ((i == j && i < D) ? reg : 0.0);
+        if (attempt > 0) {            // a retry starts over from G with the larger ridge term
+            for (int e = tid; e < DA * DA; e += NT) {
+                const int i = (int)(((float)e + 0.5f) * rDA), j = e - i * DA;
+                Wm[e] = G[e] + ((i == j && i < D) ? reg : 0.0);
+            }
         }
         __syncthreads();
+        FITW_PHASE(1);
         for (int k0 = 0; k0 < D; k0 += FITW_NB) {
             const int nb = (D - k0) < FITW_NB ? (D - k0) : FITW_NB;   // columns of this panel
-            const int nr = DA - k0;                                  // rows k0..D
-            for (int e = tid; e < nr * FITW_NB; e += NT) {
+            const int nr = DA - k0;                                  // rows k0..D (the last one is the right-hand side)
+            for (int e = tid; e < (nr + 16) * FITW_NB; e += NT) {
                 const int i = e >> 5, c = e & 31;
-                Pn[i * FITW_PS + c] = (c < nb) ? Wm[(size_t)(k0 + i) * DA + k0 + c] : 0.0;
+                Pn[i * FITW_PS + c] = (c < nb && i < nr) ? Wm[(size_t)(k0 + i) * DA + k0 + c] : 0.0;
             }
             __syncthreads();
-            for (int c = 0; c < nb; ++c) {
-                const double piv = sqrt(Pn[c * FITW_PS + c]);   // nobody writes the diagonal entry during this step
-                if (tid == 0) dg[k0 + c] = piv;
-                for (int i = c + 1 + tid; i < nr; i += NT) Pn[i * FITW_PS + c] /= piv;
-                __syncthreads();
-                const int ncr = nb - c - 1;   // panel columns right of c
-                for (int e = tid; e < (nr - c - 1) * ncr; e += NT) {
-                    const int io = e / ncr, i = c + 1 + io, c2 = c + 1 + (e - io * ncr);
-                    if (c2 <= i) Pn[i * FITW_PS + c2] -= Pn[i * FITW_PS + c] * Pn[c2 * FITW_PS + c];
+            FITW_PHASE(2);
+            if (w == 0) {
+                // ---- the diagonal block, one wave, rows in registers (lanes >= nb shadow the last row: finite, never stored)
+                const int row = lane < nb ? lane : nb - 1;
+                double W[FITW_NB];
+                double rdg = 1.0;
+#pragma unroll
+                for (int k = 0; k < FITW_NB; ++k) W[k] = Pn[row * FITW_PS + k];
+#pragma unroll
+                for (int j = 0; j < FITW_NB; ++j) {
+                    if (j < nb) {     // (wave-uniform)
+                        const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
+                        W[j] = (lane == j) ? piv : W[j] * rs;
+                        rdg = (lane == j) ? rs : rdg;
+#pragma unroll
+                        for (int k = j + 1; k < FITW_NB; ++k) W[k] -= W[j] * readlane_f64(W[j], k);     // lane k holds L[k][j] in W[j]
+                    }
                 }
-                __syncthreads();
+                if (lane < nb) {
+#pragma unroll
+                    for (int k = 0; k < FITW_NB; ++k)
+                        if (k <= lane) Pn[lane * FITW_PS + k] = W[k];
+                    dg[k0 + lane] = W[lane];
+                    rdp[lane] = rdg;
+                }
             }
+            __syncthreads();
+            FITW_PHASE(3);
+            // ---- the rows below: x L^T = a, one row per thread (forward substitution over the block's columns)
+            if (tid < nr - nb) {
+                double* xr = Pn + (size_t)(nb + tid) * FITW_PS;
+                double x[FITW_NB];
+#pragma unroll
+                for (int c = 0; c < FITW_NB; ++c) x[c] = xr[c];
+                // column by column, right-looking: once x[c] is final the later entries take their x[c] L[c2][c] at once -- 31 - c
+                // independent multiply-adds (the left-looking form is one dependent chain of c per entry).  L[c2][c] is the same
+                // address in every lane: a broadcast.  In a last panel narrower than 32 the rows / columns >= nb of the block hold
+                // other rows' data: finite junk that only reaches entries >= nb, which are stored as 0.
+#pragma unroll
+                for (int c = 0; c < FITW_NB; ++c) {
+                    if (c < nb) {
+                        x[c] *= rdp[c];
+#pragma unroll
+                        for (int c2 = c + 1; c2 < FITW_NB; ++c2) x[c2] -= x[c] * Pn[c2 * FITW_PS + c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < FITW_NB; ++c) xr[c] = (c < nb) ? x[c] : 0.0;
+            }
+            __syncthreads();
+            FITW_PHASE(4);
             // write the factored panel back (strictly-lower part and the right-hand-side row)
             for (int e = tid; e < nr * FITW_NB; e += NT) {
                 const int i = e >> 5, c = e & 31;
                 if (c < nb && i > c) Wm[(size_t)(k0 + i) * DA + k0 + c] = Pn[i * FITW_PS + c];
             }
-            // rank-nb update of the trailing matrix: rows k1..D, columns k1..D-1, lower triangle
+            // ---- rank-nb update of the trailing matrix on the FP64 matrix cores: rows k1..D, columns k1..D-1, the tiles of the
+            //      lower triangle, wave w takes tiles w, w + 16, ...
             const int k1 = k0 + nb, tr = DA - k1, tc = D - k1;
             if (tc > 0) {
-                const float rtc = 1.0f / (float)tc;
-#pragma unroll 2
-                for (int e = tid; e < tr * tc; e += NT) {
-                    const int io = (int)(((float)e + 0.5f) * rtc), jo = e - io * tc;
-                    if (jo <= io) {
-                        double* dst = Wm + (size_t)(k1 + io) * DA + k1 + jo;
-                        const double w0 = *dst;                                  // L2 round trip overlaps the dot product
-                        const double* pi = Pn + (nb + io) * FITW_PS;
-                        const double* pj = Pn + (nb + jo) * FITW_PS;
-                        double s0 = 0.0, s1 = 0.0;
+                const int nti = (tr + 15) >> 4, ntj = (tc + 15) >> 4;
+                const int ntile = nti * ntj;                    // (tiles above the diagonal are skipped below)
+                for (int tix = w; tix < ntile; tix += FITW_NT / 64) {
+                    const int bi = tix / ntj, bj = tix - bi * ntj;
+                    if (bj > bi) continue;                     // wave-uniform
+                    const double* pa = Pn + (size_t)(nb + 16 * bi + i16) * FITW_PS + kk;
+                    const double* pb = Pn + (size_t)(nb + 16 * bj + i16) * FITW_PS + kk;
+                    // the entries this lane will update, requested before the products (clamped addresses, masked at the store)
+                    double* dst[4];
+                    double old[4];
+                    bool ok[4];
 #pragma unroll
-                        for (int c = 0; c < FITW_NB; c += 2) {                   // columns >= nb of the panel are zero
-                            s0 += pi[c] * pj[c];
-                            s1 += pi[c + 1] * pj[c + 1];
-                        }
-                        *dst = w0 - (s0 + s1);
+                    for (int r = 0; r < 4; ++r) {
+                        const int io = 16 * bi + kk + 4 * r, jo = 16 * bj + i16;
+                        ok[r] = io < tr && jo < tc && jo <= io;
+                        dst[r] = Wm + (size_t)(k1 + (ok[r] ? io : 0)) * DA + k1 + (ok[r] ? jo : 0);
+                        old[r] = *dst[r];
                     }
+                    f64x4 acc = zero4d();
+#pragma unroll
+                    for (int sidx = 0; sidx < FITW_NB / 4; ++sidx) acc = mfma16d(pa[4 * sidx], pb[4 * sidx], acc);
+                    // D: col = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) *dst[r] = old[r] - acc[r];
                 }
             }
             __syncthreads();
+            FITW_PHASE(5);
         }
-        // back substitution L^T w = z, z = row D of the factor; 32 rows of L at a time through LDS
+        // ---- back substitution L^T w = z, z = row D of the factor, 32 rows of L at a time
         for (int e = tid; e < D; e += NT) yv[e] = Wm[(size_t)D * DA + e];
         __syncthreads();
         for (int kb = ((D - 1) / FITW_NB) * FITW_NB; kb >= 0; kb -= FITW_NB) {
             const int nb = (D - kb) < FITW_NB ? (D - kb) : FITW_NB;
-            const int ncol = kb + nb;        // row j of L has entries 0..j
-            for (int e = tid; e < nb * ncol; e += NT) {
-                const int r = e / ncol, cc = e - r * ncol;
-                Pn[r * (DA + 1) + cc] = (cc < kb + r) ? Wm[(size_t)(kb + r) * DA + cc] : 0.0;
+            if (w == 0) {
+                // lane t holds y[kb + t] and column t of the block's transposed triangle (L[kb + j][kb + t], j > t) in registers
+                const int t = lane < nb ? lane : nb - 1;
+                double W[FITW_NB];
+#pragma unroll
+                for (int j = 0; j < FITW_NB; ++j) W[j] = (j < nb && j > t) ? Wm[(size_t)(kb + j) * DA + kb + t] : 0.0;
+                double y = yv[kb + t];
+                const double rd = 1.0 / dg[kb + t];
+                double wsol = 0.0;
+#pragma unroll
+                for (int j = FITW_NB - 1; j >= 0; --j) {
+                    if (j < nb) {
+                        const double wj = readlane_f64(y, j) * readlane_f64(rd, j);
+                        if (lane == j) wsol = wj;
+                        if (lane < j) y -= W[j] * wj;
+                    }
+                }
+                if (lane < nb) wv[kb + lane] = wsol;
             }
             __syncthreads();
-            for (int r = nb - 1; r >= 0; --r) {
-                const int j = kb + r;
-                const double wj = yv[j] / dg[j];             // yv[j] is final: this step only touches yv[i < j]
-                if (tid == 0) wv[j] = wj;
-                for (int i = tid; i < j; i += NT) yv[i] -= Pn[r * (DA + 1) + i] * wj;
-                __syncthreads();
+            // the rows above: y[i] -= sum_r L[kb + r][i] w[kb + r]
+            for (int i = tid; i < kb; i += NT) {
+                double lv[FITW_NB];
+#pragma unroll
+                for (int r = 0; r < FITW_NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];     // all in flight together
+                double s = yv[i];
+#pragma unroll
+                for (int r = 0; r < FITW_NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
+                yv[i] = s;
             }
+            __syncthreads();
         }
+        FITW_PHASE(6);
         if (tid == 0) *flag = 0;
         __syncthreads();
         for (int e = tid; e < D; e += NT)
@@ -785,4 +933,9 @@ __global__ void __launch_bounds__(1024) k_fit_wide(SampleArgs a, int NBLK, doubl
         reg *= 10.0;
     }
     for (int e = tid; e < D; e += NT) a.coeffs[(long long)task * a.coeff_stride + e] = wv[e];
+#ifdef PROMP_DEV_STAMPS
+    if (task == 0 && tid == 0)
+        printf("k_fit_wide cycles: entry %llu | retry init %llu | panel load %llu | diagonal block %llu | rows below %llu | store + update %llu | back substitution %llu\n",
+               ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+#endif
 }

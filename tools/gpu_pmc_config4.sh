@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAVES"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/gpurun_out/pmc4/p$i -o p$i -- python $ROOT/bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/gpurun_out/pmc4/p$i.err
+  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/gpurun_out/pmc4/p$i -o p$i -- python $ROOT/bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-plugin-path > /dev/null 2> $ROOT/gpurun_out/pmc4/p$i.err
   echo "pmc pass $i rc=$?"
 done
 cd $ROOT
