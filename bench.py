@@ -91,7 +91,10 @@ def main():
         if args.shard_of > 1 and world == 1:
             task_ids = [i for i in range(M_global) if i % args.shard_of == 0]
         M = len(task_ids)
-        ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P, n_tasks_global=M_global, device_id=local_rank)
+        # (--shard-of: one rank's share timed alone, no collective -- the context is told its tasks are the whole batch, or the
+        #  library would refuse to apply a shard's sums as the meta-batch's; only the 1 / M scaling differs, not the work)
+        ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P,
+                           n_tasks_global=M if (args.shard_of > 1 and world == 1) else M_global, device_id=local_rank)
         if args.no_primal_cache:
             ctx.set_primal_cache(False)
         if args.force_primal_cache:
@@ -133,7 +136,8 @@ def main():
             from promp_amd.optimizers.conjugate_gradient_optimizer import ConjugateGradientOptimizer
             from promp_amd.utils import logger as plog
             plog.configure(quiet=True)
-            shim = SimpleNamespace(session=SimpleNamespace(ctx=ctx, M_global=M_global, world=world), num_inner_grad_steps=K,
+            shim = SimpleNamespace(session=SimpleNamespace(ctx=ctx, M_global=M_global, world=world, external=lambda: False,
+                                                           meta_eval=lambda *a, **k: ctx.meta_eval(*a, **k)), num_inner_grad_steps=K,
                                    inner_kind=_lib.INNER_LOGLIK, exploration=False, meta_batch_size=M)
             from promp_amd.optimizers.conjugate_gradient_optimizer import ExactDeviceHvp
             cgs = dict(finite_difference=ConjugateGradientOptimizer(), exact=ConjugateGradientOptimizer(hvp_approach=ExactDeviceHvp()))

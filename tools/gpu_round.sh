@@ -10,22 +10,22 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>
 timeout 900 python bench.py > $R/bench.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench.json | head -c 400; echo
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace -o trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $ROOT/$R/trace_bench.json 2> $ROOT/$R/trace.err; echo "trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace -o trace -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-plugin-path > $ROOT/$R/trace_bench.json 2> $ROOT/$R/trace.err; echo "trace rc=$?"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$R/pmc$i -o pmc$i -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/$R/pmc$i.err
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/$R/pmc$i -o pmc$i -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-plugin-path > /dev/null 2> $ROOT/$R/pmc$i.err
   echo "pmc pass $i rc=$?"
 done
 # BASELINE config 4 (Ant shapes, cooperative kernels): bench line + kernel trace
 timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 > $ROOT/$R/bench_config4.json 2> $ROOT/$R/bench_config4.err; echo "bench config4 rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace4 -o trace4 -- python $ROOT/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $ROOT/$R/trace4.err; echo "trace4 rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace4 -o trace4 -- python $ROOT/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-plugin-path > /dev/null 2> $ROOT/$R/trace4.err; echo "trace4 rc=$?"
 cd $ROOT; rm -f $R/trace4/*kernel_trace.csv
 # BASELINE config 5 (TRPO-MAML on config 3's shapes)
 timeout 600 python $ROOT/bench.py --config 5 --steps 5 --warmup 1 > $ROOT/$R/bench_config5.json 2> $ROOT/$R/bench_config5.err; echo "bench config5 rc=$?"
 # one rank's share of the fixed 40-task batch at 2 / 4 / 8 ranks, timed on this one GPU (no collective: kernels only)
 for n in 2 4 8; do
-  timeout 300 python $ROOT/bench.py --shard-of $n --steps 30 --warmup 3 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "
+  timeout 300 python $ROOT/bench.py --shard-of $n --steps 30 --warmup 3 --no-cpu-baseline --no-roofline --no-plugin-path --repeats 1 2> /dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('shard-of $n: %d tasks on this GPU, %.4f ms/step' % (d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/shard_timings.txt
 done
@@ -33,14 +33,14 @@ cat $ROOT/$R/shard_timings.txt
 # primal cache on (default rule) / forced off: full batch and shards, same box, back to back
 for n in 0 2 4 8; do for flag in "" "--no-primal-cache"; do
   sh=""; [ $n -gt 0 ] && sh="--shard-of $n"
-  timeout 300 python $ROOT/bench.py $sh --steps 30 --warmup 3 --no-cpu-baseline --no-roofline $flag 2> /dev/null | python -c "
+  timeout 300 python $ROOT/bench.py $sh --steps 30 --warmup 3 --no-cpu-baseline --no-roofline --no-plugin-path --repeats 1 $flag 2> /dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('%-12s %-18s %d tasks on this GPU, %.4f ms/step' % ('$sh' or 'full batch', '$flag' or 'default', d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/primal_cache_ab.txt
 done; done
 cat $ROOT/$R/primal_cache_ab.txt
 # staged uploads: kernel + memory-copy trace of a run fed only by promp_stage_step, and the copy / compute overlap in it
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $ROOT/$R/trace_staged -o staged -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --staged-only > $ROOT/$R/bench_staged.json 2> $ROOT/$R/trace_staged.err; echo "staged trace rc=$?"
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $ROOT/$R/trace_staged -o staged -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-plugin-path --staged-only > $ROOT/$R/bench_staged.json 2> $ROOT/$R/trace_staged.err; echo "staged trace rc=$?"
 cd $ROOT
 python tools/overlap.py $R/trace_staged > $R/h2d_overlap.txt 2>&1; cat $R/h2d_overlap.txt
 rm -f $R/trace_staged/*kernel_trace.csv $R/trace_staged/*memory_copy_trace.csv
