@@ -37,15 +37,23 @@ typedef struct promp_ctx promp_ctx;
 typedef struct promp_dims {
     int32_t n_tasks;            /* meta-tasks resident on this GPU (M_local)                       */
     int32_t n_tasks_global;     /* meta_batch_size over all ranks: the task-mean divides by this   */
-    int32_t obs_dim;            /* O, 1..128 (policy passes with O > 32 need hidden sizes 64 or 128)  */
-    int32_t act_dim;            /* A  (<= 8)                                                       */
-    int32_t hidden1, hidden2;   /* hidden_sizes: any two widths in 1..128 (policies/networks/mlp.py:5-62).  The kernels are
-                                 * instantiated for {32,64} x {32,64} (obs_dim <= 32) and (64,64) / (128,128); other widths
-                                 * run zero-padded on the next of those -- every parameter vector still crosses this ABI in the
-                                 * caller's layout (promp_param_count floats, policies/base.py:271-277 order)             */
+    int32_t obs_dim;            /* O, 1..1024.  The fused kernels serve O <= 32 (hidden widths from {32,64}) and O <= 128
+                                 * ((64,64) / (128,128)); everything else runs on the layer-by-layer kernels.
+                                 * LinearFeatureBaseline's fit (2 O + 4 features) exists for O <= 133                        */
+    int32_t act_dim;            /* A, 1..64 (fused kernels: A <= 8)                                */
+    int32_t hidden1, hidden2;   /* the first two of hidden_sizes (policies/networks/mlp.py:5-62 takes any tuple).  Two tanh
+                                 * layers of 1..128 units run on the fused kernels -- instantiated for {32,64} x {32,64}
+                                 * (obs_dim <= 32) and (64,64) / (128,128), other widths zero-padded on the next of those;
+                                 * wider layers (<= 256) and other depths run on the layer-by-layer kernels.  Every parameter
+                                 * vector crosses this ABI in the caller's layout (promp_param_count floats,
+                                 * policies/base.py:271-277 order)                                                          */
     int32_t num_inner_steps;    /* K = num_inner_grad_steps (>= 1)                                 */
     int32_t max_rows;           /* capacity: rows (env steps) per sampling step over local tasks   */
     int32_t max_paths;          /* capacity: paths per sampling step over local tasks              */
+    /* ---- ABI 3 ---- */
+    int32_t n_hidden;           /* len(hidden_sizes), 1..4; 0 means 2 (hidden1, hidden2)           */
+    int32_t hidden3, hidden4;   /* widths of the third / fourth hidden layer (n_hidden >= 3 / 4)    */
+    int32_t reserved;           /* 0                                                               */
 } promp_dims;
 
 enum { PROMP_BASELINE_ZERO = 0, PROMP_BASELINE_LINEAR_FEATURE = 1, PROMP_BASELINE_LINEAR_TIME = 2 };
@@ -76,10 +84,11 @@ typedef struct promp_proc_opts {
 int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* dims);
 void promp_ctx_destroy(promp_ctx* ctx);
 const char* promp_last_error(void);
-/* 2.  The version moves when an existing entry point changes its meaning or signature; entry points added since (round 3:
- * promp_set_reuse_adapt, promp_begin_collection / promp_end_collection, promp_state_version, the two pass counters; round 4:
- * promp_comm_fixed_order) and the wider range of hidden sizes are additions a binding built against the first v2 header
- * keeps working with. */
+/* 3.  The version moves when an existing entry point changes its meaning or signature: 3 = promp_dims grew by n_hidden,
+ * hidden3, hidden4 (hidden_sizes of any length 1..4; a v2 caller's two-layer struct is the same prefix, but the library reads the
+ * new fields, so bindings must be rebuilt).  Entry points added since the first v2 header -- round 3: promp_set_reuse_adapt,
+ * promp_begin_collection / promp_end_collection, promp_state_version, the two pass counters; round 4: promp_comm_fixed_order --
+ * were additions and did not move it. */
 int promp_abi_version(void);
 /* Theta = O*H1+H1 + H1*H2+H2 + H2*A+A + A */
 int promp_param_count(const promp_dims* dims);

@@ -29,7 +29,8 @@ class PrompError(RuntimeError):
 class Dims(C.Structure):
     _fields_ = [('n_tasks', C.c_int32), ('n_tasks_global', C.c_int32), ('obs_dim', C.c_int32), ('act_dim', C.c_int32),
                 ('hidden1', C.c_int32), ('hidden2', C.c_int32), ('num_inner_steps', C.c_int32),
-                ('max_rows', C.c_int32), ('max_paths', C.c_int32)]
+                ('max_rows', C.c_int32), ('max_paths', C.c_int32),
+                ('n_hidden', C.c_int32), ('hidden3', C.c_int32), ('hidden4', C.c_int32), ('reserved', C.c_int32)]
 
 
 class ProcOpts(C.Structure):
@@ -232,10 +233,11 @@ class Context:
                  n_tasks_global=None, device_id=0, lib=None):
         self.lib = lib or get_library()
         hs = tuple(int(h) for h in hidden_sizes)
-        if len(hs) != 2:
-            raise PrompError('hidden_sizes %r unsupported: this build implements two hidden layers' % (hidden_sizes,))
-        self.dims = Dims(int(n_tasks), int(n_tasks_global or n_tasks), int(obs_dim), int(act_dim), hs[0], hs[1],
-                         int(num_inner_steps), int(max_rows), int(max_paths))
+        if not 1 <= len(hs) <= 4:
+            raise PrompError('hidden_sizes %r unsupported: 1 to 4 hidden layers' % (hidden_sizes,))
+        h4 = hs + (0,) * (4 - len(hs))
+        self.dims = Dims(int(n_tasks), int(n_tasks_global or n_tasks), int(obs_dim), int(act_dim), h4[0], h4[1],
+                         int(num_inner_steps), int(max_rows), int(max_paths), len(hs), h4[2], h4[3], 0)
         self._h = _P()
         self.lib.check(self.lib.cdll.promp_ctx_create(C.byref(self._h), int(device_id), C.byref(self.dims)))
         self.n_params = self.lib.cdll.promp_param_count(C.byref(self.dims))

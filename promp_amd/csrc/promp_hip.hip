@@ -8,6 +8,7 @@
 #include "promp_kernels_policy_wide.h"
 #include "promp_kernels_sample.h"
 #include "promp_kernels_rollout.h"
+#include "promp_kernels_generic.h"
 #include "../../include/promp_hip.h"
 
 #include <algorithm>
@@ -133,6 +134,12 @@ struct promp_ctx {
     size_t smem_fwd = 0, smem_hvp = 0;
     size_t smem_pair = 0;              // k_pass_pair (the (64, 64) first-order pass at two waves per SIMD); 0: not this shape
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
+    // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
+    // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
+    bool generic = false;
+    int n_lin = 0, g_maxw = 0;
+    GenLin lin[GEN_MAX_LIN];
+    float *g_act[GEN_MAX_LIN] = {}, *g_ract[GEN_MAX_LIN] = {}, *g_mu = nullptr, *g_rmu = nullptr, *g_dz[2] = {}, *g_qz[2] = {};
     unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
     bool dbg_enabled = false;
     int* task_counters = nullptr;        // [tasks] arrival counters of the chain kernels' fused reductions (zero between launches)
@@ -236,30 +243,54 @@ struct StepScope {
     ~StepScope() { S.dirty = true; }
 };
 
+// hidden_sizes of a context: promp_dims carries up to four widths (n_hidden == 0: the two-layer struct of ABI 2)
+struct HiddenList {
+    int n;
+    int h[4];
+};
+static HiddenList hidden_list(const promp_dims* d) {
+    HiddenList L;
+    L.n = d->n_hidden > 0 ? d->n_hidden : 2;
+    L.h[0] = d->hidden1; L.h[1] = d->hidden2; L.h[2] = d->hidden3; L.h[3] = d->hidden4;
+    return L;
+}
 // which family of pass kernels serves a network shape (sample processing alone works for any obs_dim <= 128)
+bool policy_shape_generic(const promp_dims* d) {   // layer-by-layer kernels (promp_kernels_generic.h): everything the fused ones do not cover
+    const HiddenList L = hidden_list(d);
+    return L.n != 2 || d->obs_dim > 128 || d->act_dim > 8 || d->hidden1 > 128 || d->hidden2 > 128;
+}
 bool policy_shape_chain(const promp_dims* d) {     // register-chained kernels: hidden widths from {32, 64}, obs_dim <= 32
-    return d->obs_dim <= 32 && (d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64);
+    return !policy_shape_generic(d) && d->obs_dim <= 32 && (d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64);
 }
 bool policy_shape_coop(const promp_dims* d) {      // cooperative kernels: (128,128), or (64,64) with wide observations
-    return d->hidden1 == d->hidden2 && (d->hidden1 == 128 || (d->hidden1 == 64 && d->obs_dim > 32));
+    return !policy_shape_generic(d) && d->hidden1 == d->hidden2 && (d->hidden1 == 128 || (d->hidden1 == 64 && d->obs_dim > 32));
 }
 
 int check_dims(const promp_dims* d) {
     if (!d) return fail(-1, "dims is NULL");
     if (d->n_tasks < 1 || d->n_tasks_global < d->n_tasks) return fail(-1, "bad task counts (%d local, %d global)", d->n_tasks, d->n_tasks_global);
-    if (d->obs_dim < 1 || d->obs_dim > 128) return fail(-1, "obs_dim %d unsupported (1..128)", d->obs_dim);
-    if (d->act_dim < 1 || d->act_dim > 8) return fail(-1, "act_dim %d unsupported (1..8)", d->act_dim);
-    if (d->hidden1 < 1 || d->hidden2 < 1 || d->hidden1 > 128 || d->hidden2 > 128)
-        return fail(-1, "hidden sizes (%d,%d) unsupported: two tanh layers of 1..128 units each (narrower layers run zero-padded on the "
-                    "instantiated widths: every combination of {32, 64} for obs_dim <= 32, (64,64) / (128,128) otherwise)", d->hidden1, d->hidden2);
+    if (d->obs_dim < 1 || d->obs_dim > 1024) return fail(-1, "obs_dim %d unsupported (1..1024)", d->obs_dim);
+    if (d->act_dim < 1 || d->act_dim > GEN_MAX_A) return fail(-1, "act_dim %d unsupported (1..%d)", d->act_dim, GEN_MAX_A);
+    const HiddenList L = hidden_list(d);
+    if (d->n_hidden < 0 || L.n > 4) return fail(-1, "hidden_sizes of length %d unsupported (1..4 hidden layers)", L.n);
+    for (int l = 0; l < L.n; ++l)
+        if (L.h[l] < 1 || L.h[l] > GEN_MAX_N)
+            return fail(-1, "hidden size %d (layer %d) unsupported: tanh layers of 1..%d units.  Two layers of up to 128 units run on the fused "
+                        "kernels (narrower ones zero-padded on the instantiated widths: every combination of {32, 64} for obs_dim <= 32, "
+                        "(64,64) / (128,128) otherwise); wider layers and other depths on the layer-by-layer kernels", L.h[l], l, GEN_MAX_N);
     if (d->num_inner_steps < 1 || d->num_inner_steps > PROMP_ETA_MAX) return fail(-1, "num_inner_steps must be in [1, %d]", PROMP_ETA_MAX);
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
 }
 
 int param_count(const promp_dims* d) {
-    return d->obs_dim * d->hidden1 + d->hidden1 + d->hidden1 * d->hidden2 + d->hidden2 + d->hidden2 * d->act_dim +
-           d->act_dim + d->act_dim;
+    const HiddenList L = hidden_list(d);
+    int n = 0, in = d->obs_dim;
+    for (int l = 0; l < L.n; ++l) {
+        n += in * L.h[l] + L.h[l];
+        in = L.h[l];
+    }
+    return n + in * d->act_dim + d->act_dim + d->act_dim;
 }
 
 int feature_dim(const promp_dims* d, int kind) {
@@ -306,6 +337,59 @@ int prof_collect(promp_ctx* c) {
 }
 
 // ---- launches ----------------------------------------------------------------------------------
+// A pass on the layer-by-layer kernels (promp_kernels_generic.h): forward chain, loss level, then per layer (output first) the
+// weight gradient and the cotangent of the layer below.  One workgroup per entry of work table 0 in every launch; the partial
+// rows are the cooperative kernels' (one per work item, summed by k_reduce_task).
+#define PROMP_GEN_NBW(nbw, ...) \
+    switch (nbw) { case 1: { constexpr int NBW = 1; __VA_ARGS__ } break; case 2: { constexpr int NBW = 2; __VA_ARGS__ } break; \
+                   case 3: { constexpr int NBW = 3; __VA_ARGS__ } break; default: { constexpr int NBW = 4; __VA_ARGS__ } break; }
+int launch_pass_generic(promp_ctx* c, StepData& S, const PassArgs& a, bool hvp, bool fwd_only) {
+    GenArgs g;
+    memset(&g, 0, sizeof g);
+    g.work = a.work; g.task_row_offsets = a.task_row_offsets;
+    g.n_lin = c->n_lin;
+    for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
+    g.O = a.O; g.A = a.A; g.NP = c->NP;
+    g.theta = a.theta; g.theta_task_stride = a.theta_task_stride; g.vdir = a.vdir;
+    g.act[0] = a.obs;
+    for (int l = 1; l < c->n_lin; ++l) { g.act[l] = c->g_act[l]; g.out_act[l] = c->g_act[l]; g.ract[l] = c->g_ract[l]; }
+    g.mu = c->g_mu; g.rmu = c->g_rmu;
+    g.dz[0] = c->g_dz[0]; g.dz[1] = c->g_dz[1]; g.qz[0] = c->g_qz[0]; g.qz[1] = c->g_qz[1];
+    g.actions = a.act; g.adv = a.adv; g.old_mean = a.old_mean; g.old_log_std = a.old_log_std; g.ls_per_row = a.ls_per_row;
+    g.partials = a.partials; g.partial_stride = a.partial_stride;
+    g.loss_kind = a.loss_kind; g.clip_eps = a.clip_eps; g.clip_log_std = a.clip_log_std; g.min_log_std = a.min_log_std;
+    g.kl_weight = a.kl_weight; g.row_tan = a.row_tan;
+    const dim3 grid(S.n_work[0]);
+    // k_gen_linear: the 64-row rounds of a work item (about one CU's share of the rows) dealt to GEN_SPLIT workgroups
+    const dim3 lgrid(S.n_work[0], GEN_SPLIT);
+    hipStream_t st = c->stream;
+    for (int li = 0; li < c->n_lin; ++li) {
+        const int nbw = (c->lin[li].N + 63) / 64;
+        PROMP_GEN_NBW(nbw,
+            if (hvp) { auto k = k_gen_linear<GEN_FWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_FWD_T, NBW), st, g, li, 0); }
+            else { auto k = k_gen_linear<GEN_FWD, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_FWD, NBW), st, g, li, 0); })
+    }
+    if (hvp) { auto k = k_gen_loss<true, true>; PROMP_LAUNCH(k, grid, 256, 0, st, g, 0); }
+    else if (fwd_only) { auto k = k_gen_loss<false, false>; PROMP_LAUNCH(k, grid, 256, 0, st, g, 0); }
+    else { auto k = k_gen_loss<false, true>; PROMP_LAUNCH(k, grid, 256, 0, st, g, 0); }
+    int pp = 0;
+    for (int li = c->n_lin - 1; li >= 0 && !fwd_only; --li) {
+        const int nbw = (c->lin[li].N + 63) / 64;
+        const dim3 wgrid(S.n_work[0], (c->lin[li].K + GEN_KC - 1) / GEN_KC);     // one slab of 64 input units per workgroup
+        PROMP_GEN_NBW(nbw,
+            if (hvp) { auto k = k_gen_wgrad<2, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(2, c->lin[li].N), st, g, li, pp); }
+            else { auto k = k_gen_wgrad<1, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(1, c->lin[li].N), st, g, li, pp); })
+        if (li == 0) break;
+        const int nbk = (c->lin[li].K + 63) / 64;
+        PROMP_GEN_NBW(nbk,
+            if (hvp) { auto k = k_gen_linear<GEN_BWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_BWD_T, NBW), st, g, li, pp); }
+            else { auto k = k_gen_linear<GEN_BWD, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_BWD, NBW), st, g, li, pp); })
+        pp ^= 1;
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 // One policy pass over a step's slabs plus the per-task reduction that consumes it:
 //   red_mode RED_STEP / RED_OUTER / RED_HVP / RED_PLAIN / RED_SCAL (promp_kernels_chain.h).
 // k_chain_hvp can do both in one launch; k_pass and the cooperative kernels (hidden 128 / wide observations) are
@@ -315,14 +399,13 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
                 float* next, float* scal) {
     if (!S.has_policy) return fail(-3, "step has no actions / agent_infos uploaded");
     if (!S.has_adv) return fail(-3, "step has no advantages: call promp_process_samples or promp_set_advantages first");
-    if (!policy_shape_chain(&c->d) && !c->wide)
-        return fail(-1, "policy passes with obs_dim %d need hidden sizes (64,64) or (128,128); (%d,%d) is tiled for obs_dim <= 32",
-                    c->d.obs_dim, c->d.hidden1, c->d.hidden2);
+    if (!policy_shape_chain(&c->d) && !c->wide && !c->generic)
+        return fail(-1, "internal: no pass kernel for this policy shape");
     PassArgs a;
     memset(&a, 0, sizeof a);
     a.obs = S.obs; a.act = S.act; a.adv = c->pass_adv ? c->pass_adv : S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
     a.row_tan = hvp ? c->pass_row_tan : nullptr;
-    const int cache = (c->wide || fwd_only || !S.hcache) ? 0 : c->pass_cache;
+    const int cache = (c->wide || c->generic || fwd_only || !S.hcache) ? 0 : c->pass_cache;
     a.hcache = cache ? S.hcache : nullptr;
     if (cache == 1) S.cache_tag = ++c->cache_counter;
     a.ls_per_row = S.ls_per_row;
@@ -342,13 +425,15 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     // is exposed (66 us vs 46 + 5 us at 5 tasks); with 40 tasks the sums partly hide under other tasks' tiles, but since
     // k_reduce_task keeps eight rows per thread in flight the separate launch wins there too (123 + 5 us vs 137 us with the
     // primal cache, 147 + 5 vs 162 us without).  The in-launch form stays available (promp_set_schedule).
-    a.fuse_reduce = (hvp && !c->wide && c->d.n_tasks >= c->fuse_min_tasks) ? 1 : 0;
+    a.fuse_reduce = (hvp && !c->wide && !c->generic && c->d.n_tasks >= c->fuse_min_tasks) ? 1 : 0;
     a.red_mode = red_mode; a.step_sizes = c->step_sizes; a.cur = cur; a.cur_task_stride = cur_stride; a.next = next;
     a.lam = c->lam; a.v = c->vbuf; a.scal = scal;
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
     const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
     if (prof_begin(c, id, S.n_rows)) return -2;
-    if (c->wide) {
+    if (c->generic) {
+        if (launch_pass_generic(c, S, a, hvp, fwd_only)) return -2;
+    } else if (c->wide) {
         // cooperative kernels (promp_kernels_policy_wide.h): hidden 128, or hidden 64 with obs_dim > 32
         const int nob = c->d.obs_dim <= 32 ? 2 : c->d.obs_dim <= 64 ? 4 : 8;
         const size_t sm = hvp ? c->smem_hvp : c->smem_fwd;
@@ -394,7 +479,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     ReduceArgs r;
     r.partials = c->partials; r.partial_stride = c->partial_stride;
     // the register-chained kernels write one row per segment
-    r.task_wg_offsets = c->wide ? S.task_wg_offsets[0] : S.chain_slot_offsets;
+    r.task_wg_offsets = (c->wide || c->generic) ? S.task_wg_offsets[0] : S.chain_slot_offsets;
     r.NP = c->NP;
     r.step_sizes = c->step_sizes; r.mode = red_mode;
     r.cur = cur; r.cur_task_stride = cur_stride; r.next = next;
@@ -598,7 +683,7 @@ int alloc_step(promp_ctx* c, StepData& S) {
 extern "C" {
 
 const char* promp_last_error(void) { return g_err.c_str(); }
-int promp_abi_version(void) { return 2; }
+int promp_abi_version(void) { return 3; }
 
 // The kernels are instantiated for hidden widths from {32, 64} in any combination (obs_dim <= 32) and for (64,64) / (128,128).
 // Any other pair of widths up to 128 runs EMBEDDED in the next instantiated shape: the extra hidden units have zero incoming and
@@ -607,6 +692,7 @@ int promp_abi_version(void) { return 2; }
 // the caller's (unpadded) layout (policies/networks/mlp.py:5-62 takes any hidden_sizes; policies/base.py:271-277 fixes the order).
 static void pad_dims(const promp_dims* u, promp_dims* p) {
     *p = *u;
+    if (policy_shape_generic(u)) return;          // the layer-by-layer kernels take any width as it is
     auto up = [](int h) { return h <= 32 ? 32 : h <= 64 ? 64 : 128; };
     int a = up(u->hidden1), b = up(u->hidden2);
     if (u->obs_dim > 32) a = b = std::max(std::max(a, b), 64);
@@ -678,14 +764,29 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     }
     const int K = dims->num_inner_steps, M = dims->n_tasks;
     c->NP = param_count(dims);
-    c->Dmax = 2 * dims->obs_dim + 4;
+    // (observations wider than 128: the baseline fit's Gram / Cholesky kernels are not tiled for 2 obs_dim + 5 columns; such
+    //  contexts fit LinearTimeBaseline / no baseline on the device, or take advantages through promp_set_advantages)
+    c->Dmax = dims->obs_dim <= 128 ? 2 * dims->obs_dim + 4 : 4;
     c->coeff_stride = c->Dmax;
     c->max_work = 2 * c->n_cus + M;
     c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
     c->gram_stride = nblk_max * (nblk_max + 1) / 2 * 256;
     c->wide = policy_shape_coop(dims);
-    if (c->wide) {
+    c->generic = policy_shape_generic(dims);
+    if (c->generic) {
+        const HiddenList L = hidden_list(dims);
+        int in = dims->obs_dim, off = 0;
+        c->n_lin = L.n + 1;
+        c->g_maxw = dims->act_dim;
+        for (int l = 0; l <= L.n; ++l) {
+            const int out = l < L.n ? L.h[l] : dims->act_dim;
+            c->lin[l] = GenLin{in, out, off, off + in * out};
+            off += in * out + out;
+            if (out > c->g_maxw) c->g_maxw = out;
+            in = out;
+        }
+    } else if (c->wide) {
         const int nob = dims->obs_dim <= 32 ? 2 : dims->obs_dim <= 64 ? 4 : 8;
         c->smem_fwd = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
         c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
@@ -707,7 +808,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
 #endif
     const char* pair_env = getenv("PROMP_PASS_PAIR");
     const bool want_pair = pair_env ? atoi(pair_env) != 0 : PROMP_PASS_PAIR != 0;
-    if (want_pair && !c->wide && dims->hidden1 == 64 && dims->hidden2 == 64) {
+    if (want_pair && !c->wide && !c->generic && dims->hidden1 == 64 && dims->hidden2 == 64) {
         promp_dims pd = *dims;
         if (pd.obs_dim > 32) pd.obs_dim = 32;
         c->smem_pair = sizeof(float) * (size_t)pass2_layout(param_count(&pd)).total;
@@ -766,6 +867,20 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
             HIPCHECK(hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         HIPCHECK(hipFuncSetAttribute((const void*)k_gram_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define PROMP_GEN_ATTR(NBW)                                                                                            \
+    {                                                                                                                \
+        auto w1 = k_gen_wgrad<1, NBW>; auto w2 = k_gen_wgrad<2, NBW>;                                                 \
+        auto l0 = k_gen_linear<GEN_FWD, NBW>; auto l1 = k_gen_linear<GEN_FWD_T, NBW>;                                 \
+        auto l2 = k_gen_linear<GEN_BWD, NBW>; auto l3 = k_gen_linear<GEN_BWD_T, NBW>;                                 \
+        HIPCHECK(hipFuncSetAttribute((const void*)l0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)l1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)l2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)l3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+    }
+        PROMP_GEN_ATTR(1) PROMP_GEN_ATTR(2) PROMP_GEN_ATTR(3) PROMP_GEN_ATTR(4)
+#undef PROMP_GEN_ATTR
         HIPCHECK(hipFuncSetAttribute((const void*)k_fit_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const size_t NP = c->NP, MNP = (size_t)M * NP;
@@ -786,6 +901,15 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         rc |= dev_alloc(&c->fit_scratch_side, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
     }
     rc |= dev_alloc(&c->red64, 64);
+    if (c->generic) {
+        const size_t R = (size_t)dims->max_rows;
+        for (int l = 1; l < c->n_lin; ++l) {
+            rc |= dev_alloc(&c->g_act[l], R * c->lin[l].K);
+            rc |= dev_alloc(&c->g_ract[l], R * c->lin[l].K);
+        }
+        rc |= dev_alloc(&c->g_mu, R * dims->act_dim); rc |= dev_alloc(&c->g_rmu, R * dims->act_dim);
+        for (int i = 0; i < 2; ++i) { rc |= dev_alloc(&c->g_dz[i], R * c->g_maxw); rc |= dev_alloc(&c->g_qz[i], R * c->g_maxw); }
+    }
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
     if (hipHostMalloc((void**)&c->stats_host, sizeof(float) * (2 * (K + 2) + 1), hipHostMallocDefault) != hipSuccess) rc |= 1;
@@ -817,6 +941,12 @@ void promp_ctx_destroy(promp_ctx* c) {
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int l = 0; l < GEN_MAX_LIN; ++l) {
+        if (c->g_act[l]) (void)hipFree(c->g_act[l]);
+        if (c->g_ract[l]) (void)hipFree(c->g_ract[l]);
+    }
+    for (float* p : {c->g_mu, c->g_rmu, c->g_dz[0], c->g_dz[1], c->g_qz[0], c->g_qz[1]})
         if (p) (void)hipFree(p);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
     if (c->stats_seq_host) (void)hipHostFree(c->stats_seq_host);
@@ -1109,6 +1239,9 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (!(o->discount >= 0 && o->discount <= 1)) return fail(-1, "discount factor must be in [0,1]");      // samplers/base.py:57
     if (!(o->gae_lambda >= 0 && o->gae_lambda <= 1)) return fail(-1, "gae_lambda must be in [0,1]");       // samplers/base.py:58
     if (o->baseline_kind < 0 || o->baseline_kind > 2) return fail(-1, "unknown baseline kind %d", o->baseline_kind);
+    if (o->baseline_kind == PROMP_BASELINE_LINEAR_FEATURE && c->d.obs_dim > 128)
+        return fail(-1, "LinearFeatureBaseline's fit is tiled for obs_dim <= 128 (%d here: %d feature columns); fit LinearTimeBaseline / no "
+                    "baseline on the device, or hand advantages in through promp_set_advantages", c->d.obs_dim, 2 * c->d.obs_dim + 5);
     SampleArgs a;
     a.obs = S.obs; a.rew = S.rew; a.rew64 = S.has_rew64 ? S.rew64 : nullptr; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
     a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets;
@@ -1140,7 +1273,8 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (a.kind != BASE_ZERO) {
         const int nblk = (a.D + 1 + 15) / 16;
         if (prof_begin(c, PROMP_KERNEL_GRAM, S.n_rows)) return -2;
-        const bool small = nblk <= 5 && a.O <= 32;   // k_gram<NBLK> stages raw observation rows of at most 32 floats
+        // k_gram<NBLK> stages raw observation rows of at most 32 floats (LinearTimeBaseline reads no observations: any obs_dim)
+        const bool small = nblk <= 5 && (a.O <= 32 || a.kind != BASE_LINFEAT);
         switch (small ? nblk : 0) {
             case 1: { auto k = k_gram<1>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<1>::NW, GramCfg<1>::SMEM_BYTES, st, a); } break;
             case 2: { auto k = k_gram<2>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<2>::NW, GramCfg<2>::SMEM_BYTES, st, a); } break;
@@ -1278,7 +1412,7 @@ int promp_set_advantages(promp_ctx* c, int step, const float* adv) {
 int promp_set_dice_rewards(promp_ctx* c, int step, const float* rw) {
     if (!c || !rw) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
-    if (c->wide) return fail(-1, "the DiCE objective is built on the register-chained kernels (hidden sizes from {32,64}, obs_dim <= 32)");
+    if (c->wide || c->generic) return fail(-1, "the DiCE objective is built on the register-chained kernels (hidden sizes from {32,64}, obs_dim <= 32)");
     StepData& S = c->steps[step];
     StepScope scope_(c, S);
     if (scope_.rc) return -2;
@@ -1475,10 +1609,11 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     if (batch < 1) return fail(-1, "batch must be positive");
     const int M = c->d.n_tasks, O = c->d.obs_dim, A = c->d.act_dim;
     const size_t n_obs = (size_t)M * batch * O, n_out = (size_t)M * batch * A;
-    if (n_obs + n_out > c->fwd_capacity) {
+    const size_t n_scr = c->generic ? (size_t)M * batch * 2 * c->g_maxw : 0;
+    if (n_obs + n_out + n_scr > c->fwd_capacity) {
         if (c->fwd_buf) (void)hipFree(c->fwd_buf);
         c->fwd_buf = nullptr;
-        c->fwd_capacity = 2 * (n_obs + n_out);
+        c->fwd_capacity = 2 * (n_obs + n_out + n_scr);
         HIPCHECK(hipMalloc((void**)&c->fwd_buf, sizeof(float) * c->fwd_capacity));
     }
     float* d_obs = c->fwd_buf;
@@ -1488,6 +1623,13 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     if (tasks_materialize(c)) return -2;
     f.obs = d_obs; f.theta_tasks = c->theta_tasks; f.mean = d_out;
     f.B = batch; f.O = O; f.A = A; f.H1 = c->d.hidden1; f.H2 = c->d.hidden2;
+    if (c->generic) {
+        GenForwardArgs gf;
+        gf.obs = d_obs; gf.theta_tasks = c->theta_tasks; gf.mean = d_out; gf.scratch = d_out + n_out;
+        gf.B = batch; gf.NP = c->NP; gf.n_lin = c->n_lin; gf.maxw = c->g_maxw;
+        for (int l = 0; l < c->n_lin; ++l) gf.lin[l] = c->lin[l];
+        PROMP_LAUNCH(k_gen_policy_forward, dim3(M), 256, 0, c->stream, gf);
+    } else
     PROMP_LAUNCH(k_policy_forward, dim3(M), 256, 0, c->stream, f);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(mean_out, d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, c->stream));
@@ -1531,7 +1673,7 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     if (!c || !goals || !start || !o) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (c->d.obs_dim != 2 || c->d.act_dim != 2) return fail(-1, "the point environment has obs_dim = act_dim = 2 (context: %d, %d)", c->d.obs_dim, c->d.act_dim);
-    if (c->d.hidden1 > 128 || c->d.hidden2 > 128) return fail(-1, "hidden widths above 128 are not supported by the rollout kernels");
+    if (c->generic) return fail(-1, "the rollout kernels serve two hidden layers of up to 128 units, act_dim <= 8, obs_dim <= 128");
     if (o->reward_type < 0 || o->reward_type > 2) return fail(-1, "unknown reward type %d", o->reward_type);
     if (begin_fixed_rollout(c, step, envs_per_task, path_length)) return -2;
     const int M = c->d.n_tasks, B = envs_per_task, T = path_length;
@@ -1563,7 +1705,7 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
 
 int promp_begin_rollout(promp_ctx* c, int step, int envs_per_task, int path_length) {
     if (!c) return fail(-1, "ctx is NULL");
-    if (c->d.hidden1 > 128 || c->d.hidden2 > 128 || c->d.act_dim > 8) return fail(-1, "shape not supported by the rollout kernels");
+    if (c->generic) return fail(-1, "the rollout kernels serve two hidden layers of up to 128 units, act_dim <= 8, obs_dim <= 128");
     if (begin_fixed_rollout(c, step, envs_per_task, path_length)) return -2;
     c->steps[step].rollout_ragged = false;
     return 0;
@@ -1572,7 +1714,7 @@ int promp_begin_rollout(promp_ctx* c, int step, int envs_per_task, int path_leng
 int promp_begin_collection(promp_ctx* c, int step, int envs_per_task, int max_steps) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
-    if (c->d.hidden1 > 128 || c->d.hidden2 > 128 || c->d.act_dim > 8) return fail(-1, "shape not supported by the rollout kernels");
+    if (c->generic) return fail(-1, "the rollout kernels serve two hidden layers of up to 128 units, act_dim <= 8, obs_dim <= 128");
     if (envs_per_task < 1 || max_steps < 1) return fail(-1, "envs_per_task and max_steps must be positive");
     StepData& S = c->steps[step];
     StepScope scope_(c, S);

@@ -1,0 +1,510 @@
+// promp_kernels_generic.h -- the policy passes for ANY tanh-MLP shape the reference's create_mlp can build
+// (policies/networks/mlp.py:5-62): 1 .. 4 hidden layers, widths up to 256, obs_dim up to 1024, act_dim up to 64 -- e.g. three
+// hidden layers, or the reference's Humanoid environments (376 observations, 17 actions:
+// envs/mujoco_envs/humanoid_rand_direc.py:34-41), which the fused kernels (k_pass / k_chain_hvp: two layers of 32 / 64 units,
+// obs_dim <= 32; k_wide_*: (64,64) / (128,128), obs_dim <= 128, act_dim <= 8) do not cover.
+//
+// Same mathematics (oracle/promp.py: loss_and_grad, hvp), same PassArgs semantics, same partial rows (one per work item, summed
+// by k_reduce_task) as those kernels -- but layer by layer, one launch per layer and direction, with every layer's activations
+// and cotangents in global memory: a pass is a chain of
+//     k_gen_linear<FWD | FWD_T>  (per layer)   H_l = tanh(H_{l-1} W_l + b_l)       [+ tangent R'H_l along -v]
+//     k_gen_loss / k_gen_loss_hvp               objective, KL, cotangents of the mean [+ their tangents], log_std terms
+//     k_gen_wgrad<1 | 2>         (per layer)   dW_l = H_{l-1}^T dZ_l, db_l           [R-operator: R'H^T dZ + H^T qZ]
+//     k_gen_linear<BWD | BWD_T>  (per layer)   dZ_{l-1} = (dZ_l W_l^T) (1 - H^2)     [+ qZ_{l-1}]
+// It is the general fallback, not the fast path: activations travel through HBM / the Infinity Cache between the launches
+// (the fused kernels keep them in registers), the GEMMs are exact-FP32 MFMA (v_mfma_f32_16x16x4_f32) on LDS-staged row tiles.
+//
+// R-operator convention (as k_chain_hvp): the direction is u = -v, so that the pass yields -H v directly; the KL term of the
+// inner objective (kl_weight x grad KL) joins at the mean level.
+#pragma once
+#include "promp_kernels_policy.h"
+
+#define GEN_MAX_LIN 5          // linear layers: up to 4 hidden + the output layer
+#define GEN_R 64               // rows per chunk (4 row blocks of 16)
+#define GEN_KC 64              // contraction entries staged per chunk
+#define GEN_LD (GEN_KC + 16)   // LDS row stride of a staged chunk of k_gen_wgrad (4 rows x 16 columns of an operand read: 64 banks)
+#define GEN_RW 32              // rows per chunk of the weight-gradient kernel (its LDS also holds the cotangent rows)
+#define GEN_MAX_N 256          // widest layer output (4 waves x 4 column blocks of 16)
+#define GEN_MAX_A 64
+#define GEN_SPLIT 4            // workgroups per work item of k_gen_linear
+
+struct GenLin {
+    int K, N;                  // in / out width
+    int w_off, b_off;          // offsets of the kernel [K][N] and the bias [N] in the parameter vector (reference order)
+};
+
+struct GenArgs {
+    const WorkItem* work;              // one row range of one task per workgroup (table 0)
+    const int* task_row_offsets;
+    int n_lin;                         // hidden layers + 1
+    GenLin lin[GEN_MAX_LIN];
+    int O, A, NP;
+    const float* theta;                // [Theta] or [tasks][Theta]
+    long long theta_task_stride;
+    const float* vdir;                 // R-operator passes: [tasks][Theta]
+    // activations, row-major: act[0] = observations [rows][O], act[l] = output of hidden layer l [rows][N_l]; ract = tangents
+    const float* act[GEN_MAX_LIN];
+    float* ract[GEN_MAX_LIN];
+    float* out_act[GEN_MAX_LIN];       // (writable aliases of act[1..])
+    float *mu, *rmu;                   // [rows][A]
+    float *dz[2], *qz[2];              // cotangent ping-pong buffers [rows][<= GEN_MAX_N]
+    // row data
+    const float *actions, *adv, *old_mean, *old_log_std;
+    int ls_per_row;
+    float* partials;
+    int partial_stride;
+    int loss_kind;
+    float clip_eps;
+    int clip_log_std;
+    float min_log_std;
+    float kl_weight;
+    float* row_tan;
+};
+
+enum { GEN_FWD = 0, GEN_FWD_T = 1, GEN_BWD = 2, GEN_BWD_T = 3 };
+PROMP_HD int gen_wgrad_ld(int N) { return 64 * ((N + 63) / 64) + 16; }
+PROMP_HD size_t gen_wgrad_smem(int nt, int N) { return sizeof(float) * (size_t)nt * GEN_RW * (GEN_LD + gen_wgrad_ld(N)); }
+
+// LDS of k_gen_linear: NA row tiles [GEN_R][GEN_LA] (the layer's input rows / cotangent rows, and their tangents) and NB weight
+// tiles [GEN_KL][ncols + 16] (the layer's kernel, and the direction's), one chunk of GEN_KL contraction entries at a time.
+// Row strides: GEN_LA = 36 and (64 NBW + 16) put the 64 lanes of an MFMA operand read on 64 different banks.
+#define GEN_KL 32
+#define GEN_LA (GEN_KL + 4)
+PROMP_HD size_t gen_linear_smem(int mode, int nbw) {
+    const int nt = (mode == 1 || mode == 3) ? 2 : 1;
+    return sizeof(float) * (size_t)nt * (GEN_R * GEN_LA + GEN_KL * (64 * nbw + 16));
+}
+
+// k_gen_linear: one linear layer over the work item's rows, forward or backward, primal or primal + tangent.
+//   FWD   : H = f(X W + b)                                        f = tanh (hidden) or identity (li == n_lin - 1: the means)
+//   FWD_T : ... and R'H = f'(.) (R'X W + X U + ub),  U = -v's slice (R'X = 0 for the observations)
+//   BWD   : dZ_prev = (dZ W^T) (1 - H_prev^2)                     (li >= 1: the gradient stops at the observations)
+//   BWD_T : ... and qZ_prev = (qZ W^T + dZ U^T) (1 - H_prev^2) - 2 (dZ W^T) H_prev R'H_prev
+// Exact-FP32 MFMA (v_mfma_f32_16x16x4_f32) on LDS-staged tiles: 64 rows x the whole output width per round, wave w owns the
+// column blocks w, w + 4, ...; the tangent products share the staged tiles with the primal one.
+// grid = work items, block = 256, smem = gen_linear_smem(MODE, NBW).  NBW = column blocks per wave (output width <= 64 NBW).
+template <int MODE, int NBW>
+__global__ void __launch_bounds__(256) k_gen_linear(GenArgs a, int li, int pp) {
+    PROMP_SMEM_DECL;
+    constexpr bool TAN = MODE == GEN_FWD_T || MODE == GEN_BWD_T;
+    constexpr bool FWD = MODE == GEN_FWD || MODE == GEN_FWD_T;
+    constexpr int NCS = 64 * NBW + 16;
+    float* As = (float*)PROMP_SMEM_PTR;                       // [GEN_R][GEN_LA]
+    float* RAs = As + GEN_R * GEN_LA;                         // (TAN)
+    float* Bs = As + (TAN ? 2 : 1) * GEN_R * GEN_LA;          // [GEN_KL][NCS]
+    float* Us = Bs + GEN_KL * NCS;                            // (TAN) minus the direction's kernel
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), i16 = lane & 15, kk = lane >> 4;
+    const WorkItem wk = a.work[blockIdx.x];
+    const GenLin Ly = a.lin[li];
+    const float* th = a.theta + (long long)wk.task * a.theta_task_stride;
+    const float* W = th + Ly.w_off;
+    const float* U = TAN ? a.vdir + (long long)wk.task * a.NP + Ly.w_off : nullptr;
+    const bool last = li == a.n_lin - 1;
+    const int Kc = FWD ? Ly.K : Ly.N;            // contraction length
+    const int Nc = FWD ? Ly.N : Ly.K;            // output width
+    const float* Ain = FWD ? a.act[li] : a.dz[pp];                       // rows of width Kc
+    const float* RAin = !TAN ? nullptr : FWD ? (li > 0 ? a.ract[li] : nullptr) : a.qz[pp];
+    // (the rounds of a work item are dealt to gridDim.y workgroups: more waves per CU to hide the staging latency)
+    for (int row0 = wk.row_begin + GEN_R * (int)blockIdx.y; row0 < wk.row_end; row0 += GEN_R * (int)gridDim.y) {
+        const int nrows = wk.row_end - row0 < GEN_R ? wk.row_end - row0 : GEN_R;
+        f32x4 acc[4][NBW], racc[4][NBW];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) acc[rb][c] = racc[rb][c] = zero4();
+        for (int k0 = 0; k0 < Kc; k0 += GEN_KL) {
+            // every load of the round is issued before the first wait: clamped (always valid) addresses, zeros selected afterwards
+            constexpr int NLA = GEN_R * GEN_KL / 256, NLB = GEN_KL * 64 * NBW / 256;
+            float va[NLA], vra[NLA], vb[NLB], vu[NLB];
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                const int e = tid + 256 * i, r = e >> 5, k = e & 31;
+                const int rr = r < nrows ? r : nrows - 1, kc = k0 + k < Kc ? k0 + k : Kc - 1;
+                const long long o = (long long)(row0 + rr) * Kc + kc;
+                va[i] = Ain[o];
+                if (TAN) vra[i] = RAin != nullptr ? RAin[o] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                const int e = tid + 256 * i;
+                long long o;
+                if (FWD) {
+                    const int k = e / (64 * NBW), n = e - k * (64 * NBW);
+                    o = (long long)(k0 + k < Kc ? k0 + k : Kc - 1) * Ly.N + (n < Nc ? n : Nc - 1);
+                } else {
+                    // contraction over the layer's output units n, output columns = its input units k:  B[n][k] = W[k][n]
+                    const int n = e & 31, k = e >> 5;
+                    o = (long long)(k < Nc ? k : Nc - 1) * Ly.N + (k0 + n < Kc ? k0 + n : Kc - 1);
+                }
+                vb[i] = W[o];
+                if (TAN) vu[i] = U[o];
+            }
+            __syncthreads();                 // the previous chunk's products are done with the tiles
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) {
+                const int e = tid + 256 * i, r = e >> 5, k = e & 31;
+                const bool ok = r < nrows && k0 + k < Kc;
+                As[r * GEN_LA + k] = ok ? va[i] : 0.f;
+                if (TAN) RAs[r * GEN_LA + k] = ok ? vra[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
+                const int e = tid + 256 * i;
+                int kl, col;
+                if (FWD) { kl = e / (64 * NBW); col = e - kl * (64 * NBW); }
+                else { kl = e & 31; col = e >> 5; }
+                const bool ok = k0 + kl < Kc && col < Nc;
+                Bs[kl * NCS + col] = ok ? vb[i] : 0.f;
+                if (TAN) Us[kl * NCS + col] = ok ? -vu[i] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int s = 0; s < GEN_KL / 4; ++s) {
+                float av[4], rav[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    av[rb] = As[(16 * rb + i16) * GEN_LA + 4 * s + kk];
+                    if (TAN) rav[rb] = RAs[(16 * rb + i16) * GEN_LA + 4 * s + kk];
+                }
+#pragma unroll
+                for (int c = 0; c < NBW; ++c) {
+                    const int col = 16 * (w + 4 * c) + i16;
+                    const float bv = Bs[(4 * s + kk) * NCS + col];
+                    const float uv = TAN ? Us[(4 * s + kk) * NCS + col] : 0.f;
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        acc[rb][c] = mfma16(av[rb], bv, acc[rb][c]);
+                        if (TAN) {
+                            racc[rb][c] = mfma16(av[rb], uv, racc[rb][c]);
+                            racc[rb][c] = mfma16(rav[rb], bv, racc[rb][c]);
+                        }
+                    }
+                }
+            }
+        }
+        if (FWD) {
+            float* Hout = last ? a.mu : a.out_act[li + 1];
+            float* RHout = last ? a.rmu : a.ract[li + 1];
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) {
+                const int col = 16 * (w + 4 * c) + i16;
+                if (col < Nc) {
+                    const float b = th[Ly.b_off + col];
+                    const float ub = TAN ? -a.vdir[(long long)wk.task * a.NP + Ly.b_off + col] : 0.f;
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * rb + 4 * kk + r;
+                            if (row < nrows) {
+                                const float z = acc[rb][c][r] + b;
+                                const float h = last ? z : fast_tanh(z);
+                                Hout[(long long)(row0 + row) * Nc + col] = h;
+                                if (TAN) {
+                                    const float rz = racc[rb][c][r] + ub;
+                                    RHout[(long long)(row0 + row) * Nc + col] = last ? rz : (1.f - h * h) * rz;
+                                }
+                            }
+                        }
+                }
+            }
+        } else {
+            const float* Hp = a.act[li];                 // this layer's input = the previous hidden layer's output
+            const float* RHp = a.ract[li];
+            float* DZo = a.dz[pp ^ 1];
+            float* QZo = a.qz[pp ^ 1];
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) {
+                const int col = 16 * (w + 4 * c) + i16;
+                if (col < Nc) {
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * rb + 4 * kk + r;
+                            const long long o = (long long)(row0 + (row < nrows ? row : nrows - 1)) * Nc + col;
+                            const float h = Hp[o], rh = TAN ? RHp[o] : 0.f, d1 = 1.f - h * h, dx = acc[rb][c][r];
+                            if (row < nrows) {
+                                DZo[o] = dx * d1;
+                                if (TAN) QZo[o] = racc[rb][c][r] * d1 - 2.f * dx * h * rh;
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
+// k_gen_wgrad: this work item's share of a layer's kernel / bias gradient into its partial row:
+//   NT = 1 :  P[w_off + k N + n]  = sum_rows X[r][k] dZ[r][n]                 P[b_off + n] = sum_rows dZ[r][n]
+//   NT = 2 :  ... = sum_rows R'X[r][k] dZ[r][n] + X[r][k] qZ[r][n]            ... = sum_rows qZ[r][n]
+// The output is walked in slabs of 64 input units (4 blocks of 16) x the whole output width: 4 x NBW tiles per wave in
+// registers; the rows are streamed through LDS once per slab (64-row chunks: the input slab [64][64] and the cotangents [64][N]).
+// Sums run in row order inside a workgroup: bitwise reproducible.
+// grid = work items, block = 256.
+template <int NT, int NBW>
+__global__ void __launch_bounds__(256) k_gen_wgrad(GenArgs a, int li, int pp) {
+    PROMP_SMEM_DECL;
+    float* Xs = (float*)PROMP_SMEM_PTR;                    // [NT][GEN_RW][GEN_LD]
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), i16 = lane & 15, kk = lane >> 4;
+    const WorkItem wk = a.work[blockIdx.x];
+    const GenLin Ly = a.lin[li];
+    const int K = Ly.K, N = Ly.N, NL = gen_wgrad_ld(N);
+    float* Ds = Xs + NT * GEN_RW * GEN_LD;                  // [NT][GEN_RW][NL]
+    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    const float* X = a.act[li];
+    const float* RX = (NT == 2 && li > 0) ? a.ract[li] : nullptr;
+    const float* DZ = a.dz[pp];
+    const float* QZ = NT == 2 ? a.qz[pp] : nullptr;
+    // (one slab of 64 input units per blockIdx.y: the slabs' entries of the partial row are disjoint)
+    for (int kb0 = GEN_KC * (int)blockIdx.y; kb0 < K; kb0 += GEN_KC * (int)gridDim.y) {
+        f32x4 acc[4][NBW];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) acc[q][c] = zero4();
+        float bsum = 0.f;                                  // bias gradient of column tid (first slab only)
+        for (int row0 = wk.row_begin; row0 < wk.row_end; row0 += GEN_RW) {
+            const int nrows = wk.row_end - row0 < GEN_RW ? wk.row_end - row0 : GEN_RW;
+            // loads with clamped (always valid) addresses, all in flight together; zeros are selected on the way into LDS
+            constexpr int NLX = GEN_RW * GEN_KC / 256;
+            float vx[NLX], vrx[NLX];
+#pragma unroll
+            for (int i = 0; i < NLX; ++i) {
+                const int e = tid + 256 * i, r = e >> 6, k = e & 63;
+                const long long o = (long long)(row0 + (r < nrows ? r : nrows - 1)) * K + (kb0 + k < K ? kb0 + k : K - 1);
+                vx[i] = X[o];
+                if (NT == 2) vrx[i] = RX != nullptr ? RX[o] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NLX; ++i) {
+                const int e = tid + 256 * i, r = e >> 6, k = e & 63;
+                const bool ok = r < nrows && kb0 + k < K;
+                Xs[r * GEN_LD + k] = ok ? vx[i] : 0.f;
+                if (NT == 2) Xs[(GEN_RW + r) * GEN_LD + k] = ok ? vrx[i] : 0.f;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NBW; ++cb) {             // 64 output units at a time: [32][64] = 8 values per thread
+                float vd[NLX], vq[NLX];
+#pragma unroll
+                for (int i = 0; i < NLX; ++i) {
+                    const int e = tid + 256 * i, r = e >> 6, n = 64 * cb + (e & 63);
+                    const long long o = (long long)(row0 + (r < nrows ? r : nrows - 1)) * N + (n < N ? n : N - 1);
+                    vd[i] = DZ[o];
+                    if (NT == 2) vq[i] = QZ[o];
+                }
+#pragma unroll
+                for (int i = 0; i < NLX; ++i) {
+                    const int e = tid + 256 * i, r = e >> 6, n = 64 * cb + (e & 63);
+                    const bool ok = r < nrows && n < N;
+                    Ds[r * NL + n] = ok ? vd[i] : 0.f;
+                    if (NT == 2) Ds[(GEN_RW + r) * NL + n] = ok ? vq[i] : 0.f;
+                }
+            }
+            __syncthreads();
+            if (kb0 == 0 && tid < N) {
+                const float* src = Ds + (NT == 2 ? GEN_RW * NL : 0) + tid;
+                for (int r = 0; r < GEN_RW; ++r) bsum += src[r * NL];
+            }
+            // contraction over the chunk's rows: 16 steps of 4 rows; A[i = input unit][k = row], B[k = row][j = output unit]
+            for (int s = 0; s < GEN_RW / 4; ++s) {
+                const int r = 4 * s + kk;
+                float av[4], rav[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    av[q] = Xs[r * GEN_LD + 16 * q + i16];
+                    if (NT == 2) rav[q] = Xs[(GEN_RW + r) * GEN_LD + 16 * q + i16];
+                }
+#pragma unroll
+                for (int c = 0; c < NBW; ++c) {
+                    const int col = 16 * (w + 4 * c) + i16;
+                    const float dv = col < N ? Ds[r * NL + col] : 0.f;
+                    const float qv = (NT == 2 && col < N) ? Ds[(GEN_RW + r) * NL + col] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (NT == 1) acc[q][c] = mfma16(av[q], dv, acc[q][c]);
+                        else {
+                            acc[q][c] = mfma16(rav[q], dv, acc[q][c]);
+                            acc[q][c] = mfma16(av[q], qv, acc[q][c]);
+                        }
+                    }
+                }
+            }
+        }
+        // D: col = i16 (output unit), row = 4 kk + r (input unit of block q)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < NBW; ++c) {
+                const int col = 16 * (w + 4 * c) + i16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = kb0 + 16 * q + 4 * kk + r;
+                    if (k < K && col < N) P[Ly.w_off + (long long)k * N + col] = acc[q][c][r];
+                }
+            }
+        if (kb0 == 0 && tid < N) P[Ly.b_off + tid] = bsum;
+    }
+}
+
+// Fixed-order sum of one float per thread over the workgroup (256 threads): lanes by xor shuffles, waves through LDS.
+PROMP_DEV float gen_block_sum(float v, float* red, int tid) {
+    v = wave_sum_f32(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// k_gen_loss: objective / KL of the work item's rows, the cotangents of the means (-> dz[pp], [rows][A]) and the log_std gradient;
+// one thread per row, the row's actions in a loop.  HVP: also the tangents along u = -v (-> qz[pp]) and R'{d objective / d s},
+// with kl_weight x the KL cotangents joined in (k_chain_hvp's loss level).  Writes P[oS .. oS + A), P[NP], P[NP + 1].
+// grid = work items, block = 256.
+template <bool HVP, bool BWD>
+__global__ void __launch_bounds__(256) k_gen_loss(GenArgs a, int pp) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const WorkItem wk = a.work[blockIdx.x];
+    const int A = a.A, NP = a.NP, oS = NP - A;
+    const float* th = a.theta + (long long)wk.task * a.theta_task_stride;
+    const int trow0 = a.task_row_offsets[wk.task], tn = a.task_row_offsets[wk.task + 1] - trow0;
+    const float invN = 1.0f / (float)tn;
+    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    float loss = 0.f, klsum = 0.f;
+    float* __restrict__ GS = a.dz[pp ^ 1];            // [rows][A]: every row's log_std terms (the buffer is free at this point of a pass)
+    // (restrict-qualified copies: the row loops' loads may then be issued ahead of the stores of earlier actions)
+    const float* __restrict__ g_mu = a.mu; const float* __restrict__ g_rmu = a.rmu; const float* __restrict__ g_act = a.actions;
+    const float* __restrict__ g_om = a.old_mean; const float* __restrict__ g_vd = a.vdir;
+    float* __restrict__ g_dz = a.dz[pp]; float* __restrict__ g_qz = a.qz[pp];
+    float ssum = 0.f;          // sum of the log standard deviations (log-likelihood objective)
+    for (int j = 0; j < A; ++j) {
+        const float sr = th[oS + j];
+        ssum += (a.clip_log_std && sr < a.min_log_std) ? a.min_log_std : sr;
+    }
+    for (int n = wk.row_begin + tid; n < wk.row_end; n += 256) {
+        const float* olsp = a.old_log_std + (a.ls_per_row ? (long long)n * A : (long long)wk.task * A);
+        const float advn = a.adv[n];
+        // pass 1 over the actions: the row's log-likelihood ratio, its tangent, the KL
+        float dlp = 0.f, sumz2 = 0.f, kl = 0.f, Rlp = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < A; ++j) {
+            const float sr = th[oS + j];
+            const bool clipped = a.clip_log_std && sr < a.min_log_std;
+            const float s = clipped ? a.min_log_std : sr, e = expf(-s), sn2 = expf(2.f * s);
+            const float mu = g_mu[(long long)n * A + j], ac = g_act[(long long)n * A + j], mo = g_om[(long long)n * A + j], so = olsp[j];
+            const float z = (ac - mu) * e, zo = (ac - mo) * expf(-so);
+            const float num = (mo - mu) * (mo - mu) + expf(2.f * so) - sn2, rden = 1.0f / (2.f * sn2 + 1e-8f);
+            dlp += (so - s) - 0.5f * (z * z - zo * zo);
+            sumz2 += z * z;
+            kl += num * rden + s - so;
+            if (HVP) {
+                const float Rs = clipped ? 0.f : -g_vd[(long long)wk.task * NP + oS + j];
+                Rlp += z * e * g_rmu[(long long)n * A + j] + (z * z - 1.f) * Rs;
+            }
+        }
+        if (HVP && a.row_tan != nullptr) a.row_tan[n] = Rlp;
+        const float rho = expf(dlp), aw = advn * invN;
+        const float x = rho * advn, y = fminf(fmaxf(rho, 1.f - a.clip_eps), 1.f + a.clip_eps) * advn;
+        const float lp = -ssum - 0.5f * sumz2 - 0.5f * (float)A * 1.8378770664093453f;
+        const bool is_kl = a.loss_kind == LOSS_KL, is_ratio = a.loss_kind == LOSS_RATIO, is_clip = a.loss_kind == LOSS_CLIP;
+        float c = -aw, lrow = -lp * aw;                                  // log-likelihood
+        if (is_clip) { c = (x <= y) ? -aw * rho : 0.f; lrow = -fminf(x, y) * invN; }
+        if (is_ratio) { c = -aw * rho; lrow = -rho * aw; }
+        if (is_kl) { c = 0.f; lrow = kl * invN; }
+        const float Rc = (HVP && is_ratio) ? c * Rlp : 0.f;
+        loss += lrow;
+        klsum += kl * invN;
+        if (!BWD) continue;
+        // pass 2: cotangents of the means (and their tangents), log_std terms
+#pragma unroll 4
+        for (int j = 0; j < A; ++j) {
+            const float sr = th[oS + j];
+            const bool clipped = a.clip_log_std && sr < a.min_log_std;
+            const float s = clipped ? a.min_log_std : sr, e = expf(-s), sn2 = expf(2.f * s);
+            const float mu = g_mu[(long long)n * A + j], ac = g_act[(long long)n * A + j], mo = g_om[(long long)n * A + j], so = olsp[j];
+            const float z = (ac - mu) * e;
+            const float num = (mo - mu) * (mo - mu) + expf(2.f * so) - sn2, den = 2.f * sn2 + 1e-8f, rden = 1.0f / den;
+            const float dklm = -2.f * (mo - mu) * rden * invN;
+            const float dkls = ((-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f) * invN;
+            const float lmask = clipped ? 0.f : 1.f;
+            if (!HVP) {
+                g_dz[(long long)n * A + j] = c * z * e + (is_kl ? dklm : 0.f);
+                GS[(long long)n * A + j] = lmask * (c * (z * z - 1.f) + (is_kl ? dkls : 0.f));
+            } else {
+                const float Rs = clipped ? 0.f : -g_vd[(long long)wk.task * NP + oS + j];
+                const float Rmu = g_rmu[(long long)n * A + j];
+                float d, q, os;
+                if (is_kl) {
+                    // the objective is the mean KL itself (TRPO's constraint): see k_chain_hvp for the derivation
+                    const float D = mo - mu, Pq = sn2 * (den + 2.f * num);
+                    const float RP = 2.f * sn2 * Rs * (den + 2.f * num) - 4.f * sn2 * D * Rmu;
+                    const float Rdm = 2.f * Rmu * rden + 8.f * D * sn2 * Rs * (rden * rden);
+                    const float Rds = (-2.f * RP + 16.f * Pq * sn2 * Rs * rden) * (rden * rden);
+                    d = dklm;
+                    q = Rdm * invN;
+                    os = Rds * invN;
+                } else {
+                    const float Rz = -Rmu * e - z * Rs;
+                    const float Rd = Rc * z * e + c * (Rz * e - z * e * Rs);
+                    const float Rds = Rc * (z * z - 1.f) + 2.f * c * z * Rz;
+                    d = c * z * e;
+                    q = Rd + a.kl_weight * dklm;
+                    os = Rds + a.kl_weight * dkls;
+                }
+                g_dz[(long long)n * A + j] = d;
+                g_qz[(long long)n * A + j] = q;
+                GS[(long long)n * A + j] = lmask * os;
+            }
+        }
+    }
+    const float L = gen_block_sum(loss, red, tid), Kl = gen_block_sum(klsum, red, tid);
+    if (BWD) {
+        // the log_std gradient: column sums of the rows' terms in row order (one thread per action)
+        __threadfence_block();
+        __syncthreads();
+        if (tid < A) {
+            float g = 0.f;
+            for (int n = wk.row_begin; n < wk.row_end; ++n) g += GS[(long long)n * A + tid];
+            P[oS + tid] = g;
+        }
+    }
+    if (tid == 0) {
+        P[NP] = L;
+        P[NP + 1] = Kl;
+    }
+}
+
+// k_gen_policy_forward: k_policy_forward (promp_kernels_policy.h; MetaGaussianMLPPolicy.get_actions) for any layer table: the
+// mean network of every task's current parameters on a small batch of observations, one thread per row, the hidden vectors
+// ping-ponged through a scratch row pair in global memory (rollout-time inference: a few hundred rows per environment step).
+// grid = tasks, block = 256
+struct GenForwardArgs {
+    const float* obs;          // [tasks][B][O]
+    const float* theta_tasks;  // [tasks][Theta]
+    float* mean;               // [tasks][B][A]
+    float* scratch;            // [tasks][B][2][maxw]
+    int B, NP, n_lin, maxw;
+    GenLin lin[GEN_MAX_LIN];
+};
+
+__global__ void __launch_bounds__(256) k_gen_policy_forward(GenForwardArgs a) {
+    const int task = blockIdx.x;
+    const float* th = a.theta_tasks + (long long)task * a.NP;
+    for (int row = threadIdx.x; row < a.B; row += 256) {
+        const long long r = (long long)task * a.B + row;
+        const float* x = a.obs + r * a.lin[0].K;
+        float* buf = a.scratch + r * 2 * a.maxw;
+        for (int l = 0; l < a.n_lin; ++l) {
+            const GenLin Ly = a.lin[l];
+            const bool last = l == a.n_lin - 1;
+            float* y = last ? a.mean + r * Ly.N : buf + (l & 1) * a.maxw;
+            for (int j = 0; j < Ly.N; ++j) {
+                float z = th[Ly.b_off + j];
+                for (int k = 0; k < Ly.K; ++k) z = fmaf(x[k], th[Ly.w_off + k * Ly.N + j], z);
+                y[j] = last ? z : fast_tanh(z);
+            }
+            x = y;
+        }
+    }
+}

@@ -104,6 +104,7 @@ void launch(dim3 grid, int block, size_t smem, F body) {
 #define PROMP_LAUNCH(kern, grid, block, smem, stream, ...) emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::tl.blk->bar.arrive_and_wait(); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline int __syncthreads_or(int pred) {
     emu::Block* b = emu::tl.blk;
     b->bar.arrive_and_wait();

@@ -79,7 +79,7 @@ def make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=False, low_log_std=Fa
     theta = synthetic.init_theta(rng, O, hidden, A)
     theta = (theta + 0.05 * rng.randn(theta.size)).astype(np.float32)
     if low_log_std:
-        theta[-A:] = np.log(min_std) + np.array([-0.5, 0.5, -1.0, 0.2, -0.2, 0.1, 0.3, -0.3][:A])
+        theta[-A:] = np.log(min_std) + np.resize(np.array([-0.5, 0.5, -1.0, 0.2, -0.2, 0.1, 0.3, -0.3]), A)
     all_slabs, all_paths = [], []
     for k in range(K + 1):
         theta_old = (theta + 0.1 * rng.randn(M, theta.size)).astype(np.float32)

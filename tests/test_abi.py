@@ -24,7 +24,7 @@ def test_emulated_library_exports_every_symbol():
     lib = devlib.emu_library()
     for s in header_symbols():
         assert hasattr(lib.cdll, s)
-    assert lib.cdll.promp_abi_version() == 2
+    assert lib.cdll.promp_abi_version() == 3
 
 
 @pytest.mark.skipif(not os.path.exists(_lib.DEFAULT_LIBRARY), reason='libpromp_hip.so not built (run __graft_entry__.build())')
@@ -47,11 +47,12 @@ def test_no_cpu_fallback_without_a_gpu():
 def test_argument_errors_are_reported():
     lib = devlib.emu_library()
     with pytest.raises(_lib.PrompError, match='obs_dim'):
-        _lib.Context(2, 200, 8, (64, 64), 1, max_rows=10, max_paths=2, lib=lib)
+        _lib.Context(2, 2000, 8, (64, 64), 1, max_rows=10, max_paths=2, lib=lib)
     with pytest.raises(_lib.PrompError, match='hidden'):
-        _lib.Context(2, 4, 2, (256, 256), 1, max_rows=10, max_paths=2, lib=lib)
+        _lib.Context(2, 4, 2, (512, 256), 1, max_rows=10, max_paths=2, lib=lib)
     with pytest.raises(_lib.PrompError, match='hidden'):
-        _lib.Context(2, 4, 2, (64, 129), 1, max_rows=10, max_paths=2, lib=lib)
+        _lib.Context(2, 4, 2, (64, 64, 64, 64, 64), 1, max_rows=10, max_paths=2, lib=lib)
+    _lib.Context(2, 200, 17, (64, 129, 256), 1, max_rows=10, max_paths=2, lib=lib).close()   # layer-by-layer kernels (ABI 3)
     _lib.Context(2, 4, 2, (64, 128), 1, max_rows=10, max_paths=2, lib=lib).close()     # runs zero-padded on (128, 128)
     _lib.Context(2, 4, 2, (64, 32), 1, max_rows=10, max_paths=2, lib=lib).close()      # every combination of {32, 64}
     ctx = _lib.Context(2, 4, 2, (32, 32), 1, max_rows=10, max_paths=2, lib=lib)

@@ -68,6 +68,14 @@ def test_unequal_hidden_widths(lib):
     pc.check_hvp(lib, 16, M=1, P=2, T=40, O=6, A=3, hidden=(64, 32))
 
 
+def test_generic_policy_shapes(lib, two_cus):
+    # three hidden layers / one layer / observations and actions beyond the fused kernels' tiles: promp_kernels_generic.h
+    pc.check_loss_grad(lib, 7, M=2, P=2, T=37, O=9, A=3, hidden=(16, 24, 16), ragged=True)
+    pc.check_hvp(lib, 8, M=2, P=1, T=40, O=9, A=3, hidden=(16, 24, 16))
+    pc.check_loss_grad(lib, 9, M=2, P=1, T=30, O=140, A=17, hidden=(72,), compact_log_std=True)
+    pc.check_meta(lib, 10, M=2, P=1, T=30, O=6, A=9, hidden=(20, 20), K=1, epochs=1)
+
+
 def test_hvp_segments_straddling_tasks(lib, monkeypatch):
     # 3 tasks x ~12 tiles on 2 emulated CUs: the round list is cut into two shares, so a workgroup of k_chain_hvp walks
     # segments of two (or all three) tasks one after the other and is the last arriver for some of them

@@ -90,10 +90,37 @@ def test_pair_kernel_parity(lib, pair_kernel):
     pc.check_split_accuracy(lib, (64, 64), 20, 6)
 
 
-def test_unsupported_hidden_widths_are_rejected(lib):
-    for hidden, O in (((256, 256), 4), ((64, 129), 4), ((0, 32), 4), ((32, 32, 32), 4)):
+def test_unsupported_shapes_are_rejected(lib):
+    for hidden, O, A in (((257, 64), 4, 2), ((0, 32), 4, 2), ((32, 32, 32, 32, 32), 4, 2), ((), 4, 2), ((32, 32), 4, 65), ((32, 32), 1025, 2)):
         with pytest.raises((_lib.PrompError, ValueError, TypeError)):
-            _lib.Context(2, O, 2, hidden, 1, max_rows=10, max_paths=2, lib=lib)
+            _lib.Context(2, O, A, hidden, 1, max_rows=10, max_paths=2, lib=lib)
+
+
+@pytest.mark.parametrize('hidden,O,A', [((64, 64, 64), 20, 6), ((64, 64), 376, 17), ((256, 256), 20, 6), ((100,), 11, 3),
+                                        ((32, 48, 64, 80), 140, 9), ((136, 72), 17, 6)])
+def test_generic_policy_shapes(lib, hidden, O, A):
+    """mlp.py:5-62 builds any number of hidden layers of any width, and the reference's Humanoid environments have 376
+    observations and 17 actions (envs/mujoco_envs/humanoid_rand_direc.py): shapes outside the fused kernels run on the
+    layer-by-layer kernels (promp_kernels_generic.h) -- objective, gradient, Hessian-vector product, _adapt, the Adam epochs
+    against the float64 oracle"""
+    pc.check_loss_grad(lib, 71, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_loss_grad(lib, 74, M=2, P=2, T=45, O=O, A=A, hidden=hidden, compact_log_std=True, low_log_std=True, min_std=0.5)
+    pc.check_hvp(lib, 72, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True)
+    pc.check_meta(lib, 73, M=3, P=2, T=50, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2)
+
+
+def test_generic_policy_shapes_two_inner_steps_and_trpo_constraint(lib):
+    pc.check_meta(lib, 75, M=3, P=2, T=50, O=20, A=6, hidden=(64, 64, 64), K=2, ragged=True, epochs=2)
+    pc.check_exact_constraint_hvp(lib, 76, M=2, P=2, T=40, O=20, A=6, hidden=(64, 64, 64), K=1)
+    pc.check_trpo(lib, 77, M=3, P=2, T=50, O=20, A=6, hidden=(48, 48, 48))
+
+
+def test_wide_observations_need_another_baseline(lib):
+    """obs_dim > 128: the policy passes run, LinearFeatureBaseline's device fit (2 obs_dim + 5 columns) refuses with the reason"""
+    pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=200, ragged=True, baseline='linear_time',
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+    with pytest.raises(_lib.PrompError, match='LinearFeatureBaseline'):
+        pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=200, ragged=True, kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
 
 
 @pytest.mark.parametrize('hidden,O,A', [((100, 100), 20, 6), ((48, 20), 11, 3), ((64, 128), 20, 6), ((100, 100), 111, 8), ((24, 40), 50, 4)])

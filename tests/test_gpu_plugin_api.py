@@ -61,6 +61,7 @@ def test_trainer_with_device_rollouts():
 
 def test_get_actions_on_device():
     scen.run_get_actions_scenario(M=8, B=20, O=20, A=6, hidden=(64, 64))
+    scen.run_get_actions_scenario(M=4, B=20, O=376, A=17, hidden=(64, 64, 64))      # Humanoid's dimensions, three hidden layers
 
 
 @pytest.mark.parametrize('device_rollouts', [False, True], ids=['host_rollouts', 'device_rollouts'])

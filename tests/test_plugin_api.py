@@ -610,6 +610,7 @@ def run_get_actions_scenario(M=3, B=7, O=5, A=3, hidden=(32, 32)):
 
 def test_get_actions(emu):
     run_get_actions_scenario()
+    run_get_actions_scenario(M=2, B=5, O=9, A=10, hidden=(16, 24, 16))     # the layer-by-layer kernels' forward
 
 
 def run_baseline_fit_predict_scenario():
