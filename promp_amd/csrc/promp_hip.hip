@@ -861,7 +861,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         HIPCHECK(hipFuncSetAttribute((const void*)g5, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void*)k_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         {
-            auto f1 = k_fit_wave<12>; auto f2 = k_fit_wave<48>; auto f3 = k_fit_wave<64>;
+            auto f1 = k_fit_wave<12>; auto f2 = k_fit_wave<48>; auto f3 = k_fit_wave<64>; auto f4 = k_fit_wave<45>;
+            HIPCHECK(hipFuncSetAttribute((const void*)f4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHECK(hipFuncSetAttribute((const void*)f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHECK(hipFuncSetAttribute((const void*)f2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHECK(hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1289,11 +1290,12 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
         const int DA = a.D + 1;
         if (small) {
-            const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2);
+            const size_t fit_smem = sizeof(double) * ((size_t)2 * DA * DA + 3 * DA + 2 + fitwv_aux(64));      // (k_fit / k_fit_wave<DT <= 64>)
             // one wave per task while a row of the work matrix fits a wave's lanes (D + 1 <= 64); else one workgroup per task
-            if (DA <= 12) { auto k = k_fit_wave<12>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
-            else if (DA <= 48) { auto k = k_fit_wave<48>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
-            else if (DA <= 64) { auto k = k_fit_wave<64>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk); }
+            if (DA <= 12) { auto k = k_fit_wave<12>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITWV_NT, fit_smem, st, a, nblk); }
+            else if (DA <= 45) { auto k = k_fit_wave<45>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITWV_NT, fit_smem, st, a, nblk); }    // obs_dim 20
+            else if (DA <= 48) { auto k = k_fit_wave<48>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITWV_NT, fit_smem, st, a, nblk); }
+            else if (DA <= 64) { auto k = k_fit_wave<64>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITWV_NT, fit_smem, st, a, nblk); }
             else PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         } else {
             PROMP_LAUNCH(k_gram_sum_wide, dim3(c->d.n_tasks * FITW_SUM_SPLIT), 256, 0, st, a, nblk, fit_scratch);

@@ -13,6 +13,7 @@
 // The Gram matrix runs on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): the target is appended
 // to the features as one more column so that Phi^T R falls out of the same product.
 #pragma once
+#include <utility>
 #include "promp_device.h"
 #include "promp_kernels_policy.h"  // WorkItem
 
@@ -150,22 +151,26 @@ struct GramCfg {
 };
 
 // grid = work items, block = 64 * GramCfg<NBLK>::NW
+#ifdef PROMP_DEV_STAMPS
+#define SA_STAMPS unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = promp_clock()
+#define SA_PHASE(i) do { const unsigned long long now_ = promp_clock(); ph[i] += now_ - tph; tph = now_; } while (0)
+#else
+#define SA_STAMPS do { } while (0)
+#define SA_PHASE(i) do { } while (0)
+#endif
 template <int NBLK>
 __global__ void __launch_bounds__(64 * GramCfg<NBLK>::NW) k_gram(SampleArgs a) {
+    SA_STAMPS;
     constexpr int NW = GramCfg<NBLK>::NW, FS = GramCfg<NBLK>::FS, NPAIR = GramCfg<NBLK>::NPAIR, NC = 16 * NBLK;
     PROMP_SMEM_DECL;
     unsigned char* smem = (unsigned char*)PROMP_SMEM_PTR;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
     double* Phi = (double*)(smem + (size_t)w * GramCfg<NBLK>::WAVE_BYTES);
-    float* Ob = (float*)(Phi + 16 * FS);
-    double* Tg = (double*)(Ob + 16 * 32);
-    double* Tau = Tg + 16;
     const WorkItem wk = a.work[blockIdx.x];
     const int O = a.O, D = a.D;
     f64x4 acc[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) acc[p] = zero4d();
-    const int fr = lane >> 2, fc0 = lane & 3;   // feature build: 4 lanes per row, columns fc0, fc0+4, ...
     // A chunk's inputs (this lane's share of the [16][O <= 32] observation rows, a row's return and time index) are
     // requested one chunk ahead: the wave walks ~5 chunks and would otherwise sit out a memory round trip in each.
     float xr[8];
@@ -190,51 +195,45 @@ __global__ void __launch_bounds__(64 * GramCfg<NBLK>::NW) k_gram(SampleArgs a) {
             ttr = a.row_t[b0 + r];
         }
     };
+    // The feature tile is written straight from the registers the request filled: element e = lane + 64 u of the [16][O] chunk is
+    // observation c = e mod O of row e / O, and goes to columns c (clipped) and O + c (its square) -- the positions are the same for
+    // every chunk.  Lanes 0..15 add their row's time features, the constant and the target.  Columns past D + 1 stay zero.
+    int poff[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = lane + 64 * u, r = e / (O > 0 ? O : 1);
+        poff[u] = (a.kind == BASE_LINFEAT && e < 16 * O) ? r * FS + (e - r * O) : -1;
+    }
+    for (int e = lane; e < 16 * FS; e += 64) Phi[e] = 0.0;
+    wave_sync();
+    const int qt = (a.kind == BASE_LINFEAT) ? 2 * O : 0;        // first of the four time columns (tau, tau^2, tau^3, 1)
     request(wk.row_begin + 16 * w);
+    SA_PHASE(0);
     for (int base = wk.row_begin + 16 * w; base < wk.row_end; base += 16 * NW) {
         const int nrows = (wk.row_end - base) < 16 ? (wk.row_end - base) : 16;
-        if (a.kind == BASE_LINFEAT) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = lane + 64 * u;
-                if (e < 16 * O) Ob[e] = xr[u];
+        for (int u = 0; u < 8; ++u)
+            if (poff[u] >= 0) {
+                // (rows past the chunk's last arrive as zeros.)  the reference squares in the observations' own dtype (float32),
+                // then promotes
+                const float oc = fminf(fmaxf(xr[u], -10.f), 10.f);
+                Phi[poff[u]] = (double)oc;
+                Phi[poff[u] + O] = (double)(oc * oc);
             }
-        }
         if (lane < 16) {
-            Tg[lane] = (lane < nrows) ? tr : 0.0;
-            Tau[lane] = (lane < nrows) ? (double)ttr / 100.0 : 0.0;
+            const bool rv = lane < nrows;
+            const double tau = rv ? (double)ttr / 100.0 : 0.0;
+            double* pr = Phi + lane * FS;
+            pr[qt] = tau;
+            pr[qt + 1] = tau * tau;
+            pr[qt + 2] = tau * tau * tau;
+            pr[qt + 3] = rv ? 1.0 : 0.0;
+            pr[D] = rv ? tr : 0.0;
         }
+        SA_PHASE(1);
         request(base + 16 * NW);
         wave_sync();
-        {
-            const bool rv = fr < nrows;
-            const double tau = Tau[fr];
-            for (int c = fc0; c < NC; c += 4) {
-                double f = 0.0;
-                if (rv) {
-                    int q = c;
-                    bool done = false;
-                    if (c == D) {
-                        f = Tg[fr];
-                        done = true;
-                    } else if (c > D) {
-                        done = true;
-                    } else if (a.kind == BASE_LINFEAT) {
-                        if (c < 2 * O) {
-                            const float o = Ob[fr * O + (c < O ? c : c - O)];
-                            const float oc = fminf(fmaxf(o, -10.f), 10.f);
-                            // the reference squares in the observations' own dtype (float32), then promotes
-                            f = (c < O) ? (double)oc : (double)(oc * oc);
-                            done = true;
-                        }
-                        q = c - 2 * O;
-                    }
-                    if (!done) f = (q == 0) ? tau : (q == 1) ? tau * tau : (q == 2) ? tau * tau * tau : 1.0;
-                }
-                Phi[fr * FS + c] = f;
-            }
-        }
-        wave_sync();
+        SA_PHASE(2);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             double av[NBLK];
@@ -250,8 +249,10 @@ __global__ void __launch_bounds__(64 * GramCfg<NBLK>::NW) k_gram(SampleArgs a) {
                 }
         }
         wave_sync();
+        SA_PHASE(3);
     }
     __syncthreads();
+    SA_PHASE(4);
     double* S = (double*)smem;   // [NW][NPAIR*256]
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p)
@@ -265,6 +266,12 @@ __global__ void __launch_bounds__(64 * GramCfg<NBLK>::NW) k_gram(SampleArgs a) {
         for (int ww = 0; ww < NW; ++ww) t += S[ww * NPAIR * 256 + e];
         out[e] = t;
     }
+    SA_PHASE(5);
+#ifdef PROMP_DEV_STAMPS
+    if (blockIdx.x == 0 && tid == 0)
+        printf("k_gram cycles (wave 0 of workgroup 0): entry %llu | features %llu | request + sync %llu | products %llu | barrier %llu | slab sums %llu\n",
+               ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+#endif
 }
 
 // grid = tasks, block = 256.  smem: G[(D+1)^2] + Wm[(D+1)^2] + yv[D+1] + wv[D+1] + dg[D+1]  (doubles)
@@ -345,6 +352,46 @@ __global__ void __launch_bounds__(256) k_fit(SampleArgs a, int NBLK) {
     if (tid < D) a.coeffs[(long long)task * a.coeff_stride + tid] = wv[tid];
 }
 
+// One column step of k_fit_wave's factorisation (J is a compile-time constant: the steps are instantiated one by one, which
+// keeps the row in registers whatever the unroller's size limits say).
+#define FITWV_CS 65        // doubles between the factor's columns in LDS (k_fit_wave: 64 lanes + 1: a lane walking down its own
+                           // column -- the back substitution's operands -- is then on its own pair of banks)
+PROMP_HD size_t fitwv_aux(int dt) { return (size_t)dt * FITWV_CS + 2 + 64; }     // the factor by columns + 1 / L[j][j]
+template <int J, int DT>
+PROMP_DEV void fitw_column(double (&W)[DT], double* colbuf, double* rsv, double& rs, int lane, int D) {
+    if (J >= D) return;       // (wave-uniform)
+    // pivot and its reciprocal from ONE reciprocal square root (sqrt followed by a division is two long software sequences, this
+    // is one); `rs` arrives computed: the previous step started it as soon as column J was final (see below).  Lane J holds the
+    // pivot element d, so one multiplication makes its sqrt(d) = d rs there and L[k][J] in the lanes below: no select.
+    W[J] *= rs;
+    // The finished column also goes to LDS: the columns together are the factor the back substitution reads (no transposition pass).
+    colbuf[J * FITWV_CS + lane] = W[J];
+    rsv[J] = rs;              // (every lane, the same value: the back substitution reads lane j's reciprocal from here)
+    // lane k holds L[k][J] in W[J].  The first trailing column goes alone: it completes column J + 1, whose pivot's reciprocal
+    // square root (the long dependent sequence of a step) then runs beside the rest of this step's updates instead of after them.
+    if (J + 1 < DT) {
+        W[J + 1] -= W[J] * readlane_f64(W[J], J + 1);
+        rs = rsqrt(readlane_f64(W[J + 1], J + 1));
+    }
+    // Eight multipliers are read into eight scalar pairs before the first product: a plain loop compiles to "readlane, readlane,
+    // s_nop, fma" on ONE pair (41 cycles per column, measured).  (Broadcast reads of the LDS copy instead of v_readlane were
+    // tried: the addresses do not fit ds_read2's offsets, the compiler keeps them in spilled scalars, 1270 cycles per step.)
+#pragma unroll
+    for (int k0 = J + 2; k0 < DT; k0 += 8) {
+        double m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = (k0 + u < DT) ? readlane_f64(W[J], k0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < DT) W[k0 + u] -= W[J] * m[u];
+    }
+}
+template <int DT, int... Js>
+PROMP_DEV void fitw_columns(double (&W)[DT], double* colbuf, double* rsv, int lane, int D, std::integer_sequence<int, Js...>) {
+    double rs = rsqrt(readlane_f64(W[0], 0));
+    (fitw_column<Js, DT>(W, colbuf, rsv, rs, lane, D), ...);
+}
+
 // k_fit_wave: the same solve as k_fit, one WAVE per task, for D + 1 <= 64 (obs_dim <= 29).
 //
 // Lane i holds row i of the work matrix in registers (row D = the right-hand side, carried along as in k_fit).  A column
@@ -357,91 +404,112 @@ __global__ void __launch_bounds__(256) k_fit(SampleArgs a, int NBLK) {
 // Same elimination order as k_fit; the column scaling multiplies by 1/sqrt(pivot) instead of dividing by sqrt(pivot), so
 // the two kernels agree to rounding (1e-15 relative), not bit for bit.
 // DT = compile-time bound on D + 1 (the j / k loops are fully unrolled over it; steps j >= D leave by a uniform branch).
-// grid = tasks, block = 256: all four waves sum the task's partial Gram blocks (many loads in flight), wave 0 factorizes.
+// grid = tasks, block = FITWV_NT: all waves sum the task's partial Gram blocks (many loads in flight), wave 0 factorizes.
+#define FITWV_NT 512       // threads of k_fit_wave: eight waves sum the partial blocks, wave 0 factorizes
 template <int DT>
-__global__ void __launch_bounds__(256) k_fit_wave(SampleArgs a, int NBLK) {
+__global__ void __launch_bounds__(FITWV_NT) k_fit_wave(SampleArgs a, int NBLK) {
     PROMP_SMEM_DECL;
+    SA_STAMPS;
     const int D = a.D, DA = D + 1;
-    double* G = (double*)PROMP_SMEM_PTR;          // [DA][DA] symmetric Gram matrix (kept for the retries), then the factor
-    double* Lm = G + DA * DA;                     // [DA][DA] factor rows, read by column in the back substitution
+    double* colbuf = (double*)PROMP_SMEM_PTR;     // [DT][FITWV_CS] the factor by columns: column j = lanes' L[lane][j] (fitw_column)
+    double* rsv = colbuf + DT * FITWV_CS + 2;     // [64] 1 / L[j][j]
+    double* G = colbuf + fitwv_aux(DT);           // [DA][DA] symmetric Gram matrix (kept for the retries)
     const int lane = threadIdx.x & 63, task = blockIdx.x;
     const int NPAIR = NBLK * (NBLK + 1) / 2;
     // 1. sum the task's partial Gram blocks in workgroup order and scatter into the symmetric matrix
     const int wg0 = a.task_wg_offsets[task], wg1 = a.task_wg_offsets[task + 1];
-    for (int e = threadIdx.x; e < NPAIR * 256; e += 256) {
-        // eight partial blocks per trip, all requested before the first is added (indices past the task's last workgroup read
-        // that workgroup again and add nothing): the trip count is a run-time value, and the remainder loop of a plain unrolled
-        // loop issues load -> add -> load, one round trip to L2 per partial block (28 k of this kernel's 78 k cycles, measured)
-        double s = 0.0;
-        for (int base = wg0; base < wg1; base += 8) {
-            double v[8];
+    // Every entry a thread owns (up to five: DA <= 64 means at most ten block pairs) and sixteen partial blocks of each are
+    // requested before the first is added (indices past the task's last workgroup read that workgroup again and add nothing):
+    // the partial blocks were written by other XCDs a launch ago, a round trip costs ~3 k cycles, and a task has ~14 of them.
+    {
+        constexpr int NE = 5;
+        double sacc[NE];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int wg = base + u < wg1 ? base + u : wg1 - 1;
-                v[u] = a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+        for (int q = 0; q < NE; ++q) sacc[q] = 0.0;
+        for (int base = wg0; base < wg1; base += 16) {
+            double v[NE][16];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int e = threadIdx.x + q * FITWV_NT;
+                if (e < NPAIR * 256) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int wg = base + u < wg1 ? base + u : wg1 - 1;
+                        v[q][u] = a.gram_partials[(long long)wg * (NPAIR * 256) + e];
+                    }
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += (base + u < wg1) ? v[u] : 0.0;
+            for (int q = 0; q < NE; ++q) {
+                const int e = threadIdx.x + q * FITWV_NT;
+                if (e < NPAIR * 256) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sacc[q] += (base + u < wg1) ? v[q][u] : 0.0;
+                }
+            }
         }
-        int p = e >> 8, bi = 0, rem = p;
-        while (rem >= NBLK - bi) {
-            rem -= NBLK - bi;
-            ++bi;
-        }
-        const int bj = bi + rem;
-        const int row = 16 * bi + ((e & 255) >> 4), col = 16 * bj + (e & 15);
-        if (row < DA && col < DA) {
-            G[row * DA + col] = s;
-            if (bi != bj) G[col * DA + row] = s;
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = threadIdx.x + q * FITWV_NT;
+            if (e < NPAIR * 256) {
+                int p = e >> 8, bi = 0, rem = p;
+                while (rem >= NBLK - bi) {
+                    rem -= NBLK - bi;
+                    ++bi;
+                }
+                const int bj = bi + rem;
+                const int row = 16 * bi + ((e & 255) >> 4), col = 16 * bj + (e & 15);
+                if (row < DA && col < DA) {
+                    G[row * DA + col] = sacc[q];
+                    if (bi != bj) G[col * DA + row] = sacc[q];
+                }
+            }
         }
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
+    SA_PHASE(0);
     const int row = lane < DA ? lane : DA - 1;    // (lanes >= DA shadow the last row: finite values, never read back)
     double reg = a.reg;
     double wsol = 0.0;
     for (int attempt = 0; attempt < 5; ++attempt) {
         double W[DT];
-        double rdg = 1.0;         // lane j: 1 / L[j][j] (the reciprocal square root the column step computed anyway)
 #pragma unroll
         for (int k = 0; k < DT; ++k) W[k] = (k < D) ? G[row * DA + k] + ((k == row) ? reg : 0.0) : 0.0;
         // 2. Cholesky of (G[:D,:D] + reg I) carrying the right-hand-side row D along (forward solve for free)
+        fitw_columns<DT>(W, colbuf, rsv, lane, D, std::make_integer_sequence<int, DT>());
+        SA_PHASE(1);
+        // 3. back substitution over the transposed factor: y[t] -= L[j][t] w[j], j = D-1 .. 0 (lane t holds y[t]).  Lane t's
+        // operands L[j][t], j > t, are column t of the factor -- its own slot of the column store, read back into the registers the
+        // factorisation has just freed (zeros for j <= t: y[t] then stays what it was when step t used it).  The dependent steps
+        // contain no memory access, no select and no division: w[j] = y[j] / L[j][j] is a multiplication by the stored reciprocal.
+        wave_fence();
+        double y = (lane < D) ? colbuf[lane * FITWV_CS + D] : 0.0;
+        const double rdg = rsv[lane < D ? lane : 0];        // lane j: 1 / L[j][j] (the reciprocal square root of its column step)
 #pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            if (j < D) {          // (wave-uniform; a `break` would keep the loop rolled and the row out of registers)
-                // pivot and its reciprocal from ONE reciprocal square root (the dependent chain of a column step is the
-                // kernel's critical path: sqrt followed by a division is two long software sequences, this is one)
-                const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
-                W[j] = (lane == j) ? piv : W[j] * rs;
-                rdg = (lane == j) ? rs : rdg;
-#pragma unroll
-                for (int k = j + 1; k < DT; ++k) W[k] -= W[j] * readlane_f64(W[j], k);      // lane k holds L[k][j] in W[j]
-            }
+        for (int k = 0; k < DT; ++k) {
+            const double l = colbuf[row * FITWV_CS + (k < DA ? k : 0)];
+            W[k] = (k < D && row < k) ? l : 0.0;
         }
-        // 3. back substitution over the transposed factor: y[t] -= L[j][t] w[j], j = D-1 .. 0 (lane t holds y[t])
-#pragma unroll
-        for (int k = 0; k < DT; ++k)
-            if (k < D && lane < DA) Lm[lane * DA + k] = W[k];
-        wave_sync();
-        double y = (lane < D) ? Lm[D * DA + lane] : 0.0;
-        // lane t's column of the transposed factor goes back into the registers the factorisation has just freed: the 44
-        // dependent steps below then contain no memory access (each used to wait for its own LDS read: 310 cycles per step)
-#pragma unroll
-        for (int k = 0; k < DT; ++k) W[k] = (k < D) ? Lm[k * DA + row] : 0.0;
-        // (a multiplication by the stored reciprocal instead of a float64 division on the chain)
+        SA_PHASE(2);
 #pragma unroll
         for (int j = DT - 1; j >= 0; --j) {
             if (j < D) {
-                const double wj = readlane_f64(y, j) * readlane_f64(rdg, j);
-                if (lane == j) wsol = wj;
-                if (lane < j) y -= W[j] * wj;
+                const double wj = readlane_f64(y * rdg, j);
+                y -= W[j] * wj;
             }
         }
+        wsol = y * rdg;
         wave_sync();
+        SA_PHASE(3);
         if (!wave_any(lane < D && wsol != wsol)) break;      // NaN => reg *= 10, at most 5 tries (linear_baseline.py:68-77)
         reg *= 10.0;
     }
     if (lane < D) a.coeffs[(long long)task * a.coeff_stride + lane] = wsol;
+#ifdef PROMP_DEV_STAMPS
+    if (task == 0 && lane == 0)
+        printf("k_fit_wave cycles: partial sums %llu | factorisation %llu | column reads %llu | back substitution %llu\n", ph[0], ph[1], ph[2], ph[3]);
+#endif
 }
 
 // grid = paths, block = 64.  smem: D doubles (the task's coefficients)
