@@ -255,6 +255,7 @@ static HiddenList hidden_list(const promp_dims* d) {
     return L;
 }
 // which family of pass kernels serves a network shape (sample processing alone works for any obs_dim <= 128)
+#define PROMP_LINFEAT_MAX_O 480     // LinearFeatureBaseline on the device: 2 obs_dim + 5 <= 965 columns (16 feature rows + their observations in LDS)
 bool policy_shape_generic(const promp_dims* d) {   // layer-by-layer kernels (promp_kernels_generic.h): everything the fused ones do not cover
     const HiddenList L = hidden_list(d);
     return L.n != 2 || d->obs_dim > 128 || d->act_dim > 8 || d->hidden1 > 128 || d->hidden2 > 128;
@@ -764,9 +765,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     }
     const int K = dims->num_inner_steps, M = dims->n_tasks;
     c->NP = param_count(dims);
-    // (observations wider than 128: the baseline fit's Gram / Cholesky kernels are not tiled for 2 obs_dim + 5 columns; such
-    //  contexts fit LinearTimeBaseline / no baseline on the device, or take advantages through promp_set_advantages)
-    c->Dmax = dims->obs_dim <= 128 ? 2 * dims->obs_dim + 4 : 4;
+    // (observations wider than PROMP_LINFEAT_MAX_O: the partial Gram blocks of 2 obs_dim + 5 columns outgrow what a context should
+    //  hold -- 3.8 MB per work item at obs_dim 480; such contexts fit LinearTimeBaseline / no baseline on the device, or take
+    //  advantages through promp_set_advantages)
+    c->Dmax = dims->obs_dim <= PROMP_LINFEAT_MAX_O ? 2 * dims->obs_dim + 4 : 4;
     c->coeff_stride = c->Dmax;
     c->max_work = 2 * c->n_cus + M;
     c->partial_stride = (c->NP + PROMP_PARTIAL_EXTRA + 3) & ~3;
@@ -882,7 +884,11 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     }
         PROMP_GEN_ATTR(1) PROMP_GEN_ATTR(2) PROMP_GEN_ATTR(3) PROMP_GEN_ATTR(4)
 #undef PROMP_GEN_ATTR
-        HIPCHECK(hipFuncSetAttribute((const void*)k_fit_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        {
+            auto fw32 = k_fit_wide<32>; auto fw16 = k_fit_wide<16>;
+            HIPCHECK(hipFuncSetAttribute((const void*)fw32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)fw16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
     }
     const size_t NP = c->NP, MNP = (size_t)M * NP;
     int rc = 0;
@@ -1240,9 +1246,10 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (!(o->discount >= 0 && o->discount <= 1)) return fail(-1, "discount factor must be in [0,1]");      // samplers/base.py:57
     if (!(o->gae_lambda >= 0 && o->gae_lambda <= 1)) return fail(-1, "gae_lambda must be in [0,1]");       // samplers/base.py:58
     if (o->baseline_kind < 0 || o->baseline_kind > 2) return fail(-1, "unknown baseline kind %d", o->baseline_kind);
-    if (o->baseline_kind == PROMP_BASELINE_LINEAR_FEATURE && c->d.obs_dim > 128)
-        return fail(-1, "LinearFeatureBaseline's fit is tiled for obs_dim <= 128 (%d here: %d feature columns); fit LinearTimeBaseline / no "
-                    "baseline on the device, or hand advantages in through promp_set_advantages", c->d.obs_dim, 2 * c->d.obs_dim + 5);
+    if (o->baseline_kind == PROMP_BASELINE_LINEAR_FEATURE && c->d.obs_dim > PROMP_LINFEAT_MAX_O)
+        return fail(-1, "LinearFeatureBaseline's fit is sized for obs_dim <= %d (%d here: %d feature columns); fit LinearTimeBaseline / no "
+                    "baseline on the device, or hand advantages in through promp_set_advantages", PROMP_LINFEAT_MAX_O, c->d.obs_dim,
+                    2 * c->d.obs_dim + 5);
     SampleArgs a;
     a.obs = S.obs; a.rew = S.rew; a.rew64 = S.has_rew64 ? S.rew64 : nullptr; a.path_row_offsets = S.path_row_offsets; a.path_task = S.path_task; a.row_t = S.row_t;
     a.task_row_offsets = S.task_row_offsets; a.task_path_offsets = S.task_path_offsets;
@@ -1283,8 +1290,9 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<4>::NW, GramCfg<4>::SMEM_BYTES, st, a); } break;
             case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<5>::NW, GramCfg<5>::SMEM_BYTES, st, a); } break;
             default:
-                if (nblk > 17) return fail(-1, "feature dim %d unsupported in this build", a.D);
-                PROMP_LAUNCH(k_gram_wide, dim3(S.n_work[0]), 512, gramw_smem(nblk, a.O, gramw_rows(nblk, a.O)), st, a, nblk, gramw_rows(nblk, a.O));
+                // (more than 17 blocks -- obs_dim > 133: the pair list is cut into slices of <= 160, one workgroup per work item and slice)
+                PROMP_LAUNCH(k_gram_wide, dim3(S.n_work[0], gramw_slices(nblk)), 512, gramw_smem(nblk, a.O, gramw_rows(nblk, a.O)), st, a, nblk,
+                             gramw_rows(nblk, a.O));
         }
         HIPCHECK(hipGetLastError());
         if (prof_end(c, PROMP_KERNEL_GRAM)) return -2;
@@ -1300,7 +1308,8 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         } else {
             PROMP_LAUNCH(k_gram_sum_wide, dim3(c->d.n_tasks * FITW_SUM_SPLIT), 256, 0, st, a, nblk, fit_scratch);
             HIPCHECK(hipGetLastError());
-            PROMP_LAUNCH(k_fit_wide, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D), st, a, nblk, fit_scratch);
+            if (fitw_nb(a.D) == 32) { auto k = k_fit_wide<32>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, 32), st, a, nblk, fit_scratch); }
+            else { auto k = k_fit_wide<16>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, 16), st, a, nblk, fit_scratch); }
         }
         HIPCHECK(hipGetLastError());
     }

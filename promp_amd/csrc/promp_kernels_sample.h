@@ -619,13 +619,17 @@ __global__ void __launch_bounds__(256) k_normalize(SampleArgs a) {
 // its owner.  Rounds of GRAMW_ROWS rows; same partial layout as k_gram ([NPAIR][256] doubles per work item).
 // grid = work items (table 0), block = 512.  smem: ROWS * FS doubles + raw obs [ROWS][O] floats + 2 * ROWS doubles.
 // ---------------------------------------------------------------------------------------------
-#define GRAMW_PPW 20     // pairs per wave: 8 * 20 >= 17 * 18 / 2 (NBLK <= 17, D <= 271)
+#define GRAMW_PPW 20     // pairs per wave: 8 * 20 >= 17 * 18 / 2 (NBLK <= 17, D <= 271) in one workgroup; more blocks: the pair list is
+                         // cut into gridDim.y slices of at most 160 (gramw_slices), one workgroup per work item and slice
 PROMP_HD int gramw_fs(int NBLK) { return (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16; }
 PROMP_HD size_t gramw_smem(int NBLK, int O, int rows) {
     return sizeof(double) * (size_t)(rows * gramw_fs(NBLK) + 2 * rows) + sizeof(float) * (size_t)(rows * O);
 }
-// rows per round: 64 where the feature tile + raw observations fit the 160 KB of LDS (Ant: 151 KB), else 32
-PROMP_HD int gramw_rows(int NBLK, int O) { return gramw_smem(NBLK, O, 64) <= 160 * 1024 ? 64 : 32; }
+// rows per round: 64 where the feature tile + raw observations fit the 160 KB of LDS (Ant: 151 KB), else 32, else 16
+PROMP_HD int gramw_rows(int NBLK, int O) {
+    return gramw_smem(NBLK, O, 64) <= 160 * 1024 ? 64 : gramw_smem(NBLK, O, 32) <= 160 * 1024 ? 32 : 16;
+}
+PROMP_HD int gramw_slices(int NBLK) { return (NBLK * (NBLK + 1) / 2 + 8 * GRAMW_PPW - 1) / (8 * GRAMW_PPW); }
 
 __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, int GRAMW_ROWS) {
     PROMP_SMEM_DECL;
@@ -639,12 +643,15 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
     const int O = a.O, D = a.D;
     // this wave's pairs: a contiguous range of the row-major list (bi, bj >= bi); offsets of the two 16-column blocks inside a
     // feature row (wave-uniform)
-    const int ppw = (NPAIR + 7) / 8, p0 = w * ppw;
+    // (gridDim.y > 1: this workgroup's slice of the list first)
+    const int npy = (NPAIR + (int)gridDim.y - 1) / (int)gridDim.y, py0 = npy * (int)blockIdx.y;
+    const int pend = py0 + npy < NPAIR ? py0 + npy : NPAIR;
+    const int ppw = (npy + 7) / 8, p0 = py0 + w * ppw;
     int ca[GRAMW_PPW], cb[GRAMW_PPW];
 #pragma unroll
     for (int j = 0; j < GRAMW_PPW; ++j) {
         const int p = p0 + j;
-        int bi = 0, rem = (j < ppw && p < NPAIR) ? p : 0;
+        int bi = 0, rem = (j < ppw && p < pend) ? p : 0;
         while (rem >= NBLK - bi) {
             rem -= NBLK - bi;
             ++bi;
@@ -732,7 +739,7 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int j = 4 * g + u;
-                        if (j < ppw && p0 + j < NPAIR) acc[j] = mfma16d(xa[u], xb[u], acc[j]);      // (wave-uniform)
+                        if (j < ppw && p0 + j < pend) acc[j] = mfma16d(xa[u], xb[u], acc[j]);      // (wave-uniform)
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -749,7 +756,7 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
 #pragma unroll
     for (int j = 0; j < GRAMW_PPW; ++j) {
         const int p = p0 + j;
-        if (j < ppw && p < NPAIR)
+        if (j < ppw && p < pend)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[p * 256 + (kk + 4 * r) * 16 + i16] = acc[j][r];
     }
@@ -771,13 +778,13 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
 // (results agree to rounding, not bit for bit).
 // grid = tasks, block = FITW_NT.  smem: fitw_smem(D).
 // ---------------------------------------------------------------------------------------------
-#define FITW_NB 32
-#define FITW_PS (FITW_NB + 1)
+#define FITW_NB 32         // panel width where the panel fits LDS (D <= ~580); wider matrices take 16-column panels
 #define FITW_NT 512        // 8 waves: two per SIMD, 256 registers each (a row of the diagonal block / of the solve lives in 64 of them)
-PROMP_HD size_t fitw_smem(int D) {
-    const size_t DA = D + 1, panel = (DA + 16) * FITW_PS;       // (16 spare rows: the last 16-row tile of the update reads zeros)
-    return sizeof(double) * (panel + 3 * DA + FITW_NB + 2);
+PROMP_HD size_t fitw_smem(int D, int nb) {
+    const size_t DA = D + 1, panel = (DA + 16) * (size_t)(nb + 1);       // (16 spare rows: the last 16-row tile of the update reads zeros)
+    return sizeof(double) * (panel + 3 * DA + nb + 2);
 }
+PROMP_HD int fitw_nb(int D) { return fitw_smem(D, FITW_NB) <= 160 * 1024 ? FITW_NB : 16; }
 
 // The task's partial Gram blocks summed in workgroup order and scattered into the symmetric matrix G -- and G + reg I into the
 // work matrix of the first factorisation attempt -- by the WHOLE chip (grid = tasks x FITW_SUM_SPLIT): inside k_fit_wide the sum
@@ -823,7 +830,9 @@ __global__ void __launch_bounds__(256) k_gram_sum_wide(SampleArgs a, int NBLK, d
     }
 }
 
+template <int NB>
 __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, double* scratch) {
+    constexpr int PS = NB + 1, LOG_NB = NB == 32 ? 5 : 4;
     PROMP_SMEM_DECL;
 #ifdef PROMP_DEV_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = promp_clock();
@@ -835,11 +844,11 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
     const int tid = threadIdx.x, task = blockIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
     const int i16 = lane & 15, kk = lane >> 4;
     double* Pn = (double*)PROMP_SMEM_PTR;     // panel [DA - k0 (+ 16)][33]
-    double* yv = Pn + (size_t)(DA + 16) * FITW_PS;
+    double* yv = Pn + (size_t)(DA + 16) * PS;
     double* wv = yv + DA;
     double* dg = wv + DA;
     double* rdp = dg + DA;                    // 1 / L[c][c] of the current panel's diagonal block
-    int* flag = (int*)(rdp + FITW_NB);
+    int* flag = (int*)(rdp + NB);
     double* G = scratch + (size_t)task * 2 * DA * DA;
     double* Wm = G + (size_t)DA * DA;
     // (G, and G + reg I as the work matrix of the first attempt, were written by k_gram_sum_wide)
@@ -854,36 +863,36 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
         }
         __syncthreads();
         FITW_PHASE(1);
-        for (int k0 = 0; k0 < D; k0 += FITW_NB) {
-            const int nb = (D - k0) < FITW_NB ? (D - k0) : FITW_NB;   // columns of this panel
+        for (int k0 = 0; k0 < D; k0 += NB) {
+            const int nb = (D - k0) < NB ? (D - k0) : NB;   // columns of this panel
             const int nr = DA - k0;                                  // rows k0..D (the last one is the right-hand side)
-            for (int e = tid; e < (nr + 16) * FITW_NB; e += NT) {
-                const int i = e >> 5, c = e & 31;
-                Pn[i * FITW_PS + c] = (c < nb && i < nr) ? Wm[(size_t)(k0 + i) * DA + k0 + c] : 0.0;
+            for (int e = tid; e < (nr + 16) * NB; e += NT) {
+                const int i = e >> LOG_NB, c = e & (NB - 1);
+                Pn[i * PS + c] = (c < nb && i < nr) ? Wm[(size_t)(k0 + i) * DA + k0 + c] : 0.0;
             }
             __syncthreads();
             FITW_PHASE(2);
             if (w == 0) {
                 // ---- the diagonal block, one wave, rows in registers (lanes >= nb shadow the last row: finite, never stored)
                 const int row = lane < nb ? lane : nb - 1;
-                double W[FITW_NB];
+                double W[NB];
                 double rdg = 1.0;
 #pragma unroll
-                for (int k = 0; k < FITW_NB; ++k) W[k] = Pn[row * FITW_PS + k];
+                for (int k = 0; k < NB; ++k) W[k] = Pn[row * PS + k];
 #pragma unroll
-                for (int j = 0; j < FITW_NB; ++j) {
+                for (int j = 0; j < NB; ++j) {
                     if (j < nb) {     // (wave-uniform)
                         const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
                         W[j] = (lane == j) ? piv : W[j] * rs;
                         rdg = (lane == j) ? rs : rdg;
 #pragma unroll
-                        for (int k = j + 1; k < FITW_NB; ++k) W[k] -= W[j] * readlane_f64(W[j], k);     // lane k holds L[k][j] in W[j]
+                        for (int k = j + 1; k < NB; ++k) W[k] -= W[j] * readlane_f64(W[j], k);     // lane k holds L[k][j] in W[j]
                     }
                 }
                 if (lane < nb) {
 #pragma unroll
-                    for (int k = 0; k < FITW_NB; ++k)
-                        if (k <= lane) Pn[lane * FITW_PS + k] = W[k];
+                    for (int k = 0; k < NB; ++k)
+                        if (k <= lane) Pn[lane * PS + k] = W[k];
                     dg[k0 + lane] = W[lane];
                     rdp[lane] = rdg;
                 }
@@ -891,32 +900,32 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
             __syncthreads();
             FITW_PHASE(3);
             // ---- the rows below: x L^T = a, one row per thread (forward substitution over the block's columns)
-            if (tid < nr - nb) {
-                double* xr = Pn + (size_t)(nb + tid) * FITW_PS;
-                double x[FITW_NB];
+            for (int rr = tid; rr < nr - nb; rr += NT) {       // (one trip up to 512 rows below the block)
+                double* xr = Pn + (size_t)(nb + rr) * PS;
+                double x[NB];
 #pragma unroll
-                for (int c = 0; c < FITW_NB; ++c) x[c] = xr[c];
+                for (int c = 0; c < NB; ++c) x[c] = xr[c];
                 // column by column, right-looking: once x[c] is final the later entries take their x[c] L[c2][c] at once -- 31 - c
                 // independent multiply-adds (the left-looking form is one dependent chain of c per entry).  L[c2][c] is the same
                 // address in every lane: a broadcast.  In a last panel narrower than 32 the rows / columns >= nb of the block hold
                 // other rows' data: finite junk that only reaches entries >= nb, which are stored as 0.
 #pragma unroll
-                for (int c = 0; c < FITW_NB; ++c) {
+                for (int c = 0; c < NB; ++c) {
                     if (c < nb) {
                         x[c] *= rdp[c];
 #pragma unroll
-                        for (int c2 = c + 1; c2 < FITW_NB; ++c2) x[c2] -= x[c] * Pn[c2 * FITW_PS + c];
+                        for (int c2 = c + 1; c2 < NB; ++c2) x[c2] -= x[c] * Pn[c2 * PS + c];
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < FITW_NB; ++c) xr[c] = (c < nb) ? x[c] : 0.0;
+                for (int c = 0; c < NB; ++c) xr[c] = (c < nb) ? x[c] : 0.0;
             }
             __syncthreads();
             FITW_PHASE(4);
             // write the factored panel back (strictly-lower part and the right-hand-side row)
-            for (int e = tid; e < nr * FITW_NB; e += NT) {
-                const int i = e >> 5, c = e & 31;
-                if (c < nb && i > c) Wm[(size_t)(k0 + i) * DA + k0 + c] = Pn[i * FITW_PS + c];
+            for (int e = tid; e < nr * NB; e += NT) {
+                const int i = e >> LOG_NB, c = e & (NB - 1);
+                if (c < nb && i > c) Wm[(size_t)(k0 + i) * DA + k0 + c] = Pn[i * PS + c];
             }
             // ---- rank-nb update of the trailing matrix on the FP64 matrix cores: rows k1..D, columns k1..D-1, the tiles of the
             //      lower triangle, wave w takes tiles w, w + 16, ...
@@ -927,8 +936,8 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
                 for (int tix = w; tix < ntile; tix += FITW_NT / 64) {
                     const int bi = tix / ntj, bj = tix - bi * ntj;
                     if (bj > bi) continue;                     // wave-uniform
-                    const double* pa = Pn + (size_t)(nb + 16 * bi + i16) * FITW_PS + kk;
-                    const double* pb = Pn + (size_t)(nb + 16 * bj + i16) * FITW_PS + kk;
+                    const double* pa = Pn + (size_t)(nb + 16 * bi + i16) * PS + kk;
+                    const double* pb = Pn + (size_t)(nb + 16 * bj + i16) * PS + kk;
                     // the entries this lane will update, requested before the products (clamped addresses, masked at the store)
                     double* dst[4];
                     double old[4];
@@ -942,7 +951,7 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
                     }
                     f64x4 acc = zero4d();
 #pragma unroll
-                    for (int sidx = 0; sidx < FITW_NB / 4; ++sidx) acc = mfma16d(pa[4 * sidx], pb[4 * sidx], acc);
+                    for (int sidx = 0; sidx < NB / 4; ++sidx) acc = mfma16d(pa[4 * sidx], pb[4 * sidx], acc);
                     // D: col = lane & 15, row = (lane >> 4) + 4 r
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -955,19 +964,19 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
         // ---- back substitution L^T w = z, z = row D of the factor, 32 rows of L at a time
         for (int e = tid; e < D; e += NT) yv[e] = Wm[(size_t)D * DA + e];
         __syncthreads();
-        for (int kb = ((D - 1) / FITW_NB) * FITW_NB; kb >= 0; kb -= FITW_NB) {
-            const int nb = (D - kb) < FITW_NB ? (D - kb) : FITW_NB;
+        for (int kb = ((D - 1) / NB) * NB; kb >= 0; kb -= NB) {
+            const int nb = (D - kb) < NB ? (D - kb) : NB;
             if (w == 0) {
                 // lane t holds y[kb + t] and column t of the block's transposed triangle (L[kb + j][kb + t], j > t) in registers
                 const int t = lane < nb ? lane : nb - 1;
-                double W[FITW_NB];
+                double W[NB];
 #pragma unroll
-                for (int j = 0; j < FITW_NB; ++j) W[j] = (j < nb && j > t) ? Wm[(size_t)(kb + j) * DA + kb + t] : 0.0;
+                for (int j = 0; j < NB; ++j) W[j] = (j < nb && j > t) ? Wm[(size_t)(kb + j) * DA + kb + t] : 0.0;
                 double y = yv[kb + t];
                 const double rd = 1.0 / dg[kb + t];
                 double wsol = 0.0;
 #pragma unroll
-                for (int j = FITW_NB - 1; j >= 0; --j) {
+                for (int j = NB - 1; j >= 0; --j) {
                     if (j < nb) {
                         const double wj = readlane_f64(y, j) * readlane_f64(rd, j);
                         if (lane == j) wsol = wj;
@@ -979,12 +988,12 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
             __syncthreads();
             // the rows above: y[i] -= sum_r L[kb + r][i] w[kb + r]
             for (int i = tid; i < kb; i += NT) {
-                double lv[FITW_NB];
+                double lv[NB];
 #pragma unroll
-                for (int r = 0; r < FITW_NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];     // all in flight together
+                for (int r = 0; r < NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];     // all in flight together
                 double s = yv[i];
 #pragma unroll
-                for (int r = 0; r < FITW_NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
+                for (int r = 0; r < NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
                 yv[i] = s;
             }
             __syncthreads();

@@ -30,6 +30,12 @@ def test_sample_processing_long_ragged_paths(lib):
                                       kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
 
 
+def test_sample_processing_more_than_seventeen_feature_blocks(lib, two_cus):
+    # obs_dim 140 -> 285 columns = 18 blocks of 16, 171 block pairs: k_gram_wide's pair list in two slices (blockIdx.y)
+    pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=140, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+
+
 def test_loss_grad_h64(lib):
     pc.check_loss_grad(lib, 7, M=2, P=2, T=37, O=20, A=6, hidden=(64, 64))
 

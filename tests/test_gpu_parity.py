@@ -115,12 +115,16 @@ def test_generic_policy_shapes_two_inner_steps_and_trpo_constraint(lib):
     pc.check_trpo(lib, 77, M=3, P=2, T=50, O=20, A=6, hidden=(48, 48, 48))
 
 
-def test_wide_observations_need_another_baseline(lib):
-    """obs_dim > 128: the policy passes run, LinearFeatureBaseline's device fit (2 obs_dim + 5 columns) refuses with the reason"""
-    pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=200, ragged=True, baseline='linear_time',
-                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+def test_linear_feature_baseline_at_humanoid_width(lib):
+    """LinearFeatureBaseline with 2 obs_dim + 5 = 757 columns (Humanoid: 376 observations): k_gram_wide over pair slices, the fit on
+    16-column panels (k_fit_wide<16>) -- returns / advantages against the float64 oracle; beyond obs_dim 480 the device fit refuses
+    with the reason and LinearTimeBaseline still runs"""
+    kw = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True)
+    pc.check_sample_processing_oracle(lib, 7, M=3, P=24, T=100, O=376, ragged=True, kwargs=kw)
+    pc.check_sample_processing_oracle(lib, 8, M=2, P=6, T=80, O=140, ragged=True, kwargs=kw)
+    pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=600, ragged=True, baseline='linear_time', kwargs=kw)
     with pytest.raises(_lib.PrompError, match='LinearFeatureBaseline'):
-        pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=200, ragged=True, kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+        pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=600, ragged=True, kwargs=kw)
 
 
 @pytest.mark.parametrize('hidden,O,A', [((100, 100), 20, 6), ((48, 20), 11, 3), ((64, 128), 20, 6), ((100, 100), 111, 8), ((24, 40), 50, 4)])

@@ -9,7 +9,7 @@ from promp_amd import _lib, synthetic
 CASES = [   # name, M, P, T, O, A, hidden, baseline
     ('three hidden layers (64,64,64), HalfCheetah data shapes', 40, 20, 100, 20, 6, (64, 64, 64), 'linear_feature'),
     ('(256,256), HalfCheetah data shapes', 40, 20, 100, 20, 6, (256, 256), 'linear_feature'),
-    ('Humanoid dimensions (376 obs, 17 act), (64,64)', 40, 20, 200, 376, 17, (64, 64), 'linear_time'),
+    ('Humanoid dimensions (376 obs, 17 act), (64,64)', 40, 20, 200, 376, 17, (64, 64), 'linear_feature'),
     ('reference point: (64,64) on the fused kernels', 40, 20, 100, 20, 6, (64, 64), 'linear_feature'),
 ]
 

@@ -44,6 +44,9 @@ timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d 
 cd $ROOT
 python tools/overlap.py $R/trace_staged > $R/h2d_overlap.txt 2>&1; cat $R/h2d_overlap.txt
 rm -f $R/trace_staged/*kernel_trace.csv $R/trace_staged/*memory_copy_trace.csv
+# policy shapes outside the fused kernels (layer-by-layer kernels), and Stage A standalone (config 3 and Ant's size)
+timeout 600 python $ROOT/tools/generic_timing.py > $ROOT/$R/generic_shapes.txt 2>&1; cat $ROOT/$R/generic_shapes.txt
+(timeout 300 python $ROOT/tools/stage_a_timing.py; timeout 300 python $ROOT/tools/stage_a_timing.py 40 111) > $ROOT/$R/stage_a.txt 2>&1; cat $ROOT/$R/stage_a.txt
 # per-launch timeline of one step (both streams) from the kernel trace
 python $ROOT/tools/timeline.py $ROOT/$R/trace > $ROOT/$R/timeline.txt 2>&1
 cd $ROOT; rm -f $R/trace/*kernel_trace.csv $R/pmc*/*kernel_trace.csv   # keep the summaries small
