@@ -617,13 +617,14 @@ __global__ void __launch_bounds__(256) k_normalize(SampleArgs a) {
 // (120 pairs at D = 226), so the workgroup shares the feature tile: 8 waves, wave w owns a contiguous eighth of the pair list
 // (<= GRAMW_PPW of them) over ALL rows of the work item -- no cross-wave reduction, each partial block is written by
 // its owner.  Rounds of GRAMW_ROWS rows; same partial layout as k_gram ([NPAIR][256] doubles per work item).
-// grid = work items (table 0), block = 512.  smem: ROWS * FS doubles + raw obs [ROWS][O] floats + 2 * ROWS doubles.
+// grid = work items (table 0) x pair slices, block = 512.  smem: the feature tile, ROWS * FS doubles.
 // ---------------------------------------------------------------------------------------------
 #define GRAMW_PPW 20     // pairs per wave: 8 * 20 >= 17 * 18 / 2 (NBLK <= 17, D <= 271) in one workgroup; more blocks: the pair list is
                          // cut into gridDim.y slices of at most 160 (gramw_slices), one workgroup per work item and slice
 PROMP_HD int gramw_fs(int NBLK) { return (NBLK % 2 == 1) ? 16 * NBLK : 16 * NBLK + 16; }
 PROMP_HD size_t gramw_smem(int NBLK, int O, int rows) {
-    return sizeof(double) * (size_t)(rows * gramw_fs(NBLK) + 2 * rows) + sizeof(float) * (size_t)(rows * O);
+    (void)O;
+    return sizeof(double) * (size_t)(rows * gramw_fs(NBLK));      // the feature tile
 }
 // rows per round: 64 where the feature tile + raw observations fit the 160 KB of LDS (Ant: 151 KB), else 32, else 16
 PROMP_HD int gramw_rows(int NBLK, int O) {
@@ -636,9 +637,6 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), i16 = lane & 15, kk = lane >> 4;
     const int FS = gramw_fs(NBLK), NPAIR = NBLK * (NBLK + 1) / 2, NC = 16 * NBLK;
     double* Phi = (double*)PROMP_SMEM_PTR;
-    double* Tg = Phi + GRAMW_ROWS * FS;
-    double* Tau = Tg + GRAMW_ROWS;
-    float* Ob = (float*)(Tau + GRAMW_ROWS);
     const WorkItem wk = a.work[blockIdx.x];
     const int O = a.O, D = a.D;
     // this wave's pairs: a contiguous range of the row-major list (bi, bj >= bi); offsets of the two 16-column blocks inside a
@@ -662,51 +660,49 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
     f64x4 acc[GRAMW_PPW];
 #pragma unroll
     for (int j = 0; j < GRAMW_PPW; ++j) acc[j] = zero4d();
+    // The feature tile is written straight from the loaded observations (element e of the [ROWS][O] chunk is observation e mod O
+    // of row e / O: columns c and O + c), 16 loads per thread in flight; threads 0 .. ROWS - 1 add their row's time features, the
+    // constant and the target.  Columns past D + 1 are zeroed once.  (Until round 4 the rows were staged raw in LDS and every
+    // feature column went through a branch tree: k_gram's 32.8 k of 52 k cycles.)
+    for (int e = tid; e < GRAMW_ROWS * FS; e += 512) Phi[e] = 0.0;
+    const float rO = 1.0f / (float)(O > 0 ? O : 1);
+    const int qt = (a.kind == BASE_LINFEAT) ? 2 * O : 0;        // first of the four time columns (tau, tau^2, tau^3, 1)
     for (int base = wk.row_begin; base < wk.row_end; base += GRAMW_ROWS) {
         const int nrows = (wk.row_end - base) < GRAMW_ROWS ? (wk.row_end - base) : GRAMW_ROWS;
-        __syncthreads();   // the previous round's MFMAs are done with Phi
+        __syncthreads();   // the previous round's MFMAs are done with Phi (first round: the zeros are in place)
         if (a.kind == BASE_LINFEAT) {
-            const int lim = nrows * O;
-            for (int e = tid; e < GRAMW_ROWS * O; e += 512) {
-                const float x = a.obs[(long long)base * O + (e < lim ? e : 0)];
-                Ob[e] = (e < lim) ? x : 0.f;
+            const int lim = nrows * O, tot = GRAMW_ROWS * O;
+            for (int e0 = tid; e0 < tot; e0 += 512 * 16) {
+                float x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int e = e0 + 512 * u;
+                    x[u] = a.obs[(long long)base * O + (e < lim ? e : 0)];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int e = e0 + 512 * u;
+                    if (e < tot) {
+                        const int r = (int)(((float)e + 0.5f) * rO), c = e - r * O;
+                        // (rows past the chunk's last become zeros.)  the reference squares in the observations' own dtype, then promotes
+                        const float oc = e < lim ? fminf(fmaxf(x[u], -10.f), 10.f) : 0.f;
+                        Phi[r * FS + c] = (double)oc;
+                        Phi[r * FS + O + c] = (double)(oc * oc);
+                    }
+                }
             }
         }
         if (tid < GRAMW_ROWS) {
-            const int r = tid < nrows ? tid : 0;
+            const bool rv = tid < nrows;
+            const int r = rv ? tid : 0;
             const double t = a.ret64[base + r];
-            const double tau = (double)a.row_t[base + r] / 100.0;
-            Tg[tid] = (tid < nrows) ? t : 0.0;
-            Tau[tid] = (tid < nrows) ? tau : 0.0;
-        }
-        __syncthreads();
-        for (int fr = tid >> 4; fr < GRAMW_ROWS; fr += 32) {   // features: 16 threads per row, columns fc0, fc0 + 16, ...
-            const int fc0 = tid & 15;
-            const bool rv = fr < nrows;
-            const double tau = Tau[fr];
-            for (int c = fc0; c < NC; c += 16) {
-                double f = 0.0;
-                if (rv) {
-                    int q = c;
-                    bool done = false;
-                    if (c == D) {
-                        f = Tg[fr];
-                        done = true;
-                    } else if (c > D) {
-                        done = true;
-                    } else if (a.kind == BASE_LINFEAT) {
-                        if (c < 2 * O) {
-                            const float o = Ob[fr * O + (c < O ? c : c - O)];
-                            const float oc = fminf(fmaxf(o, -10.f), 10.f);
-                            f = (c < O) ? (double)oc : (double)(oc * oc);   // squared in float32 like the reference
-                            done = true;
-                        }
-                        q = c - 2 * O;
-                    }
-                    if (!done) f = (q == 0) ? tau : (q == 1) ? tau * tau : (q == 2) ? tau * tau * tau : 1.0;
-                }
-                Phi[fr * FS + c] = f;
-            }
+            const double tau = rv ? (double)a.row_t[base + r] / 100.0 : 0.0;
+            double* pr = Phi + tid * FS;
+            pr[qt] = tau;
+            pr[qt + 1] = tau * tau;
+            pr[qt + 2] = tau * tau * tau;
+            pr[qt + 3] = rv ? 1.0 : 0.0;
+            pr[D] = rv ? t : 0.0;
         }
         __syncthreads();
         // The products, software-pipelined: the operands of the NEXT group of four pairs are requested before the current group's
