@@ -120,6 +120,12 @@ PROMP_DEV double shfl_down_f64(double v, int d) { return __shfl_down(v, d, 64); 
 PROMP_DEV double shfl_idx_f64(double v, int l) { return __shfl(v, l, 64); }
 // value of lane `l` (a compile-time or wave-uniform index) as a wave-uniform double: two v_readlane_b32 into scalar
 // registers, no LDS round trip
+// v_rsq_f64: the hardware's reciprocal-square-root seed (~2^-26 relative); rsq_refine is the one correction step the math library's
+// rsqrt() applies to it (e = 1 - d r0^2; r1 = r0 + r0 e (1/2 + 3/8 e): relative error ~2^-52).  Apart so that a caller can place
+// the five dependent operations between independent work (k_fit_wave's column step).
+PROMP_DEV double rsq_seed(double d) { return __builtin_amdgcn_rsq(d); }
+PROMP_DEV double rsq_e(double d, double r0) { return fma(-d * r0, r0, 1.0); }
+PROMP_DEV double rsq_finish(double r0, double e) { return fma(r0 * e, fma(e, 0.375, 0.5), r0); }
 PROMP_DEV double readlane_f64(double v, int l) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
@@ -179,6 +185,13 @@ PROMP_DEV int opaque_zero() {
     int z = 0;
     asm volatile("" : "+v"(z));
     return z;
+}
+// An LDS address the optimiser cannot see through: accesses at small constant offsets from it keep those offsets as instruction
+// immediates off ONE address register (folded into an absolute address they may not fit the offset field of ds_read2 / ds_write2).
+PROMP_DEV double* opaque_lds(double* p) {
+    unsigned a = (unsigned)(size_t)p;
+    asm volatile("" : "+v"(a));
+    return (double*)(__attribute__((address_space(3))) double*)(size_t)a;
 }
 // Tells the compiler a value is the same in every lane of the wave (e.g. the wave index threadIdx.x >> 6), so that
 // everything derived from it lives in scalar registers.

@@ -368,27 +368,41 @@ PROMP_DEV void fitw_column(double (&W)[DT], double* colbuf, double* rsv, double&
     colbuf[J * FITWV_CS + lane] = W[J];
     rsv[J] = rs;              // (every lane, the same value: the back substitution reads lane j's reciprocal from here)
     // lane k holds L[k][J] in W[J].  The first trailing column goes alone: it completes column J + 1, whose pivot's reciprocal
-    // square root (the long dependent sequence of a step) then runs beside the rest of this step's updates instead of after them.
+    // square root (seed + one correction: five dependent float64 operations) is then issued in pieces BETWEEN the batches of this
+    // step's remaining updates (a wave issues in order: the pieces only overlap with independent work that sits between them in
+    // the instruction stream; sched_fence pins that order).
+    double dn = 1.0, r0 = 1.0, e = 0.0;
     if (J + 1 < DT) {
         W[J + 1] -= W[J] * readlane_f64(W[J], J + 1);
-        rs = rsqrt(readlane_f64(W[J + 1], J + 1));
+        dn = readlane_f64(W[J + 1], J + 1);
+        r0 = rsq_seed(dn);
     }
     // Eight multipliers are read into eight scalar pairs before the first product: a plain loop compiles to "readlane, readlane,
-    // s_nop, fma" on ONE pair (41 cycles per column, measured).  (Broadcast reads of the LDS copy instead of v_readlane were
-    // tried: the addresses do not fit ds_read2's offsets, the compiler keeps them in spilled scalars, 1270 cycles per step.)
+    // s_nop, fma" on ONE pair (41 cycles per column).  What is left is the price of the multipliers themselves: two v_readlane
+    // and the product cost 30 cycles per trailing column in any order (990 columns: the 29 k cycles of this phase, measured).
+    // Broadcast reads of the LDS copy instead (ds_read2_b64 off one opaque address register, four in flight) were tried and are
+    // slower: the LDS round trip sits on every step's dependent path, 34.5 k cycles.
+    constexpr int NBATCH = (DT - (J + 2) + 7) / 8;
 #pragma unroll
-    for (int k0 = J + 2; k0 < DT; k0 += 8) {
+    for (int b = 0; b < (NBATCH > 0 ? NBATCH : 0); ++b) {
+        const int k0 = J + 2 + 8 * b;
         double m[8];
+        sched_fence();
 #pragma unroll
         for (int u = 0; u < 8; ++u) m[u] = (k0 + u < DT) ? readlane_f64(W[J], k0 + u) : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (k0 + u < DT) W[k0 + u] -= W[J] * m[u];
+        sched_fence();
+        if (b == 0) e = rsq_e(dn, r0);
+        if (b == 1 || (b == 0 && NBATCH == 1)) rs = rsq_finish(r0, e);
     }
+    if (NBATCH <= 0) rs = rsq_finish(r0, rsq_e(dn, r0));
 }
 template <int DT, int... Js>
 PROMP_DEV void fitw_columns(double (&W)[DT], double* colbuf, double* rsv, int lane, int D, std::integer_sequence<int, Js...>) {
-    double rs = rsqrt(readlane_f64(W[0], 0));
+    const double d0 = readlane_f64(W[0], 0), s0 = rsq_seed(d0);
+    double rs = rsq_finish(s0, rsq_e(d0, s0));
     (fitw_column<Js, DT>(W, colbuf, rsv, rs, lane, D), ...);
 }
 

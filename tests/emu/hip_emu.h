@@ -319,6 +319,7 @@ inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __A
 inline void atomic_store_agent(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline void sched_fence() {}
 inline int opaque_zero() { return 0; }
+inline double* opaque_lds(double* p) { return p; }
 inline f32x4 pin_agpr(f32x4 v) { return v; }
 inline int wave_uniform(int v) { return v; }
 // the product's XCD-aware work-item bijection (promp_device.h), so that the emulated kernels take the same items
@@ -338,6 +339,9 @@ template <class T> inline void pin_s(T&) {}
 inline unsigned long long promp_clock() { return 0; }
 inline unsigned long long promp_wall_clock() { return 0; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }
+inline double rsq_seed(double d) { return 1.0 / sqrt(d); }
+inline double rsq_e(double d, double r0) { return fma(-d * r0, r0, 1.0); }
+inline double rsq_finish(double r0, double e) { return fma(r0 * e, fma(e, 0.375, 0.5), r0); }
 inline float fast_exp(float x) { return expf(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_exp2(float x) { return exp2f(x); }
