@@ -118,8 +118,11 @@ struct ChainLds {
     int bplanes, bplane_stride;              // (bwdp) the same kernels' planes in the orientation of the backward product
     int flag;                                // one int: "this workgroup arrived last"
     int wave0, wave_stride, tb0, tb1, db0, db1;
+    int tp, tah;                             // (bwdp) BF16 plane tiles of the hidden_1 kernel gradient, over tb0 / tb1
     int total;
 };
+#define PROMP_CH_TPL 512         // words per plane of a [16 samples][64 units] bf16 tile (B operand of the hidden_1 kernel gradient)
+#define PROMP_CH_APL 256         // words per plane of a [16 samples][32 units] bf16 half tile (its A operand, one 32-unit block at a time)
 
 // dist block of the theta network: 6 x 8 floats
 enum { CH_LS = 0, CH_ES = 8, CH_SN2 = 16, CH_LMASK = 24, CH_VLS = 32, CH_RDEN = 40 };
@@ -167,6 +170,11 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
     int q = 0;
     L.tb0 = q; q += 16 * PROMP_CH_TS;
     L.tb1 = q; q += 16 * PROMP_CH_TS;
+    if (bwdp) {                   // the hidden_1 kernel gradient's plane tiles alias the float32 transpose tiles (the phases of a
+        L.tp = 0;                 // tile are sequential): 3 planes of the B operand + 3 half planes of the A operand
+        L.tah = 3 * PROMP_CH_TPL;
+        if (q < L.tah + 3 * PROMP_CH_APL) q = L.tah + 3 * PROMP_CH_APL;
+    }
     L.db0 = q; q += 16 * PROMP_CH_DS;
     L.db1 = q; q += hvp ? 16 * PROMP_CH_DS : 0;
     L.wave_stride = q;
@@ -203,6 +211,61 @@ PROMP_DEV f32x4 lds4(const float* p) { return *(const f32x4*)p; }
 PROMP_DEV f32x2 lds2(const float* p) { return *(const f32x2*)p; }
 PROMP_DEV void sts4(float* p, f32x4 v) { *(f32x4*)p = v; }
 PROMP_DEV void sts2(float* p, f32x2 v) { *(f32x2*)p = v; }
+
+// ---- BF16 operand planes through LDS (shared with k_pass, promp_kernels_pass.h) -------------------------------------------
+// Weight gradients contract over samples and need both operands with the unit along the lane index.  An operand's three BF16
+// planes go through a per-wave LDS tile of 8-byte chunks (4 units of one sample, written by the chain side with ds_write_b64)
+// and come back through ds_read_b64_tr_b16, the 4 x 16 transpose read of gfx950: two reads give a lane the eight samples of
+// its unit, the products run on v_mfma_f32_32x32x16_bf16 (K = 16 samples).
+// chunk (sample s of 16, unit chunk q = unit / 4) of a transposed tile -> its 8-byte slot.  For the writer (16 lanes = 16
+// samples of one chunk column: ds_write_b64, banks mod 32) the low four bits are a bijection of s; for the transpose read of a
+// 32-unit block (32 lanes = 4 samples x 8 chunks, banks mod 64) the low five bits are a bijection of (s & 3, q & 7).
+PROMP_CX int pass_slot(int s, int q) { return 32 * (4 * (q >> 3) + (q & 3)) + 16 * ((q >> 2) & 1) + 4 * (s & 3) + ((s >> 2) ^ (q & 3)); }
+
+PROMP_DEV void sts_w2(float* p, unsigned a, unsigned b) {
+    u32x2 v;
+    v[0] = a;
+    v[1] = b;
+    *(u32x2*)p = v;
+}
+PROMP_DEV void sts_w4(float* p, u32x4 v) { *(u32x4*)p = v; }
+PROMP_DEV u32x4 join_w2(u32x2 lo, u32x2 hi) {
+    u32x4 v;
+    v[0] = lo[0];
+    v[1] = lo[1];
+    v[2] = hi[0];
+    v[3] = hi[1];
+    return v;
+}
+// a lane's eight k-slots of one input chunk (blocks 2P, 2P + 1) -> the three BF16 planes
+PROMP_DEV void pass_split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
+    unsigned w0[3], w1[3], w2[3], w3[3];
+    bf16_split3_pair(lo[0], lo[1], w0);
+    bf16_split3_pair(lo[2], lo[3], w1);
+    bf16_split3_pair(hi[0], hi[1], w2);
+    bf16_split3_pair(hi[2], hi[3], w3);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        pl[t][0] = w0[t];
+        pl[t][1] = w1[t];
+        pl[t][2] = w2[t];
+        pl[t][3] = w3[t];
+    }
+}
+// a chunk pair (blocks 2P, 2P + 1 of sample i16) of three planes -> a transposed tile
+PROMP_DEV void pass_store_planes(float* tile, int plane_words, int off, const u32x4 (&pl)[3]) {
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        sts_w2(tile + tt * plane_words + off, pl[tt][0], pl[tt][1]);
+        sts_w2(tile + tt * plane_words + off + 32, pl[tt][2], pl[tt][3]);
+    }
+}
+// the three planes of a 32-unit (or 16-unit) block as a lane's eight samples: two transpose reads each
+PROMP_DEV void pass_read_tr(u32x4 (&fr)[3], const float* tile, int plane_words, int rd0, int rd1) {
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) fr[tt] = join_w2(lds_tr16(tile + tt * plane_words + rd0), lds_tr16(tile + tt * plane_words + rd1));
+}
+
 
 // The networks of a segment (theta, and the direction, negated) -> fragment order in LDS, plus the BF16 planes of both
 // hidden_1 kernels.  A wave stages whole blocks of 64 four-float fragments (the block is wave-uniform, so a fragment's source
@@ -419,9 +482,12 @@ PROMP_DEV f32x4 tanh4(f32x4 z) {
 // Cross-wave, fixed-order sum of the waves' gradient tiles -> one partial row in global memory.
 // Every wave stores its tiles to its own LDS slab of [NP + 2] floats (plain stores, every entry written exactly once);
 // then all threads add the slabs in wave order.  (NW x [NP + 2] floats alias the parameter / transpose regions.)
-template <int NC1, int NC2, int NOB, int NW>
-PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC1][NC2], const f32x4 (&aw1)[NOB][NC1],
-                                       const f32x4 (&aw3)[NC2], const float (&gb1)[NC1], const float (&gb2)[NC2], float gs0,
+// W32: the hidden_1 kernel gradient arrives in the 32 x 32 result layout (aw2w) and its bias gradient in the chain layout
+// (gb2v: units 16 c + 4 kk + r, already summed over the 16 sample lanes) instead of aw2 / gb2.
+template <int NC1, int NC2, int NOB, int NW, bool W32 = false>
+PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC1][NC2], const f32x16 (&aw2w)[NC1 / 2][NC2 / 2],
+                                       const f32x4 (&aw1)[NOB][NC1], const f32x4 (&aw3)[NC2], const float (&gb1)[NC1],
+                                       const float (&gb2)[NC2], const f32x4 (&gb2v)[NC2], float gs0,
                                        float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
@@ -430,12 +496,23 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
     lds_barrier();                // every wave is done with the parameter / transpose regions
     {
         float* mine = S + w * SL;
+        if (W32) {
+            const int j32 = lane & 31, kh = lane >> 5;
 #pragma unroll
-        for (int i = 0; i < NC1; ++i)
+            for (int bi = 0; bi < NC1 / 2; ++bi)
 #pragma unroll
-            for (int j = 0; j < NC2; ++j)
+                for (int bj = 0; bj < NC2 / 2; ++bj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[oW2 + (16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+                    for (int r = 0; r < 16; ++r)
+                        mine[oW2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + 32 * bj + j32] = aw2w[bi][bj][r];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC1; ++i)
+#pragma unroll
+                for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[oW2 + (16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+        }
 #pragma unroll
         for (int i = 0; i < NOB; ++i)
 #pragma unroll
@@ -453,8 +530,16 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
         if (kk == 0) {
 #pragma unroll
             for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+            if (!W32) {
 #pragma unroll
-            for (int j = 0; j < NC2; ++j) mine[ob2 + 16 * j + i16] = gb2[j];
+                for (int j = 0; j < NC2; ++j) mine[ob2 + 16 * j + i16] = gb2[j];
+            }
+        }
+        if (W32 && i16 == 0) {
+#pragma unroll
+            for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[ob2 + 16 * j + 4 * kk + r] = gb2v[j][r];
         }
         if (i16 == 0) {           // lane (0, kk) holds the sums of actions 2 kk, 2 kk + 1
             if (2 * kk < A) {
@@ -629,6 +714,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     const bool own0 = a0 < A, own1 = a1 < A;
     const int q0 = own0 ? a0 : 0, q1 = own1 ? a1 : 0;
     const float klw = a.kl_weight;
+    // CACHED: the hidden_1 kernel gradient runs on v_mfma_f32_32x32x16_bf16 (round 4): its operands' BF16 planes go through
+    // swizzled tiles over TB0 / TB1 and come back through the transpose read (pass_slot; word addresses of this lane)
+    constexpr int NB1 = NC1 / 2, NB2 = NC2 / 2, TPL = PROMP_CH_TPL, APL = PROMP_CH_APL;
+    float *TBP = wreg + L.tp, *TAH = wreg + L.tah;
+    const int twr = 2 * pass_slot(i16, kk);
+    const int trd0 = 2 * pass_slot(8 * (lane >> 5) + (i16 >> 2), 4 * (kk & 1) + (i16 & 3));
+    const int trd1 = 2 * pass_slot(8 * (lane >> 5) + 4 + (i16 >> 2), 4 * (kk & 1) + (i16 & 3));
 
     const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
     CH_WGSTAMP(0);
@@ -696,6 +788,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         for (int j = 0; j < NC1; ++j) ob1acc[j] = 0.f;
 #pragma unroll
         for (int j = 0; j < NC2; ++j) ob2acc[j] = 0.f;
+        // CACHED: the hidden_1 kernel gradient in the 32 x 32 result layout, its bias gradient in the chain layout
+        f32x16 aw2w[NB1][NB2];
+        f32x4 gb2v[NC2];
+#pragma unroll
+        for (int i = 0; i < NB1; ++i)
+#pragma unroll
+            for (int j = 0; j < NB2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) aw2w[i][j][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC2; ++j) gb2v[j] = zero4();
         float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
 
         int tix = 0;
@@ -978,45 +1081,110 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     }
             }
             CH_TSTAMP(6);
-            // ---- out_W2 += R'H1^T dZ2 + H1^T qZ2 (two rounds through the transpose tiles); out_b2 += sum qZ2
-            wave_fence();
+            // ---- out_W2 += R'H1^T dZ2 + H1^T qZ2 ; out_b2 += sum qZ2
+            u32x4 dB[NB2][3], qB[NB2][3];     // CACHED: the BF16 planes of dZ2 / qZ2 (this product and qZ1 below)
+            if (CACHED) {
+                // On v_mfma_f32_32x32x16_bf16 (K = 16 samples = one tile), float32-equivalent: 6 of the 9 term products.  Four
+                // stages (product, 32-unit block of the A operand): (R'H1, dZ2) x NB1, (H1, qZ2) x NB1.  The B planes of a product
+                // sit in the full tile TBP, the A planes of one stage in the half tile TAH; a stage writes and requests the NEXT
+                // stage's operands before it issues its own products (LDS executes a wave's instructions in order: the half tile
+                // is rewritten behind the reads that were issued from it).
 #pragma unroll
-            for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, rh1[c]);
-#pragma unroll
-            for (int c = 0; c < NC2; ++c) sts4(TB1w + 16 * c, dz2[c]);
-            wave_fence();
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                float aop[NC1], bop[NC2];
-#pragma unroll
-                for (int c = 0; c < NC1; ++c) aop[c] = TB0r[t4 * TS + 16 * c];
-#pragma unroll
-                for (int c = 0; c < NC2; ++c) bop[c] = TB1r[t4 * TS + 16 * c];
-#pragma unroll
-                for (int i = 0; i < NC1; ++i)
-#pragma unroll
-                    for (int j = 0; j < NC2; ++j) aw2[i][j] = mfma16(aop[i], bop[j], aw2[i][j]);
-            }
-            wave_fence();
-#pragma unroll
-            for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, h1[c]);
-#pragma unroll
-            for (int c = 0; c < NC2; ++c) sts4(TB1w + 16 * c, qz2[c]);
-            wave_fence();
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                float aop[NC1], bop[NC2];
-#pragma unroll
-                for (int c = 0; c < NC1; ++c) aop[c] = TB0r[t4 * TS + 16 * c];
-#pragma unroll
-                for (int c = 0; c < NC2; ++c) {
-                    bop[c] = TB1r[t4 * TS + 16 * c];
-                    ob2acc[c] += bop[c];
+                for (int P = 0; P < NB2; ++P) {
+                    pass_split8(dz2[2 * P], dz2[2 * P + 1], dB[P]);
+                    pass_split8(qz2[2 * P], qz2[2 * P + 1], qB[P]);
                 }
 #pragma unroll
-                for (int i = 0; i < NC1; ++i)
+                for (int c = 0; c < NC2; ++c) gb2v[c] += qz2[c];
+                wave_fence();         // the output-kernel gradient's reads of TB0 / TB1 precede these writes
 #pragma unroll
-                    for (int j = 0; j < NC2; ++j) aw2[i][j] = mfma16(aop[i], bop[j], aw2[i][j]);
+                for (int P = 0; P < NB2; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, dB[P]);
+                u32x4 fa[3], fb[NB2][3];
+                {
+                    u32x4 aB[3];
+                    pass_split8(rh1[0], rh1[1], aB);
+                    pass_store_planes(TAH, APL, twr, aB);
+                }
+                wave_fence();
+                pass_read_tr(fa, TAH, APL, trd0, trd1);
+#pragma unroll
+                for (int b = 0; b < NB2; ++b) pass_read_tr(fb[b], TBP, TPL, trd0 + 256 * b, trd1 + 256 * b);
+#pragma unroll
+                for (int s = 0; s < 2 * NB1; ++s) {
+                    const int hb = s % NB1;
+                    u32x4 fan[3];
+                    if (s + 1 < 2 * NB1) {
+                        const int pn = (s + 1) / NB1, hn = (s + 1) % NB1;
+                        u32x4 aB[3];
+                        if (pn == 0) pass_split8(rh1[2 * hn], rh1[2 * hn + 1], aB);
+                        else pass_split8(h1[2 * hn], h1[2 * hn + 1], aB);
+                        wave_fence();
+                        pass_store_planes(TAH, APL, twr, aB);
+                        if (hn == 0) {
+#pragma unroll
+                            for (int P = 0; P < NB2; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, qB[P]);
+                        }
+                        wave_fence();
+                        pass_read_tr(fan, TAH, APL, trd0, trd1);
+                    }
+#pragma unroll
+                    for (int ta = 2; ta >= 0; --ta)
+#pragma unroll
+                        for (int tb = 2 - ta; tb >= 0; --tb)
+#pragma unroll
+                            for (int bj = 0; bj < NB2; ++bj) aw2w[hb][bj] = mfma32_bf16w(fa[ta], fb[bj][tb], aw2w[hb][bj]);
+                    if (s + 1 < 2 * NB1) {
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt) fa[tt] = fan[tt];
+                        if ((s + 1) % NB1 == 0) {     // the second product's B planes: behind the first product's last instructions
+                            sched_fence();            // (their registers are the first product's; the planes were written above)
+#pragma unroll
+                            for (int b = 0; b < NB2; ++b) pass_read_tr(fb[b], TBP, TPL, trd0 + 256 * b, trd1 + 256 * b);
+                        }
+                    }
+                    sched_fence();
+                }
+                wave_fence();
+            } else {
+                wave_fence();
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, rh1[c]);
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) sts4(TB1w + 16 * c, dz2[c]);
+                wave_fence();
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    float aop[NC1], bop[NC2];
+#pragma unroll
+                    for (int c = 0; c < NC1; ++c) aop[c] = TB0r[t4 * TS + 16 * c];
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) bop[c] = TB1r[t4 * TS + 16 * c];
+#pragma unroll
+                    for (int i = 0; i < NC1; ++i)
+#pragma unroll
+                        for (int j = 0; j < NC2; ++j) aw2[i][j] = mfma16(aop[i], bop[j], aw2[i][j]);
+                }
+                wave_fence();
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, h1[c]);
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) sts4(TB1w + 16 * c, qz2[c]);
+                wave_fence();
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    float aop[NC1], bop[NC2];
+#pragma unroll
+                    for (int c = 0; c < NC1; ++c) aop[c] = TB0r[t4 * TS + 16 * c];
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) {
+                        bop[c] = TB1r[t4 * TS + 16 * c];
+                        ob2acc[c] += bop[c];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NC1; ++i)
+#pragma unroll
+                        for (int j = 0; j < NC2; ++j) aw2[i][j] = mfma16(aop[i], bop[j], aw2[i][j]);
+                }
             }
             CH_TSTAMP(7);
             float xN[NOB][4];
@@ -1048,21 +1216,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
                     for (int P = 0; P < NC2 / 2; ++P) {
-                        const float xd[8] = {dz2[2 * P][0], dz2[2 * P][1], dz2[2 * P][2], dz2[2 * P][3],
-                                             dz2[2 * P + 1][0], dz2[2 * P + 1][1], dz2[2 * P + 1][2], dz2[2 * P + 1][3]};
-                        const float xq[8] = {qz2[2 * P][0], qz2[2 * P][1], qz2[2 * P][2], qz2[2 * P][3],
-                                             qz2[2 * P + 1][0], qz2[2 * P + 1][1], qz2[2 * P + 1][2], qz2[2 * P + 1][3]};
-                        bf16x8 dB[3], qB[3];
-                        bf16_split3(xd, dB);
-                        bf16_split3(xq, qB);
+                        // (the planes of dZ2 / qZ2 are the hidden_1 kernel gradient's: split once per tile)
 #pragma unroll
                         for (int p = 0; p < 6; ++p) {
 #pragma unroll
                             for (int c1 = 0; c1 < NC1; ++c1)
-                                qz1[c1] = mfma16_bf16(Wq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], qB[TB[p]], qz1[c1]);
+                                qz1[c1] = mfma16_bf16(Wq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], __builtin_bit_cast(bf16x8, qB[P][TB[p]]), qz1[c1]);
 #pragma unroll
                             for (int c1 = 0; c1 < NC1; ++c1)
-                                qz1[c1] = mfma16_bf16(Vq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], dB[TB[p]], qz1[c1]);
+                                qz1[c1] = mfma16_bf16(Vq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], __builtin_bit_cast(bf16x8, dB[P][TB[p]]), qz1[c1]);
                         }
                     }
                 } else {
@@ -1136,10 +1298,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         for (int j = 0; j < NC1; ++j) ob1acc[j] = fold_groups16(ob1acc[j]);
 #pragma unroll
         for (int j = 0; j < NC2; ++j) ob2acc[j] = fold_groups16(ob2acc[j]);
+        if (CACHED) {
+#pragma unroll
+            for (int j = 0; j < NC2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gb2v[j][r] = row16_sum(gb2v[j][r]);
+        }
         outs0 *= dist[CH_LMASK + q0];
         outs1 *= dist[CH_LMASK + q1];
         float* P = a.partials + (long long)sg * a.partial_stride;
-        chain_reduce_to_partial<NC1, NC2, NOB, NW>(sm + 4, P, aw2, aw1, aw3, ob1acc, ob2acc, outs0, outs1, outb30, outb31, 0.f, klsum, O, A, tid);
+        chain_reduce_to_partial<NC1, NC2, NOB, NW, CACHED>(sm + 4, P, aw2, aw2w, aw1, aw3, ob1acc, ob2acc, gb2v, outs0, outs1, outb30, outb31, 0.f, klsum, O, A, tid);
         CH_STAMP(3);
         if (a.fuse_reduce) chain_task_reduce<NT>(a, (int*)sm, task, NP, tid);
         CH_STAMP(4);

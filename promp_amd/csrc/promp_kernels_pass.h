@@ -35,11 +35,6 @@
 #include "promp_device.h"
 #include "promp_kernels_chain.h"
 
-// chunk (sample s of 16, unit chunk q = unit / 4) of a transposed tile -> its 8-byte slot.  For the writer (16 lanes = 16
-// samples of one chunk column: ds_write_b64, banks mod 32) the low four bits are a bijection of s; for the transpose read of a
-// 32-unit block (32 lanes = 4 samples x 8 chunks, banks mod 64) the low five bits are a bijection of (s & 3, q & 7).
-PROMP_CX int pass_slot(int s, int q) { return 32 * (4 * (q >> 3) + (q & 3)) + 16 * ((q >> 2) & 1) + 4 * (s & 3) + ((s >> 2) ^ (q & 3)); }
-
 // The six products (A-side term ta, B-side term tb) with ta + tb <= 2 are walked by A-side term: (2,0) (1,1) (1,0) (0,2) (0,1) (0,0)
 // -- roughly smallest first, and an A-side fragment is read once and feeds one to three consecutive instructions.
 // (1,2), (2,1), (2,2) are below 2^-24 of the result and dropped.
@@ -92,36 +87,6 @@ PROMP_CX PassLds pass_layout(int NC1, int NC2, int nwaves, int NP) {
 // unit a lane's k-slot e of input chunk P stands for: its own D register (block 2P + e / 4, row e % 4)
 PROMP_CX int pass_unit(int P, int kk, int e) { return 16 * (2 * P + (e >> 2)) + 4 * kk + (e & 3); }
 
-PROMP_DEV void sts_w2(float* p, unsigned a, unsigned b) {
-    u32x2 v;
-    v[0] = a;
-    v[1] = b;
-    *(u32x2*)p = v;
-}
-PROMP_DEV void sts_w4(float* p, u32x4 v) { *(u32x4*)p = v; }
-PROMP_DEV u32x4 join_w2(u32x2 lo, u32x2 hi) {
-    u32x4 v;
-    v[0] = lo[0];
-    v[1] = lo[1];
-    v[2] = hi[0];
-    v[3] = hi[1];
-    return v;
-}
-// a lane's eight k-slots of one input chunk (blocks 2P, 2P + 1) -> the three BF16 planes
-PROMP_DEV void pass_split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
-    unsigned w0[3], w1[3], w2[3], w3[3];
-    bf16_split3_pair(lo[0], lo[1], w0);
-    bf16_split3_pair(lo[2], lo[3], w1);
-    bf16_split3_pair(hi[0], hi[1], w2);
-    bf16_split3_pair(hi[2], hi[3], w3);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        pl[t][0] = w0[t];
-        pl[t][1] = w1[t];
-        pl[t][2] = w2[t];
-        pl[t][3] = w3[t];
-    }
-}
 // tanh of a pre-activation that arrives scaled by PROMP_TANH_PRESCALE, and h^2 - 1 (the NEGATED derivative): unpacked float32
 // instructions (packed-f32 VALU beside MFMAs costs more than the issue slot it saves: MI355X_MICROARCH.md)
 PROMP_DEV float pass_tanh(float y) { return __builtin_fmaf(fast_rcp(fast_exp2(y) + 1.f), -2.f, 1.f); }
@@ -412,20 +377,6 @@ PROMP_DEV void pass_load_frags(u32x4 (&wf)[3][NC], const u32x4* F, int PS, int f
 #pragma unroll
         for (int c = 0; c < NC; ++c) wf[ta][c] = F[ta * PS + first + c * cs];
 }
-// a chunk pair (blocks 2P, 2P + 1 of sample i16) of three planes -> a transposed tile
-PROMP_DEV void pass_store_planes(float* tile, int plane_words, int off, const u32x4 (&pl)[3]) {
-#pragma unroll
-    for (int tt = 0; tt < 3; ++tt) {
-        sts_w2(tile + tt * plane_words + off, pl[tt][0], pl[tt][1]);
-        sts_w2(tile + tt * plane_words + off + 32, pl[tt][2], pl[tt][3]);
-    }
-}
-// the three planes of a 32-unit (or 16-unit) block as a lane's eight samples: two transpose reads each
-PROMP_DEV void pass_read_tr(u32x4 (&fr)[3], const float* tile, int plane_words, int rd0, int rd1) {
-#pragma unroll
-    for (int tt = 0; tt < 3; ++tt) fr[tt] = join_w2(lds_tr16(tile + tt * plane_words + rd0), lds_tr16(tile + tt * plane_words + rd1));
-}
-
 // One 16-sample tile, front to back.  `w1f` arrives loaded (layer 1's fragments, requested at the end of the previous tile)
 // and leaves requested for the next tile; `xr` likewise (the observations).
 // One tile's pending hidden_0 kernel gradient: the operand planes (already in registers) of aw1 += X^T dZ1.  Its matrix
