@@ -665,6 +665,54 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
     chain_task_sum<NT>(r, tid);
 }
 
+// Two-network product of the R-operator pass on the BF16 pipe, operands streamed:
+//     acc[c] += W[.][c] xa + V[.][c] xb          (PRIMAL: accp[c] += W[.][c] xb as well)
+// W / V: the BF16 planes [term][c < NCO][chunk P < NPK][lane] of theta's and the direction's kernel, xa / xb: the planes of the two
+// activations (a lane's eight k-slots of chunk P).  Six of the nine term products, walked by weight term (2,0) (1,1) (1,0) (0,2)
+// (0,1) (0,0) -- roughly smallest first -- so that a weight fragment is read ONCE and feeds one to three consecutive groups of
+// instructions, and only two terms' fragments are in registers at a time: the fragments of group g + 1 are requested before the
+// products of group g are issued (left alone the compiler reads a fragment right in front of its first product, and the single wave
+// of a SIMD sits out one LDS latency per fragment: ~45 cycles x 35 waits per tile in each of the two K = 64 products, measured).
+template <int NCO, int NPK, bool PRIMAL>
+PROMP_DEV void chain_gemm2_bf16(f32x4 (&acc)[NCO], f32x4 (&accp)[NCO], const bf16x8* Wp, const bf16x8* Vp, const u32x4 (&xa)[NPK][3],
+                                const u32x4 (&xb)[NPK][3]) {
+    constexpr int NG = 3 * NPK, NM = (PRIMAL ? 3 : 2) * NCO;
+    bf16x8 fw[2][NCO], fv[2][NCO];
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        fw[0][c] = Wp[((2 * NCO + c) * NPK + 0) * 64];
+        fv[0][c] = Vp[((2 * NCO + c) * NPK + 0) * 64];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int P = g / 3, ta = 2 - g % 3, cur = g & 1, nxt = cur ^ 1;
+        if (g + 1 < NG) {
+            const int Pn = (g + 1) / 3, tan = 2 - (g + 1) % 3;
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) {
+                fw[nxt][c] = Wp[((tan * NCO + c) * NPK + Pn) * 64];
+                fv[nxt][c] = Vp[((tan * NCO + c) * NPK + Pn) * 64];
+            }
+        }
+#pragma unroll
+        for (int tb = 2 - ta; tb >= 0; --tb) {
+            if (PRIMAL) {
+#pragma unroll
+                for (int c = 0; c < NCO; ++c) accp[c] = mfma16_bf16(fw[cur][c], __builtin_bit_cast(bf16x8, xb[P][tb]), accp[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) acc[c] = mfma16_bf16(fw[cur][c], __builtin_bit_cast(bf16x8, xa[P][tb]), acc[c]);
+#pragma unroll
+            for (int c = 0; c < NCO; ++c) acc[c] = mfma16_bf16(fv[cur][c], __builtin_bit_cast(bf16x8, xb[P][tb]), acc[c]);
+        }
+        if (g + 1 < NG) PROMP_SCHED_DSREAD(2 * NCO);        // the requests first, then the products
+        if (ta == 2) PROMP_SCHED_MFMA(NM);
+        else if (ta == 1) PROMP_SCHED_MFMA(2 * NM);
+        else PROMP_SCHED_MFMA(3 * NM);
+        sched_fence();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_chain_hvp:  out = -(d^2 L/d theta^2) v + kl_weight * grad KL   (R-operator, see oracle/promp.py:hvp)
 //
@@ -873,34 +921,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 {
                     // R'z2 += W2^T R'H1 + (-vW2)^T H1 on the BF16 pipe: K = 32 per instruction = two 16-unit input blocks; a
                     // lane's eight k-slots are its own registers of the two blocks (units 16 c + 4 kk + r), split three ways
-                    const bf16x8* Wp = (const bf16x8*)(sm + L.planes) + lane;
-                    const bf16x8* Vp = (const bf16x8*)(sm + L.planes + L.plane_stride) + lane;
+                    // (!CACHED: the primal product z2 = W2^T H1 rides on the same planes and splits)
+                    u32x4 rB[NC1 / 2][3], hB[NC1 / 2][3];
 #pragma unroll
                     for (int P = 0; P < NC1 / 2; ++P) {
-                        const float xr[8] = {rh1[2 * P][0], rh1[2 * P][1], rh1[2 * P][2], rh1[2 * P][3],
-                                             rh1[2 * P + 1][0], rh1[2 * P + 1][1], rh1[2 * P + 1][2], rh1[2 * P + 1][3]};
-                        const float xh[8] = {h1[2 * P][0], h1[2 * P][1], h1[2 * P][2], h1[2 * P][3],
-                                             h1[2 * P + 1][0], h1[2 * P + 1][1], h1[2 * P + 1][2], h1[2 * P + 1][3]};
-                        bf16x8 rB[3], hB[3];
-                        bf16_split3(xr, rB);
-                        bf16_split3(xh, hB);
-                        // (weight term, activation term), smallest products first; (1,2), (2,1), (2,2) are below 2^-24
-                        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-                        for (int p = 0; p < 6; ++p) {
-                            if (!CACHED) {        // the primal product z2 = W2^T H1 rides on the same planes and splits
-#pragma unroll
-                                for (int c2 = 0; c2 < NC2; ++c2)
-                                    h2[c2] = mfma16_bf16(Wp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], hB[TB[p]], h2[c2]);
-                            }
-#pragma unroll
-                            for (int c2 = 0; c2 < NC2; ++c2)
-                                rh2[c2] = mfma16_bf16(Wp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], rB[TB[p]], rh2[c2]);
-#pragma unroll
-                            for (int c2 = 0; c2 < NC2; ++c2)
-                                rh2[c2] = mfma16_bf16(Vp[((TA[p] * NC2 + c2) * (NC1 / 2) + P) * 64], hB[TB[p]], rh2[c2]);
-                        }
+                        pass_split8(rh1[2 * P], rh1[2 * P + 1], rB[P]);
+                        pass_split8(h1[2 * P], h1[2 * P + 1], hB[P]);
                     }
+                    chain_gemm2_bf16<NC2, NC1 / 2, !CACHED>(rh2, h2, (const bf16x8*)(sm + L.planes) + lane,
+                                                            (const bf16x8*)(sm + L.planes + L.plane_stride) + lane, rB, hB);
                 }
 #pragma unroll
                 for (int c = 0; c < NC2; ++c)
@@ -1211,22 +1240,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     // On the BF16 pipe (round 3): K = 32 hidden_1 output units per instruction = two 16-unit blocks, a lane's eight
                     // k-slots are its own registers of the two blocks, split three ways; the planes of the second orientation
                     // come from LDS (chain_layout, bwdp).  6 of the 9 term products, smallest first, as in layer 2.
-                    const bf16x8* Wq = (const bf16x8*)(sm + L.bplanes) + lane;
-                    const bf16x8* Vq = (const bf16x8*)(sm + L.bplanes + L.bplane_stride) + lane;
-                    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-                    for (int P = 0; P < NC2 / 2; ++P) {
-                        // (the planes of dZ2 / qZ2 are the hidden_1 kernel gradient's: split once per tile)
-#pragma unroll
-                        for (int p = 0; p < 6; ++p) {
-#pragma unroll
-                            for (int c1 = 0; c1 < NC1; ++c1)
-                                qz1[c1] = mfma16_bf16(Wq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], __builtin_bit_cast(bf16x8, qB[P][TB[p]]), qz1[c1]);
-#pragma unroll
-                            for (int c1 = 0; c1 < NC1; ++c1)
-                                qz1[c1] = mfma16_bf16(Vq[((TA[p] * NC1 + c1) * (NC2 / 2) + P) * 64], __builtin_bit_cast(bf16x8, dB[P][TB[p]]), qz1[c1]);
-                        }
-                    }
+                    chain_gemm2_bf16<NC1, NC2 / 2, false>(qz1, ad1, (const bf16x8*)(sm + L.bplanes) + lane,
+                                                          (const bf16x8*)(sm + L.bplanes + L.bplane_stride) + lane, qB, dB);
                 } else {
                 // the operands of k-group g + 1 are requested before the products of group g are issued (a fence per group keeps
                 // that order): left alone the compiler reads each operand right in front of its product, and the single wave of
