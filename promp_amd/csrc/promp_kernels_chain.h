@@ -288,6 +288,11 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
     constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2, NB4 = BWDP ? NC1 * (NC2 / 2) : 0;
     constexpr int IT1 = (NB1 + NW - 1) / NW, IT2 = (NB2 + NW - 1) / NW, IT3 = (NB3 + NW - 1) / NW, IT4 = (NB4 + NW - 1) / NW;
     constexpr int N5 = H1 + H2 + 8, IS = (N5 + NT - 1) / NT;
+    // An opaque copy of the thread index: the lane-constant index arithmetic below is otherwise hoisted out of the segment loop,
+    // kept alive across the tile loop -- which has no register to spare -- and spilled.  A scratch reload in the middle of the load
+    // phase waits for every load issued before it (memory returns a wave's loads in order), and the phase becomes two round trips
+    // to memory: 9.4 k instead of 5.4 k cycles until the last load is issued, k_chain_hvp 100.2 -> 96.4 us per launch (measured).
+    tid += opaque_zero();
     const int lane = tid & 63, i16 = lane & 15, kk = lane >> 4, w = wave_uniform(tid >> 6);
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A;
     // output block: the action of row i16.  Fragment order by action SLOT (slot 4 ko + ro <-> action 2 ko + ro, ro < 2; the other
