@@ -495,6 +495,9 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
                                        const float (&gb2)[NC2], const f32x4 (&gb2v)[NC2], float gs0,
                                        float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
+    // (an opaque copy of the thread index, as in chain_stage_nets: lane-constant indices that live from the kernel's first lines to
+    //  this point are spilled across the tile loop, and each reload here is a round trip to scratch memory in the kernel's tail)
+    tid += opaque_zero();
     const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
     const int SL = (NP + 2 + 3) & ~3;

@@ -239,6 +239,7 @@ PROMP_DEV void pass_reduce_to_partial(float* S, float* P, const f32x16 (&aw2)[NC
                                       const f32x4 (&aw3)[NC2], const f32x4 (&gb1)[NC1], const f32x4 (&gb2)[NC2], float gs0,
                                       float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
+    tid += opaque_zero();         // (as in chain_reduce_to_partial: no lane-constant index kept alive, and spilled, across the tile loop)
     const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, j32 = lane & 31, kh = lane >> 5;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
     const int SL = (NP + 2 + 3) & ~3;
