@@ -281,8 +281,11 @@ PROMP_DEV void pass_read_tr(u32x4 (&fr)[3], const float* tile, int plane_words, 
 //                         [.., + NC2)                      output: (c)  W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
 //                                                          and its [c][lane][ro] copy W3[16 c + i16][2 kk + ro]; the last block
 //                                                          also carries the biases
-template <int NC1, int NC2, int NW, bool BWDP>
-PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1, int O, int A, int tid) {
+// `mid` runs between the two phases (all of this function's loads issued, none used, LDS untouched so far): the caller requests its
+// first tile's inputs there and joins the workgroup -- those requests go to memory (the observation slab, the primal cache) and
+// would, issued first, hold back the parameters behind them (a wave's loads return in order; the parameters come from L2).
+template <int NC1, int NC2, int NW, bool BWDP, typename Mid>
+PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1, int O, int A, int tid, Mid&& mid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     constexpr ChainLds L = chain_layout(NC1, NC2, 1, true, 0, BWDP);
     constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2, NB4 = BWDP ? NC1 * (NC2 / 2) : 0;
@@ -351,6 +354,8 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
         z[1][it] = src1[idx];
     }
     sched_fence();       // every load is issued before the first store (the scheduler would interleave them in batches: several round trips)
+    mid();
+    sched_fence();
     float* net0 = sm + 4;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -787,33 +792,35 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         const float invN = 1.0f / (float)tnrows;
         const float* th = a.theta + (long long)task * a.theta_task_stride;
         const float* v = a.vdir + (long long)task * NP;
-        // on their way while the networks are staged: the distribution's raw parameters, the first tile's observations and
-        // (CACHED) its cache block
+        // The segment's requests, in the order their answers are needed: the distribution's raw parameters and the networks (from
+        // L2), then -- inside the staging, behind its last load -- the first tile's observations and (CACHED) its cache block (from
+        // memory); the workgroup joins (the previous segment is done with LDS) only after everything is on its way.
         const ChainDistRaw draw = chain_dist_load(th, v, oS, A, tid);
         const int tend = seg.tile0 + seg.ntiles;
         float xT[KS];
-        {
-            const int t = seg.tile0 + w;
-            const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
-            chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
-        }
         // CACHED: this lane's share of a tile's cache block (sample i16, units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1)
         f32x4 ch1[NC1], ch2[NC2];
         f32x2 cmu;
         const float* hcl = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + i16 * 16 + 4 * kk : nullptr;
         const float* hcm = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + 256 * (NC1 + NC2) + i16 * 8 + 2 * kk : nullptr;
-        if (CACHED) {
-            const int t = seg.tile0 + w;
-            const long long o = (long long)(t < tend ? 16 * t : 16 * seg.tile0) * HCR;     // always a block of this segment
-#pragma unroll
-            for (int c = 0; c < NC1; ++c) ch1[c] = *(const f32x4*)(hcl + o + 256 * c);
-#pragma unroll
-            for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
-            cmu = *(const f32x2*)(hcm + o);
-        }
-        __syncthreads();
         CH_STAMP(0);
-        chain_stage_nets<NC1, NC2, NW, CACHED>(sm, th, v, O, A, tid);
+        chain_stage_nets<NC1, NC2, NW, CACHED>(sm, th, v, O, A, tid, [&]() {
+            {
+                const int t = seg.tile0 + w;
+                const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
+                chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
+            }
+            if (CACHED) {
+                const int t = seg.tile0 + w;
+                const long long o = (long long)(t < tend ? 16 * t : 16 * seg.tile0) * HCR;     // always a block of this segment
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) ch1[c] = *(const f32x4*)(hcl + o + 256 * c);
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
+                cmu = *(const f32x2*)(hcm + o);
+            }
+            __syncthreads();
+        });
         CH_STAMP(5);
         chain_stage_dist(net + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         CH_STAMP(6);

@@ -110,8 +110,10 @@ PROMP_DEV float pass_neg_dtanh(float h) { return __builtin_fmaf(h, h, -1.f); }
 // indices are a lane-constant pattern (pass_unit / the observation slots) scaled and shifted by scalars -- no per-element index
 // arithmetic.  All global loads of a wave are issued before its first split (one round trip to L2); padding reads element 0 and
 // is multiplied by 0 (a select would come back as an exec-masked branch around the load).
-template <int NC1, int NC2, int NW>
-PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid) {
+// `mid` runs between the load phase and the first split (all loads issued, none used, LDS untouched): the caller requests its first
+// tile's observations there and joins the workgroup (see chain_stage_nets).
+template <int NC1, int NC2, int NW, typename Mid>
+PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid, Mid&& mid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NP1 = NC1 / 2, NP2 = NC2 / 2, NT = 64 * NW;
     constexpr PassLds L = pass_layout(NC1, NC2, 1, 0);
     constexpr int B1 = L.f_w2f / 64, B2 = L.f_w2b / 64, B3 = L.f_w3f / 64, NBLK = L.n_frag / 64;
@@ -180,6 +182,8 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid)
         y[it] = th[idx] * m;
     }
     sched_fence();       // every load is issued before the first store
+    mid();
+    sched_fence();
     // scales (the kernels that feed a tanh are prescaled) and the zero masks of the padding are applied here
     auto put = [&](const float (&x)[8], int b, float m0, float m1) {
         f32x4 lo, hi;
@@ -756,14 +760,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
         W.invN = 1.0f / (float)W.tnrows;
         W.tend = seg.tile0 + seg.ntiles;
         const float* th = a.theta + (long long)seg.task * a.theta_task_stride;
-        // the first tile's observations are on their way while the network is staged
+        // the segment's requests in the order their answers are needed: the parameters (from L2) first, the first tile's
+        // observations (from memory) behind the staging's last load; the workgroup joins after everything is on its way
         float xr[8];
         int t = seg.tile0 + w;
-        pass_load_x(xr, W, t, i16, kk);
         const ChainDistRaw draw = chain_dist_load(th, nullptr, oS, A, tid);
-        __syncthreads();
         CH_STAMP(0);
-        pass_stage_net<NC1, NC2, NW>(sm, th, O, A, tid);
+        pass_stage_net<NC1, NC2, NW>(sm, th, O, A, tid, [&]() {
+            pass_load_x(xr, W, t, i16, kk);
+            __syncthreads();
+        });
         chain_stage_dist(sm + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         // the action slots >= 8 of the cotangent tiles read as zero (the end-of-segment slabs alias them: once per segment)
         for (int e = lane; e < 3 * DPL; e += 64) wreg[L.dm + e] = 0.f;

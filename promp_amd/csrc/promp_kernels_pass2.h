@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(512, 2) k_pass_pair(PassArgs a) {
         const ChainDistRaw draw = chain_dist_load(th, nullptr, oS, A, tid);
         __syncthreads();
         CH_STAMP(0);
-        pass_stage_net<4, 4, 8>(sm, th, O, A, tid);
+        pass_stage_net<4, 4, 8>(sm, th, O, A, tid, []() {});
         chain_stage_dist(sm + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         // the action slots >= 8 of the cotangent tiles read as zero (the end-of-segment slabs alias them: once per segment)
         if (half == 0) {
