@@ -198,20 +198,24 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_fwd_bwd(PassArgs a) {
     float loss = 0.f, klsum = 0.f, gs0 = 0.f, gs1 = 0.f, gb30 = 0.f, gb31 = 0.f;
 
     // epilogue role (threads 0..4R-1): 4 lanes per row, actions {q, q+4}
-    const int erow = tid >> 2, q = tid & 3;
-    const bool epi = tid < 4 * R;
-    const bool own0 = q < A, own1 = (q + 4) < A;
-    const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;
 
     for (int base = wk.row_begin; base < wk.row_end; base += R) {
         const int nrows = (wk.row_end - base) < R ? (wk.row_end - base) : R;
         const int zr = opaque_zero();               // loop-variant lane indices and LDS base (see opaque_zero)
         const int i16 = i16_ + zr, kk = kk_ + zr, col = col_ + zr;
+        // (the epilogue role too -- threads 0..4R-1: 4 lanes per row, actions {q, q+4} -- and the thread index the row loads are
+        //  spread by: kept across the round they are spilled, and a scratch reload in front of the observation loads waits for
+        //  every load issued before it)
+        const int tidz = tid + zr;
+        const int erow = tidz >> 2, q = tidz & 3;
+        const bool epi = tidz < 4 * R;
+        const bool own0 = q < A, own1 = (q + 4) < A;
+        const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;
         float* const smz = sm + zr;
         float *Xs = smz + L.x, *H1s = smz + L.h1, *H2s = smz + L.h2, *Mss = smz + L.ms, *W3s = smz + L.w3, *W3Ts = smz + L.w3t,
               *b1s = smz + L.b1, *b2s = smz + L.b2, *b3s = smz + L.b3, *lss = smz + L.ls, *ess = smz + L.es, *sn2s = smz + L.sn2;
         __syncthreads();                       // the previous round is done with X / H1
-        wide_load_x(Xs, XS, a.obs, base, nrows, R, O, tid, NT);
+        wide_load_x(Xs, XS, a.obs, base, nrows, R, O, tidz, NT);
         __syncthreads();
         // ---- layer 1: H1 = tanh(X W1 + b1)
         {
@@ -512,15 +516,19 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
     float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
     const float klw = a.kl_weight;
 
-    const int erow = tid >> 2, q = tid & 3;
-    const bool epi = tid < 4 * R;
-    const bool own0 = q < A, own1 = (q + 4) < A;
-    const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;
 
     for (int base = wk.row_begin; base < wk.row_end; base += R) {
         const int nrows = (wk.row_end - base) < R ? (wk.row_end - base) : R;
         const int zr = opaque_zero();               // loop-variant lane indices, LDS and parameter bases (see opaque_zero)
         const int i16 = i16_ + zr, kk = kk_ + zr, col = col_ + zr;
+        // (the epilogue role too -- threads 0..4R-1: 4 lanes per row, actions {q, q+4} -- and the thread index the row loads are
+        //  spread by: kept across the round they are spilled, and a scratch reload in front of the observation loads waits for
+        //  every load issued before it)
+        const int tidz = tid + zr;
+        const int erow = tidz >> 2, q = tidz & 3;
+        const bool epi = tidz < 4 * R;
+        const bool own0 = q < A, own1 = (q + 4) < A;
+        const int q0 = own0 ? q : 0, q1 = own1 ? q + 4 : 0;
         float* const smz = sm + zr;
         const float *th = th0 + zr, *v = v0 + zr;
         float *Xs = smz + L.x, *H1s = smz + L.h1, *H2s = smz + L.h2, *RH1s = smz + L.rh1, *RH2s = smz + L.rh2, *Mss = smz + L.ms,
@@ -528,7 +536,7 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
               *b1s = smz + L.b1, *b2s = smz + L.b2, *b3s = smz + L.b3, *vb1s = smz + L.vb1, *vb2s = smz + L.vb2,
               *vb3s = smz + L.vb3, *lss = smz + L.ls, *ess = smz + L.es, *sn2s = smz + L.sn2, *vls = smz + L.vls;
         __syncthreads();
-        wide_load_x(Xs, XS, a.obs, base, nrows, R, O, tid, NT);
+        wide_load_x(Xs, XS, a.obs, base, nrows, R, O, tidz, NT);
         // ---- layer 1 and its tangent:  Rz1 = X vW1 + vb1
         {
             float wr[KO / 4], vr[KO / 4];
