@@ -467,7 +467,11 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
         dp.device_ref = (sess.serial, sess.upload_serial[slot], slot)
         dp.flat = fl
         dev.append(dp)
+    fetched = _lib.LazyResults.fetch_count
     ms_dev = timed(dev[0], dev[1], n)
+    fetched = _lib.LazyResults.fetch_count - fetched
+    proc.lazy_host_arrays = False
+    ms_dev_eager = timed(dev[0], dev[1], n)
     env_steps = 2 * M * P * T
     res = {'steps': n,
            'host_paths': {'ms_per_step': ms_host, 'value': env_steps / (ms_host * 1e-3),
@@ -477,9 +481,16 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
                                   'downloads + per-task dicts, twice per step'},
            'device_resident': {'ms_per_step': ms_dev, 'value': env_steps / (ms_dev * 1e-3),
                                'ratio_to_value': (env_steps / (ms_dev * 1e-3)) / device_value,
+                               'per_row_downloads': fetched,
+                               'eager_host_arrays': {'ms_per_step': ms_dev_eager, 'value': env_steps / (ms_dev_eager * 1e-3),
+                                                     'note': 'SampleProcessor.lazy_host_arrays = False: per step 2 x (returns + raw '
+                                                             'advantages float64, advantages float32) come back over PCIe inside '
+                                                             'process_samples and 2 x %d path dicts receive their views' % (M * P)},
                                'note': 'DevicePaths with a valid device_ref (what DeviceSlabSampler / DevicePointEnvSampler return): '
-                                       'no upload; per step 2 x (returns + raw advantages float64, advantages float32) come back '
-                                       'over PCIe and 2 x %d path dicts receive their views' % (M * P)}}
+                                       'no upload; the per-row results (returns, advantages) are handed out as arrays that cross '
+                                       'PCIe on first use -- the loop, like the reference trainer, never reads them '
+                                       '(per_row_downloads counts the fetches that did happen); baseline coefficients and per-path '
+                                       'sums come back every call'}}
     policy.session._drop()
     session_mod._current = keep
     return res

@@ -10,6 +10,8 @@ compiled against the SIMT interpreter in tests/emu (kernel-source verification i
 import ctypes as C
 import os
 
+import weakref
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -226,6 +228,85 @@ class _HostPool(object):
 host_pool = _HostPool()
 
 
+class LazyResults(object):
+    """The per-row results of one promp_process_samples call (float32 advantages, float64 returns and raw advantages) as they sit
+    on the device, fetched over PCIe on FIRST USE.  The plugin classes hand these out instead of downloading 3.2 MB per
+    sampling step that the algorithms never read (they work on the device-resident copy).  A context materialises every live
+    LazyResults of a step right before anything overwrites that step's arrays (Context._pre_write), so a holder can never
+    return data of a later batch: either it fetched in time, or it fetches now from an unchanged step."""
+    __slots__ = ('ctx', 'step', '_data', '__weakref__')
+    fetch_count = 0        # downloads so far, process-wide (tests, benchmarks)
+
+    def __init__(self, ctx, step):
+        self.ctx, self.step, self._data = ctx, int(step), None
+
+    def materialize(self):
+        if self._data is None:
+            ctx = self.ctx
+            if not ctx._h:
+                raise PrompError('the device context of these results is closed')
+            R = ctx.step_rows[self.step]
+            adv = host_pool.get((R,), np.float32, ctx.lib)
+            ctx._call('promp_download_processed', self.step, None, _ptr(adv, C.c_float), None, None, None, None)
+            ret, raw = ctx.download_raw(self.step)
+            self._data = dict(advantages=adv, returns=ret, raw_advantages=raw)
+            self.ctx = None
+            LazyResults.fetch_count += 1
+        return self._data
+
+    @property
+    def fetched(self):
+        return self._data is not None
+
+
+class LazyRows(np.lib.mixins.NDArrayOperatorsMixin):
+    """rows [a, b) of one field of a LazyResults: converts to the ndarray on first use (np.asarray, arithmetic, indexing, any
+    ndarray attribute); shape / dtype / len are known without fetching"""
+    __slots__ = ('_res', '_field', '_a', '_b')
+    _DTYPES = dict(advantages=np.dtype(np.float32), returns=np.dtype(np.float64), raw_advantages=np.dtype(np.float64))
+    __array_priority__ = 100
+
+    def __init__(self, res, field, a, b):
+        self._res, self._field, self._a, self._b = res, field, int(a), int(b)
+
+    def _arr(self):
+        return self._res.materialize()[self._field][self._a:self._b]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._arr()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(x._arr() if isinstance(x, LazyRows) else x for x in inputs)
+        if 'out' in kwargs:
+            kwargs['out'] = tuple(x._arr() if isinstance(x, LazyRows) else x for x in kwargs['out'])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def __getitem__(self, k):
+        return self._arr()[k]
+
+    def __len__(self):
+        return self._b - self._a
+
+    def __iter__(self):
+        return iter(self._arr())
+
+    shape = property(lambda self: (self._b - self._a,))
+    dtype = property(lambda self: self._DTYPES[self._field])
+    ndim = 1
+    size = property(lambda self: self._b - self._a)
+
+    def __getattr__(self, name):            # mean(), reshape(), astype(), ... : the ndarray's
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return getattr(self._arr(), name)
+
+    def __repr__(self):
+        return 'LazyRows(%s[%d:%d], %s)' % (self._field, self._a, self._b, 'fetched' if self._res.fetched else 'on the device')
+
+
 class Context:
     """One promp_ctx (one GPU).  Thin, NumPy-in / NumPy-out."""
 
@@ -246,11 +327,27 @@ class Context:
         self._staged, self._live_refs = {}, {}
         self.step_ls_rows = {}
         self.step_paths = {}
+        self._lazy = {}              # step -> WeakSet of LazyResults that have not fetched yet
 
     def close(self):
         if self._h:
+            for step in list(self._lazy):
+                self._pre_write(step)
             self.lib.cdll.promp_ctx_destroy(self._h)
             self._h = _P()
+
+    def lazy_results(self, step):
+        """the processed rows of `step` as a holder that downloads on first use (see LazyResults)"""
+        res = LazyResults(self, step)
+        self._lazy.setdefault(int(step), weakref.WeakSet()).add(res)
+        return res
+
+    def _pre_write(self, step):
+        """called by everything that overwrites a step's arrays: results handed out lazily and still alive fetch now"""
+        live = self._lazy.pop(int(step), None)
+        if live:
+            for res in list(live):
+                res.materialize()
 
     def __del__(self):
         try:
@@ -264,6 +361,7 @@ class Context:
     # ---- trajectories ----
     def upload_step(self, step, task_path_offsets, path_row_offsets, obs, rew, act=None, old_mean=None,
                     old_log_std=None):
+        self._pre_write(step)
         tpo = np.ascontiguousarray(task_path_offsets, dtype=np.int32)
         pro = np.ascontiguousarray(path_row_offsets, dtype=np.int32)
         rew64 = np.ascontiguousarray(rew, dtype=np.float64) if np.asarray(rew).dtype == np.float64 else None
@@ -292,6 +390,7 @@ class Context:
         """promp_stage_step: upload_step's arguments, copied on the copy stream into the step's second slab set; call
         commit_step(step) to make it current.  The arrays are read after the call returns when they are pinned
         (pinned_empty): they are kept referenced here, and must not be written until stage_wait() or the commit's first use."""
+        self._pre_write(step)
         tpo = np.ascontiguousarray(task_path_offsets, dtype=np.int32)
         pro = np.ascontiguousarray(path_row_offsets, dtype=np.int32)
         obs, rew, act, old_mean, old_log_std = _f32(obs), _f32(rew), _f32(act), _f32(old_mean), _f32(old_log_std)
@@ -307,6 +406,7 @@ class Context:
                                   refs=(obs, rew, act, old_mean, old_log_std))
 
     def commit_step(self, step):
+        self._pre_write(step)
         st = self._staged.pop(step)
         self._call('promp_commit_step', int(step))
         self.step_rows[step], self.step_paths[step], self.step_ls_rows[step] = st['rows'], st['paths'], st['ls_rows']
@@ -317,17 +417,18 @@ class Context:
 
     def process_samples(self, step, discount=0.99, gae_lambda=1.0, normalize_adv=False, positive_adv=False,
                         baseline_kind=BASELINE_LINEAR_FEATURE, reg_coeff=1e-5):
+        self._pre_write(step)
         o = ProcOpts(float(discount), float(gae_lambda), float(reg_coeff), int(bool(normalize_adv)),
                      int(bool(positive_adv)), int(baseline_kind), 0)
         self._call('promp_process_samples', int(step), C.byref(o))
         self._last_kind = int(baseline_kind)
 
-    def download_processed(self, step, baseline_kind=None, want_returns32=True):
+    def download_processed(self, step, baseline_kind=None, want_returns32=True, want_advantages=True):
         R, P = self.step_rows[step], self.step_paths[step]
         kind = self._last_kind if baseline_kind is None else baseline_kind
         D = self.lib.cdll.promp_feature_dim(C.byref(self.dims), int(kind))
         out = dict(returns=host_pool.get((R,), np.float32, self.lib) if want_returns32 else None,
-                   advantages=host_pool.get((R,), np.float32, self.lib),
+                   advantages=host_pool.get((R,), np.float32, self.lib) if want_advantages else None,
                    coeffs=np.zeros((self.n_tasks, D), np.float64), path_returns0=np.empty(P, np.float64),
                    path_undiscounted=np.empty(P, np.float64), path_reward_sumsq=np.empty(P, np.float64))
         self._call('promp_download_processed', int(step), _ptr(out['returns'], C.c_float),
@@ -352,12 +453,14 @@ class Context:
         return out
 
     def set_advantages(self, step, adv):
+        self._pre_write(step)
         adv = _f32(adv)
         assert adv.shape == (self.step_rows[step],)
         self._call('promp_set_advantages', int(step), _ptr(adv, C.c_float))
 
     def set_dice_rewards(self, step, rw):
         """promp_set_dice_rewards: per-row DiCE rewards (valid rows, pre-scaled); the device derives the gradient weights"""
+        self._pre_write(step)
         rw = _f32(rw)
         assert rw.shape == (self.step_rows[step],)
         self._call('promp_set_dice_rewards', int(step), _ptr(rw, C.c_float))
@@ -412,6 +515,7 @@ class Context:
         """Device rollout of the 2-D point-mass meta-environment (normalize(MetaPointEnvCorner()) with normalization_scale=10; 0 = the bare environment):
         goals [M,2], start [M,B,2] (float64), noise [M,B,T,2] standard normals or None (drawn on the device from `seed`;
         then path_length is required) -> fills step `step`'s slab with M*B paths of length T (see promp_rollout_point_env)."""
+        self._pre_write(step)
         goals = np.ascontiguousarray(goals, dtype=np.float64)
         start = np.ascontiguousarray(start, dtype=np.float64)
         M, B = self.n_tasks, start.shape[1]
@@ -431,6 +535,7 @@ class Context:
 
     def begin_rollout(self, step, envs_per_task, path_length):
         """lay step `step` out as n_tasks * envs_per_task fixed-length paths for policy_step to fill"""
+        self._pre_write(step)
         self._call('promp_begin_rollout', int(step), int(envs_per_task), int(path_length))
         self._rollout_shape = (int(envs_per_task), int(path_length))
         self.step_rows[step] = self.n_tasks * envs_per_task * path_length
@@ -440,12 +545,14 @@ class Context:
     def begin_collection(self, step, envs_per_task, max_steps):
         """ragged collection: policy_step files vectorised step s under (s, environment) in a staging area until
         end_collection copies the finished episodes into the slab"""
+        self._pre_write(step)
         self._call('promp_begin_collection', int(step), int(envs_per_task), int(max_steps))
         self._rollout_shape = (int(envs_per_task), int(max_steps))
 
     def end_collection(self, step, task_path_offsets, path_env, path_start, path_len, rewards):
         """the finished episodes, in path order: path p = steps [path_start[p], path_start[p] + path_len[p]) of environment
         path_env[p]; rewards [rows] in path order"""
+        self._pre_write(step)
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
         tpo, env, start, ln = i32(task_path_offsets), i32(path_env), i32(path_start), i32(path_len)
         rew = _f32(rewards).reshape(-1)
@@ -465,6 +572,7 @@ class Context:
 
     def set_rewards(self, step, rewards):
         """float64 rewards stay float64 on the device (the returns / GAE scans read them), anything else goes as float32"""
+        self._pre_write(step)
         if np.asarray(rewards).dtype == np.float64:
             r = np.ascontiguousarray(rewards, dtype=np.float64).reshape(-1)
             assert r.size == self.step_rows[step]

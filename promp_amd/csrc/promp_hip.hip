@@ -179,6 +179,8 @@ struct promp_ctx {
     bool prof = false;
     ProfSlot prof_slots[PROMP_KERNEL_COUNT];
     float* stats_host = nullptr;         // pinned: promp_optimize_begin parks both statistics slots here (async copy)
+    double* small_host = nullptr;        // pinned: promp_download_processed gathers the per-path sums and coefficients here
+    size_t small_host_len = 0;
     unsigned* stats_seq_host = nullptr;  // pinned: sequence number the last launch of an optimisation writes behind the statistics
     unsigned stats_seq = 0;              // the number the pending optimisation will write
     bool publish_next = false;           // enqueue_meta: this launch is the one that publishes
@@ -956,6 +958,7 @@ void promp_ctx_destroy(promp_ctx* c) {
     for (float* p : {c->g_mu, c->g_rmu, c->g_dz[0], c->g_dz[1], c->g_qz[0], c->g_qz[1]})
         if (p) (void)hipFree(p);
     if (c->stats_host) (void)hipHostFree(c->stats_host);
+    if (c->small_host) (void)hipHostFree(c->small_host);
     if (c->stats_seq_host) (void)hipHostFree(c->stats_seq_host);
     for (auto& s : c->prof_slots)
         for (auto ev : s.ev) (void)hipEventDestroy(ev);
@@ -1338,17 +1341,29 @@ int promp_download_processed(promp_ctx* c, int step, float* returns, float* adv,
     hipStream_t st = c->stream;
     if (returns) HIPCHECK(hipMemcpyAsync(returns, S.ret32, sizeof(float) * S.n_rows, hipMemcpyDeviceToHost, st));
     if (adv) HIPCHECK(hipMemcpyAsync(adv, S.adv32, sizeof(float) * S.n_rows, hipMemcpyDeviceToHost, st));
-    if (ret0) HIPCHECK(hipMemcpyAsync(ret0, S.path_ret0, sizeof(double) * S.n_paths, hipMemcpyDeviceToHost, st));
-    if (undisc) HIPCHECK(hipMemcpyAsync(undisc, S.path_undisc, sizeof(double) * S.n_paths, hipMemcpyDeviceToHost, st));
-    if (rsq) HIPCHECK(hipMemcpyAsync(rsq, S.path_rsq, sizeof(double) * S.n_paths, hipMemcpyDeviceToHost, st));
-    if (coeffs && S.feat_dim > 0) {
-        std::vector<double> tmp((size_t)c->d.n_tasks * c->coeff_stride);
-        HIPCHECK(hipMemcpyAsync(tmp.data(), S.coeffs, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
-        for (int i = 0; i < c->d.n_tasks; ++i)
-            memcpy(coeffs + (size_t)i * S.feat_dim, tmp.data() + (size_t)i * c->coeff_stride, sizeof(double) * S.feat_dim);
+    // the small results (three per-path sums, the tasks' coefficients) land in one page-locked staging area behind ONE
+    // synchronisation and are copied out from there: the caller's arrays are pageable, and a device-to-pageable copy is a
+    // synchronous bounce each (the plugin classes make this call once per sampling step)
+    const size_t P = (size_t)S.n_paths, NC = (coeffs && S.feat_dim > 0) ? (size_t)c->d.n_tasks * c->coeff_stride : 0;
+    const size_t need = 3 * P + NC;
+    if (c->small_host_len < need) {
+        if (c->small_host) HIPCHECK(hipHostFree(c->small_host));
+        c->small_host = nullptr; c->small_host_len = 0;
+        HIPCHECK(hipHostMalloc((void**)&c->small_host, sizeof(double) * need, hipHostMallocDefault));
+        c->small_host_len = need;
     }
+    double* h = c->small_host;
+    if (ret0) HIPCHECK(hipMemcpyAsync(h, S.path_ret0, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+    if (undisc) HIPCHECK(hipMemcpyAsync(h + P, S.path_undisc, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+    if (rsq) HIPCHECK(hipMemcpyAsync(h + 2 * P, S.path_rsq, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+    if (NC) HIPCHECK(hipMemcpyAsync(h + 3 * P, S.coeffs, sizeof(double) * NC, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    if (ret0) memcpy(ret0, h, sizeof(double) * P);
+    if (undisc) memcpy(undisc, h + P, sizeof(double) * P);
+    if (rsq) memcpy(rsq, h + 2 * P, sizeof(double) * P);
+    if (NC)
+        for (int i = 0; i < c->d.n_tasks; ++i)
+            memcpy(coeffs + (size_t)i * S.feat_dim, h + 3 * P + (size_t)i * c->coeff_stride, sizeof(double) * S.feat_dim);
     return 0;
 }
 

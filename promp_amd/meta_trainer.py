@@ -65,6 +65,9 @@ class Trainer(object):
             self.policy.switch_to_pre_update()
 
             since = time.time()
+            all_samples_data = None       # (meta_trainer.py:99 starts every iteration with empty lists: the previous iteration's
+                                          #  samples are released BEFORE the new ones are made -- results handed out lazily that
+                                          #  nobody read are then never downloaded)
             all_samples_data = [self._sampling_step(step, watch) for step in range(self.num_inner_grad_steps + 1)]
             watch.add('all_inner', since)
 

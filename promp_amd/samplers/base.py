@@ -39,6 +39,12 @@ class SampleProcessor(object):
     Args (samplers/base.py:48-65): baseline, discount=0.99, gae_lambda=1, normalize_adv=False, positive_adv=False
     """
 
+    # A batch that is already resident on the device (DevicePaths from DeviceSlabSampler / DevicePointEnvSampler) gets its per-row
+    # results back LAZILY: 'returns' / 'advantages' of the samples data and of the path dicts are _lib.LazyRows that cross PCIe
+    # on first use (np.asarray, arithmetic, indexing ...), which the training loop never does -- _adapt / optimize_policy work on
+    # the resident copy.  False: plain ndarrays, downloaded inside process_samples as the host-path branch always does.
+    lazy_host_arrays = True
+
     def __init__(self, baseline, discount=0.99, gae_lambda=1, normalize_adv=False, positive_adv=False):
         assert 0 <= discount <= 1.0, 'discount factor must be in [0,1]'
         assert 0 <= gae_lambda <= 1.0, 'gae_lambda must be in [0,1]'
@@ -76,15 +82,20 @@ class SampleProcessor(object):
         are the same) -- and the per-path 'returns' / 'advantages' the reference leaves in the path dicts (base.py:104,159) are
         views of the two downloaded float64 arrays."""
         M = len(paths_meta_batch)
+        if hasattr(paths_meta_batch, 'settle'):
+            paths_meta_batch._pending = None      # an earlier call's side effect nobody looked at: this call's replaces it
         sess, ref = session_mod.current(), getattr(paths_meta_batch, 'device_ref', None)
-        if ref is not None and sess is not None and sess.ctx is not None and ref[0] == sess.serial \
-                and sess.upload_serial[ref[2]] == ref[1]:
+        # (the path lists as they are: looking at them through a DevicePaths' public methods would settle a pending side effect)
+        path_lists = list(paths_meta_batch.raw_values() if hasattr(paths_meta_batch, 'raw_values') else paths_meta_batch.values())
+        resident = ref is not None and sess is not None and sess.ctx is not None and ref[0] == sess.serial \
+            and sess.upload_serial[ref[2]] == ref[1]
+        if resident:
             # a device rollout (samplers/device_point_sampler.py): the slab is already resident, nothing to upload
             fl, upload, slot = paths_meta_batch.flat, ref[1], ref[2]
         else:
             fl = _lib.flatten_paths(paths_meta_batch, _lib.get_library())
             O = fl['obs'].shape[1]
-            first = next(iter(paths_meta_batch.values()))[0]
+            first = path_lists[0][0]
             A = int(np.asarray(first['actions']).reshape(len(first['rewards']), -1).shape[1]) if 'actions' in first else 1
             sess = self._session_for(M, O, A)
             slot = sess.next_slot()
@@ -94,25 +105,42 @@ class SampleProcessor(object):
         ctx.process_samples(slot, discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=self.normalize_adv,
                             positive_adv=self.positive_adv, baseline_kind=kind,
                             reg_coeff=getattr(self.baseline, '_reg_coeff', 1e-5))
-        out = ctx.download_processed(slot, kind, want_returns32=False)     # (the float64 returns below are what the API hands out)
-        ret64, raw_adv64 = ctx.download_raw(slot)
+        lazy = bool(resident and self.lazy_host_arrays and hasattr(paths_meta_batch, 'settle'))
+        # coefficients and per-path sums always come back (small); the per-row arrays now or on first use
+        out = ctx.download_processed(slot, kind, want_returns32=False, want_advantages=not lazy)
+        pro, tpo = fl['path_row_offsets'], fl['task_path_offsets']
+        n_rows = int(pro[-1])
+        if lazy:
+            res = ctx.lazy_results(slot)
+            rows = lambda field, a, b: _lib.LazyRows(res, field, a, b)
+            ret64, raw_adv64, adv32 = rows('returns', 0, n_rows), rows('raw_advantages', 0, n_rows), rows('advantages', 0, n_rows)
+            out['advantages'] = adv32
+        else:
+            ret64, raw_adv64 = ctx.download_raw(slot)
+            adv32 = out['advantages']
+            rows = lambda field, a, b: dict(returns=ret64, raw_advantages=raw_adv64, advantages=adv32)[field][a:b]
         if kind != _lib.BASELINE_ZERO:
             self.baseline._coeffs = out['coeffs'][-1].copy()      # the shared baseline ends on the last task's fit
-        pro, tpo = fl['path_row_offsets'], fl['task_path_offsets']
         # side effect of samplers/base.py:104,159: two views and two dict stores per path (plain slices on Python ints: np.split
-        # costs ten times as much per piece)
-        flat_paths = [p for plist in paths_meta_batch.values() for p in plist]
+        # costs ten times as much per piece) -- now, or when somebody looks at the paths of a resident batch again
+        flat_paths = [p for plist in path_lists for p in plist]
         ends = pro.tolist()
-        a = ends[0]
-        for p, b in zip(flat_paths, ends[1:]):
-            p['returns'] = ret64[a:b]
-            p['advantages'] = raw_adv64[a:b]
-            a = b
+
+        def side_effect():
+            a = ends[0]
+            for p, b in zip(flat_paths, ends[1:]):
+                p['returns'] = rows('returns', a, b)
+                p['advantages'] = rows('raw_advantages', a, b)
+                a = b
+        if lazy:
+            paths_meta_batch._pending = side_effect
+        else:
+            side_effect()
         first = flat_paths[0]
         shared = _shared_storage(fl, first)       # the flat arrays hold exactly what the path dicts hold (dtype and all)
         row0 = pro[tpo].tolist()
         result = []
-        for i, plist in enumerate(paths_meta_batch.values()):
+        for i, plist in enumerate(path_lists):
             r0, r1 = row0[i], row0[i + 1]
             if shared:
                 ls = fl['old_log_std']
@@ -129,7 +157,7 @@ class SampleProcessor(object):
                 rew = np.concatenate([p['rewards'] for p in plist])
                 infos = _concat_tensor_dict_list([p.get('agent_infos', {}) for p in plist])
             sd = session_mod.SamplesData(
-                observations=obs, actions=act, rewards=rew, returns=ret64[r0:r1], advantages=out['advantages'][r0:r1],
+                observations=obs, actions=act, rewards=rew, returns=rows('returns', r0, r1), advantages=rows('advantages', r0, r1),
                 env_infos=_concat_tensor_dict_list([p.get('env_infos', {}) for p in plist]) if first.get('env_infos') else {},
                 agent_infos=infos,
             )

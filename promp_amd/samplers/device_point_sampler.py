@@ -14,9 +14,47 @@ from ..utils import logger
 
 
 class DevicePaths(OrderedDict):
-    """{task -> [path dicts]} as obtain_samples returns, plus where the same data already lives on the device"""
+    """{task -> [path dicts]} as obtain_samples returns, plus where the same data already lives on the device.
+
+    process_samples leaves its per-path side effect (every path dict gains 'returns' and 'advantages', samplers/base.py:104,159
+    of the reference) PENDING on a container of this kind: it is applied the first time anybody looks at the path lists again
+    (1 600 dict stores per sampling step that the training loop never reads)."""
     device_ref = None     # (session serial, upload serial, step slot)
     flat = None           # dict(task_path_offsets, path_row_offsets) of the resident slab
+    _pending = None       # callable applying the side effect, or None
+
+    def settle(self):
+        todo, self._pending = self._pending, None
+        if todo is not None:
+            todo()
+
+    def raw_values(self):
+        """the path lists without settling (library-internal)"""
+        return OrderedDict.values(self)
+
+    def __getitem__(self, key):
+        self.settle()
+        return OrderedDict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self.settle()
+        return OrderedDict.get(self, key, default)
+
+    def values(self):
+        self.settle()
+        return OrderedDict.values(self)
+
+    def items(self):
+        self.settle()
+        return OrderedDict.items(self)
+
+    def pop(self, *args):
+        self.settle()
+        return OrderedDict.pop(self, *args)
+
+    def popitem(self, *args, **kw):
+        self.settle()
+        return OrderedDict.popitem(self, *args, **kw)
 
 
 def _point_env_options(env):

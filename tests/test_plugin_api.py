@@ -194,12 +194,41 @@ def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sp
     serial_before = list(sess.upload_serial)
     sd_dev = proc.process_samples(paths)
     assert sess.upload_serial == serial_before, 'device paths must not be uploaded again'
+    # a resident batch gets its per-row results back lazily: nothing has crossed PCIe yet ...
+    assert isinstance(sd_dev[0]['returns'], _lib.LazyRows) and isinstance(sd_dev[0]['advantages'], _lib.LazyRows)
+    assert sd_dev[0]['advantages'].shape == sd_dev[0]['rewards'].shape and sd_dev[0]['advantages'].dtype == np.float32
+    fetched = _lib.LazyResults.fetch_count
+    raw = list(paths.raw_values())            # (not paths[i]: looking at the paths settles the pending side effect)
     host_paths = OrderedDict((i, [dict(observations=p['observations'], actions=p['actions'], rewards=p['rewards'],
-                                        env_infos=p['env_infos'], agent_infos=p['agent_infos']) for p in paths[i]]) for i in range(M))
+                                        env_infos=p['env_infos'], agent_infos=p['agent_infos']) for p in raw[i]]) for i in range(M))
+    assert _lib.LazyResults.fetch_count == fetched
+    # ... and the upload of another batch into the session first brings home what was handed out (one fetch), so the lazy
+    # arrays still hold the FIRST batch's results afterwards
     sd_host = proc.process_samples(host_paths)
     for a, b in zip(sd_dev, sd_host):
         for key in ('observations', 'actions', 'rewards', 'returns', 'advantages', 'adj_avg_rewards'):
             np.testing.assert_allclose(a[key], b[key], rtol=1e-6, atol=1e-7)
+    assert _lib.LazyResults.fetch_count == fetched + 1
+    # the per-path side effect (samplers/base.py:104,159) is settled when the paths are looked at; eager == lazy, value for value
+    ret_lazy = np.concatenate([np.asarray(p['returns']) for i in range(M) for p in paths[i]])
+    adv_lazy = np.concatenate([np.asarray(p['advantages']) for i in range(M) for p in paths[i]])
+    ret_host = np.concatenate([p['returns'] for i in range(M) for p in host_paths[i]])
+    adv_host = np.concatenate([p['advantages'] for i in range(M) for p in host_paths[i]])
+    np.testing.assert_allclose(ret_lazy, ret_host, rtol=1e-12)
+    np.testing.assert_allclose(adv_lazy, adv_host, rtol=1e-6, atol=1e-9)
+    assert (sd_dev[0]['advantages'] * 2.0).dtype == np.float32 and float(np.mean(sd_dev[0]['returns'])) == float(sd_host[0]['returns'].mean())
+    # steady state of a training loop: samples released before the next batch is processed -> no download at all
+    del sd_dev, sd_host
+    fetched = _lib.LazyResults.fetch_count
+    for _ in range(2):
+        sd = proc.process_samples(paths)
+        assert sd[0].device_ref is not None
+        del sd
+    assert _lib.LazyResults.fetch_count == fetched
+    # the opt-out hands out plain arrays
+    proc.lazy_host_arrays = False
+    sd = proc.process_samples(paths)
+    assert isinstance(sd[0]['advantages'], np.ndarray) and isinstance(OrderedDict.__getitem__(paths, 0)[0]['returns'], np.ndarray)
 
 
 def test_device_rollout_point_env(emu):
