@@ -202,7 +202,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_fwd_bwd(PassArgs a) {
     for (int base = wk.row_begin; base < wk.row_end; base += R) {
         const int nrows = (wk.row_end - base) < R ? (wk.row_end - base) : R;
         const int zr = opaque_zero();               // loop-variant lane indices and LDS base (see opaque_zero)
-        const int i16 = i16_ + zr, kk = kk_ + zr, col = col_ + zr;
+        // (recomputed from the thread index every round, not kept: three lane constants fewer alive across the round)
+        const int i16 = ((tid + zr) & 15), kk = (((tid + zr) & 63) >> 4), col = 16 * ((tid + zr) >> 6) + i16;
         // (the epilogue role too -- threads 0..4R-1: 4 lanes per row, actions {q, q+4} -- and the thread index the row loads are
         //  spread by: kept across the round they are spilled, and a scratch reload in front of the observation loads waits for
         //  every load issued before it)
@@ -401,7 +402,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_fwd_bwd(PassArgs a) {
     }
 
     // ---- results: scalars through LDS in wave order, gradient slices straight from their owners ----
-    const int i16 = i16_, kk = kk_, col = col_;
+    const int tidt = tid + opaque_zero();          // (the tail's lane indices too: recomputed, not reloaded from a spill)
+    const int i16 = tidt & 15, kk = (tidt & 63) >> 4, col = 16 * (tidt >> 6) + i16;
     float* P = a.partials + (long long)wi * a.partial_stride;
 #pragma unroll
     for (int m = 4; m <= 32; m <<= 1) {
@@ -520,7 +522,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
     for (int base = wk.row_begin; base < wk.row_end; base += R) {
         const int nrows = (wk.row_end - base) < R ? (wk.row_end - base) : R;
         const int zr = opaque_zero();               // loop-variant lane indices, LDS and parameter bases (see opaque_zero)
-        const int i16 = i16_ + zr, kk = kk_ + zr, col = col_ + zr;
+        // (recomputed from the thread index every round, not kept: three lane constants fewer alive across the round)
+        const int i16 = ((tid + zr) & 15), kk = (((tid + zr) & 63) >> 4), col = 16 * ((tid + zr) >> 6) + i16;
         // (the epilogue role too -- threads 0..4R-1: 4 lanes per row, actions {q, q+4} -- and the thread index the row loads are
         //  spread by: kept across the round they are spilled, and a scratch reload in front of the observation loads waits for
         //  every load issued before it)
@@ -781,7 +784,8 @@ __global__ void __launch_bounds__(4 * H, 2) k_wide_hvp(PassArgs a) {
         }
     }
 
-    const int i16 = i16_, kk = kk_, col = col_;
+    const int tidt = tid + opaque_zero();          // (the tail's lane indices too: recomputed, not reloaded from a spill)
+    const int i16 = tidt & 15, kk = (tidt & 63) >> 4, col = 16 * (tidt >> 6) + i16;
     float* P = a.partials + (long long)wi * a.partial_stride;
 #pragma unroll
     for (int m = 4; m <= 32; m <<= 1) {

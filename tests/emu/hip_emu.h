@@ -43,11 +43,15 @@ typedef double f64x4 __attribute__((vector_size(32)));
 
 namespace emu {
 
+// Exchange slots of the wave-level instructions (MFMA operands, shuffles): two sets, used alternately.  Every lane counts its
+// wave-level operations (TL::xpar); operation k writes set k & 1, meets the other lanes at ONE barrier and reads.  A second barrier
+// behind the reads is not needed: a lane can only overwrite set k & 1 in operation k + 2, and it gets there only through the
+// barrier of operation k + 1, which every lane reaches after it has finished reading in operation k.
 struct Wave {
     std::barrier<> bar;
-    float fa[64], fb[64];
-    double da[64], db[64];
-    unsigned short ha[64][8], hb[64][8];
+    float fa[2][64], fb[2][64];
+    double da[2][64], db[2][64];
+    unsigned short ha[2][64][8], hb[2][64][8];
     explicit Wave(int n) : bar(n) {}
 };
 
@@ -67,10 +71,12 @@ struct Block {
 struct TL {
     dim3 tidx, bidx, bdim, gdim;
     Block* blk = nullptr;
+    int xpar = 0;          // parity of this lane's wave-level operation count (see Wave)
 };
 inline thread_local TL tl;
 
 inline Wave& wave() { return *tl.blk->waves[tl.tidx.x >> 6]; }
+inline int xslot() { const int p = tl.xpar; tl.xpar ^= 1; return p; }     // this operation's slot set; advances the count
 inline int lane() { return tl.tidx.x & 63; }
 
 template <class F>
@@ -87,6 +93,7 @@ void launch(dim3 grid, int block, size_t smem, F body) {
                     tl.bdim = dim3(block);
                     tl.gdim = grid;
                     tl.blk = &blk;
+                    tl.xpar = 0;
                     body();
                 });
             for (auto& x : th) x.join();
@@ -119,35 +126,33 @@ inline int __syncthreads_or(int pred) {
 
 inline f32x16 mfma32(float a, float b, f32x16 c) {
     emu::Wave& W = emu::wave();
-    const int l = emu::lane(), j = l & 31, h = l >> 5;
-    W.fa[l] = a;
-    W.fb[l] = b;
+    const int l = emu::lane(), j = l & 31, h = l >> 5, s = emu::xslot();
+    W.fa[s][l] = a;
+    W.fb[s][l] = b;
     W.bar.arrive_and_wait();
     f32x16 d;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
         float acc = c[r];
-        acc = fmaf(W.fa[i], W.fb[j], acc);
-        acc = fmaf(W.fa[i + 32], W.fb[j + 32], acc);
+        acc = fmaf(W.fa[s][i], W.fb[s][j], acc);
+        acc = fmaf(W.fa[s][i + 32], W.fb[s][j + 32], acc);
         d[r] = acc;
     }
-    W.bar.arrive_and_wait();
     return d;
 }
 inline f32x4 mfma16(float a, float b, f32x4 c) {
     emu::Wave& W = emu::wave();
-    const int l = emu::lane(), j = l & 15, g = l >> 4;
-    W.fa[l] = a;
-    W.fb[l] = b;
+    const int l = emu::lane(), j = l & 15, g = l >> 4, s = emu::xslot();
+    W.fa[s][l] = a;
+    W.fb[s][l] = b;
     W.bar.arrive_and_wait();
     f32x4 d;
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * g + r;
         float acc = c[r];
-        for (int k = 0; k < 4; ++k) acc = fmaf(W.fa[i + 16 * k], W.fb[j + 16 * k], acc);
+        for (int k = 0; k < 4; ++k) acc = fmaf(W.fa[s][i + 16 * k], W.fb[s][j + 16 * k], acc);
         d[r] = acc;
     }
-    W.bar.arrive_and_wait();
     return d;
 }
 // BF16 operands of v_mfma_f32_16x16x32_bf16: 8 values per lane and operand (k = 8 (l / 16) .. + 7 of row / column l % 16;
@@ -178,10 +183,10 @@ inline void bf16_split3(const float (&x)[8], bf16x8 (&t)[3]) {
 }
 inline f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     emu::Wave& W = emu::wave();
-    const int l = emu::lane(), j = l & 15, g = l >> 4;
+    const int l = emu::lane(), j = l & 15, g = l >> 4, s = emu::xslot();
     for (int e = 0; e < 8; ++e) {
-        W.ha[l][e] = a.h[e];
-        W.hb[l][e] = b.h[e];
+        W.ha[s][l][e] = a.h[e];
+        W.hb[s][l][e] = b.h[e];
     }
     W.bar.arrive_and_wait();
     f32x4 d;
@@ -189,10 +194,9 @@ inline f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
         const int i = 4 * g + r;
         float acc = c[r];
         for (int kb = 0; kb < 4; ++kb)
-            for (int e = 0; e < 8; ++e) acc += emu_bf2f(W.ha[i + 16 * kb][e]) * emu_bf2f(W.hb[j + 16 * kb][e]);   // (products exact in float32)
+            for (int e = 0; e < 8; ++e) acc += emu_bf2f(W.ha[s][i + 16 * kb][e]) * emu_bf2f(W.hb[s][j + 16 * kb][e]);   // (products exact in float32)
         d[r] = acc;
     }
-    W.bar.arrive_and_wait();
     return d;
 }
 // ---- word-packed BF16 fragments (two bf16 per 32-bit word, low half first), see promp_device.h ----
@@ -210,10 +214,10 @@ inline f32x4 mfma16_bf16w(u32x4 a, u32x4 b, f32x4 c) {
 // v_mfma_f32_32x32x16_bf16: A[i = l & 31][k = 8 (l >> 5) + e], B[k][j = l & 31]; D col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 inline f32x16 mfma32_bf16w(u32x4 a, u32x4 b, f32x16 c) {
     emu::Wave& W = emu::wave();
-    const int l = emu::lane(), j = l & 31, h = l >> 5;
+    const int l = emu::lane(), j = l & 31, h = l >> 5, s = emu::xslot();
     for (int e = 0; e < 8; ++e) {
-        W.ha[l][e] = emu_word_half(a, e);
-        W.hb[l][e] = emu_word_half(b, e);
+        W.ha[s][l][e] = emu_word_half(a, e);
+        W.hb[s][l][e] = emu_word_half(b, e);
     }
     W.bar.arrive_and_wait();
     f32x16 d;
@@ -221,10 +225,9 @@ inline f32x16 mfma32_bf16w(u32x4 a, u32x4 b, f32x16 c) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
         float acc = c[r];
         for (int kb = 0; kb < 2; ++kb)
-            for (int e = 0; e < 8; ++e) acc += emu_bf2f(W.ha[i + 32 * kb][e]) * emu_bf2f(W.hb[j + 32 * kb][e]);
+            for (int e = 0; e < 8; ++e) acc += emu_bf2f(W.ha[s][i + 32 * kb][e]) * emu_bf2f(W.hb[s][j + 32 * kb][e]);
         d[r] = acc;
     }
-    W.bar.arrive_and_wait();
     return d;
 }
 // ds_read_b64_tr_b16 (semantics measured on the device, tools/micro/tr16_wgrad_probe.hip): lane i of a 16-lane group receives
@@ -236,11 +239,11 @@ inline u32x2 lds_tr16(const void* p) {
     // the hardware executes a wave's LDS instructions in order, so the chunks other lanes stored before this read are there;
     // here the lanes are free-running threads: wait until every lane has reached the read (= has done its stores)
     W.bar.arrive_and_wait();
-    memcpy(W.ha[l], p, 8);
+    const int s = emu::xslot();
+    memcpy(W.ha[s][l], p, 8);
     W.bar.arrive_and_wait();
     unsigned short v[4];
-    for (int jj = 0; jj < 4; ++jj) v[jj] = W.ha[g + 4 * jj + (i >> 2)][i & 3];
-    W.bar.arrive_and_wait();
+    for (int jj = 0; jj < 4; ++jj) v[jj] = W.ha[s][g + 4 * jj + (i >> 2)][i & 3];
     u32x2 r;
     r[0] = v[0] | ((unsigned)v[1] << 16);
     r[1] = v[2] | ((unsigned)v[3] << 16);
@@ -257,29 +260,26 @@ inline void bf16_split3_pair(float x0, float x1, unsigned (&w)[3]) {
 }
 inline f64x4 mfma16d(double a, double b, f64x4 c) {
     emu::Wave& W = emu::wave();
-    const int l = emu::lane(), j = l & 15, g = l >> 4;
-    W.da[l] = a;
-    W.db[l] = b;
+    const int l = emu::lane(), j = l & 15, g = l >> 4, s = emu::xslot();
+    W.da[s][l] = a;
+    W.db[s][l] = b;
     W.bar.arrive_and_wait();
     f64x4 d;
     for (int r = 0; r < 4; ++r) {
         const int i = g + 4 * r;
         double acc = c[r];
-        for (int k = 0; k < 4; ++k) acc = fma(W.da[i + 16 * k], W.db[j + 16 * k], acc);
+        for (int k = 0; k < 4; ++k) acc = fma(W.da[s][i + 16 * k], W.db[s][j + 16 * k], acc);
         d[r] = acc;
     }
-    W.bar.arrive_and_wait();
     return d;
 }
 
 inline double emu_shfl_f64(double v, int src) {
     emu::Wave& W = emu::wave();
-    const int l = emu::lane();
-    W.da[l] = v;
+    const int l = emu::lane(), s = emu::xslot();
+    W.da[s][l] = v;
     W.bar.arrive_and_wait();
-    const double r = (src >= 0 && src < 64) ? W.da[src] : v;
-    W.bar.arrive_and_wait();
-    return r;
+    return (src >= 0 && src < 64) ? W.da[s][src] : v;
 }
 inline float shfl_xor_f32(float v, int m) { return (float)emu_shfl_f64((double)v, emu::lane() ^ m); }
 inline double shfl_xor_f64(double v, int m) { return emu_shfl_f64(v, emu::lane() ^ m); }
