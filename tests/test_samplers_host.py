@@ -145,3 +145,95 @@ def test_sparse_point_rewards_keep_their_fraction():
             np.testing.assert_array_equal(path['rewards'], np.asarray(rewards, dtype=np.float64))
             n_checked += 1
     assert n_checked == M * per
+
+
+# ---- lazily downloaded per-row results (promp_amd._lib.LazyRows / LazyResults, DevicePaths' pending side effect) ------------
+class _FakeCtx(object):
+    """stands in for _lib.Context: counts downloads, hands out recognisable data, runs the real pre-write protocol"""
+
+    def __init__(self, n):
+        import weakref
+        from promp_amd import _lib
+        self._lib, self._h, self.lib = _lib, True, None
+        self.step_rows, self._lazy, self.calls, self.gen = {0: n}, {}, [], 0
+        self._weakset = weakref.WeakSet
+
+    def _call(self, name, step, returns, adv, *rest):
+        self.calls.append(name)
+        n = self.step_rows[step]
+        np.ctypeslib.as_array(adv, shape=(n,))[:] = np.arange(n, dtype=np.float32) + 1000.0 * self.gen
+
+    def download_raw(self, step):
+        self.calls.append('promp_download_raw')
+        n = self.step_rows[step]
+        return np.arange(n, dtype=np.float64) * 2.0 + 1000.0 * self.gen, np.arange(n, dtype=np.float64) * 3.0 + 1000.0 * self.gen
+
+    lazy_results = None
+    _pre_write = None
+
+
+def _fake_ctx(n, monkeypatch):
+    from promp_amd import _lib
+    ctx = _FakeCtx(n)
+    ctx.lazy_results = lambda step: _lib.Context.lazy_results(ctx, step)
+    ctx._pre_write = lambda step: _lib.Context._pre_write(ctx, step)
+    monkeypatch.setattr(_lib.host_pool, 'get', lambda shape, dtype, lib=None: np.empty(shape, dtype))
+    return ctx
+
+
+def test_lazy_rows_behave_like_the_arrays_they_stand_for(monkeypatch):
+    from promp_amd import _lib
+    ctx = _fake_ctx(10, monkeypatch)
+    res = ctx.lazy_results(0)
+    adv, ret = _lib.LazyRows(res, 'advantages', 2, 7), _lib.LazyRows(res, 'returns', 0, 10)
+    # what is known without crossing PCIe
+    assert adv.shape == (5,) and len(adv) == 5 and adv.dtype == np.float32 and ret.dtype == np.float64 and adv.ndim == 1 and adv.size == 5
+    assert not res.fetched and ctx.calls == []
+    # first use fetches ONCE for all fields and all slices
+    np.testing.assert_array_equal(np.asarray(adv), np.arange(2, 7, dtype=np.float32))
+    assert res.fetched and ctx.calls == ['promp_download_processed', 'promp_download_raw']
+    np.testing.assert_array_equal(ret, 2.0 * np.arange(10))
+    assert ctx.calls == ['promp_download_processed', 'promp_download_raw']
+    # arithmetic, reductions, indexing, conversions, concatenation
+    assert (adv * 2.0).dtype == np.float32 and float((adv - 2.0).sum()) == 10.0 and float(np.mean(ret)) == 9.0 and adv[1] == 3.0
+    assert np.asarray(adv, dtype=np.float64).dtype == np.float64 and adv.astype(np.float64)[-1] == 6.0 and adv.mean() == 4.0
+    np.testing.assert_array_equal(np.concatenate([adv, adv]), np.tile(np.arange(2, 7, dtype=np.float32), 2))
+    assert list(adv) == [2.0, 3.0, 4.0, 5.0, 6.0] and bool((adv == np.arange(2, 7)).all())
+    out = np.zeros(5, np.float32)
+    np.add(adv, 1.0, out=out)
+    assert out[0] == 3.0
+
+
+def test_lazy_results_are_brought_home_before_their_step_is_overwritten(monkeypatch):
+    from promp_amd import _lib
+    ctx = _fake_ctx(6, monkeypatch)
+    kept, dropped = ctx.lazy_results(0), ctx.lazy_results(0)
+    rows = _lib.LazyRows(kept, 'returns', 0, 6)
+    del dropped                                   # nobody holds it any more: it must cost nothing
+    before = _lib.LazyResults.fetch_count
+    ctx._pre_write(0)                             # what upload_step / process_samples / set_advantages ... do first
+    assert _lib.LazyResults.fetch_count == before + 1 and kept.fetched
+    ctx.gen = 1                                   # the step now holds another batch
+    np.testing.assert_array_equal(rows, 2.0 * np.arange(6))      # ... the rows handed out still show the first one
+    fresh = ctx.lazy_results(0)
+    np.testing.assert_array_equal(_lib.LazyRows(fresh, 'returns', 0, 6), 2.0 * np.arange(6) + 1000.0)
+    ctx._pre_write(0)                             # nothing left to fetch
+    assert _lib.LazyResults.fetch_count == before + 2
+
+
+def test_device_paths_settle_the_pending_side_effect_on_first_look():
+    from promp_amd.samplers.device_point_sampler import DevicePaths
+    paths = DevicePaths([(0, [dict(rewards=np.zeros(3))]), (1, [dict(rewards=np.zeros(2))])])
+    looked = []
+
+    def side_effect():
+        looked.append(1)
+        for plist in paths.raw_values():
+            for p in plist:
+                p['returns'] = np.ones(len(p['rewards']))
+    paths._pending = side_effect
+    assert list(paths.keys()) == [0, 1] and len(paths) == 2 and not looked            # keys / len do not settle
+    assert 'returns' not in list(paths.raw_values())[0][0]
+    assert 'returns' in paths[1][0] and looked == [1]                                  # looking at a path list does, once
+    assert all('returns' in p for plist in paths.values() for p in plist) and looked == [1]
+    assert [k for k, _ in paths.items()] == [0, 1]
