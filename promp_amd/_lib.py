@@ -259,15 +259,33 @@ class LazyResults(object):
         return self._data is not None
 
 
+class LazyCompute(object):
+    """LazyResults' protocol for host-side expressions: fn() -> dict(field -> array), evaluated on first use"""
+    __slots__ = ('_fn', '_data')
+
+    def __init__(self, fn):
+        self._fn, self._data = fn, None
+
+    def materialize(self):
+        if self._data is None:
+            self._data, self._fn = self._fn(), None
+        return self._data
+
+    @property
+    def fetched(self):
+        return self._data is not None
+
+
 class LazyRows(np.lib.mixins.NDArrayOperatorsMixin):
     """rows [a, b) of one field of a LazyResults: converts to the ndarray on first use (np.asarray, arithmetic, indexing, any
     ndarray attribute); shape / dtype / len are known without fetching"""
-    __slots__ = ('_res', '_field', '_a', '_b')
+    __slots__ = ('_res', '_field', '_a', '_b', '_dtype')
     _DTYPES = dict(advantages=np.dtype(np.float32), returns=np.dtype(np.float64), raw_advantages=np.dtype(np.float64))
     __array_priority__ = 100
 
-    def __init__(self, res, field, a, b):
+    def __init__(self, res, field, a, b, dtype=None):
         self._res, self._field, self._a, self._b = res, field, int(a), int(b)
+        self._dtype = np.dtype(dtype) if dtype is not None else self._DTYPES[field]
 
     def _arr(self):
         return self._res.materialize()[self._field][self._a:self._b]
@@ -294,7 +312,7 @@ class LazyRows(np.lib.mixins.NDArrayOperatorsMixin):
         return iter(self._arr())
 
     shape = property(lambda self: (self._b - self._a,))
-    dtype = property(lambda self: self._DTYPES[self._field])
+    dtype = property(lambda self: self._dtype)
     ndim = 1
     size = property(lambda self: self._b - self._a)
 

@@ -1,6 +1,7 @@
 """MetaSampleProcessor (reference: meta_policy_search/samplers/meta_sample_processor.py:8-49)."""
 import numpy as np
 
+from .. import _lib
 from .base import SampleProcessor
 
 
@@ -24,12 +25,19 @@ class MetaSampleProcessor(SampleProcessor):
         mean = s1 / n
         std = np.sqrt(max(s2 / n - mean * mean, 0.0))
         # one subtraction and one division for the whole meta-batch; the per-task entries are slices of the result (the same values
-        # as task by task, a tenth of the NumPy calls)
+        # as task by task, a tenth of the NumPy calls).  Where the per-row results are handed out lazily (a resident batch,
+        # samplers/base.py) this one is too: only E-MAML's exploration term ever reads it.
         rew = [np.asarray(sd['rewards']) for sd in samples_data_meta_batch]
-        adj = (np.concatenate(rew) - mean) / (std + 1e-8)
+        compute = lambda: dict(adj=(np.concatenate(rew) - mean) / (std + 1e-8))
+        if isinstance(samples_data_meta_batch[0]['advantages'], _lib.LazyRows):
+            holder, dt = _lib.LazyCompute(compute), np.result_type(rew[0].dtype, np.float64)
+            piece = lambda a, b: _lib.LazyRows(holder, 'adj', a, b, dtype=dt)
+        else:
+            adj = compute()['adj']
+            piece = lambda a, b: adj[a:b]
         a = 0
         for sd, r in zip(samples_data_meta_batch, rew):
-            sd['adj_avg_rewards'] = adj[a:a + len(r)]
+            sd['adj_avg_rewards'] = piece(a, a + len(r))
             a += len(r)
         self._log_path_stats(out, log=log, log_prefix=log_prefix)
         return samples_data_meta_batch
