@@ -6,6 +6,7 @@
 #include "promp_kernels_pass2.h"
 #include "promp_kernels_policy.h"
 #include "promp_kernels_policy_wide.h"
+#include "promp_kernels_wide_bf16.h"
 #include "promp_kernels_sample.h"
 #include "promp_kernels_rollout.h"
 #include "promp_kernels_generic.h"
@@ -91,6 +92,7 @@ constexpr int CHAIN_NW_HVP = 4;
 int chain_ksteps(int obs_dim) { return obs_dim <= 8 ? 2 : obs_dim <= 20 ? 5 : 8; }
 // k_pass instances: (hidden_0 / 16, hidden_1 / 16)
 #define PROMP_PASS_ALL(X) X(2, 2) X(2, 4) X(4, 2) X(4, 4)
+#define PROMP_WB_ALL(X) X(1, 4, 2) X(2, 7, 4) X(3, 8, 4)
 #define PROMP_CHAIN_ALL(X) X(2, 2, 2) X(2, 2, 5) X(2, 2, 8) X(2, 4, 2) X(2, 4, 5) X(2, 4, 8) X(4, 2, 2) X(4, 2, 5) X(4, 2, 8) X(4, 4, 2) X(4, 4, 5) X(4, 4, 8)
 
 struct ProfSlot {
@@ -134,6 +136,10 @@ struct promp_ctx {
     size_t smem_fwd = 0, smem_hvp = 0;
     size_t smem_pair = 0;              // k_pass_pair (the (64, 64) first-order pass at two waves per SIMD); 0: not this shape
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
+    int wbf = 0;                         // hidden 128, obs_dim <= 127: the BF16-pipe cooperative kernels (promp_kernels_wide_bf16.h);
+                                         // 1..3 = the observation class (NKO, NXB) = (4,2) (7,4) (8,4): obs_dim <= 63 / 111 / 127
+    size_t smem_wb_fwd = 0, smem_wb_bwd = 0, smem_wb_hvp = 0;
+    unsigned *wb_planes = nullptr, *wb_vplanes = nullptr;   // [tasks][wb_planes_words]: k_wb_planes' output for theta / the direction
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
     bool generic = false;
@@ -265,6 +271,7 @@ bool policy_shape_generic(const promp_dims* d) {   // layer-by-layer kernels (pr
 bool policy_shape_chain(const promp_dims* d) {     // register-chained kernels: hidden widths from {32, 64}, obs_dim <= 32
     return !policy_shape_generic(d) && d->obs_dim <= 32 && (d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64);
 }
+int wb_nko(int cls) { return cls == 1 ? 4 : cls == 2 ? 7 : 8; }      // K = 16 steps of the observation per class
 bool policy_shape_coop(const promp_dims* d) {      // cooperative kernels: (128,128), or (64,64) with wide observations
     return !policy_shape_generic(d) && d->hidden1 == d->hidden2 && (d->hidden1 == 128 || (d->hidden1 == 64 && d->obs_dim > 32));
 }
@@ -433,9 +440,33 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.lam = c->lam; a.v = c->vbuf; a.scal = scal;
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
     const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
+    if (c->wbf) {
+        // the parameters' (and the direction's) hidden kernels as BF16 planes in fragment order (one small launch each: 276 KB per task)
+        const int nko = wb_nko(c->wbf);
+        WbPlaneArgs pa;
+        pa.src = theta; pa.src_stride = theta_stride; pa.dst = c->wb_planes; pa.O = c->d.obs_dim; pa.NKO = nko; pa.row_sign = 1.f;
+        PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 255) / 256, theta_stride ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
+        a.wb_theta_planes = c->wb_planes;
+        a.wb_plane_stride = theta_stride ? wb_planes_words(nko) : 0;
+        if (hvp) {
+            pa.src = c->vbuf; pa.src_stride = c->NP; pa.dst = c->wb_vplanes;
+            PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, pa);
+            a.wb_v_planes = c->wb_vplanes;
+        }
+    }
     if (prof_begin(c, id, S.n_rows)) return -2;
     if (c->generic) {
         if (launch_pass_generic(c, S, a, hvp, fwd_only)) return -2;
+    } else if (c->wbf) {
+        // two layers of 128 units on the BF16 matrix pipe (promp_kernels_wide_bf16.h)
+#define PROMP_WB_CASE(CLS, NKO, NXB)                                                                                              \
+    if (c->wbf == CLS) {                                                                                                          \
+        if (hvp) { auto k = k_wb_hvp<NKO, NXB>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_wb_hvp, c->stream, a); }            \
+        else if (fwd_only) { auto k = k_wb_fwd_bwd<NKO, NXB, false>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_wb_fwd, c->stream, a); } \
+        else { auto k = k_wb_fwd_bwd<NKO, NXB, true>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 256, c->smem_wb_bwd, c->stream, a); }         \
+    }
+        PROMP_WB_ALL(PROMP_WB_CASE)
+#undef PROMP_WB_CASE
     } else if (c->wide) {
         // cooperative kernels (promp_kernels_policy_wide.h): hidden 128, or hidden 64 with obs_dim > 32
         const int nob = c->d.obs_dim <= 32 ? 2 : c->d.obs_dim <= 64 ? 4 : 8;
@@ -794,6 +825,15 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         const int nob = dims->obs_dim <= 32 ? 2 : dims->obs_dim <= 64 ? 4 : 8;
         c->smem_fwd = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
         c->smem_hvp = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 2, nob, true).total;
+        // two layers of 128 units: the first-order pass on the BF16 matrix pipe (float32-equivalent 3-way split).  PROMP_WIDE_FP32=1
+        // (environment, at context creation) keeps the exact-FP32 cooperative kernels -- the A/B switch of the measurements.
+        const char* fp32_env = getenv("PROMP_WIDE_FP32");
+        if (dims->hidden1 == 128 && dims->obs_dim <= 127 && !(fp32_env && atoi(fp32_env) != 0)) {
+            c->wbf = dims->obs_dim <= 63 ? 1 : dims->obs_dim <= 111 ? 2 : 3;
+            c->smem_wb_bwd = sizeof(float) * (size_t)wb_layout(false).total;
+            c->smem_wb_fwd = c->smem_wb_bwd;
+            c->smem_wb_hvp = sizeof(float) * (size_t)wb_layout(true).total;
+        }
     } else {
         // (sized for obs_dim 32: constant offsets in the kernels; contexts with wider observations and these hidden sizes run
         //  sample processing only -- the policy passes reject them at launch -- and must not fail here on LDS they never use)
@@ -848,6 +888,15 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
             HIPCHECK(hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHECK(hipFuncSetAttribute((const void*)p2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
+#define PROMP_WB_ATTR(CLS, NKO, NXB)                                                                                       \
+    {                                                                                                                     \
+        auto b0 = k_wb_fwd_bwd<NKO, NXB, true>; auto b1 = k_wb_fwd_bwd<NKO, NXB, false>; auto b2 = k_wb_hvp<NKO, NXB>;         \
+        HIPCHECK(hipFuncSetAttribute((const void*)b2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        HIPCHECK(hipFuncSetAttribute((const void*)b0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        HIPCHECK(hipFuncSetAttribute((const void*)b1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+    }
+        PROMP_WB_ALL(PROMP_WB_ATTR)
+#undef PROMP_WB_ATTR
 #define PROMP_WIDE_ATTR(HH, NOB)                                                                                          \
     {                                                                                                                     \
         auto w0 = k_wide_fwd_bwd<HH, NOB, true>; auto w1 = k_wide_fwd_bwd<HH, NOB, false>; auto w2 = k_wide_hvp<HH, NOB>;   \
@@ -898,6 +947,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     rc |= dev_alloc(&c->adam_m, NP); rc |= dev_alloc(&c->adam_v, NP);
     rc |= dev_alloc(&c->theta_tasks, MNP); rc |= dev_alloc(&c->chain, (size_t)(K + 1) * MNP);
     rc |= dev_alloc(&c->lam, MNP); rc |= dev_alloc(&c->vbuf, MNP);
+    if (c->wbf) {
+        const size_t pw = (size_t)M * wb_planes_words(wb_nko(c->wbf));
+        rc |= dev_alloc(&c->wb_planes, pw); rc |= dev_alloc(&c->wb_vplanes, pw);
+    }
     rc |= dev_alloc(&c->partials, (size_t)c->max_work * c->partial_stride);
     rc |= dev_alloc(&c->scal_inner, (size_t)K * M * 2); rc |= dev_alloc(&c->scal_outer, (size_t)M * 2);
     rc |= dev_alloc(&c->scal_tmp, (size_t)M * 2);
@@ -946,7 +999,7 @@ void promp_ctx_destroy(promp_ctx* c) {
             if (S.ev_done) (void)hipEventDestroy(S.ev_done);
             if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
         }
-    void* ptrs[] = {c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    void* ptrs[] = {c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)

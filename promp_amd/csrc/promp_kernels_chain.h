@@ -105,6 +105,11 @@ struct PassArgs {
     float* row_tan;                 // k_chain_hvp, optional [rows]: R'{log pi} of every row = dlogpi_row . (-v)  (DiCE coupling)
     float* hcache;                  // primal cache of the step (k_pass<STORE> writes it, k_chain_hvp<CACHED> reads it), see chain_cache_row
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
+    // BF16-pipe cooperative kernels (promp_kernels_wide_bf16.h): the parameters' (and the direction's) hidden kernels as pre-split
+    // BF16 planes in fragment order, written by k_wb_planes right before the pass
+    const unsigned* wb_theta_planes;
+    const unsigned* wb_v_planes;
+    long long wb_plane_stride;      // words per task; 0 => shared parameters
 };
 
 // Layer 2 of the R-operator pass (tangent, and the primal product where it is not read from the cache) runs on the BF16 matrix pipe
