@@ -444,13 +444,13 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         // the parameters' (and the direction's) hidden kernels as BF16 planes in fragment order (one small launch each: 276 KB per task)
         const int nko = wb_nko(c->wbf);
         WbPlaneArgs pa;
-        pa.src = theta; pa.src_stride = theta_stride; pa.dst = c->wb_planes; pa.O = c->d.obs_dim; pa.NKO = nko; pa.row_sign = 1.f;
-        PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 255) / 256, theta_stride ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
+        pa.src = theta; pa.src_stride = theta_stride; pa.dst = c->wb_planes; pa.O = c->d.obs_dim; pa.A = c->d.act_dim; pa.NKO = nko; pa.row_sign = 1.f;
+        PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, theta_stride ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
         a.wb_theta_planes = c->wb_planes;
         a.wb_plane_stride = theta_stride ? wb_planes_words(nko) : 0;
         if (hvp) {
             pa.src = c->vbuf; pa.src_stride = c->NP; pa.dst = c->wb_vplanes;
-            PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, pa);
+            PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, pa);
             a.wb_v_planes = c->wb_vplanes;
         }
     }

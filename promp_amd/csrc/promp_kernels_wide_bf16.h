@@ -50,21 +50,22 @@
 #define WB_MS 17           // row stride of the float32 mean / cotangent tile
 #define WB_DMROW 8         // words per sample row of a cotangent plane (16 action slots)
 #define WB_DMPL 256        // words per cotangent plane
-#define WB_PF 4            // K steps the streamed weight planes run ahead of their products
 
 // ---- pre-split weight planes in global memory (k_wb_planes) ----
 // per task:  C1 [w 4][q NKO][t 3][lane 64] x 16 B   hidden_0 kernel, column slices: lane (i, h) of (w, q): W1[16 q + 8 h + e][32 w + i]
 //            C2 [w 4][q 8][t 3][lane 64] x 16 B     hidden_1 kernel, column slices:                         W2[16 q + 8 h + e][32 w + i]
 //            R2 [w 4][q 8][t 3][lane 64] x 16 B     hidden_1 kernel, row slices (backward product):         W2[32 w + i][16 q + 8 h + e]
+//            W3 [w 4][t 3][lane 64] x 16 B          output kernel, A operand of the 16x16x32 product: lane (a, g): W3[32 w + 8 g + e][a]
 PROMP_HD int wb_planes_c2(int nko) { return 4 * nko * 768; }                  // word offsets inside a task's block
 PROMP_HD int wb_planes_r2(int nko) { return 4 * nko * 768 + 4 * 8 * 768; }
-PROMP_HD int wb_planes_words(int nko) { return 4 * nko * 768 + 2 * 4 * 8 * 768; }
+PROMP_HD int wb_planes_w3(int nko) { return 4 * nko * 768 + 2 * 4 * 8 * 768; }
+PROMP_HD int wb_planes_words(int nko) { return 4 * nko * 768 + 2 * 4 * 8 * 768 + 4 * 768; }
 
 struct WbPlaneArgs {
     const float* src;            // [tasks][Theta] (or one shared vector: src_stride 0, grid.y 1)
     long long src_stride;
     unsigned* dst;               // [tasks][wb_planes_words]
-    int O, NKO;
+    int O, A, NKO;
     float row_sign;              // sign of the R2 region (the R-operator pass wants the direction's rows negated)
 };
 
@@ -86,6 +87,7 @@ PROMP_HD LdsWB wb_layout(bool hvp) {
     if (hvp) {
         WB_TAKE(rh1, WB_TILE);
         WB_TAKE(rh2, WB_TILE);
+        WB_TAKE(d1, 4 * 1024);                  // [wave][quad 4][lane 64][4]: h1 of the wave's own units, parked between the passes
     } else {
         WB_TAKE(x1, WB_TILE);                   // second observation tile (round r + 1 is split while round r computes)
         WB_TAKE(dz1, WB_TILE);                  // dZ1, own columns only
@@ -175,6 +177,21 @@ PROMP_DEV void wb_mma6_two(f32x16& ca, f32x16& cb, const u32x4 (&a)[3], const u3
     cb = mfma32_bf16w(b[0], z[1], cb);
     ca = mfma32_bf16w(a[0], z[0], ca);
     cb = mfma32_bf16w(b[0], z[0], cb);
+}
+// ca += a x za ;  cb += b x zb   (two unrelated products), interleaved
+PROMP_DEV void wb_mma6_x2(f32x16& ca, const u32x4 (&a)[3], const u32x4 (&za)[3], f32x16& cb, const u32x4 (&b)[3], const u32x4 (&zb)[3]) {
+    ca = mfma32_bf16w(a[2], za[0], ca);
+    cb = mfma32_bf16w(b[2], zb[0], cb);
+    ca = mfma32_bf16w(a[1], za[1], ca);
+    cb = mfma32_bf16w(b[1], zb[1], cb);
+    ca = mfma32_bf16w(a[0], za[2], ca);
+    cb = mfma32_bf16w(b[0], zb[2], cb);
+    ca = mfma32_bf16w(a[1], za[0], ca);
+    cb = mfma32_bf16w(b[1], zb[0], cb);
+    ca = mfma32_bf16w(a[0], za[1], ca);
+    cb = mfma32_bf16w(b[0], zb[1], cb);
+    ca = mfma32_bf16w(a[0], za[0], ca);
+    cb = mfma32_bf16w(b[0], zb[0], cb);
 }
 PROMP_DEV void wb_mma6_16(f32x4& c, const u32x4 (&a)[3], const u32x4 (&b)[3]) {
     c = mfma16_bf16w(a[2], b[0], c);
@@ -279,41 +296,48 @@ PROMP_DEV void wb_load_w3f(float (&r)[4], const float* W3, int A, int lane, int 
 }
 // One round's observations: requested into registers (wb_xreq: a round that does not exist reads a valid element and is all
 // padding), split and stored as the three planes of an observation tile later (wb_xput: rows >= nrows and columns >= O zero,
-// column OC one).  Thread e + 256 it takes chunk (sample e / CPR, units 4 c ..) of the tile.
+// column OC one).  Thread t takes sample t / 8 and the chunks (units 4 c ..) c = t % 8 + 8 it: no division, and the eight threads
+// of a sample read 128 contiguous bytes per step.
 template <int NKO>
 struct WbX {
-    static constexpr int CPR = 4 * NKO, NCH = WB_R * CPR, IT = (NCH + 255) / 256;
+    static constexpr int CPR = 4 * NKO, IT = (CPR + 7) / 8;
     float v[IT][4];
 };
 template <int NKO>
 PROMP_DEV void wb_xreq(WbX<NKO>& X, const float* obs, long long row0, int nrows, int O, int tid) {
+    // a wave-uniform 64-bit base and one 32-bit offset per element: rows past the round's last read its last row, columns past the
+    // observation read its last column (valid addresses; wb_xput discards them)
+    const float* rbase = obs + (nrows > 0 ? row0 * O : 0);
+    const int last = nrows > 0 ? nrows - 1 : 0;
+    const int s = (tid >> 3) < last ? (tid >> 3) : last;
+    const unsigned ro = (unsigned)(s * O);
 #pragma unroll
     for (int it = 0; it < WbX<NKO>::IT; ++it) {
-        const int e = tid + 256 * it, s = e / WbX<NKO>::CPR, c = e - s * WbX<NKO>::CPR;
+        const int c = (tid & 7) + 8 * it;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = 4 * c + i;
-            const bool ok = e < WbX<NKO>::NCH && s < nrows && o < O;
-            X.v[it][i] = obs[ok ? (row0 + s) * O + o : 0];
+            X.v[it][i] = rbase[ro + (unsigned)(o < O ? o : O - 1)];
         }
     }
 }
 template <int NKO>
 PROMP_DEV void wb_xput(float* Xs, const WbX<NKO>& X, int nrows, int O, int OC, int tid) {
+    const int s = tid >> 3;
+    const float rowm = s < nrows ? 1.f : 0.f;
 #pragma unroll
     for (int it = 0; it < WbX<NKO>::IT; ++it) {
-        const int e = tid + 256 * it, s = e / WbX<NKO>::CPR, c = e - s * WbX<NKO>::CPR;
+        const int c = (tid & 7) + 8 * it;
         float x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = 4 * c + i;
-            const bool ok = s < nrows && o < O;
-            x[i] = (o == OC) ? 1.f : ok ? X.v[it][i] : 0.f;
+            x[i] = (o == OC) ? 1.f : (o < O) ? rowm * X.v[it][i] : 0.f;
         }
         unsigned w0[3], w1[3];
         bf16_split3_pair(x[0], x[1], w0);
         bf16_split3_pair(x[2], x[3], w1);
-        if (e < WbX<NKO>::NCH) {
+        if (c < WbX<NKO>::CPR) {
             const int off = wb_chunk(s, c);
 #pragma unroll
             for (int t = 0; t < 3; ++t) sts_w2(Xs + t * WB_PLANE + off, w0[t], w1[t]);
@@ -332,23 +356,27 @@ PROMP_DEV void wb_init_x(float* Xs, int OC, int tid) {
 
 // K steps of a streamed slice: `G.r` holds the planes of WB_PF steps; wb_stream_begin requests steps 0 .. WB_PF - 1 (from anywhere
 // ahead of the products), wb_chain_stream requests step q + WB_PF as soon as the products of step q have read their slot.
+template <int PF>
 struct WbRing {
-    u32x4 r[WB_PF][3];
+    u32x4 r[PF][3];
 };
-PROMP_DEV void wb_stream_begin(WbRing& G, const unsigned* P, int nk, int w, int lane) {
+template <int PF>
+PROMP_DEV void wb_stream_begin(WbRing<PF>& G, const unsigned* P, int nk, int w, int lane) {
 #pragma unroll
-    for (int q = 0; q < WB_PF; ++q) wb_gload(G.r[q], P, nk, w, q, lane);
+    for (int q = 0; q < PF; ++q) wb_gload(G.r[q], P, nk, w, q, lane);
 }
-template <int NK>
-PROMP_DEV void wb_chain_stream(f32x16& c0, WbRing& G, const unsigned* P, int w, int lane, const float* tile, int j, int h) {
+template <int NK, int WB_PF>
+PROMP_DEV void wb_chain_stream(f32x16& c0, WbRing<WB_PF>& G, const unsigned* P, int w, int lane, const float* tile, int j, int h) {
     u32x4 fb[3];
     wb_read_b(fb, tile, j, h, 0);
 #pragma unroll
     for (int q = 0; q < NK; ++q) {
         u32x4 fn[3];
         if (q + 1 < NK) wb_read_b(fn, tile, j, h, q + 1);
+        sched_fence();
         wb_mma6(c0, G.r[q % WB_PF], fb);
         if (q + WB_PF < NK) wb_gload(G.r[q % WB_PF], P, NK, w, q + WB_PF, lane);
+        sched_fence();
         if (q + 1 < NK) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) fb[t] = fn[t];
@@ -364,10 +392,19 @@ __global__ void __launch_bounds__(256) k_wb_planes(WbPlaneArgs a) {
     const int task = blockIdx.y;
     int r = blockIdx.x * 256 + threadIdx.x;
     const int n1 = 4 * a.NKO * 64, n2 = 4 * 8 * 64;
-    if (r >= n1 + 2 * n2) return;
+    if (r >= n1 + 2 * n2 + 256) return;
     const float* src = a.src + (long long)task * a.src_stride;
     unsigned* dst = a.dst + (long long)task * wb_planes_words(a.NKO);
+    const int oW2a = a.O * 128 + 128;
     int region = 0;
+    if (r >= n1 + 2 * n2) {               // the output kernel's fragments (wb_load_w3)
+        r -= n1 + 2 * n2;
+        u32x4 pl[3];
+        wb_load_w3(pl, src + oW2a + 128 * 128 + 128, a.A, r & 63, r >> 6, 1.f);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *(u32x4*)(dst + wb_planes_w3(a.NKO) + ((r >> 6) * 3 + t) * 256 + 4 * (r & 63)) = pl[t];
+        return;
+    }
     if (r >= n1 + n2) { region = 2; r -= n1 + n2; dst += wb_planes_r2(a.NKO); }
     else if (r >= n1) { region = 1; r -= n1; dst += wb_planes_c2(a.NKO); }
     const int NK = region == 0 ? a.NKO : 8;
@@ -417,7 +454,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
     const unsigned* PR2 = PL + wb_planes_r2(NKO);
 
     // ---- forward weight planes of this lane, resident for the whole work item; the first round's observations
-    u32x4 w1p[NKO][3], w2c[8][3], w3p[3];
+    u32x4 w1p[NKO][3], w2c[8][3];
     float w3f[4];
     WbX<NKO> X;
     {
@@ -429,7 +466,6 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         for (int q = 0; q < NKO; ++q) wb_gload(w1p[q], PL, NKO, w, q, lane);
 #pragma unroll
         for (int q = 0; q < 8; ++q) wb_gload(w2c[q], PL + wb_planes_c2(NKO), 8, w, q, lane);
-        wb_load_w3(w3p, th + oW3, A, lane, w, 1.f);
         if (BWD) wb_load_w3f(w3f, th + oW3, A, lane, w, 1.f);
         for (int e = tid; e < H; e += 256) {
             b1s[e] = th[ob1 + e];
@@ -508,6 +544,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         WB_STAMP(2);
         // ---- the next round's observations (requested a round ago) -> the other tile; the round after that is requested
         wb_xput<NKO>(Xn, X, wk.row_end - base - R, O, OC, tid);
+        WB_STAMP(21);
         wb_xreq<NKO>(X, a.obs, (long long)base + 2 * R, wk.row_end - base - 2 * R, O, tid);
         WB_STAMP(3);
         __syncthreads();
@@ -531,6 +568,8 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         // ---- output layer: this wave's 32 units of the contraction, both 16-sample blocks -> partial means
         {
             const int j16 = lane & 15, g4 = lane >> 4;
+            u32x4 w3p[3];
+            wb_gload(w3p, PL + zr + wb_planes_w3(NKO), 1, w, 0, lane);
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 const int s = 16 * sb + j16;
@@ -544,7 +583,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
             }
         }
         // the backward product's row planes: the first steps are requested here, a barrier and an epilogue ahead of their products
-        WbRing G;
+        WbRing<3> G;
         if (BWD) wb_stream_begin(G, PR2, 8, w, lane);
         WB_STAMP(6);
         __syncthreads();
@@ -661,10 +700,29 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         WB_STAMP(10);
         __syncthreads();
         WB_STAMP(11);
-        // ---- dH1 = W2 dZ2^T for the own units (row planes streamed), dZ1 -> its own tile
+        // ---- dH1 = W2 dZ2^T for the own units (row planes streamed) with the hidden_1 kernel gradient columns 32 w .. (+=) in its
+        //      shadow: one block and sample half per K step (a K step is then 12 products long, and the ring's 3 steps of lead
+        //      cover an L2 round trip); dZ1 -> its own tile
         {
             f32x16 c0 = wb_zero16();
-            wb_chain_stream<8>(c0, G, PR2, w, lane, H2s, j, h);
+            u32x4 fb[3], fz[3];
+            wb_read_b(fb, H2s, j, h, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                u32x4 fn[3], fa[3];
+                if (q + 1 < 8) wb_read_b(fn, H2s, j, h, q + 1);
+                const int t = q >> 2, m = q & 3;
+                if (m == 0) wb_read_tr(fz, H2s, lane, w, t);
+                wb_read_tr(fa, H1s, lane, m, t);
+                sched_fence();        // the ring's loads must not sink to their uses: a K step's requests, then its dense product block
+                wb_mma6_x2(c0, G.r[q % 3], fb, aw2[m], fa, fz);
+                if (q + 3 < 8) wb_gload(G.r[q % 3], PR2, 8, w, q + 3, lane);
+                sched_fence();
+                if (q + 1 < 8) {
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) fb[tt] = fn[tt];
+                }
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 d1 = lds4(D1p + 256 * g + 4 * lane);
@@ -673,25 +731,9 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
             }
             wb_store_own(DZ1, c0, j, h, w);
         }
-        sched_fence();
-        WB_STAMP(12);
-        // ---- hidden_1 kernel gradient columns 32 w .. (+=)
-        {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                u32x4 fz[3];
-                wb_read_tr(fz, H2s, lane, w, t);
-#pragma unroll
-                for (int m = 0; m < 4; m += 2) {
-                    u32x4 fa0[3], fa1[3];
-                    wb_read_tr(fa0, H1s, lane, m, t);
-                    wb_read_tr(fa1, H1s, lane, m + 1, t);
-                    wb_mma6_two(aw2[m], aw2[m + 1], fa0, fa1, fz);
-                }
-            }
-        }
         wave_sync();
         sched_fence();
+        WB_STAMP(12);
         WB_STAMP(13);
         // ---- hidden_0 kernel gradient columns 32 w .. (+=): needs only this wave's own dZ1 columns
         {
@@ -797,25 +839,11 @@ PROMP_DEV void wb_mma6_ab(f32x16& ca, f32x16& cb, const u32x4 (&a)[3], const u32
     ca = mfma32_bf16w(a[0], ba[0], ca);
     cb = mfma32_bf16w(a[0], bb[0], cb);
 }
-// ca += a x za ;  cb += b x zb   (two unrelated products), interleaved
-PROMP_DEV void wb_mma6_x2(f32x16& ca, const u32x4 (&a)[3], const u32x4 (&za)[3], f32x16& cb, const u32x4 (&b)[3], const u32x4 (&zb)[3]) {
-    ca = mfma32_bf16w(a[2], za[0], ca);
-    cb = mfma32_bf16w(b[2], zb[0], cb);
-    ca = mfma32_bf16w(a[1], za[1], ca);
-    cb = mfma32_bf16w(b[1], zb[1], cb);
-    ca = mfma32_bf16w(a[0], za[2], ca);
-    cb = mfma32_bf16w(b[0], zb[2], cb);
-    ca = mfma32_bf16w(a[1], za[0], ca);
-    cb = mfma32_bf16w(b[1], zb[0], cb);
-    ca = mfma32_bf16w(a[0], za[1], ca);
-    cb = mfma32_bf16w(b[0], zb[1], cb);
-    ca = mfma32_bf16w(a[0], za[0], ca);
-    cb = mfma32_bf16w(b[0], zb[0], cb);
-}
-// The ring runs WB_PF steps ahead ACROSS slices: behind the products of step q of a slice of NK steps, slot q % WB_PF takes step
+// The ring runs WB_PF (its depth) steps ahead ACROSS slices: behind the products of step q of a slice of NK steps, slot q % WB_PF takes step
 // q + WB_PF of the same slice or, in the slice's last WB_PF steps, step q % WB_PF of the NEXT slice the wave will walk (which then
 // finds its first WB_PF steps in slots 0 .. WB_PF - 1).  Needs WB_PF <= the steps of every slice.
-PROMP_DEV void wb_ring_next(WbRing& G, const unsigned* Pcur, int nk, const unsigned* Pnext, int nkn, int w, int lane, int q) {
+template <int WB_PF>
+PROMP_DEV void wb_ring_next(WbRing<WB_PF>& G, const unsigned* Pcur, int nk, const unsigned* Pnext, int nkn, int w, int lane, int q) {
     if (q + WB_PF < nk) wb_gload(G.r[q % WB_PF], Pcur, nk, w, q + WB_PF, lane);
     else wb_gload(G.r[q % WB_PF], Pnext, nkn, w, q % WB_PF, lane);
 }
@@ -830,7 +858,7 @@ PROMP_DEV void wb_ring_next(WbRing& G, const unsigned* Pcur, int nk, const unsig
 // ---------------------------------------------------------------------------------------------
 template <int NKO, int NXB>
 __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
-    constexpr int H = 128, R = WB_R, MS = WB_MS, OC = (32 * NXB > 16 * NKO ? 32 * NXB : 16 * NKO) - 1;
+    constexpr int H = 128, R = WB_R, MS = WB_MS, OC = (32 * NXB > 16 * NKO ? 32 * NXB : 16 * NKO) - 1, WB_PF = 3;
     static_assert(NKO >= WB_PF, "the weight ring needs WB_PF <= K steps of every slice");
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
@@ -848,12 +876,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
     const float* vv = a.vdir + (long long)task * NP;
     const unsigned* PT = a.wb_theta_planes + (long long)task * a.wb_plane_stride;
     const unsigned* PV = a.wb_v_planes + (long long)task * wb_planes_words(NKO);
-    const int oC2 = wb_planes_c2(NKO), oR2 = wb_planes_r2(NKO);
+    const int oC2 = wb_planes_c2(NKO), oR2 = wb_planes_r2(NKO), oW3P = wb_planes_w3(NKO);
 
-    u32x4 w3p[3], v3p[3];
     float w3f[4], v3f[4];
     WbX<NKO> X;
-    WbRing GT, GV;
+    WbRing<WB_PF> GT, GV;
     {
         const int tid = threadIdx.x, lane = tid & 63;
         float *Xs = sm + L.x0, *Mss = sm + L.ms, *Ms2s = sm + L.ms2, *Dm = sm + L.dm, *Dm2 = sm + L.dm2, *b1s = sm + L.b1, *b2s = sm + L.b2,
@@ -862,8 +889,6 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         wb_xreq<NKO>(X, a.obs, wk.row_begin, wk.row_end - wk.row_begin, O, tid);
         wb_stream_begin(GT, PT, NKO, w, lane);
         wb_stream_begin(GV, PV, NKO, w, lane);
-        wb_load_w3(w3p, th + oW3, A, lane, w, 1.f);
-        wb_load_w3(v3p, vv + oW3, A, lane, w, 1.f);
         wb_load_w3f(w3f, th + oW3, A, lane, w, 1.f);
         wb_load_w3f(v3f, vv + oW3, A, lane, w, 1.f);
         for (int e = tid; e < H; e += 256) {
@@ -908,13 +933,16 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         float *Xs = smz + L.x0, *H1s = smz + L.h1, *H2s = smz + L.h2, *RH1s = smz + L.rh1, *RH2s = smz + L.rh2, *Mp = smz + L.mp,
               *Mp2 = smz + L.mp2, *Mss = smz + L.ms, *Ms2s = smz + L.ms2, *Dm = smz + L.dm, *Dm2 = smz + L.dm2, *b1s = smz + L.b1,
               *b2s = smz + L.b2, *b3s = smz + L.b3, *vb1s = smz + L.vb1, *vb2s = smz + L.vb2, *vb3s = smz + L.vb3, *lss = smz + L.ls,
-              *ess = smz + L.es, *sn2s = smz + L.sn2, *vls = smz + L.vls;
+              *ess = smz + L.es, *sn2s = smz + L.sn2, *vls = smz + L.vls, *D1p = smz + L.d1 + w * 1024;
         const unsigned *PTz = PT + zr, *PVz = PV + zr;
         WB_STAMP(0);
         __syncthreads();                       // the previous round is done with every tile
+        WB_STAMP(20);
         // ---- this round's observations (requested a round ago) -> the tile; the next round's are requested
         wb_xput<NKO>(Xs, X, nrows, O, OC, tid);
+        WB_STAMP(21);
         wb_xreq<NKO>(X, a.obs, (long long)base + R, wk.row_end - base - R, O, tid);
+        WB_STAMP(22);
         // ---- the loss level's row data: one (row, action) pair per thread
         const int erow = tid >> 3, eq = tid & 7;
         const bool eown = eq < A, rvalid = erow < nrows;
@@ -932,8 +960,9 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         __syncthreads();
         WB_STAMP(2);
         // ---- layer 1 and its tangent:  Rz1 = vW1^T x + vb1
-        f32x16 h1v, rh1v;
+        f32x16 rh1v;
         {
+            f32x16 h1v;
             f32x16 cz = wb_bias16(b1s, h, w), cr = wb_bias16(vb1s, h, w);
             u32x4 fb[3];
             wb_read_b(fb, Xs, j, h, 0);
@@ -941,9 +970,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
             for (int q = 0; q < NKO; ++q) {
                 u32x4 fn[3];
                 if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
+                sched_fence();
                 wb_mma6_two(cz, cr, GT.r[q % WB_PF], GV.r[q % WB_PF], fb);
                 wb_ring_next(GT, PTz, NKO, PTz + oC2, 8, w, lane, q);
                 wb_ring_next(GV, PVz, NKO, PVz + oC2, 8, w, lane, q);
+                sched_fence();
                 if (q + 1 < NKO) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) fb[t] = fn[t];
@@ -957,6 +988,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
             }
             wb_store_own(H1s, h1v, j, h, w);
             wb_store_own(RH1s, rh1v, j, h, w);
+            wb_park(D1p, h1v, lane);
         }
         sched_fence();
         WB_STAMP(3);
@@ -976,10 +1008,12 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                     wb_read_b(nb, H1s, j, h, q + 1);
                     wb_read_b(nr, RH1s, j, h, q + 1);
                 }
+                sched_fence();
                 wb_mma6_two(cz, cr, GT.r[q % WB_PF], GV.r[q % WB_PF], fb);
                 wb_mma6(cr, GT.r[q % WB_PF], fr);
                 wb_ring_next(GT, PTz + oC2, 8, PTz + oR2, 8, w, lane, q);
                 wb_ring_next(GV, PVz + oC2, 8, PVz + oR2, 8, w, lane, q);
+                sched_fence();
                 if (q + 1 < 8) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
@@ -1003,6 +1037,9 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         // ---- output layer and its tangent, this wave's 32 units of the contraction:  Rmu = vW3^T h2 + W3^T Rh2 + vb3
         {
             const int j16 = lane & 15, g4 = lane >> 4;
+            u32x4 w3p[3], v3p[3];
+            wb_gload(w3p, PTz + oW3P, 1, w, 0, lane);
+            wb_gload(v3p, PVz + oW3P, 1, w, 0, lane);
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 const int s = 16 * sb + j16;
@@ -1172,11 +1209,13 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 u32x4 far[3], fah[3];
                 wb_read_tr(far, RH1s, lane, m, t);
                 wb_read_tr(fah, H1s, lane, m, t);
+                sched_fence();
                 wb_mma6_ab(ad, aq, GT.r[q % WB_PF], fd, fq);
                 wb_mma6_x2(aq, GV.r[q % WB_PF], fd, aw2[m], far, fzn);
                 wb_mma6(aw2[m], fah, fzq);
                 wb_ring_next(GT, PTz + oR2, 8, PTz, NKO, w, lane, q);
                 wb_ring_next(GV, PVz + oR2, 8, PVz, NKO, w, lane, q);
+                sched_fence();
                 if (q + 1 < 8) {
 #pragma unroll
                     for (int tt = 0; tt < 3; ++tt) {
@@ -1186,7 +1225,14 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) qz1[r] = aq[r] * (1.f - h1v[r] * h1v[r]) - 2.f * ad[r] * h1v[r] * rh1v[r];
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 h1q = lds4(D1p + 256 * g + 4 * lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * g + i;
+                    qz1[r] = aq[r] * (1.f - h1q[i] * h1q[i]) - 2.f * ad[r] * h1q[i] * rh1v[r];
+                }
+            }
         }
         sched_fence();
         WB_STAMP(12);

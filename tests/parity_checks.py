@@ -207,12 +207,17 @@ def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False):
     ctx.close()
 
 
-def check_split_accuracy(lib, hidden, O, A, seed=11, M=2, P=2, T=48, tol=2.5e-6):
+def check_split_accuracy(lib, hidden, O, A, seed=11, M=2, P=2, T=48, tol=2.5e-6, meta_tol=None):
     """Guard of the BF16-split GEMMs (k_pass: every GEMM; k_chain_hvp: layer 2): on a small well-conditioned case the gradient,
     the Hessian-vector product and the meta-gradient must agree with the float64 oracle to float32 rounding.  Measured on the
     MI355X (profiles/r03_split_accuracy.txt, tools/split_accuracy_gpu.py): six products of the 3-way split 1.7e-7 ... 1.0e-6 of
     the result's max-norm; the same kernels built with THREE products 5e-6 ... 5e-5.  tol = 2.5e-6 sits between the two: a
-    regression of any GEMM to fewer products (or to plain BF16) fails here, long before the 1e-4 of the functional tests."""
+    regression of any GEMM to fewer products (or to plain BF16) fails here, long before the 1e-4 of the functional tests.
+    128-wide layers (k_wb_fwd_bwd / k_wb_hvp, round 5; profiles/r05_split_accuracy.txt): gradient 3.4e-7 ... 1.7e-6, Hessian-vector
+    product 5.3e-7 ... 1.2e-6 -- inside the same 2.5e-6 --, meta-gradient 2.7e-6 / 6.3e-6 (obs 20 / 111), where the exact-FP32
+    cooperative kernels (PROMP_WIDE_FP32=1) measure 3.2e-6 / 3.8e-6 on the same cases: at K = 128 that is float32 accumulation,
+    not the split, so the composite is held to meta_tol = 1e-5 there (three products would be ~5e-5)."""
+    meta_tol = tol if meta_tol is None else meta_tol
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
     spec = op.PolicySpec(O, A, hidden)
     ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
@@ -240,7 +245,7 @@ def check_split_accuracy(lib, hidden, O, A, seed=11, M=2, P=2, T=48, tol=2.5e-6)
     for cache in (0, 1):          # the recomputing and the cached second-order pass
         ctx.set_primal_cache(cache)
         g, _ = ctx.meta_grad(0.3, eta)
-        assert rel_max(g, r['grad']) < tol, ('meta-gradient', cache, rel_max(g, r['grad']))
+        assert rel_max(g, r['grad']) < meta_tol, ('meta-gradient', cache, rel_max(g, r['grad']))
     ctx.close()
 
 

@@ -66,9 +66,10 @@ def test_unequal_hidden_widths(lib, hidden, O, A):
     pc.check_meta(lib, 36, M=3, P=3, T=60, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2)
 
 
-@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2)])
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2),
+                                        ((128, 128), 111, 8), ((128, 128), 20, 6)])      # 128-wide: k_wb_fwd_bwd / k_wb_hvp (round 5)
 def test_split_gemm_accuracy_guard(lib, hidden, O, A):
-    pc.check_split_accuracy(lib, hidden, O, A)
+    pc.check_split_accuracy(lib, hidden, O, A, meta_tol=1e-5 if hidden[0] == 128 else None)
 
 
 @pytest.fixture

@@ -45,5 +45,5 @@ def errs(hidden, O, A, seed=11, M=2, P=2, T=48):
     return out
 
 
-for hidden, O, A in (((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2)):
+for hidden, O, A in (((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2), ((128, 128), 111, 8), ((128, 128), 20, 6)):
     print(hidden, O, A, {k: '%.2e' % v for k, v in errs(hidden, O, A).items()})
