@@ -467,6 +467,7 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
         dp.device_ref = (sess.serial, sess.upload_serial[slot], slot)
         dp.flat = fl
         dev.append(dp)
+    proc.lazy_host_arrays = True          # opt-in: per-row results cross PCIe on first use
     fetched = _lib.LazyResults.fetch_count
     ms_dev = timed(dev[0], dev[1], n)
     fetched = _lib.LazyResults.fetch_count - fetched
@@ -486,7 +487,8 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
                                                      'note': 'SampleProcessor.lazy_host_arrays = False: per step 2 x (returns + raw '
                                                              'advantages float64, advantages float32) come back over PCIe inside '
                                                              'process_samples and 2 x %d path dicts receive their views' % (M * P)},
-                               'note': 'DevicePaths with a valid device_ref (what DeviceSlabSampler / DevicePointEnvSampler return): '
+                               'note': 'DevicePaths with a valid device_ref (what DeviceSlabSampler / DevicePointEnvSampler return), '
+                                       'SampleProcessor.lazy_host_arrays = True (opt-in): '
                                        'no upload; the per-row results (returns, advantages) are handed out as arrays that cross '
                                        'PCIe on first use -- the loop, like the reference trainer, never reads them '
                                        '(per_row_downloads counts the fetches that did happen); baseline coefficients and per-path '

@@ -39,7 +39,7 @@ typedef struct promp_dims {
     int32_t n_tasks_global;     /* meta_batch_size over all ranks: the task-mean divides by this   */
     int32_t obs_dim;            /* O, 1..1024.  The fused kernels serve O <= 32 (hidden widths from {32,64}) and O <= 128
                                  * ((64,64) / (128,128)); everything else runs on the layer-by-layer kernels.
-                                 * LinearFeatureBaseline's fit (2 O + 4 features) exists for O <= 133                        */
+                                 * LinearFeatureBaseline's fit (2 O + 4 features) exists for O <= 480                        */
     int32_t act_dim;            /* A, 1..64 (fused kernels: A <= 8)                                */
     int32_t hidden1, hidden2;   /* the first two of hidden_sizes (policies/networks/mlp.py:5-62 takes any tuple).  Two tanh
                                  * layers of 1..128 units run on the fused kernels -- instantiated for {32,64} x {32,64}

@@ -187,28 +187,83 @@ class _HostPool(object):
     them, so a buffer is reused only when its reference count says that no view of it is alive any more.  Fresh allocations
     of this size (3 - 13 MB) cost more in page faults than the copy they receive; with a library at hand the buffers are
     page-locked (promp_host_alloc): the copies to and from the device then run at PCIe speed instead of through the
-    runtime's bounce buffers."""
+    runtime's bounce buffers.
 
-    def __init__(self, keep=8):
-        self._owners, self._keep = {}, keep
+    Requests are rounded up to a SIZE CLASS (1.25x geometric steps from 64 KB), and any free owner of the class serves them:
+    environments that end episodes early (Ant, Walker, Hopper, Humanoid) ask for a different row count every iteration, and
+    with exact sizes every iteration would leave eight more page-locked multi-MB buffers behind.  The pool also keeps at most
+    `max_bytes` of buffers; beyond that the least recently used FREE owners are dropped (their memory goes back through the
+    finalizer once the last view dies).  Thread-safe: one lock around the bookkeeping (LinearBaseline's fit thread and the
+    sampler's thread both draw from it)."""
+    _MIN_CLASS = 1 << 16
+
+    def __init__(self, keep=8, max_bytes=1 << 30):
+        import threading
+        self._owners = {}            # (class bytes, pinned) -> [owner, ...], most recently used last
+        self._keep, self._max_bytes, self._bytes = keep, int(max_bytes), 0
+        self._lock = threading.Lock()
+
+    @classmethod
+    def size_class(cls, nbytes):
+        c = cls._MIN_CLASS
+        while c < nbytes:
+            c = (c + (c >> 2) + 4095) & ~4095
+        return c
+
+    @staticmethod
+    def _free(lst, i):
+        import sys
+        cand = lst[i]
+        return sys.getrefcount(cand) == 3         # the pool's list, `cand`, getrefcount's argument: no view outside (CPython)
+
+    def retained_bytes(self):
+        return self._bytes
+
+    def retained_owners(self):
+        return sum(len(v) for v in self._owners.values())
 
     def get(self, shape, dtype, lib=None):
-        import sys
         shape = tuple(int(x) for x in shape)
         dt = np.dtype(dtype)
-        nbytes = max(int(np.prod(shape)) * dt.itemsize, 1)
-        key = (nbytes, lib is not None)
-        lst = self._owners.setdefault(key, [])
-        owner = None
-        for cand in lst:
-            if sys.getrefcount(cand) == 3:       # the list, `cand`, getrefcount's argument: no view outside
-                owner = cand
+        count = int(np.prod(shape))
+        cls_bytes = self.size_class(max(count * dt.itemsize, 1))
+        key = (cls_bytes, lib is not None)
+        with self._lock:
+            lst = self._owners.setdefault(key, [])
+            owner = None
+            for i in range(len(lst)):
+                if self._free(lst, i):
+                    owner = lst.pop(i)
+                    break
+            if owner is None:
+                owner = self._new_owner(cls_bytes, lib)
+                self._bytes += cls_bytes
+            lst.append(owner)                    # most recently used last
+            if len(lst) > self._keep:
+                self._drop_free(lst, cls_bytes, len(lst) - self._keep, skip=owner)
+            if self._bytes > self._max_bytes:
+                self._evict(skip=owner)
+        return owner[:count * dt.itemsize].view(dt).reshape(shape)
+
+    def _drop_free(self, lst, cls_bytes, n, skip):
+        i = 0
+        while n > 0 and i < len(lst):
+            if lst[i] is not skip and self._free(lst, i):
+                del lst[i]
+                self._bytes -= cls_bytes
+                n -= 1
+            else:
+                i += 1
+
+    def _evict(self, skip):
+        # least recently used free owners first, over all classes (a list's front is its oldest entry)
+        for key in sorted(self._owners, key=lambda k: -k[0]):
+            if self._bytes <= self._max_bytes:
                 break
-        if owner is None:
-            owner = self._new_owner(nbytes, lib)
-            if len(lst) < self._keep:
-                lst.append(owner)
-        return owner[:int(np.prod(shape)) * dt.itemsize].view(dt).reshape(shape)
+            lst = self._owners[key]
+            self._drop_free(lst, key[0], len(lst), skip)
+        for key in [k for k, v in self._owners.items() if not v]:
+            del self._owners[key]
 
     @staticmethod
     def _new_owner(nbytes, lib):
@@ -321,6 +376,9 @@ class LazyRows(np.lib.mixins.NDArrayOperatorsMixin):
             raise AttributeError(name)
         return getattr(self._arr(), name)
 
+    def __reduce__(self):                   # pickle / joblib / copy: the rows themselves (a LazyRows holds a device context)
+        return (np.array, (self._arr(),))
+
     def __repr__(self):
         return 'LazyRows(%s[%d:%d], %s)' % (self._field, self._a, self._b, 'fetched' if self._res.fetched else 'on the device')
 
@@ -343,6 +401,7 @@ class Context:
         self.n_tasks, self.K = int(n_tasks), int(num_inner_steps)
         self.step_rows = {}
         self._staged, self._live_refs = {}, {}
+        self._upload_refs = {}       # step -> sources of the last two promp_upload_step calls (copies possibly in flight)
         self.step_ls_rows = {}
         self.step_paths = {}
         self._lazy = {}              # step -> WeakSet of LazyResults that have not fetched yet
@@ -398,6 +457,11 @@ class Context:
         self._call('promp_upload_step', int(step), int(n_paths), _ptr(tpo, C.c_int32), _ptr(pro, C.c_int32),
                    _ptr(obs, C.c_float), _ptr(act, C.c_float), _ptr(rew, C.c_float), _ptr(old_mean, C.c_float),
                    _ptr(old_log_std, C.c_float), per_row)
+        # promp_upload_step returns with its copies enqueued: page-locked sources (host_pool's buffers) must not be recycled while the
+        # DMA may still read them.  The context keeps them referenced -- the pool only reuses buffers nobody references -- until the
+        # upload AFTER the next one of this step (stream order: by then these copies have completed) or the next sync().
+        self._upload_refs.setdefault(int(step), []).append((tpo, pro, obs, act, rew, old_mean, old_log_std, rew64))
+        del self._upload_refs[int(step)][:-2]
         self.step_rows[step] = int(pro[-1])
         self.step_paths[step] = int(n_paths)
         self.step_ls_rows[step] = int(pro[-1]) if per_row else self.n_tasks
@@ -739,6 +803,7 @@ class Context:
 
     def sync(self):
         self._call('promp_sync')
+        self._upload_refs.clear()          # every enqueued copy has completed
 
     def prof_enable(self, on=True):
         self._call('promp_prof_enable', int(bool(on)))

@@ -956,12 +956,8 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     rc |= dev_alloc(&c->scal_tmp, (size_t)M * 2);
     rc |= dev_alloc(&c->red, NP + K + 2); rc |= dev_alloc(&c->grad_mean, NP);
     rc |= dev_alloc(&c->stats, (size_t)2 * (K + 2));
-    rc |= dev_alloc(&c->gram_partials, (size_t)c->max_work * c->gram_stride);
-    rc |= dev_alloc(&c->gram_partials_side, (size_t)c->max_work * c->gram_stride);
-    if (nblk_max > 5 || dims->obs_dim > 32) {
-        rc |= dev_alloc(&c->fit_scratch, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
-        rc |= dev_alloc(&c->fit_scratch_side, (size_t)M * 2 * (c->Dmax + 1) * (c->Dmax + 1));
-    }
+    // (the baseline fit's partial Gram blocks and scratch matrices -- 2.7 GB per set at Humanoid's 757 columns -- are allocated by the
+    //  first promp_process_samples that fits a baseline on that stream: fit_buffers())
     rc |= dev_alloc(&c->red64, 64);
     if (c->generic) {
         const size_t R = (size_t)dims->max_rows;
@@ -1292,6 +1288,17 @@ int promp_stage_wait(promp_ctx* c) {
     return 0;
 }
 
+// The baseline fit's buffers of one stream (main / side), allocated on first use: contexts that never fit a LinearFeatureBaseline
+// (policy passes only, ZeroBaseline, advantages handed in) do not pay for them.
+int fit_buffers(promp_ctx* c, bool on_side) {
+    double*& gp = on_side ? c->gram_partials_side : c->gram_partials;
+    double*& fs = on_side ? c->fit_scratch_side : c->fit_scratch;
+    if (!gp && dev_alloc(&gp, (size_t)c->max_work * c->gram_stride)) return -2;
+    const int nblk_max = (c->Dmax + 1 + 15) / 16;
+    if (!fs && (nblk_max > 5 || c->d.obs_dim > 32) && dev_alloc(&fs, (size_t)c->d.n_tasks * 2 * (c->Dmax + 1) * (c->Dmax + 1))) return -2;
+    return 0;
+}
+
 int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     if (!c || !o) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
@@ -1324,6 +1331,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
     // (promp_profile) keeps everything on the one stream it brackets.
     const bool on_side = c->overlap && !c->prof && step >= 1;
     hipStream_t st = on_side ? c->side : c->stream;
+    if (o->baseline_kind != PROMP_BASELINE_ZERO && fit_buffers(c, on_side)) return -2;
     a.gram_partials = on_side ? c->gram_partials_side : c->gram_partials;
     double* fit_scratch = on_side ? c->fit_scratch_side : c->fit_scratch;
     if (on_side) {

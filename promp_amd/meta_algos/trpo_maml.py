@@ -71,6 +71,11 @@ class _DeviceEvaluator(object):
     def constraint_gradient(self):
         return self._whole_batch(self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_KL)[0])
 
+    def exact_hvp_available(self):
+        """False on ranks that exchange through session.collective (no communicator in the context: promp_constraint_hvp refuses a
+        shard's sums there); ExactDeviceHvp then falls back to the finite-difference products, whose gradients do cross it"""
+        return not self.algo.session.external()
+
     def constraint_hvp(self, x, refresh_chain=True):   # exact (d2 constraint / d theta2) x on the device
         return self.ctx.constraint_hvp(np.asarray(x, dtype=np.float32), self.algo.inner_kind, refresh_chain)
 

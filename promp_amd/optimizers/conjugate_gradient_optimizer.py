@@ -100,15 +100,22 @@ class ExactDeviceHvp(object):
         self.reg_coeff = None
         self._ev = None
         self._fresh = False
+        self._fd = None
 
     def build_graph(self, evaluator, reg_coeff):
         self._ev, self.reg_coeff = evaluator, reg_coeff
+        self._fd = FiniteDifferenceHvp()
+        self._fd.build_graph(evaluator, reg_coeff)
 
     def constraint_gradient(self):
         return self._ev.constraint_gradient()
 
     def Hx(self, x):
         assert isinstance(x, np.ndarray)
+        if getattr(self._ev, 'exact_hvp_available', lambda: True)() is False:
+            # ranks that exchange through the session's `collective` hold no communicator: the library refuses to present one
+            # shard's product as the batch's.  The reference's own construction works there (its gradients cross the collective).
+            return self._fd.Hx(x)
         out = self._ev.constraint_hvp(x, refresh_chain=not self._fresh)   # the adapted parameters are computed once per theta
         self._fresh = True
         return out

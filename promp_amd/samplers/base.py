@@ -39,11 +39,14 @@ class SampleProcessor(object):
     Args (samplers/base.py:48-65): baseline, discount=0.99, gae_lambda=1, normalize_adv=False, positive_adv=False
     """
 
-    # A batch that is already resident on the device (DevicePaths from DeviceSlabSampler / DevicePointEnvSampler) gets its per-row
-    # results back LAZILY: 'returns' / 'advantages' of the samples data and of the path dicts are _lib.LazyRows that cross PCIe
-    # on first use (np.asarray, arithmetic, indexing ...), which the training loop never does -- _adapt / optimize_policy work on
-    # the resident copy.  False: plain ndarrays, downloaded inside process_samples as the host-path branch always does.
-    lazy_host_arrays = True
+    # OPT-IN (default False = the reference's behaviour: plain ndarrays, and every path dict receives 'returns' / 'advantages' inside
+    # process_samples, samplers/base.py:104,159).  True: a batch that is already resident on the device (DevicePaths from
+    # DeviceSlabSampler / DevicePointEnvSampler) gets its per-row results back LAZILY -- 'returns' / 'advantages' of the samples
+    # data and of the path dicts are _lib.LazyRows that cross PCIe on first use (np.asarray, arithmetic, indexing ...), which the
+    # training loop never does (_adapt / optimize_policy work on the resident copy), and the path-dict side effect is applied when
+    # the DevicePaths container is next looked at.  A caller that kept references to the path lists / dicts from BEFORE the call, or
+    # tests isinstance(x, np.ndarray), must leave this off.
+    lazy_host_arrays = False
 
     def __init__(self, baseline, discount=0.99, gae_lambda=1, normalize_adv=False, positive_adv=False):
         assert 0 <= discount <= 1.0, 'discount factor must be in [0,1]'

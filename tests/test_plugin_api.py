@@ -190,8 +190,15 @@ def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sp
     assert sampler.total_timesteps_sampled == M * B * T
     # processing: resident (no upload) == uploaded
     proc = MetaSampleProcessor(baseline=LinearFeatureBaseline(), discount=0.99, gae_lambda=1, normalize_adv=True)
+    assert proc.lazy_host_arrays is False      # the default is the reference's behaviour: ndarrays, path dicts written in the call
     sess = policy.session
     serial_before = list(sess.upload_serial)
+    held = list(paths.raw_values())[0]
+    sd_eager = proc.process_samples(paths)
+    assert isinstance(sd_eager[0]['returns'], np.ndarray) and isinstance(held[0]['returns'], np.ndarray), \
+        'references to the path dicts taken before the call see the side effect (samplers/base.py:104,159)'
+    import pickle
+    proc.lazy_host_arrays = True               # opt-in
     sd_dev = proc.process_samples(paths)
     assert sess.upload_serial == serial_before, 'device paths must not be uploaded again'
     # a resident batch gets its per-row results back lazily: nothing has crossed PCIe yet ...
@@ -209,6 +216,8 @@ def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sp
         for key in ('observations', 'actions', 'rewards', 'returns', 'advantages', 'adj_avg_rewards'):
             np.testing.assert_allclose(a[key], b[key], rtol=1e-6, atol=1e-7)
     assert _lib.LazyResults.fetch_count == fetched + 1
+    unpickled = pickle.loads(pickle.dumps(sd_dev[1]['returns']))       # a LazyRows pickles as the rows themselves
+    assert isinstance(unpickled, np.ndarray) and np.array_equal(unpickled, np.asarray(sd_eager[1]['returns']))
     # the per-path side effect (samplers/base.py:104,159) is settled when the paths are looked at; eager == lazy, value for value
     ret_lazy = np.concatenate([np.asarray(p['returns']) for i in range(M) for p in paths[i]])
     adv_lazy = np.concatenate([np.asarray(p['advantages']) for i in range(M) for p in paths[i]])
@@ -671,3 +680,25 @@ def run_baseline_fit_predict_scenario():
 
 def test_baseline_fit_predict(emu):
     run_baseline_fit_predict_scenario()
+
+
+def test_host_pool_reuses_size_classes_and_caps_what_it_keeps():
+    """requests of slightly different sizes (early-terminating environments: a different row count every
+    iteration) must land on the same recycled buffers, not leave one page-locked buffer per distinct size behind"""
+    from promp_amd._lib import _HostPool
+    pool = _HostPool(max_bytes=64 << 20)
+    rng = np.random.RandomState(0)
+    for _ in range(100):
+        n = int(rng.randint(700000, 900000))
+        bufs = [pool.get((n,), np.float32) for _ in range(8)]
+        assert len(set(b.ctypes.data for b in bufs)) == 8 and all(b.shape == (n,) for b in bufs)
+        del bufs
+    assert pool.retained_owners() <= 16 and pool.retained_bytes() <= 64 << 20
+    # live views are never recycled, whatever the cap; free owners beyond the cap are dropped
+    held = [pool.get((n,), np.float32) for n in range(100000, 3000000, 100000)]
+    for i, b in enumerate(held):
+        b[:] = i
+    assert len(set(b.ctypes.data for b in held)) == len(held) and all(float(b[0]) == i for i, b in enumerate(held))
+    del held, b
+    pool.get((10,), np.float32)
+    assert pool.retained_bytes() <= 64 << 20
