@@ -68,15 +68,30 @@ def main():
                          'on the main stream (results do not depend on it)')
     ap.add_argument('--staged-only', action='store_true',
                     help='developer switch: feed the timed loop by staged uploads (tools/gpu_round.sh traces the copy / compute overlap with it)')
+    ap.add_argument('--test-shape', default='', metavar='M,P,T,O,A,H',
+                    help='test switch: a tiny meta-batch instead of the named config (tests/test_bench_ranks.py runs the N-rank code path '
+                         'of this file on the kernel emulator); the line it prints is marked and is not a benchmark result')
     args = ap.parse_args()
 
     rank, world, local_rank = comm.env_world()
+    if world != args.gpus and world == 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (promp_amd.launch: one process per GPU, RANK /
+        # LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run sets them) and let rank 0 print the line
+        import socket
+        from promp_amd import launch
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        sys.exit(launch.main(['--nproc', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+                              os.path.abspath(sys.argv[0])] + sys.argv[1:]))
     if world != args.gpus:
-        print('bench.py: --gpus %d but WORLD_SIZE=%d; for N>1 launch with python -m torch.distributed.run '
-              '--nproc-per-node N bench.py --gpus N' % (args.gpus, world), file=sys.stderr)
+        print('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     trpo = args.config == 5
     cfg = synthetic.CONFIGS[3 if trpo else args.config]
+    if args.test_shape:
+        tm, tp, tt, to, ta, thh = [int(x) for x in args.test_shape.split(',')]
+        cfg = dict(M=tm, P=tp, T=tt, O=to, A=ta, hidden=(thh, thh))
     P, T, O, A, hidden = cfg['P'], cfg['T'], cfg['O'], cfg['A'], cfg['hidden']
     K, E = 1, args.epochs
     N = P * T
@@ -104,6 +119,8 @@ def main():
         if world > 1:
             uid = comm.exchange_unique_id(rank, world, lambda: _lib.comm_unique_id())
             ctx.comm_init(rank, world, uid)
+            if os.environ.get('PROMP_FIXED_ORDER', '0') not in ('', '0'):
+                ctx.comm_fixed_order(True)
         # ---- synthetic, seeded, resident in HBM before timing ----
         ctx.set_theta(theta0)
         ctx.set_step_sizes(np.full(ctx.n_params, 0.1, np.float32))
@@ -225,8 +242,10 @@ def main():
         r = iteration.collect()          # the last step's statistics: waited for inside the timed region
         res = r if r is not None else res
         ctx.sync()
+        local = time.perf_counter() - t0     # this rank's own loop (its kernels + its waits for the exchanges)
         barrier()
         dt = time.perf_counter() - t0
+        run_timed.local_s = local
         return float(ctx.allreduce_f64([dt], op='max')[0]), res
 
     M_global = cfg['M'] * (world if args.scaling == 'weak' else 1)
@@ -277,6 +296,42 @@ def main():
                                'evaluated it instead of repeating it (promp_set_reuse_adapt, default on; bit-identical, '
                                'test_first_epoch_reuses_the_inner_adapt_pass): 11 instead of 12 first-order passes per step'},
     }
+
+    if args.test_shape:
+        out['test_shape'] = 'NOT A BENCHMARK RESULT: --test-shape %s (a code-path test of this file)' % args.test_shape
+    # ---- N ranks: who took part (what the communicator itself reports), every rank's own loop time, the exchange's latency ----
+    if world > 1:
+        ci = ctx.comm_info()
+        bus = ci['pci_bus_id'].encode()[:32]
+        row = np.zeros((world, 35))
+        row[rank, 0] = 1e3 * run_timed.local_s / args.steps
+        row[rank, 1] = ci['nranks']
+        row[rank, 2] = ci['rank']
+        row[rank, 3:3 + len(bus)] = list(bus)
+        flat = row.reshape(-1)
+        row = np.concatenate([ctx.allreduce_f64(flat[i:i + 64]) for i in range(0, flat.size, 64)]).reshape(world, 35)
+        ctx.prof_enable(True)                         # HIP events around every exchange on the stream it is enqueued on
+        n_ex = 1 if args.test_shape else 3
+        for _ in range(n_ex):
+            iteration()
+        ex = ctx.prof_read(_lib.KERNEL_EXCHANGE)
+        ctx.prof_enable(False)
+        ex_us = ctx.allreduce_f64([1e3 * ex['total_ms'] / max(ex['launches'], 1)], op='max')[0]
+        ideal = shard_ideal(args.config, world) if args.scaling == 'strong' and not args.test_shape else None
+        out['rccl'] = {
+            'nranks': int(row[0, 1]), 'nranks_reported_by_every_rank': [int(x) for x in row[:, 1]],
+            'ranks': [int(x) for x in row[:, 2]],
+            'devices': [bytes(int(c) for c in r[3:] if c > 0).decode() for r in row],
+            'distinct_devices': len(set(bytes(int(c) for c in r[3:] if c > 0) for r in row)),
+            'exchange': 'ncclAllGather + rank-ordered sum' if ci['fixed_order'] else 'ncclAllReduce(sum)',
+            'exchange_floats': int(ctx.n_params + K + 2), 'exchanges_per_step': ex['launches'] / float(n_ex),
+            'allreduce_us': ex_us, 'allreduce_us_note': 'HIP events around the exchange on the compute stream, mean per call, max over ranks '
+                                                       '(includes waiting for the slowest rank to arrive)',
+            'protocol': os.environ.get('NCCL_PROTO', 'RCCL default (LL for a %d-byte message)' % (4 * (ctx.n_params + K + 2))),
+            'per_rank_ms_per_step': [float(x) for x in row[:, 0]]}
+        if ideal:
+            out['strong_scaling'] = dict(ideal, speedup_vs_shard_ideal=ideal['shard_ms_per_step_kernels_only'] / (1e3 * elapsed / args.steps),
+                                         measured_speedup_vs_profiled_single_gpu=ideal['single_gpu_ms_per_step'] / (1e3 * elapsed / args.steps))
 
     # ---- config 5 with the exact constraint Hessian-vector product (promp_constraint_hvp) instead of the reference's finite
     # difference: reported beside the timed default, never as `value` ----
@@ -345,6 +400,14 @@ def main():
         ctx.prof_enable(False)
         dom = max((pass_name, hvp_name), key=lambda k: kern[k]['ms_per_step'])
         traffic = measured_traffic(dom) if args.config == 3 else None   # the committed PMC passes are of config 3
+        # what the launches of a step actually execute (the formula above counts passes the schedule folds away: the grad-KL
+        # backward rides the second-order pass's reverse sweep, the first epoch takes its inner pass from _adapt)
+        exec_flops = sum(k['launches_per_step'] * k['flop_per_row'] * k['rows_per_launch'] for k in kern.values() if 'flop_per_row' in k) * world
+        step_s = elapsed / args.steps
+        for name, k in kern.items():
+            t = measured_traffic(name) if args.config == 3 else None
+            if t and t.get('mfma_busy_frac') is not None:
+                k['mfma_busy_frac'] = t['mfma_busy_frac']          # committed PMC pass (sha-guarded like `traffic`)
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'], 'peak': FP32_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS,
                            'peak_note': 'algorithmic float32 FLOPs (SURVEY 8d: matmul only, 2 / MAC) over the FP32 peak of 157.3 TFLOP/s; '
@@ -352,6 +415,11 @@ def main():
                            'traffic': traffic['bytes'] if traffic else None, 'traffic_source': traffic['source'] if traffic else None,
                            'algorithmic_bytes_per_launch': 4 * (O + 2 * A + 2) * kern[dom]['rows_per_launch'],
                            'avg_launch_ms': kern[dom]['avg_ms'], 'kernels': kern,
+                           'executed': {'flops_per_step': exec_flops, 'tflops_per_gpu': exec_flops / step_s / 1e12 / world,
+                                        'frac': exec_flops / step_s / 1e12 / world / FP32_PEAK_TFLOPS,
+                                        'note': 'sum over the pass launches of one step of (launches x SURVEY 8d FLOPs per row x rows), over the '
+                                                'timed step: machine utilisation on the matmul work the step executes; end_to_end_tflops_per_gpu '
+                                                'is the same time against the FORMULA FLOPs of the reference\'s graph'},
                            'end_to_end_tflops_per_gpu': None if trpo else value * ((fl['fwd_bwd'] + E * (2 * fl['fwd'] + 3 * fl['bwd'] + fl['hvp'])
                                                                                            + 2 * fl['fwd'] + fl['bwd']) / 2.0) / 1e12 / world}
 
@@ -498,6 +566,32 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
     return res
 
 
+def shard_ideal(config, world):
+    """What the committed single-GPU measurements say an N-rank run of the FIXED 40-task batch can reach: one rank's share
+    (40 / N tasks, kernels only, no collective: bench.py --shard-of N on one GPU, profiles/rNN_shard_timings.txt) against the whole
+    batch on one GPU (profiles/rNN_bench.json).  The ceiling is below N because a pass launch carries fixed cost (parameter
+    staging, end-of-segment sums) that does not shrink with the shard: DESIGN.md section 7."""
+    import glob
+    import re
+    if config != 3:
+        return None
+    try:
+        sf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_shard_timings.txt')))[-1]
+        bf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench.json')))[-1]
+        single = json.load(open(bf))['ms_per_step']
+        shard = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r'shard-of (\d+): \d+ tasks on this GPU, ([0-9.]+) ms/step', open(sf).read())}
+        if world not in shard:
+            return None
+        return {'single_gpu_ms_per_step': single, 'shard_ms_per_step_kernels_only': shard[world],
+                'ceiling_speedup_before_exchange_latency': single / shard[world],
+                'ceilings': {str(n): single / v for n, v in sorted(shard.items())},
+                'source': '%s, %s' % (os.path.relpath(bf, ROOT), os.path.relpath(sf, ROOT)),
+                'note': 'strong scaling of the named 40-task batch: one MI355X finishes the whole update in %.2f ms, and a pass '
+                        'launch keeps its fixed cost on a %d-task shard; N x is reachable in the weak sense only (weak_batch)' % (single, 40 // world)}
+    except Exception:
+        return None
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN_hbm_traffic.json, written by tools/summarize_round.py); bench.py itself cannot read PMCs."""
@@ -512,7 +606,8 @@ def measured_traffic(kernel):
         if doc.get('_kernel_sources_sha256') != kernel_sources_sha256():
             return dict(bytes=None, source='%s is of other kernel sources (stale): not reported' % os.path.relpath(files[-1], ROOT))
         t = doc.get(kernel)
-        return dict(bytes=t['hbm_bytes_per_launch'], source=os.path.relpath(files[-1], ROOT)) if t else None
+        return dict(bytes=t['hbm_bytes_per_launch'], mfma_busy_frac=t.get('mfma_busy_frac'),
+                    source=os.path.relpath(files[-1], ROOT)) if t else None
     except Exception:
         return None
 

@@ -53,8 +53,11 @@ typedef struct promp_dims {
     /* ---- ABI 3 ---- */
     int32_t n_hidden;           /* len(hidden_sizes), 1..4; 0 means 2 (hidden1, hidden2)           */
     int32_t hidden3, hidden4;   /* widths of the third / fourth hidden layer (n_hidden >= 3 / 4)    */
-    int32_t reserved;           /* 0                                                               */
+    int32_t hidden_act;         /* hidden nonlinearity (policies/networks/mlp.py:47, policies/base.py:31): PROMP_ACT_TANH (0, the
+                                 * reference's default and every run script's), PROMP_ACT_RELU, PROMP_ACT_IDENTITY (the reference's
+                                 * hidden_nonlinearity=None: linear hidden layers).  Anything but tanh runs on the layer-by-layer kernels */
 } promp_dims;
+enum { PROMP_ACT_TANH = 0, PROMP_ACT_RELU = 1, PROMP_ACT_IDENTITY = 2 };
 
 enum { PROMP_BASELINE_ZERO = 0, PROMP_BASELINE_LINEAR_FEATURE = 1, PROMP_BASELINE_LINEAR_TIME = 2 };
 enum { PROMP_INNER_RATIO = 0,   /* -mean(ratio*adv)   meta_algos/pro_mp.py:59-65   */
@@ -338,6 +341,10 @@ int promp_comm_move(promp_ctx* dst, promp_ctx* src);
 /* Take the several-rank launch sequence (per-rank sums -> [all-reduce] -> mean + Adam as separate launches) even on
  * one rank; numerically identical to the fused single-rank launch (the parity tests assert bitwise equality). */
 int promp_comm_split_path(promp_ctx* ctx, int on);
+/* What the attached communicator says about itself (ncclCommCount, ncclCommUserRank; 1 / 0 without one), whether the exchange is
+ * the fixed-order one, and the PCI bus id of the context's device: evidence for a benchmark line that N ranks on N distinct GPUs
+ * took part (meta_algos/pro_mp.py:122,151,155 is the mean the exchange computes).  Any output may be NULL. */
+int promp_comm_info(promp_ctx* ctx, int32_t* nranks, int32_t* rank, int32_t* fixed_order, char* bus_id_out, size_t bus_id_bytes);
 /* The exchange as ncclAllGather + a sum in rank order (0, 1, ...) on every rank instead of ncclAllReduce: the replicas'
  * parameters are bitwise identical by construction -- not by the grace of RCCL choosing the same reduction order on every
  * rank -- and equal to one process adding the ranks' shards in that order.  The buffer is ~6 k floats:
@@ -364,7 +371,8 @@ int promp_eval_hvp(promp_ctx* ctx, int step, int inner_kind, int clip_log_std, f
 
 /* ---- measurement: HIP-event timing of the pass kernels on the context's stream ------------- */
 enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PROMP_KERNEL_FWD = 3 /* forward-only k_pass */,
-       PROMP_KERNEL_COUNT = 4 };
+       PROMP_KERNEL_EXCHANGE = 4 /* the ranks' exchange of [Theta+K+2] floats (all-reduce, or all-gather + ordered sum) */,
+       PROMP_KERNEL_COUNT = 5 };
 int promp_prof_enable(promp_ctx* ctx, int on);
 int promp_prof_read(promp_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches, int64_t* rows);
 int promp_device_info(promp_ctx* ctx, char* name_out, size_t name_bytes, int32_t* n_cus, int32_t* clock_mhz);

@@ -21,7 +21,9 @@ LOG_2PI = float(np.log(2.0 * np.pi))
 
 
 class PolicySpec:
-    def __init__(self, obs_dim, action_dim, hidden_sizes=(64, 64), min_std=1e-6):
+    def __init__(self, obs_dim, action_dim, hidden_sizes=(64, 64), min_std=1e-6, hidden_act='tanh'):
+        assert hidden_act in ('tanh', 'relu', 'identity')      # policies/networks/mlp.py:47 (None = identity)
+        self.hidden_act = hidden_act
         self.obs_dim = int(obs_dim)
         self.action_dim = int(action_dim)
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
@@ -68,6 +70,21 @@ class PolicySpec:
         return self.flatten(parts).astype(np.float64)
 
 
+def act_f(kind, z):
+    """hidden nonlinearity (mlp.py:47): tanh (default, policies/base.py:31), relu, identity (hidden_nonlinearity=None)"""
+    return np.tanh(z) if kind == 'tanh' else np.maximum(z, 0.0) if kind == 'relu' else z
+
+
+def act_d(kind, h):
+    """its derivative as a function of the OUTPUT h (TF: relu'(0) = 0)"""
+    return 1.0 - h ** 2 if kind == 'tanh' else (h > 0).astype(np.float64) if kind == 'relu' else np.ones_like(h)
+
+
+def act_dd_over_d(kind, h):
+    """f''(z) / f'(z) as a function of h: the R-operator of f'(z) is this times R{h} (tanh: -2 h; relu / identity: 0)"""
+    return -2.0 * h if kind == 'tanh' else np.zeros_like(h)
+
+
 def forward(spec, theta, obs, clip_log_std):
     """-> (mean [N,A], log_std [A], cache).  mlp.py:65-119, gaussian_mlp_policy.py:142-184."""
     parts = spec.unflatten(np.asarray(theta, dtype=np.float64))
@@ -76,7 +93,7 @@ def forward(spec, theta, obs, clip_log_std):
     nl = len(spec.layer_shapes)
     for li in range(nl):
         z = x @ parts[2 * li] + parts[2 * li + 1]
-        x = np.tanh(z) if li < nl - 1 else z
+        x = act_f(spec.hidden_act, z) if li < nl - 1 else z
         acts.append(x)
     s_raw = parts[-1].reshape(-1)
     if clip_log_std:

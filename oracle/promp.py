@@ -22,7 +22,7 @@ Hessian-vector product.  It is cross-checked by finite differences and torch.aut
     passes gradient inside [lo, hi]; tf.maximum(x, c) passes gradient when x >= c.
 """
 import numpy as np
-from .policy import forward, LOG_2PI
+from .policy import forward, act_d, act_dd_over_d, LOG_2PI
 
 INNER_RATIO = 'ratio'      # pro_mp.py:59-65
 INNER_LOGLIK = 'loglik'    # trpo_maml.py:58-62
@@ -50,7 +50,7 @@ def _backprop(spec, cache, dmu, ds):
         grads[2 * li] = acts[li].T @ dz
         grads[2 * li + 1] = dz.sum(axis=0)
         if li > 0:
-            dz = (dz @ parts[2 * li].T) * (1.0 - acts[li] ** 2)
+            dz = (dz @ parts[2 * li].T) * act_d(spec.hidden_act, acts[li])
     grads[2 * nl] = (ds * cache['s_mask']).reshape(1, -1)
     return spec.flatten(grads)
 
@@ -126,7 +126,7 @@ def hvp(spec, theta, slab, v, kind, clip_log_std):
     Rx = Racts[0]
     for li in range(nl):
         Rz = Rx @ parts[2 * li] + acts[li] @ vparts[2 * li] + vparts[2 * li + 1]
-        Rx = (1.0 - acts[li + 1] ** 2) * Rz if li < nl - 1 else Rz
+        Rx = act_d(spec.hidden_act, acts[li + 1]) * Rz if li < nl - 1 else Rz
         Racts.append(Rx)
     Rmu = Racts[-1]
     Rs = vparts[-1].reshape(-1) * s_mask
@@ -158,8 +158,8 @@ def hvp(spec, theta, slab, v, kind, clip_log_std):
         if li > 0:
             dx = dz @ parts[2 * li].T
             Rdx = Rdz @ parts[2 * li].T + dz @ vparts[2 * li].T
-            d1 = 1.0 - acts[li] ** 2
-            Rdz = Rdx * d1 - 2.0 * dx * acts[li] * Racts[li]
+            d1 = act_d(spec.hidden_act, acts[li])
+            Rdz = Rdx * d1 + dx * act_dd_over_d(spec.hidden_act, acts[li]) * Racts[li]
             dz = dx * d1
     out[2 * nl] = (Rds * s_mask).reshape(1, -1)
     return spec.flatten(out)

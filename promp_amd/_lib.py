@@ -21,7 +21,7 @@ BASELINE_ZERO, BASELINE_LINEAR_FEATURE, BASELINE_LINEAR_TIME = 0, 1, 2
 INNER_RATIO, INNER_LOGLIK, INNER_DICE = 0, 1, 2
 OUTER_CLIP, OUTER_RATIO, OUTER_KL, OUTER_LOGLIK = 0, 1, 2, 3
 LOSS_RATIO, LOSS_CLIP, LOSS_LOGLIK, LOSS_KL = 0, 1, 2, 3
-KERNEL_FWD_BWD, KERNEL_HVP, KERNEL_GRAM, KERNEL_FWD = 0, 1, 2, 3
+KERNEL_FWD_BWD, KERNEL_HVP, KERNEL_GRAM, KERNEL_FWD, KERNEL_EXCHANGE = 0, 1, 2, 3, 4
 
 
 class PrompError(RuntimeError):
@@ -32,7 +32,7 @@ class Dims(C.Structure):
     _fields_ = [('n_tasks', C.c_int32), ('n_tasks_global', C.c_int32), ('obs_dim', C.c_int32), ('act_dim', C.c_int32),
                 ('hidden1', C.c_int32), ('hidden2', C.c_int32), ('num_inner_steps', C.c_int32),
                 ('max_rows', C.c_int32), ('max_paths', C.c_int32),
-                ('n_hidden', C.c_int32), ('hidden3', C.c_int32), ('hidden4', C.c_int32), ('reserved', C.c_int32)]
+                ('n_hidden', C.c_int32), ('hidden3', C.c_int32), ('hidden4', C.c_int32), ('hidden_act', C.c_int32)]
 
 
 class ProcOpts(C.Structure):
@@ -111,6 +111,7 @@ SIGNATURES = {
     'promp_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     'promp_comm_move': (C.c_int, [_P, _P]),
     'promp_comm_split_path': (C.c_int, [_P, C.c_int]),
+    'promp_comm_info': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_size_t]),
     'promp_comm_fixed_order': (C.c_int, [_P, C.c_int]),
     'promp_reduced_get': (C.c_int, [_P, _F]),
     'promp_reduced_set': (C.c_int, [_P, _F]),
@@ -383,18 +384,34 @@ class LazyRows(np.lib.mixins.NDArrayOperatorsMixin):
         return 'LazyRows(%s[%d:%d], %s)' % (self._field, self._a, self._b, 'fetched' if self._res.fetched else 'on the device')
 
 
+HIDDEN_ACTS = dict(tanh=0, relu=1, identity=2)
+
+
+def hidden_act_id(act):
+    """the reference's hidden_nonlinearity argument (policies/base.py:31, mlp.py:47: a TF function or None) -> promp_dims.hidden_act:
+    'tanh' / a callable named tanh -> 0, 'relu' / a callable named relu -> 1, None / 'identity' / 'linear' -> 2 (linear hidden
+    layers, as tf.layers.dense(activation=None) builds them); anything else is refused -- never silently replaced"""
+    if act is None:
+        return HIDDEN_ACTS['identity']
+    name = act if isinstance(act, str) else getattr(act, '__name__', '')
+    name = {'linear': 'identity'}.get(name, name)
+    if name not in HIDDEN_ACTS:
+        raise PrompError('hidden nonlinearity %r unsupported: tanh, relu or None (identity)' % (act,))
+    return HIDDEN_ACTS[name]
+
+
 class Context:
     """One promp_ctx (one GPU).  Thin, NumPy-in / NumPy-out."""
 
     def __init__(self, n_tasks, obs_dim, act_dim, hidden_sizes, num_inner_steps=1, max_rows=0, max_paths=0,
-                 n_tasks_global=None, device_id=0, lib=None):
+                 n_tasks_global=None, device_id=0, lib=None, hidden_act='tanh'):
         self.lib = lib or get_library()
         hs = tuple(int(h) for h in hidden_sizes)
         if not 1 <= len(hs) <= 4:
             raise PrompError('hidden_sizes %r unsupported: 1 to 4 hidden layers' % (hidden_sizes,))
         h4 = hs + (0,) * (4 - len(hs))
         self.dims = Dims(int(n_tasks), int(n_tasks_global or n_tasks), int(obs_dim), int(act_dim), h4[0], h4[1],
-                         int(num_inner_steps), int(max_rows), int(max_paths), len(hs), h4[2], h4[3], 0)
+                         int(num_inner_steps), int(max_rows), int(max_paths), len(hs), h4[2], h4[3], hidden_act_id(hidden_act))
         self._h = _P()
         self.lib.check(self.lib.cdll.promp_ctx_create(C.byref(self._h), int(device_id), C.byref(self.dims)))
         self.n_params = self.lib.cdll.promp_param_count(C.byref(self.dims))
@@ -774,6 +791,13 @@ class Context:
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._call('promp_comm_init', int(rank), int(nranks), C.cast(buf, _P), 128)
+
+    def comm_info(self):
+        """what the attached communicator reports (ncclCommCount / ncclCommUserRank; 1 / 0 without one) and this context's GPU"""
+        n, r, fo = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        buf = C.create_string_buffer(64)
+        self._call('promp_comm_info', C.byref(n), C.byref(r), C.byref(fo), buf, 64)
+        return dict(nranks=int(n.value), rank=int(r.value), fixed_order=bool(fo.value), pci_bus_id=buf.value.decode())
 
     def comm_move_from(self, other):
         """take over `other`'s communicator (a context re-created with more capacity keeps it: no new rendezvous)"""

@@ -266,7 +266,7 @@ static HiddenList hidden_list(const promp_dims* d) {
 #define PROMP_LINFEAT_MAX_O 480     // LinearFeatureBaseline on the device: 2 obs_dim + 5 <= 965 columns (16 feature rows + their observations in LDS)
 bool policy_shape_generic(const promp_dims* d) {   // layer-by-layer kernels (promp_kernels_generic.h): everything the fused ones do not cover
     const HiddenList L = hidden_list(d);
-    return L.n != 2 || d->obs_dim > 128 || d->act_dim > 8 || d->hidden1 > 128 || d->hidden2 > 128;
+    return L.n != 2 || d->obs_dim > 128 || d->act_dim > 8 || d->hidden1 > 128 || d->hidden2 > 128 || d->hidden_act != PROMP_ACT_TANH;
 }
 bool policy_shape_chain(const promp_dims* d) {     // register-chained kernels: hidden widths from {32, 64}, obs_dim <= 32
     return !policy_shape_generic(d) && d->obs_dim <= 32 && (d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64);
@@ -288,6 +288,8 @@ int check_dims(const promp_dims* d) {
             return fail(-1, "hidden size %d (layer %d) unsupported: tanh layers of 1..%d units.  Two layers of up to 128 units run on the fused "
                         "kernels (narrower ones zero-padded on the instantiated widths: every combination of {32, 64} for obs_dim <= 32, "
                         "(64,64) / (128,128) otherwise); wider layers and other depths on the layer-by-layer kernels", L.h[l], l, GEN_MAX_N);
+    if (d->hidden_act < PROMP_ACT_TANH || d->hidden_act > PROMP_ACT_IDENTITY)
+        return fail(-1, "hidden_act %d unknown (0 tanh, 1 relu, 2 identity)", d->hidden_act);
     if (d->num_inner_steps < 1 || d->num_inner_steps > PROMP_ETA_MAX) return fail(-1, "num_inner_steps must be in [1, %d]", PROMP_ETA_MAX);
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
@@ -359,7 +361,7 @@ int launch_pass_generic(promp_ctx* c, StepData& S, const PassArgs& a, bool hvp, 
     g.work = a.work; g.task_row_offsets = a.task_row_offsets;
     g.n_lin = c->n_lin;
     for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
-    g.O = a.O; g.A = a.A; g.NP = c->NP;
+    g.O = a.O; g.A = a.A; g.NP = c->NP; g.act_kind = c->d.hidden_act;
     g.theta = a.theta; g.theta_task_stride = a.theta_task_stride; g.vdir = a.vdir;
     g.act[0] = a.obs;
     for (int l = 1; l < c->n_lin; ++l) { g.act[l] = c->g_act[l]; g.out_act[l] = c->g_act[l]; g.ract[l] = c->g_ract[l]; }
@@ -546,8 +548,16 @@ static bool adapt0_stands(const promp_ctx* c, int inner_kind, bool cached) {
 //   fixed_order  ncclAllGather of the ranks' vectors + k_sum_ranks adding them in rank order 0, 1, ... on every rank: replicas
 //                bitwise identical by construction, and equal to what one process adding its shards in that order computes
 //                (the fixed-order one-shot variant; n is ~6 k floats, the gather moves nranks x 24 KB).
+static int exchange_sums_raw(promp_ctx* c, float* buf, size_t n);
 static int exchange_sums(promp_ctx* c, float* buf, size_t n) {
     if (!c->comm) return 0;
+    // (promp_prof_enable: HIP events around the exchange on the stream it is enqueued on -- the per-call latency bench.py reports)
+    if (prof_begin(c, PROMP_KERNEL_EXCHANGE, 0)) return -2;
+    const int rc = exchange_sums_raw(c, buf, n);
+    if (rc) return rc;
+    return prof_end(c, PROMP_KERNEL_EXCHANGE);
+}
+static int exchange_sums_raw(promp_ctx* c, float* buf, size_t n) {
     if (c->fixed_order) {
         const size_t need = (size_t)c->nranks * n;
         if (c->gather_len < need) {
@@ -1713,7 +1723,7 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     if (c->generic) {
         GenForwardArgs gf;
         gf.obs = d_obs; gf.theta_tasks = c->theta_tasks; gf.mean = d_out; gf.scratch = d_out + n_out;
-        gf.B = batch; gf.NP = c->NP; gf.n_lin = c->n_lin; gf.maxw = c->g_maxw;
+        gf.B = batch; gf.NP = c->NP; gf.n_lin = c->n_lin; gf.maxw = c->g_maxw; gf.act_kind = c->d.hidden_act;
         for (int l = 0; l < c->n_lin; ++l) gf.lin[l] = c->lin[l];
         PROMP_LAUNCH(k_gen_policy_forward, dim3(M), 256, 0, c->stream, gf);
     } else
@@ -2201,6 +2211,24 @@ int promp_comm_init(promp_ctx* c, int rank, int nranks, const void* id, size_t i
     if (r != ncclSuccess) return fail(-4, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
     c->rank = rank;
     c->nranks = nranks;
+    return 0;
+}
+
+int promp_comm_info(promp_ctx* c, int32_t* nranks, int32_t* rank, int32_t* fixed_order, char* bus_id_out, size_t bus_id_bytes) {
+    if (!c) return fail(-1, "ctx is NULL");
+    int n = 1, r = 0;
+    if (c->comm) {        // what the communicator itself says, not what the caller passed to promp_comm_init
+        ncclResult_t e = ncclCommCount(c->comm, &n);
+        if (e == ncclSuccess) e = ncclCommUserRank(c->comm, &r);
+        if (e != ncclSuccess) return fail(-4, "ncclCommCount / ncclCommUserRank failed: %s", ncclGetErrorString(e));
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (fixed_order) *fixed_order = c->fixed_order ? 1 : 0;
+    if (bus_id_out && bus_id_bytes) {
+        bus_id_out[0] = 0;
+        HIPCHECK(hipDeviceGetPCIBusId(bus_id_out, (int)bus_id_bytes, c->device));
+    }
     return 0;
 }
 

@@ -59,9 +59,15 @@ struct GenArgs {
     float min_log_std;
     float kl_weight;
     float* row_tan;
+    int act_kind;                      // hidden nonlinearity: GEN_ACT_TANH / _RELU / _IDENTITY (policies/networks/mlp.py:47 takes any)
 };
 
 enum { GEN_FWD = 0, GEN_FWD_T = 1, GEN_BWD = 2, GEN_BWD_T = 3 };
+// Hidden nonlinearities.  The derivative is a function of the OUTPUT for all three (tanh: 1 - h^2; relu: h > 0, TF's relu'(0) = 0;
+// identity: 1), so the backward kernels need no pre-activations; only tanh has a second derivative (-2 h (1 - h^2)).
+enum { GEN_ACT_TANH = 0, GEN_ACT_RELU = 1, GEN_ACT_IDENTITY = 2 };
+PROMP_DEV float gen_act(int kind, float z) { return kind == GEN_ACT_TANH ? fast_tanh(z) : kind == GEN_ACT_RELU ? fmaxf(z, 0.f) : z; }
+PROMP_DEV float gen_act_d(int kind, float h) { return kind == GEN_ACT_TANH ? 1.f - h * h : kind == GEN_ACT_RELU ? (h > 0.f ? 1.f : 0.f) : 1.f; }
 PROMP_HD int gen_wgrad_ld(int N) { return 64 * ((N + 63) / 64) + 16; }
 PROMP_HD size_t gen_wgrad_smem(int nt, int N) { return sizeof(float) * (size_t)nt * GEN_RW * (GEN_LD + gen_wgrad_ld(N)); }
 
@@ -198,11 +204,11 @@ __global__ void __launch_bounds__(256) k_gen_linear(GenArgs a, int li, int pp) {
                             const int row = 16 * rb + 4 * kk + r;
                             if (row < nrows) {
                                 const float z = acc[rb][c][r] + b;
-                                const float h = last ? z : fast_tanh(z);
+                                const float h = last ? z : gen_act(a.act_kind, z);
                                 Hout[(long long)(row0 + row) * Nc + col] = h;
                                 if (TAN) {
                                     const float rz = racc[rb][c][r] + ub;
-                                    RHout[(long long)(row0 + row) * Nc + col] = last ? rz : (1.f - h * h) * rz;
+                                    RHout[(long long)(row0 + row) * Nc + col] = last ? rz : gen_act_d(a.act_kind, h) * rz;
                                 }
                             }
                         }
@@ -223,10 +229,10 @@ __global__ void __launch_bounds__(256) k_gen_linear(GenArgs a, int li, int pp) {
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * rb + 4 * kk + r;
                             const long long o = (long long)(row0 + (row < nrows ? row : nrows - 1)) * Nc + col;
-                            const float h = Hp[o], rh = TAN ? RHp[o] : 0.f, d1 = 1.f - h * h, dx = acc[rb][c][r];
+                            const float h = Hp[o], rh = TAN ? RHp[o] : 0.f, d1 = gen_act_d(a.act_kind, h), dx = acc[rb][c][r];
                             if (row < nrows) {
                                 DZo[o] = dx * d1;
-                                if (TAN) QZo[o] = racc[rb][c][r] * d1 - 2.f * dx * h * rh;
+                                if (TAN) QZo[o] = racc[rb][c][r] * d1 - (a.act_kind == GEN_ACT_TANH ? 2.f * dx * h * rh : 0.f);
                             }
                         }
                 }
@@ -484,7 +490,7 @@ struct GenForwardArgs {
     const float* theta_tasks;  // [tasks][Theta]
     float* mean;               // [tasks][B][A]
     float* scratch;            // [tasks][B][2][maxw]
-    int B, NP, n_lin, maxw;
+    int B, NP, n_lin, maxw, act_kind;
     GenLin lin[GEN_MAX_LIN];
 };
 
@@ -502,7 +508,7 @@ __global__ void __launch_bounds__(256) k_gen_policy_forward(GenForwardArgs a) {
             for (int j = 0; j < Ly.N; ++j) {
                 float z = th[Ly.b_off + j];
                 for (int k = 0; k < Ly.K; ++k) z = fmaf(x[k], th[Ly.w_off + k * Ly.N + j], z);
-                y[j] = last ? z : fast_tanh(z);
+                y[j] = last ? z : gen_act(a.act_kind, z);
             }
             x = y;
         }

@@ -360,7 +360,11 @@ typedef EmuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { char name[256]; char gcnArchName[64]; int multiProcessorCount; int clockRate; };
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipGetDeviceCount(int* n) {      // PROMP_EMU_DEVICES: the ranks of a several-process test each take "their" device
+    const char* e = getenv("PROMP_EMU_DEVICES");
+    *n = e ? atoi(e) : 1;
+    return 0;
+}
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     snprintf(p->name, sizeof p->name, "kernel-emulator (tests only)");
@@ -399,29 +403,118 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 }
 
 // ---- RCCL shim ------------------------------------------------------------------------------------
-// The host code calls RCCL unconditionally (same sequence as the product); here a communicator exists for ONE rank only
-// (all-reduce = identity), anything wider fails like an RCCL error would.  Multi-rank tests of the emulated library exchange the
-// reduction buffer themselves (promp_reduced_get / _set over gloo).
+// The host code calls RCCL unconditionally (same sequence as the product).  One rank: all-reduce = identity.  Several ranks
+// (processes of this host, e.g. tests that run bench.py --gpus 2 on this library): the communicator is a POSIX shared-memory
+// segment named after the unique id -- one slot per rank, a sense-reversing barrier in the segment -- and a collective is
+// "write my slot, meet, combine the slots in rank order, meet".  Synchronous like everything else in this interpreter.
+#include <atomic>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 typedef struct EmuComm* ncclComm_t;
-struct EmuComm { int nranks; };
+struct EmuShm {
+    std::atomic<int> arrived, generation;
+    char pad[56];
+};
+struct EmuComm {
+    int nranks, rank;
+    EmuShm* sh;
+    unsigned char* slots;
+    size_t slot_bytes, map_bytes;
+    char name[64];
+};
 struct ncclUniqueId { char internal[128]; };
 typedef int ncclResult_t;
-enum { ncclSuccess = 0, ncclInvalidUsage = 5 };
+enum { ncclSuccess = 0, ncclInvalidUsage = 5, ncclSystemError = 2 };
 enum ncclDataType_t { ncclFloat, ncclDouble };
 enum ncclRedOp_t { ncclSum, ncclMax };
-inline const char* ncclGetErrorString(ncclResult_t) { return "no multi-rank communicator in the kernel-emulation build"; }
-inline ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { memset(id, 0, sizeof *id); return ncclSuccess; }
-inline ncclResult_t ncclCommInitRank(ncclComm_t* c, int nranks, ncclUniqueId, int) {
-    if (nranks != 1) return ncclInvalidUsage;
-    *c = new EmuComm{1};
+inline const char* ncclGetErrorString(ncclResult_t) { return "kernel-emulation RCCL shim failed (shared-memory communicator)"; }
+inline ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+    memset(id, 0, sizeof *id);
+    snprintf(id->internal, sizeof id->internal, "/promp_emu_%d_%lld", (int)getpid(),
+             (long long)std::chrono::steady_clock::now().time_since_epoch().count());
     return ncclSuccess;
 }
-inline ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
-inline ncclResult_t ncclAllGather(const void* in, void* out, size_t n, ncclDataType_t t, ncclComm_t, hipStream_t) {
-    if (in != out) memcpy(out, in, n * (t == ncclDouble ? 8 : 4));
+inline void emu_comm_barrier(EmuComm* c) {
+    const int gen = c->sh->generation.load();
+    if (c->sh->arrived.fetch_add(1) + 1 == c->nranks) {
+        c->sh->arrived.store(0);
+        c->sh->generation.fetch_add(1);
+    } else {
+        while (c->sh->generation.load() == gen) sched_yield();
+    }
+}
+inline ncclResult_t ncclCommInitRank(ncclComm_t* c, int nranks, ncclUniqueId id, int rank) {
+    EmuComm* m = new EmuComm{nranks, rank, nullptr, nullptr, 0, 0, {0}};
+    if (nranks > 1) {
+        id.internal[sizeof(m->name) - 1] = 0;
+        snprintf(m->name, sizeof m->name, "%s", id.internal);
+        m->slot_bytes = 1 << 20;
+        m->map_bytes = sizeof(EmuShm) + (size_t)nranks * m->slot_bytes;
+        const int fd = shm_open(m->name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)m->map_bytes) != 0) { delete m; return ncclSystemError; }
+        void* p = mmap(nullptr, m->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { delete m; return ncclSystemError; }
+        m->sh = (EmuShm*)p;                    // (a fresh segment is zero-filled: arrived = generation = 0)
+        m->slots = (unsigned char*)p + sizeof(EmuShm);
+        emu_comm_barrier(m);
+    }
+    *c = m;
     return ncclSuccess;
 }
-inline ncclResult_t ncclAllReduce(const void* in, void* out, size_t n, ncclDataType_t t, ncclRedOp_t, ncclComm_t, hipStream_t) {
-    if (in != out) memcpy(out, in, n * (t == ncclDouble ? 8 : 4));
+inline ncclResult_t ncclCommDestroy(ncclComm_t c) {
+    if (c->nranks > 1) {
+        emu_comm_barrier(c);
+        if (c->rank == 0) shm_unlink(c->name);
+        munmap((void*)c->sh, c->map_bytes);
+    }
+    delete c;
     return ncclSuccess;
 }
+inline ncclResult_t ncclCommCount(ncclComm_t c, int* n) { *n = c->nranks; return ncclSuccess; }
+inline ncclResult_t ncclCommUserRank(ncclComm_t c, int* r) { *r = c->rank; return ncclSuccess; }
+inline ncclResult_t ncclAllGather(const void* in, void* out, size_t n, ncclDataType_t t, ncclComm_t c, hipStream_t) {
+    const size_t bytes = n * (t == ncclDouble ? 8 : 4);
+    if (c->nranks == 1) {
+        if (in != out) memcpy(out, in, bytes);
+        return ncclSuccess;
+    }
+    if (bytes > c->slot_bytes) return ncclInvalidUsage;
+    memcpy(c->slots + (size_t)c->rank * c->slot_bytes, in, bytes);
+    emu_comm_barrier(c);
+    for (int r = 0; r < c->nranks; ++r) memcpy((unsigned char*)out + (size_t)r * bytes, c->slots + (size_t)r * c->slot_bytes, bytes);
+    emu_comm_barrier(c);
+    return ncclSuccess;
+}
+inline ncclResult_t ncclAllReduce(const void* in, void* out, size_t n, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t) {
+    const size_t bytes = n * (t == ncclDouble ? 8 : 4);
+    if (c->nranks == 1) {
+        if (in != out) memcpy(out, in, bytes);
+        return ncclSuccess;
+    }
+    if (bytes > c->slot_bytes) return ncclInvalidUsage;
+    memcpy(c->slots + (size_t)c->rank * c->slot_bytes, in, bytes);
+    emu_comm_barrier(c);
+    for (size_t i = 0; i < n; ++i) {           // rank order 0, 1, ...: every rank computes the same bits
+        if (t == ncclDouble) {
+            double acc = ((const double*)c->slots)[i];
+            for (int r = 1; r < c->nranks; ++r) {
+                const double x = ((const double*)(c->slots + (size_t)r * c->slot_bytes))[i];
+                acc = op == ncclMax ? (x > acc ? x : acc) : acc + x;
+            }
+            ((double*)out)[i] = acc;
+        } else {
+            float acc = ((const float*)c->slots)[i];
+            for (int r = 1; r < c->nranks; ++r) {
+                const float x = ((const float*)(c->slots + (size_t)r * c->slot_bytes))[i];
+                acc = op == ncclMax ? (x > acc ? x : acc) : acc + x;
+            }
+            ((float*)out)[i] = acc;
+        }
+    }
+    emu_comm_barrier(c);
+    return ncclSuccess;
+}
+inline hipError_t hipDeviceGetPCIBusId(char* out, int n, int dev) { snprintf(out, n, "emu:%02d:00.0", dev); return 0; }

@@ -149,20 +149,21 @@ def check_fit_retry_on_rank_deficient_features(lib, seed, M=2, P=3, T=40, O=4):
     np.testing.assert_allclose(out['advantages'], adv_ref, rtol=1e-3, atol=1e-3 * np.abs(adv_ref).max())
 
 
-def make_ctx(lib, M, O, A, hidden, K, all_paths, n_tasks_global=None):
+def make_ctx(lib, M, O, A, hidden, K, all_paths, n_tasks_global=None, hidden_act='tanh'):
     R = max(sum(len(p['rewards']) for pl in paths.values() for p in pl) for paths in all_paths)
     NPaths = max(sum(len(pl) for pl in paths.values()) for paths in all_paths)
-    return _lib.Context(M, O, A, hidden, K, max_rows=R, max_paths=NPaths, lib=lib, n_tasks_global=n_tasks_global)
+    return _lib.Context(M, O, A, hidden, K, max_rows=R, max_paths=NPaths, lib=lib, n_tasks_global=n_tasks_global, hidden_act=hidden_act)
 
 
-def check_loss_grad(lib, seed, M, P, T, O, A, hidden, ragged=False, compact_log_std=False, low_log_std=False, min_std=1e-6):
+def check_loss_grad(lib, seed, M, P, T, O, A, hidden, ragged=False, compact_log_std=False, low_log_std=False, min_std=1e-6,
+                    hidden_act='tanh'):
     """low_log_std: some log_std entries below log(min_std), i.e. the tf.maximum clip is active.  At the default min_std = 1e-6
     values are not comparable in float32 (see below); with a benign min_std (0.5) they are, and are compared."""
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=ragged,
                                                           low_log_std=low_log_std, min_std=min_std)
-    spec = op.PolicySpec(O, A, hidden, min_std=min_std)
+    spec = op.PolicySpec(O, A, hidden, min_std=min_std, hidden_act=hidden_act)
     comparable = not low_log_std or min_std > 1e-3
-    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths, hidden_act=hidden_act)
     ctx.set_min_std(min_std)
     helpers.upload_slabs(ctx, all_paths, all_slabs, compact_log_std=compact_log_std)
     rng = np.random.RandomState(seed + 1)
@@ -188,10 +189,10 @@ def check_loss_grad(lib, seed, M, P, T, O, A, hidden, ragged=False, compact_log_
     ctx.close()
 
 
-def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False):
+def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False, hidden_act='tanh'):
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=ragged)
-    spec = op.PolicySpec(O, A, hidden)
-    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths, hidden_act=hidden_act)
     helpers.upload_slabs(ctx, all_paths, all_slabs)
     rng = np.random.RandomState(seed + 2)
     th = (theta + 0.02 * rng.randn(M, theta.size)).astype(np.float32)
@@ -306,11 +307,11 @@ def check_adam_golden(lib, name):
     return worst, excluded
 
 
-def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, compact_log_std=False):
+def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, compact_log_std=False, hidden_act='tanh'):
     """meta-objective + exact gradient, _adapt, and E Adam epochs + compute_stats."""
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=ragged)
-    spec = op.PolicySpec(O, A, hidden)
-    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act)
+    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths, hidden_act=hidden_act)
     helpers.upload_slabs(ctx, all_paths, all_slabs, compact_log_std=compact_log_std)
     alpha = np.full(spec.n_params, 0.1, np.float32)
     eta = np.array([5e-4, 1e-3, 2e-3][:K], np.float32)

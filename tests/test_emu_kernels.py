@@ -82,6 +82,15 @@ def test_generic_policy_shapes(lib, two_cus):
     pc.check_meta(lib, 10, M=2, P=1, T=30, O=6, A=9, hidden=(20, 20), K=1, epochs=1)
 
 
+@pytest.mark.parametrize('act', ['relu', 'identity'])
+def test_hidden_nonlinearities_other_than_tanh(lib, two_cus, act):
+    # policies/networks/mlp.py:47 takes any hidden_nonlinearity; relu and None (= linear hidden layers) run on the layer-by-layer
+    # kernels whatever the widths -- here a shape the fused tanh kernels would otherwise take
+    pc.check_loss_grad(lib, 41, M=2, P=1, T=33, O=6, A=3, hidden=(32, 32), hidden_act=act)
+    pc.check_hvp(lib, 42, M=1, P=1, T=40, O=6, A=3, hidden=(32, 32), hidden_act=act)
+    pc.check_meta(lib, 43, M=2, P=1, T=30, O=6, A=3, hidden=(32, 32), K=1, epochs=1, hidden_act=act)
+
+
 def test_hvp_segments_straddling_tasks(lib, monkeypatch):
     # 3 tasks x ~12 tiles on 2 emulated CUs: the round list is cut into two shares, so a workgroup of k_chain_hvp walks
     # segments of two (or all three) tasks one after the other and is the last arriver for some of them

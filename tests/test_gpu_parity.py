@@ -110,6 +110,16 @@ def test_generic_policy_shapes(lib, hidden, O, A):
     pc.check_meta(lib, 73, M=3, P=2, T=50, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2)
 
 
+@pytest.mark.parametrize('act,hidden,O,A', [('relu', (64, 64), 20, 6), ('identity', (64, 64), 20, 6), ('relu', (128, 128), 111, 8),
+                                            ('relu', (64, 64, 64), 20, 6)])
+def test_hidden_nonlinearities_other_than_tanh(lib, act, hidden, O, A):
+    """policies/base.py:31, networks/mlp.py:47: hidden_nonlinearity is an argument.  relu and None (linear hidden layers) run on the
+    layer-by-layer kernels at any shape: objective, gradient, Hessian-vector product, _adapt, Adam epochs against the float64 oracle"""
+    pc.check_loss_grad(lib, 81, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True, hidden_act=act)
+    pc.check_hvp(lib, 82, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True, hidden_act=act)
+    pc.check_meta(lib, 83, M=3, P=2, T=50, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2, hidden_act=act)
+
+
 def test_generic_policy_shapes_two_inner_steps_and_trpo_constraint(lib):
     pc.check_meta(lib, 75, M=3, P=2, T=50, O=20, A=6, hidden=(64, 64, 64), K=2, ragged=True, epochs=2)
     pc.check_exact_constraint_hvp(lib, 76, M=2, P=2, T=40, O=20, A=6, hidden=(64, 64, 64), K=1)

@@ -168,3 +168,47 @@ def test_sharded_partial_sums_add_up():
     p1 = pm.meta_objective_and_grad(spec, theta, all_slabs, a, eta, c['clip_eps'], tasks=[1], n_tasks_total=3)
     np.testing.assert_allclose(p0['grad'] + p1['grad'], full['grad'], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(p0['inner_kl'] + p1['inner_kl'], full['inner_kl'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('act', ['relu', 'identity', 'tanh'])
+def test_hidden_nonlinearities_gradient_and_hvp_match_torch_autograd(act):
+    """policies/networks/mlp.py:47 takes any hidden_nonlinearity (policies/base.py:31 defaults to tanh; None builds linear hidden
+    layers).  The oracle's hand-derived gradient and R-operator product for relu / identity, against torch.autograd on a
+    transcription of the forward arithmetic (double backward for the Hessian-vector product; relu'' = 0, relu'(0) = 0 as in TF)."""
+    torch = pytest.importorskip('torch')
+    O, A, hidden = 7, 3, (12, 10)
+    theta, all_slabs, _ = helpers.make_promp_case(5, 1, 2, 25, O, A, hidden, 1)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=act)
+    slab = all_slabs[0][0]
+    t64 = theta.astype(np.float64)
+    obs, acts = torch.tensor(slab['observations'], dtype=torch.float64), torch.tensor(slab['actions'], dtype=torch.float64)
+    adv = torch.tensor(slab['advantages'], dtype=torch.float64)
+    om = torch.tensor(slab['agent_infos']['mean'], dtype=torch.float64)
+    ols = torch.tensor(slab['agent_infos']['log_std'], dtype=torch.float64)
+    f = dict(tanh=torch.tanh, relu=torch.relu, identity=lambda x: x)[act]
+
+    def loss_fn(th, kind):
+        x, off = obs, 0
+        sizes = (O,) + hidden + (A,)
+        for i in range(len(sizes) - 1):
+            W = th[off:off + sizes[i] * sizes[i + 1]].reshape(sizes[i], sizes[i + 1])
+            off += sizes[i] * sizes[i + 1]
+            b = th[off:off + sizes[i + 1]]
+            off += sizes[i + 1]
+            x = x @ W + b
+            if i < len(sizes) - 2:
+                x = f(x)
+        s = th[off:off + A]
+        lp = -s.sum() - 0.5 * (((acts - x) * torch.exp(-s)) ** 2).sum(1)
+        lp_old = -ols.sum(1) - 0.5 * (((acts - om) * torch.exp(-ols)) ** 2).sum(1)
+        return -(torch.exp(lp - lp_old) * adv).mean() if kind == 'ratio' else -(lp * adv).mean()
+
+    rng = np.random.RandomState(9)
+    v = rng.randn(spec.n_params)
+    for kind in ('ratio', 'loglik'):
+        th = torch.tensor(t64, requires_grad=True)
+        g, = torch.autograd.grad(loss_fn(th, kind), th, create_graph=True)
+        hv, = torch.autograd.grad((g * torch.tensor(v)).sum(), th)
+        r = pm.loss_and_grad(spec, t64, slab, kind, False)
+        np.testing.assert_allclose(r['grad'], g.detach().numpy(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(pm.hvp(spec, t64, slab, v, kind, clip_log_std=False), hv.numpy(), rtol=1e-8, atol=1e-11)

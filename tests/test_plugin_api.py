@@ -702,3 +702,29 @@ def test_host_pool_reuses_size_classes_and_caps_what_it_keeps():
     del held, b
     pool.get((10,), np.float32)
     assert pool.retained_bytes() <= 64 << 20
+
+
+def test_hidden_nonlinearity_argument_is_honoured_or_refused(emu):
+    """policies/base.py:31 / networks/mlp.py:47: hidden_nonlinearity is tf.tanh by default, any TF function or None (linear hidden
+    layers).  The plugin class maps 'tanh' / 'relu' / None (and callables of those names) onto the device kernels and refuses the
+    rest by name -- in particular None is NOT run as tanh (Missing #4)."""
+    from oracle import policy as op
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    obs = [np.random.RandomState(3).randn(5, 4).astype(np.float32) for _ in range(2)]
+
+    def relu(x):
+        return x
+    for arg, kind in ((None, 'identity'), ('relu', 'relu'), (relu, 'relu'), ('tanh', 'tanh')):
+        np.random.seed(4)
+        pol = MetaGaussianMLPPolicy(name='p', obs_dim=4, action_dim=2, meta_batch_size=2, hidden_sizes=(16, 16), hidden_nonlinearity=arg)
+        assert pol.hidden_nonlinearity == kind
+        pol.switch_to_pre_update()
+        _, infos = pol.get_actions(obs)
+        spec = op.PolicySpec(4, 2, (16, 16), hidden_act=kind)
+        theta = spec.from_ordered_dict(pol.get_param_values())
+        for i in range(2):
+            mean, _, _ = op.forward(spec, theta, obs[i], False)
+            np.testing.assert_allclose(np.stack([inf['mean'] for inf in infos[i]]), mean, atol=2e-6)
+        pol.session._drop()
+    with pytest.raises(_lib.PrompError, match='unsupported'):
+        MetaGaussianMLPPolicy(name='p', obs_dim=4, action_dim=2, meta_batch_size=2, hidden_sizes=(16, 16), hidden_nonlinearity='elu')

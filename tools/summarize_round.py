@@ -52,6 +52,10 @@ for k, r in pmc.iterrows():
         traffic[short] = dict(fetch_size_kib=r['FETCH_SIZE'], write_size_kib=r['WRITE_SIZE'],
                               hbm_bytes_per_launch=(2.0 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024.0,
                               note='(2 x FETCH_SIZE + WRITE_SIZE) KiB; separate --pmc passes of bench.py --steps 3; gfx950 FETCH_SIZE x2 correction')
+        # matrix-pipe utilisation: busy cycles summed over the chip's 1024 SIMDs against the kernel's own cycles (GRBM_GUI_ACTIVE)
+        if r.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) == r.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) and r.get('GRBM_GUI_ACTIVE', 0) > 0:
+            traffic[short]['mfma_busy_frac'] = float(r['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024.0 * float(r['GRBM_GUI_ACTIVE']))
+            traffic[short]['valu_active_frac'] = float(r.get('SQ_ACTIVE_INST_VALU', float('nan'))) / float(r['SQ_WAVE_CYCLES']) if r.get('SQ_WAVE_CYCLES', 0) > 0 else None
 sys.path.insert(0, ROOT)
 import bench
 traffic['_kernel_sources_sha256'] = bench.kernel_sources_sha256()    # bench.py reports these counters only for the same sources
