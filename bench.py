@@ -524,7 +524,14 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
         return 1e3 * (time.perf_counter() - t0) / n
 
     n = 10
-    ms_host = timed(p0, p1, n)
+    ms_plain = timed(p0, p1, n)          # independent arrays per path: process_samples concatenates 800 paths x 5 arrays, twice
+    # the batch as MetaSampler.obtain_samples returns it for a fixed-horizon environment (this config): path dicts whose device-bound
+    # fields are views of flat page-locked arrays the sampler filled while it collected (samplers/meta_sampler.py: HostPaths)
+    from copy import copy as _shallow
+    from promp_amd.samplers.meta_sampler import slab_backed
+    h0 = slab_backed(OrderedDict((i, [dict(p, agent_infos=dict(p['agent_infos'])) for p in pl]) for i, pl in p0.items()))
+    h1 = slab_backed(OrderedDict((i, [dict(p, agent_infos=dict(p['agent_infos'])) for p in pl]) for i, pl in p1.items()))
+    ms_host = timed(h0, h1, n)
     # (b) the batch as a device sampler leaves it: slot k holds step k, the path dicts are views of the downloaded slab
     sess = policy.session
     dev = []
@@ -546,8 +553,13 @@ def plugin_path(cfg, theta0, E, eta, opts, device_value, upload_ms):
            'host_paths': {'ms_per_step': ms_host, 'value': env_steps / (ms_host * 1e-3),
                           'pcie_upload_ms_per_step': upload_ms,
                           'pcie_share': (upload_ms / ms_host) if upload_ms else None,
-                          'note': 'path dicts in host memory: flatten (800 paths x 5 arrays) + promp_upload_step from pageable memory + '
-                                  'downloads + per-task dicts, twice per step'},
+                          'note': 'path dicts in host memory as MetaSampler.obtain_samples returns them for a fixed-horizon environment '
+                                  '(HostPaths: the dicts\' observations / actions / rewards / agent_infos are views of the flat page-locked '
+                                  'arrays the sampler wrote each finished episode into, once): promp_upload_step of those arrays + downloads + '
+                                  'per-task dicts, twice per step',
+                          'plain_dicts': {'ms_per_step': ms_plain, 'value': env_steps / (ms_plain * 1e-3),
+                                          'note': 'the same batch as independent arrays per path (a custom sampler, early-terminating '
+                                                  'environments): process_samples first concatenates 800 paths x 5 arrays per sampling step'}},
            'device_resident': {'ms_per_step': ms_dev, 'value': env_steps / (ms_dev * 1e-3),
                                'ratio_to_value': (env_steps / (ms_dev * 1e-3)) / device_value,
                                'per_row_downloads': fetched,

@@ -194,11 +194,13 @@ class _HostPool(object):
     environments that end episodes early (Ant, Walker, Hopper, Humanoid) ask for a different row count every iteration, and
     with exact sizes every iteration would leave eight more page-locked multi-MB buffers behind.  The pool also keeps at most
     `max_bytes` of buffers; beyond that the least recently used FREE owners are dropped (their memory goes back through the
-    finalizer once the last view dies).  Thread-safe: one lock around the bookkeeping (LinearBaseline's fit thread and the
+    finalizer once the last view dies).  The per-class `keep` is deliberately generous: a training loop holds two generations of
+    a step's buffers (this batch's SamplesData while the previous batch's are being released), and dropping / re-allocating
+    page-locked memory every step costs milliseconds (measured: 19.7 vs 11 ms per plugin step with keep = 8).  Thread-safe: one lock around the bookkeeping (LinearBaseline's fit thread and the
     sampler's thread both draw from it)."""
     _MIN_CLASS = 1 << 16
 
-    def __init__(self, keep=8, max_bytes=1 << 30):
+    def __init__(self, keep=64, max_bytes=1 << 30):
         import threading
         self._owners = {}            # (class bytes, pinned) -> [owner, ...], most recently used last
         self._keep, self._max_bytes, self._bytes = keep, int(max_bytes), 0
@@ -856,6 +858,11 @@ def flatten_paths(paths_meta_batch, lib=None):
     One concatenation per field over all paths of all tasks, straight into recycled (page-locked, when `lib` is given) host
     buffers: no per-path conversions (at 800 paths they cost more than the copy), no page faults of a fresh allocation.
     Observations / actions / agent_infos as float32 [rows, dim], rewards float64 if the environment's are, else float32."""
+    intact = getattr(paths_meta_batch, 'flat_if_intact', None)
+    if intact is not None:
+        fl = intact()            # samplers.meta_sampler.HostPaths: the sampler built the flat arrays while it collected
+        if fl is not None:
+            return fl
     plists = list(paths_meta_batch.values())
     flat = [p for plist in plists for p in plist]
     lens = [len(p['rewards']) for p in flat]

@@ -92,14 +92,133 @@ class _StepTables(object):
     def advance(self):
         self.fill += 1
 
-    def cut(self, env):
-        """the finished episode of environment `env` as a path dict; its slot starts over"""
+    def cut(self, env, slabs=None, task=0):
+        """the finished episode of environment `env` as a path dict; its slot starts over.  With `slabs` (_EpisodeSlabs) the
+        fields that go to the device leave the tables ONCE, straight into their final position of the meta-batch's flat arrays,
+        and the path dict holds views of those rows"""
         n = int(self.fill[env])
         path = {'env_infos': {}, 'agent_infos': {}}
+        dest = slabs.place(task, n, self._tables) if slabs is not None else None
         for key_path, table in self._tables.items():
-            _graft(path, key_path, table[env, :n].copy())
+            if dest is not None and key_path in dest:
+                view = dest[key_path]
+                view[...] = table[env, :n]
+                _graft(path, key_path, view)
+            else:
+                _graft(path, key_path, table[env, :n].copy())
         self.fill[env] = 0
+        if dest is not None:
+            slabs.remember(task, path, n)
         return path, n
+
+
+class HostPaths(OrderedDict):
+    """MetaSampler.obtain_samples' return value (OrderedDict{task -> [path dicts]}, meta_sampler.py:59-137) whose device-bound
+    fields -- observations, actions, rewards, agent_infos mean / log_std -- are VIEWS of flat [rows, dim] arrays in task-major,
+    path-major order: `flat` is what promp_amd._lib.flatten_paths would build from the dicts, already built (in page-locked
+    memory when the library is there).  process_samples then uploads it as it is instead of concatenating 800 paths x 5 arrays
+    again.  The dicts stay ordinary dicts; flat_if_intact() hands `flat` out only while every path still holds the very arrays
+    the sampler put there (a caller that replaces a path's rewards, drops a path, ... gets the general route)."""
+    flat = None
+    _origin = ()
+
+    def flat_if_intact(self):
+        fl, org = self.flat, self._origin
+        if fl is None:
+            return None
+        i, n = 0, len(org)
+        for plist in OrderedDict.values(self):
+            for p in plist:
+                if i >= n:
+                    return None
+                o = org[i]
+                i += 1
+                ai = p.get('agent_infos')
+                if o[0] is not p or p.get('observations') is not o[1] or p.get('actions') is not o[2] or p.get('rewards') is not o[3] \
+                        or ai is None or ai.get('mean') is not o[4] or ai.get('log_std') is not o[5]:
+                    return None
+        return fl if i == n else None
+
+
+class _EpisodeSlabs(object):
+    """The flat arrays of a meta-batch under construction: task i owns rows [i cap, (i + 1) cap) of every array, cap =
+    rollouts_per_meta_task x max_path_length (what a task contributes when no episode ends early: then the arrays are final
+    the moment the last episode is cut, and nothing is ever copied again).  Environments that end episodes early fill the tasks
+    unevenly (collection stops on the TOTAL of finished steps): a task that outgrows its share, or tables that are not float32
+    (an environment with float64 observations keeps its dtype in the path dicts, as the reference does), switch the slabs off
+    for this batch -- the paths are then what they always were, independent arrays, and process_samples flattens them."""
+    FIELDS = (('observations',), ('actions',), ('rewards',), ('agent_infos', 'mean'), ('agent_infos', 'log_std'))
+    NAMES = ('obs', 'act', 'rew', 'old_mean', 'old_log_std')
+
+    def __init__(self, n_tasks, cap):
+        self.M, self.cap = int(n_tasks), int(cap)
+        self.cursor = [0] * self.M
+        self.bufs = None
+        self.ok = True
+        self.entries = [[] for _ in range(self.M)]        # per task: (path dict, n)
+
+    def _allocate(self, tables):
+        from .. import _lib
+        try:
+            lib = _lib.get_library()
+        except Exception:
+            lib = None
+        bufs = {}
+        for key in self.FIELDS:
+            t = tables.get(key)
+            if t is None or (t.dtype != np.float32 and not (key == ('rewards',) and t.dtype == np.float64)):
+                return None
+            if key == ('rewards',):
+                if t.ndim != 2:
+                    return None
+                bufs[key] = _lib.host_pool.get((self.M * self.cap,), t.dtype, lib)
+            else:
+                if t.ndim != 3:
+                    return None
+                bufs[key] = _lib.host_pool.get((self.M * self.cap, t.shape[2]), np.float32, lib)
+        return bufs
+
+    def place(self, task, n, tables):
+        if not self.ok:
+            return None
+        if self.bufs is None:
+            self.bufs = self._allocate(tables)
+            if self.bufs is None:
+                self.ok = False
+                return None
+        if self.cursor[task] + n > self.cap or any(tables[k].dtype != self.bufs[k].dtype for k in self.FIELDS):
+            self.ok = False                       # (paths cut so far keep their views: valid arrays, just no shared flat any more)
+            return None
+        a = task * self.cap + self.cursor[task]
+        self.cursor[task] += n
+        return {k: self.bufs[k][a:a + n] for k in self.FIELDS}
+
+    def remember(self, task, path, n):
+        self.entries[task].append((path, n))
+
+    def finish(self, paths):
+        """-> HostPaths with .flat, or a plain OrderedDict when the slabs were switched off"""
+        if not self.ok or self.bufs is None or any(len(paths[i]) != len(self.entries[i]) for i in range(self.M)):
+            return paths
+        rows = sum(self.cursor)
+        if any(c != self.cap for c in self.cursor):
+            # Episodes ended early.  Collection stops at M x cap finished steps in all, so a task below its share means another
+            # one above it (which switched the slabs off in place()) -- or an interrupted collection: the general route either way
+            # (the views the paths hold are valid arrays on their own).
+            return paths
+        out = HostPaths(paths)
+        lens = [n for i in range(self.M) for _, n in self.entries[i]]
+        pro = np.zeros(len(lens) + 1, np.int32)
+        np.cumsum(lens, out=pro[1:])
+        tpo = np.zeros(self.M + 1, np.int32)
+        np.cumsum([len(self.entries[i]) for i in range(self.M)], out=tpo[1:])
+        flat = dict(task_path_offsets=tpo, path_row_offsets=pro)
+        for k, name in zip(self.FIELDS, self.NAMES):
+            flat[name] = self.bufs[k][:rows]
+        out.flat = flat
+        out._origin = [(p, p['observations'], p['actions'], p['rewards'], p['agent_infos']['mean'], p['agent_infos']['log_std'])
+                       for i in range(self.M) for p, _ in self.entries[i]]
+        return out
 
 
 class MetaSampler(object):
@@ -134,6 +253,7 @@ class MetaSampler(object):
         M, per_task = self.meta_batch_size, self.envs_per_task
         tables = _StepTables(self.vec_env.num_envs, self.max_path_length)
         paths = OrderedDict((task, []) for task in range(M))
+        slabs = _EpisodeSlabs(M, self.batch_size * self.max_path_length)
         collected, policy_seconds, env_seconds = 0, 0.0, 0.0
         observations = self.vec_env.reset()
         while collected < self.total_samples:
@@ -154,7 +274,7 @@ class MetaSampler(object):
             tables.put_infos('agent_infos', self._per_env(infos_by_task))
             tables.advance()
             for env in np.flatnonzero(np.asarray(finished)):
-                path, n = tables.cut(env)
+                path, n = tables.cut(env, slabs, env // per_task)
                 paths[env // per_task].append(path)
                 collected += n
             observations = next_observations
@@ -162,7 +282,8 @@ class MetaSampler(object):
         if log:
             logger.logkv(log_prefix + 'PolicyExecTime', policy_seconds)
             logger.logkv(log_prefix + 'EnvExecTime', env_seconds)
-        return paths
+        return slabs.finish(paths)
+
 
     def _per_env(self, infos_by_task):
         """agent infos arrive as list[task] of list[env of the task]; flatten to environment order"""
@@ -170,3 +291,33 @@ class MetaSampler(object):
             return []
         assert len(infos_by_task) == self.meta_batch_size and all(len(t) == self.envs_per_task for t in infos_by_task)
         return [info for task_infos in infos_by_task for info in task_infos]
+
+
+def slab_backed(paths_meta_batch):
+    """Ordinary path dicts -> the HostPaths MetaSampler.obtain_samples builds (one copy of the device-bound fields into flat
+    arrays, the dicts re-pointed at views of them); returns the input unchanged when the fields are not float32 arrays.
+    For callers that assemble path dicts themselves (a custom sampler, replayed trajectories, bench.py's synthetic batch)."""
+    from .. import _lib
+    M = len(paths_meta_batch)
+    plists = list(paths_meta_batch.values())
+    try:
+        fl = _lib.flatten_paths(paths_meta_batch, _lib.get_library())
+    except Exception:
+        return paths_meta_batch
+    first = plists[0][0]
+    if fl['act'] is None or any(np.asarray(x).dtype != np.float32 for x in (first['observations'], first['actions'], first['agent_infos']['mean'],
+                                                                             first['agent_infos']['log_std'])):
+        return paths_meta_batch
+    out = HostPaths((k, v) for k, v in paths_meta_batch.items())
+    pro = fl['path_row_offsets']
+    i = 0
+    origin = []
+    for plist in plists:
+        for p in plist:
+            a, b = int(pro[i]), int(pro[i + 1])
+            i += 1
+            p['observations'], p['actions'], p['rewards'] = fl['obs'][a:b], fl['act'][a:b], fl['rew'][a:b]
+            p['agent_infos']['mean'], p['agent_infos']['log_std'] = fl['old_mean'][a:b], fl['old_log_std'][a:b]
+            origin.append((p, p['observations'], p['actions'], p['rewards'], p['agent_infos']['mean'], p['agent_infos']['log_std']))
+    out.flat, out._origin = fl, origin
+    return out

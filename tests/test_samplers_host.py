@@ -237,3 +237,69 @@ def test_device_paths_settle_the_pending_side_effect_on_first_look():
     assert 'returns' in paths[1][0] and looked == [1]                                  # looking at a path list does, once
     assert all('returns' in p for plist in paths.values() for p in plist) and looked == [1]
     assert [k for k, _ in paths.items()] == [0, 1]
+
+
+class FixedHorizonEnv(CounterEnv):
+    """never terminates by itself (HalfCheetah-like): every episode is max_path_length long"""
+
+    def step(self, action):
+        obs, rew, _, info = CounterEnv.step(self, action)
+        return obs, np.float32(rew), False, info
+
+
+def test_fixed_horizon_batches_come_back_as_views_of_the_flat_arrays():
+    """the sampler writes every finished episode once, into its final rows of the meta-batch's flat arrays; the path
+    dicts are views of them and flatten_paths has nothing left to do -- field by field what the general route builds"""
+    from collections import OrderedDict
+    from promp_amd import _lib
+    from promp_amd.samplers.meta_sampler import HostPaths
+    M, B, T = 3, 4, 5
+    sampler = MetaSampler(FixedHorizonEnv(), EchoPolicy(M), rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T, envs_per_task=2)
+    sampler.update_tasks()
+    paths = sampler.obtain_samples()
+    assert isinstance(paths, HostPaths) and paths.flat is not None
+    plain = OrderedDict((i, [dict(observations=p['observations'].copy(), actions=p['actions'].copy(), rewards=p['rewards'].copy(),
+                                  env_infos=p['env_infos'], agent_infos={k: v.copy() for k, v in p['agent_infos'].items()})
+                             for p in plist]) for i, plist in paths.items())
+    fast, general = _lib.flatten_paths(paths), _lib.flatten_paths(plain)
+    assert fast is paths.flat
+    for key in general:
+        np.testing.assert_array_equal(fast[key], general[key], err_msg=key)
+        assert fast[key].dtype == general[key].dtype, key
+    first = paths[0][0]
+    assert np.shares_memory(first['observations'], fast['obs']) and np.shares_memory(paths[M - 1][-1]['agent_infos']['mean'], fast['old_mean'])
+    # in-place edits are seen (same memory) ...
+    first['rewards'][0] = 123.0
+    assert _lib.flatten_paths(paths)['rew'][0] == 123.0
+    # ... and a path whose array was REPLACED, or a dropped path, sends the batch down the general route
+    paths[1][0]['rewards'] = paths[1][0]['rewards'] + 1.0
+    again = _lib.flatten_paths(paths)
+    assert again is not paths.flat and again['rew'][B * T] == general['rew'][B * T] + 1.0
+    paths[1][0]['rewards'] = fast['rew'][B * T:B * T + T]          # (an equal view is still another object)
+    paths2 = sampler.obtain_samples()
+    paths2[2].pop()
+    assert _lib.flatten_paths(paths2) is not paths2.flat
+
+
+def test_early_terminations_take_the_general_route_unchanged():
+    M, B, T = 3, 2, 4
+    sampler = MetaSampler(CounterEnv(), EchoPolicy(M), rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
+    sampler.update_tasks()
+    paths = sampler.obtain_samples()
+    assert getattr(paths, 'flat', None) is None                     # task 1 ends its episodes after 3 steps and outgrows its share
+    assert [len(p['rewards']) for p in paths[1]] == [3, 3, 3, 3] and all(len(p['rewards']) == 4 for p in paths[0])
+
+
+def test_slab_backed_repoints_ordinary_path_dicts():
+    from promp_amd import _lib, synthetic
+    from promp_amd.samplers.meta_sampler import slab_backed
+    rng = np.random.RandomState(0)
+    theta = synthetic.init_theta(rng, 5, (8, 8), 2)
+    paths = synthetic.make_paths(rng, theta, 3, 2, 7, 5, 2, (8, 8))
+    general = _lib.flatten_paths(paths)
+    general = {k: (v.copy() if v is not None else None) for k, v in general.items()}
+    hp = slab_backed(paths)
+    fl = _lib.flatten_paths(hp)
+    assert fl is hp.flat
+    for key in general:
+        np.testing.assert_array_equal(fl[key], general[key], err_msg=key)

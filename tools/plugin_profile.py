@@ -41,7 +41,10 @@ def step(b0, b1):
     s1 = proc.process_samples(b1, log=False)
     algo.optimize_policy([s0, s1], log=False)
 
-for name, (b0, b1) in (('device_resident', dev), ('host_paths', (p0, p1))):
+from collections import OrderedDict
+from promp_amd.samplers.meta_sampler import slab_backed
+hp = [slab_backed(OrderedDict((i, [dict(p, agent_infos=dict(p['agent_infos'])) for p in pl]) for i, pl in px.items())) for px in (p0, p1)]
+for name, (b0, b1) in (('host_paths (HostPaths)', hp), ('host_paths (plain dicts)', (p0, p1))):
     for _ in range(2):
         step(b0, b1)
     t0 = time.perf_counter()
