@@ -249,6 +249,28 @@ def gen_promp():
         print('wrote promp_autograd_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
 
 
+# ---- full BASELINE sizes, by seed: only the OUTPUTS are stored (round 5) -------------------------------------------------------
+# The inputs of configs 3 and 4 (40 tasks x 20 paths x 200 steps; 42 / 130 MB) are regenerated from the seed by the same recipe
+# the tests use (tests/helpers.make_promp_case); the fixture holds what torch.autograd says about them: loss, KLs and the
+# Theta-sized meta-gradient.  The device result is compared at 2e-4 of the gradient's max-norm (tests/test_gpu_parity.py).
+FULL_CASES = {
+    'config3': dict(seed=3003, M=40, P=20, T=200, O=20, A=6, hidden=(64, 64), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1),
+    'config4': dict(seed=3004, M=40, P=20, T=200, O=111, A=8, hidden=(128, 128), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1),
+}
+
+
+def gen_promp_full():
+    sys.path.insert(0, ROOT)
+    from tests import helpers
+    for name, c in FULL_CASES.items():
+        theta, all_slabs, _ = helpers.make_promp_case(c['seed'], c['M'], c['P'], c['T'], c['O'], c['A'], tuple(c['hidden']), c['K'])
+        loss, ikl, okl, grad = torch_meta_objective(theta, all_slabs, c)
+        np.savez_compressed(os.path.join(GOLDEN, 'promp_full_%s.npz' % name), meta=json.dumps(c), loss=loss, inner_kl=ikl,
+                            outer_kl=okl, grad=grad, theta_checksum=float(np.sum(theta.astype(np.float64))),
+                            obs_checksum=float(np.sum(all_slabs[1][-1]['observations'].astype(np.float64))))
+        print('wrote promp_full_%s.npz  loss=%.6f |grad|=%.4e' % (name, loss, np.linalg.norm(grad)))
+
+
 # ---- E Adam epochs on the autograd gradient (tf.train.AdamOptimizer's update, transcribed) -------------------------------
 # optimizers/maml_first_order_optimizer.py:22-46,82-115: AdamOptimizer(lr).minimize(loss); E full-batch steps.  TF-1's update
 # (python/training/adam.py, _apply_dense): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); m += (1 - b1)(g - m); v += (1 - b2)(g^2 - v);
@@ -562,6 +584,9 @@ if __name__ == '__main__':
         gen_dice_proc(only=('retbase', 'retbase_raw'))
         gen_vpg_dice()
         sys.exit(0)
+    if '--full-only' in sys.argv:            # (round 5 additions only: the other fixtures stay byte-identical)
+        gen_promp_full()
+        sys.exit(0)
     if '--adam-only' in sys.argv:            # (round 4 additions only: the other fixtures stay byte-identical)
         gen_promp_adam()
         sys.exit(0)
@@ -569,6 +594,7 @@ if __name__ == '__main__':
         gen_sample_proc()
         gen_promp()
         gen_promp_adam()
+        gen_promp_full()
     gen_dist_reference()
     gen_point_env()
     gen_dice_proc()

@@ -3,7 +3,6 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC promp_hip.hip -lrccl -o libpromp_hip.so
 #include "promp_kernels_chain.h"
 #include "promp_kernels_pass.h"
-#include "promp_kernels_pass2.h"
 #include "promp_kernels_policy.h"
 #include "promp_kernels_policy_wide.h"
 #include "promp_kernels_wide_bf16.h"
@@ -134,7 +133,6 @@ struct promp_ctx {
     size_t rollout_capacity = 0;
     double* fit_scratch = nullptr;       // k_fit_wide: [tasks][2][(D+1)^2] when the matrices do not fit in LDS
     size_t smem_fwd = 0, smem_hvp = 0;
-    size_t smem_pair = 0;              // k_pass_pair (the (64, 64) first-order pass at two waves per SIMD); 0: not this shape
     bool wide = false;                   // cooperative kernels for hidden 128 / obs_dim > 32
     int wbf = 0;                         // hidden 128, obs_dim <= 127: the BF16-pipe cooperative kernels (promp_kernels_wide_bf16.h);
                                          // 1..3 = the observation class (NKO, NXB) = (4,2) (7,4) (8,4): obs_dim <= 63 / 111 / 127
@@ -493,12 +491,6 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
 #undef PROMP_CHAIN_CASE
         HIPCHECK(hipGetLastError());
         if (a.fuse_reduce) return prof_end(c, id);
-    } else if (c->smem_pair) {
-        // (64, 64): pairs of waves share a tile, two waves per SIMD (promp_kernels_pass2.h); segment table, partial rows and
-        // primal-cache blocks are k_pass's
-        if (fwd_only) { auto k = k_pass_pair<false, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 512, c->smem_pair, c->stream, a); }
-        else if (cache == 1) { auto k = k_pass_pair<true, true>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 512, c->smem_pair, c->stream, a); }
-        else { auto k = k_pass_pair<true, false>; PROMP_LAUNCH(k, dim3(S.n_chain_wg), 512, c->smem_pair, c->stream, a); }
     } else {
         const int n1 = c->d.hidden1 / 16, n2 = c->d.hidden2 / 16;
 #define PROMP_PASS_CASE(N1, N2)                                                                                                          \
@@ -854,20 +846,6 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         c->smem_hvp = sizeof(float) * (size_t)std::max(chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd)).total,
                                                        chain_layout(dims->hidden1 / 16, dims->hidden2 / 16, CHAIN_NW_HVP, true, param_count(&pd), true).total);
     }
-    // k_pass_pair (promp_kernels_pass2.h: the (64, 64) first-order pass at two waves per SIMD) is the MEASURED-SLOWER alternative
-    // (65 vs 62 us per launch); it stays selectable -- environment PROMP_PASS_PAIR=1 when the context is created,
-    // or a -DPROMP_PASS_PAIR=1 build -- and is covered by the parity tests
-#ifndef PROMP_PASS_PAIR
-#define PROMP_PASS_PAIR 0
-#endif
-    const char* pair_env = getenv("PROMP_PASS_PAIR");
-    const bool want_pair = pair_env ? atoi(pair_env) != 0 : PROMP_PASS_PAIR != 0;
-    if (want_pair && !c->wide && !c->generic && dims->hidden1 == 64 && dims->hidden2 == 64) {
-        promp_dims pd = *dims;
-        if (pd.obs_dim > 32) pd.obs_dim = 32;
-        c->smem_pair = sizeof(float) * (size_t)pass2_layout(param_count(&pd)).total;
-        if (c->smem_pair > 160 * 1024) c->smem_pair = 0;
-    }
     if (c->smem_hvp > 160 * 1024 || c->smem_fwd > 160 * 1024) {
         const size_t need = c->smem_hvp > c->smem_fwd ? c->smem_hvp : c->smem_fwd;
         promp_ctx_destroy(c);
@@ -892,12 +870,6 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     }
         PROMP_PASS_ALL(PROMP_PASS_ATTR)
 #undef PROMP_PASS_ATTR
-        {
-            auto p0 = k_pass_pair<true, false>; auto p1 = k_pass_pair<false, false>; auto p2 = k_pass_pair<true, true>;
-            HIPCHECK(hipFuncSetAttribute((const void*)p0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHECK(hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIPCHECK(hipFuncSetAttribute((const void*)p2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
 #define PROMP_WB_ATTR(CLS, NKO, NXB)                                                                                       \
     {                                                                                                                     \
         auto b0 = k_wb_fwd_bwd<NKO, NXB, true>; auto b1 = k_wb_fwd_bwd<NKO, NXB, false>; auto b2 = k_wb_hvp<NKO, NXB>;         \

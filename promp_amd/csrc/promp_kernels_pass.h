@@ -339,7 +339,6 @@ struct PassWalk {
     bool own0, own1;
     unsigned long long* dbg;     // developer tooling: cycle stamps (NULL unless a -DPROMP_DEV_STAMPS build asks for them)
     int tix;
-    unsigned m_ratio, m_clip, m_ll, m_kl;    // k_pass_pair: the objective kind as all-ones / zero bit masks
 };
 #ifdef PROMP_DEV_STAMPS
 #define PASS_STAMP(j) do { if (W.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) W.dbg[8 + 16 * (W.tix < 3 ? W.tix : 3) + (j)] = promp_clock(); } while (0)

@@ -53,6 +53,18 @@ def load_promp(name):
     return c, g['theta'], all_slabs, g
 
 
+def load_promp_full(name):
+    """-> (case dict, theta, all_slabs, all_paths, golden npz): the inputs of a full BASELINE config regenerated from the seed by
+    make_promp_case, the outputs torch.autograd computed on them (oracle/gen_golden.py: gen_promp_full)"""
+    g = np.load(os.path.join(GOLDEN, 'promp_full_%s.npz' % name))
+    c = json.loads(str(g['meta']))
+    theta, all_slabs, all_paths = make_promp_case(c['seed'], c['M'], c['P'], c['T'], c['O'], c['A'], tuple(c['hidden']), c['K'])
+    # the regenerated inputs are the ones the fixture was computed on (a NumPy whose RandomState streams differed would show here)
+    assert float(np.sum(theta.astype(np.float64))) == float(g['theta_checksum'])
+    assert float(np.sum(all_slabs[1][-1]['observations'].astype(np.float64))) == float(g['obs_checksum'])
+    return c, theta, all_slabs, all_paths, g
+
+
 def promp_adam_cases():
     return sorted(os.path.basename(p)[len('promp_adam_'):-4] for p in glob.glob(os.path.join(GOLDEN, 'promp_adam_*.npz')))
 

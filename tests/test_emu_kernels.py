@@ -40,10 +40,6 @@ def test_loss_grad_h64(lib):
     pc.check_loss_grad(lib, 7, M=2, P=2, T=37, O=20, A=6, hidden=(64, 64))
 
 
-def test_loss_grad_h64_pair_kernel(lib, monkeypatch):
-    # k_pass_pair (two waves per SIMD, pairs of waves share a tile: promp_kernels_pass2.h), opt-in through the environment
-    monkeypatch.setenv('PROMP_PASS_PAIR', '1')
-    pc.check_loss_grad(lib, 41, M=3, P=2, T=100, O=20, A=6, hidden=(64, 64), ragged=True)
 
 
 def test_loss_grad_workgroups_straddling_two_tasks(lib):

@@ -72,25 +72,6 @@ def test_split_gemm_accuracy_guard(lib, hidden, O, A):
     pc.check_split_accuracy(lib, hidden, O, A, meta_tol=1e-5 if hidden[0] == 128 else None)
 
 
-@pytest.fixture
-def pair_kernel(monkeypatch):
-    """contexts created inside the test run the (64, 64) first-order pass on k_pass_pair (two waves per SIMD; the measured-slower
-    alternative of k_pass, promp_kernels_pass2.h) -- read from the environment when a context is created"""
-    monkeypatch.setenv('PROMP_PASS_PAIR', '1')
-
-
-def test_pair_kernel_parity(lib, pair_kernel):
-    # objective / KL / gradient of every objective kind (ragged tasks, partial and null tiles, compact log_std), the whole
-    # meta-gradient + Adam epochs, the primal cache it fills for the second-order pass, the 2.5e-6 accuracy guard
-    pc.check_loss_grad(lib, 31, M=5, P=6, T=150, O=20, A=6, hidden=(64, 64), ragged=True)
-    pc.check_loss_grad(lib, 32, M=3, P=4, T=100, O=17, A=6, hidden=(64, 64), compact_log_std=True)
-    pc.check_loss_grad(lib, 33, M=2, P=3, T=90, O=32, A=8, hidden=(64, 64), ragged=True)
-    pc.check_meta(lib, 34, M=6, P=5, T=120, O=20, A=6, hidden=(64, 64), K=1, ragged=True)
-    pc.check_primal_cache(lib, 83, M=7, P=4, T=110, O=20, A=6, hidden=(64, 64), K=1)
-    pc.check_adapt_reuse(lib, 61, M=5, P=3, T=70, O=20, A=6, hidden=(64, 64))
-    pc.check_split_accuracy(lib, (64, 64), 20, 6)
-
-
 def test_unsupported_shapes_are_rejected(lib):
     for hidden, O, A in (((257, 64), 4, 2), ((0, 32), 4, 2), ((32, 32, 32, 32, 32), 4, 2), ((), 4, 2), ((32, 32), 4, 65), ((32, 32), 1025, 2)):
         with pytest.raises((_lib.PrompError, ValueError, TypeError)):
@@ -313,6 +294,29 @@ def test_full_config_meta_gradient_vs_oracle_and_determinism(config_full):
     np.testing.assert_allclose(st1['inner_kl'], r['inner_kl'], rtol=1e-3, atol=1e-9)
     np.testing.assert_allclose(st1['outer_kl'], r['outer_kl'], rtol=1e-3, atol=1e-9)
     assert pc.rel_max(g1, r['grad']) < 1e-3      # meta-gradient 1e-3 of its max-norm
+
+
+@pytest.mark.parametrize('name', ['config3', 'config4'])
+def test_full_config_meta_gradient_vs_torch_autograd_golden(lib, name):
+    """the dominant compute at FULL size against an independent authority -- torch.autograd on a transcription of the
+    TF graph (oracle/gen_golden.py: torch_meta_objective), inputs regenerated from the seed, outputs from the fixture.  2e-4 of the
+    gradient's max-norm; the measured error is printed (profiles/r05_full_size_parity.txt holds the MI355X's)."""
+    c, theta, all_slabs, all_paths, g = helpers.load_promp_full(name)
+    M, O, A, hidden = c['M'], c['O'], c['A'], tuple(c['hidden'])
+    ctx = pc.make_ctx(lib, M, O, A, hidden, c['K'], all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(np.full(ctx.n_params, c['alpha'], np.float32))
+    gd, st = ctx.meta_grad(c['clip_eps'], np.asarray(c['eta'], np.float32))
+    err = pc.rel_max(gd, g['grad'])
+    print('full-size parity %s: meta-gradient %.2e of its max-norm, loss %.2e rel, inner KL %.2e rel, outer KL %.2e rel' % (
+        name, err, abs(st['loss'] - float(g['loss'])) / abs(float(g['loss'])),
+        float(np.max(np.abs(st['inner_kl'] - g['inner_kl']) / np.abs(g['inner_kl']))), abs(st['outer_kl'] - float(g['outer_kl'])) / abs(float(g['outer_kl']))))
+    np.testing.assert_allclose(st['loss'], float(g['loss']), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st['inner_kl'], g['inner_kl'], rtol=2e-4)
+    np.testing.assert_allclose(st['outer_kl'], float(g['outer_kl']), rtol=2e-4)
+    assert err < 2e-4
+    ctx.close()
 
 
 def test_full_config_zero_advantages_give_zero_surrogate_gradient(config_full):

@@ -212,3 +212,14 @@ def test_hidden_nonlinearities_gradient_and_hvp_match_torch_autograd(act):
         r = pm.loss_and_grad(spec, t64, slab, kind, False)
         np.testing.assert_allclose(r['grad'], g.detach().numpy(), rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(pm.hvp(spec, t64, slab, v, kind, clip_log_std=False), hv.numpy(), rtol=1e-8, atol=1e-11)
+
+
+def test_full_size_golden_config3_matches_the_oracle():
+    """the full-size fixture (inputs by seed, outputs from torch.autograd) against the NumPy oracle at BASELINE config 3's size: the
+    two authorities of the GPU parity tests agree where the GPU is compared with them"""
+    c, theta, all_slabs, _, g = helpers.load_promp_full('config3')
+    spec = op.PolicySpec(c['O'], c['A'], tuple(c['hidden']))
+    r = pm.meta_objective_and_grad(spec, theta.astype(np.float64), all_slabs, np.full(spec.n_params, c['alpha']), np.array(c['eta']),
+                                   c['clip_eps'])
+    assert r['loss'] == pytest.approx(float(g['loss']), rel=1e-10)
+    np.testing.assert_allclose(r['grad'], g['grad'], rtol=1e-7, atol=1e-9 * np.max(np.abs(g['grad'])))
