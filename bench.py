@@ -287,7 +287,11 @@ def main():
                    'meta_batch_size': M_global, 'tasks_per_gpu': M, 'rows_per_task_per_step': N,
                    'env_steps_per_step': M_global * N * (K + 1), 'parallelism': 'task-sharded dp%d, RCCL all-reduce of the meta-gradient' % world,
                    'device': info['name'],
-                   'numerics': 'float32-equivalent: the first-order passes (k_pass) compute every GEMM, and the second-order pass '
+                   'numerics': ('float32-equivalent: 128-wide layers (k_wb_fwd_bwd, k_wb_hvp, promp_kernels_wide_bf16.h) compute every large GEMM as '
+                                '6 BF16 products of a 3-way error-compensated split with float32 accumulation (measured <= 1.7e-6 of the float64 '
+                                'oracle on gradient and Hessian-vector product, the exact-FP32 kernels\' own level; guarded by '
+                                'test_split_gemm_accuracy_guard); sample processing float64') if (hidden[0] == 128 and O <= 127) else
+                               'float32-equivalent: the first-order passes (k_pass) compute every GEMM, and the second-order pass '
                                '(k_chain_hvp) its layer 2, as 6 BF16 products of a 3-way error-compensated split with float32 '
                                'accumulation (measured <= 1.0e-6 of the float64 oracle, the FP32 fma chain\'s own level; a 3-product '
                                'build measures 5e-6 .. 5e-5; guarded at 2.5e-6 by test_split_gemm_accuracy_guard); the other GEMMs '
@@ -384,8 +388,10 @@ def main():
             iteration()
         fl = flops_per_row(O, hidden[0], hidden[1], A)
         kern = {}
-        hvp_name = 'k_chain_hvp' if (hidden[0] <= 64 and O <= 32) else 'k_wide_hvp'
-        pass_name = 'k_pass' if (hidden[0] <= 64 and O <= 32) else 'k_wide_fwd_bwd'
+        chain = hidden[0] <= 64 and O <= 32
+        wb = (not chain) and hidden[0] == 128 and O <= 127 and os.environ.get('PROMP_WIDE_FP32', '0') in ('', '0')   # promp_kernels_wide_bf16.h
+        hvp_name = 'k_chain_hvp' if chain else 'k_wb_hvp' if wb else 'k_wide_hvp'
+        pass_name = 'k_pass' if chain else 'k_wb_fwd_bwd' if wb else 'k_wide_fwd_bwd'
         for name, kid, f in ((pass_name, _lib.KERNEL_FWD_BWD, fl['fwd_bwd']), (hvp_name, _lib.KERNEL_HVP, fl['hvp']),
                              (pass_name + '<fwd-only>', _lib.KERNEL_FWD, fl['fwd'])):
             pr = ctx.prof_read(kid)

@@ -5,7 +5,9 @@ R=gpurun_out/round
 rm -rf $R && mkdir -p $R
 export TMPDIR=/tmp
 rocminfo | grep -E "Marketing Name|gfx" | head -4 > $R/device.txt 2>&1
-timeout 1200 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log; tail -3 $R/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q -s > $R/pytest_gpu_verbose.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu_verbose.log
+grep -E "passed|failed|pytest rc" $R/pytest_gpu_verbose.log > $R/pytest_gpu.log; grep -E "full-size parity|adam golden" $R/pytest_gpu_verbose.log > $R/full_size_parity.txt; cat $R/pytest_gpu.log $R/full_size_parity.txt; rm -f $R/pytest_gpu_verbose.log
+python tools/split_accuracy_gpu.py > $R/split_accuracy.txt 2>&1; PROMP_WIDE_FP32=1 python tools/split_accuracy_gpu.py 2>&1 | tail -2 | sed 's/^/exact-FP32 cooperative kernels (PROMP_WIDE_FP32=1): /' >> $R/split_accuracy.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log; tail -2 $R/smoke.log
 timeout 900 python bench.py > $R/bench.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench.json | head -c 400; echo
 ROOT=$GRAFT_REPO_ROOT
@@ -21,6 +23,10 @@ done
 timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 > $ROOT/$R/bench_config4.json 2> $ROOT/$R/bench_config4.err; echo "bench config4 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace4 -o trace4 -- python $ROOT/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-plugin-path > /dev/null 2> $ROOT/$R/trace4.err; echo "trace4 rc=$?"
 cd $ROOT; rm -f $R/trace4/*kernel_trace.csv
+# config 4 with the exact-FP32 cooperative kernels (the A/B of the BF16-pipe kernels, same box), cycle stamps, PMC counters
+PROMP_WIDE_FP32=1 timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-plugin-path > $ROOT/$R/bench_config4_fp32_kernels.json 2> /dev/null; echo "bench config4 fp32 rc=$?"
+bash tools/gpu_wb_stamps.sh 0,1 > $ROOT/$R/wb_stamps.txt 2>&1
+bash tools/gpu_pmc_config4.sh > /dev/null 2>&1; cp gpurun_out/pmc4/summary.txt $ROOT/$R/pmc_config4.txt
 # BASELINE config 5 (TRPO-MAML on config 3's shapes)
 timeout 600 python $ROOT/bench.py --config 5 --steps 5 --warmup 1 > $ROOT/$R/bench_config5.json 2> $ROOT/$R/bench_config5.err; echo "bench config5 rc=$?"
 # one rank's share of the fixed 40-task batch at 2 / 4 / 8 ranks, timed on this one GPU (no collective: kernels only)

@@ -17,7 +17,10 @@ for name, out in [('bench.json', '%s_bench.json'), ('pytest_gpu.log', '%s_pytest
                   ('trace/trace_domain_stats.csv', '%s_rocprofv3_domain_stats.csv'),
                   ('bench_config4.json', '%s_bench_config4.json'), ('bench_config5.json', '%s_bench_config5.json'),
                   ('shard_timings.txt', '%s_shard_timings.txt'), ('primal_cache_ab.txt', '%s_primal_cache_ab.txt'), ('h2d_overlap.txt', '%s_h2d_overlap.txt'), ('bench_staged.json', '%s_bench_staged_uploads.json'), ('timeline.txt', '%s_step_timeline.txt'), ('generic_shapes.txt', '%s_generic_shapes.txt'), ('stage_a.txt', '%s_stage_a.txt'),
-                  ('trace4/trace4_kernel_stats.csv', '%s_rocprofv3_kernel_stats_config4.csv')]:
+                  ('trace4/trace4_kernel_stats.csv', '%s_rocprofv3_kernel_stats_config4.csv'),
+                  ('full_size_parity.txt', '%s_full_size_parity.txt'), ('split_accuracy.txt', '%s_split_accuracy.txt'),
+                  ('bench_config4_fp32_kernels.json', '%s_bench_config4_fp32_kernels.json'), ('wb_stamps.txt', '%s_wb_kernels_phase_stamps.txt'),
+                  ('pmc_config4.txt', '%s_pmc_config4.txt')]:
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out % tag))
 def short_name(k):
@@ -52,9 +55,10 @@ for k, r in pmc.iterrows():
         traffic[short] = dict(fetch_size_kib=r['FETCH_SIZE'], write_size_kib=r['WRITE_SIZE'],
                               hbm_bytes_per_launch=(2.0 * r['FETCH_SIZE'] + r['WRITE_SIZE']) * 1024.0,
                               note='(2 x FETCH_SIZE + WRITE_SIZE) KiB; separate --pmc passes of bench.py --steps 3; gfx950 FETCH_SIZE x2 correction')
-        # matrix-pipe utilisation: busy cycles summed over the chip's 1024 SIMDs against the kernel's own cycles (GRBM_GUI_ACTIVE)
+        # matrix-pipe utilisation: busy cycles summed over the chip's 1024 SIMDs against the kernel's own cycles (GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs: k_pass 1.19 M per dispatch = 8 x the 148 k cycles of a 58 us launch)
         if r.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) == r.get('SQ_VALU_MFMA_BUSY_CYCLES', float('nan')) and r.get('GRBM_GUI_ACTIVE', 0) > 0:
-            traffic[short]['mfma_busy_frac'] = float(r['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024.0 * float(r['GRBM_GUI_ACTIVE']))
+            traffic[short]['mfma_busy_frac'] = float(r['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024.0 * float(r['GRBM_GUI_ACTIVE']) / 8.0)
             traffic[short]['valu_active_frac'] = float(r.get('SQ_ACTIVE_INST_VALU', float('nan'))) / float(r['SQ_WAVE_CYCLES']) if r.get('SQ_WAVE_CYCLES', 0) > 0 else None
 sys.path.insert(0, ROOT)
 import bench
