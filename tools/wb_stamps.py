@@ -18,17 +18,19 @@ ctx.process_samples(0, normalize_adv=True)
 fn = ctx.lib.cdll.promp_debug_phase_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
-names = {0: ['B0 (top)', 'req, L1, park', 'xput, xreq', 'B2', 'L2', 'L3p, stream_begin', 'B3', 'epilogue', 'B4', 'dW3,dH2,dz2,db2', 'B5', 'dH1 + dW2, dz1', '-', 'dW1'],
-         1: ['B0', 'xput, xreq, epi req', 'B1', 'F1 (L1 + tangent)', 'B2', 'F2 (L2 + tangent)', 'F3 means', 'B3', 'epilogue', 'B4', 'dW3, dH2, dz2, qz2', 'B5', 'chains + dW2', 'B6', 'qz1 store, dW1']}
+names = {0: ['B0 (top barrier)', 'row-data request, L1, park', 'xput, xreq', 'B2', 'L2', 'L3 partial, ring begin', 'B3', 'epilogue', 'B4',
+             'dW3, dH2, dz2, db2', 'B5', 'dH1 + dW2 fused, dz1', '-', 'dW1'],
+         1: ['B0, xput, xreq, row-data request', 'B1', 'F1 (layer 1 + tangent)', 'B2', 'F2 (layer 2 + tangent)', 'F3 (partial means)', 'B3',
+             'loss-level R-operator', 'B4', 'dW3, dH2, ndz2, qz2, db2', 'B5', 'backward chains + dW2', 'B6', 'qz1 store, dW1']}
 for hvp in (int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else '0').split(',')):
     for rep in range(3):
         buf = np.zeros(256 + 4096, np.uint64)
         rc = fn(ctx._h, 0, hvp, buf.ctypes.data_as(C.POINTER(C.c_uint64)))
         assert rc == 0, ctx.lib.cdll.promp_last_error()
     s = buf.astype(np.int64)[8:8 + 40]
-    n = int(np.max(np.nonzero(s)[0])) if s.any() else 0
-    nm = names.get(hvp) or ['p%d' % i for i in range(n)]
-    print('kernel', ('fwd_bwd', 'hvp')[hvp], ' round total', s[n] - s[0], 'cycles')
-    for i in range(min(n, len(nm))):
-        print('   %-20s %7d' % (nm[i], s[i + 1] - s[i]))
-    print('   extra stamps (cycles after stamp 0):', {i: int(s[i] - s[0]) for i in range(17, 40) if s[i]})
+    nm = names[hvp]
+    n = len(nm)
+    print('kernel', ('k_wb_fwd_bwd', 'k_wb_hvp')[hvp], ' second round of workgroup 0 (thread 0): %d cycles' % (s[n] - s[0]))
+    for i in range(n):
+        print('   %-34s %7d' % (nm[i], s[i + 1] - s[i]))
+    print('   finer stamps (cycles after the round\'s first):', {i: int(s[i] - s[0]) for i in range(17, 40) if s[i]})
