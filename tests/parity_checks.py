@@ -839,3 +839,30 @@ def check_vpg_dice(lib, name, tol=1e-4):
     grad_dice, _ = ctx.meta_grad(0.0, np.zeros(K, np.float32), _lib.INNER_DICE, _lib.OUTER_LOGLIK)
     assert rel_max(grad_dice, r['grad']) > 10 * tol
     ctx.close()
+
+
+def check_comm_info_and_exchange_timing(lib):
+    """what bench.py's `rccl` block is built from: promp_comm_info (ncclCommCount / ncclCommUserRank of the attached communicator, the
+    device's PCI bus id) and the PROMP_KERNEL_EXCHANGE profiling slot (HIP events around every exchange)"""
+    ctx = _lib.Context(2, 5, 3, (32, 32), 1, max_rows=64, max_paths=4, lib=lib)
+    info = ctx.comm_info()
+    assert info['nranks'] == 1 and info['rank'] == 0 and len(info['pci_bus_id']) >= 7
+    ctx.comm_init(0, 1, _lib.comm_unique_id(lib))
+    info = ctx.comm_info()
+    assert info['nranks'] == 1 and info['rank'] == 0 and not info['fixed_order']
+    ctx.comm_fixed_order(True)
+    assert ctx.comm_info()['fixed_order']
+    ctx.close()
+    # the exchange's events: E epochs + the statistics pass, each timed
+    theta, all_slabs, all_paths = helpers.make_promp_case(91, 2, 2, 16, 5, 3, (32, 32), 1)
+    ctx = pc.make_ctx(lib, 2, 5, 3, (32, 32), 1, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(np.full(ctx.n_params, 0.1, np.float32))
+    ctx.comm_init(0, 1, _lib.comm_unique_id(lib))
+    ctx.prof_enable(True)
+    ctx.optimize(3, 1e-3, 0.3, np.array([5e-4], np.float32))
+    ex = ctx.prof_read(_lib.KERNEL_EXCHANGE)
+    ctx.prof_enable(False)
+    assert ex['launches'] == 4 and ex['total_ms'] > 0
+    ctx.close()

@@ -196,6 +196,12 @@ def test_wide_hvp_ant_h128(lib):
     pc.check_hvp(lib, 24, M=1, P=1, T=45, O=111, A=8, hidden=(128, 128))            # 32-row rounds
 
 
+def test_wide_bf16_edge_shapes(lib, two_cus):
+    # k_wb_*: one action, a task of 33 rows (a full round + one row), obs_dim 64 (the second observation class starts here)
+    pc.check_loss_grad(lib, 27, M=2, P=1, T=33, O=64, A=1, hidden=(128, 128))
+    pc.check_hvp(lib, 28, M=1, P=1, T=33, O=64, A=1, hidden=(128, 128))
+
+
 def test_wide_hvp_h128_narrow_obs(lib):
     pc.check_hvp(lib, 25, M=1, P=2, T=20, O=20, A=6, hidden=(128, 128), ragged=True)
 
@@ -250,3 +256,7 @@ def test_trpo_e_maml_exploration_term(lib, two_cus):
 
 def test_trpo_maml_step(lib, two_cus):
     pc.check_trpo(lib, 17, M=2, P=1, T=16, O=4, A=2, hidden=(32, 32), cg_iters=1, max_backtracks=2)
+
+
+def test_comm_info_and_exchange_timing_on_a_one_rank_communicator(lib, two_cus):
+    pc.check_comm_info_and_exchange_timing(lib)

@@ -293,14 +293,16 @@ def test_full_config_meta_gradient_vs_oracle_and_determinism(config_full):
     np.testing.assert_allclose(st1['loss'], r['loss'], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(st1['inner_kl'], r['inner_kl'], rtol=1e-3, atol=1e-9)
     np.testing.assert_allclose(st1['outer_kl'], r['outer_kl'], rtol=1e-3, atol=1e-9)
-    assert pc.rel_max(g1, r['grad']) < 1e-3      # meta-gradient 1e-3 of its max-norm
+    # BASELINE.md 3.5 allows the meta-gradient 1e-3 of its max-norm; measured at full size against the torch goldens: 1e-6
+    # (test_full_config_meta_gradient_vs_torch_autograd_golden); held to 1e-4 here (inputs processed on the device)
+    assert pc.rel_max(g1, r['grad']) < 1e-4
 
 
 @pytest.mark.parametrize('name', ['config3', 'config4'])
 def test_full_config_meta_gradient_vs_torch_autograd_golden(lib, name):
     """the dominant compute at FULL size against an independent authority -- torch.autograd on a transcription of the
-    TF graph (oracle/gen_golden.py: torch_meta_objective), inputs regenerated from the seed, outputs from the fixture.  2e-4 of the
-    gradient's max-norm; the measured error is printed (profiles/r05_full_size_parity.txt holds the MI355X's)."""
+    TF graph (oracle/gen_golden.py: torch_meta_objective), inputs regenerated from the seed, outputs from the fixture.  Held to 2e-5 of
+    the gradient's max-norm; measured on the MI355X: 9.9e-7 (config 3), 1.0e-6 (config 4) -- profiles/r05_full_size_parity.txt."""
     c, theta, all_slabs, all_paths, g = helpers.load_promp_full(name)
     M, O, A, hidden = c['M'], c['O'], c['A'], tuple(c['hidden'])
     ctx = pc.make_ctx(lib, M, O, A, hidden, c['K'], all_paths)
@@ -312,10 +314,10 @@ def test_full_config_meta_gradient_vs_torch_autograd_golden(lib, name):
     print('full-size parity %s: meta-gradient %.2e of its max-norm, loss %.2e rel, inner KL %.2e rel, outer KL %.2e rel' % (
         name, err, abs(st['loss'] - float(g['loss'])) / abs(float(g['loss'])),
         float(np.max(np.abs(st['inner_kl'] - g['inner_kl']) / np.abs(g['inner_kl']))), abs(st['outer_kl'] - float(g['outer_kl'])) / abs(float(g['outer_kl']))))
-    np.testing.assert_allclose(st['loss'], float(g['loss']), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(st['inner_kl'], g['inner_kl'], rtol=2e-4)
-    np.testing.assert_allclose(st['outer_kl'], float(g['outer_kl']), rtol=2e-4)
-    assert err < 2e-4
+    np.testing.assert_allclose(st['loss'], float(g['loss']), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(st['inner_kl'], g['inner_kl'], rtol=2e-5)
+    np.testing.assert_allclose(st['outer_kl'], float(g['outer_kl']), rtol=2e-5)
+    assert err < 2e-5
     ctx.close()
 
 
@@ -338,6 +340,22 @@ def test_split_reduce_allreduce_adam_equals_fused_launch(lib):
     pc.check_split_path_equals_fused(lib, 73, M=3, P=3, T=50, O=20, A=6, hidden=(48, 20), epochs=2, attach_comm=True)
     # the fixed-order exchange (ncclAllGather on the one-rank communicator + k_sum_ranks): the same bits again
     pc.check_split_path_equals_fused(lib, 74, M=5, P=4, T=90, O=20, A=6, hidden=(64, 64), attach_comm=True, fixed_order=True)
+
+
+@pytest.mark.parametrize('O,A,T,ragged', [(1, 1, 33, False), (63, 8, 31, True), (64, 3, 65, True), (111, 8, 1, False), (112, 2, 64, False),
+                                         (127, 8, 40, True), (128, 8, 40, False)])
+def test_bf16_cooperative_kernels_edge_shapes(lib, O, A, T, ragged):
+    """k_wb_fwd_bwd / k_wb_hvp (two layers of 128 units) at the edges of their observation classes (obs_dim 63 | 64, 111 | 112, 127;
+    128 falls back to the exact-FP32 kernels), one and eight actions, tasks of 1 ... 130 rows (rounds of 32: partial, exact, one over),
+    compact log_std, an active min_std clip"""
+    pc.check_loss_grad(lib, 201 + O, M=3, P=2, T=T, O=O, A=A, hidden=(128, 128), ragged=ragged)
+    pc.check_loss_grad(lib, 202 + O, M=2, P=1, T=T, O=O, A=A, hidden=(128, 128), compact_log_std=True, low_log_std=True, min_std=0.5)
+    pc.check_hvp(lib, 203 + O, M=3, P=2, T=T, O=O, A=A, hidden=(128, 128), ragged=ragged)
+    pc.check_meta(lib, 204 + O, M=2, P=2, T=max(T, 8), O=O, A=A, hidden=(128, 128), K=2, ragged=ragged, epochs=1)
+
+
+def test_comm_info_and_exchange_timing_on_a_one_rank_communicator(lib):
+    pc.check_comm_info_and_exchange_timing(lib)
 
 
 def test_trpo_maml_step_with_exact_constraint_hvp(lib):

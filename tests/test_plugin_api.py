@@ -728,3 +728,38 @@ def test_hidden_nonlinearity_argument_is_honoured_or_refused(emu):
         pol.session._drop()
     with pytest.raises(_lib.PrompError, match='unsupported'):
         MetaGaussianMLPPolicy(name='p', obs_dim=4, action_dim=2, meta_batch_size=2, hidden_sizes=(16, 16), hidden_nonlinearity='elu')
+
+
+def test_host_paths_give_process_samples_the_same_results_as_plain_dicts(emu):
+    """path dicts that are views of the flat page-locked arrays (what MetaSampler.obtain_samples returns for a
+    fixed-horizon environment) against the same batch as independent arrays -- every field of every task's samples data, the
+    per-path side effect and the baseline coefficients are equal, and the fast route did not concatenate anything"""
+    from collections import OrderedDict
+    from promp_amd import synthetic
+    from promp_amd.baselines.linear_baseline import LinearFeatureBaseline
+    from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
+    from promp_amd.samplers.meta_sampler import HostPaths, slab_backed
+    rng = np.random.RandomState(7)
+    M, P, T, O, A = 3, 4, 12, 5, 2
+    theta = synthetic.init_theta(rng, O, (8, 8), A)
+    plain = synthetic.make_paths(rng, theta, M, P, T, O, A, (8, 8))
+    copy = OrderedDict((i, [dict(observations=p['observations'].copy(), actions=p['actions'].copy(), rewards=p['rewards'].copy(),
+                                 env_infos={}, agent_infos={k: v.copy() for k, v in p['agent_infos'].items()}) for p in pl])
+                       for i, pl in plain.items())
+    fast = slab_backed(copy)
+    assert isinstance(fast, HostPaths) and fast.flat_if_intact() is fast.flat
+    kw = dict(discount=0.97, gae_lambda=0.9, normalize_adv=True)
+    pa, pb = MetaSampleProcessor(baseline=LinearFeatureBaseline(), **kw), MetaSampleProcessor(baseline=LinearFeatureBaseline(), **kw)
+    out_plain, out_fast = pa.process_samples(plain), pb.process_samples(fast)
+    for a, b in zip(out_plain, out_fast):
+        assert set(a.keys()) == set(b.keys())
+        for key in ('observations', 'actions', 'rewards', 'returns', 'advantages', 'adj_avg_rewards'):
+            np.testing.assert_array_equal(np.asarray(a[key]), np.asarray(b[key]), err_msg=key)
+        for key in ('mean', 'log_std'):
+            np.testing.assert_array_equal(a['agent_infos'][key], b['agent_infos'][key])
+    for i in range(M):
+        for p, q in zip(plain[i], fast[i]):
+            np.testing.assert_array_equal(p['returns'], q['returns'])
+            np.testing.assert_array_equal(p['advantages'], q['advantages'])
+    np.testing.assert_array_equal(pa.baseline.get_param_values(), pb.baseline.get_param_values())
+    assert np.shares_memory(out_fast[0]['observations'], fast.flat['obs'])       # the samples data are views of the same arrays
