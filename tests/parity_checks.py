@@ -855,7 +855,7 @@ def check_comm_info_and_exchange_timing(lib):
     ctx.close()
     # the exchange's events: E epochs + the statistics pass, each timed
     theta, all_slabs, all_paths = helpers.make_promp_case(91, 2, 2, 16, 5, 3, (32, 32), 1)
-    ctx = pc.make_ctx(lib, 2, 5, 3, (32, 32), 1, all_paths)
+    ctx = make_ctx(lib, 2, 5, 3, (32, 32), 1, all_paths)
     helpers.upload_slabs(ctx, all_paths, all_slabs)
     ctx.set_theta(theta)
     ctx.set_step_sizes(np.full(ctx.n_params, 0.1, np.float32))
