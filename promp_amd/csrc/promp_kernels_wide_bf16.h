@@ -236,6 +236,15 @@ PROMP_DEV void wb_store_own(float* tile, const f32x16& v, int j, int h, int w) {
         for (int t = 0; t < 3; ++t) sts_w2(tile + t * WB_PLANE + off, w0[t], w1[t]);
     }
 }
+// one register quad of a D fragment (units 32 w + 8 g + 4 h + i of sample j) -> the three planes
+PROMP_DEV void wb_store_quad(float* tile, float v0, float v1, float v2, float v3, int j, int h, int w, int g) {
+    unsigned w0[3], w1[3];
+    bf16_split3_pair(v0, v1, w0);
+    bf16_split3_pair(v2, v3, w1);
+    const int off = wb_chunk(j, 8 * w + 2 * g + h);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) sts_w2(tile + t * WB_PLANE + off, w0[t], w1[t]);
+}
 // a D fragment parked in / fetched from a wave-private, lane-linear LDS block (16-byte accesses, conflict-free)
 PROMP_DEV void wb_park(float* blk, const f32x16& v, int lane) {
 #pragma unroll
@@ -318,6 +327,28 @@ PROMP_DEV void wb_xreq(WbX<NKO>& X, const float* obs, long long row0, int nrows,
         for (int i = 0; i < 4; ++i) {
             const int o = 4 * c + i;
             X.v[it][i] = rbase[ro + (unsigned)(o < O ? o : O - 1)];
+        }
+    }
+}
+template <int NKO>
+PROMP_DEV void wb_xput_one(float* Xs, const WbX<NKO>& X, int it, int nrows, int O, int OC, int tid) {
+    const int s = tid >> 3;
+    const float rowm = s < nrows ? 1.f : 0.f;
+    {
+        const int c = (tid & 7) + 8 * it;
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 4 * c + i;
+            x[i] = (o == OC) ? 1.f : (o < O) ? rowm * X.v[it][i] : 0.f;
+        }
+        unsigned w0[3], w1[3];
+        bf16_split3_pair(x[0], x[1], w0);
+        bf16_split3_pair(x[2], x[3], w1);
+        if (c < WbX<NKO>::CPR) {
+            const int off = wb_chunk(s, c);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) sts_w2(Xs + t * WB_PLANE + off, w0[t], w1[t]);
         }
     }
 }
@@ -527,10 +558,24 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
             emo = a.old_mean[n * A + qq];
             eso = olsp[qq];
         }
-        // ---- layer 1: H1 = tanh(W1^T X^T + b1), own units
+        // ---- layer 1: H1 = tanh(W1^T X^T + b1), own units.  The NEXT round's observations (requested a round ago, in registers) are
+        //      split into the other observation tile chunk by chunk among the chain's products: vector work in the matrix
+        //      instructions' shadow (it used to run behind the layer: 2.2 k of a round's 21.7 k cycles)
         {
             f32x16 c0 = wb_bias16(b1s, h, w);
-            wb_chain<NKO>(c0, w1p, Xs, j, h);
+            u32x4 fb[3];
+            wb_read_b(fb, Xs, j, h, 0);
+#pragma unroll
+            for (int q = 0; q < NKO; ++q) {
+                u32x4 fn[3];
+                if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
+                if (q < WbX<NKO>::IT) wb_xput_one<NKO>(Xn, X, q, wk.row_end - base - R, O, OC, tid);
+                wb_mma6(c0, w1p[q], fb);
+                if (q + 1 < NKO) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) c0[r] = fast_tanh(c0[r]);
             wb_store_own(H1s, c0, j, h, w);
@@ -542,9 +587,8 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         }
         sched_fence();
         WB_STAMP(2);
-        // ---- the next round's observations (requested a round ago) -> the other tile; the round after that is requested
-        wb_xput<NKO>(Xn, X, wk.row_end - base - R, O, OC, tid);
         WB_STAMP(21);
+        // ---- the round after the next is requested
         wb_xreq<NKO>(X, a.obs, (long long)base + 2 * R, wk.row_end - base - 2 * R, O, tid);
         WB_STAMP(3);
         __syncthreads();
@@ -962,8 +1006,10 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         // ---- layer 1 and its tangent:  Rz1 = vW1^T x + vb1
         f32x16 rh1v;
         {
+            // the primal chain first (theta's planes), then the tangent chain (the direction's planes) with the primal's tanh, plane split
+            // and stores quad by quad among its products: vector work in the matrix instructions' shadow instead of behind them
             f32x16 h1v;
-            f32x16 cz = wb_bias16(b1s, h, w), cr = wb_bias16(vb1s, h, w);
+            f32x16 cz = wb_bias16(b1s, h, w);
             u32x4 fb[3];
             wb_read_b(fb, Xs, j, h, 0);
 #pragma unroll
@@ -971,8 +1017,32 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 u32x4 fn[3];
                 if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
                 sched_fence();
-                wb_mma6_two(cz, cr, GT.r[q % WB_PF], GV.r[q % WB_PF], fb);
+                wb_mma6(cz, GT.r[q % WB_PF], fb);
                 wb_ring_next(GT, PTz, NKO, PTz + oC2, 8, w, lane, q);
+                sched_fence();
+                if (q + 1 < NKO) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+                }
+            }
+            f32x16 cr = wb_bias16(vb1s, h, w);
+            wb_read_b(fb, Xs, j, h, 0);
+#pragma unroll
+            for (int q = 0; q < NKO; ++q) {
+                u32x4 fn[3];
+                if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
+                if (q < 4) {
+                    const int g = q;
+                    f32x4 hq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        hq[i] = fast_tanh(cz[4 * g + i]);
+                        h1v[4 * g + i] = hq[i];
+                    }
+                    wb_store_quad(H1s, hq[0], hq[1], hq[2], hq[3], j, h, w, g);
+                    sts4(D1p + 256 * g + 4 * lane, hq);
+                }
+                wb_mma6(cr, GV.r[q % WB_PF], fb);
                 wb_ring_next(GV, PVz, NKO, PVz + oC2, 8, w, lane, q);
                 sched_fence();
                 if (q + 1 < NKO) {
@@ -981,14 +1051,8 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float hv = fast_tanh(cz[r]);
-                h1v[r] = hv;
-                rh1v[r] = (1.f - hv * hv) * cr[r];
-            }
-            wb_store_own(H1s, h1v, j, h, w);
+            for (int r = 0; r < 16; ++r) rh1v[r] = (1.f - h1v[r] * h1v[r]) * cr[r];
             wb_store_own(RH1s, rh1v, j, h, w);
-            wb_park(D1p, h1v, lane);
         }
         sched_fence();
         WB_STAMP(3);
