@@ -349,9 +349,10 @@ def test_bf16_cooperative_kernels_edge_shapes(lib, O, A, T, ragged):
     128 falls back to the exact-FP32 kernels), one and eight actions, tasks of 1 ... 130 rows (rounds of 32: partial, exact, one over),
     compact log_std, an active min_std clip"""
     pc.check_loss_grad(lib, 201 + O, M=3, P=2, T=T, O=O, A=A, hidden=(128, 128), ragged=ragged)
-    pc.check_loss_grad(lib, 202 + O, M=2, P=1, T=T, O=O, A=A, hidden=(128, 128), compact_log_std=True, low_log_std=True, min_std=0.5)
-    pc.check_hvp(lib, 203 + O, M=3, P=2, T=T, O=O, A=A, hidden=(128, 128), ragged=ragged)
-    pc.check_meta(lib, 204 + O, M=2, P=2, T=max(T, 8), O=O, A=A, hidden=(128, 128), K=2, ragged=ragged, epochs=1)
+    pc.check_hvp(lib, 203 + O, M=2, P=2, T=T, O=O, A=A, hidden=(128, 128), ragged=ragged)
+    if O == 64:        # (the composite once: two inner steps, compact log_std with an active clip)
+        pc.check_loss_grad(lib, 202 + O, M=2, P=1, T=T, O=O, A=A, hidden=(128, 128), compact_log_std=True, low_log_std=True, min_std=0.5)
+        pc.check_meta(lib, 204 + O, M=2, P=2, T=T, O=O, A=A, hidden=(128, 128), K=2, ragged=ragged, epochs=1)
 
 
 def test_comm_info_and_exchange_timing_on_a_one_rank_communicator(lib):
