@@ -9,6 +9,7 @@
 #include "promp_kernels_sample.h"
 #include "promp_kernels_rollout.h"
 #include "promp_kernels_generic.h"
+#include "promp_kernels_generic_bf16.h"
 #include "../../include/promp_hip.h"
 
 #include <algorithm>
@@ -141,6 +142,10 @@ struct promp_ctx {
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
     bool generic = false;
+    bool gen_bf16 = true;                // their GEMMs on the BF16 matrix pipe (promp_kernels_generic_bf16.h); PROMP_GEN_FP32=1: the exact-FP32 kernels (A/B runs)
+    unsigned short *gb_wplanes = nullptr, *gb_vplanes = nullptr;   // [tasks][gb_plane_stride]: k_gb_planes' output for theta / minus the direction
+    long long gb_plane_stride = 0;
+    int gb_pf_off[GEN_MAX_LIN] = {}, gb_pb_off[GEN_MAX_LIN] = {};
     int n_lin = 0, g_maxw = 0;
     GenLin lin[GEN_MAX_LIN];
     float *g_act[GEN_MAX_LIN] = {}, *g_ract[GEN_MAX_LIN] = {}, *g_mu = nullptr, *g_rmu = nullptr, *g_dz[2] = {}, *g_qz[2] = {};
@@ -370,29 +375,62 @@ int launch_pass_generic(promp_ctx* c, StepData& S, const PassArgs& a, bool hvp, 
     g.loss_kind = a.loss_kind; g.clip_eps = a.clip_eps; g.clip_log_std = a.clip_log_std; g.min_log_std = a.min_log_std;
     g.kl_weight = a.kl_weight; g.row_tan = a.row_tan;
     const dim3 grid(S.n_work[0]);
-    // k_gen_linear: the 64-row rounds of a work item (about one CU's share of the rows) dealt to GEN_SPLIT workgroups
+    // k_gen_linear / k_gb_linear: the 64-row rounds of a work item (about one CU's share of the rows) dealt to GEN_SPLIT workgroups
     const dim3 lgrid(S.n_work[0], GEN_SPLIT);
     hipStream_t st = c->stream;
+    const bool bf = c->gen_bf16;
+    if (bf) {
+        // the parameters' (and minus the direction's) kernels as BF16 planes, both orientations, in the GEMMs' chunk order
+        GbPlaneArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.n_lin = c->n_lin;
+        int most = 0;
+        for (int l = 0; l < c->n_lin; ++l) {
+            pa.lin[l] = c->lin[l]; pa.pf_off[l] = c->gb_pf_off[l]; pa.pb_off[l] = c->gb_pb_off[l];
+            g.pf_off[l] = c->gb_pf_off[l]; g.pb_off[l] = c->gb_pb_off[l];
+            const int oct = (int)(gb_f_elems(c->lin[l].K, c->lin[l].N) / 24);
+            most = oct > most ? oct : most;
+        }
+        const int gx = (most + 255) / 256 < 16 ? (most + 255) / 256 : 16;
+        pa.src = a.theta; pa.src_task_stride = a.theta_task_stride; pa.dst = c->gb_wplanes;
+        pa.dst_task_stride = a.theta_task_stride ? c->gb_plane_stride : 0; pa.sign = 1.f;
+        PROMP_LAUNCH(k_gb_planes, dim3(gx, 2 * c->n_lin, a.theta_task_stride ? c->d.n_tasks : 1), 256, 0, st, pa);
+        g.wplanes = c->gb_wplanes; g.wplane_stride = pa.dst_task_stride;
+        if (hvp) {
+            pa.src = a.vdir; pa.src_task_stride = c->NP; pa.dst = c->gb_vplanes; pa.dst_task_stride = c->gb_plane_stride; pa.sign = -1.f;
+            PROMP_LAUNCH(k_gb_planes, dim3(gx, 2 * c->n_lin, c->d.n_tasks), 256, 0, st, pa);
+            g.vplanes = c->gb_vplanes; g.vplane_stride = c->gb_plane_stride;
+        }
+    }
     for (int li = 0; li < c->n_lin; ++li) {
         const int nbw = (c->lin[li].N + 63) / 64;
         PROMP_GEN_NBW(nbw,
-            if (hvp) { auto k = k_gen_linear<GEN_FWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_FWD_T, NBW), st, g, li, 0); }
+            if (bf) {
+                if (hvp) { auto k = k_gb_linear<GEN_FWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gb_smem(2, NBW), st, g, li, 0); }
+                else { auto k = k_gb_linear<GEN_FWD, NBW>; PROMP_LAUNCH(k, lgrid, 256, gb_smem(1, NBW), st, g, li, 0); }
+            } else if (hvp) { auto k = k_gen_linear<GEN_FWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_FWD_T, NBW), st, g, li, 0); }
             else { auto k = k_gen_linear<GEN_FWD, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_FWD, NBW), st, g, li, 0); })
     }
-    if (hvp) { auto k = k_gen_loss<true, true>; PROMP_LAUNCH(k, grid, 256, 0, st, g, 0); }
-    else if (fwd_only) { auto k = k_gen_loss<false, false>; PROMP_LAUNCH(k, grid, 256, 0, st, g, 0); }
-    else { auto k = k_gen_loss<false, true>; PROMP_LAUNCH(k, grid, 256, 0, st, g, 0); }
+    if (hvp) { auto k = k_gen_loss<true, true>; PROMP_LAUNCH(k, grid, 256, gen_loss_smem(g.A), st, g, 0); }
+    else if (fwd_only) { auto k = k_gen_loss<false, false>; PROMP_LAUNCH(k, grid, 256, gen_loss_smem(g.A), st, g, 0); }
+    else { auto k = k_gen_loss<false, true>; PROMP_LAUNCH(k, grid, 256, gen_loss_smem(g.A), st, g, 0); }
     int pp = 0;
     for (int li = c->n_lin - 1; li >= 0 && !fwd_only; --li) {
         const int nbw = (c->lin[li].N + 63) / 64;
         const dim3 wgrid(S.n_work[0], (c->lin[li].K + GEN_KC - 1) / GEN_KC);     // one slab of 64 input units per workgroup
         PROMP_GEN_NBW(nbw,
-            if (hvp) { auto k = k_gen_wgrad<2, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(2, c->lin[li].N), st, g, li, pp); }
+            if (bf) {
+                if (hvp) { auto k = k_gb_wgrad<2, NBW>; PROMP_LAUNCH(k, wgrid, 256, gb_smem(2, NBW), st, g, li, pp); }
+                else { auto k = k_gb_wgrad<1, NBW>; PROMP_LAUNCH(k, wgrid, 256, gb_smem(1, NBW), st, g, li, pp); }
+            } else if (hvp) { auto k = k_gen_wgrad<2, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(2, c->lin[li].N), st, g, li, pp); }
             else { auto k = k_gen_wgrad<1, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(1, c->lin[li].N), st, g, li, pp); })
         if (li == 0) break;
         const int nbk = (c->lin[li].K + 63) / 64;
         PROMP_GEN_NBW(nbk,
-            if (hvp) { auto k = k_gen_linear<GEN_BWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_BWD_T, NBW), st, g, li, pp); }
+            if (bf) {
+                if (hvp) { auto k = k_gb_linear<GEN_BWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gb_smem(2, NBW), st, g, li, pp); }
+                else { auto k = k_gb_linear<GEN_BWD, NBW>; PROMP_LAUNCH(k, lgrid, 256, gb_smem(1, NBW), st, g, li, pp); }
+            } else if (hvp) { auto k = k_gen_linear<GEN_BWD_T, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_BWD_T, NBW), st, g, li, pp); }
             else { auto k = k_gen_linear<GEN_BWD, NBW>; PROMP_LAUNCH(k, lgrid, 256, gen_linear_smem(GEN_BWD, NBW), st, g, li, pp); })
         pp ^= 1;
     }
@@ -823,6 +861,11 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
             if (out > c->g_maxw) c->g_maxw = out;
             in = out;
         }
+        { const char* e = getenv("PROMP_GEN_FP32"); if (e && e[0] == '1') c->gen_bf16 = false; }
+        for (int l = 0; l < c->n_lin; ++l) {
+            c->gb_pf_off[l] = (int)c->gb_plane_stride; c->gb_plane_stride += gb_f_elems(c->lin[l].K, c->lin[l].N);
+            c->gb_pb_off[l] = (int)c->gb_plane_stride; c->gb_plane_stride += gb_b_elems(c->lin[l].K, c->lin[l].N);
+        }
     } else if (c->wide) {
         const int nob = dims->obs_dim <= 32 ? 2 : dims->obs_dim <= 64 ? 4 : 8;
         c->smem_fwd = sizeof(float) * (size_t)make_layout_wide(dims->hidden1, 4, nob, false).total;
@@ -914,9 +957,24 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         HIPCHECK(hipFuncSetAttribute((const void*)l3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
         HIPCHECK(hipFuncSetAttribute((const void*)w1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
         HIPCHECK(hipFuncSetAttribute((const void*)w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        auto bw1 = k_gb_wgrad<1, NBW>; auto bw2 = k_gb_wgrad<2, NBW>;                                                 \
+        auto b0 = k_gb_linear<GEN_FWD, NBW>; auto b1 = k_gb_linear<GEN_FWD_T, NBW>;                                   \
+        auto b2 = k_gb_linear<GEN_BWD, NBW>; auto b3 = k_gb_linear<GEN_BWD_T, NBW>;                                   \
+        HIPCHECK(hipFuncSetAttribute((const void*)b0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)b1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)b2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)b3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        HIPCHECK(hipFuncSetAttribute((const void*)bw1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
+        HIPCHECK(hipFuncSetAttribute((const void*)bw2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));     \
     }
         PROMP_GEN_ATTR(1) PROMP_GEN_ATTR(2) PROMP_GEN_ATTR(3) PROMP_GEN_ATTR(4)
 #undef PROMP_GEN_ATTR
+        {
+            auto s0 = k_gen_loss<true, true>; auto s1 = k_gen_loss<false, true>; auto s2 = k_gen_loss<false, false>;
+            HIPCHECK(hipFuncSetAttribute((const void*)s0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gen_loss_smem(GEN_MAX_A)));
+            HIPCHECK(hipFuncSetAttribute((const void*)s1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gen_loss_smem(GEN_MAX_A)));
+            HIPCHECK(hipFuncSetAttribute((const void*)s2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gen_loss_smem(GEN_MAX_A)));
+        }
         {
             auto fw32 = k_fit_wide<32>; auto fw16 = k_fit_wide<16>;
             HIPCHECK(hipFuncSetAttribute((const void*)fw32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -949,6 +1007,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         }
         rc |= dev_alloc(&c->g_mu, R * dims->act_dim); rc |= dev_alloc(&c->g_rmu, R * dims->act_dim);
         for (int i = 0; i < 2; ++i) { rc |= dev_alloc(&c->g_dz[i], R * c->g_maxw); rc |= dev_alloc(&c->g_qz[i], R * c->g_maxw); }
+        if (c->gen_bf16) { rc |= dev_alloc(&c->gb_wplanes, (size_t)M * c->gb_plane_stride); rc |= dev_alloc(&c->gb_vplanes, (size_t)M * c->gb_plane_stride); }
     }
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
@@ -977,7 +1036,7 @@ void promp_ctx_destroy(promp_ctx* c) {
             if (S.ev_done) (void)hipEventDestroy(S.ev_done);
             if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
         }
-    void* ptrs[] = {c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    void* ptrs[] = {c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)

@@ -60,6 +60,10 @@ struct GenArgs {
     float kl_weight;
     float* row_tan;
     int act_kind;                      // hidden nonlinearity: GEN_ACT_TANH / _RELU / _IDENTITY (policies/networks/mlp.py:47 takes any)
+    // the BF16 plane copies of the parameters / of minus the direction (promp_kernels_generic_bf16.h: k_gb_planes), 16-bit elements
+    const unsigned short *wplanes, *vplanes;
+    long long wplane_stride, vplane_stride;        // per task (0: one copy for all tasks)
+    int pf_off[GEN_MAX_LIN], pb_off[GEN_MAX_LIN];  // a layer's forward / backward plane block
 };
 
 enum { GEN_FWD = 0, GEN_FWD_T = 1, GEN_BWD = 2, GEN_BWD_T = 3 };
@@ -366,81 +370,106 @@ PROMP_DEV float gen_block_sum(float v, float* red, int tid) {
 // k_gen_loss: objective / KL of the work item's rows, the cotangents of the means (-> dz[pp], [rows][A]) and the log_std gradient;
 // one thread per row, the row's actions in a loop.  HVP: also the tangents along u = -v (-> qz[pp]) and R'{d objective / d s},
 // with kl_weight x the KL cotangents joined in (k_chain_hvp's loss level).  Writes P[oS .. oS + A), P[NP], P[NP + 1].
-// grid = work items, block = 256.
+// What depends on the action only (the clipped log_std, its exponentials, the direction's entry; the old distribution's when it is
+// per task) is tabulated in LDS once per workgroup.  The rows' log_std terms go through an LDS tile [256][A | 1], 256 rows at a
+// time, and are summed per action by 4 x 64 threads (thread (q, j): rows q, q + 4, ... in row order; the four parts combined in
+// fixed order at the end) -- until round 5 they went through global memory and A threads walked all rows of the work item one
+// after the other: that tail was most of the kernel (46 us at 312 rows x 6 actions, 189 us at 625 x 17).
+// grid = work items, block = 256, smem = gen_loss_smem(A).
+#define GEN_LOSS_NC 8          // per-action constants
+PROMP_HD size_t gen_loss_smem(int A) { return sizeof(float) * (size_t)(256 * (A | 1) + GEN_LOSS_NC * GEN_MAX_A + 4 * GEN_MAX_A); }
 template <bool HVP, bool BWD>
 __global__ void __launch_bounds__(256) k_gen_loss(GenArgs a, int pp) {
+    PROMP_SMEM_DECL;
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const WorkItem wk = a.work[blockIdx.x];
-    const int A = a.A, NP = a.NP, oS = NP - A;
+    const int A = a.A, NP = a.NP, oS = NP - A, AS = A | 1;
+    float* T = (float*)PROMP_SMEM_PTR;                 // [256][AS]
+    float* cst = T + 256 * AS;                         // [GEN_LOSS_NC][GEN_MAX_A]: s, exp(-s), exp(2 s), mask, R's, so, exp(-so), exp(2 so)
+    float* parts = cst + GEN_LOSS_NC * GEN_MAX_A;      // [4][GEN_MAX_A]
     const float* th = a.theta + (long long)wk.task * a.theta_task_stride;
     const int trow0 = a.task_row_offsets[wk.task], tn = a.task_row_offsets[wk.task + 1] - trow0;
     const float invN = 1.0f / (float)tn;
     float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
     float loss = 0.f, klsum = 0.f;
-    float* __restrict__ GS = a.dz[pp ^ 1];            // [rows][A]: every row's log_std terms (the buffer is free at this point of a pass)
     // (restrict-qualified copies: the row loops' loads may then be issued ahead of the stores of earlier actions)
     const float* __restrict__ g_mu = a.mu; const float* __restrict__ g_rmu = a.rmu; const float* __restrict__ g_act = a.actions;
-    const float* __restrict__ g_om = a.old_mean; const float* __restrict__ g_vd = a.vdir;
+    const float* __restrict__ g_om = a.old_mean;
     float* __restrict__ g_dz = a.dz[pp]; float* __restrict__ g_qz = a.qz[pp];
-    float ssum = 0.f;          // sum of the log standard deviations (log-likelihood objective)
-    for (int j = 0; j < A; ++j) {
-        const float sr = th[oS + j];
-        ssum += (a.clip_log_std && sr < a.min_log_std) ? a.min_log_std : sr;
+    if (tid < A) {
+        const float sr = th[oS + tid];
+        const bool clipped = a.clip_log_std && sr < a.min_log_std;
+        const float s = clipped ? a.min_log_std : sr;
+        cst[tid] = s;
+        cst[GEN_MAX_A + tid] = expf(-s);
+        cst[2 * GEN_MAX_A + tid] = expf(2.f * s);
+        cst[3 * GEN_MAX_A + tid] = clipped ? 0.f : 1.f;
+        cst[4 * GEN_MAX_A + tid] = (HVP && !clipped) ? -a.vdir[(long long)wk.task * NP + oS + tid] : 0.f;
+        if (!a.ls_per_row) {
+            const float so = a.old_log_std[(long long)wk.task * A + tid];
+            cst[5 * GEN_MAX_A + tid] = so;
+            cst[6 * GEN_MAX_A + tid] = expf(-so);
+            cst[7 * GEN_MAX_A + tid] = expf(2.f * so);
+        }
     }
-    for (int n = wk.row_begin + tid; n < wk.row_end; n += 256) {
-        const float* olsp = a.old_log_std + (a.ls_per_row ? (long long)n * A : (long long)wk.task * A);
+    __syncthreads();
+    float ssum = 0.f;          // sum of the log standard deviations (log-likelihood objective)
+    for (int j = 0; j < A; ++j) ssum += cst[j];
+    const bool is_kl = a.loss_kind == LOSS_KL, is_ratio = a.loss_kind == LOSS_RATIO, is_clip = a.loss_kind == LOSS_CLIP;
+    const int cj = tid & 63, cq = tid >> 6;
+    float gacc = 0.f;          // this thread's share of the log_std gradient of action cj
+    for (int base = wk.row_begin; base < wk.row_end; base += 256) {
+        const bool rv = base + tid < wk.row_end;
+        const int n = rv ? base + tid : wk.row_end - 1;            // (threads past the end shadow the last row and store nothing)
+        const float* olsp = a.old_log_std + (long long)n * A;
         const float advn = a.adv[n];
         // pass 1 over the actions: the row's log-likelihood ratio, its tangent, the KL
         float dlp = 0.f, sumz2 = 0.f, kl = 0.f, Rlp = 0.f;
 #pragma unroll 4
         for (int j = 0; j < A; ++j) {
-            const float sr = th[oS + j];
-            const bool clipped = a.clip_log_std && sr < a.min_log_std;
-            const float s = clipped ? a.min_log_std : sr, e = expf(-s), sn2 = expf(2.f * s);
-            const float mu = g_mu[(long long)n * A + j], ac = g_act[(long long)n * A + j], mo = g_om[(long long)n * A + j], so = olsp[j];
-            const float z = (ac - mu) * e, zo = (ac - mo) * expf(-so);
-            const float num = (mo - mu) * (mo - mu) + expf(2.f * so) - sn2, rden = 1.0f / (2.f * sn2 + 1e-8f);
+            const float s = cst[j], e = cst[GEN_MAX_A + j], sn2 = cst[2 * GEN_MAX_A + j];
+            const float mu = g_mu[(long long)n * A + j], ac = g_act[(long long)n * A + j], mo = g_om[(long long)n * A + j];
+            float so, eo, so2;
+            if (a.ls_per_row) { so = olsp[j]; eo = expf(-so); so2 = expf(2.f * so); }
+            else { so = cst[5 * GEN_MAX_A + j]; eo = cst[6 * GEN_MAX_A + j]; so2 = cst[7 * GEN_MAX_A + j]; }
+            const float z = (ac - mu) * e, zo = (ac - mo) * eo;
+            const float num = (mo - mu) * (mo - mu) + so2 - sn2, rden = 1.0f / (2.f * sn2 + 1e-8f);
             dlp += (so - s) - 0.5f * (z * z - zo * zo);
             sumz2 += z * z;
             kl += num * rden + s - so;
-            if (HVP) {
-                const float Rs = clipped ? 0.f : -g_vd[(long long)wk.task * NP + oS + j];
-                Rlp += z * e * g_rmu[(long long)n * A + j] + (z * z - 1.f) * Rs;
-            }
+            if (HVP) Rlp += z * e * g_rmu[(long long)n * A + j] + (z * z - 1.f) * cst[4 * GEN_MAX_A + j];
         }
-        if (HVP && a.row_tan != nullptr) a.row_tan[n] = Rlp;
+        if (HVP && a.row_tan != nullptr && rv) a.row_tan[n] = Rlp;
         const float rho = expf(dlp), aw = advn * invN;
         const float x = rho * advn, y = fminf(fmaxf(rho, 1.f - a.clip_eps), 1.f + a.clip_eps) * advn;
         const float lp = -ssum - 0.5f * sumz2 - 0.5f * (float)A * 1.8378770664093453f;
-        const bool is_kl = a.loss_kind == LOSS_KL, is_ratio = a.loss_kind == LOSS_RATIO, is_clip = a.loss_kind == LOSS_CLIP;
         float c = -aw, lrow = -lp * aw;                                  // log-likelihood
         if (is_clip) { c = (x <= y) ? -aw * rho : 0.f; lrow = -fminf(x, y) * invN; }
         if (is_ratio) { c = -aw * rho; lrow = -rho * aw; }
         if (is_kl) { c = 0.f; lrow = kl * invN; }
         const float Rc = (HVP && is_ratio) ? c * Rlp : 0.f;
-        loss += lrow;
-        klsum += kl * invN;
+        loss += rv ? lrow : 0.f;
+        klsum += rv ? kl * invN : 0.f;
         if (!BWD) continue;
         // pass 2: cotangents of the means (and their tangents), log_std terms
+        __syncthreads();                 // the previous block's column sums are done with the tile
 #pragma unroll 4
         for (int j = 0; j < A; ++j) {
-            const float sr = th[oS + j];
-            const bool clipped = a.clip_log_std && sr < a.min_log_std;
-            const float s = clipped ? a.min_log_std : sr, e = expf(-s), sn2 = expf(2.f * s);
-            const float mu = g_mu[(long long)n * A + j], ac = g_act[(long long)n * A + j], mo = g_om[(long long)n * A + j], so = olsp[j];
+            const float e = cst[GEN_MAX_A + j], sn2 = cst[2 * GEN_MAX_A + j], lmask = cst[3 * GEN_MAX_A + j];
+            const float mu = g_mu[(long long)n * A + j], ac = g_act[(long long)n * A + j], mo = g_om[(long long)n * A + j];
+            const float so2 = a.ls_per_row ? expf(2.f * olsp[j]) : cst[7 * GEN_MAX_A + j];
             const float z = (ac - mu) * e;
-            const float num = (mo - mu) * (mo - mu) + expf(2.f * so) - sn2, den = 2.f * sn2 + 1e-8f, rden = 1.0f / den;
+            const float num = (mo - mu) * (mo - mu) + so2 - sn2, den = 2.f * sn2 + 1e-8f, rden = 1.0f / den;
             const float dklm = -2.f * (mo - mu) * rden * invN;
             const float dkls = ((-2.f * sn2 * den - 4.f * num * sn2) * (rden * rden) + 1.f) * invN;
-            const float lmask = clipped ? 0.f : 1.f;
+            float d, q = 0.f, os;
             if (!HVP) {
-                g_dz[(long long)n * A + j] = c * z * e + (is_kl ? dklm : 0.f);
-                GS[(long long)n * A + j] = lmask * (c * (z * z - 1.f) + (is_kl ? dkls : 0.f));
+                d = c * z * e + (is_kl ? dklm : 0.f);
+                os = c * (z * z - 1.f) + (is_kl ? dkls : 0.f);
             } else {
-                const float Rs = clipped ? 0.f : -g_vd[(long long)wk.task * NP + oS + j];
+                const float Rs = cst[4 * GEN_MAX_A + j];
                 const float Rmu = g_rmu[(long long)n * A + j];
-                float d, q, os;
                 if (is_kl) {
                     // the objective is the mean KL itself (TRPO's constraint): see k_chain_hvp for the derivation
                     const float D = mo - mu, Pq = sn2 * (den + 2.f * num);
@@ -458,22 +487,23 @@ __global__ void __launch_bounds__(256) k_gen_loss(GenArgs a, int pp) {
                     q = Rd + a.kl_weight * dklm;
                     os = Rds + a.kl_weight * dkls;
                 }
-                g_dz[(long long)n * A + j] = d;
-                g_qz[(long long)n * A + j] = q;
-                GS[(long long)n * A + j] = lmask * os;
             }
+            if (rv) {
+                g_dz[(long long)n * A + j] = d;
+                if (HVP) g_qz[(long long)n * A + j] = q;
+            }
+            T[tid * AS + j] = rv ? lmask * os : 0.f;
         }
+        __syncthreads();
+        if (cj < A)
+            for (int r = cq; r < 256; r += 4) gacc += T[r * AS + cj];
     }
     const float L = gen_block_sum(loss, red, tid), Kl = gen_block_sum(klsum, red, tid);
     if (BWD) {
-        // the log_std gradient: column sums of the rows' terms in row order (one thread per action)
-        __threadfence_block();
+        // the log_std gradient: the four row parts of every action in fixed order
+        if (cj < A) parts[cq * GEN_MAX_A + cj] = gacc;
         __syncthreads();
-        if (tid < A) {
-            float g = 0.f;
-            for (int n = wk.row_begin; n < wk.row_end; ++n) g += GS[(long long)n * A + tid];
-            P[oS + tid] = g;
-        }
+        if (tid < A) P[oS + tid] = (parts[tid] + parts[GEN_MAX_A + tid]) + (parts[2 * GEN_MAX_A + tid] + parts[3 * GEN_MAX_A + tid]);
     }
     if (tid == 0) {
         P[NP] = L;

@@ -81,6 +81,7 @@ inline int lane() { return tl.tidx.x & 63; }
 
 template <class F>
 void launch(dim3 grid, int block, size_t smem, F body) {
+    for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
         for (unsigned bx = 0; bx < grid.x; ++bx) {
             Block blk(block, smem);
@@ -89,7 +90,7 @@ void launch(dim3 grid, int block, size_t smem, F body) {
             for (int t = 0; t < block; ++t)
                 th.emplace_back([&, t]() {
                     tl.tidx = dim3(t);
-                    tl.bidx = dim3(bx, by);
+                    tl.bidx = dim3(bx, by, bz);
                     tl.bdim = dim3(block);
                     tl.gdim = grid;
                     tl.blk = &blk;

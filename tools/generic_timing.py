@@ -17,8 +17,9 @@ CASES = [   # name, M, P, T, O, A, hidden, baseline
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--case', type=int, default=-1, help='run only this entry of CASES')
     args = ap.parse_args()
-    for name, M, P, T, O, A, hidden, baseline in CASES:
+    for name, M, P, T, O, A, hidden, baseline in (CASES if args.case < 0 else CASES[args.case:args.case + 1]):
         K, E, N = 1, 5, P * T
         theta0 = synthetic.init_theta(np.random.RandomState(1), O, hidden, A)
         ctx = _lib.Context(M, O, A, hidden, K, max_rows=M * N, max_paths=M * P)
