@@ -420,8 +420,9 @@ int launch_pass_generic(promp_ctx* c, StepData& S, const PassArgs& a, bool hvp, 
         const dim3 wgrid(S.n_work[0], (c->lin[li].K + GEN_KC - 1) / GEN_KC);     // one slab of 64 input units per workgroup
         PROMP_GEN_NBW(nbw,
             if (bf) {
-                if (hvp) { auto k = k_gb_wgrad<2, NBW>; PROMP_LAUNCH(k, wgrid, 256, gb_smem(2, NBW), st, g, li, pp); }
-                else { auto k = k_gb_wgrad<1, NBW>; PROMP_LAUNCH(k, wgrid, 256, gb_smem(1, NBW), st, g, li, pp); }
+                const dim3 bgrid(S.n_work[0] * Ly_K_slabs(c->lin[li].K));
+                if (hvp) { auto k = k_gb_wgrad<2, NBW>; PROMP_LAUNCH(k, bgrid, 256, gb_smem(2, NBW), st, g, li, pp); }
+                else { auto k = k_gb_wgrad<1, NBW>; PROMP_LAUNCH(k, bgrid, 256, gb_smem(1, NBW), st, g, li, pp); }
             } else if (hvp) { auto k = k_gen_wgrad<2, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(2, c->lin[li].N), st, g, li, pp); }
             else { auto k = k_gen_wgrad<1, NBW>; PROMP_LAUNCH(k, wgrid, 256, gen_wgrad_smem(1, c->lin[li].N), st, g, li, pp); })
         if (li == 0) break;

@@ -36,7 +36,17 @@ PROMP_HD int gb_up(int x, int m) { return m * ((x + m - 1) / m); }
 // elements (16-bit) of one layer's plane blocks
 PROMP_HD long long gb_f_elems(int K, int N) { return (long long)gb_up(K, 32) * 3 * gb_up(N, 64); }
 PROMP_HD long long gb_b_elems(int K, int N) { return (long long)gb_up(N, 32) * 3 * gb_up(K, 64); }
+PROMP_HD int Ly_K_slabs(int K) { return (K + 63) / 64; }
 PROMP_HD size_t gb_smem(int nt, int nbw) { return (size_t)nt * (GB_TILE64 + 3 * 64 * nbw * GB_ROWB); }
+
+// developer tooling: cycles per phase of workgroup (0, 0) / thread 0 (-DPROMP_DEV_STAMPS), printed at the end of the launch
+#ifdef PROMP_DEV_STAMPS
+#define GB_PHASE_DECL unsigned long long gb_ph[6] = {0, 0, 0, 0, 0, 0}, gb_t = promp_clock()
+#define GB_PHASE(i) do { const unsigned long long now_ = promp_clock(); gb_ph[i] += now_ - gb_t; gb_t = now_; } while (0)
+#else
+#define GB_PHASE_DECL do { } while (0)
+#define GB_PHASE(i) do { } while (0)
+#endif
 
 struct GbPlaneArgs {
     const float* src;               // the parameters [Theta] / [tasks][Theta], or the direction [tasks][Theta]
@@ -135,7 +145,14 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
     unsigned char* Bs = As + (TAN ? 2 : 1) * GB_TILE64;       // [3][NC][80 B]
     unsigned char* Us = Bs + 3 * NC * GB_ROWB;                // (TAN) minus the direction's kernel
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-    const WorkItem wk = a.work[blockIdx.x];
+    // Consecutive workgroups go to consecutive XCDs (8, each with its own 4 MB L2), and the work items are ordered by task: with
+    // item = blockIdx.x every XCD streams every task's planes (40 x 393 KB for a 256 x 256 layer).  Every XCD gets a contiguous
+    // eighth of the items instead -- five tasks' planes (-3 % per pass at 256 x 256.  Going further -- a 1-D grid in which an XCD
+    // walks its items one or two tasks at a time -- measured slower, 15.9 against 13.2 ms per step, with unchanged phase stamps:
+    // the 24 B / clock / CU at which a chunk's 28 loads issue is not an L2 miss rate).
+    const int per = (int)gridDim.x >> 3, bx = (int)blockIdx.x;
+    const int split = (int)blockIdx.y;
+    const WorkItem wk = a.work[bx < 8 * per ? (bx & 7) * per + (bx >> 3) : bx];
     const GenLin Ly = a.lin[li];
     const float* th = a.theta + (long long)wk.task * a.theta_task_stride;
     const bool last = li == a.n_lin - 1;
@@ -184,8 +201,10 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
         }
     };
     // (the first chunk of the workgroup's NEXT round is requested under the last products of this one)
-    const int rfirst = wk.row_begin + GB_R * (int)blockIdx.y;
+    GB_PHASE_DECL;
+    const int rfirst = wk.row_begin + GB_R * split;
     if (rfirst < wk.row_end) issue(rfirst, 0);
+    GB_PHASE(0);
     for (int row0 = rfirst; row0 < wk.row_end; row0 += rstep) {
         const int nrows = wk.row_end - row0 < GB_R ? wk.row_end - row0 : GB_R;
         f32x16 acc[RPW][CPW], racc[RPW][CPW];
@@ -197,6 +216,7 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
                 for (int j = 0; j < 16; ++j) acc[rb][c][j] = racc[rb][c][j] = 0.f;
         for (int k0 = 0; k0 < Kc; k0 += GB_KC) {
             __syncthreads();                 // the previous chunk's products are done with the tiles
+            GB_PHASE(1);
             {
                 float x[8], rx[8];
 #pragma unroll
@@ -216,11 +236,13 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
                 }
             }
             __syncthreads();
+            GB_PHASE(2);
             {
                 const bool more = k0 + GB_KC < Kc;
                 const int nrow0 = more ? row0 : row0 + rstep;
                 if (nrow0 < wk.row_end) issue(nrow0, more ? k0 + GB_KC : 0);
             }
+            GB_PHASE(3);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (k0 + 16 * ks < Kc) {       // (uniform)
@@ -255,6 +277,7 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
         // (the output arrays may alias them as far as the compiler knows -- which also keeps it from hoisting the NEXT block's
         // loads over this block's stores, 128 more live registers --: load / store pairs in one loop ran one memory round trip after
         // the other, 90 us per launch at 256 x 256).  The nonlinearity is a compile-time constant inside the loops.
+        GB_PHASE(4);
         const int kind = (FWD && last) ? GEN_ACT_IDENTITY : a.act_kind;
         auto epilogue = [&](auto kind_c) {
             constexpr int KIND = decltype(kind_c)::value;
@@ -309,13 +332,19 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
         if (kind == GEN_ACT_TANH) epilogue(std::integral_constant<int, GEN_ACT_TANH>{});
         else if (kind == GEN_ACT_RELU) epilogue(std::integral_constant<int, GEN_ACT_RELU>{});
         else epilogue(std::integral_constant<int, GEN_ACT_IDENTITY>{});
+        GB_PHASE(5);
     }
+#ifdef PROMP_DEV_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        printf("k_gb_linear<%d,%d> li %d Kc %d Nc %d cycles: first issue %llu | wait for products %llu | split + store %llu | issue next %llu | products %llu | epilogue %llu\n",
+               MODE, NBW, li, Kc, Nc, gb_ph[0], gb_ph[1], gb_ph[2], gb_ph[3], gb_ph[4], gb_ph[5]);
+#endif
 }
 
 // k_gb_wgrad: k_gen_wgrad (this work item's share of a layer's kernel / bias gradient into its partial row) on the BF16 pipe.
 // Output slab: 64 input units (blockIdx.y) x 64 NBW output units, summed over the work item's rows 32 at a time; both operands are
 // staged transposed ([unit][32 rows]).  Sums run in row order inside a workgroup: bitwise reproducible.
-// grid = (work items, ceil(K / 64)), block = 256, smem = gb_smem(NT, NBW).
+// grid = work items x ceil(K / 64), block = 256, smem = gb_smem(NT, NBW).
 template <int NT, int NBW>
 __global__ void __launch_bounds__(256) k_gb_wgrad(GenArgs a, int li, int pp) {
     PROMP_SMEM_DECL;
@@ -326,17 +355,28 @@ __global__ void __launch_bounds__(256) k_gb_wgrad(GenArgs a, int li, int pp) {
     unsigned char* Ds = Xs + NT * GB_TILE64;                  // [3][NC output units][80 B]
     unsigned char* Qs = Ds + 3 * NC * GB_ROWB;                // (NT == 2)
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-    const WorkItem wk = a.work[blockIdx.x];
+    // 1-D grid of work items x slabs.  Consecutive workgroups go to consecutive XCDs (8, each with its own L2): workgroup id = 8 t + x
+    // is slab t % nslab of work item 8 (t / nslab) + x, so that the slabs of an item -- which all read the item's cotangent rows, 4 x
+    // 82 MB per launch at 256 x 256 -- are dispatched back to back onto ONE XCD and share the rows through its L2.
+    const int nslab = (Ly_K_slabs(a.lin[li].K)), nitem = (int)gridDim.x / nslab, n8 = (nitem >> 3) * 8;
+    int item, slab;
+    {
+        const int id = (int)blockIdx.x;
+        if (id < n8 * nslab) { const int t = id >> 3; slab = t % nslab; item = 8 * (t / nslab) + (id & 7); }
+        else { const int r = id - n8 * nslab; item = n8 + r / nslab; slab = r - (r / nslab) * nslab; }
+    }
+    const WorkItem wk = a.work[item];
     const GenLin Ly = a.lin[li];
     const int K = Ly.K, N = Ly.N;
-    float* P = a.partials + (long long)blockIdx.x * a.partial_stride;
+    float* P = a.partials + (long long)item * a.partial_stride;
     const float* __restrict__ X = a.act[li];
     const float* __restrict__ RX = (NT == 2 && li > 0) ? a.ract[li] : nullptr;
     const float* __restrict__ DZ = a.dz[pp];
     const float* __restrict__ QZ = NT == 2 ? a.qz[pp] : nullptr;
     const int rb0 = NBW == 1 ? (w >> 1) : 0;
     const int su = lane, so = w;                 // staging: unit (of a block of 64), 8-row part
-    for (int kb0 = 64 * (int)blockIdx.y; kb0 < K; kb0 += 64 * (int)gridDim.y) {
+    {
+        const int kb0 = 64 * slab;
         f32x16 acc[RPW][CPW];
 #pragma unroll
         for (int rb = 0; rb < RPW; ++rb)
@@ -349,19 +389,23 @@ __global__ void __launch_bounds__(256) k_gb_wgrad(GenArgs a, int li, int pp) {
         for (int c = 0; c < NBW; ++c) bs[c] = 0.f;
         float xx[8], xr[8], xd[NBW][8], xq[NBW][8];
         auto issue = [&](int row0) {
+            // (one 64-bit base per array and chunk; the rows are 32-bit offsets from it)
             const int nrows = wk.row_end - row0 < GB_KC ? wk.row_end - row0 : GB_KC;
             const int kq = kb0 + su < K ? kb0 + su : K - 1;
+            const float* xb = X + (long long)row0 * K + kq;
+            const float* rxb = (NT == 2 && RX != nullptr) ? RX + (long long)row0 * K + kq : nullptr;
+            const float* db = DZ + (long long)row0 * N;
+            const float* qb = NT == 2 ? QZ + (long long)row0 * N : nullptr;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int r = 8 * so + i;
-                const long long row = row0 + (r < nrows ? r : nrows - 1);
-                xx[i] = X[row * K + kq];
-                if (NT == 2 && RX != nullptr) xr[i] = RX[row * K + kq];
+                const int r = 8 * so + i, rr = r < nrows ? r : nrows - 1;
+                xx[i] = xb[rr * K];
+                if (NT == 2 && RX != nullptr) xr[i] = rxb[rr * K];
 #pragma unroll
                 for (int c = 0; c < NBW; ++c) {
                     const int n = 64 * c + su < N ? 64 * c + su : N - 1;
-                    xd[c][i] = DZ[row * N + n];
-                    if (NT == 2) xq[c][i] = QZ[row * N + n];
+                    xd[c][i] = db[rr * N + n];
+                    if (NT == 2) xq[c][i] = qb[rr * N + n];
                 }
             }
         };
