@@ -141,6 +141,7 @@ struct promp_ctx {
     unsigned *wb_planes = nullptr, *wb_vplanes = nullptr;   // [tasks][wb_planes_words]: k_wb_planes' output for theta / the direction
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
+    bool fit_one_launch = false;         // PROMP_FIT_ONE_LAUNCH=1: k_fit_wide alone at every width (A/B runs against the per-phase launches)
     bool generic = false;
     bool gen_bf16 = true;                // their GEMMs on the BF16 matrix pipe (promp_kernels_generic_bf16.h); PROMP_GEN_FP32=1: the exact-FP32 kernels (A/B runs)
     unsigned short *gb_wplanes = nullptr, *gb_vplanes = nullptr;   // [tasks][gb_plane_stride]: k_gb_planes' output for theta / minus the direction
@@ -825,6 +826,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     c->NPu = param_count(user_dims);
     c->padded = c->NPu != param_count(dims);
     c->device = device_id;
+    { const char* e = getenv("PROMP_FIT_ONE_LAUNCH"); c->fit_one_launch = e && e[0] == '1'; }
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -978,6 +980,14 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         }
         {
             auto fw32 = k_fit_wide<32>; auto fw16 = k_fit_wide<16>;
+            auto p32 = k_fitw_panel<32>; auto p16 = k_fitw_panel<16>; auto u32 = k_fitw_update<32>; auto u16 = k_fitw_update<16>;
+            auto b32 = k_fitw_back<32>; auto b16 = k_fitw_back<16>;
+            HIPCHECK(hipFuncSetAttribute((const void*)p32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)p16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)u32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)u16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)b32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIPCHECK(hipFuncSetAttribute((const void*)b16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHECK(hipFuncSetAttribute((const void*)fw32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIPCHECK(hipFuncSetAttribute((const void*)fw16, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
@@ -1337,7 +1347,7 @@ int fit_buffers(promp_ctx* c, bool on_side) {
     double*& fs = on_side ? c->fit_scratch_side : c->fit_scratch;
     if (!gp && dev_alloc(&gp, (size_t)c->max_work * c->gram_stride)) return -2;
     const int nblk_max = (c->Dmax + 1 + 15) / 16;
-    if (!fs && (nblk_max > 5 || c->d.obs_dim > 32) && dev_alloc(&fs, (size_t)c->d.n_tasks * 2 * (c->Dmax + 1) * (c->Dmax + 1))) return -2;
+    if (!fs && (nblk_max > 5 || c->d.obs_dim > 32) && dev_alloc(&fs, (size_t)c->d.n_tasks * 2 * (c->Dmax + 1) * (c->Dmax + 1) + c->d.n_tasks)) return -2;   // (+ k_fitw_back's flags)
     return 0;
 }
 
@@ -1414,8 +1424,21 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
         } else {
             PROMP_LAUNCH(k_gram_sum_wide, dim3(c->d.n_tasks * FITW_SUM_SPLIT), 256, 0, st, a, nblk, fit_scratch);
             HIPCHECK(hipGetLastError());
-            if (fitw_nb(a.D) == 32) { auto k = k_fit_wide<32>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, 32), st, a, nblk, fit_scratch); }
-            else { auto k = k_fit_wide<16>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, 16), st, a, nblk, fit_scratch); }
+            const int* none = nullptr;
+            int* bad = (int*)(fit_scratch + (size_t)c->d.n_tasks * 2 * (c->Dmax + 1) * (c->Dmax + 1));
+            const bool phases = a.D >= FITW_ML_MIN_D && !c->fit_one_launch;      // one launch per phase: all CUs in the trailing updates
+#define PROMP_FITW(NB)                                                                                                              \
+    if (phases) {                                                                                                                   \
+        auto kp = k_fitw_panel<NB>; auto ku = k_fitw_update<NB>; auto kb = k_fitw_back<NB>; auto kf = k_fit_wide<NB>;              \
+        for (int k0 = 0; k0 < a.D; k0 += NB) {                                                                                      \
+            PROMP_LAUNCH(kp, dim3(c->d.n_tasks), FITW_NT, fitw_panel_smem(a.D, NB), st, a, fit_scratch, k0);                        \
+            if (k0 + NB < a.D) PROMP_LAUNCH(ku, dim3(c->d.n_tasks, FITW_UPD_SPLIT), FITW_NT, fitw_panel_smem(a.D, NB), st, a, fit_scratch, k0); \
+        }                                                                                                                           \
+        PROMP_LAUNCH(kb, dim3(c->d.n_tasks), FITW_NT, fitw_back_smem(a.D), st, a, fit_scratch, bad);                               \
+        PROMP_LAUNCH(kf, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, NB), st, a, nblk, fit_scratch, (const int*)bad);               \
+    } else { auto k = k_fit_wide<NB>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, NB), st, a, nblk, fit_scratch, none); }
+            if (fitw_nb(a.D) == 32) { PROMP_FITW(32) } else { PROMP_FITW(16) }
+#undef PROMP_FITW
         }
         HIPCHECK(hipGetLastError());
     }

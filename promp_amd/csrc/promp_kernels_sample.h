@@ -840,8 +840,10 @@ __global__ void __launch_bounds__(256) k_gram_sum_wide(SampleArgs a, int NBLK, d
     }
 }
 
+// only_bad != nullptr: the launch behind the one-launch-per-phase factorisation below -- tasks whose flag is 0 are done; the others
+// (a NaN in the solution: the ridge term was too small) start over at the second attempt, reg x 10, exactly as they would have here.
 template <int NB>
-__global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, double* scratch) {
+__global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, double* scratch, const int* only_bad) {
     constexpr int PS = NB + 1, LOG_NB = NB == 32 ? 5 : 4;
     PROMP_SMEM_DECL;
 #ifdef PROMP_DEV_STAMPS
@@ -863,8 +865,10 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
     double* Wm = G + (size_t)DA * DA;
     // (G, and G + reg I as the work matrix of the first attempt, were written by k_gram_sum_wide)
     const float rDA = 1.0f / (float)DA;
-    double reg = a.reg;
-    for (int attempt = 0; attempt < 5; ++attempt) {
+    if (only_bad != nullptr && !only_bad[task]) return;          // (uniform over the workgroup)
+    const int first_attempt = only_bad != nullptr ? 1 : 0;
+    double reg = first_attempt ? a.reg * 10.0 : a.reg;
+    for (int attempt = first_attempt; attempt < 5; ++attempt) {
         if (attempt > 0) {            // a retry starts over from G with the larger ridge term
             for (int e = tid; e < DA * DA; e += NT) {
                 const int i = (int)(((float)e + 0.5f) * rDA), j = e - i * DA;
@@ -1025,4 +1029,184 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
         printf("k_fit_wide cycles: entry %llu | retry init %llu | panel load %llu | diagonal block %llu | rows below %llu | store + update %llu | back substitution %llu\n",
                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same factorisation with ONE LAUNCH PER PHASE, for matrices so large that one compute unit per task is the wrong shape
+// (Humanoid: D = 756, 48 panels of 16 columns; the rank-16 update of a 740 x 740 trailing matrix is 1100 tiles of 16 x 16 per
+// panel -- in k_fit_wide 8 waves of ONE CU walk them while 216 CUs idle: 3.5 ms per fit at 40 tasks):
+//   k_fitw_panel  (grid = tasks)                    panel k0: diagonal block, rows below, factored panel back into the work matrix
+//   k_fitw_update (grid = tasks x FITW_UPD_SPLIT)   trailing matrix -= panel panel^T on the FP64 matrix cores, all CUs
+//   ... per panel, then
+//   k_fitw_back   (grid = tasks)                    back substitution, NaN check -> coefficients, or bad[task] = 1
+//   k_fit_wide(only_bad)                            the (rare) retries with a larger ridge term, unchanged
+// Same elimination order and the same arithmetic per entry as k_fit_wide (every trailing entry takes one 16-term MFMA sum per
+// panel whichever wave computes it): bit-identical coefficients.  The diagonal of the factor is kept on the work matrix' diagonal.
+// ---------------------------------------------------------------------------------------------
+#define FITW_UPD_SPLIT 6          // 40 tasks x 6 = 240 workgroups
+#define FITW_ML_MIN_D 400         // below: k_fit_wide (8 panels at Ant's 226 columns are a chain of dependent steps, not tile work)
+PROMP_HD size_t fitw_panel_smem(int D, int nb) { return sizeof(double) * ((size_t)(D + 1 + 16) * (nb + 1) + nb + 2); }
+PROMP_HD size_t fitw_back_smem(int D) { return sizeof(double) * ((size_t)2 * (D + 1) + 2); }
+
+template <int NB>
+__global__ void __launch_bounds__(FITW_NT) k_fitw_panel(SampleArgs a, double* scratch, int k0) {
+    constexpr int PS = NB + 1, LOG_NB = NB == 32 ? 5 : 4;
+    PROMP_SMEM_DECL;
+    const int D = a.D, DA = D + 1, NT = FITW_NT;
+    const int tid = threadIdx.x, task = blockIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    double* Pn = (double*)PROMP_SMEM_PTR;             // [DA - k0][PS]
+    double* rdp = Pn + (size_t)(DA + 16) * PS;        // 1 / L[c][c] of the diagonal block
+    double* Wm = scratch + (size_t)task * 2 * DA * DA + (size_t)DA * DA;
+    const int nb = (D - k0) < NB ? (D - k0) : NB;     // columns of this panel
+    const int nr = DA - k0;                           // rows k0..D (the last one is the right-hand side)
+    for (int e = tid; e < nr * NB; e += NT) {
+        const int i = e >> LOG_NB, c = e & (NB - 1);
+        Pn[i * PS + c] = c < nb ? Wm[(size_t)(k0 + i) * DA + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    if (w == 0) {
+        // ---- the diagonal block, one wave, rows in registers (k_fit_wide's step 1)
+        const int row = lane < nb ? lane : nb - 1;
+        double W[NB];
+        double rdg = 1.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) W[k] = Pn[row * PS + k];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (j < nb) {     // (wave-uniform)
+                const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
+                W[j] = (lane == j) ? piv : W[j] * rs;
+                rdg = (lane == j) ? rs : rdg;
+#pragma unroll
+                for (int k = j + 1; k < NB; ++k) W[k] -= W[j] * readlane_f64(W[j], k);
+            }
+        }
+        if (lane < nb) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (k <= lane) Pn[lane * PS + k] = W[k];
+            rdp[lane] = rdg;
+        }
+    }
+    __syncthreads();
+    // ---- the rows below: x L^T = a, one row per thread (k_fit_wide's step 2)
+    for (int rr = tid; rr < nr - nb; rr += NT) {
+        double* xr = Pn + (size_t)(nb + rr) * PS;
+        double x[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) x[c] = xr[c];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (c < nb) {
+                x[c] *= rdp[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < NB; ++c2) x[c2] -= x[c] * Pn[c2 * PS + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c) xr[c] = (c < nb) ? x[c] : 0.0;
+    }
+    __syncthreads();
+    // the factored panel back: lower part INCLUDING the diagonal, and the right-hand-side row
+    for (int e = tid; e < nr * NB; e += NT) {
+        const int i = e >> LOG_NB, c = e & (NB - 1);
+        if (c < nb && i >= c) Wm[(size_t)(k0 + i) * DA + k0 + c] = Pn[i * PS + c];
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(FITW_NT) k_fitw_update(SampleArgs a, double* scratch, int k0) {
+    constexpr int PS = NB + 1, LOG_NB = NB == 32 ? 5 : 4;
+    PROMP_SMEM_DECL;
+    const int D = a.D, DA = D + 1, NT = FITW_NT;
+    const int tid = threadIdx.x, task = blockIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    double* Pn = (double*)PROMP_SMEM_PTR;             // [tr + 16][PS]: the factored panel's rows below its diagonal block
+    double* Wm = scratch + (size_t)task * 2 * DA * DA + (size_t)DA * DA;
+    const int nb = (D - k0) < NB ? (D - k0) : NB;
+    const int k1 = k0 + nb, tr = DA - k1, tc = D - k1;
+    for (int e = tid; e < (tr + 16) * NB; e += NT) {
+        const int i = e >> LOG_NB, c = e & (NB - 1);
+        Pn[i * PS + c] = (c < nb && i < tr) ? Wm[(size_t)(k1 + i) * DA + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    // rows k1..D, columns k1..D-1, the 16 x 16 tiles of the lower triangle dealt to all waves of the task's workgroups
+    const int nti = (tr + 15) >> 4, ntj = (tc + 15) >> 4, ntile = nti * ntj;
+    const int nw = (FITW_NT / 64) * (int)gridDim.y;
+    for (int tix = w + (FITW_NT / 64) * (int)blockIdx.y; tix < ntile; tix += nw) {
+        const int bi = tix / ntj, bj = tix - bi * ntj;
+        if (bj > bi) continue;                     // wave-uniform
+        const double* pa = Pn + (size_t)(16 * bi + i16) * PS + kk;
+        const double* pb = Pn + (size_t)(16 * bj + i16) * PS + kk;
+        double* dst[4];
+        double old[4];
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int io = 16 * bi + kk + 4 * r, jo = 16 * bj + i16;
+            ok[r] = io < tr && jo < tc && jo <= io;
+            dst[r] = Wm + (size_t)(k1 + (ok[r] ? io : 0)) * DA + k1 + (ok[r] ? jo : 0);
+            old[r] = *dst[r];
+        }
+        f64x4 acc = zero4d();
+#pragma unroll
+        for (int sidx = 0; sidx < NB / 4; ++sidx) acc = mfma16d(pa[4 * sidx], pb[4 * sidx], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (ok[r]) *dst[r] = old[r] - acc[r];
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(FITW_NT) k_fitw_back(SampleArgs a, double* scratch, int* bad) {
+    PROMP_SMEM_DECL;
+    const int D = a.D, DA = D + 1, NT = FITW_NT;
+    const int tid = threadIdx.x, task = blockIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    double* yv = (double*)PROMP_SMEM_PTR;
+    double* wv = yv + DA;
+    int* flag = (int*)(wv + DA);
+    const double* Wm = scratch + (size_t)task * 2 * DA * DA + (size_t)DA * DA;
+    // ---- back substitution L^T w = z, z = row D of the factor, NB rows of L at a time (k_fit_wide's)
+    for (int e = tid; e < D; e += NT) yv[e] = Wm[(size_t)D * DA + e];
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int kb = ((D - 1) / NB) * NB; kb >= 0; kb -= NB) {
+        const int nb = (D - kb) < NB ? (D - kb) : NB;
+        if (w == 0) {
+            const int t = lane < nb ? lane : nb - 1;
+            double W[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) W[j] = (j < nb && j > t) ? Wm[(size_t)(kb + j) * DA + kb + t] : 0.0;
+            double y = yv[kb + t];
+            const double rd = 1.0 / Wm[(size_t)(kb + t) * DA + kb + t];
+            double wsol = 0.0;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                if (j < nb) {
+                    const double wj = readlane_f64(y, j) * readlane_f64(rd, j);
+                    if (lane == j) wsol = wj;
+                    if (lane < j) y -= W[j] * wj;
+                }
+            }
+            if (lane < nb) wv[kb + lane] = wsol;
+        }
+        __syncthreads();
+        for (int i = tid; i < kb; i += NT) {
+            double lv[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];
+            double s = yv[i];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
+            yv[i] = s;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < D; e += NT)
+        if (wv[e] != wv[e]) *flag = 1;
+    __syncthreads();
+    const int isbad = *flag;
+    if (tid == 0) bad[task] = isbad;
+    if (!isbad)
+        for (int e = tid; e < D; e += NT) a.coeffs[(long long)task * a.coeff_stride + e] = wv[e];
 }

@@ -149,6 +149,34 @@ def check_fit_retry_on_rank_deficient_features(lib, seed, M=2, P=3, T=40, O=4):
     np.testing.assert_allclose(out['advantages'], adv_ref, rtol=1e-3, atol=1e-3 * np.abs(adv_ref).max())
 
 
+def check_fit_phases_equal_one_launch(lib, seed, M=3, P=6, T=100, O=376):
+    """The baseline fit of wide feature matrices runs as one launch per phase (k_fitw_panel / k_fitw_update / k_fitw_back) from
+    FITW_ML_MIN_D columns on; PROMP_FIT_ONE_LAUNCH=1 keeps k_fit_wide alone.  Same elimination order, same arithmetic per entry:
+    the coefficients agree bit for bit."""
+    import os
+    from promp_amd import synthetic
+    rng = np.random.RandomState(seed)
+    theta = synthetic.init_theta(rng, O, (8, 8), 2)
+    paths = synthetic.make_paths(rng, theta, M, P, T, O, 2, (8, 8))
+    fl = _lib.flatten_paths(paths)
+    kwargs = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True)
+    outs = []
+    for one in ('0', '1'):
+        old = os.environ.get('PROMP_FIT_ONE_LAUNCH')
+        os.environ['PROMP_FIT_ONE_LAUNCH'] = one
+        try:
+            ctx = _lib.Context(M, O, 2, (32, 32), 1, max_rows=len(fl['rew']), max_paths=len(fl['path_row_offsets']) - 1, lib=lib)
+        finally:
+            if old is None: del os.environ['PROMP_FIT_ONE_LAUNCH']
+            else: os.environ['PROMP_FIT_ONE_LAUNCH'] = old
+        ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'])
+        ctx.process_samples(0, baseline_kind=KIND['linear_feature'], **kwargs)
+        outs.append(ctx.download_processed(0))
+        ctx.close()
+    assert np.array_equal(outs[0]['coeffs'], outs[1]['coeffs'])
+    assert np.array_equal(outs[0]['advantages'], outs[1]['advantages'])
+
+
 def make_ctx(lib, M, O, A, hidden, K, all_paths, n_tasks_global=None, hidden_act='tanh'):
     R = max(sum(len(p['rewards']) for pl in paths.values() for p in pl) for paths in all_paths)
     NPaths = max(sum(len(pl) for pl in paths.values()) for paths in all_paths)

@@ -260,3 +260,12 @@ def test_trpo_maml_step(lib, two_cus):
 
 def test_comm_info_and_exchange_timing_on_a_one_rank_communicator(lib, two_cus):
     pc.check_comm_info_and_exchange_timing(lib)
+
+
+def test_sample_processing_fit_with_one_launch_per_phase(lib, two_cus, monkeypatch):
+    # obs_dim 200 -> 404 columns >= FITW_ML_MIN_D: k_fitw_panel / k_fitw_update / k_fitw_back (13 panels of 32 columns) and the
+    # only_bad launch of k_fit_wide behind them, against the oracle; then the same batch through k_fit_wide alone
+    kw = dict(discount=0.99, gae_lambda=0.97, normalize_adv=True)
+    pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=200, ragged=True, kwargs=kw)
+    monkeypatch.setenv('PROMP_FIT_ONE_LAUNCH', '1')
+    pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=200, ragged=True, kwargs=kw)

@@ -140,6 +140,13 @@ def test_fit_retries_with_larger_reg_on_rank_deficient_features(lib):
     pc.check_fit_retry_on_rank_deficient_features(lib, 39)
     pc.check_fit_retry_on_rank_deficient_features(lib, 40, M=3, P=4, T=120, O=20)       # k_fit_wave<48>
     pc.check_fit_retry_on_rank_deficient_features(lib, 41, M=2, P=4, T=100, O=40)       # k_fit_wide
+    pc.check_fit_retry_on_rank_deficient_features(lib, 42, M=2, P=4, T=150, O=200)      # one launch per phase, then k_fit_wide<32>(only_bad)
+    pc.check_fit_retry_on_rank_deficient_features(lib, 43, M=2, P=4, T=200, O=300)      # ... 16-column panels
+
+
+def test_fit_with_one_launch_per_phase_equals_the_single_launch(lib):
+    pc.check_fit_phases_equal_one_launch(lib, 44)                                       # Humanoid width: 757 columns, 48 panels of 16
+    pc.check_fit_phases_equal_one_launch(lib, 45, M=2, P=4, T=120, O=200)               # 405 columns, 13 panels of 32
 
 
 @pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 2, 2), ((64, 64), 5, 3), ((128, 128), 111, 8),
