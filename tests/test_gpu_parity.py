@@ -72,6 +72,15 @@ def test_split_gemm_accuracy_guard(lib, hidden, O, A):
     pc.check_split_accuracy(lib, hidden, O, A, meta_tol=1e-5 if hidden[0] == 128 else None)
 
 
+@pytest.mark.parametrize('hidden,O,A', [((64, 64, 64), 20, 6), ((256, 256), 20, 6), ((64, 64), 376, 17), ((100,), 11, 3)])
+def test_split_gemm_accuracy_guard_layer_by_layer(lib, hidden, O, A):
+    """The layer-by-layer kernels' GEMMs on the BF16 pipe (k_gb_linear / k_gb_wgrad, round 5): 2.5e-7 ... 5.0e-6 of the result's
+    max-norm against the float64 oracle, the exact-FP32 kernels (PROMP_GEN_FP32=1) 2.9e-7 ... 2.8e-6 on the same cases
+    (profiles/r05_split_accuracy_generic.txt; contraction lengths to 376, float32 accumulation in both).  Three products instead
+    of six would be ~5e-5: the guard sits at 1e-5."""
+    pc.check_split_accuracy(lib, hidden, O, A, tol=1e-5)
+
+
 def test_unsupported_shapes_are_rejected(lib):
     for hidden, O, A in (((257, 64), 4, 2), ((0, 32), 4, 2), ((32, 32, 32, 32, 32), 4, 2), ((), 4, 2), ((32, 32), 4, 65), ((32, 32), 1025, 2)):
         with pytest.raises((_lib.PrompError, ValueError, TypeError)):

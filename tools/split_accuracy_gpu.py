@@ -45,5 +45,8 @@ def errs(hidden, O, A, seed=11, M=2, P=2, T=48):
     return out
 
 
-for hidden, O, A in (((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2), ((128, 128), 111, 8), ((128, 128), 20, 6)):
+import os
+GENERIC = (((64, 64, 64), 20, 6), ((256, 256), 20, 6), ((64, 64), 376, 17), ((100,), 11, 3))      # the layer-by-layer kernels
+FUSED = (((64, 64), 20, 6), ((32, 32), 7, 3), ((32, 64), 20, 6), ((64, 32), 11, 2), ((128, 128), 111, 8), ((128, 128), 20, 6))
+for hidden, O, A in (GENERIC if os.environ.get('PROMP_ACC_GENERIC_ONLY') else FUSED + GENERIC):
     print(hidden, O, A, {k: '%.2e' % v for k, v in errs(hidden, O, A).items()})
