@@ -141,6 +141,9 @@ struct promp_ctx {
     unsigned *wb_planes = nullptr, *wb_vplanes = nullptr;   // [tasks][wb_planes_words]: k_wb_planes' output for theta / the direction
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
+    bool gram_untiled = false;           // PROMP_GRAM_UNTILED=1: k_gram_wide at every width (A/B runs against k_gram_tiled)
+    int gramt_map_nblk = -1;             // the block count c->gramt_map was balanced for
+    GramtMap gramt_map;                  // one-slice k_gram_tiled launches: wave -> rectangle
     bool fit_one_launch = false;         // PROMP_FIT_ONE_LAUNCH=1: k_fit_wide alone at every width (A/B runs against the per-phase launches)
     bool generic = false;
     bool gen_bf16 = true;                // their GEMMs on the BF16 matrix pipe (promp_kernels_generic_bf16.h); PROMP_GEN_FP32=1: the exact-FP32 kernels (A/B runs)
@@ -827,6 +830,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     c->padded = c->NPu != param_count(dims);
     c->device = device_id;
     { const char* e = getenv("PROMP_FIT_ONE_LAUNCH"); c->fit_one_launch = e && e[0] == '1'; }
+    { const char* e = getenv("PROMP_GRAM_UNTILED"); c->gram_untiled = e && e[0] == '1'; }
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -949,6 +953,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
             HIPCHECK(hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         HIPCHECK(hipFuncSetAttribute((const void*)k_gram_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        {
+            auto t1 = k_gram_tiled<GRAMT_TB, GRAMT_NWV, GRAMT_NLD>;
+            HIPCHECK(hipFuncSetAttribute((const void*)t1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
 #define PROMP_GEN_ATTR(NBW)                                                                                            \
     {                                                                                                                \
         auto w1 = k_gen_wgrad<1, NBW>; auto w2 = k_gen_wgrad<2, NBW>;                                                 \
@@ -1342,6 +1350,28 @@ int promp_stage_wait(promp_ctx* c) {
 
 // The baseline fit's buffers of one stream (main / side), allocated on first use: contexts that never fit a LinearFeatureBaseline
 // (policy passes only, ZeroBaseline, advantages handed in) do not pay for them.
+// k_gram_tiled, one slice (at most GRAMT_NWV squares): share the squares out over the waves so that the four SIMDs of a compute
+// unit carry about the same number of matrix instructions per k-step (wave w of a workgroup runs on SIMD w mod 4).  Longest
+// first, each to the least loaded SIMD that still has a wave free; more squares than waves: slices in list order (identity).
+void gramt_balance(int nblk, int nwv, GramtMap* map) {
+    const int nb = gramt_nb(nblk), nr = gramt_nrect(nblk);
+    memset(map->rect, 255, sizeof map->rect);
+    if (nr > nwv || nwv > 16) return;       // (the kernel takes slice * NWV + w when gridDim.y > 1)
+    int slots[4] = {0, 0, 0, 0}, load[4] = {0, 0, 0, 0}, next[4] = {0, 1, 2, 3};
+    for (int w = 0; w < nwv; ++w) slots[w & 3]++;
+    for (int pass = 0; pass < 2; ++pass)            // off-diagonal squares (TB^2 products) first, then the diagonal ones
+        for (int bi = 0, r = 0; bi < nb; ++bi)
+            for (int bj = bi; bj < nb; ++bj, ++r) {
+                if ((bi == bj) != (pass == 1)) continue;
+                const int cost = bi == bj ? GRAMT_TB * (GRAMT_TB + 1) / 2 : GRAMT_TB * GRAMT_TB;
+                int q = -1;
+                for (int t = 0; t < 4; ++t)
+                    if (slots[t] > 0 && (q < 0 || load[t] < load[q])) q = t;
+                map->rect[next[q]] = (unsigned char)r;
+                next[q] += 4; slots[q]--; load[q] += cost;
+            }
+}
+
 int fit_buffers(promp_ctx* c, bool on_side) {
     double*& gp = on_side ? c->gram_partials_side : c->gram_partials;
     double*& fs = on_side ? c->fit_scratch_side : c->fit_scratch;
@@ -1406,6 +1436,16 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             case 4: { auto k = k_gram<4>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<4>::NW, GramCfg<4>::SMEM_BYTES, st, a); } break;
             case 5: { auto k = k_gram<5>; PROMP_LAUNCH(k, dim3(S.n_work[0]), 64 * GramCfg<5>::NW, GramCfg<5>::SMEM_BYTES, st, a); } break;
             default:
+                // 13 blocks and more (obs_dim >= 94; Ant: 15, Humanoid: 48): a square of 3 x 3 blocks per wave, operands reused in
+                // registers (k_gram_tiled); fewer blocks make too few squares to fill a compute unit: k_gram_wide
+                if (nblk >= GRAMT_MIN_NBLK && !c->gram_untiled) {
+                    const int nr = gramt_nrect(nblk), cap = 64 * GRAMT_NWV * GRAMT_NLD;
+                    if (c->gramt_map_nblk != nblk) { gramt_balance(nblk, GRAMT_NWV, &c->gramt_map); c->gramt_map_nblk = nblk; }
+                    auto k = k_gram_tiled<GRAMT_TB, GRAMT_NWV, GRAMT_NLD>;
+                    PROMP_LAUNCH(k, dim3(S.n_work[0], (nr + GRAMT_NWV - 1) / GRAMT_NWV), 64 * GRAMT_NWV, gramt_smem(nblk, a.O, cap), st, a, nblk,
+                                 c->gramt_map);
+                    break;
+                }
                 // (more than 17 blocks -- obs_dim > 133: the pair list is cut into slices of <= 160, one workgroup per work item and slice)
                 PROMP_LAUNCH(k_gram_wide, dim3(S.n_work[0], gramw_slices(nblk)), 512, gramw_smem(nblk, a.O, gramw_rows(nblk, a.O)), st, a, nblk,
                              gramw_rows(nblk, a.O));

@@ -773,6 +773,207 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_gram_tiled (round 5, second half): the same product as k_gram_wide with the operands of the FP64 matrix instruction REUSED in
+// registers.  k_gram_wide reads two LDS operands per v_mfma_f64_16x16x4_f64 (its waves own arbitrary runs of the pair list, so the
+// shared row block of a run is fetched again for every pair): 40 ds_read_b64 per 15 products and wave at Ant's width, two thirds
+// of the LDS bandwidth of the CU when the matrix pipe is full -- the pipe measured 44 % busy.  Here a wave owns a SQUARE of
+// TB x TB column blocks (bands of TB = 3 blocks, 48 feature columns; band pair bi <= bj): 3 + 3 operand reads feed 9 products, at
+// immediate offsets from two lane addresses.  Squares on the diagonal issue their upper triangle (6 products from 3 reads).  The
+// two shapes are two instances of the step loop: products behind wave-uniform branches, or more loop shapes (short last bands),
+// made the register allocator spill accumulators -- the block count is padded to whole bands instead (the padding columns are
+// zero in the tile and are never written out).  out[] keeps k_gram_wide's layout ([pair][256] per work item, pair = row-major
+// index of the upper block triangle), so k_gram_sum_wide / the fits do not change.
+//   * Ant's 15 blocks are 5 bands = 15 squares = 15 waves of ONE workgroup (10 x 9 + 5 x 6 = 120 products per k-step, the
+//     unpadded count); the host shares them out over the SIMDs by cost (GramtMap; wave w runs on SIMD w mod 4).  More squares:
+//     slices of NWV along gridDim.y (Humanoid's 48 blocks: 136 squares, 9 slices).
+//   * The feature tile is double-buffered where two tiles fit LDS (Ant: 2 x 32 rows x 240 columns = 123 KB): the observations
+//     of round r + 1 are requested before the products of round r and written into the other tile behind them -- one barrier
+//     per round, the global latency and the tile build off the matrix pipe's path.  Wider tiles (Humanoid: 16 rows x 784) are
+//     single: the request is still issued a round ahead, the write sits between two barriers.
+//   * A partial last round issues only the k-steps that hold rows.
+// grid = work items (table 0) x slices, block = 64 NWV.  smem: gramt_smem(NBLK, O, NT * NLD).
+// ---------------------------------------------------------------------------------------------
+#define GRAMT_MIN_NBLK 13
+#define GRAMT_TB 3
+#define GRAMT_NWV 16
+#define GRAMT_NLD 8
+struct GramtMap { unsigned char rect[16]; };      // one-slice launches: wave -> square (255: none)
+PROMP_HD int gramt_nb(int NBLK) { return (NBLK + GRAMT_TB - 1) / GRAMT_TB; }
+PROMP_HD int gramt_fs(int NBLK) {       // 16 x odd: the four k-rows of a step land on disjoint banks
+    const int nc = GRAMT_TB * gramt_nb(NBLK);
+    return (nc % 2 == 1) ? 16 * nc : 16 * nc + 16;
+}
+PROMP_HD int gramt_nrect(int NBLK) { return gramt_nb(NBLK) * (gramt_nb(NBLK) + 1) / 2; }
+// rows per round: 32 where the tile fits LDS and the round's observations fit the threads' request registers, else 16
+PROMP_HD int gramt_rows(int NBLK, int O, int cap) {
+    return (sizeof(double) * 32 * (size_t)gramt_fs(NBLK) <= 160 * 1024 && 32 * O <= cap) ? 32 : 16;
+}
+PROMP_HD int gramt_db(int NBLK, int O, int cap) {
+    return sizeof(double) * 2 * (size_t)gramt_rows(NBLK, O, cap) * gramt_fs(NBLK) <= 160 * 1024 ? 1 : 0;
+}
+PROMP_HD size_t gramt_smem(int NBLK, int O, int cap) {
+    return sizeof(double) * (size_t)((gramt_db(NBLK, O, cap) ? 2 : 1) * gramt_rows(NBLK, O, cap) * gramt_fs(NBLK));
+}
+
+// the k-steps of one round for one square: pa / pb = this lane's element of the first block of the row / column band in k-row
+// kk of the tile; FS4 = 4 rows of the tile.  DIAG: row band = column band, only the products jj >= ii.
+template <int TB, bool DIAG>
+PROMP_DEV void gramt_steps(f64x4 (&acc)[TB][TB], const double* pa, const double* pb, int nst, int FS4) {
+#pragma unroll 1
+    for (int st = 0; st < nst; ++st) {
+        double fa[TB], fb[TB];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) {
+            fa[u] = pa[16 * u];
+            fb[u] = DIAG ? fa[u] : pb[16 * u];
+        }
+#pragma unroll
+        for (int ii = 0; ii < TB; ++ii)
+#pragma unroll
+            for (int jj = DIAG ? ii : 0; jj < TB; ++jj) acc[ii][jj] = mfma16d(fa[ii], fb[jj], acc[ii][jj]);
+        pa += FS4;
+        pb += FS4;
+    }
+}
+
+// One wave's whole walk over the work item's rows for its square (bi, bj); DIAG = (bi == bj).  The two shapes are two instances of
+// the WHOLE walk, accumulators included: with one set of accumulators around two step loops the compiler gave each loop its own
+// registers for them (72 + 48 of 128) and spilled.  Every wave passes the same barriers whatever its shape.
+template <int TB, int NWV, int NLD, bool DIAG>
+PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, double* Phi, bool active, int bi, int bj) {
+    constexpr int NT = 64 * NWV;
+    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
+    const int FS = gramt_fs(NBLK);
+    const int O = a.O, D = a.D;
+    const int ROWS = gramt_rows(NBLK, O, NT * NLD), DB = gramt_db(NBLK, O, NT * NLD);
+    const WorkItem wk = a.work[blockIdx.x];
+    f64x4 acc[TB][TB];
+#pragma unroll
+    for (int ii = 0; ii < TB; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) acc[ii][jj] = zero4d();
+
+    // The tile build, as k_gram_wide's: element e of the round's [ROWS][O] chunk of observations is observation e mod O of row
+    // e / O and goes to columns c and O + c; threads 0 .. ROWS - 1 add their row's time features, the constant and the target.
+    // Split in two: the requests (into x[], tgt, rt) and, a round of products later, the writes.
+    const float rO = 1.0f / (float)(O > 0 ? O : 1);
+    const int qt = (a.kind == BASE_LINFEAT) ? 2 * O : 0;        // first of the four time columns (tau, tau^2, tau^3, 1)
+    const int tot = ROWS * O;
+    float x[NLD];
+    double tgt = 0.0;
+    int rt = 0;
+    auto request = [&](int base, int nrows) {
+        if (a.kind == BASE_LINFEAT) {
+            const int lim = nrows * O;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int e = tid + NT * u;
+                x[u] = a.obs[(long long)base * O + (e < lim ? e : 0)];
+            }
+        }
+        if (tid < ROWS) {
+            const int r = tid < nrows ? tid : 0;
+            tgt = a.ret64[base + r];
+            rt = a.row_t[base + r];
+        }
+    };
+    auto build = [&](double* buf, int nrows) {
+        if (a.kind == BASE_LINFEAT) {
+            const int lim = nrows * O;
+            // (the positions are recomputed every round: kept across the products they would cost 2 NLD registers)
+            const int oz = opaque_zero();
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int e = tid + NT * u + oz;
+                if (e < tot) {
+                    const int r = (int)(((float)e + 0.5f) * rO), c = e - r * O;
+                    // (rows past the chunk's last become zeros.)  the reference squares in the observations' own dtype, then promotes
+                    const float oc = e < lim ? fminf(fmaxf(x[u], -10.f), 10.f) : 0.f;
+                    buf[r * FS + c] = (double)oc;
+                    buf[r * FS + O + c] = (double)(oc * oc);
+                }
+                sched_fence();      // one element at a time: interleaved, the NLD elements' temporaries push accumulators into scratch
+            }
+        }
+        if (tid < ROWS) {
+            const bool rv = tid < nrows;
+            const double tau = rv ? (double)rt / 100.0 : 0.0;
+            double* pr = buf + tid * FS;
+            pr[qt] = tau;
+            pr[qt + 1] = tau * tau;
+            pr[qt + 2] = tau * tau * tau;
+            pr[qt + 3] = rv ? 1.0 : 0.0;
+            pr[D] = rv ? tgt : 0.0;
+        }
+    };
+
+    for (int e = tid; e < (DB ? 2 : 1) * ROWS * FS; e += NT) Phi[e] = 0.0;      // columns past D + 1 stay zero
+    __syncthreads();
+    {
+        const int n0 = (wk.row_end - wk.row_begin) < ROWS ? (wk.row_end - wk.row_begin) : ROWS;
+        request(wk.row_begin, n0);
+        build(Phi, n0);
+    }
+    __syncthreads();
+    int cur = 0;
+    const int lofs = kk * FS + i16;
+    for (int base = wk.row_begin; base < wk.row_end; base += ROWS) {
+        const int nrows = (wk.row_end - base) < ROWS ? (wk.row_end - base) : ROWS;
+        const int nbase = base + ROWS;
+        const bool more = nbase < wk.row_end;
+        const int nnext = (wk.row_end - nbase) < ROWS ? (wk.row_end - nbase) : ROWS;
+        if (more) request(nbase, nnext);
+        const double* buf = Phi + cur * ROWS * FS;
+        if (active) {
+            const int nst = (nrows + 3) >> 2;
+            const double* pa = buf + lofs + 16 * TB * bi;
+            const double* pb = buf + lofs + 16 * TB * bj;
+            gramt_steps<TB, DIAG>(acc, pa, pb, nst, 4 * FS);
+        }
+        if (DB) {
+            if (more) build(Phi + (cur ^ 1) * ROWS * FS, nnext);    // nobody reads that tile before the barrier below
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();                                        // the products of this round are done with the tile
+            if (more) build(Phi, nnext);
+            __syncthreads();
+        }
+    }
+    const int NPAIR = NBLK * (NBLK + 1) / 2;
+    double* out = a.gram_partials + (long long)blockIdx.x * (NPAIR * 256);
+#pragma unroll
+    for (int ii = 0; ii < TB; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < TB; ++jj) {
+            const int gi = TB * bi + ii, gj = TB * bj + jj;
+            if (active && gi <= gj && gj < NBLK) {
+                const int p = gi * NBLK - gi * (gi - 1) / 2 + (gj - gi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[p * 256 + (kk + 4 * r) * 16 + i16] = acc[ii][jj][r];
+            }
+        }
+}
+
+template <int TB, int NWV, int NLD>
+__global__ void __launch_bounds__(64 * NWV) k_gram_tiled(SampleArgs a, int NBLK, GramtMap map) {
+    PROMP_SMEM_DECL;
+    const int w = wave_uniform((int)threadIdx.x >> 6);
+    const int NB = gramt_nb(NBLK), NR = NB * (NB + 1) / 2;
+    // this wave's square: band pair bi <= bj of the row-major list
+    const int rect = wave_uniform(gridDim.y == 1 ? (int)map.rect[w] : (int)blockIdx.y * NWV + w);
+    const bool active = rect < NR;
+    int bi = 0, rem = active ? rect : 0;
+    while (rem >= NB - bi) {
+        rem -= NB - bi;
+        ++bi;
+    }
+    const int bj = bi + rem;
+    if (bi == bj) gramt_walk<TB, NWV, NLD, true>(a, NBLK, (double*)PROMP_SMEM_PTR, active, bi, bj);
+    else gramt_walk<TB, NWV, NLD, false>(a, NBLK, (double*)PROMP_SMEM_PTR, active, bi, bj);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fit_wide: the same solve as k_fit when the (D+1)^2 matrices do not fit in LDS (Ant: D = 226).  G and the work matrix live in
 // global memory (L2-resident, 0.4 MB per task).  Right-looking blocked Cholesky, 32-column panels through LDS, the right-hand
 // side carried along as row D (k_fit's forward solve for free):

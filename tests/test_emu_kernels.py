@@ -31,8 +31,25 @@ def test_sample_processing_long_ragged_paths(lib):
 
 
 def test_sample_processing_more_than_seventeen_feature_blocks(lib, two_cus):
-    # obs_dim 140 -> 285 columns = 18 blocks of 16, 171 block pairs: k_gram_wide's pair list in two slices (blockIdx.y)
+    # obs_dim 140 -> 285 columns = 18 blocks of 16 = 6 bands of three, 21 squares: k_gram_tiled in two slices (blockIdx.y)
     pc.check_sample_processing_oracle(lib, 5, M=2, P=3, T=40, O=140, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+
+
+def test_sample_processing_ant_width_tiled_gram(lib, two_cus):
+    # obs_dim 111 -> 227 columns = 15 blocks = 5 bands: 15 squares on the 16 waves of ONE workgroup, host-balanced wave map,
+    # double-buffered 32-row feature tile, partial last rounds (ragged paths)
+    pc.check_sample_processing_oracle(lib, 6, M=2, P=3, T=40, O=111, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+
+
+def test_sample_processing_short_last_band_and_untiled_gram(lib, two_cus, monkeypatch):
+    # obs_dim 100 -> 205 columns = 13 blocks: the fifth band holds one block (the padding columns are zero and never written out);
+    # then the same batch on k_gram_wide (PROMP_GRAM_UNTILED=1, the A/B switch)
+    pc.check_sample_processing_oracle(lib, 7, M=2, P=2, T=40, O=100, ragged=True,
+                                      kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
+    monkeypatch.setenv('PROMP_GRAM_UNTILED', '1')
+    pc.check_sample_processing_oracle(lib, 7, M=2, P=2, T=40, O=100, ragged=True,
                                       kwargs=dict(discount=0.99, gae_lambda=0.97, normalize_adv=True))
 
 
