@@ -141,6 +141,7 @@ struct promp_ctx {
     unsigned *wb_planes = nullptr, *wb_vplanes = nullptr;   // [tasks][wb_planes_words]: k_wb_planes' output for theta / the direction
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
+    bool gramt_single = false;           // PROMP_GRAMT_SINGLE=1: k_gram_tiled with one feature tile (A/B runs against the double-buffered rounds)
     bool gram_untiled = false;           // PROMP_GRAM_UNTILED=1: k_gram_wide at every width (A/B runs against k_gram_tiled)
     int gramt_map_nblk = -1;             // the block count c->gramt_map was balanced for
     GramtMap gramt_map;                  // one-slice k_gram_tiled launches: wave -> rectangle
@@ -831,6 +832,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     c->device = device_id;
     { const char* e = getenv("PROMP_FIT_ONE_LAUNCH"); c->fit_one_launch = e && e[0] == '1'; }
     { const char* e = getenv("PROMP_GRAM_UNTILED"); c->gram_untiled = e && e[0] == '1'; }
+    { const char* e = getenv("PROMP_GRAMT_SINGLE"); c->gramt_single = e && e[0] == '1'; }
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -841,7 +843,10 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
         // higher priority their workgroups are placed first, the string finishes before the main stream needs its result
         int lo = 0, hi = 0;
         HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHECK(hipStreamCreateWithPriority(&c->side, hipStreamDefault, hi));
+        // (PROMP_SIDE_PRIO=lo / none: the A/B switch)
+        const char* e = getenv("PROMP_SIDE_PRIO");
+        if (e && e[0] == 'n') HIPCHECK(hipStreamCreate(&c->side));
+        else HIPCHECK(hipStreamCreateWithPriority(&c->side, hipStreamDefault, (e && e[0] == 'l') ? lo : hi));
     }
     const int K = dims->num_inner_steps, M = dims->n_tasks;
     c->NP = param_count(dims);
@@ -1439,11 +1444,13 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
                 // 13 blocks and more (obs_dim >= 94; Ant: 15, Humanoid: 48): a square of 3 x 3 blocks per wave, operands reused in
                 // registers (k_gram_tiled); fewer blocks make too few squares to fill a compute unit: k_gram_wide
                 if (nblk >= GRAMT_MIN_NBLK && !c->gram_untiled) {
-                    const int nr = gramt_nrect(nblk), cap = 64 * GRAMT_NWV * GRAMT_NLD;
+                    const int nr = gramt_nrect(nblk);
+                    int rows, db;
+                    gramt_cfg(nblk, a.O, 64 * GRAMT_NWV * GRAMT_NLD, c->gramt_single, &rows, &db);
                     if (c->gramt_map_nblk != nblk) { gramt_balance(nblk, GRAMT_NWV, &c->gramt_map); c->gramt_map_nblk = nblk; }
                     auto k = k_gram_tiled<GRAMT_TB, GRAMT_NWV, GRAMT_NLD>;
-                    PROMP_LAUNCH(k, dim3(S.n_work[0], (nr + GRAMT_NWV - 1) / GRAMT_NWV), 64 * GRAMT_NWV, gramt_smem(nblk, a.O, cap), st, a, nblk,
-                                 c->gramt_map);
+                    PROMP_LAUNCH(k, dim3(S.n_work[0], (nr + GRAMT_NWV - 1) / GRAMT_NWV), 64 * GRAMT_NWV, gramt_smem(nblk, rows, db), st, a, nblk,
+                                 c->gramt_map, rows, db);
                     break;
                 }
                 // (more than 17 blocks -- obs_dim > 133: the pair list is cut into slices of <= 160, one workgroup per work item and slice)

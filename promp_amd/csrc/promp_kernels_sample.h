@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
 //     per round, the global latency and the tile build off the matrix pipe's path.  Wider tiles (Humanoid: 16 rows x 784) are
 //     single: the request is still issued a round ahead, the write sits between two barriers.
 //   * A partial last round issues only the k-steps that hold rows.
-// grid = work items (table 0) x slices, block = 64 NWV.  smem: gramt_smem(NBLK, O, NT * NLD).
+// grid = work items (table 0) x slices, block = 64 NWV.  ROWS / DB: gramt_cfg; smem: gramt_smem(NBLK, ROWS, DB).
 // ---------------------------------------------------------------------------------------------
 #define GRAMT_MIN_NBLK 13
 #define GRAMT_TB 3
@@ -804,16 +804,19 @@ PROMP_HD int gramt_fs(int NBLK) {       // 16 x odd: the four k-rows of a step l
     return (nc % 2 == 1) ? 16 * nc : 16 * nc + 16;
 }
 PROMP_HD int gramt_nrect(int NBLK) { return gramt_nb(NBLK) * (gramt_nb(NBLK) + 1) / 2; }
-// rows per round: 32 where the tile fits LDS and the round's observations fit the threads' request registers, else 16
-PROMP_HD int gramt_rows(int NBLK, int O, int cap) {
-    return (sizeof(double) * 32 * (size_t)gramt_fs(NBLK) <= 160 * 1024 && 32 * O <= cap) ? 32 : 16;
+// rows per round and single / double tile: two tiles of 32 or 16 rows where they fit LDS (and a round's observations the
+// threads' request registers: cap = NT * NLD elements) -- the build of round r + 1 then runs beside the products of round r
+// behind ONE barrier per round; `single` (PROMP_GRAMT_SINGLE=1, the A/B switch) or nothing fitting twice: one tile of 32 / 16 rows,
+// the build between two barriers.
+PROMP_HD void gramt_cfg(int NBLK, int O, int cap, bool single, int* rows, int* db) {
+    const size_t row_bytes = sizeof(double) * (size_t)gramt_fs(NBLK), lds = 160 * 1024;
+    if (!single)
+        for (int r = 32; r >= 16; r >>= 1)      // (two tiles of 8 rows measured slower than one of 16 at Humanoid's width: 2.37 vs 2.21 ms)
+            if (2 * r * row_bytes <= lds && r * O <= cap) { *rows = r; *db = 1; return; }
+    *rows = (32 * row_bytes <= lds && 32 * O <= cap) ? 32 : 16;
+    *db = 0;
 }
-PROMP_HD int gramt_db(int NBLK, int O, int cap) {
-    return sizeof(double) * 2 * (size_t)gramt_rows(NBLK, O, cap) * gramt_fs(NBLK) <= 160 * 1024 ? 1 : 0;
-}
-PROMP_HD size_t gramt_smem(int NBLK, int O, int cap) {
-    return sizeof(double) * (size_t)((gramt_db(NBLK, O, cap) ? 2 : 1) * gramt_rows(NBLK, O, cap) * gramt_fs(NBLK));
-}
+PROMP_HD size_t gramt_smem(int NBLK, int rows, int db) { return sizeof(double) * (size_t)((db ? 2 : 1) * rows * gramt_fs(NBLK)); }
 
 // the k-steps of one round for one square: pa / pb = this lane's element of the first block of the row / column band in k-row
 // kk of the tile; FS4 = 4 rows of the tile.  DIAG: row band = column band, only the products jj >= ii.
@@ -840,12 +843,11 @@ PROMP_DEV void gramt_steps(f64x4 (&acc)[TB][TB], const double* pa, const double*
 // the WHOLE walk, accumulators included: with one set of accumulators around two step loops the compiler gave each loop its own
 // registers for them (72 + 48 of 128) and spilled.  Every wave passes the same barriers whatever its shape.
 template <int TB, int NWV, int NLD, bool DIAG>
-PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, double* Phi, bool active, int bi, int bj) {
+PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, int ROWS, int DB, double* Phi, bool active, int bi, int bj) {
     constexpr int NT = 64 * NWV;
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
     const int FS = gramt_fs(NBLK);
     const int O = a.O, D = a.D;
-    const int ROWS = gramt_rows(NBLK, O, NT * NLD), DB = gramt_db(NBLK, O, NT * NLD);
     const WorkItem wk = a.work[blockIdx.x];
     f64x4 acc[TB][TB];
 #pragma unroll
@@ -956,7 +958,7 @@ PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, double* Phi, bool activ
 }
 
 template <int TB, int NWV, int NLD>
-__global__ void __launch_bounds__(64 * NWV) k_gram_tiled(SampleArgs a, int NBLK, GramtMap map) {
+__global__ void __launch_bounds__(64 * NWV) k_gram_tiled(SampleArgs a, int NBLK, GramtMap map, int ROWS, int DB) {
     PROMP_SMEM_DECL;
     const int w = wave_uniform((int)threadIdx.x >> 6);
     const int NB = gramt_nb(NBLK), NR = NB * (NB + 1) / 2;
@@ -969,8 +971,8 @@ __global__ void __launch_bounds__(64 * NWV) k_gram_tiled(SampleArgs a, int NBLK,
         ++bi;
     }
     const int bj = bi + rem;
-    if (bi == bj) gramt_walk<TB, NWV, NLD, true>(a, NBLK, (double*)PROMP_SMEM_PTR, active, bi, bj);
-    else gramt_walk<TB, NWV, NLD, false>(a, NBLK, (double*)PROMP_SMEM_PTR, active, bi, bj);
+    if (bi == bj) gramt_walk<TB, NWV, NLD, true>(a, NBLK, ROWS, DB, (double*)PROMP_SMEM_PTR, active, bi, bj);
+    else gramt_walk<TB, NWV, NLD, false>(a, NBLK, ROWS, DB, (double*)PROMP_SMEM_PTR, active, bi, bj);
 }
 
 // ---------------------------------------------------------------------------------------------

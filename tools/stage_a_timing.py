@@ -3,7 +3,8 @@ back to back on the main stream (no second-stream overlap), for A/B runs of the 
 usage: stage_a_timing.py [tasks [obs_dim]]   (obs_dim > 32: Ant shapes, k_gram_wide / k_fit_wide)"""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from promp_amd import _lib, synthetic
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 40
