@@ -1356,25 +1356,38 @@ int promp_stage_wait(promp_ctx* c) {
 // The baseline fit's buffers of one stream (main / side), allocated on first use: contexts that never fit a LinearFeatureBaseline
 // (policy passes only, ZeroBaseline, advantages handed in) do not pay for them.
 // k_gram_tiled, one slice (at most GRAMT_NWV squares): share the squares out over the waves so that the four SIMDs of a compute
-// unit carry about the same number of matrix instructions per k-step (wave w of a workgroup runs on SIMD w mod 4).  Longest
-// first, each to the least loaded SIMD that still has a wave free; more squares than waves: slices in list order (identity).
+// unit carry about the same number of matrix instructions per k-step (wave w of a workgroup runs on SIMD w mod 4).  Waves to
+// spare take halves of diagonal squares (first row of the triangle / the rest: 3 + 3 products at TB = 3) -- Ant's 15 squares on
+// 16 waves: 10 x 9 + 4 x 6 + 2 x 3 products = 30 per SIMD.  Longest first, each to the least loaded SIMD that still has a wave
+// free.  More squares than waves: slices in list order, diagonal squares whole (the kernel ignores the map).
 void gramt_balance(int nblk, int nwv, GramtMap* map) {
-    const int nb = gramt_nb(nblk), nr = gramt_nrect(nblk);
+    const int nb = gramt_nb(nblk), nr = gramt_nrect(nblk), TB = GRAMT_TB;
     memset(map->rect, 255, sizeof map->rect);
-    if (nr > nwv || nwv > 16) return;       // (the kernel takes slice * NWV + w when gridDim.y > 1)
+    memset(map->part, GRAMT_DIAG, sizeof map->part);
+    if (nr > nwv || nwv > 16) return;
+    struct Piece { int rect, part, cost; };
+    std::vector<Piece> pieces;
+    int spare = nwv - nr;
+    for (int bi = 0, r = 0; bi < nb; ++bi)
+        for (int bj = bi; bj < nb; ++bj, ++r) {
+            if (bi != bj) pieces.push_back({r, GRAMT_FULL, TB * TB});
+            else if (spare > 0) {
+                pieces.push_back({r, GRAMT_DIAG_TOP, TB});
+                pieces.push_back({r, GRAMT_DIAG_REST, TB * (TB + 1) / 2 - TB});
+                --spare;
+            } else pieces.push_back({r, GRAMT_DIAG, TB * (TB + 1) / 2});
+        }
+    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& x, const Piece& y) { return x.cost > y.cost; });
     int slots[4] = {0, 0, 0, 0}, load[4] = {0, 0, 0, 0}, next[4] = {0, 1, 2, 3};
     for (int w = 0; w < nwv; ++w) slots[w & 3]++;
-    for (int pass = 0; pass < 2; ++pass)            // off-diagonal squares (TB^2 products) first, then the diagonal ones
-        for (int bi = 0, r = 0; bi < nb; ++bi)
-            for (int bj = bi; bj < nb; ++bj, ++r) {
-                if ((bi == bj) != (pass == 1)) continue;
-                const int cost = bi == bj ? GRAMT_TB * (GRAMT_TB + 1) / 2 : GRAMT_TB * GRAMT_TB;
-                int q = -1;
-                for (int t = 0; t < 4; ++t)
-                    if (slots[t] > 0 && (q < 0 || load[t] < load[q])) q = t;
-                map->rect[next[q]] = (unsigned char)r;
-                next[q] += 4; slots[q]--; load[q] += cost;
-            }
+    for (const Piece& pc : pieces) {
+        int q = -1;
+        for (int t = 0; t < 4; ++t)
+            if (slots[t] > 0 && (q < 0 || load[t] < load[q])) q = t;
+        map->rect[next[q]] = (unsigned char)pc.rect;
+        map->part[next[q]] = (unsigned char)pc.part;
+        next[q] += 4; slots[q]--; load[q] += pc.cost;
+    }
 }
 
 int fit_buffers(promp_ctx* c, bool on_side) {

@@ -797,7 +797,10 @@ __global__ void __launch_bounds__(512, 2) k_gram_wide(SampleArgs a, int NBLK, in
 #define GRAMT_TB 3
 #define GRAMT_NWV 16
 #define GRAMT_NLD 8
-struct GramtMap { unsigned char rect[16]; };      // one-slice launches: wave -> square (255: none)
+struct GramtMap {        // one-slice launches: wave -> square (255: none) and which part of a diagonal square (GRAMT_*)
+    unsigned char rect[16], part[16];
+};
+enum { GRAMT_FULL = 0, GRAMT_DIAG = 1, GRAMT_DIAG_TOP = 2, GRAMT_DIAG_REST = 3 };
 PROMP_HD int gramt_nb(int NBLK) { return (NBLK + GRAMT_TB - 1) / GRAMT_TB; }
 PROMP_HD int gramt_fs(int NBLK) {       // 16 x odd: the four k-rows of a step land on disjoint banks
     const int nc = GRAMT_TB * gramt_nb(NBLK);
@@ -818,10 +821,18 @@ PROMP_HD void gramt_cfg(int NBLK, int O, int cap, bool single, int* rows, int* d
 }
 PROMP_HD size_t gramt_smem(int NBLK, int rows, int db) { return sizeof(double) * (size_t)((db ? 2 : 1) * rows * gramt_fs(NBLK)); }
 
+// which of a square's TB x TB products a wave of shape SHAPE issues: all (off the diagonal); the upper triangle jj >= ii (a
+// diagonal square); the triangle's first row / its other rows (a diagonal square shared by two waves: with a wave to spare the
+// host splits one so that the four SIMDs carry the same number of products)
+template <int SHAPE>
+PROMP_HD PROMP_CX bool gramt_has(int ii, int jj) {
+    return SHAPE == GRAMT_FULL ? true : SHAPE == GRAMT_DIAG ? jj >= ii : SHAPE == GRAMT_DIAG_TOP ? ii == 0 : (ii >= 1 && jj >= ii);
+}
 // the k-steps of one round for one square: pa / pb = this lane's element of the first block of the row / column band in k-row
-// kk of the tile; FS4 = 4 rows of the tile.  DIAG: row band = column band, only the products jj >= ii.
-template <int TB, bool DIAG>
+// kk of the tile; FS4 = 4 rows of the tile.  On the diagonal the column band IS the row band: one set of operands.
+template <int TB, int SHAPE>
 PROMP_DEV void gramt_steps(f64x4 (&acc)[TB][TB], const double* pa, const double* pb, int nst, int FS4) {
+    constexpr bool DIAG = SHAPE != GRAMT_FULL;
 #pragma unroll 1
     for (int st = 0; st < nst; ++st) {
         double fa[TB], fb[TB];
@@ -833,16 +844,17 @@ PROMP_DEV void gramt_steps(f64x4 (&acc)[TB][TB], const double* pa, const double*
 #pragma unroll
         for (int ii = 0; ii < TB; ++ii)
 #pragma unroll
-            for (int jj = DIAG ? ii : 0; jj < TB; ++jj) acc[ii][jj] = mfma16d(fa[ii], fb[jj], acc[ii][jj]);
+            for (int jj = 0; jj < TB; ++jj)
+                if (gramt_has<SHAPE>(ii, jj)) acc[ii][jj] = mfma16d(fa[ii], fb[jj], acc[ii][jj]);
         pa += FS4;
         pb += FS4;
     }
 }
 
-// One wave's whole walk over the work item's rows for its square (bi, bj); DIAG = (bi == bj).  The two shapes are two instances of
+// One wave's whole walk over the work item's rows for its square (bi, bj); SHAPE: GRAMT_*.  The shapes are separate instances of
 // the WHOLE walk, accumulators included: with one set of accumulators around two step loops the compiler gave each loop its own
 // registers for them (72 + 48 of 128) and spilled.  Every wave passes the same barriers whatever its shape.
-template <int TB, int NWV, int NLD, bool DIAG>
+template <int TB, int NWV, int NLD, int SHAPE>
 PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, int ROWS, int DB, double* Phi, bool active, int bi, int bj) {
     constexpr int NT = 64 * NWV;
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
@@ -930,7 +942,7 @@ PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, int ROWS, int DB, doubl
             const int nst = (nrows + 3) >> 2;
             const double* pa = buf + lofs + 16 * TB * bi;
             const double* pb = buf + lofs + 16 * TB * bj;
-            gramt_steps<TB, DIAG>(acc, pa, pb, nst, 4 * FS);
+            gramt_steps<TB, SHAPE>(acc, pa, pb, nst, 4 * FS);
         }
         if (DB) {
             if (more) build(Phi + (cur ^ 1) * ROWS * FS, nnext);    // nobody reads that tile before the barrier below
@@ -949,7 +961,7 @@ PROMP_DEV void gramt_walk(const SampleArgs& a, int NBLK, int ROWS, int DB, doubl
 #pragma unroll
         for (int jj = 0; jj < TB; ++jj) {
             const int gi = TB * bi + ii, gj = TB * bj + jj;
-            if (active && gi <= gj && gj < NBLK) {
+            if (active && gramt_has<SHAPE>(ii, jj) && gj < NBLK) {
                 const int p = gi * NBLK - gi * (gi - 1) / 2 + (gj - gi);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) out[p * 256 + (kk + 4 * r) * 16 + i16] = acc[ii][jj][r];
@@ -971,8 +983,12 @@ __global__ void __launch_bounds__(64 * NWV) k_gram_tiled(SampleArgs a, int NBLK,
         ++bi;
     }
     const int bj = bi + rem;
-    if (bi == bj) gramt_walk<TB, NWV, NLD, true>(a, NBLK, ROWS, DB, (double*)PROMP_SMEM_PTR, active, bi, bj);
-    else gramt_walk<TB, NWV, NLD, false>(a, NBLK, ROWS, DB, (double*)PROMP_SMEM_PTR, active, bi, bj);
+    const int part = wave_uniform(gridDim.y == 1 ? (int)map.part[w] : GRAMT_DIAG);
+    double* Phi = (double*)PROMP_SMEM_PTR;
+    if (bi != bj) gramt_walk<TB, NWV, NLD, GRAMT_FULL>(a, NBLK, ROWS, DB, Phi, active, bi, bj);
+    else if (part == GRAMT_DIAG_TOP) gramt_walk<TB, NWV, NLD, GRAMT_DIAG_TOP>(a, NBLK, ROWS, DB, Phi, active, bi, bj);
+    else if (part == GRAMT_DIAG_REST) gramt_walk<TB, NWV, NLD, GRAMT_DIAG_REST>(a, NBLK, ROWS, DB, Phi, active, bi, bj);
+    else gramt_walk<TB, NWV, NLD, GRAMT_DIAG>(a, NBLK, ROWS, DB, Phi, active, bi, bj);
 }
 
 // ---------------------------------------------------------------------------------------------
