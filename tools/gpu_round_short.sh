@@ -25,6 +25,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_
 done
 cd $ROOT
 python tools/timeline.py $R/trace > $R/timeline.txt 2>&1
+TIMELINE_STEP=3 python tools/timeline.py $R/trace4 > $R/timeline_config4.txt 2>&1
 rm -f $R/trace/*kernel_trace.csv $R/trace4/*kernel_trace.csv $R/pmc*/*kernel_trace.csv
 timeout 300 python tools/generic_timing.py --case 2 --steps 5 > $R/generic_humanoid.txt 2>&1; head -8 $R/generic_humanoid.txt
 ls $R
