@@ -247,7 +247,8 @@ int promp_policy_forward(promp_ctx* ctx, const float* obs, int batch, float* mea
  *     samplers/meta_sampler.py:87-125 do with one sess.run and a Python loop per environment step.  The rewards
  *     follow once at the end (promp_set_rewards, float32 [rows]); promp_process_samples then needs no upload.
  *     clip_infos != 0: the log_std recorded for agent_infos is max(log_std, log 1e-6) (pre-update policy,
- *     policies/gaussian_mlp_policy.py:71); the noise scale always uses the raw value (:74). */
+ *     policies/gaussian_mlp_policy.py:71); the noise scale always uses the raw value (:74).
+ *     Every policy shape the context accepts is served (layer-by-layer shapes: one workgroup per environment). */
 int promp_begin_rollout(promp_ctx* ctx, int step, int envs_per_task, int path_length);
 /* (a') the same for environments whose episodes end early (samplers/meta_sampler.py:100-125: an environment that reports
  *     `done` is reset and keeps collecting; gym-style termination, e.g. envs/mujoco_envs/ant_rand_direc.py:32-46).  The slab

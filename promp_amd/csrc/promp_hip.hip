@@ -1885,7 +1885,6 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     if (!c || !goals || !start || !o) return fail(-1, "NULL argument");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
     if (c->d.obs_dim != 2 || c->d.act_dim != 2) return fail(-1, "the point environment has obs_dim = act_dim = 2 (context: %d, %d)", c->d.obs_dim, c->d.act_dim);
-    if (c->generic) return fail(-1, "the rollout kernels serve two hidden layers of up to 128 units, act_dim <= 8, obs_dim <= 128");
     if (o->reward_type < 0 || o->reward_type > 2) return fail(-1, "unknown reward type %d", o->reward_type);
     if (begin_fixed_rollout(c, step, envs_per_task, path_length)) return -2;
     const int M = c->d.n_tasks, B = envs_per_task, T = path_length;
@@ -1910,6 +1909,12 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     a.obs = S.obs; a.act = S.act; a.rew = S.rew; a.mean = S.old_mean; a.old_ls = S.old_ls;
     a.clip_infos = o->clip_infos; a.min_log_std = c->min_log_std;
     a.normalization_scale = o->normalization_scale; a.max_step = o->max_step; a.reward_type = o->reward_type; a.sparse_radius = o->sparse_radius;
+    if (c->generic) {          // any layer table: one workgroup per environment (promp_kernels_generic.h)
+        GenPointRolloutArgs g;
+        g.p = a; g.n_lin = c->n_lin; g.act_kind = c->d.hidden_act;
+        for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
+        PROMP_LAUNCH(k_gen_point_rollout, dim3(B, M), 256, gen_rollout_smem(2), st, g);
+    } else
     PROMP_LAUNCH(k_point_rollout, dim3(M), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
     return 0;
@@ -1917,7 +1922,6 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
 
 int promp_begin_rollout(promp_ctx* c, int step, int envs_per_task, int path_length) {
     if (!c) return fail(-1, "ctx is NULL");
-    if (c->generic) return fail(-1, "the rollout kernels serve two hidden layers of up to 128 units, act_dim <= 8, obs_dim <= 128");
     if (begin_fixed_rollout(c, step, envs_per_task, path_length)) return -2;
     c->steps[step].rollout_ragged = false;
     return 0;
@@ -1926,7 +1930,6 @@ int promp_begin_rollout(promp_ctx* c, int step, int envs_per_task, int path_leng
 int promp_begin_collection(promp_ctx* c, int step, int envs_per_task, int max_steps) {
     if (!c) return fail(-1, "ctx is NULL");
     if (step < 0 || step > c->d.num_inner_steps) return fail(-1, "step %d out of range", step);
-    if (c->generic) return fail(-1, "the rollout kernels serve two hidden layers of up to 128 units, act_dim <= 8, obs_dim <= 128");
     if (envs_per_task < 1 || max_steps < 1) return fail(-1, "envs_per_task and max_steps must be positive");
     StepData& S = c->steps[step];
     StepScope scope_(c, S);
@@ -2010,6 +2013,12 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     a.B = B; a.T = T; a.t = t; a.O = O; a.A = A; a.H1 = c->d.hidden1; a.H2 = c->d.hidden2; a.NP = c->NP;
     a.clip_infos = clip_infos; a.min_log_std = c->min_log_std;
     a.seed = seed; a.stream = (unsigned)step;
+    if (c->generic) {          // any layer table: one workgroup per environment (promp_kernels_generic.h)
+        GenPolicyStepArgs g;
+        g.p = a; g.n_lin = c->n_lin; g.act_kind = c->d.hidden_act;
+        for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
+        PROMP_LAUNCH(k_gen_policy_step, dim3(B, M), 256, gen_rollout_smem(O), st, g);
+    } else
     PROMP_LAUNCH(k_policy_step, dim3((B + 63) / 64, M), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(actions_out, d_act, sizeof(float) * n_act, hipMemcpyDeviceToHost, st));

@@ -18,6 +18,7 @@
 // inner objective (kl_weight x grad KL) joins at the mean level.
 #pragma once
 #include "promp_kernels_policy.h"
+#include "promp_kernels_rollout.h"
 
 #define GEN_MAX_LIN 5          // linear layers: up to 4 hidden + the output layer
 #define GEN_R 64               // rows per chunk (4 row blocks of 16)
@@ -542,5 +543,128 @@ __global__ void __launch_bounds__(256) k_gen_policy_forward(GenForwardArgs a) {
             }
             x = y;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rollout-side kernels for any layer table (promp_kernels_rollout.h holds the two-layer forms and the
+// contracts).  One WORKGROUP per environment: thread j owns unit j of a layer (kernel rows read coalesced, the layer's input
+// broadcast from LDS), the layers follow one another behind a barrier -- an environment step at Humanoid's 376 x (64, 64) x 17 is
+// ~500 dependent multiply-adds per thread instead of the 29 k a thread per environment would walk.  Every unit sums its inputs in
+// index order with fmaf, as k_gen_policy_forward and mlp_mean do.
+// ---------------------------------------------------------------------------------------------
+PROMP_HD size_t gen_rollout_smem(int O) { return sizeof(float) * (size_t)(O + 2 * 256); }
+
+// xs [lin[0].K] holds the observation; returns the mean [A] (in LDS, valid for every thread: the last barrier has been passed)
+PROMP_DEV const float* gen_mlp_block(const float* th, const GenLin* lin, int n_lin, int act_kind, const float* xs, float* hs, int tid) {
+    const float* in = xs;
+    for (int l = 0; l < n_lin; ++l) {
+        const GenLin Ly = lin[l];
+        float* out = hs + (l & 1) * 256;
+        if (tid < Ly.N) {
+            float z = th[Ly.b_off + tid];
+            for (int k = 0; k < Ly.K; ++k) z = fmaf(in[k], th[Ly.w_off + k * Ly.N + tid], z);
+            out[tid] = l == n_lin - 1 ? z : gen_act(act_kind, z);
+        }
+        __syncthreads();
+        in = out;
+    }
+    return in;
+}
+
+struct GenPolicyStepArgs {
+    PolicyStepArgs p;          // k_policy_step's arguments (H1 / H2 unused)
+    int n_lin, act_kind;
+    GenLin lin[GEN_MAX_LIN];
+};
+
+// grid = (B, tasks), block = 256.  smem: gen_rollout_smem(O)
+__global__ void __launch_bounds__(256) k_gen_policy_step(GenPolicyStepArgs g) {
+    PROMP_SMEM_DECL;
+    const PolicyStepArgs& a = g.p;
+    float* xs = (float*)PROMP_SMEM_PTR;
+    float* hs = xs + a.O;
+    const int task = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const float* th = a.theta_tasks + (long long)task * a.NP;
+    const int oS = a.NP - a.A;
+    if (a.t == 0 && b == 0 && tid < a.A) {
+        const float ls = th[oS + tid];
+        a.old_ls[task * a.A + tid] = a.clip_infos ? fmaxf(ls, a.min_log_std) : ls;
+    }
+    const long long env = (long long)task * a.B + b, row = env * a.row_env_stride + a.t * a.row_t_stride;
+    const float* x = a.obs_in + env * a.O;
+    for (int k = tid; k < a.O; k += 256) {
+        const float v = x[k];
+        xs[k] = v;
+        a.obs[row * a.O + k] = v;
+    }
+    __syncthreads();
+    const float* mean = gen_mlp_block(th, g.lin, g.n_lin, g.act_kind, xs, hs, tid);
+    const int j = 2 * tid;
+    if (j < a.A) {
+        float n0, n1;
+        action_noise(a.seed, (unsigned long long)row, (unsigned)tid, a.stream, n0, n1);
+        const float a0 = fmaf(expf(th[oS + j]), n0, mean[j]);
+        a.mean[row * a.A + j] = mean[j];
+        a.act[row * a.A + j] = a0;
+        a.actions_out[env * a.A + j] = a0;
+        if (j + 1 < a.A) {
+            const float a1 = fmaf(expf(th[oS + j + 1]), n1, mean[j + 1]);
+            a.mean[row * a.A + j + 1] = mean[j + 1];
+            a.act[row * a.A + j + 1] = a1;
+            a.actions_out[env * a.A + j + 1] = a1;
+        }
+    }
+}
+
+struct GenPointRolloutArgs {
+    PointRolloutArgs p;        // k_point_rollout's arguments (H1 / H2 unused)
+    int n_lin, act_kind;
+    GenLin lin[GEN_MAX_LIN];
+};
+
+// grid = (B, tasks), block = 256: the environment's state lives in thread 0, the network runs on the workgroup.
+// smem: gen_rollout_smem(2)
+__global__ void __launch_bounds__(256) k_gen_point_rollout(GenPointRolloutArgs g) {
+    PROMP_SMEM_DECL;
+    const PointRolloutArgs& a = g.p;
+    float* xs = (float*)PROMP_SMEM_PTR;
+    float* hs = xs + 2;
+    const int task = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
+    const float* th = a.theta_tasks + (long long)task * a.NP;
+    const int oS = a.NP - 2;
+    const float ls0 = th[oS], ls1 = th[oS + 1];
+    if (b == 0 && tid == 0) {
+        a.old_ls[task * 2 + 0] = a.clip_infos ? fmaxf(ls0, a.min_log_std) : ls0;
+        a.old_ls[task * 2 + 1] = a.clip_infos ? fmaxf(ls1, a.min_log_std) : ls1;
+    }
+    const float sd0 = expf(ls0), sd1 = expf(ls1);
+    const double g0 = a.goals[task * 2], g1 = a.goals[task * 2 + 1];
+    const long long env = (long long)task * a.B + b;
+    double s0 = a.start[env * 2], s1 = a.start[env * 2 + 1];       // (advanced by thread 0 only)
+    for (int t = 0; t < a.T; ++t) {
+        const long long row = env * a.T + t;
+        if (tid == 0) {
+            xs[0] = (float)s0;
+            xs[1] = (float)s1;
+        }
+        __syncthreads();
+        const float* m = gen_mlp_block(th, g.lin, g.n_lin, g.act_kind, xs, hs, tid);
+        if (tid == 0) {
+            float n0, n1;
+            if (a.noise != nullptr) {
+                n0 = a.noise[row * 2];
+                n1 = a.noise[row * 2 + 1];
+            } else {
+                action_noise(a.seed, (unsigned long long)row, 0u, a.stream, n0, n1);
+            }
+            const float a0 = fmaf(sd0, n0, m[0]), a1 = fmaf(sd1, n1, m[1]);
+            a.obs[row * 2] = xs[0];  a.obs[row * 2 + 1] = xs[1];
+            a.mean[row * 2] = m[0];  a.mean[row * 2 + 1] = m[1];
+            a.act[row * 2] = a0;  a.act[row * 2 + 1] = a1;
+            const double r = point_env_step(a, s0, s1, g0, g1, a0, a1);
+            a.rew[row] = (float)r;
+        }
+        __syncthreads();       // the next step's observation and hidden vectors overwrite what thread 0 has just read
     }
 }

@@ -173,6 +173,37 @@ struct PointRolloutArgs {
     double sparse_radius;       // 0.5
 };
 
+// one step of the normalised point environment: the state advances in place, the reward comes back
+PROMP_DEV double point_env_step(const PointRolloutArgs& a, double& s0, double& s1, double g0, double g1, float a0, float a1) {
+    // normalize wrapper: lb + (a + s) (ub - lb) / (2 s), clipped to the action box; then the environment's own clip
+    // (same bounds).  Same operation order as normalized_env.py:113-114 so that float64 states agree bit for bit.
+    const double lb = -a.max_step, ub = a.max_step, sc = a.normalization_scale;
+    const double e0 = sc > 0.0 ? lb + ((double)a0 + sc) * (ub - lb) / (2.0 * sc) : (double)a0;
+    const double e1 = sc > 0.0 ? lb + ((double)a1 + sc) * (ub - lb) / (2.0 * sc) : (double)a1;
+    const double d0 = fmin(fmax(e0, lb), ub), d1 = fmin(fmax(e1, lb), ub);
+    const double p0 = s0, p1 = s1;
+    s0 += d0;
+    s1 += d1;
+    const double dist = point_distance(s0, s1, g0, g1);
+    double r;
+    if (a.reward_type == POINT_REWARD_DENSE) {
+        r = -dist;
+    } else if (a.reward_type == POINT_REWARD_DENSE_SQUARED) {
+        r = -(dist * dist);
+    } else {
+        r = 0.0;
+        if (fabs(s0) + fabs(s1) >= a.sparse_radius) {        // left the start region (L1 norm)
+            double nearest = dist;
+            for (int c = 0; c < 4; ++c) {                    // corners (-2,-2), (2,-2), (-2,2), (2,2)
+                const double c0 = (c & 1) ? 2.0 : -2.0, c1 = (c & 2) ? 2.0 : -2.0;
+                nearest = fmin(nearest, point_distance(s0, s1, c0, c1));
+            }
+            if (dist == nearest) r = point_distance(p0, p1, g0, g1) - dist;   // progress
+        }
+    }
+    return r;
+}
+
 // grid = tasks, block = 64
 __global__ void __launch_bounds__(64) k_point_rollout(PointRolloutArgs a) {
     const int task = blockIdx.x;
@@ -203,32 +234,7 @@ __global__ void __launch_bounds__(64) k_point_rollout(PointRolloutArgs a) {
             a.obs[row * 2] = o[0];  a.obs[row * 2 + 1] = o[1];
             a.mean[row * 2] = m[0];  a.mean[row * 2 + 1] = m[1];
             a.act[row * 2] = a0;  a.act[row * 2 + 1] = a1;
-            // normalize wrapper: lb + (a + s) (ub - lb) / (2 s), clipped to the action box; then the environment's own clip
-            // (same bounds).  Same operation order as normalized_env.py:113-114 so that float64 states agree bit for bit.
-            const double lb = -a.max_step, ub = a.max_step, sc = a.normalization_scale;
-            const double e0 = sc > 0.0 ? lb + ((double)a0 + sc) * (ub - lb) / (2.0 * sc) : (double)a0;
-            const double e1 = sc > 0.0 ? lb + ((double)a1 + sc) * (ub - lb) / (2.0 * sc) : (double)a1;
-            const double d0 = fmin(fmax(e0, lb), ub), d1 = fmin(fmax(e1, lb), ub);
-            const double p0 = s0, p1 = s1;
-            s0 += d0;
-            s1 += d1;
-            const double dist = point_distance(s0, s1, g0, g1);
-            double r;
-            if (a.reward_type == POINT_REWARD_DENSE) {
-                r = -dist;
-            } else if (a.reward_type == POINT_REWARD_DENSE_SQUARED) {
-                r = -(dist * dist);
-            } else {
-                r = 0.0;
-                if (fabs(s0) + fabs(s1) >= a.sparse_radius) {        // left the start region (L1 norm)
-                    double nearest = dist;
-                    for (int c = 0; c < 4; ++c) {                    // corners (-2,-2), (2,-2), (-2,2), (2,2)
-                        const double c0 = (c & 1) ? 2.0 : -2.0, c1 = (c & 2) ? 2.0 : -2.0;
-                        nearest = fmin(nearest, point_distance(s0, s1, c0, c1));
-                    }
-                    if (dist == nearest) r = point_distance(p0, p1, g0, g1) - dist;   // progress
-                }
-            }
+            const double r = point_env_step(a, s0, s1, g0, g1, a0, a1);
             a.rew[row] = (float)r;
         }
     }

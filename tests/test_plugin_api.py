@@ -150,7 +150,7 @@ def run_trainer_scenario(n_itr=2, device_rollouts=False, log_dir=None, resume=No
     assert any(np.any(before[k] != after[k]) for k in before) and all(np.all(np.isfinite(v)) for v in after.values())
 
 
-def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sparse'):
+def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sparse', hidden_act='tanh'):
     """DevicePointEnvSampler: the trajectories equal a float64 NumPy rollout of the same environment with the same start
     states and noise (oracle/point_rollout.py, itself pinned by the reference environment's own trajectories); process_samples
     takes the resident slab (no upload) and returns what it returns for the same paths handed over as plain host dicts."""
@@ -163,10 +163,11 @@ def run_device_rollout_scenario(M=3, B=4, T=15, hidden=(32, 32), reward_type='sp
     from promp_amd.samplers.meta_sample_processor import MetaSampleProcessor
     np.random.seed(21)
     env = normalize(MetaPointEnvCorner(reward_type=reward_type))
-    policy = MetaGaussianMLPPolicy(name='p', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=hidden)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=2, action_dim=2, meta_batch_size=M, hidden_sizes=hidden,
+                                   hidden_nonlinearity=None if hidden_act == 'identity' else hidden_act)
     sampler = DevicePointEnvSampler(env=env, policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
     sampler.update_tasks()
-    spec = op.PolicySpec(2, 2, hidden)
+    spec = op.PolicySpec(2, 2, hidden, hidden_act=hidden_act)
     theta = spec.from_ordered_dict(policy.get_param_values())
     theta[-2:] = np.log(12.0)             # wide exploration: actions beyond the wrapper's +-10 box, points that leave the start region
     policy.set_params(spec.to_ordered_dict(theta))
@@ -245,7 +246,7 @@ def test_device_rollout_point_env(emu):
     run_device_rollout_scenario(M=2, B=3, T=9, reward_type='dense_squared')
 
 
-def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
+def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32), hidden_act='tanh'):
     """DeviceSlabSampler: every environment step is one promp_policy_step; the slab rows equal the oracle's forward pass plus
     the oracle's Philox noise; rewards arrive once; process_samples uploads nothing; an early `done` falls back to the host."""
     from oracle import philox, policy as op
@@ -269,7 +270,8 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
             return self.s.copy(), -float(np.abs(self.s).sum()), bool(self.stop_at and self.t >= self.stop_at), dict(t=self.t)
 
     np.random.seed(5)
-    policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+    policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden,
+                                   hidden_nonlinearity=None if hidden_act == 'identity' else hidden_act)
     sampler = DeviceSlabSampler(env=DriftEnv(), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
     sampler.update_tasks()
     policy.switch_to_pre_update()
@@ -277,7 +279,7 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32)):
     paths = sampler.obtain_samples()
     np.random.set_state(state)
     seed = int(np.random.randint(0, 2 ** 31 - 1))
-    spec = op.PolicySpec(O, A, hidden)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act)
     theta = spec.from_ordered_dict(policy.get_param_values()).astype(np.float64)
     assert sampler.host_fallbacks == 0 and all(len(paths[i]) == B for i in range(M))
     cat = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths[i]])
@@ -569,6 +571,15 @@ def test_trainer_snapshot_round_trip(emu, tmp_path):
 
 def test_policy_step_fills_the_slab(emu):
     run_policy_step_scenario()
+
+
+def test_rollout_kernels_on_any_layer_table(emu):
+    """Shapes outside the two-layer kernels (a third layer, more than 8 actions, relu / linear hidden units) collect on the device too:
+    one workgroup per environment walks the layer table (k_gen_policy_step / k_gen_point_rollout)."""
+    run_policy_step_scenario(M=2, B=3, T=5, O=9, A=11, hidden=(48, 40, 24))
+    run_policy_step_scenario(M=2, B=2, T=4, O=5, A=3, hidden=(20,), hidden_act='relu')
+    run_device_rollout_scenario(M=2, B=3, T=9, hidden=(32, 16, 24), reward_type='sparse')
+    run_device_rollout_scenario(M=2, B=2, T=6, hidden=(24, 24), reward_type='dense', hidden_act='identity')
 
 
 def test_device_rollout_point_env_with_device_noise(emu):
