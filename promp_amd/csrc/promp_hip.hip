@@ -1494,7 +1494,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             PROMP_LAUNCH(kp, dim3(c->d.n_tasks), FITW_NT, fitw_panel_smem(a.D, NB), st, a, fit_scratch, k0);                        \
             if (k0 + NB < a.D) PROMP_LAUNCH(ku, dim3(c->d.n_tasks, FITW_UPD_SPLIT), FITW_NT, fitw_panel_smem(a.D, NB), st, a, fit_scratch, k0); \
         }                                                                                                                           \
-        PROMP_LAUNCH(kb, dim3(c->d.n_tasks), FITW_NT, fitw_back_smem(a.D), st, a, fit_scratch, bad);                               \
+        PROMP_LAUNCH(kb, dim3(c->d.n_tasks), FITW_NT, fitw_back_smem(a.D, NB), st, a, fit_scratch, bad);                               \
         PROMP_LAUNCH(kf, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, NB), st, a, nblk, fit_scratch, (const int*)bad);               \
     } else { auto k = k_fit_wide<NB>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITW_NT, fitw_smem(a.D, NB), st, a, nblk, fit_scratch, none); }
             if (fitw_nb(a.D) == 32) { PROMP_FITW(32) } else { PROMP_FITW(16) }

@@ -1059,6 +1059,94 @@ __global__ void __launch_bounds__(256) k_gram_sum_wide(SampleArgs a, int NBLK, d
     }
 }
 
+// Back substitution L^T w = z over the factor's NB-row blocks from the bottom up (k_fit_wide, k_fitw_back): wave 0 solves the block's
+// triangle in registers (lane t holds y[kb + t] and column t of the transposed triangle), the other waves then apply the block's
+// solved entries to the rows above, one row per thread.  yv = z on entry (LDS, written by the caller without a barrier), rdv =
+// 1 / diag(L) (LDS, likewise), the result goes to wv (LDS); tri: 2 x NB x (NB + 1) doubles of LDS.
+// The factor lives in global memory (L2) and is final, so nothing taken from there depends on the solve: a thread requests the NB
+// factor entries of its row BEFORE wave 0 solves the block, and the NEXT block's triangle is requested at the same point (by waves
+// 1.., a few entries per thread, parked in LDS behind the first barrier: in wave 0's registers a second triangle spilled) -- a block
+// costs one solve (NB dependent steps) instead of two round trips to L2 plus the solve (21 % of k_fit_wide's time at Ant's 8 blocks;
+// 48 blocks at Humanoid's width).  Same operations on the same values in the same order as the loop it replaces.
+template <int NB>
+PROMP_DEV void fitw_back_substitute(const double* Wm, int D, int DA, double* yv, double* wv, const double* rdv, double* tri, int tid,
+                                    int lane, int w) {
+    constexpr int NT = FITW_NT, NH = NT - 64, TS = NB + 1, NTV = (NB * NB + NH - 1) / NH;
+    const int row = tid - 64;                 // (wave 0 solves; the rows above and the prefetch belong to the other waves)
+    int kb = ((D - 1) / NB) * NB, cur = 0;
+    {
+        const int nb = (D - kb) < NB ? (D - kb) : NB;
+        for (int e = row; e >= 0 && e < NB * NB; e += NH) {
+            const int j = e / NB, t = e - j * NB;
+            if (j < nb && j > t) tri[j * TS + t] = Wm[(size_t)(kb + j) * DA + kb + t];
+        }
+    }
+    __syncthreads();
+    for (; kb >= 0; kb -= NB) {
+        const int nb = (D - kb) < NB ? (D - kb) : NB;
+        const bool mine = row >= 0 && row < kb;
+        double lv[NB], tv[NTV];
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + row];     // all in flight together
+        }
+        if (row >= 0 && kb >= NB) {           // the next block's triangle (every block above the last one is full)
+            const int kn = kb - NB;
+#pragma unroll
+            for (int u = 0; u < NTV; ++u) {
+                const int e = row + u * NH, j = e / NB, t = e - j * NB;
+                tv[u] = (e < NB * NB && j > t) ? Wm[(size_t)(kn + j) * DA + kn + t] : 0.0;
+            }
+        }
+        if (w == 0) {
+            const int t = lane < nb ? lane : nb - 1;
+            const double* T = tri + cur * NB * TS;
+            double W[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) W[j] = (j < nb && j > t) ? T[j * TS + t] : 0.0;
+            double y = yv[kb + t];
+            const double rd = rdv[kb + t];
+            double wsol = 0.0;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; --j) {
+                if (j < nb) {
+                    const double wj = readlane_f64(y, j) * readlane_f64(rd, j);
+                    if (lane == j) wsol = wj;
+                    if (lane < j) y -= W[j] * wj;
+                }
+            }
+            if (lane < nb) wv[kb + lane] = wsol;
+        }
+        __syncthreads();
+        // the rows above: y[i] -= sum_r L[kb + r][i] w[kb + r]
+        if (mine) {
+            double s = yv[row];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
+            yv[row] = s;
+        }
+        for (int i = row + NH; row >= 0 && i < kb; i += NH) {         // (more than NT - 64 rows above: Humanoid's first blocks)
+            double l2[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) l2[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];
+            double s = yv[i];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) s -= (r < nb) ? l2[r] * wv[kb + r] : 0.0;
+            yv[i] = s;
+        }
+        if (row >= 0 && kb >= NB) {
+            double* Tn = tri + (cur ^ 1) * NB * TS;
+#pragma unroll
+            for (int u = 0; u < NTV; ++u) {
+                const int e = row + u * NH, j = e / NB, t = e - j * NB;
+                if (e < NB * NB && j > t) Tn[j * TS + t] = tv[u];
+            }
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
 // only_bad != nullptr: the launch behind the one-launch-per-phase factorisation below -- tasks whose flag is 0 are done; the others
 // (a NaN in the solution: the ridge term was too small) start over at the second attempt, reg x 10, exactly as they would have here.
 template <int NB>
@@ -1194,43 +1282,13 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
             __syncthreads();
             FITW_PHASE(5);
         }
-        // ---- back substitution L^T w = z, z = row D of the factor, 32 rows of L at a time
-        for (int e = tid; e < D; e += NT) yv[e] = Wm[(size_t)D * DA + e];
-        __syncthreads();
-        for (int kb = ((D - 1) / NB) * NB; kb >= 0; kb -= NB) {
-            const int nb = (D - kb) < NB ? (D - kb) : NB;
-            if (w == 0) {
-                // lane t holds y[kb + t] and column t of the block's transposed triangle (L[kb + j][kb + t], j > t) in registers
-                const int t = lane < nb ? lane : nb - 1;
-                double W[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) W[j] = (j < nb && j > t) ? Wm[(size_t)(kb + j) * DA + kb + t] : 0.0;
-                double y = yv[kb + t];
-                const double rd = 1.0 / dg[kb + t];
-                double wsol = 0.0;
-#pragma unroll
-                for (int j = NB - 1; j >= 0; --j) {
-                    if (j < nb) {
-                        const double wj = readlane_f64(y, j) * readlane_f64(rd, j);
-                        if (lane == j) wsol = wj;
-                        if (lane < j) y -= W[j] * wj;
-                    }
-                }
-                if (lane < nb) wv[kb + lane] = wsol;
-            }
-            __syncthreads();
-            // the rows above: y[i] -= sum_r L[kb + r][i] w[kb + r]
-            for (int i = tid; i < kb; i += NT) {
-                double lv[NB];
-#pragma unroll
-                for (int r = 0; r < NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];     // all in flight together
-                double s = yv[i];
-#pragma unroll
-                for (int r = 0; r < NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
-                yv[i] = s;
-            }
-            __syncthreads();
+        // ---- back substitution L^T w = z, z = row D of the factor, 32 rows of L at a time (the reciprocals of the factor's diagonal
+        //      take the diagonal's place: one division per thread here instead of one per block on wave 0's chain)
+        for (int e = tid; e < D; e += NT) {
+            yv[e] = Wm[(size_t)D * DA + e];
+            dg[e] = 1.0 / dg[e];
         }
+        fitw_back_substitute<NB>(Wm, D, DA, yv, wv, dg, Pn, tid, lane, w);     // (the panel's LDS is free: two triangles)
         FITW_PHASE(6);
         if (tid == 0) *flag = 0;
         __syncthreads();
@@ -1265,7 +1323,7 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
 #define FITW_UPD_SPLIT 6          // 40 tasks x 6 = 240 workgroups
 #define FITW_ML_MIN_D 400         // below: k_fit_wide (8 panels at Ant's 226 columns are a chain of dependent steps, not tile work)
 PROMP_HD size_t fitw_panel_smem(int D, int nb) { return sizeof(double) * ((size_t)(D + 1 + 16) * (nb + 1) + nb + 2); }
-PROMP_HD size_t fitw_back_smem(int D) { return sizeof(double) * ((size_t)2 * (D + 1) + 2); }
+PROMP_HD size_t fitw_back_smem(int D, int nb) { return sizeof(double) * ((size_t)3 * (D + 1) + 2 * nb * (nb + 1) + 2); }
 
 template <int NB>
 __global__ void __launch_bounds__(FITW_NT) k_fitw_panel(SampleArgs a, double* scratch, int k0) {
@@ -1383,44 +1441,17 @@ __global__ void __launch_bounds__(FITW_NT) k_fitw_back(SampleArgs a, double* scr
     const int tid = threadIdx.x, task = blockIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
     double* yv = (double*)PROMP_SMEM_PTR;
     double* wv = yv + DA;
-    int* flag = (int*)(wv + DA);
+    double* rdv = wv + DA;                    // 1 / diag(L)
+    double* tri = rdv + DA;                   // two triangles of the factor's diagonal blocks
+    int* flag = (int*)(tri + 2 * NB * (NB + 1));
     const double* Wm = scratch + (size_t)task * 2 * DA * DA + (size_t)DA * DA;
     // ---- back substitution L^T w = z, z = row D of the factor, NB rows of L at a time (k_fit_wide's)
-    for (int e = tid; e < D; e += NT) yv[e] = Wm[(size_t)D * DA + e];
-    if (tid == 0) *flag = 0;
-    __syncthreads();
-    for (int kb = ((D - 1) / NB) * NB; kb >= 0; kb -= NB) {
-        const int nb = (D - kb) < NB ? (D - kb) : NB;
-        if (w == 0) {
-            const int t = lane < nb ? lane : nb - 1;
-            double W[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) W[j] = (j < nb && j > t) ? Wm[(size_t)(kb + j) * DA + kb + t] : 0.0;
-            double y = yv[kb + t];
-            const double rd = 1.0 / Wm[(size_t)(kb + t) * DA + kb + t];
-            double wsol = 0.0;
-#pragma unroll
-            for (int j = NB - 1; j >= 0; --j) {
-                if (j < nb) {
-                    const double wj = readlane_f64(y, j) * readlane_f64(rd, j);
-                    if (lane == j) wsol = wj;
-                    if (lane < j) y -= W[j] * wj;
-                }
-            }
-            if (lane < nb) wv[kb + lane] = wsol;
-        }
-        __syncthreads();
-        for (int i = tid; i < kb; i += NT) {
-            double lv[NB];
-#pragma unroll
-            for (int r = 0; r < NB; ++r) lv[r] = Wm[(size_t)(kb + (r < nb ? r : 0)) * DA + i];
-            double s = yv[i];
-#pragma unroll
-            for (int r = 0; r < NB; ++r) s -= (r < nb) ? lv[r] * wv[kb + r] : 0.0;
-            yv[i] = s;
-        }
-        __syncthreads();
+    for (int e = tid; e < D; e += NT) {
+        yv[e] = Wm[(size_t)D * DA + e];
+        rdv[e] = 1.0 / Wm[(size_t)e * DA + e];
     }
+    if (tid == 0) *flag = 0;
+    fitw_back_substitute<NB>(Wm, D, DA, yv, wv, rdv, tri, tid, lane, w);
     for (int e = tid; e < D; e += NT)
         if (wv[e] != wv[e]) *flag = 1;
     __syncthreads();

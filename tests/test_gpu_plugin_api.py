@@ -58,7 +58,7 @@ def test_policy_step_fills_the_slab():
 def test_rollout_kernels_on_any_layer_table():
     scen.test_rollout_kernels_on_any_layer_table(None)
     scen.run_policy_step_scenario(M=4, B=20, T=6, O=376, A=17, hidden=(64, 64))        # Humanoid's dimensions
-    scen.run_policy_step_scenario(M=3, B=5, T=4, O=30, A=6, hidden=(256, 256), hidden_act='relu')
+    scen.run_policy_step_scenario(M=3, B=5, T=6, O=30, A=6, hidden=(256, 256), hidden_act='relu')
     scen.run_device_rollout_scenario(M=4, B=20, T=100, hidden=(64, 64, 64), reward_type='sparse')
 
 
