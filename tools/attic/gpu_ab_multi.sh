@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer tool: several library builds (tools/ablate/lib_<name>.so) against each other on one box, configs 3 and 4, alternating
-# usage: bash tools/gpu_ab_multi.sh name1 name2 ...
+# usage: bash tools/attic/gpu_ab_multi.sh name1 name2 ...
 mkdir -p gpurun_out/ab
 cp promp_amd/libpromp_hip.so /tmp/lib_keep.so
 for rep in 1 2; do for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # developer tool: A/B of two library builds on the same box: tools/ablate/lib_<A>.so against lib_<B>.so, config 4, alternating
-# usage: bash tools/gpu_ab_wb.sh A B [config]
+# usage: bash tools/attic/gpu_ab_wb.sh A B [config]
 A=$1; B=$2; CFG=${3:-4}
 mkdir -p gpurun_out/ab
 cp promp_amd/libpromp_hip.so /tmp/lib_keep.so
