@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
                 // ---- the diagonal block, one wave, rows in registers (lanes >= nb shadow the last row: finite, never stored)
                 const int row = lane < nb ? lane : nb - 1;
                 double W[NB];
-                double rdg = 1.0;
+                double rdg = 1.0, dgv = 0.0;
 #pragma unroll
                 for (int k = 0; k < NB; ++k) W[k] = Pn[row * PS + k];
 #pragma unroll
@@ -1206,6 +1206,8 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
                         const double dj = readlane_f64(W[j], j), rs = rsqrt(dj), piv = dj * rs;
                         W[j] = (lane == j) ? piv : W[j] * rs;
                         rdg = (lane == j) ? rs : rdg;
+                        dgv = (lane == j) ? piv : dgv;       // (W[lane] read at the end would index the array by a runtime value: the
+                                                             //  whole row then lives in scratch memory, loop included)
 #pragma unroll
                         for (int k = j + 1; k < NB; ++k) W[k] -= W[j] * readlane_f64(W[j], k);     // lane k holds L[k][j] in W[j]
                     }
@@ -1214,7 +1216,7 @@ __global__ void __launch_bounds__(FITW_NT) k_fit_wide(SampleArgs a, int NBLK, do
 #pragma unroll
                     for (int k = 0; k < NB; ++k)
                         if (k <= lane) Pn[lane * PS + k] = W[k];
-                    dg[k0 + lane] = W[lane];
+                    dg[k0 + lane] = dgv;
                     rdp[lane] = rdg;
                 }
             }
