@@ -167,7 +167,11 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
     const bool vec = (Kc & 3) == 0 && (((size_t)Ain) & 15) == 0 && (RAin == nullptr || (((size_t)RAin) & 15) == 0);
     const int rb0 = NBW == 1 ? (w >> 1) : 0;
     const int sr = tid >> 2, so = tid & 3;       // staging: row, 8-entry part
-    float xa[8], xra[8];
+    // The requested chunk of activations (and of their tangents) stays in four VECTOR values across the products, not in float
+    // arrays: with arrays the scalar-load path below kept a runtime-indexed store, the arrays then lived partly in scratch memory, and
+    // in the tangent modes every 16-byte request was waited for (s_waitcnt vmcnt(0)) and copied to scratch on the spot -- four
+    // serial round trips to memory per request instead of a prefetch under the products.
+    f32x4 xa0 = {0.f, 0.f, 0.f, 0.f}, xa1 = xa0, xra0 = xa0, xra1 = xa0;
     u32x4 pb[NPB], pu[NPB];
     const int rstep = GB_R * (int)gridDim.y;
     auto issue = [&](int row0, int k0) {
@@ -175,23 +179,25 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
         const long long ro = (long long)(row0 + (sr < nrows ? sr : nrows - 1)) * Kc;
         const int k = k0 + 8 * so;
         if (vec) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kq = k + 4 * h < Kc ? k + 4 * h : 0;
-                const f32x4 v = *(const f32x4*)(Ain + ro + kq);
-                xa[4 * h] = v[0]; xa[4 * h + 1] = v[1]; xa[4 * h + 2] = v[2]; xa[4 * h + 3] = v[3];
-                if (TAN && RAin != nullptr) {
-                    const f32x4 rv = *(const f32x4*)(RAin + ro + kq);
-                    xra[4 * h] = rv[0]; xra[4 * h + 1] = rv[1]; xra[4 * h + 2] = rv[2]; xra[4 * h + 3] = rv[3];
-                }
+            const int kq0 = k < Kc ? k : 0, kq1 = k + 4 < Kc ? k + 4 : 0;
+            xa0 = *(const f32x4*)(Ain + ro + kq0);
+            xa1 = *(const f32x4*)(Ain + ro + kq1);
+            if (TAN && RAin != nullptr) {
+                xra0 = *(const f32x4*)(RAin + ro + kq0);
+                xra1 = *(const f32x4*)(RAin + ro + kq1);
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kq = k + i < Kc ? k + i : Kc - 1;
-                xa[i] = Ain[ro + kq];
-                if (TAN && RAin != nullptr) xra[i] = RAin[ro + kq];
+            const float* pa_ = Ain + ro;
+            const int km = Kc - 1;
+#define GB_KQ(i) (k + (i) < Kc ? k + (i) : km)
+            xa0 = f32x4{pa_[GB_KQ(0)], pa_[GB_KQ(1)], pa_[GB_KQ(2)], pa_[GB_KQ(3)]};
+            xa1 = f32x4{pa_[GB_KQ(4)], pa_[GB_KQ(5)], pa_[GB_KQ(6)], pa_[GB_KQ(7)]};
+            if (TAN && RAin != nullptr) {
+                const float* pr_ = RAin + ro;
+                xra0 = f32x4{pr_[GB_KQ(0)], pr_[GB_KQ(1)], pr_[GB_KQ(2)], pr_[GB_KQ(3)]};
+                xra1 = f32x4{pr_[GB_KQ(4)], pr_[GB_KQ(5)], pr_[GB_KQ(6)], pr_[GB_KQ(7)]};
             }
+#undef GB_KQ
         }
         const long long cb = (long long)(k0 >> 5) * (12 * NC);
 #pragma unroll
@@ -222,8 +228,8 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const bool ok = sr < nrows && k0 + 8 * so + i < Kc;
-                    x[i] = ok ? xa[i] : 0.f;
-                    rx[i] = (TAN && ok && RAin != nullptr) ? xra[i] : 0.f;
+                    x[i] = ok ? (i < 4 ? xa0[i & 3] : xa1[i & 3]) : 0.f;
+                    rx[i] = (TAN && ok && RAin != nullptr) ? (i < 4 ? xra0[i & 3] : xra1[i & 3]) : 0.f;
                 }
                 gb_split_store(x, As, 64, sr, so);
                 if (TAN) gb_split_store(rx, RAs, 64, sr, so);
