@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) k_gb_planes(GbPlaneArgs a) {
                 const int ct = 8 * oc + 2 * i + h;
                 const bool ok = orient ? (ct < N && col < K) : (ct < K && col < N);
                 const long long o = orient ? (long long)col * N + ct : (long long)ct * N + col;
-                x[h] = ok ? a.sign * W[o] : 0.f;
+                const float wv = W[ok ? o : 0];          // (unconditional: a load under `ok ? :` is a branch and a wait of its own -- eight serial round trips per thread)
+                x[h] = ok ? a.sign * wv : 0.f;
             }
             unsigned t[3];
             bf16_split3_pair(x[0], x[1], t);
