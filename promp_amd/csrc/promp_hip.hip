@@ -1482,7 +1482,7 @@ int promp_process_samples(promp_ctx* c, int step, const promp_proc_opts* o) {
             else if (DA <= 64) { auto k = k_fit_wave<64>; PROMP_LAUNCH(k, dim3(c->d.n_tasks), FITWV_NT, fit_smem, st, a, nblk); }
             else PROMP_LAUNCH(k_fit, dim3(c->d.n_tasks), 256, fit_smem, st, a, nblk);
         } else {
-            PROMP_LAUNCH(k_gram_sum_wide, dim3(c->d.n_tasks * FITW_SUM_SPLIT), 256, 0, st, a, nblk, fit_scratch);
+            PROMP_LAUNCH(k_gram_sum_wide, dim3(c->d.n_tasks * fitw_sum_split(nblk)), 256, 0, st, a, nblk, fit_scratch, fitw_sum_split(nblk));
             HIPCHECK(hipGetLastError());
             const int* none = nullptr;
             int* bad = (int*)(fit_scratch + (size_t)c->d.n_tasks * 2 * (c->Dmax + 1) * (c->Dmax + 1));

@@ -1016,11 +1016,13 @@ PROMP_HD size_t fitw_smem(int D, int nb) {
 PROMP_HD int fitw_nb(int D) { return fitw_smem(D, FITW_NB) <= 160 * 1024 ? FITW_NB : 16; }
 
 // The task's partial Gram blocks summed in workgroup order and scattered into the symmetric matrix G -- and G + reg I into the
-// work matrix of the first factorisation attempt -- by the WHOLE chip (grid = tasks x FITW_SUM_SPLIT): inside k_fit_wide the sum
+// work matrix of the first factorisation attempt -- by the WHOLE chip (grid = tasks x fitw_sum_split(NBLK)): inside k_fit_wide the sum
 // ran on one compute unit per task (40 of 256 busy, a quarter of that kernel's time at Ant's size).
 // scratch: [tasks][2][(D+1)^2].  block = 256.
-#define FITW_SUM_SPLIT 8
-__global__ void __launch_bounds__(256) k_gram_sum_wide(SampleArgs a, int NBLK, double* scratch) {
+// (the split grows with the matrix: Humanoid's 1176 blocks of 256 entries per task are 617 MB of partial blocks per launch, and with
+//  8 workgroups per task the loads in flight -- not the memory system -- set the pace; every entry is still one thread's sum in workgroup order)
+PROMP_HD int fitw_sum_split(int NBLK) { return NBLK >= 32 ? 32 : NBLK >= 13 ? 16 : 8; }
+__global__ void __launch_bounds__(256) k_gram_sum_wide(SampleArgs a, int NBLK, double* scratch, int FITW_SUM_SPLIT) {
     const int D = a.D, DA = D + 1;
     const int task = blockIdx.x / FITW_SUM_SPLIT, part = blockIdx.x % FITW_SUM_SPLIT;
     double* G = scratch + (size_t)task * 2 * DA * DA;
