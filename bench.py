@@ -271,6 +271,7 @@ def main():
         elapsed = float(np.median(loops))
     if not np.isfinite(res['loss_after']):
         raise SystemExit('bench: non-finite loss')
+    split_events = dict(ctx.split_events(), steps=args.warmup + args.steps * len(loops))      # over the warm-up and every timed loop
     env_steps = M_global * N * (K + 1) * args.steps
     value = env_steps / elapsed
 
@@ -279,6 +280,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'timed_loops_ms_per_step': [1e3 * e / args.steps for e in loops],
+        'fp16_split_events': split_events,
         'config': {'workload': 'BASELINE config %d: %d-task %s shapes (obs=%d, act=%d, 2x%d tanh MLP, H=%d, '
                                'P=%d paths/task, K=1 inner step, %s); process_samples x2 + _adapt + '
                                'optimize_policy per step' % (args.config, M_global, ENV_NAMES[args.config], O, A, hidden[0], T, P,
@@ -292,10 +294,12 @@ def main():
                                 'oracle on gradient and Hessian-vector product, the exact-FP32 kernels\' own level; guarded by '
                                 'test_split_gemm_accuracy_guard); sample processing float64') if (hidden[0] == 128 and O <= 127) else
                                'float32-equivalent: the first-order passes (k_pass) compute every GEMM, and the second-order pass '
-                               '(k_chain_hvp) its layer 2, as 6 BF16 products of a 3-way error-compensated split with float32 '
-                               'accumulation (measured <= 1.0e-6 of the float64 oracle, the FP32 fma chain\'s own level; a 3-product '
-                               'build measures 5e-6 .. 5e-5; guarded at 2.5e-6 by test_split_gemm_accuracy_guard); the other GEMMs '
-                               'of the second-order pass on the exact-FP32 MFMA; sample processing float64',
+                               '(k_chain_hvp) its layer 2, backward product and hidden_1 kernel gradient, as 3 FP16 products of a '
+                               'two-term error-compensated split (hi.hi + hi.lo + lo.hi, float32 accumulation, operands kept inside '
+                               'FP16\'s range by exact powers of two that follow the data: fp16_split_events counts the tiles / segments '
+                               'walked again for it); measured <= 1.2e-6 of the float64 oracle, the FP32 fma chain\'s own level, '
+                               'guarded at 2.5e-6 by test_split_gemm_accuracy_guard; the other GEMMs of the second-order pass on the '
+                               'exact-FP32 MFMA; sample processing float64',
                    'schedule': 'the first Adam epoch takes its first inner pass (theta on step 0) from the _adapt call that just '
                                'evaluated it instead of repeating it (promp_set_reuse_adapt, default on; bit-identical, '
                                'test_first_epoch_reuses_the_inner_adapt_pass): 11 instead of 12 first-order passes per step'},

@@ -376,6 +376,12 @@ enum { PROMP_KERNEL_FWD_BWD = 0, PROMP_KERNEL_HVP = 1, PROMP_KERNEL_GRAM = 2, PR
        PROMP_KERNEL_COUNT = 5 };
 int promp_prof_enable(promp_ctx* ctx, int on);
 int promp_prof_read(promp_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches, int64_t* rows);
+/* The fused pass kernels run their float32-equivalent products as a two-term FP16 split (promp_amd/csrc/promp_device.h); FP16 has a
+ * range, so cotangents carry per-wave powers of two that follow the data.  out2 receives, and the call clears, how many segments
+ * (a workgroup's share of a task's rows) were walked a second time since the last call because a cotangent left the format at the
+ * scale its wave had chosen: k_pass [0], k_chain_hvp [1].  Diagnostics only -- heavy-tailed importance ratios (a policy far from the
+ * one that sampled) cost time, never accuracy; the reference has no counterpart. */
+int promp_split_events(promp_ctx* ctx, int64_t* out2);
 int promp_device_info(promp_ctx* ctx, char* name_out, size_t name_bytes, int32_t* n_cus, int32_t* clock_mhz);
 
 #ifdef __cplusplus

@@ -120,6 +120,7 @@ SIGNATURES = {
     'promp_eval_hvp': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, _F, _F]),
     'promp_prof_enable': (C.c_int, [_P, C.c_int]),
     'promp_prof_read': (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'promp_split_events': (C.c_int, [_P, C.POINTER(C.c_int64)]),
     'promp_device_info': (C.c_int, [_P, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
@@ -838,6 +839,13 @@ class Context:
         ms, n, rows = C.c_double(0), C.c_int64(0), C.c_int64(0)
         self._call('promp_prof_read', int(kernel_id), C.byref(ms), C.byref(n), C.byref(rows))
         return dict(total_ms=ms.value, launches=n.value, rows=rows.value)
+
+    def split_events(self):
+        """FP16 split of the fused pass kernels: segments walked a second time since the last call because a cotangent left the format
+        at its wave's scale, for k_pass and k_chain_hvp (promp_split_events; the call clears the counters)"""
+        out = (C.c_int64 * 2)()
+        self._call('promp_split_events', out)
+        return dict(pass_segments=out[0], hvp_segments=out[1])
 
     def device_info(self):
         name = C.create_string_buffer(256)

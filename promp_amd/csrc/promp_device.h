@@ -9,6 +9,12 @@
 // in a container without a GPU; it is never built into or loaded by the product.
 #pragma once
 
+#ifndef PROMP_SPLIT_TERMS
+#define PROMP_SPLIT_TERMS 2
+#endif
+constexpr int PROMP_NT = PROMP_SPLIT_TERMS;                      // terms per value
+constexpr int PROMP_NPROD = PROMP_NT * (PROMP_NT + 1) / 2;       // matrix instructions per product
+
 #ifdef PROMP_EMU
 #include "hip_emu.h"
 #else
@@ -93,6 +99,41 @@ PROMP_DEV void bf16_split3_pair(float x0, float x1, unsigned (&w)[3]) {
         if (t < 2) r -= __builtin_convertvector(h, f32x2);
     }
 }
+// ---- float32-equivalent products on the 16-bit matrix pipe: the split (round 6) ---------------------------------------------
+// PROMP_SPLIT_TERMS = 2 (default): x = hi + lo, two FP16 terms (11 significant bits each: 2^-22 |x| as long as lo is not below the
+// subnormal floor 2^-25 -- the matrix instruction keeps subnormal FP16 inputs, tools/micro/f16_split_probe.hip); a product is the
+// THREE instructions hi.hi + hi.lo + lo.hi (lo.lo ~ 2^-22 dropped) on v_mfma_f32_*_f16, the split is four vector instructions per
+// pair of values (v_cvt_pk_f16_f32, two v_fma_mix_f32 for the residuals, v_cvt_pk_f16_f32).  FP16 has a RANGE, so every operand a
+// kernel splits is kept near 1 by an exact power of two that the kernel undoes on its accumulators (observations: per task;
+// cotangents and the direction of the R-operator pass: per wave / per segment) -- see the kernels.
+// PROMP_SPLIT_TERMS = 3 (-DPROMP_SPLIT_TERMS=3; rounds 3-5): three BF16 terms, SIX instructions (terms ta + tb <= 2), no range.
+// Either way: word t of a split holds term t of x0 (low half) and of x1 (high half); products are walked ta = NT-1 .. 0,
+// tb = NT-1-ta .. 0 (smallest first).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+// (the term count of an operand array names its format: 2 = FP16, 3 = BF16)
+template <int NT>
+PROMP_DEV void split_pair(float x0, float x1, unsigned (&w)[NT]) {
+    static_assert(NT == 2 || NT == 3, "two FP16 terms or three BF16 terms");
+    if constexpr (NT == 2) {
+        float r0, r1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w[0]) : "v"(x0), "v"(x1));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(w[0]), "v"(x0));                   // x0 - hi (low half)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(w[0]), "v"(x1));    // x1 - hi (high half)
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w[1]) : "v"(r0), "v"(r1));
+    } else {
+        bf16_split3_pair(x0, x1, w);
+    }
+}
+template <int NT>
+PROMP_DEV f32x4 mfma16_sw(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (NT == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else return mfma16_bf16w(a, b, c);
+}
+template <int NT>
+PROMP_DEV f32x16 mfma32_sw(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (NT == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+    else return mfma32_bf16w(a, b, c);
+}
 PROMP_DEV float shfl_xor_f32(float v, int m) { return __shfl_xor(v, m, 64); }
 // Cross-lane sums on the vector ALU (no LDS round trip, unlike ds_bpermute):
 //   fold_groups16: v + the values of the same lane index in the other three 16-lane groups (v_permlane32_swap / v_permlane16_swap:
@@ -171,6 +212,7 @@ PROMP_DEV void fence_release_agent() {
 PROMP_DEV void fence_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 PROMP_DEV int atomic_add_agent(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PROMP_DEV void atomic_store_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PROMP_DEV void atomic_max_agent(unsigned* p, unsigned v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // hand-off to the HOST through page-locked memory: everything this thread stored before is visible to a host thread that
 // reads the flag with acquire semantics and finds the new value
 PROMP_DEV void release_store_system(unsigned* p, unsigned v) {
@@ -250,6 +292,10 @@ PROMP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_e
 PROMP_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 
+// Exact scales of the FP16 split's operands: 2^e as a float (e in [-126, 127]), and the exponent k that brings m = 2^e (1 + f) to
+// [2^t, 2^(t+1)): k = t - e.  (m = 0 / subnormal reads as e = -127, infinity / NaN as e = 128: callers test m and clamp k.)
+PROMP_DEV float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+PROMP_DEV int scale_exp(float m, int t) { return t - ((int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xFF) - 127); }
 PROMP_DEV f32x4 zero4() {
     f32x4 z;
 #pragma unroll

@@ -56,6 +56,8 @@ struct StepData {
     int ls_per_row = 0;
     int feat_dim = 0;
     float *obs = nullptr, *act = nullptr, *rew = nullptr, *old_mean = nullptr, *old_ls = nullptr;
+    unsigned* obs_absmax = nullptr;    // [tasks]: bits of the largest |observation| of each task's rows (k_obs_range; the FP16 split's scale)
+    bool obs_range_valid = false;      // false from every entry point that writes S.obs until k_obs_range has been enqueued behind it
     double* rew64 = nullptr;           // promp_set_rewards_f64 (allocated on first use); valid while has_rew64
     // DiCE (promp_set_dice_rewards; allocated on first use): per-row adjusted rewards, row tangents of the R-operator pass,
     // coupling weights, scan scratch
@@ -157,6 +159,7 @@ struct promp_ctx {
     unsigned long long* dbg = nullptr;   // cycle stamps (developer tooling, tools/phase_timing.py)
     bool dbg_enabled = false;
     int* task_counters = nullptr;        // [tasks] arrival counters of the chain kernels' fused reductions (zero between launches)
+    int* split_events = nullptr;         // [2] see PassArgs::split_events
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     float min_log_std = -13.815510558f;  // log(1e-6): GaussianMLPPolicy's default min_std
@@ -444,6 +447,21 @@ int launch_pass_generic(promp_ctx* c, StepData& S, const PassArgs& a, bool hvp, 
     return 0;
 }
 
+// The per-task range of a step's observations (the FP16 split's scale, promp_kernels_pass.h: k_obs_range), enqueued on `st` behind
+// whatever wrote the slab there.  The uploads call it on their own stream (its cost is the upload's); the device-side writers only
+// mark the table stale and the first policy pass recomputes it.
+int enqueue_obs_range(promp_ctx* c, StepData& S, hipStream_t st) {
+    if (S.n_rows <= 0) return 0;
+    HIPCHECK(hipMemsetAsync(S.obs_absmax, 0, sizeof(unsigned) * c->d.n_tasks, st));
+    ObsRangeArgs r;
+    r.obs = S.obs; r.task_row_offsets = S.task_row_offsets; r.absmax = S.obs_absmax; r.O = c->d.obs_dim;
+    const int slices = (c->n_cus * 4 + c->d.n_tasks - 1) / c->d.n_tasks;
+    PROMP_LAUNCH(k_obs_range, dim3(slices < 1 ? 1 : slices > 64 ? 64 : slices, c->d.n_tasks), 256, 0, st, r);
+    HIPCHECK(hipGetLastError());
+    S.obs_range_valid = true;
+    return 0;
+}
+
 // One policy pass over a step's slabs plus the per-task reduction that consumes it:
 //   red_mode RED_STEP / RED_OUTER / RED_HVP / RED_PLAIN / RED_SCAL (promp_kernels_chain.h).
 // k_chain_hvp can do both in one launch; k_pass and the cooperative kernels (hidden 128 / wide observations) are
@@ -455,8 +473,10 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     if (!S.has_adv) return fail(-3, "step has no advantages: call promp_process_samples or promp_set_advantages first");
     if (!policy_shape_chain(&c->d) && !c->wide && !c->generic)
         return fail(-1, "internal: no pass kernel for this policy shape");
+    if (!S.obs_range_valid && enqueue_obs_range(c, S, c->stream)) return -2;
     PassArgs a;
     memset(&a, 0, sizeof a);
+    a.obs_absmax = (const float*)S.obs_absmax;
     a.obs = S.obs; a.act = S.act; a.adv = c->pass_adv ? c->pass_adv : S.adv32; a.old_mean = S.old_mean; a.old_log_std = S.old_ls;
     a.row_tan = hvp ? c->pass_row_tan : nullptr;
     const int cache = (c->wide || c->generic || fwd_only || !S.hcache) ? 0 : c->pass_cache;
@@ -483,6 +503,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.red_mode = red_mode; a.step_sizes = c->step_sizes; a.cur = cur; a.cur_task_stride = cur_stride; a.next = next;
     a.lam = c->lam; a.v = c->vbuf; a.scal = scal;
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
+    a.split_events = c->split_events;
     const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
     if (c->wbf) {
         // the parameters' (and the direction's) hidden kernels as BF16 planes in fragment order (one small launch each: 276 KB per task)
@@ -728,7 +749,7 @@ int upload_eta(promp_ctx* c, const float* eta) {
 }
 
 void free_step(StepData& S) {
-    void* ptrs[] = {S.hcache, S.dice_rw, S.dice_c, S.dice_u, S.dice_tmp, S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
+    void* ptrs[] = {S.obs_absmax, S.hcache, S.dice_rw, S.dice_c, S.dice_u, S.dice_tmp, S.rew64, S.obs, S.act, S.rew, S.old_mean, S.old_ls, S.ret32, S.adv32, S.ret64, S.adv64, S.path_row_offsets,
                     S.path_task, S.row_t, S.task_row_offsets, S.task_path_offsets, S.task_wg_offsets[0], S.task_wg_offsets[1], S.chain_segs, S.chain_wg_offsets,
                     S.chain_slot_offsets, S.path_ret0,
                     S.path_undisc, S.path_rsq, S.path_mom, S.coeffs, S.work[0], S.work[1]};
@@ -742,6 +763,7 @@ int alloc_step(promp_ctx* c, StepData& S) {
     const size_t R = dims->max_rows, P = dims->max_paths, A = dims->act_dim, O = dims->obs_dim;
     int rc = 0;
     rc |= dev_alloc(&S.obs, R * O); rc |= dev_alloc(&S.act, R * A); rc |= dev_alloc(&S.rew, R);
+    rc |= dev_alloc(&S.obs_absmax, (size_t)M);
     rc |= dev_alloc(&S.old_mean, R * A); rc |= dev_alloc(&S.old_ls, R * A);
     rc |= dev_alloc(&S.ret32, R); rc |= dev_alloc(&S.adv32, R); rc |= dev_alloc(&S.ret64, R); rc |= dev_alloc(&S.adv64, R);
     rc |= dev_alloc(&S.path_row_offsets, P + 1); rc |= dev_alloc(&S.path_task, P); rc |= dev_alloc(&S.row_t, R);
@@ -1035,6 +1057,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     }
     rc |= dev_alloc(&c->task_counters, (size_t)M);
     rc |= dev_alloc(&c->dbg, 256 + 4 * 1024);
+    rc |= dev_alloc(&c->split_events, 4);
     if (hipHostMalloc((void**)&c->stats_host, sizeof(float) * (2 * (K + 2) + 1), hipHostMallocDefault) != hipSuccess) rc |= 1;
     if (hipHostMalloc((void**)&c->stats_seq_host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) rc |= 1;
     else *c->stats_seq_host = 0;
@@ -1062,7 +1085,7 @@ void promp_ctx_destroy(promp_ctx* c) {
         }
     void* ptrs[] = {c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
-                    c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->dbg, c->fit_scratch, c->rollout_buf};
+                    c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->split_events, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int l = 0; l < GEN_MAX_LIN; ++l) {
@@ -1097,6 +1120,7 @@ int promp_sync(promp_ctx* c) {
 static int set_step_layout(promp_ctx* c, StepData& S, hipStream_t st, bool async, int n_paths, const int32_t* tpo, const int32_t* pro) {
     if (!tpo || !pro) return fail(-1, "offsets are required");
     const int M = c->d.n_tasks;
+    S.obs_range_valid = false;         // (whoever describes a slab anew is about to fill it)
     if (n_paths < 1 || n_paths > c->d.max_paths) return fail(-1, "n_paths %d outside [1, max_paths=%d]", n_paths, c->d.max_paths);
     if (tpo[0] != 0 || tpo[M] != n_paths) return fail(-1, "task_path_offsets must start at 0 and end at n_paths");
     if (pro[0] != 0) return fail(-1, "path_row_offsets must start at 0");
@@ -1270,6 +1294,7 @@ static int copy_step_data(promp_ctx* c, StepData& S, hipStream_t st, const float
     const size_t R = (size_t)S.n_rows;
     const size_t O = c->d.obs_dim, A = c->d.act_dim;
     HIPCHECK(hipMemcpyAsync(S.obs, obs, sizeof(float) * R * O, hipMemcpyHostToDevice, st));
+    if (enqueue_obs_range(c, S, st)) return -2;
     HIPCHECK(hipMemcpyAsync(S.rew, rew, sizeof(float) * R, hipMemcpyHostToDevice, st));
     S.has_policy = act && old_mean && old_ls;
     if (S.has_policy) {
@@ -1917,6 +1942,7 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     } else
     PROMP_LAUNCH(k_point_rollout, dim3(M), 64, 0, st, a);
     HIPCHECK(hipGetLastError());
+    S.obs_range_valid = false;
     return 0;
 }
 
@@ -1982,6 +2008,7 @@ int promp_end_collection(promp_ctx* c, int step, int n_paths, const int32_t* tas
     HIPCHECK(hipStreamSynchronize(c->stream));
     S.has_policy = true; S.ls_per_row = 0; S.has_rew64 = false; S.processed = false; S.has_adv = false;
     S.rollout_ragged = false; S.rollout_B = 0;
+    S.obs_range_valid = false;
     return 0;
 }
 
@@ -2023,6 +2050,7 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(actions_out, d_act, sizeof(float) * n_act, hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    S.obs_range_valid = false;
     return 0;
 }
 
@@ -2451,6 +2479,16 @@ int promp_prof_read(promp_ctx* c, int id, double* total_ms, int64_t* launches, i
     if (total_ms) *total_ms = c->prof_slots[id].total_ms;
     if (launches) *launches = c->prof_slots[id].launches;
     if (rows) *rows = c->prof_slots[id].rows;
+    return 0;
+}
+
+int promp_split_events(promp_ctx* c, int64_t* out2) {
+    if (!c || !out2) return fail(-1, "NULL argument");
+    int h[2];
+    HIPCHECK(hipMemcpyAsync(h, c->split_events, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemsetAsync(c->split_events, 0, sizeof h, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) out2[i] = h[i];
     return 0;
 }
 

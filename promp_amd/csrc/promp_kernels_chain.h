@@ -70,6 +70,7 @@ enum { RED_STEP = 0, RED_OUTER = 1, RED_HVP = 2, RED_PLAIN = 3, RED_SCAL = 4 };
 
 struct PassArgs {
     const float* obs;           // [rows][O]
+    const float* obs_absmax;    // [tasks]: the largest |observation| of each task's rows (k_obs_range, when the slab arrived); may be NULL
     const float* act;           // [rows][A]
     const float* adv;           // [rows]
     const float* old_mean;      // [rows][A]
@@ -105,6 +106,8 @@ struct PassArgs {
     float* row_tan;                 // k_chain_hvp, optional [rows]: R'{log pi} of every row = dlogpi_row . (-v)  (DiCE coupling)
     float* hcache;                  // primal cache of the step (k_pass<STORE> writes it, k_chain_hvp<CACHED> reads it), see chain_cache_row
     unsigned long long* dbg;        // optional cycle stamps (developer tooling), else NULL
+    int* split_events;              // [2] FP16 split: segments walked again because a cotangent left the format, by k_pass [0] and by
+                                    // k_chain_hvp [1] (promp_split_events); counted when it happens
     // BF16-pipe cooperative kernels (promp_kernels_wide_bf16.h): the parameters' (and the direction's) hidden kernels as pre-split
     // BF16 planes in fragment order, written by k_wb_planes right before the pass
     const unsigned* wb_theta_planes;
@@ -123,7 +126,8 @@ struct ChainLds {
     int bplanes, bplane_stride;              // (bwdp) the same kernels' planes in the orientation of the backward product
     int flag;                                // one int: "this workgroup arrived last"
     int wave0, wave_stride, tb0, tb1, db0, db1;
-    int tp, tah;                             // (bwdp) BF16 plane tiles of the hidden_1 kernel gradient, over tb0 / tb1
+    int tp, tah;                             // (bwdp) plane tiles of the hidden_1 kernel gradient, over tb0 / tb1
+    int vmx;                                 // one float per wave: the largest |direction entry| its staging share holds (FP16 split)
     int total;
 };
 #define PROMP_CH_TPL 512         // words per plane of a [16 samples][64 units] bf16 tile (B operand of the hidden_1 kernel gradient)
@@ -164,12 +168,12 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
     // (behind BOTH network blocks: inside them they would push the second network's float32 fragments past the 64 KB that
     // a ds_read immediate offset reaches, and every such read would cost an address add: +4.5 us per launch, measured)
     L.planes = o;
-    L.plane_stride = 3 * NC2 * (NC1 / 2) * 256;
+    L.plane_stride = PROMP_NT * NC2 * (NC1 / 2) * 256;
     o += hvp ? 2 * L.plane_stride : 0;
     // bwdp: [term 3][c1][pair of hidden_1 OUTPUT blocks P][lane] x 8 bf16: lane (i16, kk) of chunk (c1, P):
     // W2[16 c1 + i16][16 (2P) + 4 kk + r], r = 0..3, then W2[16 c1 + i16][16 (2P + 1) + 4 kk + r]
     L.bplanes = o;
-    L.bplane_stride = 3 * NC1 * (NC2 / 2) * 256;
+    L.bplane_stride = PROMP_NT * NC1 * (NC2 / 2) * 256;
     o += bwdp ? 2 * L.bplane_stride : 0;
     L.wave0 = o;
     int q = 0;
@@ -177,8 +181,8 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
     L.tb1 = q; q += 16 * PROMP_CH_TS;
     if (bwdp) {                   // the hidden_1 kernel gradient's plane tiles alias the float32 transpose tiles (the phases of a
         L.tp = 0;                 // tile are sequential): 3 planes of the B operand + 3 half planes of the A operand
-        L.tah = 3 * PROMP_CH_TPL;
-        if (q < L.tah + 3 * PROMP_CH_APL) q = L.tah + 3 * PROMP_CH_APL;
+        L.tah = PROMP_NT * PROMP_CH_TPL;
+        if (q < L.tah + PROMP_NT * PROMP_CH_APL) q = L.tah + PROMP_NT * PROMP_CH_APL;
     }
     L.db0 = q; q += 16 * PROMP_CH_DS;
     L.db1 = q; q += hvp ? 16 * PROMP_CH_DS : 0;
@@ -188,6 +192,8 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
         const int need = 4 + nwaves * ((NP + 2 + 3) & ~3);
         if (o < need) o = need;
     }
+    L.vmx = o;                    // behind everything, the slabs included: written at the head of a segment, before its first barrier
+    o += 4 * ((nwaves + 3) / 4);
     L.total = o;
     return L;
 }
@@ -242,33 +248,43 @@ PROMP_DEV u32x4 join_w2(u32x2 lo, u32x2 hi) {
     v[3] = hi[1];
     return v;
 }
-// a lane's eight k-slots of one input chunk (blocks 2P, 2P + 1) -> the three BF16 planes
-PROMP_DEV void pass_split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
-    unsigned w0[3], w1[3], w2[3], w3[3];
-    bf16_split3_pair(lo[0], lo[1], w0);
-    bf16_split3_pair(lo[2], lo[3], w1);
-    bf16_split3_pair(hi[0], hi[1], w2);
-    bf16_split3_pair(hi[2], hi[3], w3);
+// a lane's eight k-slots of one input chunk (blocks 2P, 2P + 1) -> the planes of the split (NT = 2: FP16, 3: BF16)
+template <int NT>
+PROMP_DEV void pass_split8(const f32x4& lo, const f32x4& hi, u32x4 (&pl)[NT]) {
+    unsigned w0[NT], w1[NT], w2[NT], w3[NT];
+    split_pair<NT>(lo[0], lo[1], w0);
+    split_pair<NT>(lo[2], lo[3], w1);
+    split_pair<NT>(hi[0], hi[1], w2);
+    split_pair<NT>(hi[2], hi[3], w3);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NT; ++t) {
         pl[t][0] = w0[t];
         pl[t][1] = w1[t];
         pl[t][2] = w2[t];
         pl[t][3] = w3[t];
     }
 }
-// a chunk pair (blocks 2P, 2P + 1 of sample i16) of three planes -> a transposed tile
-PROMP_DEV void pass_store_planes(float* tile, int plane_words, int off, const u32x4 (&pl)[3]) {
+// a chunk pair (blocks 2P, 2P + 1 of sample i16) of the planes -> a transposed tile
+template <int NT>
+PROMP_DEV void pass_store_planes(float* tile, int plane_words, int off, const u32x4 (&pl)[NT]) {
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) {
+    for (int tt = 0; tt < NT; ++tt) {
         sts_w2(tile + tt * plane_words + off, pl[tt][0], pl[tt][1]);
         sts_w2(tile + tt * plane_words + off + 32, pl[tt][2], pl[tt][3]);
     }
 }
-// the three planes of a 32-unit (or 16-unit) block as a lane's eight samples: two transpose reads each
-PROMP_DEV void pass_read_tr(u32x4 (&fr)[3], const float* tile, int plane_words, int rd0, int rd1) {
+// the planes of a 32-unit (or 16-unit) block as a lane's eight samples: two transpose reads each
+template <int NT>
+PROMP_DEV void pass_read_tr(u32x4 (&fr)[NT], const float* tile, int plane_words, int rd0, int rd1) {
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) fr[tt] = join_w2(lds_tr16(tile + tt * plane_words + rd0), lds_tr16(tile + tt * plane_words + rd1));
+    for (int tt = 0; tt < NT; ++tt) fr[tt] = join_w2(lds_tr16(tile + tt * plane_words + rd0), lds_tr16(tile + tt * plane_words + rd1));
+}
+// the largest |value| of a wave, in every lane (once per segment: scales of the FP16 split's operands)
+PROMP_DEV float wave_absmax_f32(float v) {
+    v = fabsf(v);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor_f32(v, m));
+    return v;
 }
 
 
@@ -287,10 +303,14 @@ PROMP_DEV void pass_read_tr(u32x4 (&fr)[3], const float* tile, int plane_words, 
 //                                                          and its [c][lane][ro] copy W3[16 c + i16][2 kk + ro]; the last block
 //                                                          also carries the biases
 // `mid` runs between the two phases (all of this function's loads issued, none used, LDS untouched so far): the caller requests its
-// first tile's inputs there and joins the workgroup -- those requests go to memory (the observation slab, the primal cache) and
+// first tile's inputs there, then the workgroup joins -- those requests go to memory (the observation slab, the primal cache) and
 // would, issued first, hold back the parameters behind them (a wave's loads return in order; the parameters come from L2).
+// FP16 split: the direction is staged multiplied by -2^kv, the power of two that brings its largest entry (over the whole vector:
+// every wave's share, exchanged through L.vmx across the barrier inside `mid`) to [2^vt, 2^(vt+1)).  The R-operator is linear in the
+// direction, so every tangent the kernel computes simply carries 2^kv (returned; undone on the accumulators at the end of the
+// segment).  The three-term BF16 split has no range and returns 1.
 template <int NC1, int NC2, int NW, bool BWDP, typename Mid>
-PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1, int O, int A, int tid, Mid&& mid) {
+PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const float* src1, int O, int A, int tid, int vt, Mid&& mid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     constexpr ChainLds L = chain_layout(NC1, NC2, 1, true, 0, BWDP);
     constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2, NB4 = BWDP ? NC1 * (NC2 / 2) : 0;
@@ -359,13 +379,42 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
         z[1][it] = src1[idx];
     }
     sched_fence();       // every load is issued before the first store (the scheduler would interleave them in batches: several round trips)
-    mid();
+    mid();               // (the caller's requests for its first tile: behind the parameters', in front of the barrier)
+    if (PROMP_NT == 2) {
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT1; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x1[1][it][r]));
+#pragma unroll
+        for (int it = 0; it < IT2; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x2[1][it][e]));
+#pragma unroll
+        for (int it = 0; it < IT3; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x3[1][it][r]));
+#pragma unroll
+        for (int it = 0; it < IS; ++it) m = fmaxf(m, fabsf(z[1][it]));
+        m = wave_absmax_f32(m);
+        if (lane == 0) vmx[w] = m;       // (the KERNEL's layout: behind its slabs; the one-wave layout of this function ends earlier)
+    }
+    __syncthreads();     // the previous segment is done with LDS; every wave's share of the direction's range has been written
+    float vs = 1.f;
+    if (PROMP_NT == 2) {
+        float m = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) m = fmaxf(m, vmx[ww]);
+        int k = (m > 0.f && m < 3.0e38f) ? scale_exp(m, vt) : 0;
+        k = k < -100 ? -100 : k > 100 ? 100 : k;
+        vs = pow2f(k);
+    }
     sched_fence();
     float* net0 = sm + 4;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         float* nb = net0 + n * L.net_stride;
-        const float sg = n ? -1.f : 1.f;         // the direction is staged negated
+        const float sg = n ? -vs : 1.f;          // the direction is staged negated (and scaled: FP16 split)
         if (!BWDP || n == 1) {
 #pragma unroll
             for (int it = 0; it < IT1; ++it) {
@@ -385,29 +434,31 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
                 lo[r] = x2[n][it][r] * sg;
                 hi[r] = x2[n][it][4 + r] * sg;
             }
-            // the pair is this lane's eight k-slots of the BF16 instruction: the three planes [term][c2][P][lane] x 8 bf16
-            const float xs[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            bf16x8 t[3];
-            bf16_split3(xs, t);
+            // the pair is this lane's eight k-slots of the matrix instruction: the planes [term][c2][P][lane] x 8 halves
+            u32x4 t[PROMP_NT];
+            pass_split8(lo, hi, t);
             if (!BWDP) {
                 sts4(nb + L.w2 + (c2 * NC1 + 2 * P) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, lo);
                 sts4(nb + L.w2 + (c2 * NC1 + 2 * P + 1) * PROMP_CH_BLK + kk * PROMP_CH_ROW + i16 * 4, hi);
             }
             float* pl = sm + L.planes + n * L.plane_stride;
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC2 + c2) * (NC1 / 2) + P) * 64 + lane) * 4) = t[sp];
+            for (int sp = 0; sp < PROMP_NT; ++sp) sts_w4(pl + (((sp * NC2 + c2) * (NC1 / 2) + P) * 64 + lane) * 4, t[sp]);
         }
 #pragma unroll
         for (int it = 0; it < IT4; ++it) {       // (BWDP) the planes of the backward product: [term][c1][P][lane] x 8 bf16
             const int bj = w + it * NW, b = bj < NB4 ? bj : NB4 - 1, c1 = b / (NC2 / 2), P = b - c1 * (NC2 / 2);
-            float xs[8];
+            f32x4 lo, hi;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xs[e] = x4[n][it][e] * sg;
-            bf16x8 t[3];
-            bf16_split3(xs, t);
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = x4[n][it][e] * sg;
+                hi[e] = x4[n][it][4 + e] * sg;
+            }
+            u32x4 t[PROMP_NT];
+            pass_split8(lo, hi, t);
             float* pl = sm + L.bplanes + n * L.bplane_stride;
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) *(bf16x8*)(pl + (((sp * NC1 + c1) * (NC2 / 2) + P) * 64 + lane) * 4) = t[sp];
+            for (int sp = 0; sp < PROMP_NT; ++sp) sts_w4(pl + (((sp * NC1 + c1) * (NC2 / 2) + P) * 64 + lane) * 4, t[sp]);
         }
 #pragma unroll
         for (int it = 0; it < IT3; ++it) {
@@ -429,8 +480,9 @@ PROMP_DEV void chain_stage_nets(float* sm, const float* src0, const float* src1,
         const int off = d < H1 ? L.b1 + d : d < H1 + H2 ? L.b2 + d - H1 : L.b3 + d - H1 - H2;
         const float m = d < H1 + H2 || d - H1 - H2 < A ? 1.f : 0.f;
         net0[off] = z[0][it] * m;
-        net0[L.net_stride + off] = z[1][it] * -m;
+        net0[L.net_stride + off] = z[1][it] * (-m * vs);
     }
+    return vs;
 }
 
 // distribution constants of the theta network: s (clipped), exp(-s), exp(2 s), gradient mask, R{s}, 1 / (2 exp(2 s) + 1e-8).
@@ -444,7 +496,7 @@ PROMP_DEV ChainDistRaw chain_dist_load(const float* th, const float* v, int oS, 
     r.v = (v != nullptr) ? v[oS + q] : 0.f;
     return r;
 }
-PROMP_DEV void chain_stage_dist(float* dist, ChainDistRaw raw, int A, int clip_log_std, float min_log_std, int tid) {
+PROMP_DEV void chain_stage_dist(float* dist, ChainDistRaw raw, int A, int clip_log_std, float min_log_std, int tid, float vs = 1.f) {
     if (tid < 8) {
         const float sr = (tid < A) ? raw.s : 0.f;
         const bool clipped = clip_log_std && (sr < min_log_std);   // tf.maximum: gradient iff var >= min
@@ -454,7 +506,7 @@ PROMP_DEV void chain_stage_dist(float* dist, ChainDistRaw raw, int A, int clip_l
         dist[CH_ES + tid] = expf(-s);
         dist[CH_SN2 + tid] = sn2;
         dist[CH_LMASK + tid] = clipped ? 0.f : 1.f;
-        dist[CH_VLS + tid] = (tid < A && !clipped) ? -raw.v : 0.f;   // tangent along -v
+        dist[CH_VLS + tid] = (tid < A && !clipped) ? -raw.v * vs : 0.f;   // tangent along -v (times the direction's scale)
         dist[CH_RDEN + tid] = fast_rcp(2.f * sn2 + 1e-8f);      // one v_rcp_f32 (1 ulp) serves the KL and both of its cotangents
     }
 }
@@ -499,11 +551,14 @@ PROMP_DEV f32x4 tanh4(f32x4 z) {
 // then all threads add the slabs in wave order.  (NW x [NP + 2] floats alias the parameter / transpose regions.)
 // W32: the hidden_1 kernel gradient arrives in the 32 x 32 result layout (aw2w) and its bias gradient in the chain layout
 // (gb2v: units 16 c + 4 kk + r, already summed over the 16 sample lanes) instead of aw2 / gb2.
+// us: the exact power of two that undoes this wave's scales (FP16 split) on the way into the slab; bad: this wave's overflow vote --
+// the function returns whether any wave of the workgroup voted.
 template <int NC1, int NC2, int NOB, int NW, bool W32 = false>
-PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC1][NC2], const f32x16 (&aw2w)[NC1 / 2][NC2 / 2],
+PROMP_DEV bool chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC1][NC2], const f32x16 (&aw2w)[NC1 / 2][NC2 / 2],
                                        const f32x4 (&aw1)[NOB][NC1], const f32x4 (&aw3)[NC2], const float (&gb1)[NC1],
                                        const float (&gb2)[NC2], const f32x4 (&gb2v)[NC2], float gs0,
-                                       float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
+                                       float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid, float us = 1.f,
+                                       int bad = 0) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     // (an opaque copy of the thread index, as in chain_stage_nets: lane-constant indices that live from the kernel's first lines to
     //  this point are spilled across the tile loop, and each reload here is a round trip to scratch memory in the kernel's tail)
@@ -511,6 +566,7 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
     const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
     const int SL = (NP + 2 + 3) & ~3;
+    if (lane == 0) ((int*)S)[w - 4] = bad;      // the four words in front of the slabs
     lds_barrier();                // every wave is done with the parameter / transpose regions
     {
         float* mine = S + w * SL;
@@ -522,14 +578,14 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
                 for (int bj = 0; bj < NC2 / 2; ++bj)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        mine[oW2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + 32 * bj + j32] = aw2w[bi][bj][r];
+                        mine[oW2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + 32 * bj + j32] = aw2w[bi][bj][r] * us;
         } else {
 #pragma unroll
             for (int i = 0; i < NC1; ++i)
 #pragma unroll
                 for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mine[oW2 + (16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r];
+                    for (int r = 0; r < 4; ++r) mine[oW2 + (16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r] * us;
         }
 #pragma unroll
         for (int i = 0; i < NOB; ++i)
@@ -538,26 +594,26 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + 4 * kk + r;
-                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r];
+                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r] * us;
                 }
 #pragma unroll
         for (int j = 0; j < NC2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (i16 < A) mine[oW3 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][r];
+                if (i16 < A) mine[oW3 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][r] * us;
         if (kk == 0) {
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j];
+            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j] * us;
             if (!W32) {
 #pragma unroll
-                for (int j = 0; j < NC2; ++j) mine[ob2 + 16 * j + i16] = gb2[j];
+                for (int j = 0; j < NC2; ++j) mine[ob2 + 16 * j + i16] = gb2[j] * us;
             }
         }
         if (W32 && i16 == 0) {
 #pragma unroll
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[ob2 + 16 * j + 4 * kk + r] = gb2v[j][r];
+                for (int r = 0; r < 4; ++r) mine[ob2 + 16 * j + 4 * kk + r] = gb2v[j][r] * us;
         }
         if (i16 == 0) {           // lane (0, kk) holds the sums of actions 2 kk, 2 kk + 1
             if (2 * kk < A) {
@@ -588,6 +644,10 @@ PROMP_DEV void chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
         for (int ww = 1; ww < NW; ++ww) t += v[ww];
         *(f32x4*)(P + e) = t;
     }
+    int any = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) any |= ((const int*)S)[ww - 4];
+    return any != 0;
 }
 
 // Sum of a task's partial rows in slot order + the update that consumes it.
@@ -683,29 +743,46 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
     chain_task_sum<NT>(r, tid);
 }
 
+// FP16 split of k_chain_hvp (see pass_cotangent_scale in promp_kernels_pass.h for the reasoning): the direction's largest entry goes
+// to [2, 4) -- its hidden_1 block, the only part that is split, then sits around 2^-3 .. 1, the tangent activations (sums over the
+// observations) around 1 .. 100 --, the first tile's largest mean cotangent to [4, 8), the tangent cotangents follow from the two
+// (x 2^4 .. 2^6).  A wave whose largest cotangent passed 2^CHAIN_CT_LIMIT at its scale, or that finds an infinity in its sums, has the
+// workgroup walk the segment again: the direction 2^CHAIN_V_RETRY lower, the largest cotangent -- known by then -- at 2^CHAIN_CT_REDO.
+#ifndef PROMP_CT_ATTEMPTS
+#define PROMP_CT_ATTEMPTS 3
+#endif
+#ifndef PROMP_CHAIN_V_TARGET
+#define PROMP_CHAIN_V_TARGET 1
+#endif
+#ifndef PROMP_CHAIN_CT_TARGET
+#define PROMP_CHAIN_CT_TARGET 2
+#endif
+PROMP_CX int CHAIN_V_TARGET = PROMP_CHAIN_V_TARGET, CHAIN_V_RETRY = 6, CHAIN_CT_TARGET = PROMP_CHAIN_CT_TARGET, CHAIN_CT_LIMIT = CHAIN_CT_TARGET + 6,
+             CHAIN_CT_REDO = CHAIN_CT_LIMIT - 1, CHAIN_CT_RETRY = 10, CHAIN_ATTEMPTS = PROMP_CT_ATTEMPTS;
+
 // Two-network product of the R-operator pass on the BF16 pipe, operands streamed:
 //     acc[c] += W[.][c] xa + V[.][c] xb          (PRIMAL: accp[c] += W[.][c] xb as well)
 // W / V: the BF16 planes [term][c < NCO][chunk P < NPK][lane] of theta's and the direction's kernel, xa / xb: the planes of the two
 // activations (a lane's eight k-slots of chunk P).  Six of the nine term products, walked by weight term (2,0) (1,1) (1,0) (0,2)
 // (0,1) (0,0) -- roughly smallest first -- so that a weight fragment is read ONCE and feeds one to three consecutive groups of
-// instructions, and only two terms' fragments are in registers at a time: the fragments of group g + 1 are requested before the
+// instructions (FP16 split, round 6: two terms, (1,0) (0,1) (0,0)), and only two terms' fragments are in registers at a time: the fragments of group g + 1 are requested before the
 // products of group g are issued (left alone the compiler reads a fragment right in front of its first product, and the single wave
 // of a SIMD sits out one LDS latency per fragment: ~45 cycles x 35 waits per tile in each of the two K = 64 products, measured).
 template <int NCO, int NPK, bool PRIMAL>
-PROMP_DEV void chain_gemm2_bf16(f32x4 (&acc)[NCO], f32x4 (&accp)[NCO], const bf16x8* Wp, const bf16x8* Vp, const u32x4 (&xa)[NPK][3],
-                                const u32x4 (&xb)[NPK][3]) {
-    constexpr int NG = 3 * NPK, NM = (PRIMAL ? 3 : 2) * NCO;
-    bf16x8 fw[2][NCO], fv[2][NCO];
+PROMP_DEV void chain_gemm2_bf16(f32x4 (&acc)[NCO], f32x4 (&accp)[NCO], const u32x4* Wp, const u32x4* Vp, const u32x4 (&xa)[NPK][PROMP_NT],
+                                const u32x4 (&xb)[NPK][PROMP_NT]) {
+    constexpr int NT = PROMP_NT, NG = NT * NPK, NM = (PRIMAL ? 3 : 2) * NCO;
+    u32x4 fw[2][NCO], fv[2][NCO];
 #pragma unroll
     for (int c = 0; c < NCO; ++c) {
-        fw[0][c] = Wp[((2 * NCO + c) * NPK + 0) * 64];
-        fv[0][c] = Vp[((2 * NCO + c) * NPK + 0) * 64];
+        fw[0][c] = Wp[(((NT - 1) * NCO + c) * NPK + 0) * 64];
+        fv[0][c] = Vp[(((NT - 1) * NCO + c) * NPK + 0) * 64];
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int P = g / 3, ta = 2 - g % 3, cur = g & 1, nxt = cur ^ 1;
+        const int P = g / NT, ta = NT - 1 - g % NT, cur = g & 1, nxt = cur ^ 1;
         if (g + 1 < NG) {
-            const int Pn = (g + 1) / 3, tan = 2 - (g + 1) % 3;
+            const int Pn = (g + 1) / NT, tan = NT - 1 - (g + 1) % NT;
 #pragma unroll
             for (int c = 0; c < NCO; ++c) {
                 fw[nxt][c] = Wp[((tan * NCO + c) * NPK + Pn) * 64];
@@ -713,19 +790,19 @@ PROMP_DEV void chain_gemm2_bf16(f32x4 (&acc)[NCO], f32x4 (&accp)[NCO], const bf1
             }
         }
 #pragma unroll
-        for (int tb = 2 - ta; tb >= 0; --tb) {
+        for (int tb = NT - 1 - ta; tb >= 0; --tb) {
             if (PRIMAL) {
 #pragma unroll
-                for (int c = 0; c < NCO; ++c) accp[c] = mfma16_bf16(fw[cur][c], __builtin_bit_cast(bf16x8, xb[P][tb]), accp[c]);
+                for (int c = 0; c < NCO; ++c) accp[c] = mfma16_sw<NT>(fw[cur][c], xb[P][tb], accp[c]);
             }
 #pragma unroll
-            for (int c = 0; c < NCO; ++c) acc[c] = mfma16_bf16(fw[cur][c], __builtin_bit_cast(bf16x8, xa[P][tb]), acc[c]);
+            for (int c = 0; c < NCO; ++c) acc[c] = mfma16_sw<NT>(fw[cur][c], xa[P][tb], acc[c]);
 #pragma unroll
-            for (int c = 0; c < NCO; ++c) acc[c] = mfma16_bf16(fv[cur][c], __builtin_bit_cast(bf16x8, xb[P][tb]), acc[c]);
+            for (int c = 0; c < NCO; ++c) acc[c] = mfma16_sw<NT>(fv[cur][c], xb[P][tb], acc[c]);
         }
         if (g + 1 < NG) PROMP_SCHED_DSREAD(2 * NCO);        // the requests first, then the products
-        if (ta == 2) PROMP_SCHED_MFMA(NM);
-        else if (ta == 1) PROMP_SCHED_MFMA(2 * NM);
+        if (NT - ta == 1) PROMP_SCHED_MFMA(NM);
+        else if (NT - ta == 2) PROMP_SCHED_MFMA(2 * NM);
         else PROMP_SCHED_MFMA(3 * NM);
         sched_fence();
     }
@@ -790,6 +867,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 
     const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
     CH_WGSTAMP(0);
+    int attempt = 0;              // FP16 split: how often the current segment has overflowed (see the end of the tile walk)
+    float redo_amax = 0.f;        // ... and the largest cotangent this wave met on the way
     for (int sg = sg0; sg < sg1; ++sg) {
         const ChainSeg seg = a.segs[sg];
         const int task = seg.task;
@@ -809,7 +888,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         const float* hcl = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + i16 * 16 + 4 * kk : nullptr;
         const float* hcm = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + 256 * (NC1 + NC2) + i16 * 8 + 2 * kk : nullptr;
         CH_STAMP(0);
-        chain_stage_nets<NC1, NC2, NW, CACHED>(sm, th, v, O, A, tid, [&]() {
+        // FP16 split: where the largest direction entry / the first tile's largest mean cotangent go (chain_stage_nets; below)
+        const int vt = CHAIN_V_TARGET - attempt * CHAIN_V_RETRY, ct = attempt ? CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY : CHAIN_CT_TARGET;
+        // (L is the layout for a parameter count of 0: the slabs of the real one may end behind L.vmx; the host sized LDS for both)
+        const int slabs_end = 4 + NW * ((NP + 2 + 3) & ~3), vmx_off = slabs_end > L.vmx ? slabs_end : L.vmx;
+        const float vs = chain_stage_nets<NC1, NC2, NW, CACHED>(sm, sm + vmx_off, th, v, O, A, tid, vt, [&]() {
             {
                 const int t = seg.tile0 + w;
                 const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
@@ -824,10 +907,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 for (int c = 0; c < NC2; ++c) ch2[c] = *(const f32x4*)(hcl + o + 256 * (NC1 + c));
                 cmu = *(const f32x2*)(hcm + o);
             }
-            __syncthreads();
         });
         CH_STAMP(5);
-        chain_stage_dist(net + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
+        chain_stage_dist(net + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid, vs);
         CH_STAMP(6);
         // action slots >= 8 of the cotangent tiles must read as zero (slots < 8 and the transpose tiles are rewritten by
         // every tile before they are read); the end-of-segment slabs alias them, so once per segment
@@ -868,6 +950,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
         for (int j = 0; j < NC2; ++j) gb2v[j] = zero4();
         float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
+        // FP16 split: this wave's cotangent scale in the segment (set by its first tile with a cotangent, as in k_pass), the tangent
+        // cotangents' (they carry the direction's scale too) and the weight of the KL cotangents among them
+        float cs = 1.f, qs = vs, klws = klw * vs, ivs = 1.f / vs, amax = 0.f;
+        int prov = 1;
+        if (PROMP_NT == 2 && attempt > 0 && redo_amax > 0.f && redo_amax < 3.0e38f) {      // the segment again: the largest cotangent is known
+            int k = scale_exp(redo_amax, CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY);
+            k = k < -100 ? -100 : k > 100 ? 100 : k;
+            cs = pow2f(k);
+            qs = cs * vs;
+            klws = klw * qs;
+            prov = 0;
+        }
 
         int tix = 0;
         for (int t = seg.tile0 + w; t < tend; t += NW, ++tix) {
@@ -942,14 +1036,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     // R'z2 += W2^T R'H1 + (-vW2)^T H1 on the BF16 pipe: K = 32 per instruction = two 16-unit input blocks; a
                     // lane's eight k-slots are its own registers of the two blocks (units 16 c + 4 kk + r), split three ways
                     // (!CACHED: the primal product z2 = W2^T H1 rides on the same planes and splits)
-                    u32x4 rB[NC1 / 2][3], hB[NC1 / 2][3];
+                    u32x4 rB[NC1 / 2][PROMP_NT], hB[NC1 / 2][PROMP_NT];
 #pragma unroll
                     for (int P = 0; P < NC1 / 2; ++P) {
                         pass_split8(rh1[2 * P], rh1[2 * P + 1], rB[P]);
                         pass_split8(h1[2 * P], h1[2 * P + 1], hB[P]);
                     }
-                    chain_gemm2_bf16<NC2, NC1 / 2, !CACHED>(rh2, h2, (const bf16x8*)(sm + L.planes) + lane,
-                                                            (const bf16x8*)(sm + L.planes + L.plane_stride) + lane, rB, hB);
+                    chain_gemm2_bf16<NC2, NC1 / 2, !CACHED>(rh2, h2, (const u32x4*)(sm + L.planes) + lane,
+                                                            (const u32x4*)(sm + L.planes + L.plane_stride) + lane, rB, hB);
                 }
 #pragma unroll
                 for (int c = 0; c < NC2; ++c)
@@ -1018,22 +1112,40 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 dlp = fold_groups16(dlp);      // sums over the row's actions (the four lane groups): lane swaps, no LDS round trip
                 Rlp = fold_groups16(Rlp);
                 kl = fold_groups16(kl);
-                if (a.row_tan != nullptr && rvalid && kk == 0) a.row_tan[n] = Rlp;
-                float c = 0.f, Rc = 0.f, km = 0.f;
+                if (a.row_tan != nullptr && rvalid && kk == 0) a.row_tan[n] = Rlp * ivs;
+                float c = 0.f, km = 0.f;
                 if (rvalid) {
                     km = 1.f;
-                    if (a.loss_kind == LOSS_RATIO) {
-                        c = -advn * expf(dlp) * invN;
-                        Rc = c * Rlp;
-                    } else {
-                        c = -advn * invN;
-                    }
-                    if (kk == 0) klsum += kl * invN;
+                    c = (a.loss_kind == LOSS_RATIO) ? -advn * expf(dlp) * invN : -advn * invN;
                 }
                 const float dklm0 = -2.f * (mo0 - mu0) * rden0 * invN, dklm1 = -2.f * (mo1 - mu1) * rden1 * invN;
                 const float dkls0 = ((-2.f * sn20 * den0 - 4.f * num0 * sn20) * (rden0 * rden0) + 1.f) * invN;
                 const float dkls1 = ((-2.f * sn21 * den1 - 4.f * num1 * sn21) * (rden1 * rden1) + 1.f) * invN;
-                if (a.loss_kind == LOSS_KL) {
+                const bool is_kl = a.loss_kind == LOSS_KL;
+                // the primal cotangents of the mean, unscaled
+                const float du0 = own0 ? (is_kl ? km * dklm0 : c * z0 * e0) : 0.f, du1 = own1 ? (is_kl ? km * dklm1 : c * z1 * e1) : 0.f;
+                if (PROMP_NT == 2) {
+                    // FP16 has a range (promp_kernels_pass.h: pass_cotangent_scale): the wave's first tile with a cotangent sets the
+                    // power of two every cotangent of the segment carries, cs; the tangent cotangents carry cs vs.  The tile pays one
+                    // instruction for the wave's running maximum; what it means is settled at the end of the segment.
+                    const float am = fmaxf(fabsf(du0), fabsf(du1));
+                    amax = fmaxf(amax, am);
+                    if (wave_uniform(prov)) {
+                        const float mx = wave_absmax_f32(am);
+                        const bool okm = mx > 0.f && mx < 3.0e38f;
+                        int k = scale_exp(okm ? mx : invN, okm ? ct : -4);
+                        k = k < -100 ? -100 : k > 100 ? 100 : k;
+                        cs = pow2f(k);
+                        qs = cs * vs;
+                        klws = klw * qs;
+                        prov = okm ? 0 : 1;
+                    }
+                }
+                if (rvalid && kk == 0) klsum += kl * invN;     // (behind the point where a tile may be abandoned)
+                c *= cs;
+                const float Rc = (a.loss_kind == LOSS_RATIO) ? c * Rlp : 0.f;
+                const float kms = km * cs;
+                if (is_kl) {
                     // The objective is the mean KL itself (the TRPO constraint): primal cotangent dKL/dmu, tangent cotangents
                     // R'{dKL/dmu}, R'{dKL/ds}.  With D = mu_old - mu, den = 2 e^{2s} + 1e-8, num = D^2 + e^{2 s_old} - e^{2s}:
                     //   dKL/dmu = -2 D / den                     R'{.} = 2 R'mu / den + 8 D e^{2s} R's / den^2
@@ -1044,9 +1156,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         const float RP = 2.f * sn20 * Rs0 * (den0 + 2.f * num0) - 4.f * sn20 * D * Rmu0;
                         const float Rdm = 2.f * Rmu0 * rden0 + 8.f * D * sn20 * Rs0 * (rden0 * rden0);
                         const float Rds = (-2.f * RP + 16.f * P * sn20 * Rs0 * rden0) * (rden0 * rden0);
-                        d0 = own0 ? km * dklm0 : 0.f;
-                        qm0 = own0 ? km * Rdm * invN : 0.f;
-                        outs0 += own0 ? km * Rds * invN : 0.f;
+                        d0 = own0 ? kms * dklm0 : 0.f;
+                        qm0 = own0 ? kms * Rdm * invN : 0.f;
+                        outs0 += own0 ? kms * Rds * invN : 0.f;
                         outb30 += qm0;
                     }
                     {
@@ -1054,9 +1166,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         const float RP = 2.f * sn21 * Rs1 * (den1 + 2.f * num1) - 4.f * sn21 * D * Rmu1;
                         const float Rdm = 2.f * Rmu1 * rden1 + 8.f * D * sn21 * Rs1 * (rden1 * rden1);
                         const float Rds = (-2.f * RP + 16.f * P * sn21 * Rs1 * rden1) * (rden1 * rden1);
-                        d1 = own1 ? km * dklm1 : 0.f;
-                        qm1 = own1 ? km * Rdm * invN : 0.f;
-                        outs1 += own1 ? km * Rds * invN : 0.f;
+                        d1 = own1 ? kms * dklm1 : 0.f;
+                        qm1 = own1 ? kms * Rdm * invN : 0.f;
+                        outs1 += own1 ? kms * Rds * invN : 0.f;
                         outb31 += qm1;
                     }
                 } else {
@@ -1065,8 +1177,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
                         const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
                         d0 = own0 ? c * z0 * e0 : 0.f;
-                        qm0 = own0 ? km * (Rd + klw * dklm0) : 0.f;
-                        outs0 += own0 ? km * (Rds + klw * dkls0) : 0.f;
+                        qm0 = own0 ? km * (Rd + klws * dklm0) : 0.f;
+                        outs0 += own0 ? km * (Rds + klws * dkls0) : 0.f;
                         outb30 += qm0;
                     }
                     {
@@ -1074,8 +1186,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
                         const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
                         d1 = own1 ? c * z1 * e1 : 0.f;
-                        qm1 = own1 ? km * (Rd + klw * dklm1) : 0.f;
-                        outs1 += own1 ? km * (Rds + klw * dkls1) : 0.f;
+                        qm1 = own1 ? km * (Rd + klws * dklm1) : 0.f;
+                        outs1 += own1 ? km * (Rds + klws * dkls1) : 0.f;
                         outb31 += qm1;
                     }
                 }
@@ -1131,7 +1243,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             }
             CH_TSTAMP(6);
             // ---- out_W2 += R'H1^T dZ2 + H1^T qZ2 ; out_b2 += sum qZ2
-            u32x4 dB[NB2][3], qB[NB2][3];     // CACHED: the BF16 planes of dZ2 / qZ2 (this product and qZ1 below)
+            u32x4 dB[NB2][PROMP_NT], qB[NB2][PROMP_NT];     // CACHED: the planes of dZ2 / qZ2 (this product and qZ1 below)
             if (CACHED) {
                 // On v_mfma_f32_32x32x16_bf16 (K = 16 samples = one tile), float32-equivalent: 6 of the 9 term products.  Four
                 // stages (product, 32-unit block of the A operand): (R'H1, dZ2) x NB1, (H1, qZ2) x NB1.  The B planes of a product
@@ -1148,9 +1260,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 wave_fence();         // the output-kernel gradient's reads of TB0 / TB1 precede these writes
 #pragma unroll
                 for (int P = 0; P < NB2; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, dB[P]);
-                u32x4 fa[3], fb[NB2][3];
+                u32x4 fa[PROMP_NT], fb[NB2][PROMP_NT];
                 {
-                    u32x4 aB[3];
+                    u32x4 aB[PROMP_NT];
                     pass_split8(rh1[0], rh1[1], aB);
                     pass_store_planes(TAH, APL, twr, aB);
                 }
@@ -1161,10 +1273,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
                 for (int s = 0; s < 2 * NB1; ++s) {
                     const int hb = s % NB1;
-                    u32x4 fan[3];
+                    u32x4 fan[PROMP_NT];
                     if (s + 1 < 2 * NB1) {
                         const int pn = (s + 1) / NB1, hn = (s + 1) % NB1;
-                        u32x4 aB[3];
+                        u32x4 aB[PROMP_NT];
                         if (pn == 0) pass_split8(rh1[2 * hn], rh1[2 * hn + 1], aB);
                         else pass_split8(h1[2 * hn], h1[2 * hn + 1], aB);
                         wave_fence();
@@ -1177,14 +1289,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         pass_read_tr(fan, TAH, APL, trd0, trd1);
                     }
 #pragma unroll
-                    for (int ta = 2; ta >= 0; --ta)
+                    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
-                        for (int tb = 2 - ta; tb >= 0; --tb)
+                        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
 #pragma unroll
-                            for (int bj = 0; bj < NB2; ++bj) aw2w[hb][bj] = mfma32_bf16w(fa[ta], fb[bj][tb], aw2w[hb][bj]);
+                            for (int bj = 0; bj < NB2; ++bj) aw2w[hb][bj] = mfma32_sw<PROMP_NT>(fa[ta], fb[bj][tb], aw2w[hb][bj]);
                     if (s + 1 < 2 * NB1) {
 #pragma unroll
-                        for (int tt = 0; tt < 3; ++tt) fa[tt] = fan[tt];
+                        for (int tt = 0; tt < PROMP_NT; ++tt) fa[tt] = fan[tt];
                         if ((s + 1) % NB1 == 0) {     // the second product's B planes: behind the first product's last instructions
                             sched_fence();            // (their registers are the first product's; the planes were written above)
 #pragma unroll
@@ -1260,8 +1372,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     // On the BF16 pipe (round 3): K = 32 hidden_1 output units per instruction = two 16-unit blocks, a lane's eight
                     // k-slots are its own registers of the two blocks, split three ways; the planes of the second orientation
                     // come from LDS (chain_layout, bwdp).  6 of the 9 term products, smallest first, as in layer 2.
-                    chain_gemm2_bf16<NC1, NC2 / 2, false>(qz1, ad1, (const bf16x8*)(sm + L.bplanes) + lane,
-                                                          (const bf16x8*)(sm + L.bplanes + L.bplane_stride) + lane, qB, dB);
+                    chain_gemm2_bf16<NC1, NC2 / 2, false>(qz1, ad1, (const u32x4*)(sm + L.bplanes) + lane,
+                                                          (const u32x4*)(sm + L.bplanes + L.bplane_stride) + lane, qB, dB);
                 } else {
                 // the operands of k-group g + 1 are requested before the products of group g are issued (a fence per group keeps
                 // that order): left alone the compiler reads each operand right in front of its product, and the single wave of
@@ -1300,7 +1412,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float h = h1[c][r];
-                        const float ad2 = 2.f * (CACHED ? cad1[c][r] : ad1[c][r]);
+                        const float ad2 = CACHED ? (2.f * cs) * cad1[c][r] : 2.f * ad1[c][r];      // (the cache holds it unscaled)
                         qz1[c][r] = qz1[c][r] * (1.f - h * h) - ad2 * h * rh1[c][r];
                     }
             }
@@ -1339,10 +1451,34 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gb2v[j][r] = row16_sum(gb2v[j][r]);
         }
-        outs0 *= dist[CH_LMASK + q0];
-        outs1 *= dist[CH_LMASK + q1];
+        // FP16 split: everything this pass accumulates carries the wave's cs vs; an overflow anywhere in the tile walk ends as an
+        // infinity or a NaN in the hidden_0 kernel sums (the last link of every chain): x * 0 is 0 for finite x only.  The waves vote
+        // inside chain_reduce_to_partial; a workgroup with an overflow walks the segment again with both scales lowered.
+        const float us = PROMP_NT == 2 ? 1.f / qs : 1.f;
+        int bad = 0;
+        if (PROMP_NT == 2 && attempt + 1 < CHAIN_ATTEMPTS) {
+            float chk = 0.f;
+#pragma unroll
+            for (int i = 0; i < NOB; ++i)
+#pragma unroll
+                for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) chk = __builtin_fmaf(aw1[i][j][r], 0.f, chk);
+            redo_amax = wave_absmax_f32(amax);
+            bad = (wave_any(chk != chk) || !(redo_amax * cs <= (float)(1 << CHAIN_CT_LIMIT))) ? 1 : 0;
+        }
+        outs0 *= dist[CH_LMASK + q0] * us;
+        outs1 *= dist[CH_LMASK + q1] * us;
         float* P = a.partials + (long long)sg * a.partial_stride;
-        chain_reduce_to_partial<NC1, NC2, NOB, NW, CACHED>(sm + 4, P, aw2, aw2w, aw1, aw3, ob1acc, ob2acc, gb2v, outs0, outs1, outb30, outb31, 0.f, klsum, O, A, tid);
+        const bool redo = chain_reduce_to_partial<NC1, NC2, NOB, NW, CACHED>(sm + 4, P, aw2, aw2w, aw1, aw3, ob1acc, ob2acc, gb2v, outs0, outs1, outb30 * us,
+                                                                             outb31 * us, 0.f, klsum, O, A, tid, us, bad);
+        if (redo) {               // (the partial row just written is written again)
+            if (tid == 0) atomic_add_agent(a.split_events + 1, 1);
+            attempt += 1;
+            sg -= 1;
+            continue;
+        }
+        attempt = 0;
         CH_STAMP(3);
         if (a.fuse_reduce) chain_task_reduce<NT>(a, (int*)sm, task, NP, tid);
         CH_STAMP(4);

@@ -61,7 +61,7 @@ PROMP_CX PassLds pass_layout(int NC1, int NC2, int nwaves, int NP) {
     L.f_w3f = L.f_w2b + NC1 * (NC2 / 2) * 64;             // W3[u(P, kk, e)][action of row i16]
     L.n_frag = L.f_w3f + (NC2 / 2) * 64;
     L.plane_stride = 4 * L.n_frag;
-    L.wp = o; o += 3 * L.plane_stride;
+    L.wp = o; o += PROMP_NT * L.plane_stride;
     L.w3b = o; o += NC2 * 128;                            // [c][lane][ro]: W3[16 c + i16][2 kk + ro]
     L.b1 = o; o += 16 * NC1;
     L.b2 = o; o += 16 * NC2;
@@ -70,10 +70,10 @@ PROMP_CX PassLds pass_layout(int NC1, int NC2, int nwaves, int NP) {
     L.dist = o; o += 48;
     L.wave0 = o;
     int q = 0;
-    L.xt = q; q += 3 * PROMP_PASS_XPLANE;
-    L.ta = q; q += 3 * PROMP_PASS_TPLANE;
-    L.tb = q; q += 3 * PROMP_PASS_TPLANE;
-    L.dm = q; q += 3 * PROMP_PASS_DPLANE;
+    L.xt = q; q += PROMP_NT * PROMP_PASS_XPLANE;
+    L.ta = q; q += PROMP_NT * PROMP_PASS_TPLANE;
+    L.tb = q; q += PROMP_NT * PROMP_PASS_TPLANE;
+    L.dm = q; q += PROMP_NT * PROMP_PASS_DPLANE;
     L.wave_stride = q;
     o += nwaves * q;
     {   // end of segment: one slab of [NP + 2] floats per wave, from offset 4 (aliases everything else)
@@ -113,7 +113,7 @@ PROMP_DEV float pass_neg_dtanh(float h) { return __builtin_fmaf(h, h, -1.f); }
 // `mid` runs between the load phase and the first split (all loads issued, none used, LDS untouched): the caller requests its first
 // tile's observations there and joins the workgroup (see chain_stage_nets).
 template <int NC1, int NC2, int NW, typename Mid>
-PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid, Mid&& mid) {
+PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid, float w1s, Mid&& mid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NP1 = NC1 / 2, NP2 = NC2 / 2, NT = 64 * NW;
     constexpr PassLds L = pass_layout(NC1, NC2, 1, 0);
     constexpr int B1 = L.f_w2f / 64, B2 = L.f_w2b / 64, B3 = L.f_w3f / 64, NBLK = L.n_frag / 64;
@@ -184,7 +184,9 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid,
     sched_fence();       // every load is issued before the first store
     mid();
     sched_fence();
-    // scales (the kernels that feed a tanh are prescaled) and the zero masks of the padding are applied here
+    // scales (the kernels that feed a tanh are prescaled; the hidden_0 kernel also by w1s, the inverse of the power of two the
+    // segment's observations are multiplied by) and the zero masks of the padding are applied here
+    const float w1p = PROMP_TANH_PRESCALE * w1s;
     auto put = [&](const float (&x)[8], int b, float m0, float m1) {
         f32x4 lo, hi;
 #pragma unroll
@@ -192,10 +194,10 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid,
             lo[e] = x[e] * m0;
             hi[e] = x[4 + e] * m1;
         }
-        u32x4 pl[3];
+        u32x4 pl[PROMP_NT];
         pass_split8(lo, hi, pl);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
+        for (int t = 0; t < PROMP_NT; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
     };
     // (a wave past the end of a kind stores the kind's last block a second time: same values, same addresses, no branch -- a
     //  guarded store invites the compiler to sink the block's loads into the guard, one more round trip)
@@ -205,13 +207,13 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid,
         f32x4 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            lo[e] = x1[it][e] * (8 * kk + e < O ? PROMP_TANH_PRESCALE : 0.f);
-            hi[e] = x1[it][4 + e] * (8 * kk + 4 + e < O ? PROMP_TANH_PRESCALE : 0.f);
+            lo[e] = x1[it][e] * (8 * kk + e < O ? w1p : 0.f);
+            hi[e] = x1[it][4 + e] * (8 * kk + 4 + e < O ? w1p : 0.f);
         }
-        u32x4 pl[3];
+        u32x4 pl[PROMP_NT];
         pass_split8(lo, hi, pl);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
+        for (int t = 0; t < PROMP_NT; ++t) sts_w4(sm + L.wp + t * L.plane_stride + 4 * (64 * b + lane), pl[t]);
     }
 #pragma unroll
     for (int it = 0; it < IT2; ++it) {
@@ -236,17 +238,20 @@ PROMP_DEV void pass_stage_net(float* sm, const float* th, int O, int A, int tid,
 }
 
 // Cross-wave, fixed-order sum of the waves' gradient tiles -> one partial row in global memory (accumulators in the
-// 32x32 / 16x16 result layouts of this kernel).  Every wave stores its tiles to its own LDS slab of [NP + 2] floats (every
+// 32x32 / 16x16 result layouts of this kernel).  gsc / gsc1: the exact powers of two that undo this wave's cotangent scale (and, for
+// the hidden_0 kernel, the observations' scale) on the way into the slab.  Every wave stores its tiles to its own LDS slab of [NP + 2] floats (every
 // entry written exactly once), then all threads add the slabs in wave order.
 template <int NC1, int NC2, int NW>
-PROMP_DEV void pass_reduce_to_partial(float* S, float* P, const f32x16 (&aw2)[NC1 / 2][NC2 / 2], const f32x16 (&aw1)[NC1 / 2],
+PROMP_DEV bool pass_reduce_to_partial(float* S, float* P, const f32x16 (&aw2)[NC1 / 2][NC2 / 2], const f32x16 (&aw1)[NC1 / 2],
                                       const f32x4 (&aw3)[NC2], const f32x4 (&gb1)[NC1], const f32x4 (&gb2)[NC2], float gs0,
-                                      float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid) {
+                                      float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid, float gsc,
+                                      float gsc1, int bad) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     tid += opaque_zero();         // (as in chain_reduce_to_partial: no lane-constant index kept alive, and spilled, across the tile loop)
     const int lane = tid & 63, w = tid >> 6, i16 = lane & 15, kk = lane >> 4, j32 = lane & 31, kh = lane >> 5;
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
     const int SL = (NP + 2 + 3) & ~3;
+    if (lane == 0) ((int*)S)[w - 4] = bad;     // the spare words in front of the slabs: this wave's overflow vote
     lds_barrier();                // every wave is done with the parameter planes / transposed tiles
     {
         float* mine = S + w * SL;
@@ -256,28 +261,28 @@ PROMP_DEV void pass_reduce_to_partial(float* S, float* P, const f32x16 (&aw2)[NC
             for (int bj = 0; bj < NC2 / 2; ++bj)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    mine[oW2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + 32 * bj + j32] = aw2[bi][bj][r];
+                    mine[oW2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + 32 * bj + j32] = aw2[bi][bj][r] * gsc;
 #pragma unroll
         for (int bj = 0; bj < NC1 / 2; ++bj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;      // observation index
-                if (row < O) mine[row * H1 + 32 * bj + j32] = aw1[bj][r];
+                if (row < O) mine[row * H1 + 32 * bj + j32] = aw1[bj][r] * gsc1;
             }
 #pragma unroll
         for (int c = 0; c < NC2; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (i16 < A) mine[oW3 + (16 * c + 4 * kk + r) * A + i16] = aw3[c][r];
+                if (i16 < A) mine[oW3 + (16 * c + 4 * kk + r) * A + i16] = aw3[c][r] * gsc;
         if (i16 == 0) {           // (bias sums already folded over the 16 sample lanes) units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1
 #pragma unroll
             for (int c = 0; c < NC1; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[ob1 + 16 * c + 4 * kk + r] = gb1[c][r];
+                for (int r = 0; r < 4; ++r) mine[ob1 + 16 * c + 4 * kk + r] = gb1[c][r] * gsc;
 #pragma unroll
             for (int c = 0; c < NC2; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[ob2 + 16 * c + 4 * kk + r] = gb2[c][r];
+                for (int r = 0; r < 4; ++r) mine[ob2 + 16 * c + 4 * kk + r] = gb2[c][r] * gsc;
             if (2 * kk < A) {
                 mine[ob3 + 2 * kk] = gb30;
                 mine[oS + 2 * kk] = gs0;
@@ -306,6 +311,10 @@ PROMP_DEV void pass_reduce_to_partial(float* S, float* P, const f32x16 (&aw2)[NC
         for (int ww = 1; ww < NW; ++ww) t += v[ww];
         *(f32x4*)(P + e) = t;
     }
+    int any = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) any |= ((const int*)S)[ww - 4];
+    return any != 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -326,14 +335,45 @@ struct PassSums {                // what a wave accumulates over its tiles of a 
     f32x16 aw2[NC1 / 2][NC2 / 2], aw1[NC1 / 2];
     f32x4 aw3[NC2], gb1[NC1], gb2[NC2];
     float loss, klsum, gs0, gs1, gb30, gb31;
+    // FP16 split: the power of two 2^ck this wave's cotangents are multiplied by in the segment (cs), its inverse (ics); prov: no tile
+    // has had a nonzero cotangent yet (the accumulators are exactly zero and the scale is still free)
+    float cs, ics, amax;         // amax: the largest |mean cotangent| the wave has met in the segment, unscaled
+    int prov;
 };
+// FP16 has a range.  From the distribution epilogue on, a tile's cotangents -- and everything the backward half accumulates --
+// carry the wave's power of two S.cs, undone on the way into the end-of-segment slab.  The wave's first tile with a cotangent sets
+// it (until then the accumulators are exactly zero and the scale is free): the largest mean cotangent of that tile goes to
+// [2^t, 2^(t+1)), t = PASS_CT_TARGET: the typical cotangent of every backward stage then stays above 2^-3 (where a value's low term
+// turns subnormal and its error stops shrinking with the value: 2^-25 absolute) for layer gains down to ~2^-6, and later tiles have
+// 2^6 of headroom (times 2^5 of backward gain) under FP16's 65504.  The tile itself pays one instruction for this: the wave's running
+// maximum S.amax.  Cotangents are heavy-tailed when the policy has moved far from the one that sampled (the ratio is an exponential);
+// a wave whose maximum has passed 2^PASS_CT_LIMIT at its scale, or that finds an infinity in its sums (gains beyond the bound), says so
+// at the end of the segment, and the workgroup walks the segment again -- now every wave knows the largest cotangent it will meet
+// and puts THAT at 2^PASS_CT_REDO (a third walk, for gains beyond 2^5: PASS_CT_RETRY lower).  Guarded in-tile variants (rescaling
+// the sums in place; abandoning the tile and walking it again) were built and measured: +3.4 / +4.7 us per launch for an event that
+// does not occur at PPO's operating point.
+#ifndef PROMP_CT_ATTEMPTS
+#define PROMP_CT_ATTEMPTS 3
+#endif
+PROMP_CX int PASS_CT_TARGET = 5, PASS_CT_LIMIT = 11, PASS_CT_REDO = 10, PASS_CT_RETRY = 12, PASS_CT_ATTEMPTS = PROMP_CT_ATTEMPTS;
+// the scale a largest |mean cotangent| of mx asks for (mx = 0 / not finite: 2^-4 N, for adv / N, and `prov`)
+template <int NC1, int NC2>
+PROMP_DEV void pass_cotangent_scale(PassSums<NC1, NC2>& S, float mx, float invN, int target) {
+    const bool okm = mx > 0.f && mx < 3.0e38f;
+    int k = scale_exp(okm ? mx : invN, okm ? target : -4);
+    k = k < -100 ? -100 : k > 100 ? 100 : k;
+    S.cs = pow2f(k);
+    S.ics = pow2f(-k);
+    S.prov = okm ? 0 : 1;
+}
 
 // constants of a wave's walk through a segment
 struct PassWalk {
     const float *obs, *act, *adv, *old_mean, *old_log_std;
     float* hcache;
     int ls_per_row, O, A, task, trow0, tnrows, tend, loss_kind;
-    float invN, clip_eps, sums;
+    int ct_target;               // FP16 split: where the first tile's largest cotangent goes (pass_cotangent_scale)
+    float invN, clip_eps, sums, xs;      // xs: the power of two the task's observations are multiplied by (FP16 split)
     float s0, s1, e0, e1, sn20, sn21, rden0, rden1;
     int q0, q1;
     bool own0, own1;
@@ -359,25 +399,25 @@ PROMP_DEV void pass_load_x(float (&xr)[8], const PassWalk& W, int t, int i16, in
     for (int e = 0; e < 8; ++e) {
         const int o = 8 * kk + e;
         const bool ok = rv && o < W.O;
-        xr[e] = src[ok ? o : 0] * (ok ? 1.f : 0.f);
+        xr[e] = src[ok ? o : 0] * (ok ? W.xs : 0.f);
     }
 }
 
-// acc[c] += sum over the six products of (A-side fragments wf[ta][c]) x (B-side planes xb[tb])
+// acc[c] += sum over the products (ta + tb < NT) of (A-side fragments wf[ta][c]) x (B-side planes xb[tb])
 template <int NC>
-PROMP_DEV void pass_gemm16(f32x4 (&acc)[NC], const u32x4 (&wf)[3][NC], const u32x4 (&xb)[3]) {
+PROMP_DEV void pass_gemm16(f32x4 (&acc)[NC], const u32x4 (&wf)[PROMP_NT][NC], const u32x4 (&xb)[PROMP_NT]) {
 #pragma unroll
-    for (int ta = 2; ta >= 0; --ta)
+    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
-        for (int tb = 2 - ta; tb >= 0; --tb)
+        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = mfma16_bf16w(wf[ta][c], xb[tb], acc[c]);
+            for (int c = 0; c < NC; ++c) acc[c] = mfma16_sw<PROMP_NT>(wf[ta][c], xb[tb], acc[c]);
 }
 // the fragments [term][c] of NC consecutive 64-fragment blocks starting at `first`, stride `cs` blocks between them
 template <int NC>
-PROMP_DEV void pass_load_frags(u32x4 (&wf)[3][NC], const u32x4* F, int PS, int first, int cs) {
+PROMP_DEV void pass_load_frags(u32x4 (&wf)[PROMP_NT][NC], const u32x4* F, int PS, int first, int cs) {
 #pragma unroll
-    for (int ta = 0; ta < 3; ++ta)
+    for (int ta = 0; ta < PROMP_NT; ++ta)
 #pragma unroll
         for (int c = 0; c < NC; ++c) wf[ta][c] = F[ta * PS + first + c * cs];
 }
@@ -387,20 +427,20 @@ PROMP_DEV void pass_load_frags(u32x4 (&wf)[3][NC], const u32x4* F, int PS, int f
 // instructions are issued in the NEXT tile's first tanh / split region, whose vector work runs in their shadow.
 template <int NC1>
 struct PassPending {
-    u32x4 fx[3], fd[NC1 / 2][3];
+    u32x4 fx[PROMP_NT], fd[NC1 / 2][PROMP_NT];
 };
 template <int NC1, int NC2>
 PROMP_DEV void pass_flush_pending(PassSums<NC1, NC2>& S, const PassPending<NC1>& Q) {
 #pragma unroll
-    for (int ta = 2; ta >= 0; --ta)
+    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
-        for (int tb = 2 - ta; tb >= 0; --tb)
+        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
 #pragma unroll
-            for (int bj = 0; bj < NC1 / 2; ++bj) S.aw1[bj] = mfma32_bf16w(Q.fx[ta], Q.fd[bj][tb], S.aw1[bj]);
+            for (int bj = 0; bj < NC1 / 2; ++bj) S.aw1[bj] = mfma32_sw<PROMP_NT>(Q.fx[ta], Q.fd[bj][tb], S.aw1[bj]);
 }
 
 template <int NC1, int NC2, bool BWD, bool STORE, bool PENDING>
-PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f)[3][NC1], float (&xr)[8], const PassWalk& W,
+PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f)[PROMP_NT][NC1], float (&xr)[8], const PassWalk& W,
                          const PassTileAddr& T, float* sm, float* wreg, int lane, int t, int tnext) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NP1 = NC1 / 2, NP2 = NC2 / 2, NB1 = NC1 / 2, NB2 = NC2 / 2;
     constexpr int HCR = chain_cache_row(H1, H2);
@@ -423,7 +463,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     const float ac0 = W.act[n * W.A + W.q0], ac1 = W.act[n * W.A + W.q1];
     const float mo0 = W.old_mean[n * W.A + W.q0], mo1 = W.old_mean[n * W.A + W.q1];
     const float so0 = olsp[W.q0], so1 = olsp[W.q1];
-    u32x4 xB[3];
+    u32x4 xB[PROMP_NT];
     {
         f32x4 lo, hi;
 #pragma unroll
@@ -436,7 +476,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     pass_load_x(xr, W, tnext, i16, kk);
     if (BWD) {
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
+        for (int tt = 0; tt < PROMP_NT; ++tt) {
             sts_w2(XT + tt * XPL + T.xw0, xB[tt][0], xB[tt][1]);
             sts_w2(XT + tt * XPL + T.xw1, xB[tt][2], xB[tt][3]);
         }
@@ -448,12 +488,12 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
         for (int c = 0; c < NC1; ++c) h1[c] = lds4(B1l + 16 * c);
     }
     pass_gemm16<NC1>(h1, w1f, xB);                               // Z1^T = W1^T X^T + b1 (K = 32 observation slots, zero padded)
-    u32x4 w2f[NP1][3][NC2];
+    u32x4 w2f[NP1][PROMP_NT][NC2];
     pass_load_frags<NC2>(w2f[0], F, PS, L.f_w2f, NP1 * 64);      // [c2][P = 0]
     // (the split first; then layer 1's matrix instructions with the region's address arithmetic and requests in their shadow)
-    PROMP_SCHED_VALU(48);
+    PROMP_SCHED_VALU(PROMP_NT == 3 ? 48 : 20);
 #pragma unroll
-    for (int i = 0; i < 6 * NC1; ++i) {
+    for (int i = 0; i < PROMP_NPROD * NC1; ++i) {
         PROMP_SCHED_MFMA(1);
         PROMP_SCHED_VALU(3);
         PROMP_SCHED_DSREAD(1);
@@ -461,7 +501,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     sched_fence();
     // ---- region 1: tanh, hidden_0 planes (-> first tile); requests the rest of layer 2
     PASS_STAMP(1);
-    u32x4 hB1[NP1][3];
+    u32x4 hB1[NP1][PROMP_NT];
 #pragma unroll
     for (int c = 0; c < NC1; ++c) {
         h1[c] = pass_tanh4(h1[c]);
@@ -478,9 +518,9 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
         // the previous tile's hidden_0 kernel gradient: 6 NB1 matrix instructions of 32 cycles, this region's vector work in between
         pass_flush_pending<NC1, NC2>(S, Q);
 #pragma unroll
-        for (int i = 0; i < 6 * NB1; ++i) {
+        for (int i = 0; i < PROMP_NPROD * NB1; ++i) {
             PROMP_SCHED_MFMA(1);
-            PROMP_SCHED_VALU(7);
+            PROMP_SCHED_VALU(PROMP_NT == 3 ? 7 : 14);
         }
     }
     sched_fence();
@@ -493,13 +533,13 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     }
 #pragma unroll
     for (int P = 0; P < NP1; ++P) pass_gemm16<NC2>(h2, w2f[P], hB1[P]);
-    u32x4 w3f[NP2][3][1];
+    u32x4 w3f[NP2][PROMP_NT][1];
 #pragma unroll
     for (int P = 0; P < NP2; ++P) pass_load_frags<1>(w3f[P], F, PS, L.f_w3f + P * 64, 0);
     sched_fence();
     // ---- region 3: tanh, hidden_1 planes (-> second tile)
     PASS_STAMP(3);
-    u32x4 hB2[NP2][3];
+    u32x4 hB2[NP2][PROMP_NT];
 #pragma unroll
     for (int c = 0; c < NC2; ++c) {
         h2[c] = pass_tanh4(h2[c]);
@@ -525,10 +565,10 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
 #pragma unroll
         for (int P = 0; P < NP2; ++P)
 #pragma unroll
-            for (int ta = 2; ta >= 0; --ta)
+            for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
-                for (int tb = 2 - ta; tb >= 0; --tb)
-                    m[(ta + tb + P) & 1] = mfma16_bf16w(w3f[P][ta][0], hB2[P][tb], m[(ta + tb + P) & 1]);
+                for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
+                    m[(ta + tb + P) & 1] = mfma16_sw<PROMP_NT>(w3f[P][ta][0], hB2[P][tb], m[(ta + tb + P) & 1]);
         mu0 = m[0][0] + m[1][0];
         mu1 = m[0][1] + m[1][1];
         if (STORE) {
@@ -562,17 +602,26 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
         const float ck = is_kl ? rv * W.invN : 0.f;
         const float lrow = is_kl ? kl * W.invN : is_ratio ? -rho * aw : is_clip ? -fminf(x, y) * W.invN : -lp * aw;
         const float first = (kk == 0) ? rv : 0.f;          // one lane per row carries the row's scalars
-        S.loss += first * lrow;
-        S.klsum += first * (kl * W.invN);
         const float dklm0 = -2.f * (mo0 - mu0) * W.rden0, dklm1 = -2.f * (mo1 - mu1) * W.rden1;
         const float dkls0 = (-2.f * W.sn20 * den0 - 4.f * num0 * W.sn20) * (W.rden0 * W.rden0) + 1.f;
         const float dkls1 = (-2.f * W.sn21 * den1 - 4.f * num1 * W.sn21) * (W.rden1 * W.rden1) + 1.f;
         d0 = o0 * (c * z0 * W.e0 + ck * dklm0);
         d1 = o1 * (c * z1 * W.e1 + ck * dklm1);
+        if (BWD && PROMP_NT == 2) {
+            const float am = fmaxf(fabsf(d0), fabsf(d1));
+            S.amax = fmaxf(S.amax, am);
+            if (!PENDING || wave_uniform(S.prov)) pass_cotangent_scale<NC1, NC2>(S, wave_absmax_f32(am), W.invN, W.ct_target);
+        }
+        S.loss += first * lrow;
+        S.klsum += first * (kl * W.invN);
         S.gs0 += o0 * (c * (z0 * z0 - 1.f) + ck * dkls0);
         S.gs1 += o1 * (c * (z1 * z1 - 1.f) + ck * dkls1);
         S.gb30 += d0;
         S.gb31 += d1;
+        if (BWD && PROMP_NT == 2) {
+            d0 *= S.cs;
+            d1 *= S.cs;
+        }
     }
     if (!BWD) {
         pass_load_frags<NC1>(w1f, F, PS, L.f_w1, 64);            // the next tile's layer 1
@@ -580,12 +629,12 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
         return;
     }
     {
-        unsigned dw[3];
-        bf16_split3_pair(d0, d1, dw);
+        unsigned dw[PROMP_NT];
+        split_pair<PROMP_NT>(d0, d1, dw);
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) DM[tt * DPL + T.dmw] = __builtin_bit_cast(float, dw[tt]);
+        for (int tt = 0; tt < PROMP_NT; ++tt) DM[tt * DPL + T.dmw] = __builtin_bit_cast(float, dw[tt]);
     }
-    u32x4 bD[3], aH[NC2][3];
+    u32x4 bD[PROMP_NT], aH[NC2][PROMP_NT];
     pass_read_tr(bD, DM, DPL, T.dr0, T.dr1);
 #pragma unroll
     for (int c = 0; c < NC2; ++c) pass_read_tr(aH[c], TB, TPL, T.rd16_0 + 2 * (128 * (c >> 1) + 16 * (c & 1)), T.rd16_1 + 2 * (128 * (c >> 1) + 16 * (c & 1)));
@@ -604,12 +653,12 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     for (int c = 0; c < NC2; ++c) dz2[c] = mfma16(wb[c][0], d0, zero4());
 #pragma unroll
     for (int c = 0; c < NC2; ++c) dz2[c] = mfma16(wb[c][1], d1, dz2[c]);
-    u32x4 w2b[NP2][3][NC1];
+    u32x4 w2b[NP2][PROMP_NT][NC1];
     pass_load_frags<NC1>(w2b[0], F, PS, L.f_w2b, NP2 * 64);      // [c1][P = 0]
     sched_fence();
     // ---- region 6: dZ2^T = dH2^T * (1 - H2^2), its planes (-> second tile, over the hidden_1 planes)
     PASS_STAMP(6);
-    u32x4 dB2[NP2][3];
+    u32x4 dB2[NP2][PROMP_NT];
 #pragma unroll
     for (int c = 0; c < NC2; ++c)
 #pragma unroll
@@ -625,15 +674,15 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     // the output-kernel gradient aw3[unit][action] += sum_s H2[s][unit] dmu[s][action] (operands read in region 4) in this
     // region's shadow: 6 NC2 matrix instructions of 16 cycles, three vector instructions after each
 #pragma unroll
-    for (int ta = 2; ta >= 0; --ta)
+    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
-        for (int tb = 2 - ta; tb >= 0; --tb)
+        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
 #pragma unroll
-            for (int c = 0; c < NC2; ++c) S.aw3[c] = mfma16_bf16w(aH[c][ta], bD[tb], S.aw3[c]);
+            for (int c = 0; c < NC2; ++c) S.aw3[c] = mfma16_sw<PROMP_NT>(aH[c][ta], bD[tb], S.aw3[c]);
 #pragma unroll
-    for (int i = 0; i < 6 * NC2; ++i) {
+    for (int i = 0; i < PROMP_NPROD * NC2; ++i) {
         PROMP_SCHED_MFMA(1);
-        PROMP_SCHED_VALU(4);
+        PROMP_SCHED_VALU(PROMP_NT == 3 ? 4 : 6);
         PROMP_SCHED_DSWRITE(1);
     }
     sched_fence();
@@ -642,7 +691,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     PASS_STAMP(7);
 #pragma unroll
     for (int P = 1; P < NP2; ++P) pass_load_frags<NC1>(w2b[P], F, PS, L.f_w2b + P * 64, NP2 * 64);
-    u32x4 fa[NB1][3], fb[NB2][3];
+    u32x4 fa[NB1][PROMP_NT], fb[NB2][PROMP_NT];
 #pragma unroll
     for (int b = 0; b < NB1; ++b) pass_read_tr(fa[b], TA, TPL, T.rd32_0 + 256 * b, T.rd32_1 + 256 * b);
 #pragma unroll
@@ -654,9 +703,9 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     for (int P = 0; P < NP2; ++P) pass_gemm16<NC1>(ad1, w2b[P], dB2[P]);
     if (STORE) {
 #pragma unroll
-        for (int c = 0; c < NC1; ++c) *(f32x4*)(hcb + 256 * (NC1 + NC2) + 128 + 256 * c) = ad1[c];
+        for (int c = 0; c < NC1; ++c) *(f32x4*)(hcb + 256 * (NC1 + NC2) + 128 + 256 * c) = PROMP_NT == 2 ? ad1[c] * S.ics : ad1[c];
     }
-    u32x4 fx[3];
+    u32x4 fx[PROMP_NT];
     pass_read_tr(fx, XT, XPL, T.rd32_0, T.rd32_1);
     sched_fence();
     // ---- region 8: dZ1^T = dH1^T * (1 - H1^2), its planes (-> first tile, over the hidden_0 planes: their reads were issued in
@@ -671,24 +720,24 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
         }
 #pragma unroll
     for (int P = 0; P < NP1; ++P) {
-        u32x4 dB1[3];
+        u32x4 dB1[PROMP_NT];
         pass_split8(ad1[2 * P], ad1[2 * P + 1], dB1);
         pass_store_planes(TA, TPL, T.wr + 256 * P, dB1);
     }
     // the hidden_1 kernel gradient aw2[u1][u2] += sum_s H1[s][u1] dZ2[s][u2] on 32x32x16 (operands read in regions 5 / 6) in this
     // region's shadow: 6 NB1 NB2 matrix instructions of 32 cycles, seven vector / LDS instructions after each
 #pragma unroll
-    for (int ta = 2; ta >= 0; --ta)
+    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
-        for (int tb = 2 - ta; tb >= 0; --tb)
+        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
 #pragma unroll
             for (int bi = 0; bi < NB1; ++bi)
 #pragma unroll
-                for (int bj = 0; bj < NB2; ++bj) S.aw2[bi][bj] = mfma32_bf16w(fa[bi][ta], fb[bj][tb], S.aw2[bi][bj]);
+                for (int bj = 0; bj < NB2; ++bj) S.aw2[bi][bj] = mfma32_sw<PROMP_NT>(fa[bi][ta], fb[bj][tb], S.aw2[bi][bj]);
 #pragma unroll
-    for (int i = 0; i < 6 * NB1 * NB2; ++i) {
+    for (int i = 0; i < PROMP_NPROD * NB1 * NB2; ++i) {
         PROMP_SCHED_MFMA(1);
-        PROMP_SCHED_VALU(6);
+        PROMP_SCHED_VALU(PROMP_NT == 3 ? 6 : 7);
         PROMP_SCHED_DSWRITE(1);
     }
     sched_fence();
@@ -697,7 +746,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
     //      the next tile's layer 1
     PASS_STAMP(9);
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) Q.fx[tt] = fx[tt];
+    for (int tt = 0; tt < PROMP_NT; ++tt) Q.fx[tt] = fx[tt];
 #pragma unroll
     for (int b = 0; b < NB1; ++b) pass_read_tr(Q.fd[b], TA, TPL, T.rd32_0 + 256 * b, T.rd32_1 + 256 * b);
     pass_load_frags<NC1>(w1f, F, PS, L.f_w1, 64);
@@ -751,6 +800,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
 
     const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
     CH_WGSTAMP(0);
+    int attempt = 0;             // FP16 split: how often the current segment has overflowed (see the end of the tile walk)
+    float redo_amax = 0.f;       // ... and the largest cotangent this wave met on the way
     for (int sg = sg0; sg < sg1; ++sg) {
         const ChainSeg seg = a.segs[sg];
         W.task = seg.task;
@@ -765,13 +816,25 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
         int t = seg.tile0 + w;
         const ChainDistRaw draw = chain_dist_load(th, nullptr, oS, A, tid);
         CH_STAMP(0);
-        pass_stage_net<NC1, NC2, NW>(sm, th, O, A, tid, [&]() {
+        // FP16 split: the task's observations are multiplied by the power of two that brings the largest of them (promp_ctx's
+        // per-task table, filled when the slab arrives) to [8, 16) -- between 2^-6 and 2^8, so that the hidden_0 kernel, which
+        // takes the inverse, stays inside the format too
+        float w1s = 1.f;
+        W.xs = 1.f;
+        if (PROMP_NT == 2 && a.obs_absmax != nullptr) {
+            const float mx = a.obs_absmax[seg.task];
+            int sx = (mx > 0.f && mx < 3.0e38f) ? -scale_exp(mx, 3) : 0;
+            sx = sx < -6 ? -6 : sx > 8 ? 8 : sx;
+            W.xs = pow2f(-sx);
+            w1s = pow2f(sx);
+        }
+        pass_stage_net<NC1, NC2, NW>(sm, th, O, A, tid, w1s, [&]() {
             pass_load_x(xr, W, t, i16, kk);
             __syncthreads();
         });
         chain_stage_dist(sm + L.dist, draw, A, a.clip_log_std, a.min_log_std, tid);
         // the action slots >= 8 of the cotangent tiles read as zero (the end-of-segment slabs alias them: once per segment)
-        for (int e = lane; e < 3 * DPL; e += 64) wreg[L.dm + e] = 0.f;
+        for (int e = lane; e < PROMP_NT * DPL; e += 64) wreg[L.dm + e] = 0.f;
         __syncthreads();
         CH_STAMP(1);
         W.s0 = dist[CH_LS + W.q0]; W.s1 = dist[CH_LS + W.q1]; W.e0 = dist[CH_ES + W.q0]; W.e1 = dist[CH_ES + W.q1];
@@ -797,8 +860,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
 #pragma unroll
         for (int c = 0; c < NC1; ++c) S.gb1[c] = zero4();
         S.loss = S.klsum = S.gs0 = S.gs1 = S.gb30 = S.gb31 = 0.f;
+        S.cs = S.ics = 1.f;
+        S.amax = 0.f;
+        S.prov = 1;
+        W.ct_target = PASS_CT_TARGET;
+        if (PROMP_NT == 2 && attempt > 0) {      // the segment again: the wave's largest cotangent is known
+            pass_cotangent_scale<NC1, NC2>(S, redo_amax, W.invN, PASS_CT_REDO - (attempt - 1) * PASS_CT_RETRY);
+            W.ct_target = PASS_CT_REDO - (attempt - 1) * PASS_CT_RETRY;      // (a wave that met no cotangent: still provisional)
+        }
 
-        u32x4 w1f[3][NC1];
+        u32x4 w1f[PROMP_NT][NC1];
         pass_load_frags<NC1>(w1f, (const u32x4*)(sm + L.wp) + lane, L.n_frag, L.f_w1, 64);
         W.tix = 0;
         PassPending<NC1> Q;
@@ -809,6 +880,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
                 pass_tile<NC1, NC2, BWD, STORE, true>(S, Q, w1f, xr, W, T, sm, wreg, lane, t, t + NW);
             }
             if (BWD) pass_flush_pending<NC1, NC2>(S, Q);
+        }
+        // FP16 split (pass_cotangent_scale): did this wave's cotangents stay inside the format?  Its largest one at its scale, and --
+        // for backward gains beyond the bound -- an infinity or a NaN in the hidden_0 bias / kernel sums, the last links of the
+        // chain (x * 0 is 0 for finite x only).  The waves vote inside pass_reduce_to_partial (its first barrier); a workgroup with
+        // an overflow walks the segment again, every wave with the largest cotangent it met (redo_amax) for a scale.
+        int bad = 0;
+        if (BWD && PROMP_NT == 2 && attempt + 1 < PASS_CT_ATTEMPTS) {
+            float chk = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC1; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) chk = __builtin_fmaf(S.gb1[c][r], 0.f, chk);
+#pragma unroll
+            for (int i = 0; i < NB1; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(S.aw1[i][r], 0.f, chk);
+            redo_amax = wave_absmax_f32(S.amax);
+            bad = (wave_any(chk != chk) || !(redo_amax * S.cs <= (float)(1 << PASS_CT_LIMIT))) ? 1 : 0;
         }
         CH_STAMP(2);
 
@@ -845,8 +934,47 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
             for (int r = 0; r < 4; ++r) S.gb2[c][r] = row16_sum(S.gb2[c][r]);
         gs0 *= dist[CH_LMASK + W.q0];
         gs1 *= dist[CH_LMASK + W.q1];
-        pass_reduce_to_partial<NC1, NC2, NW>(sm + 4, P, S.aw2, S.aw1, S.aw3, S.gb1, S.gb2, gs0, gs1, gb30, gb31, loss, klsum, O, A, tid);
+        const bool redo = pass_reduce_to_partial<NC1, NC2, NW>(sm + 4, P, S.aw2, S.aw1, S.aw3, S.gb1, S.gb2, gs0, gs1, gb30, gb31, loss, klsum, O, A, tid,
+                                                               S.ics, S.ics * w1s, bad);
+        if (redo) {              // (the partial row just written is written again)
+            if (tid == 0) atomic_add_agent(a.split_events + 0, 1);
+            attempt += 1;
+            sg -= 1;
+            continue;
+        }
+        attempt = 0;
         CH_STAMP(3);
         CH_WGSTAMP(1 + (sg - sg0 < 2 ? sg - sg0 : 1));
     }
+}
+
+// Largest |observation| of every task's rows -> obs_absmax[task] (as the bits of a non-negative float: ordered like unsigned
+// integers, NaN above everything).  Run once when a slab arrives (upload, end of a collection, device rollout): the FP16 split
+// of the pass kernels keeps the observations near 1 with the power of two this yields (k_pass: W.xs).  Grid (tasks, slices);
+// the table is zeroed in front of the launch.  HBM-bound: 4 O bytes per row, once per slab.
+struct ObsRangeArgs {
+    const float* obs;
+    const int* task_row_offsets;
+    unsigned* absmax;       // [tasks]
+    int O;
+};
+__global__ void __launch_bounds__(256) k_obs_range(ObsRangeArgs a) {
+    const int task = blockIdx.y, tid = threadIdx.x;
+    const long long r0 = a.task_row_offsets[task], r1 = a.task_row_offsets[task + 1];
+    const long long n = (r1 - r0) * a.O, per = (n + gridDim.x - 1) / gridDim.x;
+    const long long b = per * blockIdx.x, e = b + per < n ? b + per : n;
+    const float* src = a.obs + r0 * a.O;
+    unsigned m = 0;
+    for (long long i = b + tid; i < e; i += 256) {
+        const unsigned u = __builtin_bit_cast(unsigned, src[i]) & 0x7FFFFFFFu;
+        m = u > m ? u : m;
+    }
+    float mf = __builtin_bit_cast(float, m);      // (compared as integers below: the bit patterns of non-negative floats are ordered)
+#pragma unroll
+    for (int x = 32; x >= 1; x >>= 1) {
+        const unsigned o = __builtin_bit_cast(unsigned, shfl_xor_f32(mf, x));
+        m = o > m ? o : m;
+        mf = __builtin_bit_cast(float, m);
+    }
+    if ((tid & 63) == 0 && m != 0) atomic_max_agent(a.absmax + task, m);
 }

@@ -259,6 +259,87 @@ inline void bf16_split3_pair(float x0, float x1, unsigned (&w)[3]) {
         r1 -= emu_bf2f(h1);
     }
 }
+// ---- the split of round 6 (promp_device.h: split_pair / mfma16_sw / mfma32_sw) -------------------------------------------
+// FP16: round to nearest even with subnormal results kept (v_cvt_pk_f16_f32 under the kernels' default mode), subnormal inputs kept
+// by the matrix instruction (tools/micro/f16_split_probe.hip); overflow -> inf.
+inline unsigned short emu_f2h(float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    const unsigned sign = (u >> 16) & 0x8000u, au = u & 0x7FFFFFFFu;
+    if (au >= 0x7F800000u) return (unsigned short)(sign | 0x7C00u | ((au > 0x7F800000u) ? 0x200u : 0u));
+    const int e = (int)(au >> 23) - 127;
+    if (e > 15) return (unsigned short)(sign | 0x7C00u);
+    unsigned mant = (au & 0x7FFFFFu) | 0x800000u;           // 24 significant bits
+    int shift;                                              // bits dropped from the 24-bit significand
+    unsigned hexp;
+    if (e >= -14) { shift = 13; hexp = (unsigned)(e + 15); }
+    else { shift = 13 + (-14 - e); hexp = 0; }
+    if (au < 0x00800000u || shift > 25) return (unsigned short)sign;      // (float32 subnormals and anything below 2^-26: zero)
+    const unsigned q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    unsigned r = q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u);
+    // normal: q carries the implicit bit (0x400); a carry out of the significand bumps the exponent; subnormal: r is the field
+    unsigned h = hexp ? ((hexp - 1u) << 10) + r : r;
+    if (h >= 0x7C00u) h = 0x7C00u;
+    return (unsigned short)(sign | h);
+}
+inline float emu_h2f(unsigned short h) {
+    const unsigned sign = ((unsigned)h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    float x;
+    if (e == 0) x = ldexpf((float)m, -24);
+    else if (e == 31) x = m ? NAN : INFINITY;
+    else x = ldexpf((float)(m | 0x400u), (int)e - 25);
+    return sign ? -x : x;
+}
+template <int NT>
+inline float emu_half2f(unsigned short h) { return NT == 2 ? emu_h2f(h) : emu_bf2f(h); }
+template <int NT>
+inline void split_pair(float x0, float x1, unsigned (&w)[NT]) {
+    float r0 = x0, r1 = x1;
+    for (int t = 0; t < NT; ++t) {
+        const unsigned short h0 = NT == 2 ? emu_f2h(r0) : emu_f2bf(r0), h1 = NT == 2 ? emu_f2h(r1) : emu_f2bf(r1);
+        w[t] = h0 | ((unsigned)h1 << 16);
+        r0 -= emu_half2f<NT>(h0);
+        r1 -= emu_half2f<NT>(h1);
+    }
+}
+template <int NT>
+inline f32x4 mfma16_sw(u32x4 a, u32x4 b, f32x4 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 15, g = l >> 4, s = emu::xslot();
+    for (int e = 0; e < 8; ++e) {
+        W.ha[s][l][e] = emu_word_half(a, e);
+        W.hb[s][l][e] = emu_word_half(b, e);
+    }
+    W.bar.arrive_and_wait();
+    f32x4 d;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int kb = 0; kb < 4; ++kb)
+            for (int e = 0; e < 8; ++e) acc += emu_half2f<NT>(W.ha[s][i + 16 * kb][e]) * emu_half2f<NT>(W.hb[s][j + 16 * kb][e]);   // (products exact in float32)
+        d[r] = acc;
+    }
+    return d;
+}
+template <int NT>
+inline f32x16 mfma32_sw(u32x4 a, u32x4 b, f32x16 c) {
+    emu::Wave& W = emu::wave();
+    const int l = emu::lane(), j = l & 31, h = l >> 5, s = emu::xslot();
+    for (int e = 0; e < 8; ++e) {
+        W.ha[s][l][e] = emu_word_half(a, e);
+        W.hb[s][l][e] = emu_word_half(b, e);
+    }
+    W.bar.arrive_and_wait();
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float acc = c[r];
+        for (int kb = 0; kb < 2; ++kb)
+            for (int e = 0; e < 8; ++e) acc += emu_half2f<NT>(W.ha[s][i + 32 * kb][e]) * emu_half2f<NT>(W.hb[s][j + 32 * kb][e]);
+        d[r] = acc;
+    }
+    return d;
+}
 inline f64x4 mfma16d(double a, double b, f64x4 c) {
     emu::Wave& W = emu::wave();
     const int l = emu::lane(), j = l & 15, g = l >> 4, s = emu::xslot();
@@ -318,6 +399,10 @@ inline void fence_release_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void fence_acquire_agent() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline int atomic_add_agent(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline void atomic_store_agent(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline void atomic_max_agent(unsigned* p, unsigned v) {
+    unsigned cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+}
 inline void sched_fence() {}
 inline int opaque_zero() { return 0; }
 inline double* opaque_lds(double* p) { return p; }
