@@ -858,6 +858,11 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     hipDeviceProp_t prop;
     HIPCHECK(hipGetDeviceProperties(&prop, device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // tests: work tables for fewer workgroups than the chip has compute units (a wave then walks several tiles of a small batch)
+        const char* e = getenv("PROMP_MAX_CUS");
+        const int cap = e ? atoi(e) : 0;
+        if (cap > 0 && cap < c->n_cus) c->n_cus = cap;
+    }
     c->clock_mhz = prop.clockRate / 1000;
     snprintf(c->dev_name, sizeof c->dev_name, "%s", prop.name[0] ? prop.name : PROMP_ARCH_NAME(prop));
     HIPCHECK(hipStreamCreate(&c->stream));

@@ -746,8 +746,10 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
 // FP16 split of k_chain_hvp (see pass_cotangent_scale in promp_kernels_pass.h for the reasoning): the direction's largest entry goes
 // to [2, 4) -- its hidden_1 block, the only part that is split, then sits around 2^-3 .. 1, the tangent activations (sums over the
 // observations) around 1 .. 100 --, the first tile's largest mean cotangent to [4, 8), the tangent cotangents follow from the two
-// (x 2^4 .. 2^6).  A wave whose largest cotangent passed 2^CHAIN_CT_LIMIT at its scale, or that finds an infinity in its sums, has the
-// workgroup walk the segment again: the direction 2^CHAIN_V_RETRY lower, the largest cotangent -- known by then -- at 2^CHAIN_CT_REDO.
+// (x 2^4 .. 2^6).  A wave that finds an infinity or a NaN in its sums -- every overflow of a split ends there -- has the workgroup
+// walk the segment again: the direction 2^CHAIN_V_RETRY lower, the largest cotangent -- known by then -- at 2^CHAIN_CT_REDO.  One
+// such segment doubles the launch's duration (the other workgroups wait), so the first walk's targets leave room: 2^13 above the
+// first tile's largest primal cotangent, 2^8 above 1/32 of its largest tangent cotangent.
 #ifndef PROMP_CT_ATTEMPTS
 #define PROMP_CT_ATTEMPTS 3
 #endif
@@ -757,8 +759,8 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
 #ifndef PROMP_CHAIN_CT_TARGET
 #define PROMP_CHAIN_CT_TARGET 2
 #endif
-PROMP_CX int CHAIN_V_TARGET = PROMP_CHAIN_V_TARGET, CHAIN_V_RETRY = 6, CHAIN_CT_TARGET = PROMP_CHAIN_CT_TARGET, CHAIN_CT_LIMIT = CHAIN_CT_TARGET + 6,
-             CHAIN_CT_REDO = CHAIN_CT_LIMIT - 1, CHAIN_CT_RETRY = 10, CHAIN_ATTEMPTS = PROMP_CT_ATTEMPTS;
+PROMP_CX int CHAIN_V_TARGET = PROMP_CHAIN_V_TARGET, CHAIN_V_RETRY = 6, CHAIN_CT_TARGET = PROMP_CHAIN_CT_TARGET,
+             CHAIN_CT_REDO = 8, CHAIN_CT_RETRY = 10, CHAIN_Q_OVER_D = 5, CHAIN_ATTEMPTS = PROMP_CT_ATTEMPTS;
 
 // Two-network product of the R-operator pass on the BF16 pipe, operands streamed:
 //     acc[c] += W[.][c] xa + V[.][c] xb          (PRIMAL: accp[c] += W[.][c] xb as well)
@@ -952,14 +954,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         float klsum = 0.f, outs0 = 0.f, outs1 = 0.f, outb30 = 0.f, outb31 = 0.f;
         // FP16 split: this wave's cotangent scale in the segment (set by its first tile with a cotangent, as in k_pass), the tangent
         // cotangents' (they carry the direction's scale too) and the weight of the KL cotangents among them
-        float cs = 1.f, qs = vs, klws = klw * vs, ivs = 1.f / vs, amax = 0.f;
+        float cs = 1.f, qs = vs, ivs = 1.f / vs, amax = 0.f;
         int prov = 1;
         if (PROMP_NT == 2 && attempt > 0 && redo_amax > 0.f && redo_amax < 3.0e38f) {      // the segment again: the largest cotangent is known
             int k = scale_exp(redo_amax, CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY);
             k = k < -100 ? -100 : k > 100 ? 100 : k;
             cs = pow2f(k);
             qs = cs * vs;
-            klws = klw * qs;
             prov = 0;
         }
 
@@ -1122,29 +1123,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 const float dkls0 = ((-2.f * sn20 * den0 - 4.f * num0 * sn20) * (rden0 * rden0) + 1.f) * invN;
                 const float dkls1 = ((-2.f * sn21 * den1 - 4.f * num1 * sn21) * (rden1 * rden1) + 1.f) * invN;
                 const bool is_kl = a.loss_kind == LOSS_KL;
-                // the primal cotangents of the mean, unscaled
-                const float du0 = own0 ? (is_kl ? km * dklm0 : c * z0 * e0) : 0.f, du1 = own1 ? (is_kl ? km * dklm1 : c * z1 * e1) : 0.f;
-                if (PROMP_NT == 2) {
-                    // FP16 has a range (promp_kernels_pass.h: pass_cotangent_scale): the wave's first tile with a cotangent sets the
-                    // power of two every cotangent of the segment carries, cs; the tangent cotangents carry cs vs.  The tile pays one
-                    // instruction for the wave's running maximum; what it means is settled at the end of the segment.
-                    const float am = fmaxf(fabsf(du0), fabsf(du1));
-                    amax = fmaxf(amax, am);
-                    if (wave_uniform(prov)) {
-                        const float mx = wave_absmax_f32(am);
-                        const bool okm = mx > 0.f && mx < 3.0e38f;
-                        int k = scale_exp(okm ? mx : invN, okm ? ct : -4);
-                        k = k < -100 ? -100 : k > 100 ? 100 : k;
-                        cs = pow2f(k);
-                        qs = cs * vs;
-                        klws = klw * qs;
-                        prov = okm ? 0 : 1;
-                    }
-                }
-                if (rvalid && kk == 0) klsum += kl * invN;     // (behind the point where a tile may be abandoned)
-                c *= cs;
                 const float Rc = (a.loss_kind == LOSS_RATIO) ? c * Rlp : 0.f;
-                const float kms = km * cs;
+                const float klv = klw * vs;          // (the KL cotangents carry no factor of the direction: they take its scale here)
+                // the cotangents of the mean -- primal d (unscaled), tangent q (at the direction's scale vs) -- and the tangent
+                // cotangents of log_std, os
+                float os0, os1;
                 if (is_kl) {
                     // The objective is the mean KL itself (the TRPO constraint): primal cotangent dKL/dmu, tangent cotangents
                     // R'{dKL/dmu}, R'{dKL/ds}.  With D = mu_old - mu, den = 2 e^{2s} + 1e-8, num = D^2 + e^{2 s_old} - e^{2s}:
@@ -1156,20 +1139,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         const float RP = 2.f * sn20 * Rs0 * (den0 + 2.f * num0) - 4.f * sn20 * D * Rmu0;
                         const float Rdm = 2.f * Rmu0 * rden0 + 8.f * D * sn20 * Rs0 * (rden0 * rden0);
                         const float Rds = (-2.f * RP + 16.f * P * sn20 * Rs0 * rden0) * (rden0 * rden0);
-                        d0 = own0 ? kms * dklm0 : 0.f;
-                        qm0 = own0 ? kms * Rdm * invN : 0.f;
-                        outs0 += own0 ? kms * Rds * invN : 0.f;
-                        outb30 += qm0;
+                        d0 = own0 ? km * dklm0 : 0.f;
+                        qm0 = own0 ? km * Rdm * invN : 0.f;
+                        os0 = own0 ? km * Rds * invN : 0.f;
                     }
                     {
                         const float D = mo1 - mu1, P = sn21 * (den1 + 2.f * num1);
                         const float RP = 2.f * sn21 * Rs1 * (den1 + 2.f * num1) - 4.f * sn21 * D * Rmu1;
                         const float Rdm = 2.f * Rmu1 * rden1 + 8.f * D * sn21 * Rs1 * (rden1 * rden1);
                         const float Rds = (-2.f * RP + 16.f * P * sn21 * Rs1 * rden1) * (rden1 * rden1);
-                        d1 = own1 ? kms * dklm1 : 0.f;
-                        qm1 = own1 ? kms * Rdm * invN : 0.f;
-                        outs1 += own1 ? kms * Rds * invN : 0.f;
-                        outb31 += qm1;
+                        d1 = own1 ? km * dklm1 : 0.f;
+                        qm1 = own1 ? km * Rdm * invN : 0.f;
+                        os1 = own1 ? km * Rds * invN : 0.f;
                     }
                 } else {
                     {
@@ -1177,20 +1158,42 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                         const float Rd = Rc * z0 * e0 + c * (Rz * e0 - z0 * e0 * Rs0);
                         const float Rds = Rc * (z0 * z0 - 1.f) + 2.f * c * z0 * Rz;
                         d0 = own0 ? c * z0 * e0 : 0.f;
-                        qm0 = own0 ? km * (Rd + klws * dklm0) : 0.f;
-                        outs0 += own0 ? km * (Rds + klws * dkls0) : 0.f;
-                        outb30 += qm0;
+                        qm0 = own0 ? km * (Rd + klv * dklm0) : 0.f;
+                        os0 = own0 ? km * (Rds + klv * dkls0) : 0.f;
                     }
                     {
                         const float Rz = -Rmu1 * e1 - z1 * Rs1;
                         const float Rd = Rc * z1 * e1 + c * (Rz * e1 - z1 * e1 * Rs1);
                         const float Rds = Rc * (z1 * z1 - 1.f) + 2.f * c * z1 * Rz;
                         d1 = own1 ? c * z1 * e1 : 0.f;
-                        qm1 = own1 ? km * (Rd + klws * dklm1) : 0.f;
-                        outs1 += own1 ? km * (Rds + klws * dkls1) : 0.f;
-                        outb31 += qm1;
+                        qm1 = own1 ? km * (Rd + klv * dklm1) : 0.f;
+                        os1 = own1 ? km * (Rds + klv * dkls1) : 0.f;
                     }
                 }
+                if (PROMP_NT == 2) {
+                    // FP16 has a range (promp_kernels_pass.h: pass_cotangent_scale): the wave's first tile with a cotangent sets the
+                    // power of two cs every cotangent of the segment carries (the tangent cotangents: cs vs).  What has to fit is the
+                    // larger of the primal cotangent and 2^-CHAIN_Q_OVER_D of the tangent one -- at TRPO's operating point the primal
+                    // cotangent of the KL is rounding noise and the tangent one is everything.  The tile pays two instructions for the
+                    // wave's running maximum; what it means is settled at the end of the segment.
+                    const float am = fmaxf(fmaxf(fabsf(d0), fabsf(d1)), (1.f / (float)(1 << CHAIN_Q_OVER_D)) * fmaxf(fabsf(qm0), fabsf(qm1)));
+                    amax = fmaxf(amax, am);
+                    if (wave_uniform(prov)) {
+                        const float mx = wave_absmax_f32(am);
+                        const bool okm = mx > 0.f && mx < 3.0e38f;
+                        int k = scale_exp(okm ? mx : invN, okm ? ct : -4);
+                        k = k < -100 ? -100 : k > 100 ? 100 : k;
+                        cs = pow2f(k);
+                        qs = cs * vs;
+                        prov = okm ? 0 : 1;
+                    }
+                    d0 *= cs; d1 *= cs; qm0 *= cs; qm1 *= cs; os0 *= cs; os1 *= cs;
+                }
+                if (rvalid && kk == 0) klsum += kl * invN;
+                outs0 += os0;
+                outs1 += os1;
+                outb30 += qm0;
+                outb31 += qm1;
             }
             CH_TSTAMP(4);
             {
@@ -1465,7 +1468,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) chk = __builtin_fmaf(aw1[i][j][r], 0.f, chk);
             redo_amax = wave_absmax_f32(amax);
-            bad = (wave_any(chk != chk) || !(redo_amax * cs <= (float)(1 << CHAIN_CT_LIMIT))) ? 1 : 0;
+            bad = wave_any(chk != chk) ? 1 : 0;      // (every split of this kernel feeds the hidden_0 kernel sums: nothing else to test)
         }
         outs0 *= dist[CH_LMASK + q0] * us;
         outs1 *= dist[CH_LMASK + q1] * us;

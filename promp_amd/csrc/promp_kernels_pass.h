@@ -347,15 +347,16 @@ struct PassSums {                // what a wave accumulates over its tiles of a 
 // turns subnormal and its error stops shrinking with the value: 2^-25 absolute) for layer gains down to ~2^-6, and later tiles have
 // 2^6 of headroom (times 2^5 of backward gain) under FP16's 65504.  The tile itself pays one instruction for this: the wave's running
 // maximum S.amax.  Cotangents are heavy-tailed when the policy has moved far from the one that sampled (the ratio is an exponential);
-// a wave whose maximum has passed 2^PASS_CT_LIMIT at its scale, or that finds an infinity in its sums (gains beyond the bound), says so
-// at the end of the segment, and the workgroup walks the segment again -- now every wave knows the largest cotangent it will meet
-// and puts THAT at 2^PASS_CT_REDO (a third walk, for gains beyond 2^5: PASS_CT_RETRY lower).  Guarded in-tile variants (rescaling
+// a wave whose maximum has left the format at its scale (the mean cotangents' planes feed the output kernel's sums only), or that finds
+// an infinity or a NaN in its hidden_0 sums (every other split ends there), says so at the end of the segment, and the workgroup
+// walks the segment again -- now every wave knows the largest cotangent it will meet and puts THAT at 2^PASS_CT_REDO (a third walk,
+// for backward gains beyond 2^5: PASS_CT_RETRY lower).  One such segment doubles the launch's duration: the other workgroups wait.  Guarded in-tile variants (rescaling
 // the sums in place; abandoning the tile and walking it again) were built and measured: +3.4 / +4.7 us per launch for an event that
 // does not occur at PPO's operating point.
 #ifndef PROMP_CT_ATTEMPTS
 #define PROMP_CT_ATTEMPTS 3
 #endif
-PROMP_CX int PASS_CT_TARGET = 5, PASS_CT_LIMIT = 11, PASS_CT_REDO = 10, PASS_CT_RETRY = 12, PASS_CT_ATTEMPTS = PROMP_CT_ATTEMPTS;
+PROMP_CX int PASS_CT_TARGET = 5, PASS_CT_REDO = 10, PASS_CT_RETRY = 12, PASS_CT_ATTEMPTS = PROMP_CT_ATTEMPTS;
 // the scale a largest |mean cotangent| of mx asks for (mx = 0 / not finite: 2^-4 N, for adv / N, and `prov`)
 template <int NC1, int NC2>
 PROMP_DEV void pass_cotangent_scale(PassSums<NC1, NC2>& S, float mx, float invN, int target) {
@@ -610,7 +611,7 @@ PROMP_DEV void pass_tile(PassSums<NC1, NC2>& S, PassPending<NC1>& Q, u32x4 (&w1f
         if (BWD && PROMP_NT == 2) {
             const float am = fmaxf(fabsf(d0), fabsf(d1));
             S.amax = fmaxf(S.amax, am);
-            if (!PENDING || wave_uniform(S.prov)) pass_cotangent_scale<NC1, NC2>(S, wave_absmax_f32(am), W.invN, W.ct_target);
+            if (wave_uniform(S.prov)) pass_cotangent_scale<NC1, NC2>(S, wave_absmax_f32(am), W.invN, W.ct_target);
         }
         S.loss += first * lrow;
         S.klsum += first * (kl * W.invN);
@@ -897,7 +898,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(S.aw1[i][r], 0.f, chk);
             redo_amax = wave_absmax_f32(S.amax);
-            bad = (wave_any(chk != chk) || !(redo_amax * S.cs <= (float)(1 << PASS_CT_LIMIT))) ? 1 : 0;
+            bad = (wave_any(chk != chk) || !(redo_amax * S.cs <= 65504.f)) ? 1 : 0;
         }
         CH_STAMP(2);
 

@@ -278,6 +278,75 @@ def check_split_accuracy(lib, hidden, O, A, seed=11, M=2, P=2, T=48, tol=2.5e-6,
     ctx.close()
 
 
+def check_split_range(lib, hidden, O, A, seed=17, M=2, P=2, T=48, tol=2.5e-6, expect_redo=True):
+    """The FP16 split of the fused kernels has a range; the kernels keep every split operand inside it with exact powers of two that
+    follow the data (promp_device.h: split_pair; promp_kernels_pass.h: pass_cotangent_scale, k_obs_range).  Float32 has no such
+    range, so the results must not depend on any of this:
+      * advantages spanning 12 orders of magnitude with the LARGE ones behind each wave's first tile (the cotangents leave the
+        format at the scale the first tile set: the segment is walked again -- promp_split_events counts it),
+      * all-zero advantages in the leading rows (no cotangent to set a scale from),
+      * observations of size 3e3 and 3e-4, the hidden_0 kernel scaled the other way so that the network computes the same function
+        (per-task power of two on the observations, its inverse on the kernel, taken off the kernel's gradient again),
+      * a direction of size 1e-9 and 1e6 in the R-operator pass.
+    Each against the float64 oracle at the accuracy guard's tolerance."""
+    theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1)
+    spec = op.PolicySpec(O, A, hidden)
+    rng = np.random.RandomState(seed + 1)
+    th = (theta + 0.02 * rng.randn(M, theta.size)).astype(np.float32)
+    n = [len(s['advantages']) for s in all_slabs[1]]
+    cases = {}
+    adv = [rng.randn(k).astype(np.float32) * np.float32(1e-7) for k in n]
+    for a in adv:
+        a[len(a) // 2:] *= np.float32(1e12)          # 1e-7 in every wave's first tile, 1e5 later
+    cases['heavy_tail'] = (adv, 1.0)
+    adv = [rng.randn(k).astype(np.float32) for k in n]
+    for a in adv:
+        a[:min(len(a) - 3, 70)] = 0.0                   # the first tiles of every wave have no cotangent at all
+    cases['leading_zeros'] = (adv, 1.0)
+    cases['big_obs'] = ([s['advantages'] for s in all_slabs[1]], 3e3)
+    cases['small_obs'] = ([s['advantages'] for s in all_slabs[1]], 3e-4)
+    redone = 0
+    for name, (adv, oscale) in cases.items():
+        slabs = [[dict(s, observations=(s['observations'] * np.float32(oscale)).astype(np.float32)) for s in step] for step in all_slabs]
+        for i in range(M):
+            slabs[1][i] = dict(slabs[1][i], advantages=adv[i])
+        paths = []
+        for step in all_paths:
+            q = type(step)()
+            for key, plist in step.items():
+                q[key] = [dict(p, observations=(p['observations'] * np.float32(oscale)).astype(np.float32)) for p in plist]
+            paths.append(q)
+        thc = th.copy()
+        thc[:, :O * hidden[0]] *= np.float32(1.0 / oscale)
+        ctx = make_ctx(lib, M, O, A, hidden, 1, paths)
+        helpers.upload_slabs(ctx, paths, slabs)
+        ctx.set_task_thetas(thc)
+        ctx.split_events()
+        for kind, oname in ((0, 'ratio'), (2, 'loglik')):
+            g, l, _ = ctx.eval_loss_grad(1, kind, clip_eps=0.3, clip_log_std=False)
+            for i in range(M):
+                r = pm.loss_and_grad(spec, thc[i].astype(np.float64), slabs[1][i], oname, False, clip_eps=0.3)
+                assert np.all(np.isfinite(g[i])), (name, oname, i)
+                assert rel_max(g[i], r['grad']) < tol, (name, oname, i, rel_max(g[i], r['grad']))
+        ev = ctx.split_events()
+        if name == 'heavy_tail':
+            redone = ev['pass_segments']
+        for vscale in (1.0, 1e-9, 1e6):
+            v = (vscale * rng.randn(M, theta.size)).astype(np.float32)
+            hv = ctx.eval_hvp(1, v, inner_kind=0, clip_log_std=True, kl_weight=0.37)
+            for i in range(M):
+                t64 = thc[i].astype(np.float64)
+                ref = -pm.hvp(spec, t64, slabs[1][i], v[i].astype(np.float64), 'ratio', True) + \
+                    0.37 * pm.loss_and_grad(spec, t64, slabs[1][i], 'ratio', True)['grad_kl']
+                assert np.all(np.isfinite(hv[i])), (name, vscale, i)
+                assert rel_max(hv[i], ref) < tol, (name, 'hvp', vscale, i, rel_max(hv[i], ref))
+        if name == 'heavy_tail':
+            redone += ctx.split_events()['hvp_segments']
+        ctx.close()
+    if expect_redo:
+        assert redone > 0, 'the heavy-tailed case was meant to walk a segment twice'
+
+
 ADAM_GRAD_FLOOR = 1e-3      # entries whose |g| stays above this fraction of the gradient's max-norm in EVERY epoch are compared
 ADAM_STEP_TOL = 5e-3        # ... to this fraction of ONE Adam step (lr) over the whole trajectory (measured on the MI355X: 5e-5 .. 2.5e-4)
 ADAM_MAX_EXCLUDED = 0.25    # and they must be most of the vector

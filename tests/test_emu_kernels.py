@@ -59,6 +59,12 @@ def test_loss_grad_h64(lib):
 
 
 
+def test_split_range_follows_the_data(lib, two_cus):
+    # FP16 split (round 6): the scales of cotangents, observations and directions follow the data, a segment whose cotangents leave
+    # the format is walked again -- the kernel sources' control flow, checked here at the functional tolerance
+    pc.check_split_range(lib, (32, 32), 7, 3, M=2, P=1, T=140, tol=1e-4)
+
+
 def test_loss_grad_workgroups_straddling_two_tasks(lib):
     # 3 tasks x ~12 tiles on the emulator's 4 CUs (32 waves): every task gets >= 8 waves, so the wave-granular split
     # puts two tasks into one workgroup (two parameter copies in LDS, two partial rows out)

@@ -72,6 +72,17 @@ def test_split_gemm_accuracy_guard(lib, hidden, O, A):
     pc.check_split_accuracy(lib, hidden, O, A, meta_tol=1e-5 if hidden[0] == 128 else None)
 
 
+@pytest.mark.parametrize('hidden,O,A', [((64, 64), 20, 6), ((32, 32), 7, 3), ((64, 32), 11, 2)])
+def test_split_range_follows_the_data(lib, hidden, O, A, monkeypatch):
+    """FP16 split (round 6): heavy-tailed / leading-zero advantages, large and small observations and directions, each at the
+    accuracy guard's 2.5e-6 of the float64 oracle; the heavy-tailed case must have walked a segment twice (work tables for two
+    workgroups, so that a wave walks several tiles of the small batch)"""
+    monkeypatch.setenv('PROMP_MAX_CUS', '2')
+    pc.check_split_range(lib, hidden, O, A, T=160)
+    monkeypatch.delenv('PROMP_MAX_CUS')
+    pc.check_split_range(lib, hidden, O, A, expect_redo=False)
+
+
 @pytest.mark.parametrize('hidden,O,A', [((64, 64, 64), 20, 6), ((256, 256), 20, 6), ((64, 64), 376, 17), ((100,), 11, 3)])
 def test_split_gemm_accuracy_guard_layer_by_layer(lib, hidden, O, A):
     """The layer-by-layer kernels' GEMMs on the BF16 pipe (k_gb_linear / k_gb_wgrad, round 5): 2.5e-7 ... 5.0e-6 of the result's
