@@ -124,6 +124,13 @@ PROMP_DEV void split_pair(float x0, float x1, unsigned (&w)[NT]) {
         bf16_split3_pair(x0, x1, w);
     }
 }
+// both FP16 halves of a word times a power of two (exact unless a half leaves the format: v_pk_mul_f16)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+PROMP_DEV unsigned pk_scale_f16(unsigned w, float p2) {
+    h16x2 f;
+    f[0] = f[1] = (_Float16)p2;
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(h16x2, w) * f);
+}
 template <int NT>
 PROMP_DEV f32x4 mfma16_sw(u32x4 a, u32x4 b, f32x4 c) {
     if constexpr (NT == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);

@@ -141,6 +141,7 @@ struct promp_ctx {
                                          // 1..3 = the observation class (NKO, NXB) = (4,2) (7,4) (8,4): obs_dim <= 63 / 111 / 127
     size_t smem_wb_fwd = 0, smem_wb_bwd = 0, smem_wb_hvp = 0;
     unsigned *wb_planes = nullptr, *wb_vplanes = nullptr;   // [tasks][wb_planes_words]: k_wb_planes' output for theta / the direction
+    unsigned* vdir_absmax = nullptr;     // [tasks]: k_vec_absmax's output for the direction (FP16 split)
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
     bool gramt_single = false;           // PROMP_GRAMT_SINGLE=1: k_gram_tiled with one feature tile (A/B runs against the double-buffered rounds)
@@ -510,11 +511,20 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         const int nko = wb_nko(c->wbf);
         WbPlaneArgs pa;
         pa.src = theta; pa.src_stride = theta_stride; pa.dst = c->wb_planes; pa.O = c->d.obs_dim; pa.A = c->d.act_dim; pa.NKO = nko; pa.row_sign = 1.f;
-        PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, theta_stride ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
+        pa.obs_absmax = a.obs_absmax; pa.vec_absmax = nullptr;       // FP16 split: the hidden_0 kernel takes the inverse of the observations' scale
+        // (one copy per task even when the tasks share their parameters: the hidden_0 kernel's planes carry the task's observation scale)
+        const bool per_task = theta_stride != 0 || PROMP_NT == 2;
+        PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, per_task ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
         a.wb_theta_planes = c->wb_planes;
-        a.wb_plane_stride = theta_stride ? wb_planes_words(nko) : 0;
+        a.wb_plane_stride = per_task ? wb_planes_words(nko) : 0;
         if (hvp) {
-            pa.src = c->vbuf; pa.src_stride = c->NP; pa.dst = c->wb_vplanes;
+            // the direction's planes carry its scale: its largest entry per task first (one small launch)
+            VecAbsmaxArgs va;
+            va.src = c->vbuf; va.stride = c->NP; va.n = c->NP; va.out = c->vdir_absmax;
+            va.n_w1 = c->d.obs_dim * c->d.hidden1; va.obs_absmax = a.obs_absmax;
+            PROMP_LAUNCH(k_vec_absmax, dim3(c->d.n_tasks), 256, 16, c->stream, va);
+            a.vdir_absmax = (const float*)c->vdir_absmax;
+            pa.src = c->vbuf; pa.src_stride = c->NP; pa.dst = c->wb_vplanes; pa.vec_absmax = a.vdir_absmax;
             PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, pa);
             a.wb_v_planes = c->wb_vplanes;
         }
@@ -1041,6 +1051,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     if (c->wbf) {
         const size_t pw = (size_t)M * wb_planes_words(wb_nko(c->wbf));
         rc |= dev_alloc(&c->wb_planes, pw); rc |= dev_alloc(&c->wb_vplanes, pw);
+        rc |= dev_alloc(&c->vdir_absmax, (size_t)M);
     }
     rc |= dev_alloc(&c->partials, (size_t)c->max_work * c->partial_stride);
     rc |= dev_alloc(&c->scal_inner, (size_t)K * M * 2); rc |= dev_alloc(&c->scal_outer, (size_t)M * 2);
@@ -1088,7 +1099,7 @@ void promp_ctx_destroy(promp_ctx* c) {
             if (S.ev_done) (void)hipEventDestroy(S.ev_done);
             if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
         }
-    void* ptrs[] = {c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    void* ptrs[] = {c->vdir_absmax, c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->split_events, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)

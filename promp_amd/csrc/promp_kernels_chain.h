@@ -110,6 +110,7 @@ struct PassArgs {
                                     // k_chain_hvp [1] (promp_split_events); counted when it happens
     // BF16-pipe cooperative kernels (promp_kernels_wide_bf16.h): the parameters' (and the direction's) hidden kernels as pre-split
     // BF16 planes in fragment order, written by k_wb_planes right before the pass
+    const float* vdir_absmax;       // [tasks]: the largest |entry| of each task's direction (k_vec_absmax), the FP16 split's scale for it
     const unsigned* wb_theta_planes;
     const unsigned* wb_v_planes;
     long long wb_plane_stride;      // words per task; 0 => shared parameters
@@ -279,6 +280,18 @@ PROMP_DEV void pass_read_tr(u32x4 (&fr)[NT], const float* tile, int plane_words,
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) fr[tt] = join_w2(lds_tr16(tile + tt * plane_words + rd0), lds_tr16(tile + tt * plane_words + rd1));
 }
+// The task's observations are multiplied by 2^-sx, the hidden_0 kernels by 2^sx: the largest observation (k_obs_range) goes to
+// [1, 2).  Both sides of the product then sit where the split is exact to 2^-22 for the networks the reference builds (Xavier
+// kernels, observations of size ~10: the kernel's entries come to ~1 as well -- unshifted most of them are below 2^-3, where a
+// value's low term is subnormal); a network that reads observations of size 2^15 has a hidden_0 kernel of size 2^-12 or saturated
+// units, and the other way round.  sx <= 12 keeps the kernel's side inside the format for entries up to 5;
+// |W1| max |obs| <= 2^17 is the limit of the fused kernels' FP16 split (beyond it: infinities, loudly).
+PROMP_DEV int obs_shift(const float* obs_absmax, int task) {
+    if (PROMP_NT != 2 || obs_absmax == nullptr) return 0;
+    const float mx = obs_absmax[task];
+    const int sx = (mx > 0.f && mx < 3.0e38f) ? -scale_exp(mx, 0) : 0;
+    return sx < -24 ? -24 : sx > 12 ? 12 : sx;
+}
 // the largest |value| of a wave, in every lane (once per segment: scales of the FP16 split's operands)
 PROMP_DEV float wave_absmax_f32(float v) {
     v = fabsf(v);
@@ -306,11 +319,13 @@ PROMP_DEV float wave_absmax_f32(float v) {
 // first tile's inputs there, then the workgroup joins -- those requests go to memory (the observation slab, the primal cache) and
 // would, issued first, hold back the parameters behind them (a wave's loads return in order; the parameters come from L2).
 // FP16 split: the direction is staged multiplied by -2^kv, the power of two that brings its largest entry (over the whole vector:
-// every wave's share, exchanged through L.vmx across the barrier inside `mid`) to [2^vt, 2^(vt+1)).  The R-operator is linear in the
+// every wave's share, exchanged through `vmx` across the barrier behind `mid`) to [2^vt, 2^(vt+1)) -- the hidden_0 block weighed by
+// w1w = 2^sx, the inverse of the observations' scale: what it contributes to a tangent is its product with an observation, and the
+// blocks are to be compared by what they contribute.  The R-operator is linear in the
 // direction, so every tangent the kernel computes simply carries 2^kv (returned; undone on the accumulators at the end of the
 // segment).  The three-term BF16 split has no range and returns 1.
 template <int NC1, int NC2, int NW, bool BWDP, typename Mid>
-PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const float* src1, int O, int A, int tid, int vt, Mid&& mid) {
+PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const float* src1, int O, int A, int tid, int vt, float w1w, Mid&& mid) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     constexpr ChainLds L = chain_layout(NC1, NC2, 1, true, 0, BWDP);
     constexpr int NB1 = 2 * NC1, NB2 = NC2 * (NC1 / 2), NB3 = NC2, NB4 = BWDP ? NC1 * (NC2 / 2) : 0;
@@ -385,7 +400,7 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
 #pragma unroll
         for (int it = 0; it < IT1; ++it)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x1[1][it][r]));
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, w1w * fabsf(x1[1][it][r]));
 #pragma unroll
         for (int it = 0; it < IT2; ++it)
 #pragma unroll
@@ -747,7 +762,8 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
 // to [2, 4) -- its hidden_1 block, the only part that is split, then sits around 2^-3 .. 1, the tangent activations (sums over the
 // observations) around 1 .. 100 --, the first tile's largest mean cotangent to [4, 8), the tangent cotangents follow from the two
 // (x 2^4 .. 2^6).  A wave that finds an infinity or a NaN in its sums -- every overflow of a split ends there -- has the workgroup
-// walk the segment again: the direction 2^CHAIN_V_RETRY lower, the largest cotangent -- known by then -- at 2^CHAIN_CT_REDO.  One
+// walk the segment again: the largest cotangent -- known by then -- at 2^CHAIN_CT_REDO, and on a third walk the direction
+// 2^CHAIN_V_RETRY lower as well (tangent activations that left the format: observations x direction beyond 2^16).  One
 // such segment doubles the launch's duration (the other workgroups wait), so the first walk's targets leave room: 2^13 above the
 // first tile's largest primal cotangent, 2^8 above 1/32 of its largest tangent cotangent.
 #ifndef PROMP_CT_ATTEMPTS
@@ -759,7 +775,7 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
 #ifndef PROMP_CHAIN_CT_TARGET
 #define PROMP_CHAIN_CT_TARGET 2
 #endif
-PROMP_CX int CHAIN_V_TARGET = PROMP_CHAIN_V_TARGET, CHAIN_V_RETRY = 6, CHAIN_CT_TARGET = PROMP_CHAIN_CT_TARGET,
+PROMP_CX int CHAIN_V_TARGET = PROMP_CHAIN_V_TARGET, CHAIN_V_RETRY = 10, CHAIN_CT_TARGET = PROMP_CHAIN_CT_TARGET,
              CHAIN_CT_REDO = 8, CHAIN_CT_RETRY = 10, CHAIN_Q_OVER_D = 5, CHAIN_ATTEMPTS = PROMP_CT_ATTEMPTS;
 
 // Two-network product of the R-operator pass on the BF16 pipe, operands streamed:
@@ -891,10 +907,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         const float* hcm = CACHED ? a.hcache + ((long long)trow0 + 16 * task) * HCR + 256 * (NC1 + NC2) + i16 * 8 + 2 * kk : nullptr;
         CH_STAMP(0);
         // FP16 split: where the largest direction entry / the first tile's largest mean cotangent go (chain_stage_nets; below)
-        const int vt = CHAIN_V_TARGET - attempt * CHAIN_V_RETRY, ct = attempt ? CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY : CHAIN_CT_TARGET;
+        // (the second walk keeps the direction's scale -- heavy-tailed cotangents are the usual reason, and the known maximum settles
+        //  them --, the third lowers it too)
+        const int vt = CHAIN_V_TARGET - (attempt >= 2 ? CHAIN_V_RETRY : 0), ct = attempt ? CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY : CHAIN_CT_TARGET;
         // (L is the layout for a parameter count of 0: the slabs of the real one may end behind L.vmx; the host sized LDS for both)
         const int slabs_end = 4 + NW * ((NP + 2 + 3) & ~3), vmx_off = slabs_end > L.vmx ? slabs_end : L.vmx;
-        const float vs = chain_stage_nets<NC1, NC2, NW, CACHED>(sm, sm + vmx_off, th, v, O, A, tid, vt, [&]() {
+        const float vs = chain_stage_nets<NC1, NC2, NW, CACHED>(sm, sm + vmx_off, th, v, O, A, tid, vt, pow2f(obs_shift(a.obs_absmax, task)), [&]() {
             {
                 const int t = seg.tile0 + w;
                 const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;

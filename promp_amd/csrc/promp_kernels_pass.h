@@ -817,15 +817,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
         int t = seg.tile0 + w;
         const ChainDistRaw draw = chain_dist_load(th, nullptr, oS, A, tid);
         CH_STAMP(0);
-        // FP16 split: the task's observations are multiplied by the power of two that brings the largest of them (promp_ctx's
-        // per-task table, filled when the slab arrives) to [8, 16) -- between 2^-6 and 2^8, so that the hidden_0 kernel, which
-        // takes the inverse, stays inside the format too
+        // FP16 split: the task's observations times 2^-sx, the hidden_0 kernel times 2^sx (obs_shift, promp_kernels_chain.h)
         float w1s = 1.f;
         W.xs = 1.f;
-        if (PROMP_NT == 2 && a.obs_absmax != nullptr) {
-            const float mx = a.obs_absmax[seg.task];
-            int sx = (mx > 0.f && mx < 3.0e38f) ? -scale_exp(mx, 3) : 0;
-            sx = sx < -6 ? -6 : sx > 8 ? 8 : sx;
+        {
+            const int sx = obs_shift(a.obs_absmax, seg.task);
             W.xs = pow2f(-sx);
             w1s = pow2f(sx);
         }

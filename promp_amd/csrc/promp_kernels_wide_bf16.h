@@ -46,20 +46,24 @@
 #define WB_R 32            // rows per round
 #define WB_ROWW 64         // words per sample row of a plane (128 bf16)
 #define WB_PLANE 2048      // words per plane of a [32 samples][128 units] tile
-#define WB_TILE 6144       // three planes
+#define WB_TILE (PROMP_NT * WB_PLANE)   // the planes of the split (round 6: two FP16 terms; -DPROMP_SPLIT_TERMS=3: three BF16 terms)
 #define WB_MS 17           // row stride of the float32 mean / cotangent tile
 #define WB_DMROW 8         // words per sample row of a cotangent plane (16 action slots)
 #define WB_DMPL 256        // words per cotangent plane
+// FP16 split (see promp_kernels_pass.h: pass_cotangent_scale, promp_kernels_chain.h: CHAIN_*): where the direction's largest entry,
+// the first round's largest cotangent and -- when a work item is walked again -- its largest cotangent overall go
+#define WB_V_TARGET 1
 
 // ---- pre-split weight planes in global memory (k_wb_planes) ----
 // per task:  C1 [w 4][q NKO][t 3][lane 64] x 16 B   hidden_0 kernel, column slices: lane (i, h) of (w, q): W1[16 q + 8 h + e][32 w + i]
 //            C2 [w 4][q 8][t 3][lane 64] x 16 B     hidden_1 kernel, column slices:                         W2[16 q + 8 h + e][32 w + i]
 //            R2 [w 4][q 8][t 3][lane 64] x 16 B     hidden_1 kernel, row slices (backward product):         W2[32 w + i][16 q + 8 h + e]
 //            W3 [w 4][t 3][lane 64] x 16 B          output kernel, A operand of the 16x16x32 product: lane (a, g): W3[32 w + 8 g + e][a]
-PROMP_HD int wb_planes_c2(int nko) { return 4 * nko * 768; }                  // word offsets inside a task's block
-PROMP_HD int wb_planes_r2(int nko) { return 4 * nko * 768 + 4 * 8 * 768; }
-PROMP_HD int wb_planes_w3(int nko) { return 4 * nko * 768 + 2 * 4 * 8 * 768; }
-PROMP_HD int wb_planes_words(int nko) { return 4 * nko * 768 + 2 * 4 * 8 * 768 + 4 * 768; }
+#define WB_FRAG (PROMP_NT * 256)          // words of one (wave, K step): its planes x 64 lanes x 16 B
+PROMP_HD int wb_planes_c2(int nko) { return 4 * nko * WB_FRAG; }                  // word offsets inside a task's block
+PROMP_HD int wb_planes_r2(int nko) { return 4 * nko * WB_FRAG + 4 * 8 * WB_FRAG; }
+PROMP_HD int wb_planes_w3(int nko) { return 4 * nko * WB_FRAG + 2 * 4 * 8 * WB_FRAG; }
+PROMP_HD int wb_planes_words(int nko) { return 4 * nko * WB_FRAG + 2 * 4 * 8 * WB_FRAG + 4 * WB_FRAG; }
 
 struct WbPlaneArgs {
     const float* src;            // [tasks][Theta] (or one shared vector: src_stride 0, grid.y 1)
@@ -67,7 +71,19 @@ struct WbPlaneArgs {
     unsigned* dst;               // [tasks][wb_planes_words]
     int O, A, NKO;
     float row_sign;              // sign of the R2 region (the R-operator pass wants the direction's rows negated)
+    // FP16 split: exact powers of two on the way into the planes --
+    const float* obs_absmax;     // [tasks] or NULL: the hidden_0 kernel times the inverse of the observations' scale (wb_obs_shift)
+    const float* vec_absmax;     // [tasks] or NULL: src is a direction of the R-operator pass; everything times its scale (wb_vec_scale)
 };
+PROMP_DEV int wb_obs_shift(const float* obs_absmax, int task) { return obs_shift(obs_absmax, task); }
+// the direction's scale: its largest entry (k_vec_absmax) to [2^t, 2^(t+1)) (k_chain_hvp: chain_stage_nets)
+PROMP_DEV float wb_vec_scale(const float* vec_absmax, int task, int t) {
+    if (PROMP_NT != 2 || vec_absmax == nullptr) return 1.f;
+    const float mx = vec_absmax[task];
+    int k = (mx > 0.f && mx < 3.0e38f) ? scale_exp(mx, t) : 0;
+    k = k < -100 ? -100 : k > 100 ? 100 : k;
+    return pow2f(k);
+}
 
 struct LdsWB {
     int x0, x1, h1, h2, dz1, rh1, rh2, d1, mp, mp2, ms, ms2, dm, dm2, b1, b2, b3, vb1, vb2, vb3, ls, lmask, es, sn2, vls, red;
@@ -95,11 +111,11 @@ PROMP_HD LdsWB wb_layout(bool hvp) {
     }
     WB_TAKE(mp, 4 * WB_R * 8);                  // [wave][sample][action]: partial means
     WB_TAKE(ms, WB_R * WB_MS);
-    WB_TAKE(dm, 3 * WB_DMPL);
+    WB_TAKE(dm, PROMP_NT * WB_DMPL);
     if (hvp) {
         WB_TAKE(mp2, 4 * WB_R * 8);
         WB_TAKE(ms2, WB_R * WB_MS);
-        WB_TAKE(dm2, 3 * WB_DMPL);
+        WB_TAKE(dm2, PROMP_NT * WB_DMPL);
     }
     WB_TAKE(b1, 128);
     WB_TAKE(b2, 128);
@@ -128,79 +144,58 @@ PROMP_DEV int wb_chunk(int s, int c) { return s * WB_ROWW + 2 * (c ^ wb_sigma(s)
 PROMP_DEV u32x4 wb_lds4(const float* p) { return *(const u32x4*)p; }
 
 // B operand of a K = 16 step of v_mfma_f32_32x32x16_bf16: units 16 q + 8 h .. + 7 of sample j, three planes
-PROMP_DEV void wb_read_b(u32x4 (&f)[3], const float* tile, int j, int h, int q) {
+PROMP_DEV void wb_read_b(u32x4 (&f)[PROMP_NT], const float* tile, int j, int h, int q) {
     const int off = wb_chunk(j, 4 * q + 2 * h);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) f[t] = wb_lds4(tile + t * WB_PLANE + off);
+    for (int t = 0; t < PROMP_NT; ++t) f[t] = wb_lds4(tile + t * WB_PLANE + off);
 }
 // Transposed operand: unit 32 m + (lane & 31), samples 16 t + 8 (lane >> 5) .. + 7, three planes (two transpose reads each)
-PROMP_DEV void wb_read_tr(u32x4 (&f)[3], const float* tile, int lane, int m, int t) {
+PROMP_DEV void wb_read_tr(u32x4 (&f)[PROMP_NT], const float* tile, int lane, int m, int t) {
     const int p = lane & 15, ug = (lane >> 4) & 1, h = lane >> 5;
     const int c = 8 * m + 4 * ug + (p & 3);
     const int s0 = 16 * t + 8 * h + (p >> 2);
     const int o0 = wb_chunk(s0, c), o1 = wb_chunk(s0 + 4, c);
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) f[tt] = join_w2(lds_tr16(tile + tt * WB_PLANE + o0), lds_tr16(tile + tt * WB_PLANE + o1));
+    for (int tt = 0; tt < PROMP_NT; ++tt) f[tt] = join_w2(lds_tr16(tile + tt * WB_PLANE + o0), lds_tr16(tile + tt * WB_PLANE + o1));
 }
 // The same for the 16x16x32 instruction: unit 16 ub16 + (lane & 15) (ub16 counts 16-unit blocks of the whole tile),
 // samples 8 (lane >> 4) .. + 7
-PROMP_DEV void wb_read_tr16(u32x4 (&f)[3], const float* tile, int lane, int ub16) {
+PROMP_DEV void wb_read_tr16(u32x4 (&f)[PROMP_NT], const float* tile, int lane, int ub16) {
     const int p = lane & 15, g = lane >> 4;
     const int c = 4 * ub16 + (p & 3);
     const int s0 = 8 * g + (p >> 2);
     const int o0 = wb_chunk(s0, c), o1 = wb_chunk(s0 + 4, c);
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) f[tt] = join_w2(lds_tr16(tile + tt * WB_PLANE + o0), lds_tr16(tile + tt * WB_PLANE + o1));
+    for (int tt = 0; tt < PROMP_NT; ++tt) f[tt] = join_w2(lds_tr16(tile + tt * WB_PLANE + o0), lds_tr16(tile + tt * WB_PLANE + o1));
 }
-// six of the nine term products (the dropped ones are below 2^-24 relative), smallest first.  One accumulator chain: the matrix
-// pipe forwards a result to the next instruction's C operand (same shape, same registers) without a bubble, and a second chain
-// would cost 16 registers this kernel does not have.
-PROMP_DEV void wb_mma6(f32x16& c0, const u32x4 (&a)[3], const u32x4 (&b)[3]) {
-    c0 = mfma32_bf16w(a[2], b[0], c0);
-    c0 = mfma32_bf16w(a[1], b[1], c0);
-    c0 = mfma32_bf16w(a[0], b[2], c0);
-    c0 = mfma32_bf16w(a[1], b[0], c0);
-    c0 = mfma32_bf16w(a[0], b[1], c0);
-    c0 = mfma32_bf16w(a[0], b[0], c0);
+// The products of a split pair (promp_device.h: two FP16 terms: (1,0) (0,1) (0,0); three BF16 terms: the six with ta + tb <= 2),
+// smallest first.  One accumulator chain: the matrix pipe forwards a result to the next instruction's C operand (same shape, same
+// registers) without a bubble.  (The names keep the "6" of the BF16 form.)
+#define WB_FOR_PRODUCTS(ta, tb) \
+    _Pragma("unroll") for (int ta = PROMP_NT - 1; ta >= 0; --ta) _Pragma("unroll") for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
+PROMP_DEV void wb_mma6(f32x16& c0, const u32x4 (&a)[PROMP_NT], const u32x4 (&b)[PROMP_NT]) {
+    WB_FOR_PRODUCTS(ta, tb) c0 = mfma32_sw<PROMP_NT>(a[ta], b[tb], c0);
 }
 // two independent outputs against the same B operand, products interleaved (no instruction waits for its predecessor)
-PROMP_DEV void wb_mma6_two(f32x16& ca, f32x16& cb, const u32x4 (&a)[3], const u32x4 (&b)[3], const u32x4 (&z)[3]) {
-    ca = mfma32_bf16w(a[2], z[0], ca);
-    cb = mfma32_bf16w(b[2], z[0], cb);
-    ca = mfma32_bf16w(a[1], z[1], ca);
-    cb = mfma32_bf16w(b[1], z[1], cb);
-    ca = mfma32_bf16w(a[0], z[2], ca);
-    cb = mfma32_bf16w(b[0], z[2], cb);
-    ca = mfma32_bf16w(a[1], z[0], ca);
-    cb = mfma32_bf16w(b[1], z[0], cb);
-    ca = mfma32_bf16w(a[0], z[1], ca);
-    cb = mfma32_bf16w(b[0], z[1], cb);
-    ca = mfma32_bf16w(a[0], z[0], ca);
-    cb = mfma32_bf16w(b[0], z[0], cb);
+PROMP_DEV void wb_mma6_two(f32x16& ca, f32x16& cb, const u32x4 (&a)[PROMP_NT], const u32x4 (&b)[PROMP_NT], const u32x4 (&z)[PROMP_NT]) {
+    WB_FOR_PRODUCTS(ta, tb) {
+        ca = mfma32_sw<PROMP_NT>(a[ta], z[tb], ca);
+        cb = mfma32_sw<PROMP_NT>(b[ta], z[tb], cb);
+    }
 }
 // ca += a x za ;  cb += b x zb   (two unrelated products), interleaved
-PROMP_DEV void wb_mma6_x2(f32x16& ca, const u32x4 (&a)[3], const u32x4 (&za)[3], f32x16& cb, const u32x4 (&b)[3], const u32x4 (&zb)[3]) {
-    ca = mfma32_bf16w(a[2], za[0], ca);
-    cb = mfma32_bf16w(b[2], zb[0], cb);
-    ca = mfma32_bf16w(a[1], za[1], ca);
-    cb = mfma32_bf16w(b[1], zb[1], cb);
-    ca = mfma32_bf16w(a[0], za[2], ca);
-    cb = mfma32_bf16w(b[0], zb[2], cb);
-    ca = mfma32_bf16w(a[1], za[0], ca);
-    cb = mfma32_bf16w(b[1], zb[0], cb);
-    ca = mfma32_bf16w(a[0], za[1], ca);
-    cb = mfma32_bf16w(b[0], zb[1], cb);
-    ca = mfma32_bf16w(a[0], za[0], ca);
-    cb = mfma32_bf16w(b[0], zb[0], cb);
+PROMP_DEV void wb_mma6_x2(f32x16& ca, const u32x4 (&a)[PROMP_NT], const u32x4 (&za)[PROMP_NT], f32x16& cb, const u32x4 (&b)[PROMP_NT],
+                          const u32x4 (&zb)[PROMP_NT]) {
+    WB_FOR_PRODUCTS(ta, tb) {
+        ca = mfma32_sw<PROMP_NT>(a[ta], za[tb], ca);
+        cb = mfma32_sw<PROMP_NT>(b[ta], zb[tb], cb);
+    }
 }
-PROMP_DEV void wb_mma6_16(f32x4& c, const u32x4 (&a)[3], const u32x4 (&b)[3]) {
-    c = mfma16_bf16w(a[2], b[0], c);
-    c = mfma16_bf16w(a[1], b[1], c);
-    c = mfma16_bf16w(a[0], b[2], c);
-    c = mfma16_bf16w(a[1], b[0], c);
-    c = mfma16_bf16w(a[0], b[1], c);
-    c = mfma16_bf16w(a[0], b[0], c);
+PROMP_DEV void wb_mma6_16(f32x4& c, const u32x4 (&a)[PROMP_NT], const u32x4 (&b)[PROMP_NT]) {
+    WB_FOR_PRODUCTS(ta, tb) c = mfma16_sw<PROMP_NT>(a[ta], b[tb], c);
 }
+// the 16-bit pattern of 1.0 in both halves of a word (a row / column of ones rides in a gradient product)
+PROMP_CX unsigned WB_ONE2 = PROMP_NT == 2 ? 0x3C003C00u : 0x3F803F80u;
 PROMP_DEV f32x16 wb_zero16() {
     f32x16 z;
 #pragma unroll
@@ -210,17 +205,17 @@ PROMP_DEV f32x16 wb_zero16() {
 // out^T[own unit][sample] (+)= sum over NK steps of  W-planes (registers) x activation planes (LDS tile); the fragments of step
 // q + 1 are requested before the products of step q
 template <int NK>
-PROMP_DEV void wb_chain(f32x16& c0, const u32x4 (&wpl)[NK][3], const float* tile, int j, int h) {
-    u32x4 fb[3];
+PROMP_DEV void wb_chain(f32x16& c0, const u32x4 (&wpl)[NK][PROMP_NT], const float* tile, int j, int h) {
+    u32x4 fb[PROMP_NT];
     wb_read_b(fb, tile, j, h, 0);
 #pragma unroll
     for (int q = 0; q < NK; ++q) {
-        u32x4 fn[3];
+        u32x4 fn[PROMP_NT];
         if (q + 1 < NK) wb_read_b(fn, tile, j, h, q + 1);
         wb_mma6(c0, wpl[q], fb);
         if (q + 1 < NK) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+            for (int t = 0; t < PROMP_NT; ++t) fb[t] = fn[t];
         }
     }
 }
@@ -228,22 +223,22 @@ PROMP_DEV void wb_chain(f32x16& c0, const u32x4 (&wpl)[NK][3], const float* tile
 PROMP_DEV void wb_store_own(float* tile, const f32x16& v, int j, int h, int w) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        unsigned w0[3], w1[3];
-        bf16_split3_pair(v[4 * g], v[4 * g + 1], w0);
-        bf16_split3_pair(v[4 * g + 2], v[4 * g + 3], w1);
+        unsigned w0[PROMP_NT], w1[PROMP_NT];
+        split_pair<PROMP_NT>(v[4 * g], v[4 * g + 1], w0);
+        split_pair<PROMP_NT>(v[4 * g + 2], v[4 * g + 3], w1);
         const int off = wb_chunk(j, 8 * w + 2 * g + h);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) sts_w2(tile + t * WB_PLANE + off, w0[t], w1[t]);
+        for (int t = 0; t < PROMP_NT; ++t) sts_w2(tile + t * WB_PLANE + off, w0[t], w1[t]);
     }
 }
 // one register quad of a D fragment (units 32 w + 8 g + 4 h + i of sample j) -> the three planes
 PROMP_DEV void wb_store_quad(float* tile, float v0, float v1, float v2, float v3, int j, int h, int w, int g) {
-    unsigned w0[3], w1[3];
-    bf16_split3_pair(v0, v1, w0);
-    bf16_split3_pair(v2, v3, w1);
+    unsigned w0[PROMP_NT], w1[PROMP_NT];
+    split_pair<PROMP_NT>(v0, v1, w0);
+    split_pair<PROMP_NT>(v2, v3, w1);
     const int off = wb_chunk(j, 8 * w + 2 * g + h);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) sts_w2(tile + t * WB_PLANE + off, w0[t], w1[t]);
+    for (int t = 0; t < PROMP_NT; ++t) sts_w2(tile + t * WB_PLANE + off, w0[t], w1[t]);
 }
 // a D fragment parked in / fetched from a wave-private, lane-linear LDS block (16-byte accesses, conflict-free)
 PROMP_DEV void wb_park(float* blk, const f32x16& v, int lane) {
@@ -277,12 +272,12 @@ PROMP_DEV f32x16 wb_bias16(const float* bs, int h, int w) {
     return z;
 }
 // a slice's planes of one K step from the pre-split copy (k_wb_planes): one 16-byte load per plane, lane-linear
-PROMP_DEV void wb_gload(u32x4 (&pl)[3], const unsigned* P, int nk, int w, int q, int lane) {
+PROMP_DEV void wb_gload(u32x4 (&pl)[PROMP_NT], const unsigned* P, int nk, int w, int q, int lane) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) pl[t] = *(const u32x4*)(P + ((w * nk + q) * 3 + t) * 256 + 4 * lane);
+    for (int t = 0; t < PROMP_NT; ++t) pl[t] = *(const u32x4*)(P + ((w * nk + q) * PROMP_NT + t) * 256 + 4 * lane);
 }
 // Output kernel, own 32 units: A operand of the 16x16x32 product  mu[a] = sum_u W3[32 w + u][a] h2[u]  (lane (a = l & 15, g): u = 8 g + e)
-PROMP_DEV void wb_load_w3(u32x4 (&pl)[3], const float* W3, int A, int lane, int w, float sgn) {
+PROMP_DEV void wb_load_w3(u32x4 (&pl)[PROMP_NT], const float* W3, int A, int lane, int w, float sgn) {
     const int aa = lane & 15, g = lane >> 4;
     f32x4 lo, hi;
 #pragma unroll
@@ -331,9 +326,9 @@ PROMP_DEV void wb_xreq(WbX<NKO>& X, const float* obs, long long row0, int nrows,
     }
 }
 template <int NKO>
-PROMP_DEV void wb_xput_one(float* Xs, const WbX<NKO>& X, int it, int nrows, int O, int OC, int tid) {
+PROMP_DEV void wb_xput_one(float* Xs, const WbX<NKO>& X, int it, int nrows, int O, int OC, int tid, float xs) {
     const int s = tid >> 3;
-    const float rowm = s < nrows ? 1.f : 0.f;
+    const float rowm = s < nrows ? xs : 0.f;       // (xs: the power of two the task's observations are multiplied by, FP16 split)
     {
         const int c = (tid & 7) + 8 * it;
         float x[4];
@@ -342,20 +337,20 @@ PROMP_DEV void wb_xput_one(float* Xs, const WbX<NKO>& X, int it, int nrows, int 
             const int o = 4 * c + i;
             x[i] = (o == OC) ? 1.f : (o < O) ? rowm * X.v[it][i] : 0.f;
         }
-        unsigned w0[3], w1[3];
-        bf16_split3_pair(x[0], x[1], w0);
-        bf16_split3_pair(x[2], x[3], w1);
+        unsigned w0[PROMP_NT], w1[PROMP_NT];
+        split_pair<PROMP_NT>(x[0], x[1], w0);
+        split_pair<PROMP_NT>(x[2], x[3], w1);
         if (c < WbX<NKO>::CPR) {
             const int off = wb_chunk(s, c);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) sts_w2(Xs + t * WB_PLANE + off, w0[t], w1[t]);
+            for (int t = 0; t < PROMP_NT; ++t) sts_w2(Xs + t * WB_PLANE + off, w0[t], w1[t]);
         }
     }
 }
 template <int NKO>
-PROMP_DEV void wb_xput(float* Xs, const WbX<NKO>& X, int nrows, int O, int OC, int tid) {
+PROMP_DEV void wb_xput(float* Xs, const WbX<NKO>& X, int nrows, int O, int OC, int tid, float xs) {
     const int s = tid >> 3;
-    const float rowm = s < nrows ? 1.f : 0.f;
+    const float rowm = s < nrows ? xs : 0.f;
 #pragma unroll
     for (int it = 0; it < WbX<NKO>::IT; ++it) {
         const int c = (tid & 7) + 8 * it;
@@ -365,13 +360,13 @@ PROMP_DEV void wb_xput(float* Xs, const WbX<NKO>& X, int nrows, int O, int OC, i
             const int o = 4 * c + i;
             x[i] = (o == OC) ? 1.f : (o < O) ? rowm * X.v[it][i] : 0.f;
         }
-        unsigned w0[3], w1[3];
-        bf16_split3_pair(x[0], x[1], w0);
-        bf16_split3_pair(x[2], x[3], w1);
+        unsigned w0[PROMP_NT], w1[PROMP_NT];
+        split_pair<PROMP_NT>(x[0], x[1], w0);
+        split_pair<PROMP_NT>(x[2], x[3], w1);
         if (c < WbX<NKO>::CPR) {
             const int off = wb_chunk(s, c);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) sts_w2(Xs + t * WB_PLANE + off, w0[t], w1[t]);
+            for (int t = 0; t < PROMP_NT; ++t) sts_w2(Xs + t * WB_PLANE + off, w0[t], w1[t]);
         }
     }
 }
@@ -381,7 +376,7 @@ PROMP_DEV void wb_init_x(float* Xs, int OC, int tid) {
     __syncthreads();
     if (tid < WB_R) {
         const int off = wb_chunk(tid, OC >> 2) + ((OC & 3) >> 1);
-        ((unsigned*)Xs)[off] = (OC & 1) ? 0x3F800000u : 0x00003F80u;
+        ((unsigned*)Xs)[off] = (OC & 1) ? (WB_ONE2 & 0xFFFF0000u) : (WB_ONE2 & 0xFFFFu);
     }
 }
 
@@ -389,20 +384,32 @@ PROMP_DEV void wb_init_x(float* Xs, int OC, int tid) {
 // ahead of the products), wb_chain_stream requests step q + WB_PF as soon as the products of step q have read their slot.
 template <int PF>
 struct WbRing {
-    u32x4 r[PF][3];
+    u32x4 r[PF][PROMP_NT];
 };
-template <int PF>
-PROMP_DEV void wb_stream_begin(WbRing<PF>& G, const unsigned* P, int nk, int w, int lane) {
+// (FP16 split, k_wb_hvp walking a work item again: the direction's planes were made for a scale that turned out too large; `fix`, a
+//  power of two below 1, brings a fragment down on its way into the registers.  1: the planes as they are.)
+PROMP_DEV void wb_fix(u32x4 (&pl)[PROMP_NT], float fix) {
+    if (PROMP_NT != 2 || fix == 1.f) return;
 #pragma unroll
-    for (int q = 0; q < PF; ++q) wb_gload(G.r[q], P, nk, w, q, lane);
+    for (int t = 0; t < PROMP_NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pl[t][i] = pk_scale_f16(pl[t][i], fix);
+}
+template <int PF>
+PROMP_DEV void wb_stream_begin(WbRing<PF>& G, const unsigned* P, int nk, int w, int lane, float fix = 1.f) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        wb_gload(G.r[q], P, nk, w, q, lane);
+        wb_fix(G.r[q], fix);
+    }
 }
 template <int NK, int WB_PF>
 PROMP_DEV void wb_chain_stream(f32x16& c0, WbRing<WB_PF>& G, const unsigned* P, int w, int lane, const float* tile, int j, int h) {
-    u32x4 fb[3];
+    u32x4 fb[PROMP_NT];
     wb_read_b(fb, tile, j, h, 0);
 #pragma unroll
     for (int q = 0; q < NK; ++q) {
-        u32x4 fn[3];
+        u32x4 fn[PROMP_NT];
         if (q + 1 < NK) wb_read_b(fn, tile, j, h, q + 1);
         sched_fence();
         wb_mma6(c0, G.r[q % WB_PF], fb);
@@ -410,7 +417,7 @@ PROMP_DEV void wb_chain_stream(f32x16& c0, WbRing<WB_PF>& G, const unsigned* P, 
         sched_fence();
         if (q + 1 < NK) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+            for (int t = 0; t < PROMP_NT; ++t) fb[t] = fn[t];
         }
     }
 }
@@ -428,12 +435,13 @@ __global__ void __launch_bounds__(256) k_wb_planes(WbPlaneArgs a) {
     unsigned* dst = a.dst + (long long)task * wb_planes_words(a.NKO);
     const int oW2a = a.O * 128 + 128;
     int region = 0;
+    const float vsc = wb_vec_scale(a.vec_absmax, task, WB_V_TARGET), w1sc = pow2f(wb_obs_shift(a.obs_absmax, task)) * vsc;
     if (r >= n1 + 2 * n2) {               // the output kernel's fragments (wb_load_w3)
         r -= n1 + 2 * n2;
-        u32x4 pl[3];
-        wb_load_w3(pl, src + oW2a + 128 * 128 + 128, a.A, r & 63, r >> 6, 1.f);
+        u32x4 pl[PROMP_NT];
+        wb_load_w3(pl, src + oW2a + 128 * 128 + 128, a.A, r & 63, r >> 6, vsc);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) *(u32x4*)(dst + wb_planes_w3(a.NKO) + ((r >> 6) * 3 + t) * 256 + 4 * (r & 63)) = pl[t];
+        for (int t = 0; t < PROMP_NT; ++t) *(u32x4*)(dst + wb_planes_w3(a.NKO) + ((r >> 6) * PROMP_NT + t) * 256 + 4 * (r & 63)) = pl[t];
         return;
     }
     if (r >= n1 + n2) { region = 2; r -= n1 + n2; dst += wb_planes_r2(a.NKO); }
@@ -447,16 +455,39 @@ __global__ void __launch_bounds__(256) k_wb_planes(WbPlaneArgs a) {
     for (int e = 0; e < 8; ++e) {
         const int k = 16 * q + 8 * h + e;
         float x;
-        if (region == 0) x = k < a.O ? src[k * 128 + 32 * w + i] : 0.f;
-        else if (region == 1) x = src[oW2 + k * 128 + 32 * w + i];
-        else x = a.row_sign * src[oW2 + (32 * w + i) * 128 + k];
+        if (region == 0) x = k < a.O ? w1sc * src[k * 128 + 32 * w + i] : 0.f;
+        else if (region == 1) x = vsc * src[oW2 + k * 128 + 32 * w + i];
+        else x = (a.row_sign * vsc) * src[oW2 + (32 * w + i) * 128 + k];
         if (e < 4) lo[e] = x;
         else hi[e - 4] = x;
     }
-    u32x4 pl[3];
+    u32x4 pl[PROMP_NT];
     pass_split8(lo, hi, pl);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) *(u32x4*)(dst + ((w * NK + q) * 3 + t) * 256 + 4 * lane) = pl[t];
+    for (int t = 0; t < PROMP_NT; ++t) *(u32x4*)(dst + ((w * NK + q) * PROMP_NT + t) * 256 + 4 * lane) = pl[t];
+}
+
+// The largest |entry| of every task's vector (the direction of an R-operator pass) -> out[task], bits of a non-negative float
+// (k_wb_planes and k_wb_hvp take the direction's scale from it: wb_vec_scale).  grid = tasks, block = 256.
+struct VecAbsmaxArgs {
+    const float* src;
+    long long stride;
+    int n, n_w1;                 // entries; the leading ones that belong to the hidden_0 kernel
+    const float* obs_absmax;     // [tasks] or NULL: the hidden_0 block is weighed by the inverse of the observations' scale
+    unsigned* out;               // (chain_stage_nets: the blocks are compared by what they contribute to a tangent)
+};
+__global__ void __launch_bounds__(256) k_vec_absmax(VecAbsmaxArgs a) {
+    const int task = blockIdx.x, tid = threadIdx.x;
+    const float* src = a.src + (long long)task * a.stride;
+    const float w1w = pow2f(obs_shift(a.obs_absmax, task));
+    float m = 0.f;
+    for (int i = tid; i < a.n; i += 256) m = fmaxf(m, (i < a.n_w1 ? w1w : 1.f) * fabsf(src[i]));
+    m = wave_absmax_f32(m);
+    PROMP_SMEM_DECL;
+    float* sm = (float*)PROMP_SMEM_PTR;
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) a.out[task] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,9 +514,12 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
     const float* th = a.theta + (long long)task * a.theta_task_stride;
     const unsigned* PL = a.wb_theta_planes + (long long)task * a.wb_plane_stride;
     const unsigned* PR2 = PL + wb_planes_r2(NKO);
+    // FP16 split: the task's observations times 2^-sx (k_wb_planes multiplied the hidden_0 kernel by 2^sx)
+    const int sx = wb_obs_shift(a.obs_absmax, task);
+    const float xs = pow2f(-sx), w1u = pow2f(sx);
 
     // ---- forward weight planes of this lane, resident for the whole work item; the first round's observations
-    u32x4 w1p[NKO][3], w2c[8][3];
+    u32x4 w1p[NKO][PROMP_NT], w2c[8][PROMP_NT];
     float w3f[4];
     WbX<NKO> X;
     {
@@ -513,10 +547,10 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
             b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
         }
         for (int e = tid; e < R * MS; e += 256) Mss[e] = 0.f;
-        for (int e = tid; e < 3 * WB_DMPL; e += 256) ((unsigned*)Dm)[e] = 0u;
+        for (int e = tid; e < PROMP_NT * WB_DMPL; e += 256) ((unsigned*)Dm)[e] = 0u;
         wb_init_x(Xs, OC, tid);
         wb_init_x(sm + L.x1, OC, tid);
-        wb_xput<NKO>(Xs, X, wk.row_end - wk.row_begin, O, OC, tid);
+        wb_xput<NKO>(Xs, X, wk.row_end - wk.row_begin, O, OC, tid, xs);
         wb_xreq<NKO>(X, a.obs, wk.row_begin + R, wk.row_end - wk.row_begin - R, O, tid);
     }
 
@@ -524,12 +558,36 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
     // output kernel rows 32 w + 16 ub + (lane & 15) (row 15 of its action axis: the hidden_1 bias gradient)
     f32x16 aw1[NXB], aw2[4];
     f32x4 aw3[2];
+    float loss, klsum, gs, gb3;
+    // FP16 split (promp_kernels_pass.h: pass_cotangent_scale; here the four waves share every tile, so the scale is the
+    // workgroup's): the cotangents carry cs, set by the first round that has one; the work item is walked again, with its largest
+    // cotangent for a scale, if a split left the format (`attempt`)
+    float cs = 1.f, ics = 1.f, amax = 0.f, redo_amax = 0.f;
+    int prov = 1;
+    for (int attempt = 0;; ++attempt) {
+    if (attempt > 0) {           // the first two rounds' observations again
+        const int tid = threadIdx.x;
+        __syncthreads();
+        wb_xreq<NKO>(X, a.obs, wk.row_begin, wk.row_end - wk.row_begin, O, tid);
+        wb_xput<NKO>(sm + L.x0, X, wk.row_end - wk.row_begin, O, OC, tid, xs);
+        wb_xreq<NKO>(X, a.obs, wk.row_begin + R, wk.row_end - wk.row_begin - R, O, tid);
+    }
 #pragma unroll
     for (int m = 0; m < NXB; ++m) aw1[m] = wb_zero16();
 #pragma unroll
     for (int m = 0; m < 4; ++m) aw2[m] = wb_zero16();
     aw3[0] = aw3[1] = zero4();
-    float loss = 0.f, klsum = 0.f, gs = 0.f, gb3 = 0.f;
+    loss = klsum = gs = gb3 = 0.f;
+    cs = ics = 1.f;
+    amax = 0.f;
+    prov = 1;
+    if (PROMP_NT == 2 && attempt > 0 && redo_amax > 0.f && redo_amax < 3.0e38f) {
+        int k = scale_exp(redo_amax, PASS_CT_REDO - (attempt - 1) * PASS_CT_RETRY);
+        k = k < -100 ? -100 : k > 100 ? 100 : k;
+        cs = pow2f(k);
+        ics = pow2f(-k);
+        prov = 0;
+    }
 
     int rix = 0;
     for (int base = wk.row_begin; base < wk.row_end; base += R) {
@@ -563,17 +621,17 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         //      instructions' shadow (it used to run behind the layer: 2.2 k of a round's 21.7 k cycles)
         {
             f32x16 c0 = wb_bias16(b1s, h, w);
-            u32x4 fb[3];
+            u32x4 fb[PROMP_NT];
             wb_read_b(fb, Xs, j, h, 0);
 #pragma unroll
             for (int q = 0; q < NKO; ++q) {
-                u32x4 fn[3];
+                u32x4 fn[PROMP_NT];
                 if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
-                if (q < WbX<NKO>::IT) wb_xput_one<NKO>(Xn, X, q, wk.row_end - base - R, O, OC, tid);
+                if (q < WbX<NKO>::IT) wb_xput_one<NKO>(Xn, X, q, wk.row_end - base - R, O, OC, tid, xs);
                 wb_mma6(c0, w1p[q], fb);
                 if (q + 1 < NKO) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+                    for (int t = 0; t < PROMP_NT; ++t) fb[t] = fn[t];
                 }
             }
 #pragma unroll
@@ -612,15 +670,15 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         // ---- output layer: this wave's 32 units of the contraction, both 16-sample blocks -> partial means
         {
             const int j16 = lane & 15, g4 = lane >> 4;
-            u32x4 w3p[3];
+            u32x4 w3p[PROMP_NT];
             wb_gload(w3p, PL + zr + wb_planes_w3(NKO), 1, w, 0, lane);
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 const int s = 16 * sb + j16;
-                u32x4 fb[3];
+                u32x4 fb[PROMP_NT];
                 const int off = wb_chunk(s, 8 * w + 2 * g4);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) fb[t] = wb_lds4(H2s + t * WB_PLANE + off);
+                for (int t = 0; t < PROMP_NT; ++t) fb[t] = wb_lds4(H2s + t * WB_PLANE + off);
                 f32x4 dm = zero4();
                 wb_mma6_16(dm, w3p, fb);
                 if (g4 < 2) sts4(Mp + (w * R + s) * 8 + 4 * g4, dm);      // rows 4 g4 + r = actions
@@ -683,17 +741,36 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
                     klsum += kl * invN;
                 }
             }
+            float d = 0.f;
             if (BWD && eown) {
-                // the cotangent of the mean: float32 for the exact W3 product, three BF16 planes for the output-kernel gradient
-                const float d = c * z * ee + ck * dklm;
-                Mss[erow * MS + eq] = d;
+                d = c * z * ee + ck * dklm;
                 gs += c * (z * z - 1.f) + ck * dkls;
                 gb3 += d;
-                unsigned t3[3];
-                bf16_split3_pair(d, 0.f, t3);
+            }
+            if (BWD && PROMP_NT == 2) {
+                amax = fmaxf(amax, fabsf(d));
+                if (prov) {          // (the same in every thread) no round has had a cotangent yet: this one sets the scale
+                    const float m = wave_absmax_f32(d);
+                    if (lane == 0) red[w] = m;
+                    __syncthreads();
+                    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                    const bool okm = mx > 0.f && mx < 3.0e38f;
+                    int k = scale_exp(okm ? mx : invN, okm ? PASS_CT_TARGET : -4);
+                    k = k < -100 ? -100 : k > 100 ? 100 : k;
+                    cs = pow2f(k);
+                    ics = pow2f(-k);
+                    prov = okm ? 0 : 1;
+                }
+                d *= cs;
+            }
+            if (BWD && eown) {
+                // the cotangent of the mean: float32 for the exact W3 product, the split's planes for the output-kernel gradient
+                Mss[erow * MS + eq] = d;
+                unsigned t3[PROMP_NT];
+                split_pair<PROMP_NT>(d, 0.f, t3);
                 unsigned short* Dh = (unsigned short*)Dm;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) Dh[2 * (t * WB_DMPL + erow * WB_DMROW) + eq] = (unsigned short)(t3[t] & 0xFFFFu);
+                for (int t = 0; t < PROMP_NT; ++t) Dh[2 * (t * WB_DMPL + erow * WB_DMROW) + eq] = (unsigned short)(t3[t] & 0xFFFFu);
             }
         }
         WB_STAMP(8);
@@ -707,15 +784,15 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         {
             const int p = lane & 15, g4 = lane >> 4;
             // A = dmu^T: action l & 15, samples 8 g4 .. + 7
-            u32x4 fa[3];
+            u32x4 fa[PROMP_NT];
             {
                 const int o0 = (8 * g4 + (p >> 2)) * WB_DMROW + 2 * (p & 3), o1 = o0 + 4 * WB_DMROW;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) fa[t] = join_w2(lds_tr16(Dm + t * WB_DMPL + o0), lds_tr16(Dm + t * WB_DMPL + o1));
+                for (int t = 0; t < PROMP_NT; ++t) fa[t] = join_w2(lds_tr16(Dm + t * WB_DMPL + o0), lds_tr16(Dm + t * WB_DMPL + o1));
             }
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub) {
-                u32x4 fb[3];
+                u32x4 fb[PROMP_NT];
                 wb_read_tr16(fb, H2s, lane, 2 * w + ub);
                 wb_mma6_16(aw3[ub], fa, fb);
             }
@@ -730,14 +807,13 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
             // hidden_1 bias gradient: a row of ones (action slot 15) against the wave's own dZ2 columns
             u32x4 ones;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ones[i] = (p == 15) ? 0x3F803F80u : 0u;
+            for (int i = 0; i < 4; ++i) ones[i] = (p == 15) ? WB_ONE2 : 0u;
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub) {
-                u32x4 fb[3];
+                u32x4 fb[PROMP_NT];
                 wb_read_tr16(fb, H2s, lane, 2 * w + ub);
-                aw3[ub] = mfma16_bf16w(ones, fb[2], aw3[ub]);
-                aw3[ub] = mfma16_bf16w(ones, fb[1], aw3[ub]);
-                aw3[ub] = mfma16_bf16w(ones, fb[0], aw3[ub]);
+#pragma unroll
+                for (int t = PROMP_NT - 1; t >= 0; --t) aw3[ub] = mfma16_sw<PROMP_NT>(ones, fb[t], aw3[ub]);
             }
         }
         sched_fence();
@@ -749,11 +825,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         //      cover an L2 round trip); dZ1 -> its own tile
         {
             f32x16 c0 = wb_zero16();
-            u32x4 fb[3], fz[3];
+            u32x4 fb[PROMP_NT], fz[PROMP_NT];
             wb_read_b(fb, H2s, j, h, 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                u32x4 fn[3], fa[3];
+                u32x4 fn[PROMP_NT], fa[PROMP_NT];
                 if (q + 1 < 8) wb_read_b(fn, H2s, j, h, q + 1);
                 const int t = q >> 2, m = q & 3;
                 if (m == 0) wb_read_tr(fz, H2s, lane, w, t);
@@ -764,7 +840,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
                 sched_fence();
                 if (q + 1 < 8) {
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) fb[tt] = fn[tt];
+                    for (int tt = 0; tt < PROMP_NT; ++tt) fb[tt] = fn[tt];
                 }
             }
 #pragma unroll
@@ -783,16 +859,16 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                u32x4 fz[3];
+                u32x4 fz[PROMP_NT];
                 wb_read_tr(fz, DZ1, lane, w, t);
                 if (NXB == 1) {
-                    u32x4 fa[3];
+                    u32x4 fa[PROMP_NT];
                     wb_read_tr(fa, Xs, lane, 0, t);
                     wb_mma6(aw1[0], fa, fz);
                 } else {
 #pragma unroll
                     for (int m = 0; m + 1 < NXB; m += 2) {
-                        u32x4 fa0[3], fa1[3];
+                        u32x4 fa0[PROMP_NT], fa1[PROMP_NT];
                         wb_read_tr(fa0, Xs, lane, m, t);
                         wb_read_tr(fa1, Xs, lane, m + 1, t);
                         wb_mma6_two(aw1[m], aw1[m + 1], fa0, fa1, fz);
@@ -802,6 +878,29 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
         }
         WB_STAMP(14);
         ++rix;
+    }
+    // FP16 split: did every split stay inside the format?  The mean cotangents' planes (they feed the output kernel's sums only): their
+    // largest value at the scale; everything else ends in the hidden_0 kernel sums (x * 0 is 0 for finite x only).
+    if (!BWD || PROMP_NT != 2 || attempt + 1 >= PASS_CT_ATTEMPTS) break;
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int m = 0; m < NXB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(aw1[m][r], 0.f, chk);
+        const float wm = wave_absmax_f32(amax), wbad = wave_any(chk != chk) ? 1.f : 0.f;
+        const int lane = threadIdx.x & 63;
+        __syncthreads();
+        if (lane == 0) {
+            red[w] = wm;
+            red[4 + w] = wbad;
+        }
+        __syncthreads();
+        redo_amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const bool bad = (red[4] + red[5] + red[6] + red[7]) > 0.f || !(redo_amax * cs <= 65504.f);
+        if (!bad) break;
+        if (threadIdx.x == 0) atomic_add_agent(a.split_events + 0, 1);
+    }
     }
 
     // ---- results: scalars through LDS in wave order, gradient slices straight from their owners ----
@@ -844,15 +943,15 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[oW2 + (32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * H + 32 * w + j] = aw2[m][r];
+        for (int r = 0; r < 16; ++r) P[oW2 + (32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * H + 32 * w + j] = aw2[m][r] * ics;
     // hidden_0 kernel gradient; row OC = the hidden_0 bias gradient
 #pragma unroll
     for (int m = 0; m < NXB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * m + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (row < O) P[row * H + 32 * w + j] = aw1[m][r];
-            else if (row == OC) P[ob1 + 32 * w + j] = aw1[m][r];
+            if (row < O) P[row * H + 32 * w + j] = aw1[m][r] * (ics * w1u);     // (the observations' scale comes off here)
+            else if (row == OC) P[ob1 + 32 * w + j] = aw1[m][r] * ics;
         }
     // output kernel rows 32 w + 16 ub + (lane & 15): D rows 4 g4 + r = actions; action slot 15 = hidden_1 bias gradient
     {
@@ -862,34 +961,27 @@ __global__ void __launch_bounds__(256, 1) k_wb_fwd_bwd(PassArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int aa = 4 * g4 + r, unit = 32 * w + 16 * ub + j16;
-                if (aa < A) P[oW3 + unit * A + aa] = aw3[ub][r];
-                else if (aa == 15) P[ob2 + unit] = aw3[ub][r];
+                if (aa < A) P[oW3 + unit * A + aa] = aw3[ub][r] * ics;
+                else if (aa == 15) P[ob2 + unit] = aw3[ub][r] * ics;
             }
     }
 }
 
 // ca += a x ba ;  cb += a x bb   (one weight slice against two activation tensors), products interleaved
-PROMP_DEV void wb_mma6_ab(f32x16& ca, f32x16& cb, const u32x4 (&a)[3], const u32x4 (&ba)[3], const u32x4 (&bb)[3]) {
-    ca = mfma32_bf16w(a[2], ba[0], ca);
-    cb = mfma32_bf16w(a[2], bb[0], cb);
-    ca = mfma32_bf16w(a[1], ba[1], ca);
-    cb = mfma32_bf16w(a[1], bb[1], cb);
-    ca = mfma32_bf16w(a[0], ba[2], ca);
-    cb = mfma32_bf16w(a[0], bb[2], cb);
-    ca = mfma32_bf16w(a[1], ba[0], ca);
-    cb = mfma32_bf16w(a[1], bb[0], cb);
-    ca = mfma32_bf16w(a[0], ba[1], ca);
-    cb = mfma32_bf16w(a[0], bb[1], cb);
-    ca = mfma32_bf16w(a[0], ba[0], ca);
-    cb = mfma32_bf16w(a[0], bb[0], cb);
+PROMP_DEV void wb_mma6_ab(f32x16& ca, f32x16& cb, const u32x4 (&a)[PROMP_NT], const u32x4 (&ba)[PROMP_NT], const u32x4 (&bb)[PROMP_NT]) {
+    WB_FOR_PRODUCTS(ta, tb) {
+        ca = mfma32_sw<PROMP_NT>(a[ta], ba[tb], ca);
+        cb = mfma32_sw<PROMP_NT>(a[ta], bb[tb], cb);
+    }
 }
 // The ring runs WB_PF (its depth) steps ahead ACROSS slices: behind the products of step q of a slice of NK steps, slot q % WB_PF takes step
 // q + WB_PF of the same slice or, in the slice's last WB_PF steps, step q % WB_PF of the NEXT slice the wave will walk (which then
 // finds its first WB_PF steps in slots 0 .. WB_PF - 1).  Needs WB_PF <= the steps of every slice.
 template <int WB_PF>
-PROMP_DEV void wb_ring_next(WbRing<WB_PF>& G, const unsigned* Pcur, int nk, const unsigned* Pnext, int nkn, int w, int lane, int q) {
+PROMP_DEV void wb_ring_next(WbRing<WB_PF>& G, const unsigned* Pcur, int nk, const unsigned* Pnext, int nkn, int w, int lane, int q, float fix = 1.f) {
     if (q + WB_PF < nk) wb_gload(G.r[q % WB_PF], Pcur, nk, w, q + WB_PF, lane);
     else wb_gload(G.r[q % WB_PF], Pnext, nkn, w, q % WB_PF, lane);
+    wb_fix(G.r[q % WB_PF], fix);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -921,6 +1013,12 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
     const unsigned* PT = a.wb_theta_planes + (long long)task * a.wb_plane_stride;
     const unsigned* PV = a.wb_v_planes + (long long)task * wb_planes_words(NKO);
     const int oC2 = wb_planes_c2(NKO), oR2 = wb_planes_r2(NKO), oW3P = wb_planes_w3(NKO);
+    // FP16 split: the task's observations times 2^-sx (k_wb_planes multiplied both hidden_0 kernels by 2^sx); the direction times vs
+    // (k_wb_planes did its kernels; the biases, the output kernel's float32 copy and log_std follow here) -- every tangent carries vs
+    const int sx = wb_obs_shift(a.obs_absmax, task);
+    const float xs = pow2f(-sx), w1u = pow2f(sx);
+    const float vs0 = wb_vec_scale(a.vdir_absmax, task, WB_V_TARGET);
+    float vs = vs0, ivs = 1.f / vs0, vfix = 1.f;      // (vfix: see `attempt`)
 
     float w3f[4], v3f[4];
     WbX<NKO> X;
@@ -934,12 +1032,12 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         wb_stream_begin(GT, PT, NKO, w, lane);
         wb_stream_begin(GV, PV, NKO, w, lane);
         wb_load_w3f(w3f, th + oW3, A, lane, w, 1.f);
-        wb_load_w3f(v3f, vv + oW3, A, lane, w, 1.f);
+        wb_load_w3f(v3f, vv + oW3, A, lane, w, vs);
         for (int e = tid; e < H; e += 256) {
             b1s[e] = th[ob1 + e];
             b2s[e] = th[ob2 + e];
-            vb1s[e] = vv[ob1 + e];
-            vb2s[e] = vv[ob2 + e];
+            vb1s[e] = vs * vv[ob1 + e];
+            vb2s[e] = vs * vv[ob2 + e];
         }
         if (tid < 16) {
             const float sr = (tid < A) ? th[oS + tid] : 0.f;
@@ -949,24 +1047,65 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
             lmask[tid] = clipped ? 0.f : 1.f;
             ess[tid] = expf(-s);
             sn2s[tid] = expf(2.f * s);
-            vls[tid] = (tid < A && !clipped) ? vv[oS + tid] : 0.f;   // R{s} = mask * v_s
+            vls[tid] = (tid < A && !clipped) ? vs * vv[oS + tid] : 0.f;   // R{s} = mask * v_s
             b3s[tid] = (tid < A) ? th[ob3 + tid] : 0.f;
-            vb3s[tid] = (tid < A) ? vv[ob3 + tid] : 0.f;
+            vb3s[tid] = (tid < A) ? vs * vv[ob3 + tid] : 0.f;
         }
         for (int e = tid; e < R * MS; e += 256) Mss[e] = Ms2s[e] = 0.f;
-        for (int e = tid; e < 3 * WB_DMPL; e += 256) ((unsigned*)Dm)[e] = ((unsigned*)Dm2)[e] = 0u;
+        for (int e = tid; e < PROMP_NT * WB_DMPL; e += 256) ((unsigned*)Dm)[e] = ((unsigned*)Dm2)[e] = 0u;
         wb_init_x(Xs, OC, tid);
     }
 
     f32x16 aw1[NXB], aw2[4];
     f32x4 aw3[2];
+    float klsum, outs, outb3;
+    float klv = a.kl_weight * vs;            // (the KL cotangents carry no factor of the direction: they take its scale here)
+    // FP16 split (k_wb_fwd_bwd; promp_kernels_chain.h: CHAIN_*): the workgroup's cotangent scale cs, sized by the larger of the primal
+    // cotangent and 2^-CHAIN_Q_OVER_D of the tangent one; the work item is walked again if a split left the format
+    float cs = 1.f, amax = 0.f, redo_amax = 0.f;
+    int prov = 1;
+    for (int attempt = 0;; ++attempt) {
+    if (attempt > 0) {
+        // the work item again; the third time with the direction 2^CHAIN_V_RETRY lower (its planes were made by k_wb_planes: every
+        // fragment is brought down on its way into the registers, wb_fix; the float32 copies here); the first round's observations
+        // and the rings' first steps anew
+        const int tid = threadIdx.x, lane = tid & 63;
+        float *vb1s = sm + L.vb1, *vb2s = sm + L.vb2, *vb3s = sm + L.vb3, *vls = sm + L.vls;
+        vfix = attempt >= 2 ? pow2f(-CHAIN_V_RETRY) : 1.f;      // (the second walk keeps the direction's scale, the third lowers it too)
+        vs = vs0 * vfix;
+        ivs = 1.f / vs;
+        klv = a.kl_weight * vs;
+        __syncthreads();
+        wb_load_w3f(v3f, vv + oW3, A, lane, w, vs);
+        for (int e = tid; e < H; e += 256) {
+            vb1s[e] = vs * vv[ob1 + e];
+            vb2s[e] = vs * vv[ob2 + e];
+        }
+        if (tid < 16) {
+            const float sr = (tid < A) ? th[oS + tid] : 0.f;
+            const bool clipped = a.clip_log_std && (sr < a.min_log_std);
+            vls[tid] = (tid < A && !clipped) ? vs * vv[oS + tid] : 0.f;
+            vb3s[tid] = (tid < A) ? vs * vv[ob3 + tid] : 0.f;
+        }
+        wb_xreq<NKO>(X, a.obs, wk.row_begin, wk.row_end - wk.row_begin, O, tid);
+        wb_stream_begin(GT, PT, NKO, w, lane);
+        wb_stream_begin(GV, PV, NKO, w, lane, vfix);
+    }
 #pragma unroll
     for (int m = 0; m < NXB; ++m) aw1[m] = wb_zero16();
 #pragma unroll
     for (int m = 0; m < 4; ++m) aw2[m] = wb_zero16();
     aw3[0] = aw3[1] = zero4();
-    float klsum = 0.f, outs = 0.f, outb3 = 0.f;
-    const float klw = a.kl_weight;
+    klsum = outs = outb3 = 0.f;
+    cs = 1.f;
+    amax = 0.f;
+    prov = 1;
+    if (PROMP_NT == 2 && attempt > 0 && redo_amax > 0.f && redo_amax < 3.0e38f) {
+        int k = scale_exp(redo_amax, CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY);
+        k = k < -100 ? -100 : k > 100 ? 100 : k;
+        cs = pow2f(k);
+        prov = 0;
+    }
 
     int rix = 0;
     for (int base = wk.row_begin; base < wk.row_end; base += R) {
@@ -983,7 +1122,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         __syncthreads();                       // the previous round is done with every tile
         WB_STAMP(20);
         // ---- this round's observations (requested a round ago) -> the tile; the next round's are requested
-        wb_xput<NKO>(Xs, X, nrows, O, OC, tid);
+        wb_xput<NKO>(Xs, X, nrows, O, OC, tid, xs);
         WB_STAMP(21);
         wb_xreq<NKO>(X, a.obs, (long long)base + R, wk.row_end - base - R, O, tid);
         WB_STAMP(22);
@@ -1010,11 +1149,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
             // and stores quad by quad among its products: vector work in the matrix instructions' shadow instead of behind them
             f32x16 h1v;
             f32x16 cz = wb_bias16(b1s, h, w);
-            u32x4 fb[3];
+            u32x4 fb[PROMP_NT];
             wb_read_b(fb, Xs, j, h, 0);
 #pragma unroll
             for (int q = 0; q < NKO; ++q) {
-                u32x4 fn[3];
+                u32x4 fn[PROMP_NT];
                 if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
                 sched_fence();
                 wb_mma6(cz, GT.r[q % WB_PF], fb);
@@ -1022,14 +1161,14 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 sched_fence();
                 if (q + 1 < NKO) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+                    for (int t = 0; t < PROMP_NT; ++t) fb[t] = fn[t];
                 }
             }
             f32x16 cr = wb_bias16(vb1s, h, w);
             wb_read_b(fb, Xs, j, h, 0);
 #pragma unroll
             for (int q = 0; q < NKO; ++q) {
-                u32x4 fn[3];
+                u32x4 fn[PROMP_NT];
                 if (q + 1 < NKO) wb_read_b(fn, Xs, j, h, q + 1);
                 if (q < 4) {
                     const int g = q;
@@ -1043,11 +1182,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                     sts4(D1p + 256 * g + 4 * lane, hq);
                 }
                 wb_mma6(cr, GV.r[q % WB_PF], fb);
-                wb_ring_next(GV, PVz, NKO, PVz + oC2, 8, w, lane, q);
+                wb_ring_next(GV, PVz, NKO, PVz + oC2, 8, w, lane, q, vfix);
                 sched_fence();
                 if (q + 1 < NKO) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) fb[t] = fn[t];
+                    for (int t = 0; t < PROMP_NT; ++t) fb[t] = fn[t];
                 }
             }
 #pragma unroll
@@ -1062,12 +1201,12 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         f32x16 h2v, rh2v;
         {
             f32x16 cz = wb_bias16(b2s, h, w), cr = wb_bias16(vb2s, h, w);
-            u32x4 fb[3], fr[3];
+            u32x4 fb[PROMP_NT], fr[PROMP_NT];
             wb_read_b(fb, H1s, j, h, 0);
             wb_read_b(fr, RH1s, j, h, 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                u32x4 nb[3], nr[3];
+                u32x4 nb[PROMP_NT], nr[PROMP_NT];
                 if (q + 1 < 8) {
                     wb_read_b(nb, H1s, j, h, q + 1);
                     wb_read_b(nr, RH1s, j, h, q + 1);
@@ -1076,11 +1215,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 wb_mma6_two(cz, cr, GT.r[q % WB_PF], GV.r[q % WB_PF], fb);
                 wb_mma6(cr, GT.r[q % WB_PF], fr);
                 wb_ring_next(GT, PTz + oC2, 8, PTz + oR2, 8, w, lane, q);
-                wb_ring_next(GV, PVz + oC2, 8, PVz + oR2, 8, w, lane, q);
+                wb_ring_next(GV, PVz + oC2, 8, PVz + oR2, 8, w, lane, q, vfix);
                 sched_fence();
                 if (q + 1 < 8) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
+                    for (int t = 0; t < PROMP_NT; ++t) {
                         fb[t] = nb[t];
                         fr[t] = nr[t];
                     }
@@ -1101,16 +1240,17 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         // ---- output layer and its tangent, this wave's 32 units of the contraction:  Rmu = vW3^T h2 + W3^T Rh2 + vb3
         {
             const int j16 = lane & 15, g4 = lane >> 4;
-            u32x4 w3p[3], v3p[3];
+            u32x4 w3p[PROMP_NT], v3p[PROMP_NT];
             wb_gload(w3p, PTz + oW3P, 1, w, 0, lane);
             wb_gload(v3p, PVz + oW3P, 1, w, 0, lane);
+            wb_fix(v3p, vfix);
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
                 const int s = 16 * sb + j16;
-                u32x4 fb[3], fr[3];
+                u32x4 fb[PROMP_NT], fr[PROMP_NT];
                 const int off = wb_chunk(s, 8 * w + 2 * g4);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < PROMP_NT; ++t) {
                     fb[t] = wb_lds4(H2s + t * WB_PLANE + off);
                     fr[t] = wb_lds4(RH2s + t * WB_PLANE + off);
                 }
@@ -1170,22 +1310,42 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 if (eq == 0) klsum += kl * invN;
             }
             const bool klobj = a.loss_kind == LOSS_KL;      // the outputs are MINUS the tangent of the gradient
+            float d = 0.f, qm = 0.f;                        // (the tangent quantities at the direction's scale vs)
             if (eown) {
                 const float Rz = -Rmu * ee - z * Rs;
                 const float Rd = Rc * z * ee + c * (Rz * ee - z * ee * Rs);
                 const float Rds = Rc * (z * z - 1.f) + 2.f * c * z * Rz;
-                const float d = klobj ? km * dklm : c * z * ee;
-                const float qm = klobj ? -km * kRdm : km * (-Rd + klw * dklm);
+                d = klobj ? km * dklm : c * z * ee;
+                qm = klobj ? -km * kRdm : km * (-Rd + klv * dklm);
+                outs += klobj ? -km * kRds : km * (-Rds + klv * dkls);
+                outb3 += qm;
+            }
+            if (PROMP_NT == 2) {
+                const float am = fmaxf(fabsf(d), (1.f / (float)(1 << CHAIN_Q_OVER_D)) * fabsf(qm));
+                amax = fmaxf(amax, am);
+                if (prov) {          // (the same in every thread) no round has had a cotangent yet: this one sets the scale
+                    const float m = wave_absmax_f32(am);
+                    if (lane == 0) red[w] = m;
+                    __syncthreads();
+                    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                    const bool okm = mx > 0.f && mx < 3.0e38f;
+                    int k = scale_exp(okm ? mx : invN, okm ? CHAIN_CT_TARGET : -4);
+                    k = k < -100 ? -100 : k > 100 ? 100 : k;
+                    cs = pow2f(k);
+                    prov = okm ? 0 : 1;
+                }
+                d *= cs;
+                qm *= cs;
+            }
+            if (eown) {
                 Mss[erow * MS + eq] = -d;
                 Ms2s[erow * MS + eq] = qm;
-                outs += klobj ? -km * kRds : km * (-Rds + klw * dkls);
-                outb3 += qm;
-                unsigned t3[3];
-                bf16_split3_pair(-d, qm, t3);
+                unsigned t3[PROMP_NT];
+                split_pair<PROMP_NT>(-d, qm, t3);
                 unsigned short* Dh = (unsigned short*)Dm;
                 unsigned short* Dh2 = (unsigned short*)Dm2;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < PROMP_NT; ++t) {
                     Dh[2 * (t * WB_DMPL + erow * WB_DMROW) + eq] = (unsigned short)(t3[t] & 0xFFFFu);
                     Dh2[2 * (t * WB_DMPL + erow * WB_DMROW) + eq] = (unsigned short)(t3[t] >> 16);
                 }
@@ -1197,18 +1357,18 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         // ---- out_W3 rows 32 w .. += Rh2^T nd + h2^T qmu;  ndZ2 = (W3 nd^T)(1 - h2^2);  qZ2 = (W3 qmu^T + vW3 nd^T)(1 - h2^2) - 2 (W3 nd^T) h2 Rh2
         {
             const int p = lane & 15, g4 = lane >> 4;
-            u32x4 fan[3], faq[3];
+            u32x4 fan[PROMP_NT], faq[PROMP_NT];
             {
                 const int o0 = (8 * g4 + (p >> 2)) * WB_DMROW + 2 * (p & 3), o1 = o0 + 4 * WB_DMROW;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < PROMP_NT; ++t) {
                     fan[t] = join_w2(lds_tr16(Dm + t * WB_DMPL + o0), lds_tr16(Dm + t * WB_DMPL + o1));
                     faq[t] = join_w2(lds_tr16(Dm2 + t * WB_DMPL + o0), lds_tr16(Dm2 + t * WB_DMPL + o1));
                 }
             }
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub) {
-                u32x4 fbr[3], fbh[3];
+                u32x4 fbr[PROMP_NT], fbh[PROMP_NT];
                 wb_read_tr16(fbr, RH2s, lane, 2 * w + ub);
                 wb_read_tr16(fbh, H2s, lane, 2 * w + ub);
                 wb_mma6_16(aw3[ub], fan, fbr);
@@ -1236,14 +1396,13 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
             // out_b2: a row of ones (action slot 15) against the wave's own qZ2 columns
             u32x4 ones;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ones[i] = (p == 15) ? 0x3F803F80u : 0u;
+            for (int i = 0; i < 4; ++i) ones[i] = (p == 15) ? WB_ONE2 : 0u;
 #pragma unroll
             for (int ub = 0; ub < 2; ++ub) {
-                u32x4 fb[3];
+                u32x4 fb[PROMP_NT];
                 wb_read_tr16(fb, RH2s, lane, 2 * w + ub);
-                aw3[ub] = mfma16_bf16w(ones, fb[2], aw3[ub]);
-                aw3[ub] = mfma16_bf16w(ones, fb[1], aw3[ub]);
-                aw3[ub] = mfma16_bf16w(ones, fb[0], aw3[ub]);
+#pragma unroll
+                for (int t = PROMP_NT - 1; t >= 0; --t) aw3[ub] = mfma16_sw<PROMP_NT>(ones, fb[t], aw3[ub]);
             }
         }
         sched_fence();
@@ -1255,12 +1414,12 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         f32x16 qz1;
         {
             f32x16 ad = wb_zero16(), aq = wb_zero16();
-            u32x4 fd[3], fq[3], fzn[3], fzq[3];
+            u32x4 fd[PROMP_NT], fq[PROMP_NT], fzn[PROMP_NT], fzq[PROMP_NT];
             wb_read_b(fd, H2s, j, h, 0);
             wb_read_b(fq, RH2s, j, h, 0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                u32x4 nd[3], nq[3];
+                u32x4 nd[PROMP_NT], nq[PROMP_NT];
                 if (q + 1 < 8) {
                     wb_read_b(nd, H2s, j, h, q + 1);
                     wb_read_b(nq, RH2s, j, h, q + 1);
@@ -1270,7 +1429,7 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                     wb_read_tr(fzn, H2s, lane, w, t);
                     wb_read_tr(fzq, RH2s, lane, w, t);
                 }
-                u32x4 far[3], fah[3];
+                u32x4 far[PROMP_NT], fah[PROMP_NT];
                 wb_read_tr(far, RH1s, lane, m, t);
                 wb_read_tr(fah, H1s, lane, m, t);
                 sched_fence();
@@ -1278,11 +1437,11 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
                 wb_mma6_x2(aq, GV.r[q % WB_PF], fd, aw2[m], far, fzn);
                 wb_mma6(aw2[m], fah, fzq);
                 wb_ring_next(GT, PTz + oR2, 8, PTz, NKO, w, lane, q);
-                wb_ring_next(GV, PVz + oR2, 8, PVz, NKO, w, lane, q);
+                wb_ring_next(GV, PVz + oR2, 8, PVz, NKO, w, lane, q, vfix);
                 sched_fence();
                 if (q + 1 < 8) {
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) {
+                    for (int tt = 0; tt < PROMP_NT; ++tt) {
                         fd[tt] = nd[tt];
                         fq[tt] = nq[tt];
                     }
@@ -1308,16 +1467,16 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                u32x4 fz[3];
+                u32x4 fz[PROMP_NT];
                 wb_read_tr(fz, H2s, lane, w, t);
                 if (NXB == 1) {
-                    u32x4 fa[3];
+                    u32x4 fa[PROMP_NT];
                     wb_read_tr(fa, Xs, lane, 0, t);
                     wb_mma6(aw1[0], fa, fz);
                 } else {
 #pragma unroll
                     for (int m = 0; m + 1 < NXB; m += 2) {
-                        u32x4 fa0[3], fa1[3];
+                        u32x4 fa0[PROMP_NT], fa1[PROMP_NT];
                         wb_read_tr(fa0, Xs, lane, m, t);
                         wb_read_tr(fa1, Xs, lane, m + 1, t);
                         wb_mma6_two(aw1[m], aw1[m + 1], fa0, fa1, fz);
@@ -1328,6 +1487,33 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
         WB_STAMP(14);
         ++rix;
     }
+    // FP16 split: every split of this kernel ends in the hidden_0 kernel sums (x * 0 is 0 for finite x only)
+    if (PROMP_NT != 2 || attempt + 1 >= CHAIN_ATTEMPTS) break;
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int m = 0; m < NXB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(aw1[m][r], 0.f, chk);
+        const float wm = wave_absmax_f32(amax), wbad = wave_any(chk != chk) ? 1.f : 0.f;
+        const int lane = threadIdx.x & 63;
+        __syncthreads();
+        if (lane == 0) {
+            red[w] = wm;
+            red[4 + w] = wbad;
+        }
+        __syncthreads();
+        redo_amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        // (the mean cotangents' planes feed the output kernel's sums only: their largest values at the scale -- amax holds the larger of
+        //  |d| and 2^-CHAIN_Q_OVER_D |q|)
+        const bool bad = (red[4] + red[5] + red[6] + red[7]) > 0.f || !(redo_amax * cs * (float)(1 << CHAIN_Q_OVER_D) <= 65504.f);
+        if (!bad) break;
+        if (threadIdx.x == 0) atomic_add_agent(a.split_events + 1, 1);
+    }
+    }
+    const float us = PROMP_NT == 2 ? 1.f / (cs * vs) : 1.f;      // what the tangent cotangents' sums carry
+    outs *= ivs;
+    outb3 *= ivs;
 
     float* P = a.partials + (long long)wi * a.partial_stride;
     const int tidt = threadIdx.x + opaque_zero(), lane = tidt & 63, j = lane & 31, h = lane >> 5, tid = tidt;
@@ -1361,14 +1547,14 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[oW2 + (32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * H + 32 * w + j] = aw2[m][r];
+        for (int r = 0; r < 16; ++r) P[oW2 + (32 * m + 8 * (r >> 2) + 4 * h + (r & 3)) * H + 32 * w + j] = aw2[m][r] * us;
 #pragma unroll
     for (int m = 0; m < NXB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = 32 * m + 8 * (r >> 2) + 4 * h + (r & 3);
-            if (row < O) P[row * H + 32 * w + j] = aw1[m][r];
-            else if (row == OC) P[ob1 + 32 * w + j] = aw1[m][r];
+            if (row < O) P[row * H + 32 * w + j] = aw1[m][r] * (us * w1u);
+            else if (row == OC) P[ob1 + 32 * w + j] = aw1[m][r] * us;
         }
     {
         const int j16 = lane & 15, g4 = lane >> 4;
@@ -1377,8 +1563,8 @@ __global__ void __launch_bounds__(256, 1) k_wb_hvp(PassArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int aa = 4 * g4 + r, unit = 32 * w + 16 * ub + j16;
-                if (aa < A) P[oW3 + unit * A + aa] = aw3[ub][r];
-                else if (aa == 15) P[ob2 + unit] = aw3[ub][r];
+                if (aa < A) P[oW3 + unit * A + aa] = aw3[ub][r] * us;
+                else if (aa == 15) P[ob2 + unit] = aw3[ub][r] * us;
             }
     }
 }

@@ -122,6 +122,13 @@ class HostPaths(OrderedDict):
     flat = None
     _origin = ()
 
+    def __reduce__(self):
+        # A copy (copy.copy / copy.deepcopy / pickle: replay buffers, worker processes) is a HostPaths WITHOUT `flat`: the arrays
+        # of its path dicts no longer alias the flat arrays, so an in-place edit of the copy would otherwise be ignored in favour
+        # of the stale flat arrays (the identities flat_if_intact compares survive a pickle round trip).  The copy takes the
+        # general route; slab_backed() re-points it if the fast one is wanted.
+        return (HostPaths, (), None, None, iter(OrderedDict.items(self)))
+
     def flat_if_intact(self):
         fl, org = self.flat, self._origin
         if fl is None:

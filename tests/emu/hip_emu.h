@@ -290,6 +290,10 @@ inline float emu_h2f(unsigned short h) {
     else x = ldexpf((float)(m | 0x400u), (int)e - 25);
     return sign ? -x : x;
 }
+inline unsigned pk_scale_f16(unsigned w, float p2) {
+    const unsigned short lo = emu_f2h(emu_h2f((unsigned short)(w & 0xFFFFu)) * p2), hi = emu_f2h(emu_h2f((unsigned short)(w >> 16)) * p2);
+    return lo | ((unsigned)hi << 16);
+}
 template <int NT>
 inline float emu_half2f(unsigned short h) { return NT == 2 ? emu_h2f(h) : emu_bf2f(h); }
 template <int NT>

@@ -65,6 +65,12 @@ def test_split_range_follows_the_data(lib, two_cus):
     pc.check_split_range(lib, (32, 32), 7, 3, M=2, P=1, T=140, tol=1e-4)
 
 
+def test_split_range_follows_the_data_h128(lib, two_cus):
+    # the same on the cooperative 128-wide kernels (k_wb_fwd_bwd / k_wb_hvp: workgroup-wide scales, the work item walked again)
+    # (two work items: rows [0, 32) and [32, 80); the second one's first round is all small, its second all large)
+    pc.check_split_range(lib, (128, 128), 20, 6, M=1, P=1, T=80, tol=1e-4, tail_from=0.8)
+
+
 def test_loss_grad_workgroups_straddling_two_tasks(lib):
     # 3 tasks x ~12 tiles on the emulator's 4 CUs (32 waves): every task gets >= 8 waves, so the wave-granular split
     # puts two tasks into one workgroup (two parameter copies in LDS, two partial rows out)

@@ -281,6 +281,26 @@ def test_fixed_horizon_batches_come_back_as_views_of_the_flat_arrays():
     assert _lib.flatten_paths(paths2) is not paths2.flat
 
 
+def test_copies_of_a_flat_backed_batch_take_the_general_route():
+    """a deep copy or a pickle round trip keeps the identities flat_if_intact() compares but not the aliasing of the
+    flat arrays; an in-place edit of the copy must reach the device"""
+    import copy
+    import pickle
+    from promp_amd import _lib
+    M, B, T = 3, 4, 5
+    sampler = MetaSampler(FixedHorizonEnv(), EchoPolicy(M), rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T, envs_per_task=2)
+    sampler.update_tasks()
+    paths = sampler.obtain_samples()
+    assert paths.flat_if_intact() is paths.flat
+    for clone in (copy.deepcopy(paths), pickle.loads(pickle.dumps(paths)), copy.copy(paths)):
+        assert type(clone) is type(paths) and list(clone.keys()) == list(paths.keys())
+        assert clone.flat is None and clone.flat_if_intact() is None
+        np.testing.assert_array_equal(clone[1][2]['rewards'], paths[1][2]['rewards'])
+    clone = pickle.loads(pickle.dumps(paths))
+    clone[0][0]['rewards'][0] = 999.0
+    assert _lib.flatten_paths(clone)['rew'][0] == 999.0 and _lib.flatten_paths(paths)['rew'][0] != 999.0
+
+
 def test_early_terminations_take_the_general_route_unchanged():
     M, B, T = 3, 2, 4
     sampler = MetaSampler(CounterEnv(), EchoPolicy(M), rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
