@@ -326,7 +326,18 @@ def main():
         ctx.prof_enable(False)
         ex_us = ctx.allreduce_f64([1e3 * ex['total_ms'] / max(ex['launches'], 1)], op='max')[0]
         ideal = shard_ideal(args.config, world) if args.scaling == 'strong' and not args.test_shape else None
+        # the replicas after the timed loops: every rank holds the same meta-parameters and Adam moments, or the exchange went wrong
+        # (a checksum of each, min and max over the ranks; fixed-order exchange: bit-identical, all-reduce: equal to rounding)
+        th = ctx.get_theta().astype(np.float64)
+        m_, v_, t_ = ctx.get_adam_state()
+        sums = [float(th.sum()), float(np.abs(th).sum()), float(m_.astype(np.float64).sum()), float(v_.astype(np.float64).sum()), float(t_)]
+        lo, hi = -ctx.allreduce_f64([-x for x in sums], op='max'), ctx.allreduce_f64(sums, op='max')
+        spread = max(abs(h - l) / max(abs(h), abs(l), 1e-300) for l, h in zip(lo, hi))
         out['rccl'] = {
+            'replicas_equal': bool(spread <= (0.0 if ci['fixed_order'] else 1e-6)), 'replica_checksum_spread': float(spread),
+            'replica_checksums': {'theta_sum': [float(lo[0]), float(hi[0])], 'theta_abs_sum': [float(lo[1]), float(hi[1])],
+                                  'adam_m_sum': [float(lo[2]), float(hi[2])], 'adam_v_sum': [float(lo[3]), float(hi[3])],
+                                  'adam_t': [float(lo[4]), float(hi[4])]},
             'nranks': int(row[0, 1]), 'nranks_reported_by_every_rank': [int(x) for x in row[:, 1]],
             'ranks': [int(x) for x in row[:, 2]],
             'devices': [bytes(int(c) for c in r[3:] if c > 0).decode() for r in row],
@@ -338,8 +349,15 @@ def main():
             'protocol': os.environ.get('NCCL_PROTO', 'RCCL default (LL for a %d-byte message)' % (4 * (ctx.n_params + K + 2))),
             'per_rank_ms_per_step': [float(x) for x in row[:, 0]]}
         if ideal:
+            # what the committed one-GPU shard timing predicts for this run: the shard's kernels + one exchange per epoch and one for
+            # the statistics at the latency measured right here
+            n_exch = ex['launches'] / float(n_ex)
+            predicted = ideal['shard_ms_per_step_kernels_only'] + 1e-3 * ex_us * n_exch
             out['strong_scaling'] = dict(ideal, speedup_vs_shard_ideal=ideal['shard_ms_per_step_kernels_only'] / (1e3 * elapsed / args.steps),
-                                         measured_speedup_vs_profiled_single_gpu=ideal['single_gpu_ms_per_step'] / (1e3 * elapsed / args.steps))
+                                         measured_speedup_vs_profiled_single_gpu=ideal['single_gpu_ms_per_step'] / (1e3 * elapsed / args.steps),
+                                         predicted_ms_per_step=predicted, predicted_speedup=ideal['single_gpu_ms_per_step'] / predicted,
+                                         prediction='shard kernels %.3f ms + %.1f exchanges x %.1f us measured in this run'
+                                                    % (ideal['shard_ms_per_step_kernels_only'], n_exch, ex_us))
 
     # ---- config 5 with the exact constraint Hessian-vector product (promp_constraint_hvp) instead of the reference's finite
     # difference: reported beside the timed default, never as `value` ----
@@ -595,11 +613,12 @@ def shard_ideal(config, world):
     staging, end-of-segment sums) that does not shrink with the shard: DESIGN.md section 7."""
     import glob
     import re
-    if config != 3:
+    if config not in (3, 4):
         return None
     try:
-        sf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_shard_timings.txt')))[-1]
-        bf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench.json')))[-1]
+        suffix = '' if config == 3 else '_config4'
+        sf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_shard_timings%s.txt' % suffix)))[-1]
+        bf = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench%s.json' % suffix)))[-1]
         single = json.load(open(bf))['ms_per_step']
         shard = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r'shard-of (\d+): \d+ tasks on this GPU, ([0-9.]+) ms/step', open(sf).read())}
         if world not in shard:

@@ -506,6 +506,8 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
     a.dbg = c->dbg_enabled ? c->dbg : nullptr;
     a.split_events = c->split_events;
     const int id = hvp ? PROMP_KERNEL_HVP : fwd_only ? PROMP_KERNEL_FWD : PROMP_KERNEL_FWD_BWD;
+    // (the timed slot covers the pass with the small launches that prepare its operands: k_wb_planes, k_vec_absmax)
+    if (prof_begin(c, id, S.n_rows)) return -2;
     if (c->wbf) {
         // the parameters' (and the direction's) hidden kernels as BF16 planes in fragment order (one small launch each: 276 KB per task)
         const int nko = wb_nko(c->wbf);
@@ -529,7 +531,6 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
             a.wb_v_planes = c->wb_vplanes;
         }
     }
-    if (prof_begin(c, id, S.n_rows)) return -2;
     if (c->generic) {
         if (launch_pass_generic(c, S, a, hvp, fwd_only)) return -2;
     } else if (c->wbf) {

@@ -28,5 +28,6 @@ def test_bench_gpus_2_launches_its_ranks_and_describes_them():
     assert r['distinct_devices'] == 2 and len(r['devices']) == 2
     assert len(r['per_rank_ms_per_step']) == 2 and all(x > 0 for x in r['per_rank_ms_per_step'])
     assert r['exchanges_per_step'] == 6 and r['allreduce_us'] > 0        # E = 5 epochs + the statistics pass
+    assert r['replicas_equal'] is True and r['replica_checksums']['adam_t'][0] == r['replica_checksums']['adam_t'][1] > 0
     assert d['weak_batch']['meta_batch_size'] == 8 and d['weak_batch']['tasks_per_gpu'] == 4
     assert d['value'] > 0 and d['ms_per_step'] > 0

@@ -36,6 +36,13 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('shard-of $n: %d tasks on this GPU, %.4f ms/step' % (d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/shard_timings.txt
 done
 cat $ROOT/$R/shard_timings.txt
+# ... and of BASELINE config 4's batch (Ant shapes)
+for n in 2 4 8; do
+  timeout 300 python $ROOT/bench.py --config 4 --shard-of $n --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-plugin-path --repeats 1 2> /dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('shard-of $n: %d tasks on this GPU, %.4f ms/step' % (d['config']['tasks_per_gpu'], d['ms_per_step']))" >> $ROOT/$R/shard_timings_config4.txt
+done
+cat $ROOT/$R/shard_timings_config4.txt
 # primal cache on (default rule) / forced off: full batch and shards, same box, back to back
 for n in 0 2 4 8; do for flag in "" "--no-primal-cache"; do
   sh=""; [ $n -gt 0 ] && sh="--shard-of $n"
