@@ -758,19 +758,19 @@ PROMP_DEV void chain_task_reduce(const PassArgs& a, int* flag, int task, int NP,
     chain_task_sum<NT>(r, tid);
 }
 
-// FP16 split of k_chain_hvp (see pass_cotangent_scale in promp_kernels_pass.h for the reasoning): the direction's largest entry goes
-// to [2, 4) -- its hidden_1 block, the only part that is split, then sits around 2^-3 .. 1, the tangent activations (sums over the
-// observations) around 1 .. 100 --, the first tile's largest mean cotangent to [4, 8), the tangent cotangents follow from the two
-// (x 2^4 .. 2^6).  A wave that finds an infinity or a NaN in its sums -- every overflow of a split ends there -- has the workgroup
-// walk the segment again: the largest cotangent -- known by then -- at 2^CHAIN_CT_REDO, and on a third walk the direction
-// 2^CHAIN_V_RETRY lower as well (tangent activations that left the format: observations x direction beyond 2^16).  One
-// such segment doubles the launch's duration (the other workgroups wait), so the first walk's targets leave room: 2^13 above the
-// first tile's largest primal cotangent, 2^8 above 1/32 of its largest tangent cotangent.
+// FP16 split of k_chain_hvp (see pass_cotangent_scale in promp_kernels_pass.h for the reasoning): the direction's largest entry
+// (hidden_0 block weighed by the observations' scale) goes to [8, 16) -- tangent activations, sums over the observations, then sit
+// around 1 .. 1000 --, the larger of the first tile's largest primal cotangent and 1/32 of its largest tangent cotangent to [4, 8).
+// Measured on configs 3 and 4 with the direction's target at 2, 8 and 32 (profiles/r06_split_targets.txt): no segment walked again
+// in any of them, the meta-gradient's error at 128-wide layers 4.7 / 3.5 / 3.2 e-6.  A wave that finds an infinity or a NaN in its
+// sums -- every overflow of a split ends there -- has the workgroup walk the segment again: the largest cotangent -- known by
+// then -- at 2^CHAIN_CT_REDO, and on a third walk the direction 2^CHAIN_V_RETRY lower as well (tangent activations that left the
+// format: observations x direction beyond 2^16).  One such segment doubles the launch's duration (the other workgroups wait).
 #ifndef PROMP_CT_ATTEMPTS
 #define PROMP_CT_ATTEMPTS 3
 #endif
 #ifndef PROMP_CHAIN_V_TARGET
-#define PROMP_CHAIN_V_TARGET 1
+#define PROMP_CHAIN_V_TARGET 3
 #endif
 #ifndef PROMP_CHAIN_CT_TARGET
 #define PROMP_CHAIN_CT_TARGET 2

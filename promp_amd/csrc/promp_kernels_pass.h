@@ -356,7 +356,10 @@ struct PassSums {                // what a wave accumulates over its tiles of a 
 #ifndef PROMP_CT_ATTEMPTS
 #define PROMP_CT_ATTEMPTS 3
 #endif
-PROMP_CX int PASS_CT_TARGET = 5, PASS_CT_REDO = 10, PASS_CT_RETRY = 12, PASS_CT_ATTEMPTS = PROMP_CT_ATTEMPTS;
+#ifndef PROMP_PASS_CT_TARGET
+#define PROMP_PASS_CT_TARGET 5
+#endif
+PROMP_CX int PASS_CT_TARGET = PROMP_PASS_CT_TARGET, PASS_CT_REDO = 10, PASS_CT_RETRY = 12, PASS_CT_ATTEMPTS = PROMP_CT_ATTEMPTS;
 // the scale a largest |mean cotangent| of mx asks for (mx = 0 / not finite: 2^-4 N, for adv / N, and `prov`)
 template <int NC1, int NC2>
 PROMP_DEV void pass_cotangent_scale(PassSums<NC1, NC2>& S, float mx, float invN, int target) {

@@ -52,7 +52,10 @@
 #define WB_DMPL 256        // words per cotangent plane
 // FP16 split (see promp_kernels_pass.h: pass_cotangent_scale, promp_kernels_chain.h: CHAIN_*): where the direction's largest entry,
 // the first round's largest cotangent and -- when a work item is walked again -- its largest cotangent overall go
-#define WB_V_TARGET 1
+#ifndef PROMP_CHAIN_V_TARGET
+#define PROMP_CHAIN_V_TARGET 3
+#endif
+#define WB_V_TARGET PROMP_CHAIN_V_TARGET
 
 // ---- pre-split weight planes in global memory (k_wb_planes) ----
 // per task:  C1 [w 4][q NKO][t 3][lane 64] x 16 B   hidden_0 kernel, column slices: lane (i, h) of (w, q): W1[16 q + 8 h + e][32 w + i]
