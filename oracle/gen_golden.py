@@ -312,6 +312,75 @@ def gen_promp_adam():
         print('wrote promp_adam_%s.npz  loss %.6f -> %.6f  max|dtheta| %.3e' % (name, losses[0], loss_after, np.max(np.abs(th - theta0))))
 
 
+# ---- BASELINE sizes by seed (round 6): the optimiser trajectory of config 3 and the TRPO-MAML step of config 5 ------------------
+# The inputs (42 MB) are regenerated from the seed by tests/helpers.make_promp_case and pinned by two checksums, as in gen_promp_full.
+ADAM_FULL_CASES = {
+    'config3': dict(seed=3003, M=40, P=20, T=200, O=20, A=6, hidden=(64, 64), K=1, clip_eps=0.3, eta=[5e-4], alpha=0.1, lr=1e-3, epochs=5),
+}
+
+
+def gen_promp_adam_full():
+    """optimizers/maml_first_order_optimizer.py:82-115 at config 3's batch: E = 5 epochs of tf.train.AdamOptimizer (transcribed as in
+    gen_promp_adam) on the torch.autograd gradient of the transcribed ProMP graph"""
+    sys.path.insert(0, ROOT)
+    from tests import helpers
+    for name, c in ADAM_FULL_CASES.items():
+        theta0, all_slabs, _ = helpers.make_promp_case(c['seed'], c['M'], c['P'], c['T'], c['O'], c['A'], tuple(c['hidden']), c['K'])
+        th = theta0.astype(np.float64)
+        m, v = np.zeros_like(th), np.zeros_like(th)
+        b1, b2, eps, lr = 0.9, 0.999, 1e-8, c['lr']
+        losses, grads = [], []
+        for t in range(1, c['epochs'] + 1):
+            loss, _, _, g = torch_meta_objective(th, all_slabs, c)
+            losses.append(loss)
+            grads.append(g)
+            lr_t = lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            m = m + (1.0 - b1) * (g - m)
+            v = v + (1.0 - b2) * (g * g - v)
+            th = th - lr_t * m / (np.sqrt(v) + eps)
+        loss_after, ikl, okl, _ = torch_meta_objective(th, all_slabs, c)
+        np.savez_compressed(os.path.join(GOLDEN, 'promp_adam_full_%s.npz' % name), meta=json.dumps(c), theta_after=th,
+                            adam_m=m.astype(np.float32), adam_v=v.astype(np.float32), losses=np.array(losses),
+                            grad_min_abs=np.min(np.abs(np.stack(grads)), axis=0).astype(np.float32),
+                            grad_max_norm=np.array([np.max(np.abs(g)) for g in grads]),
+                            loss_after=loss_after, inner_kl_after=ikl, outer_kl_after=okl,
+                            theta_checksum=float(np.sum(theta0.astype(np.float64))),
+                            obs_checksum=float(np.sum(all_slabs[1][-1]['observations'].astype(np.float64))))
+        print('wrote promp_adam_full_%s.npz  loss %.6f -> %.6f  max|dtheta| %.3e' % (name, losses[0], loss_after, np.max(np.abs(th - theta0))))
+
+
+TRPO_FULL_CASES = {
+    # BASELINE config 5: MAML-TRPO on config 3's shapes, inner log-likelihood (run_scripts/maml_run_mujoco.py:119), at TRPO's
+    # operating point: the last sampling step's recorded distribution IS the adapted policy's (tests/parity_checks.py: on_policy_case,
+    # what sampling with the adapted parameters records, meta_trainer.py:97-116), so the constraint starts at zero
+    'config5': dict(seed=66, M=40, P=20, T=200, O=20, A=6, hidden=(64, 64), K=1, alpha=0.1, inner_kind='loglik', max_kl=0.01, cg_iters=10),
+}
+
+
+def gen_trpo_full():
+    """optimizers/conjugate_gradient_optimizer.py:239-307 at config 5's batch, in float64: gradient of the surrogate, ten conjugate-
+    gradient iterations on the constraint's Hessian-vector product, the initial step sqrt(2 delta / d^T H d) and the backtracking
+    line search -- oracle/trpo.py: trpo_maml_step (its product is the reference's central difference carried out in float64: exact to
+    ~1e-9; the NumPy gradients it differences are pinned by torch.autograd at small sizes and at config 3's size)"""
+    sys.path.insert(0, ROOT)
+    from tests import parity_checks as pc
+    from oracle import policy as op, trpo as otrpo
+    for name, c in TRPO_FULL_CASES.items():
+        spec = op.PolicySpec(c['O'], c['A'], tuple(c['hidden']))
+        theta, all_slabs, _ = pc.on_policy_case(c['seed'], c['M'], c['P'], c['T'], c['O'], c['A'], tuple(c['hidden']), c['K'],
+                                                np.full(spec.n_params, c['alpha'], np.float32), c['inner_kind'], ragged=False)
+        r = otrpo.trpo_maml_step(spec, theta, all_slabs, np.full(spec.n_params, c['alpha']), inner_kind=c['inner_kind'], max_kl=c['max_kl'],
+                                 cg_iters=c['cg_iters'])
+        np.savez_compressed(os.path.join(GOLDEN, 'trpo_full_%s.npz' % name), meta=json.dumps(c), gradient=r['gradient'],
+                            descent_direction=r['descent_direction'], initial_step_size=r['initial_step_size'], theta_new=r['theta'],
+                            rejected=bool(r['rejected']), n_backtracks=int(r['n_backtracks']), loss_before=r['loss_before'],
+                            loss_after=r['loss_after'], kl_before=r['kl_before'], kl_after=r['kl_after'],
+                            theta_checksum=float(np.sum(theta.astype(np.float64))),
+                            obs_checksum=float(np.sum(all_slabs[1][-1]['observations'].astype(np.float64))))
+        print('wrote trpo_full_%s.npz  loss %.6f -> %.6f  kl %.5f  step %.4e  backtracks %d  rejected %s'
+              % (name, r['loss_before'], r['loss_after'], r['kl_after'], r['initial_step_size'], r['n_backtracks'], r['rejected']))
+
+
 # --------------------------------------------------------------------------------------------------
 DICE_PROC_CASES = {
     # name: (seed, dims, max_path_length, processor kwargs, baseline, ragged)
@@ -587,6 +656,10 @@ if __name__ == '__main__':
     if '--full-only' in sys.argv:            # (round 5 additions only: the other fixtures stay byte-identical)
         gen_promp_full()
         sys.exit(0)
+    if '--full-steps-only' in sys.argv:      # (round 6 additions only: the other fixtures stay byte-identical)
+        gen_promp_adam_full()
+        gen_trpo_full()
+        sys.exit(0)
     if '--adam-only' in sys.argv:            # (round 4 additions only: the other fixtures stay byte-identical)
         gen_promp_adam()
         sys.exit(0)
@@ -595,6 +668,8 @@ if __name__ == '__main__':
         gen_promp()
         gen_promp_adam()
         gen_promp_full()
+        gen_promp_adam_full()
+        gen_trpo_full()
     gen_dist_reference()
     gen_point_env()
     gen_dice_proc()

@@ -2,6 +2,7 @@
 import numpy as np
 
 from .. import _lib
+from ..optimizers.maml_first_order_optimizer import MAMLPPOOptimizer
 from ..utils import logger
 from .base import MAMLAlgo
 
@@ -31,16 +32,22 @@ class ProMP(MAMLAlgo):
         self.anneal_factor = anneal_factor
         self._optimization_keys = ['observations', 'actions', 'advantages', 'agent_infos']
         self.name = name
+        # pro_mp.py:59-62: the optimiser object a caller may reach for (algo.optimizer.loss / optimize / compute_stats)
+        self.optimizer = MAMLPPOOptimizer(learning_rate=learning_rate, max_epochs=num_ppo_steps, num_minibatches=num_minibatches)
+        self.optimizer.build_graph(self)
 
     def optimize_policy(self, all_samples_data, log=True):
         """MAML outer step: E Adam epochs on the meta-objective, then stats (pro_mp.py:165-199)"""
         assert len(all_samples_data) == self.num_inner_grad_steps + 1
         self._place_steps(all_samples_data)           # sampling step k must sit in slot k
         if log: logger.log('Optimizing')
-        res = self.session.optimize(self.num_ppo_steps, self.learning_rate, self.clip_eps, self.inner_kl_coeff,
-                                        self.inner_kind, self.outer_kind)
+        # (the epochs and the statistics pass behind them are ONE device call: compute_stats answers from what optimize got back)
+        feed = dict(clip_eps=self.clip_eps, inner_kl_coeff=self.inner_kl_coeff)
+        self.optimizer._learning_rate, self.optimizer._max_epochs = float(self.learning_rate), int(self.num_ppo_steps)
+        loss_before = self.optimizer.optimize(feed)
         if log: logger.log('Computing statistics')
-        loss_before, loss_after, inner_kls = res['loss_before'], res['loss_after'], res['inner_kl']
+        loss_after, inner_kls, outer_kl = self.optimizer.compute_stats(feed)
+        res = self.optimizer.last_result
         if self.adaptive_inner_kl_penalty:
             if log: logger.log('Updating inner KL loss coefficients')
             self.inner_kl_coeff = self.adapt_kl_coeff(self.inner_kl_coeff, inner_kls, self.target_inner_step)
@@ -50,7 +57,6 @@ class ProMP(MAMLAlgo):
             logger.logkv('KLInner', np.mean(inner_kls))
             logger.logkv('KLCoeffInner', np.mean(self.inner_kl_coeff))
         self.last_stats = res
-        self.session.param_version += 1
 
     def adapt_kl_coeff(self, kl_coeff, kl_values, kl_target):
         """per inner step: one coefficient per KL value (arrays), or a single pair (scalars)"""

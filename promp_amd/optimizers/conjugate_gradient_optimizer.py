@@ -195,7 +195,7 @@ class ConjugateGradientOptimizer(object):
         curvature = self._hvp_approach.build_eval()
         direction = conjugate_gradients(curvature, grad, cg_iters=self._cg_iters)
         length = np.sqrt(2.0 * self._max_constraint_val * (1. / (direction.dot(curvature(direction)) + 1e-8)))
-        self.last = dict(loss_before=loss_before, descent_direction=direction, initial_step_size=float(length),
+        self.last = dict(loss_before=loss_before, gradient=grad, descent_direction=direction, initial_step_size=float(length),
                          n_backtracks=0, rejected=False)
         if np.isnan(length):
             logger.log('trust-region step: step length is NaN, update rejected')

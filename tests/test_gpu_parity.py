@@ -4,6 +4,8 @@
   * the float64 oracle on seeded inputs (sizes the oracle finishes in seconds),
   * size-independent properties at BASELINE.json's full config-3 size.
 Tolerances are stated in tests/parity_checks.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -351,6 +353,84 @@ def test_full_config_meta_gradient_vs_torch_autograd_golden(lib, name):
     np.testing.assert_allclose(st['outer_kl'], float(g['outer_kl']), rtol=2e-5)
     assert err < 2e-5
     ctx.close()
+
+
+def test_full_config3_adam_trajectory_vs_torch_autograd_golden(lib):
+    """the optimiser trajectory at BASELINE size (optimizers/maml_first_order_optimizer.py:82-115): theta, m, v after
+    E = 5 epochs of config 3's 40 x 4 000-row batch against torch.autograd + the transcribed tf.train.AdamOptimizer, per element
+    (assert_adam_trajectory), inputs by seed"""
+    c, theta, all_slabs, all_paths, g = helpers.load_full_by_seed('promp_adam_full', 'config3')
+    M, O, A, hidden = c['M'], c['O'], c['A'], tuple(c['hidden'])
+    ctx = pc.make_ctx(lib, M, O, A, hidden, c['K'], all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(np.full(ctx.n_params, c['alpha'], np.float32))
+    res = ctx.optimize(c['epochs'], c['lr'], c['clip_eps'], np.array(c['eta'], np.float32))
+    np.testing.assert_allclose(res['loss_before'], float(g['losses'][0]), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(res['loss_after'], float(g['loss_after']), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(res['inner_kl'], g['inner_kl_after'], rtol=1e-4)
+    m, v, t = ctx.get_adam_state()
+    assert t == c['epochs']
+    worst, excluded = pc.assert_adam_trajectory(ctx.get_theta().astype(np.float64) - theta.astype(np.float64),
+                                                g['theta_after'] - theta.astype(np.float64), g['grad_min_abs'], g['grad_max_norm'],
+                                                c['lr'], c['epochs'], m_dev=m, v_dev=v, m_ref=g['adam_m'].astype(np.float64),
+                                                v_ref=g['adam_v'].astype(np.float64))
+    print('adam golden full config3: worst judged entry %.2e of one step, %.2f %% of the entries under the gradient floor; loss after %.2e rel'
+          % (worst, 100 * excluded, abs(res['loss_after'] - float(g['loss_after'])) / abs(float(g['loss_after']))))
+    ctx.close()
+
+
+def test_full_config5_trpo_step_vs_float64_golden(lib):
+    """the TRPO-MAML step at BASELINE size (optimizers/conjugate_gradient_optimizer.py:239-307) with the EXACT constraint
+    product on the device against the float64 step of the oracle (tests/golden/trpo_full_config5.npz): gradient, search direction,
+    initial step size, the line search's outcome and the new parameters"""
+    from promp_amd import session
+    from promp_amd.meta_algos.trpo_maml import TRPOMAML
+    from promp_amd.policies.meta_gaussian_mlp_policy import MetaGaussianMLPPolicy
+    from promp_amd.utils import logger
+    import json
+    g = np.load(os.path.join(helpers.GOLDEN, 'trpo_full_config5.npz'))
+    c = json.loads(str(g['meta']))
+    M, O, A, hidden = c['M'], c['O'], c['A'], tuple(c['hidden'])
+    spec = op.PolicySpec(O, A, hidden)
+    theta, all_slabs, all_paths = pc.on_policy_case(c['seed'], M, c['P'], c['T'], O, A, hidden, c['K'], np.full(spec.n_params, c['alpha'], np.float32),
+                                                    c['inner_kind'], ragged=False)
+    assert float(np.sum(theta.astype(np.float64))) == float(g['theta_checksum'])
+    assert abs(float(np.sum(all_slabs[1][-1]['observations'].astype(np.float64))) - float(g['obs_checksum'])) == 0.0
+    logger.configure(quiet=True)
+    _lib.set_library_for_testing(lib)
+    try:
+        policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden)
+        policy.set_params(spec.to_ordered_dict(theta))
+        algo = TRPOMAML(policy=policy, step_size=c['max_kl'], inner_type='log_likelihood', inner_lr=c['alpha'], meta_batch_size=M,
+                        num_inner_grad_steps=1, hvp_approach='exact')
+        algo.optimizer._cg_iters = c['cg_iters']
+        samples = [[dict(observations=s['observations'], actions=s['actions'], advantages=s['advantages'], agent_infos=s['agent_infos'])
+                    for s in step] for step in all_slabs]
+        algo.optimize_policy(samples, log=False)
+        st, last = algo.last_stats, algo.optimizer.last
+        d, dr = last['descent_direction'].astype(np.float64), g['descent_direction']
+        cos = d.dot(dr) / (np.linalg.norm(d) * np.linalg.norm(dr))
+        gerr = pc.rel_max(last['gradient'], g['gradient'])
+        th_new = np.asarray(spec.from_ordered_dict(policy.get_params()))
+        derr = pc.rel_max(th_new.astype(np.float64) - theta.astype(np.float64), g['theta_new'] - theta.astype(np.float64))
+        print('trpo golden full config5: direction cosine %.8f (|d - d_ref| / |d_ref|_max %.2e), gradient %.2e, initial step %.4e (ref %.4e), '
+              'backtracks %d (ref %d), step taken %.2e of its max-norm, loss after %.6f (ref %.6f), kl %.6f (ref %.6f)'
+              % (cos, pc.rel_max(d, dr), gerr, last['initial_step_size'], float(g['initial_step_size']), last.get('n_backtracks', -1),
+                 int(g['n_backtracks']), derr, st['loss_after'], float(g['loss_after']), st['mean_kl'], float(g['kl_after'])))
+        assert not last['rejected'] and not bool(g['rejected'])
+        # measured on the MI355X (profiles/r06_full_size_parity.txt): direction 1.2e-6, gradient 1.2e-6, step 1.3e-6 of their max-norms
+        assert cos > 0.999999 and pc.rel_max(d, dr) < 5e-5, (cos, pc.rel_max(d, dr))
+        assert gerr < 2e-5, gerr
+        assert last['n_backtracks'] == int(g['n_backtracks'])
+        np.testing.assert_allclose(last['initial_step_size'], float(g['initial_step_size']), rtol=2e-4)
+        np.testing.assert_allclose(st['loss_before'], float(g['loss_before']), rtol=1e-3, atol=1e-6)      # (the on-policy loss is ~2e-5)
+        np.testing.assert_allclose(st['loss_after'], float(g['loss_after']), rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(st['mean_kl'], float(g['kl_after']), rtol=1e-3, atol=1e-7)
+        assert derr < 5e-5, derr
+    finally:
+        _lib.set_library_for_testing(None)
+        session._current = None
 
 
 def test_full_config_zero_advantages_give_zero_surrogate_gradient(config_full):

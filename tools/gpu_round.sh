@@ -6,7 +6,7 @@ rm -rf $R && mkdir -p $R
 export TMPDIR=/tmp
 rocminfo | grep -E "Marketing Name|gfx" | head -4 > $R/device.txt 2>&1
 timeout 1200 python -m pytest tests -m gpu -q -s > $R/pytest_gpu_verbose.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu_verbose.log
-grep -E "passed|failed|pytest rc" $R/pytest_gpu_verbose.log > $R/pytest_gpu.log; grep -E "full-size parity|adam golden" $R/pytest_gpu_verbose.log > $R/full_size_parity.txt; cat $R/pytest_gpu.log $R/full_size_parity.txt; rm -f $R/pytest_gpu_verbose.log
+grep -E "passed|failed|pytest rc" $R/pytest_gpu_verbose.log > $R/pytest_gpu.log; grep -E "full-size parity|adam golden|trpo golden" $R/pytest_gpu_verbose.log > $R/full_size_parity.txt; cat $R/pytest_gpu.log $R/full_size_parity.txt; rm -f $R/pytest_gpu_verbose.log
 python tools/split_accuracy_gpu.py > $R/split_accuracy.txt 2>&1; PROMP_WIDE_FP32=1 python tools/split_accuracy_gpu.py 2>&1 | tail -2 | sed 's/^/exact-FP32 cooperative kernels (PROMP_WIDE_FP32=1): /' >> $R/split_accuracy.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log; tail -2 $R/smoke.log
 timeout 900 python bench.py > $R/bench.json 2> $R/bench.err; echo "bench rc=$?"; cat $R/bench.json | head -c 400; echo

@@ -9,7 +9,7 @@ exec < /dev/null
 ROOT=$GRAFT_REPO_ROOT
 rocminfo | grep -E "Marketing Name|gfx" | head -4 > $R/device.txt 2>&1
 timeout 600 python -m pytest tests -m gpu -q -s > $R/pytest_gpu_verbose.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu_verbose.log
-grep -E "passed|failed|pytest rc" $R/pytest_gpu_verbose.log > $R/pytest_gpu.log; grep -E "full-size parity|adam golden" $R/pytest_gpu_verbose.log > $R/full_size_parity.txt; cat $R/pytest_gpu.log; grep -E "^FAILED|^ERROR" $R/pytest_gpu_verbose.log | head; rm -f $R/pytest_gpu_verbose.log
+grep -E "passed|failed|pytest rc" $R/pytest_gpu_verbose.log > $R/pytest_gpu.log; grep -E "full-size parity|adam golden|trpo golden" $R/pytest_gpu_verbose.log > $R/full_size_parity.txt; cat $R/pytest_gpu.log; grep -E "^FAILED|^ERROR" $R/pytest_gpu_verbose.log | head; rm -f $R/pytest_gpu_verbose.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log; tail -2 $R/smoke.log
 timeout 400 python bench.py > $R/bench.json 2> $R/bench.err; echo "bench rc=$?"; head -c 300 $R/bench.json; echo
 timeout 300 python bench.py --config 4 --steps 10 --warmup 2 > $R/bench_config4.json 2> $R/bench_config4.err; echo "bench config4 rc=$?"; head -c 300 $R/bench_config4.json; echo
