@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 from promp_amd import _lib, comm, synthetic  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+F16_PEAK_TFLOPS = 2516.6      # MI355X_MICROARCH.md: dense FP16 / BF16 MFMA peak (no sparsity)
+SPLIT_PRODUCTS = 3            # matrix instructions per float32-equivalent product of the two-term FP16 split (promp_device.h)
 HBM_PEAK_GBS = 8000.0
 ENV_NAMES = {1: 'Point2D', 2: 'HalfCheetahRandVel', 3: 'HalfCheetahRandVel', 4: 'AntRandDirec', 5: 'HalfCheetahRandVel'}
 
@@ -438,8 +440,18 @@ def main():
                 k['mfma_busy_frac'] = t['mfma_busy_frac']          # committed PMC pass (sha-guarded like `traffic`)
         out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': kern[dom]['tflops'], 'peak': FP32_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': kern[dom]['tflops'] / FP32_PEAK_TFLOPS,
-                           'peak_note': 'algorithmic float32 FLOPs (SURVEY 8d: matmul only, 2 / MAC) over the FP32 peak of 157.3 TFLOP/s; '
-                                        'k_pass issues them as float32-equivalent BF16 products (6 per float32 product), see config.numerics',
+                           'peak_note': 'algorithmic float32 FLOPs (SURVEY 8d: matmul only, 2 / MAC) over the FP32 peak of 157.3 TFLOP/s, as in '
+                                        'every round (the arithmetic type is float32); the kernel issues them as float32-equivalent FP16 '
+                                        'products (3 matrix instructions per float32 product, see config.numerics), so 157.3 is not its '
+                                        'ceiling -- `pipe` prices the same launch against the matrix pipe it occupies',
+                           'pipe': {'dtype': 'f16 x 3 (two-term split: hi.hi + hi.lo + lo.hi, float32 accumulation)',
+                                    'executed_tflops': SPLIT_PRODUCTS * kern[dom]['tflops'], 'peak': F16_PEAK_TFLOPS,
+                                    'frac': SPLIT_PRODUCTS * kern[dom]['tflops'] / F16_PEAK_TFLOPS,
+                                    'float32_equivalent_peak': F16_PEAK_TFLOPS / SPLIT_PRODUCTS,
+                                    'note': 'matrix FLOPs the split issues for the formula FLOPs (x3; the few K = act_dim products on '
+                                            'the exact-FP32 instruction counted alike) over the dense FP16 peak: what is not matrix time is '
+                                            'the split itself (2 vector instructions per value), tanh, the distribution epilogue and '
+                                            'the waits of one wave per SIMD'},
                            'traffic': traffic['bytes'] if traffic else None, 'traffic_source': traffic['source'] if traffic else None,
                            'algorithmic_bytes_per_launch': 4 * (O + 2 * A + 2) * kern[dom]['rows_per_launch'],
                            'avg_launch_ms': kern[dom]['avg_ms'], 'kernels': kern,

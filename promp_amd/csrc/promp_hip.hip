@@ -456,8 +456,8 @@ int enqueue_obs_range(promp_ctx* c, StepData& S, hipStream_t st) {
     HIPCHECK(hipMemsetAsync(S.obs_absmax, 0, sizeof(unsigned) * c->d.n_tasks, st));
     ObsRangeArgs r;
     r.obs = S.obs; r.task_row_offsets = S.task_row_offsets; r.absmax = S.obs_absmax; r.O = c->d.obs_dim;
-    const int slices = (c->n_cus * 4 + c->d.n_tasks - 1) / c->d.n_tasks;
-    PROMP_LAUNCH(k_obs_range, dim3(slices < 1 ? 1 : slices > 64 ? 64 : slices, c->d.n_tasks), 256, 0, st, r);
+    const int slices = (c->n_cus * 2 + c->d.n_tasks - 1) / c->d.n_tasks;
+    PROMP_LAUNCH(k_obs_range, dim3(slices < 1 ? 1 : slices > 32 ? 32 : slices, c->d.n_tasks), 256, 16, st, r);
     HIPCHECK(hipGetLastError());
     S.obs_range_valid = true;
     return 0;
@@ -524,7 +524,7 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
             VecAbsmaxArgs va;
             va.src = c->vbuf; va.stride = c->NP; va.n = c->NP; va.out = c->vdir_absmax;
             va.n_w1 = c->d.obs_dim * c->d.hidden1; va.obs_absmax = a.obs_absmax;
-            PROMP_LAUNCH(k_vec_absmax, dim3(c->d.n_tasks), 256, 16, c->stream, va);
+            PROMP_LAUNCH(k_vec_absmax, dim3(c->d.n_tasks), 1024, 64, c->stream, va);
             a.vdir_absmax = (const float*)c->vdir_absmax;
             pa.src = c->vbuf; pa.src_stride = c->NP; pa.dst = c->wb_vplanes; pa.vec_absmax = a.vdir_absmax;
             PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, c->d.n_tasks), 256, 0, c->stream, pa);

@@ -6,13 +6,14 @@
 // Arithmetic follows oracle/promp.py (which restates meta_algos/pro_mp.py:59-155, meta_algos/base.py:192-215,
 // policies/networks/mlp.py:65-119, policies/distributions/diagonal_gaussian.py:16-109 of the reference).
 //
-// Design.  FP32 is a vector-rate format on gfx950 (v_mfma_f32_16x16x4_f32 = 64 FLOP / clock / SIMD); the BF16 matrix pipe is
-// sixteen times faster.  Every GEMM of this kernel therefore runs on the BF16 pipe in float32-EQUIVALENT arithmetic: both
-// operands are split into three BF16 terms (x = x0 + x1 + x2 up to 2^-24 |x|), the six largest of the nine cross products
-// are accumulated in float32 -- the dropped ones are below 2^-24 relative, the result is at least as accurate as the FP32
-// fma chain (measured: 5.6e-8 against 1.5e-7 of the result's max-norm, profiles/r03_tr16_wgrad_probe.txt).  Six BF16 MFMAs
-// of K = 32 replace eight FP32 MFMAs of K = 4 at half the issue time each: 2.7x less matrix-pipe time, and the BF16
-// instructions leave the vector ALU free for the splits and the tanh / distribution epilogues.
+// Design.  FP32 is a vector-rate format on gfx950 (v_mfma_f32_16x16x4_f32 = 64 FLOP / clock / SIMD); the 16-bit matrix pipe is
+// sixteen times faster.  Every GEMM of this kernel therefore runs on that pipe in float32-EQUIVALENT arithmetic: both operands
+// are split into terms of a 16-bit format and the significant cross products are accumulated in float32.  Since round 6: TWO FP16
+// terms, THREE products (hi.hi + hi.lo + lo.hi; promp_device.h: split_pair) -- as accurate as the FP32 fma
+// chain on the network's shapes as long as every split operand sits near 1, which the kernel arranges with exact powers of two
+// that follow the data (obs_shift, pass_cotangent_scale below).  Rounds 3-5 (-DPROMP_SPLIT_TERMS=3): three BF16 terms, six of the
+// nine products, no range to mind, twice the matrix instructions and 2.7 times the split instructions.  (Comments below that say
+// "BF16 planes" describe the layout, which is the same for both: 16-bit halves in 32-bit words.)
 //
 //  * Register chain (as k_chain_hvp): a wave owns 16-sample tiles and keeps its activations TRANSPOSED, samples along n.
 //    Lane (i16 = sample, kk) receives units 16 c + 4 kk + r of a layer as its four D registers; the eight k-slots a lane
@@ -964,11 +965,25 @@ __global__ void __launch_bounds__(256) k_obs_range(ObsRangeArgs a) {
     const long long n = (r1 - r0) * a.O, per = (n + gridDim.x - 1) / gridDim.x;
     const long long b = per * blockIdx.x, e = b + per < n ? b + per : n;
     const float* src = a.obs + r0 * a.O;
-    unsigned m = 0;
-    for (long long i = b + tid; i < e; i += 256) {
-        const unsigned u = __builtin_bit_cast(unsigned, src[i]) & 0x7FFFFFFFu;
-        m = u > m ? u : m;
+    // four loads in flight per thread and trip; ONE atomic per workgroup (the waves' maxima meet in LDS first: a task's address
+    // takes gridDim.x atomics, not four times that -- they serialise in L2 at a few hundred nanoseconds each)
+    unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    long long i = b + tid;
+    for (; i + 768 < e; i += 1024) {
+        const unsigned u0 = __builtin_bit_cast(unsigned, src[i]) & 0x7FFFFFFFu, u1 = __builtin_bit_cast(unsigned, src[i + 256]) & 0x7FFFFFFFu;
+        const unsigned u2 = __builtin_bit_cast(unsigned, src[i + 512]) & 0x7FFFFFFFu, u3 = __builtin_bit_cast(unsigned, src[i + 768]) & 0x7FFFFFFFu;
+        m0 = u0 > m0 ? u0 : m0;
+        m1 = u1 > m1 ? u1 : m1;
+        m2 = u2 > m2 ? u2 : m2;
+        m3 = u3 > m3 ? u3 : m3;
     }
+    for (; i < e; i += 256) {
+        const unsigned u = __builtin_bit_cast(unsigned, src[i]) & 0x7FFFFFFFu;
+        m0 = u > m0 ? u : m0;
+    }
+    unsigned m = m0 > m1 ? m0 : m1;
+    m = m > m2 ? m : m2;
+    m = m > m3 ? m : m3;
     float mf = __builtin_bit_cast(float, m);      // (compared as integers below: the bit patterns of non-negative floats are ordered)
 #pragma unroll
     for (int x = 32; x >= 1; x >>= 1) {
@@ -976,5 +991,13 @@ __global__ void __launch_bounds__(256) k_obs_range(ObsRangeArgs a) {
         m = o > m ? o : m;
         mf = __builtin_bit_cast(float, m);
     }
-    if ((tid & 63) == 0 && m != 0) atomic_max_agent(a.absmax + task, m);
+    PROMP_SMEM_DECL;
+    unsigned* sm = (unsigned*)PROMP_SMEM_PTR;
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned t = sm[0] > sm[1] ? sm[0] : sm[1], u = sm[2] > sm[3] ? sm[2] : sm[3];
+        t = t > u ? t : u;
+        if (t != 0) atomic_max_agent(a.absmax + task, t);
+    }
 }

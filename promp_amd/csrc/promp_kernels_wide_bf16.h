@@ -1,4 +1,6 @@
-// promp_kernels_wide_bf16.h -- the policy passes for two hidden layers of 128 units on the BF16 matrix pipe
+// promp_kernels_wide_bf16.h -- the policy passes for two hidden layers of 128 units on the 16-bit matrix pipe (round 5: three BF16
+// terms, six products; round 6: two FP16 terms, three products with data-following scales -- promp_device.h: split_pair,
+// DESIGN.md sections 5.1, 5.5; "BF16" in the comments below names round 5's format, the layouts are the same)
 // (BASELINE config 4: AntRandDirec, obs 111, act 8, 2x128 tanh MLP; reference policies/networks/mlp.py:65-119,
 // envs/mujoco_envs/ant_rand_direc.py:52-57; arithmetic: oracle/promp.py = meta_algos/pro_mp.py:59-155, base.py:192-215).
 //
@@ -479,18 +481,31 @@ struct VecAbsmaxArgs {
     const float* obs_absmax;     // [tasks] or NULL: the hidden_0 block is weighed by the inverse of the observations' scale
     unsigned* out;               // (chain_stage_nets: the blocks are compared by what they contribute to a tangent)
 };
-__global__ void __launch_bounds__(256) k_vec_absmax(VecAbsmaxArgs a) {
+__global__ void __launch_bounds__(1024) k_vec_absmax(VecAbsmaxArgs a) {
     const int task = blockIdx.x, tid = threadIdx.x;
     const float* src = a.src + (long long)task * a.stride;
     const float w1w = pow2f(obs_shift(a.obs_absmax, task));
-    float m = 0.f;
-    for (int i = tid; i < a.n; i += 256) m = fmaxf(m, (i < a.n_w1 ? w1w : 1.f) * fabsf(src[i]));
-    m = wave_absmax_f32(m);
+    // four loads in flight per thread and trip (one workgroup of 16 waves per task: the vector is ~30 k floats)
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    int i = tid;
+    for (; i + 3072 < a.n; i += 4096) {
+        const float x0 = src[i], x1 = src[i + 1024], x2 = src[i + 2048], x3 = src[i + 3072];
+        m0 = fmaxf(m0, (i < a.n_w1 ? w1w : 1.f) * fabsf(x0));
+        m1 = fmaxf(m1, (i + 1024 < a.n_w1 ? w1w : 1.f) * fabsf(x1));
+        m2 = fmaxf(m2, (i + 2048 < a.n_w1 ? w1w : 1.f) * fabsf(x2));
+        m3 = fmaxf(m3, (i + 3072 < a.n_w1 ? w1w : 1.f) * fabsf(x3));
+    }
+    for (; i < a.n; i += 1024) m0 = fmaxf(m0, (i < a.n_w1 ? w1w : 1.f) * fabsf(src[i]));
+    const float m = wave_absmax_f32(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
     PROMP_SMEM_DECL;
     float* sm = (float*)PROMP_SMEM_PTR;
     if ((tid & 63) == 0) sm[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0) a.out[task] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t = fmaxf(t, sm[w]);
+        a.out[task] = __builtin_bit_cast(unsigned, t);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
