@@ -31,6 +31,9 @@
 #pragma once
 #include "promp_device.h"
 
+#define PROMP_PASS_TPLANE 512    // words per plane of a [16 samples][64 units] tile of 16-bit halves
+#define PROMP_PASS_XPLANE 256    // [16][32 observation slots]
+#define PROMP_PASS_DPLANE 160    // [16][16 action slots], rows of 8 words, 32 words of padding between samples 7 and 8
 #define PROMP_PARTIAL_EXTRA 4   // loss, kl, 2 spare
 #define PROMP_CH_TS 68          // row stride of a [16 samples][<= 64 units] transpose tile
 #define PROMP_CH_DS 20          // row stride of the [16 samples][16 action slots] cotangent tile
@@ -127,7 +130,7 @@ struct ChainLds {
     int bplanes, bplane_stride;              // (bwdp) the same kernels' planes in the orientation of the backward product
     int flag;                                // one int: "this workgroup arrived last"
     int wave0, wave_stride, tb0, tb1, db0, db1;
-    int tp, tah;                             // (bwdp) plane tiles of the hidden_1 kernel gradient, over tb0 / tb1
+    int tp, tq, tah, xt, dm0, dm1;           // (bwdp) the cached instance's plane tiles (chain_layout)
     int vmx;                                 // one float per wave: the largest |direction entry| its staging share holds (FP16 split)
     int total;
 };
@@ -150,8 +153,10 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
         L.w1 = n;  n += NC1 * 512;                  // [c][t4][lane][4]: W1[4 (4 t4 + r) + kk][16 c + i16], obs padded to 32
         L.w2 = n;  n += NC2 * NC1 * PROMP_CH_BLK;   // [c2][c1][kk][i16][r]: W2[16 c1 + 4 kk + r][16 c2 + i16]
     }
-    L.w3 = n;  n += bwdp ? NC2 * 128 : NC2 * 256;   // [c][lane][r]: W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
-                                                    // bwdp: [c][kk][action 0..7][r]: W3[16 c + 4 kk + r][action]
+    L.w3 = n;  n += bwdp ? PROMP_NT * (NC2 / 2) * 256 : NC2 * 256;
+                                                    // [c][lane][r]: W3[16 c + 4 kk + r][a(i16)], a(4 ko + ro) = 2 ko + ro (ro < 2)
+                                                    // bwdp (round 6): the split's planes [term][P][lane] x 16 B, k_pass's output fragments:
+                                                    // W3[16 (2P + e / 4) + 4 kk + e % 4][action of row i16]
     L.w3b = n; n += NC2 * 128;                      // [c][lane][ro]: W3[16 c + i16][2 kk + ro]
     L.b1 = n;  n += 16 * NC1;
     L.b2 = n;  n += 16 * NC2;
@@ -159,10 +164,10 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
     L.dist = n; n += 48;
     L.net_stride = n;
     o += (hvp ? 2 : 1) * n;
-    if (bwdp) {                   // the direction's hidden_0 fragments alone: (network block 0) + L.w1 + net_stride lands here
-        L.w1 = (o - 4) - n;
+    if (bwdp) {                   // the direction's hidden_0 kernel alone: (network block 0) + L.w1 + net_stride lands here.  Round 6:
+        L.w1 = (o - 4) - n;       // as the split's planes [term][c][lane] x 16 B, k_pass's layer-1 fragments: W1[obs 8 kk + e][16 c + i16]
         L.w2 = 0;
-        o += NC1 * 512;
+        o += PROMP_NT * NC1 * 256;
     }
     // BF16 planes of the hidden_1 kernel for v_mfma_f32_16x16x32_bf16: [term 3][c2][pair of input blocks][lane] x 8 bf16 (16 B):
     // lane (i16, kk) of chunk (c2, P): W2[16 (2P) + 4 kk + r][16 c2 + i16], r = 0..3, then W2[16 (2P + 1) + 4 kk + r][.]
@@ -178,15 +183,23 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
     o += bwdp ? 2 * L.bplane_stride : 0;
     L.wave0 = o;
     int q = 0;
-    L.tb0 = q; q += 16 * PROMP_CH_TS;
-    L.tb1 = q; q += 16 * PROMP_CH_TS;
-    if (bwdp) {                   // the hidden_1 kernel gradient's plane tiles alias the float32 transpose tiles (the phases of a
-        L.tp = 0;                 // tile are sequential): 3 planes of the B operand + 3 half planes of the A operand
-        L.tah = PROMP_NT * PROMP_CH_TPL;
-        if (q < L.tah + PROMP_NT * PROMP_CH_APL) q = L.tah + PROMP_NT * PROMP_CH_APL;
+    if (bwdp) {
+        // round 6: every product of the cached instance runs on the split's planes (k_pass's tiles): two full plane tiles (tangent /
+        // primal hidden_1 activations for the output-kernel gradient, then the cotangents dZ2 / qZ2, then qZ1), the half tile of
+        // the hidden_1 kernel gradient's A operand, the observations, the two cotangents of the mean.  No float32 tile is left.
+        L.tb0 = L.tb1 = L.db0 = L.db1 = 0;
+        L.tp = q;  q += PROMP_NT * PROMP_CH_TPL;
+        L.tq = q;  q += PROMP_NT * PROMP_CH_TPL;
+        L.tah = q; q += PROMP_NT * PROMP_CH_APL;
+        L.xt = q;  q += PROMP_NT * PROMP_PASS_XPLANE;
+        L.dm0 = q; q += PROMP_NT * PROMP_PASS_DPLANE;
+        L.dm1 = q; q += PROMP_NT * PROMP_PASS_DPLANE;
+    } else {
+        L.tb0 = q; q += 16 * PROMP_CH_TS;
+        L.tb1 = q; q += 16 * PROMP_CH_TS;
+        L.db0 = q; q += 16 * PROMP_CH_DS;
+        L.db1 = q; q += hvp ? 16 * PROMP_CH_DS : 0;
     }
-    L.db0 = q; q += 16 * PROMP_CH_DS;
-    L.db1 = q; q += hvp ? 16 * PROMP_CH_DS : 0;
     L.wave_stride = q;
     o += nwaves * q;
     {   // end-of-segment: one slab of [NP + 2] floats per wave, from offset 4 (aliases everything else)
@@ -233,6 +246,31 @@ PROMP_DEV void sts2(float* p, f32x2 v) { *(f32x2*)p = v; }
 // samples of one chunk column: ds_write_b64, banks mod 32) the low four bits are a bijection of s; for the transpose read of a
 // 32-unit block (32 lanes = 4 samples x 8 chunks, banks mod 64) the low five bits are a bijection of (s & 3, q & 7).
 PROMP_CX int pass_slot(int s, int q) { return 32 * (4 * (q >> 3) + (q & 3)) + 16 * ((q >> 2) & 1) + 4 * (s & 3) + ((s >> 2) ^ (q & 3)); }
+
+// per-lane addresses (in words) of the transposed tiles (k_pass; k_chain_hvp's cached instance)
+struct PassTileAddr {
+    int wr, xw0, xw1, rd32_0, rd32_1, rd16_0, rd16_1, dmw, dr0, dr1;
+};
+PROMP_DEV PassTileAddr pass_tile_addr(int lane) {
+    PassTileAddr T;
+    const int i16 = lane & 15, kk = lane >> 4, p16 = lane & 15, g32 = (lane >> 4) & 1, kh = lane >> 5;
+    // where this lane writes (chain side: sample i16, chunk 4 c + kk) ...
+    T.wr = 2 * pass_slot(i16, kk);
+    T.xw0 = 2 * pass_slot(i16, 2 * kk);
+    T.xw1 = 2 * pass_slot(i16, 2 * kk + 1);
+    // ... and reads: 32-unit blocks (v_mfma_f32_32x32x16 operands): samples 8 kh + 4 t + p16 / 4, chunk 8 b + 4 g32 + p16 % 4
+    T.rd32_0 = 2 * pass_slot(8 * kh + (p16 >> 2), 4 * g32 + (p16 & 3));
+    T.rd32_1 = 2 * pass_slot(8 * kh + 4 + (p16 >> 2), 4 * g32 + (p16 & 3));
+    // 16-unit blocks (A operand of the output-kernel gradient on v_mfma_f32_16x16x32): samples 8 (kk & 1) + 4 t + p16 / 4
+    // (the k-slots of the lane groups kk >= 2 meet zeros on the B side; they read the same finite data as kk - 2)
+    T.rd16_0 = 2 * pass_slot(8 * (kk & 1) + (p16 >> 2), p16 & 3);
+    T.rd16_1 = 2 * pass_slot(8 * (kk & 1) + 4 + (p16 >> 2), p16 & 3);
+    // cotangent-of-the-mean tile [16 samples][16 action slots]: rows of 8 words, 32 words of padding after sample 7
+    T.dmw = 8 * i16 + 32 * (i16 >> 3) + kk;
+    T.dr0 = (kk < 2) ? 8 * (8 * kk + (p16 >> 2)) + 32 * kk + 2 * (p16 & 3) : 4;     // kk >= 2: a chunk of zeros (actions 8..11 of sample 0)
+    T.dr1 = (kk < 2) ? 8 * (8 * kk + 4 + (p16 >> 2)) + 32 * kk + 2 * (p16 & 3) : 4;
+    return T;
+}
 
 PROMP_DEV void sts_w2(float* p, unsigned a, unsigned b) {
     u32x2 v;
@@ -346,11 +384,18 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
     // stores the kind's last block a second time (same values, same addresses): no branch anywhere (loads inside a block-kind
     // branch make the compiler wait, at the head of the next branch, for loads it believes may still target the registers it
     // reuses; a guarded store invites it to sink the block's loads into the guard).
+    // (BWDP, round 6: the direction's hidden_0 kernel and both output kernels as the split's planes in k_pass's fragment order --
+    //  NC1 blocks of eight observation slots per lane, NC2 / 2 blocks of eight units per lane -- instead of float32 fragments)
+    constexpr int NB1P = BWDP ? NC1 : 0, NB3P = BWDP ? NC2 / 2 : 0;
+    constexpr int IT1P = (NB1P + NW - 1) / NW, IT3P = (NB3P + NW - 1) / NW;
+    const int aro = i16 & 3, aact = 2 * (i16 >> 2) + aro;        // k_pass's output rows: action 2 (m / 4) + m % 4 for m % 4 < 2
+    const bool aok = aro < 2 && aact < A;
     float x1[2][IT1][4], x2[2][IT2][8], x3[2][IT3][4], y3[2][IT3][2], x4[2][IT4 ? IT4 : 1][8], z[2][IS];
+    float x1p[IT1P ? IT1P : 1][8], x3p[2][IT3P ? IT3P : 1][8];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const float* src = n ? src1 : src0;
-        if (!BWDP || n == 1) {
+        if (!BWDP) {
 #pragma unroll
             for (int it = 0; it < IT1; ++it) {
                 const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, c = b >> 1, t4 = b & 1;
@@ -359,6 +404,25 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
                     const int o = 4 * (4 * t4 + r) + kk;
                     x1[n][it][r] = src[(o < O ? o : O - 1) * H1 + 16 * c + i16];
                 }
+            }
+        } else if (n == 1) {
+#pragma unroll
+            for (int it = 0; it < IT1P; ++it) {
+                const int bj = w + it * NW, b = bj < NB1P ? bj : NB1P - 1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int o = 8 * kk + e;
+                    x1p[it][e] = src[(o < O ? o : 0) * H1 + 16 * b + i16];
+                }
+            }
+        }
+        if (BWDP) {
+#pragma unroll
+            for (int it = 0; it < IT3P; ++it) {
+                const int bj = w + it * NW, P = bj < NB3P ? bj : NB3P - 1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    x3p[n][it][e] = src[oW3 + (16 * (2 * P + (e >> 2)) + 4 * kk + (e & 3)) * A + (aok ? aact : 0)];
             }
         }
 #pragma unroll
@@ -376,8 +440,10 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
 #pragma unroll
         for (int it = 0; it < IT3; ++it) {
             const int bj = w + it * NW, c = bj < NB3 ? bj : NB3 - 1;
+            if (!BWDP) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x3[n][it][r] = src[oW3 + (16 * c + 4 * kk + r) * A + (ok3 ? aa3 : 0)];
+                for (int r = 0; r < 4; ++r) x3[n][it][r] = src[oW3 + (16 * c + 4 * kk + r) * A + (ok3 ? aa3 : 0)];
+            }
 #pragma unroll
             for (int ro = 0; ro < 2; ++ro) {
                 const int aa = 2 * kk + ro;
@@ -398,17 +464,25 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
     if (PROMP_NT == 2) {
         float m = 0.f;
 #pragma unroll
-        for (int it = 0; it < IT1; ++it)
+        for (int it = 0; it < (BWDP ? 0 : IT1); ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, w1w * fabsf(x1[1][it][r]));
+#pragma unroll
+        for (int it = 0; it < IT1P; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, w1w * fabsf(x1p[it][e]));
 #pragma unroll
         for (int it = 0; it < IT2; ++it)
 #pragma unroll
             for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x2[1][it][e]));
 #pragma unroll
-        for (int it = 0; it < IT3; ++it)
+        for (int it = 0; it < (BWDP ? 0 : IT3); ++it)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(x3[1][it][r]));
+#pragma unroll
+        for (int it = 0; it < IT3P; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x3p[1][it][e]));
 #pragma unroll
         for (int it = 0; it < IS; ++it) m = fmaxf(m, fabsf(z[1][it]));
         m = wave_absmax_f32(m);
@@ -430,7 +504,7 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
     for (int n = 0; n < 2; ++n) {
         float* nb = net0 + n * L.net_stride;
         const float sg = n ? -vs : 1.f;          // the direction is staged negated (and scaled: FP16 split)
-        if (!BWDP || n == 1) {
+        if (!BWDP) {
 #pragma unroll
             for (int it = 0; it < IT1; ++it) {
                 const int bj = w + it * NW, b = bj < NB1 ? bj : NB1 - 1, t4 = b & 1;
@@ -438,6 +512,37 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = x1[n][it][r] * (4 * (4 * t4 + r) + kk < O ? sg : 0.f);
                 sts4(nb + L.w1 + b * 256 + lane * 4, v);
+            }
+        } else if (n == 1) {      // the direction's hidden_0 planes (they also take the inverse of the observations' scale, w1w)
+#pragma unroll
+            for (int it = 0; it < IT1P; ++it) {
+                const int bj = w + it * NW, b = bj < NB1P ? bj : NB1P - 1;
+                f32x4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = x1p[it][e] * (8 * kk + e < O ? sg * w1w : 0.f);
+                    hi[e] = x1p[it][4 + e] * (8 * kk + 4 + e < O ? sg * w1w : 0.f);
+                }
+                u32x4 t[PROMP_NT];
+                pass_split8(lo, hi, t);
+#pragma unroll
+                for (int sp = 0; sp < PROMP_NT; ++sp) sts_w4(nb + L.w1 + (sp * NB1P + b) * 256 + lane * 4, t[sp]);
+            }
+        }
+        if (BWDP) {               // both output kernels' planes
+#pragma unroll
+            for (int it = 0; it < IT3P; ++it) {
+                const int bj = w + it * NW, P = bj < NB3P ? bj : NB3P - 1;
+                f32x4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = x3p[n][it][e] * (aok ? sg : 0.f);
+                    hi[e] = x3p[n][it][4 + e] * (aok ? sg : 0.f);
+                }
+                u32x4 t[PROMP_NT];
+                pass_split8(lo, hi, t);
+#pragma unroll
+                for (int sp = 0; sp < PROMP_NT; ++sp) sts_w4(nb + L.w3 + (sp * NB3P + P) * 256 + lane * 4, t[sp]);
             }
         }
 #pragma unroll
@@ -478,14 +583,15 @@ PROMP_DEV float chain_stage_nets(float* sm, float* vmx, const float* src0, const
 #pragma unroll
         for (int it = 0; it < IT3; ++it) {
             const int cj = w + it * NW, c = cj < NB3 ? cj : NB3 - 1;
-            f32x4 v;
             f32x2 u;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = x3[n][it][r] * (ok3 ? sg : 0.f);
             u[0] = y3[n][it][0] * (2 * kk < A ? sg : 0.f);
             u[1] = y3[n][it][1] * (2 * kk + 1 < A ? sg : 0.f);
-            if (BWDP) sts4(nb + L.w3 + c * 128 + (kk * 8 + (i16 & 7)) * 4, v);
-            else sts4(nb + L.w3 + c * 256 + lane * 4, v);
+            if (!BWDP) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = x3[n][it][r] * (ok3 ? sg : 0.f);
+                sts4(nb + L.w3 + c * 256 + lane * 4, v);
+            }
             sts2(nb + L.w3b + c * 128 + lane * 2, u);
         }
     }
@@ -542,6 +648,18 @@ PROMP_DEV void chain_load_xT(float (&xT)[KS], const float* obs, long long row0, 
         xT[t] = src[ok ? o : 0] * (ok ? 1.f : 0.f);
     }
 }
+// this lane's eight observation entries of its sample: obs[row i16][8 kk .. 8 kk + 7] times xs (the FP16 split's observation
+// scale), zeros outside the tile / the observation (k_pass: pass_load_x)
+PROMP_DEV void chain_load_x8(float (&xr)[8], const float* obs, long long row0, int nvalid, int O, int i16, int kk, float xs) {
+    const bool rv = i16 < nvalid;
+    const float* src = obs + (row0 + (rv ? i16 : 0)) * O;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 8 * kk + e;
+        const bool ok = rv && o < O;
+        xr[e] = src[ok ? o : 0] * (ok ? xs : 0.f);
+    }
+}
 template <int NOB>
 PROMP_DEV void chain_load_xN(float (&xN)[NOB][4], const float* obs, long long row0, int nvalid, int O, int i16, int kk) {
 #pragma unroll
@@ -570,10 +688,11 @@ PROMP_DEV f32x4 tanh4(f32x4 z) {
 // the function returns whether any wave of the workgroup voted.
 template <int NC1, int NC2, int NOB, int NW, bool W32 = false>
 PROMP_DEV bool chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC1][NC2], const f32x16 (&aw2w)[NC1 / 2][NC2 / 2],
-                                       const f32x4 (&aw1)[NOB][NC1], const f32x4 (&aw3)[NC2], const float (&gb1)[NC1],
+                                       const f32x4 (&aw1)[NOB][NC1], const f32x16 (&aw1w)[NC1 / 2], const f32x4 (&gb1v)[NC1],
+                                       const f32x4 (&aw3)[NC2], const float (&gb1)[NC1],
                                        const float (&gb2)[NC2], const f32x4 (&gb2v)[NC2], float gs0,
                                        float gs1, float gb30, float gb31, float loss, float klsum, int O, int A, int tid, float us = 1.f,
-                                       int bad = 0) {
+                                       int bad = 0, float us1 = 1.f) {
     constexpr int H1 = 16 * NC1, H2 = 16 * NC2, NT = 64 * NW;
     // (an opaque copy of the thread index, as in chain_stage_nets: lane-constant indices that live from the kernel's first lines to
     //  this point are spilled across the tile loop, and each reload here is a round trip to scratch memory in the kernel's tail)
@@ -602,23 +721,36 @@ PROMP_DEV bool chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mine[oW2 + (16 * i + 4 * kk + r) * H2 + 16 * j + i16] = aw2[i][j][r] * us;
         }
+        if (W32) {                // (round 6) the hidden_0 kernel gradient in the 32 x 32 result layout: rows = observation slots
+            const int j32 = lane & 31, kh = lane >> 5;
 #pragma unroll
-        for (int i = 0; i < NOB; ++i)
+            for (int bj = 0; bj < NC1 / 2; ++bj)
 #pragma unroll
-            for (int j = 0; j < NC1; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + 4 * kk + r;
-                    if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r] * us;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row < O) mine[row * H1 + 32 * bj + j32] = aw1w[bj][r] * us1;
                 }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NOB; ++i)
+#pragma unroll
+                for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * kk + r;
+                        if (row < O) mine[row * H1 + 16 * j + i16] = aw1[i][j][r] * us;
+                    }
+        }
 #pragma unroll
         for (int j = 0; j < NC2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (i16 < A) mine[oW3 + (16 * j + 4 * kk + r) * A + i16] = aw3[j][r] * us;
         if (kk == 0) {
+            if (!W32) {
 #pragma unroll
-            for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j] * us;
+                for (int j = 0; j < NC1; ++j) mine[ob1 + 16 * j + i16] = gb1[j] * us;
+            }
             if (!W32) {
 #pragma unroll
                 for (int j = 0; j < NC2; ++j) mine[ob2 + 16 * j + i16] = gb2[j] * us;
@@ -629,6 +761,10 @@ PROMP_DEV bool chain_reduce_to_partial(float* S, float* P, const f32x4 (&aw2)[NC
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[ob2 + 16 * j + 4 * kk + r] = gb2v[j][r] * us;
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[ob1 + 16 * j + 4 * kk + r] = gb1v[j][r] * us;
         }
         if (i16 == 0) {           // lane (0, kk) holds the sums of actions 2 kk, 2 kk + 1
             if (2 * kk < A) {
@@ -858,10 +994,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     const float* W2b = net + L.w2 + (i16 >> 2) * PROMP_CH_ROW + (i16 & 3) + 16 * kk;
     // output kernel fragments: by action slot (one per lane), or -- CACHED -- by action: lanes of a padding slot read a valid
     // fragment and multiply it by zero
-    constexpr int W3C = CACHED ? 128 : 256;
-    const float w3m = (!CACHED || (i16 & 3) < 2) ? 1.f : 0.f;
-    const float* W3l = net + L.w3 + (CACHED ? (kk * 8 + 2 * (i16 >> 2) + (i16 & 1)) * 4 : lane * 4);
+    constexpr int W3C = 256;
+    const float* W3l = net + L.w3 + lane * 4;        // (!CACHED: float32 fragments by action slot)
     const float* W3b = net + L.w3b + lane * 2;
+    // CACHED (round 6): the output kernels and the direction's hidden_0 kernel as the split's planes in k_pass's fragment order
+    const u32x4* W3F = (const u32x4*)(net + L.w3) + lane;
+    const u32x4* V3F = (const u32x4*)(vnet + L.w3) + lane;
+    const u32x4* V1F = (const u32x4*)(vnet + L.w1) + lane;
     const float *B1l = net + L.b1 + 4 * kk, *B2l = net + L.b2 + 4 * kk, *B3l = net + L.b3 + 2 * kk;
     float* TB0w = TB0 + i16 * TS + 4 * kk;
     float* TB1w = TB1 + i16 * TS + 4 * kk;
@@ -879,6 +1018,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     // swizzled tiles over TB0 / TB1 and come back through the transpose read (pass_slot; word addresses of this lane)
     constexpr int NB1 = NC1 / 2, NB2 = NC2 / 2, TPL = PROMP_CH_TPL, APL = PROMP_CH_APL;
     float *TBP = wreg + L.tp, *TAH = wreg + L.tah;
+    // ... and (round 6) every other product of the cached instance too: k_pass's tiles and lane addresses
+    constexpr int XPL = PROMP_PASS_XPLANE, DPL = PROMP_PASS_DPLANE, NP1 = NC1 / 2, NP2 = NC2 / 2;
+    float *TQ = wreg + L.tq, *XT = wreg + L.xt, *DM0 = wreg + L.dm0, *DM1 = wreg + L.dm1;
+    const PassTileAddr T = pass_tile_addr(lane);
     const int twr = 2 * pass_slot(i16, kk);
     const int trd0 = 2 * pass_slot(8 * (lane >> 5) + (i16 >> 2), 4 * (kk & 1) + (i16 & 3));
     const int trd1 = 2 * pass_slot(8 * (lane >> 5) + 4 + (i16 >> 2), 4 * (kk & 1) + (i16 & 3));
@@ -900,6 +1043,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         const ChainDistRaw draw = chain_dist_load(th, v, oS, A, tid);
         const int tend = seg.tile0 + seg.ntiles;
         float xT[KS];
+        float xr[8];              // CACHED: the tile's observations as k_pass reads them (eight consecutive slots of the lane's sample)
+        const int sx = obs_shift(a.obs_absmax, task);
+        const float xs = pow2f(-sx), w1w = pow2f(sx);
         // CACHED: this lane's share of a tile's cache block (sample i16, units 16 c + 4 kk + r; actions 2 kk, 2 kk + 1)
         f32x4 ch1[NC1], ch2[NC2];
         f32x2 cmu;
@@ -912,11 +1058,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         const int vt = CHAIN_V_TARGET - (attempt >= 2 ? CHAIN_V_RETRY : 0), ct = attempt ? CHAIN_CT_REDO - (attempt - 1) * CHAIN_CT_RETRY : CHAIN_CT_TARGET;
         // (L is the layout for a parameter count of 0: the slabs of the real one may end behind L.vmx; the host sized LDS for both)
         const int slabs_end = 4 + NW * ((NP + 2 + 3) & ~3), vmx_off = slabs_end > L.vmx ? slabs_end : L.vmx;
-        const float vs = chain_stage_nets<NC1, NC2, NW, CACHED>(sm, sm + vmx_off, th, v, O, A, tid, vt, pow2f(obs_shift(a.obs_absmax, task)), [&]() {
+        const float vs = chain_stage_nets<NC1, NC2, NW, CACHED>(sm, sm + vmx_off, th, v, O, A, tid, vt, w1w, [&]() {
             {
                 const int t = seg.tile0 + w;
                 const int nv = (t < tend) ? (tnrows - 16 * t < 16 ? tnrows - 16 * t : 16) : 0;
-                chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
+                if (CACHED) chain_load_x8(xr, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk, xs);
+                else chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (t < tend ? 16 * t : 0), nv, O, i16, kk);
             }
             if (CACHED) {
                 const int t = seg.tile0 + w;
@@ -933,7 +1080,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         CH_STAMP(6);
         // action slots >= 8 of the cotangent tiles must read as zero (slots < 8 and the transpose tiles are rewritten by
         // every tile before they are read); the end-of-segment slabs alias them, so once per segment
-        for (int e = lane; e < 2 * 16 * DS; e += 64) DB0[e] = 0.f;
+        if (CACHED) {
+            for (int e = lane; e < 2 * PROMP_NT * DPL; e += 64) DM0[e] = 0.f;       // (DM1 follows DM0)
+        } else {
+            for (int e = lane; e < 2 * 16 * DS; e += 64) DB0[e] = 0.f;
+        }
         CH_STAMP(7);
         __syncthreads();
         CH_STAMP(1);
@@ -958,9 +1109,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         for (int j = 0; j < NC1; ++j) ob1acc[j] = 0.f;
 #pragma unroll
         for (int j = 0; j < NC2; ++j) ob2acc[j] = 0.f;
-        // CACHED: the hidden_1 kernel gradient in the 32 x 32 result layout, its bias gradient in the chain layout
-        f32x16 aw2w[NB1][NB2];
-        f32x4 gb2v[NC2];
+        // CACHED: the hidden_1 and hidden_0 kernel gradients in the 32 x 32 result layout, their bias gradients in the chain layout
+        f32x16 aw2w[NB1][NB2], aw1w[NB1];
+        f32x4 gb2v[NC2], gb1v[NC1];
+#pragma unroll
+        for (int i = 0; i < NB1; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aw1w[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC1; ++j) gb1v[j] = zero4();
 #pragma unroll
         for (int i = 0; i < NB1; ++i)
 #pragma unroll
@@ -1009,24 +1166,53 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     h1[c] = CACHED ? ch1[c] : lds4(B1l + 16 * c);
                     rh1[c] = lds4(B1l + VO + 16 * c);
                 }
+                if (CACHED) {
+                    // (round 6) on the split pipe, k_pass's layer 1: the observations' planes (kept in their tile for the hidden_0
+                    // kernel gradient at the end of the tile) against the direction's hidden_0 planes, K = 32 observation slots
+                    u32x4 xB[PROMP_NT], v1f[PROMP_NT][NC1];
+                    {
+                        f32x4 lo, hi;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            lo[e] = xr[e];
+                            hi[e] = xr[4 + e];
+                        }
+                        pass_split8(lo, hi, xB);
+                    }
+#pragma unroll
+                    for (int ta = 0; ta < PROMP_NT; ++ta)
+#pragma unroll
+                        for (int c = 0; c < NC1; ++c) v1f[ta][c] = V1F[(ta * NC1 + c) * 64];
+                    wave_fence();         // the previous tile's reads of the observation tile precede these writes
+#pragma unroll
+                    for (int tt = 0; tt < PROMP_NT; ++tt) {
+                        sts_w2(XT + tt * XPL + T.xw0, xB[tt][0], xB[tt][1]);
+                        sts_w2(XT + tt * XPL + T.xw1, xB[tt][2], xB[tt][3]);
+                    }
+#pragma unroll
+                    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
+#pragma unroll
+                        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
+#pragma unroll
+                            for (int c = 0; c < NC1; ++c) rh1[c] = mfma16_sw<PROMP_NT>(v1f[ta][c], xB[tb], rh1[c]);
+                } else {
 #pragma unroll
                 for (int t4 = 0; t4 < NOB; ++t4) {
                     f32x4 wf[NC1], vf[NC1];
 #pragma unroll
                     for (int c = 0; c < NC1; ++c) {
-                        if (!CACHED) wf[c] = lds4(W1l + (2 * c + t4) * 256);
+                        wf[c] = lds4(W1l + (2 * c + t4) * 256);
                         vf[c] = lds4(W1l + VO + (2 * c + t4) * 256);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (4 * t4 + r < KS) {
-                            if (!CACHED) {
 #pragma unroll
-                                for (int c = 0; c < NC1; ++c) h1[c] = mfma16(wf[c][r], xT[4 * t4 + r], h1[c]);
-                            }
+                            for (int c = 0; c < NC1; ++c) h1[c] = mfma16(wf[c][r], xT[4 * t4 + r], h1[c]);
 #pragma unroll
                             for (int c = 0; c < NC1; ++c) rh1[c] = mfma16(vf[c][r], xT[4 * t4 + r], rh1[c]);
                         }
+                }
                 }
 #pragma unroll
                 for (int c = 0; c < NC1; ++c)
@@ -1040,7 +1226,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             {
                 const int tn = t + NW;
                 const int nv = (tn < tend) ? (tnrows - 16 * tn < 16 ? tnrows - 16 * tn : 16) : 0;
-                chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (tn < tend ? 16 * tn : 0), nv, O, i16, kk);
+                if (CACHED) chain_load_x8(xr, a.obs, (long long)trow0 + (tn < tend ? 16 * tn : 0), nv, O, i16, kk, xs);
+                else chain_load_xT<KS>(xT, a.obs, (long long)trow0 + (tn < tend ? 16 * tn : 0), nv, O, i16, kk);
             }
             CH_TSTAMP(1);
             // ---- layer 2 and its tangent:  R'z2 = W2^T R'H1 + (-vW2)^T H1 + (-vb2)
@@ -1074,15 +1261,55 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     }
             }
             CH_TSTAMP(2);
-            wave_fence();         // the previous tile's reads of TB0 / TB1 precede these writes
-#pragma unroll
-            for (int c = 0; c < NC2; ++c) {
-                sts4(TB0w + 16 * c, rh2[c]);
-                sts4(TB1w + 16 * c, h2[c]);
-            }
             // ---- output layer and its tangent:  R'mu = W3^T R'H2 + (-vW3)^T H2 + (-vb3)
             float mu0, mu1, Rmu0, Rmu1;
-            {
+            if (CACHED) {
+                // (round 6) on the split pipe, k_pass's output layer: the planes of R'H2 / H2 feed the two products here (rows of
+                // the product: action slots, the lane's registers 0, 1 = actions 2 kk, 2 kk + 1) and, through their tiles and the
+                // transpose read, the output-kernel gradient below
+                u32x4 rB2[NP2][PROMP_NT], hB2[NP2][PROMP_NT];
+#pragma unroll
+                for (int P = 0; P < NP2; ++P) {
+                    pass_split8(rh2[2 * P], rh2[2 * P + 1], rB2[P]);
+                    pass_split8(h2[2 * P], h2[2 * P + 1], hB2[P]);
+                }
+                wave_fence();         // the previous tile's reads of the plane tiles precede these writes
+#pragma unroll
+                for (int P = 0; P < NP2; ++P) {
+                    pass_store_planes(TBP, TPL, twr + 256 * P, rB2[P]);
+                    pass_store_planes(TQ, TPL, twr + 256 * P, hB2[P]);
+                }
+                f32x4 ra[2] = {zero4(), zero4()};
+                const f32x2 vb = lds2(B3l + VO);
+                ra[0][0] = vb[0];
+                ra[0][1] = vb[1];
+#pragma unroll
+                for (int P = 0; P < NP2; ++P) {
+                    u32x4 w3f[PROMP_NT], v3f[PROMP_NT];
+#pragma unroll
+                    for (int ta = 0; ta < PROMP_NT; ++ta) {
+                        w3f[ta] = W3F[(ta * NP2 + P) * 64];
+                        v3f[ta] = V3F[(ta * NP2 + P) * 64];
+                    }
+#pragma unroll
+                    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
+#pragma unroll
+                        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb) {
+                            ra[0] = mfma16_sw<PROMP_NT>(w3f[ta], rB2[P][tb], ra[0]);
+                            ra[1] = mfma16_sw<PROMP_NT>(v3f[ta], hB2[P][tb], ra[1]);
+                        }
+                }
+                mu0 = cmu[0];
+                mu1 = cmu[1];
+                Rmu0 = ra[0][0] + ra[1][0];
+                Rmu1 = ra[0][1] + ra[1][1];
+            } else {
+                wave_fence();         // the previous tile's reads of TB0 / TB1 precede these writes
+#pragma unroll
+                for (int c = 0; c < NC2; ++c) {
+                    sts4(TB0w + 16 * c, rh2[c]);
+                    sts4(TB1w + 16 * c, h2[c]);
+                }
                 f32x4 m0 = zero4(), m1 = zero4(), ra0 = zero4(), ra1 = zero4(), rb0 = zero4(), rb1 = zero4();
                 const f32x2 bb = lds2(B3l), vb = lds2(B3l + VO);
                 m0[0] = bb[0];
@@ -1094,25 +1321,21 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 for (int c = 0; c < NC2; ++c) {
                     wf[c] = lds4(W3l + c * W3C);
                     vf[c] = lds4(W3l + VO + c * W3C);
-                    if (CACHED) {
-                        wf[c] *= w3m;
-                        vf[c] *= w3m;
-                    }
                 }
 #pragma unroll
                 for (int c = 0; c < NC2; ++c) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        if (!CACHED) m0 = mfma16(wf[c][r], h2[c][r], m0);
+                        m0 = mfma16(wf[c][r], h2[c][r], m0);
                         ra0 = mfma16(wf[c][r], rh2[c][r], ra0);
                         rb0 = mfma16(vf[c][r], h2[c][r], rb0);
-                        if (!CACHED) m1 = mfma16(wf[c][r + 1], h2[c][r + 1], m1);
+                        m1 = mfma16(wf[c][r + 1], h2[c][r + 1], m1);
                         ra1 = mfma16(wf[c][r + 1], rh2[c][r + 1], ra1);
                         rb1 = mfma16(vf[c][r + 1], h2[c][r + 1], rb1);
                     }
                 }
-                mu0 = CACHED ? cmu[0] : m0[0] + m1[0];
-                mu1 = CACHED ? cmu[1] : m0[1] + m1[1];
+                mu0 = m0[0] + m1[0];
+                mu1 = m0[1] + m1[1];
                 Rmu0 = (ra0[0] + ra1[0]) + (rb0[0] + rb1[0]);
                 Rmu1 = (ra0[1] + ra1[1]) + (rb0[1] + rb1[1]);
             }
@@ -1214,22 +1437,53 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 outb31 += qm1;
             }
             CH_TSTAMP(4);
-            {
-                f32x2 dd, qq;
-                dd[0] = d0;  dd[1] = d1;
-                qq[0] = qm0; qq[1] = qm1;
-                sts2(DB0w, dd);
-                sts2(DB1w, qq);
-            }
-            wave_fence();
             // ---- out_W3 += R'H2^T dmu + H2^T qmu
+            if (CACHED) {
+                // (round 6) on the split pipe, k_pass's output-kernel gradient: the cotangents of the mean through two small plane
+                // tiles, R'H2 / H2 back from their tiles through the transpose read (16-unit blocks, K = 16 samples zero-padded to 32)
+                unsigned dw[PROMP_NT], qw[PROMP_NT];
+                split_pair<PROMP_NT>(d0, d1, dw);
+                split_pair<PROMP_NT>(qm0, qm1, qw);
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const float bd = DB0r[t4 * DS], bq = DB1r[t4 * DS];
+                for (int tt = 0; tt < PROMP_NT; ++tt) {
+                    DM0[tt * DPL + T.dmw] = __builtin_bit_cast(float, dw[tt]);
+                    DM1[tt * DPL + T.dmw] = __builtin_bit_cast(float, qw[tt]);
+                }
+                wave_fence();
+                u32x4 bD[PROMP_NT], bQ[PROMP_NT];
+                pass_read_tr(bD, DM0, DPL, T.dr0, T.dr1);
+                pass_read_tr(bQ, DM1, DPL, T.dr0, T.dr1);
 #pragma unroll
-                for (int c = 0; c < NC2; ++c) aw3[c] = mfma16(TB0r[t4 * TS + 16 * c], bd, aw3[c]);
+                for (int c = 0; c < NC2; ++c) {
+                    u32x4 aR[PROMP_NT], aH[PROMP_NT];
+                    const int off = 2 * (128 * (c >> 1) + 16 * (c & 1));
+                    pass_read_tr(aR, TBP, TPL, T.rd16_0 + off, T.rd16_1 + off);
+                    pass_read_tr(aH, TQ, TPL, T.rd16_0 + off, T.rd16_1 + off);
 #pragma unroll
-                for (int c = 0; c < NC2; ++c) aw3[c] = mfma16(TB1r[t4 * TS + 16 * c], bq, aw3[c]);
+                    for (int ta = PROMP_NT - 1; ta >= 0; --ta)
+#pragma unroll
+                        for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb) {
+                            aw3[c] = mfma16_sw<PROMP_NT>(aR[ta], bD[tb], aw3[c]);
+                            aw3[c] = mfma16_sw<PROMP_NT>(aH[ta], bQ[tb], aw3[c]);
+                        }
+                }
+            } else {
+                {
+                    f32x2 dd, qq;
+                    dd[0] = d0;  dd[1] = d1;
+                    qq[0] = qm0; qq[1] = qm1;
+                    sts2(DB0w, dd);
+                    sts2(DB1w, qq);
+                }
+                wave_fence();
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const float bd = DB0r[t4 * DS], bq = DB1r[t4 * DS];
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) aw3[c] = mfma16(TB0r[t4 * TS + 16 * c], bd, aw3[c]);
+#pragma unroll
+                    for (int c = 0; c < NC2; ++c) aw3[c] = mfma16(TB1r[t4 * TS + 16 * c], bq, aw3[c]);
+                }
             }
             CH_TSTAMP(5);
             // ---- dZ2, qZ2 (transposed): ad = W3 dmu^T, aq = W3 qmu^T + (-vW3) dmu^T
@@ -1370,7 +1624,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             }
             CH_TSTAMP(7);
             float xN[NOB][4];
-            chain_load_xN<NOB>(xN, a.obs, base, nrows, O, i16, kk);           // (needed after the next 48 NC1 NC2 MFMAs)
+            if (!CACHED) chain_load_xN<NOB>(xN, a.obs, base, nrows, O, i16, kk);           // (needed after the next 48 NC1 NC2 MFMAs)
             if (CACHED) {         // the next tile's cache block (the registers' current contents were copied out at the top)
                 const int tn = t + NW;
                 const long long o = (long long)(tn < tend ? 16 * tn : 16 * seg.tile0) * HCR;
@@ -1438,23 +1692,48 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                     }
             }
             CH_TSTAMP(8);
-            wave_fence();
-#pragma unroll
-            for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, qz1[c]);
-            wave_fence();
             // ---- out_W1 += X^T qZ1 ; out_b1 += sum qZ1
+            if (CACHED) {
+                // (round 6) on the split pipe, k_pass's hidden_0 kernel gradient: qZ1's planes through the full tile (the hidden_1
+                // kernel gradient's reads of it are done), the observations' planes from the tile layer 1 wrote, 32 x 32 x 16 over
+                // the 16 samples; the bias gradient from the registers (summed over the sample lanes at the end of the segment)
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                float bop[NC1];
+                for (int c = 0; c < NC1; ++c) gb1v[c] += qz1[c];
+                u32x4 qB1[NP1][PROMP_NT];
 #pragma unroll
-                for (int c = 0; c < NC1; ++c) {
-                    bop[c] = TB0r[t4 * TS + 16 * c];
-                    ob1acc[c] += bop[c];
+                for (int P = 0; P < NP1; ++P) pass_split8(qz1[2 * P], qz1[2 * P + 1], qB1[P]);
+                wave_fence();
+#pragma unroll
+                for (int P = 0; P < NP1; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, qB1[P]);
+                wave_fence();
+                u32x4 fx[PROMP_NT], fd[NB1][PROMP_NT];
+                pass_read_tr(fx, XT, XPL, trd0, trd1);
+#pragma unroll
+                for (int b = 0; b < NB1; ++b) pass_read_tr(fd[b], TBP, TPL, trd0 + 256 * b, trd1 + 256 * b);
+#pragma unroll
+                for (int ta = PROMP_NT - 1; ta >= 0; --ta)
+#pragma unroll
+                    for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
+#pragma unroll
+                        for (int bj = 0; bj < NB1; ++bj) aw1w[bj] = mfma32_sw<PROMP_NT>(fx[ta], fd[bj][tb], aw1w[bj]);
+            } else {
+                wave_fence();
+#pragma unroll
+                for (int c = 0; c < NC1; ++c) sts4(TB0w + 16 * c, qz1[c]);
+                wave_fence();
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    float bop[NC1];
+#pragma unroll
+                    for (int c = 0; c < NC1; ++c) {
+                        bop[c] = TB0r[t4 * TS + 16 * c];
+                        ob1acc[c] += bop[c];
+                    }
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                        for (int c = 0; c < NC1; ++c) aw1[ob][c] = mfma16(xN[ob][t4], bop[c], aw1[ob][c]);
                 }
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-                    for (int c = 0; c < NC1; ++c) aw1[ob][c] = mfma16(xN[ob][t4], bop[c], aw1[ob][c]);
             }
             CH_TSTAMP(9);
         }
@@ -1471,6 +1750,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             for (int j = 0; j < NC2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gb2v[j][r] = row16_sum(gb2v[j][r]);
+#pragma unroll
+            for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gb1v[j][r] = row16_sum(gb1v[j][r]);
         }
         // FP16 split: everything this pass accumulates carries the wave's cs vs; an overflow anywhere in the tile walk ends as an
         // infinity or a NaN in the hidden_0 kernel sums (the last link of every chain): x * 0 is 0 for finite x only.  The waves vote
@@ -1479,20 +1762,30 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
         int bad = 0;
         if (PROMP_NT == 2 && attempt + 1 < CHAIN_ATTEMPTS) {
             float chk = 0.f;
+            if (CACHED) {
 #pragma unroll
-            for (int i = 0; i < NOB; ++i)
+                for (int i = 0; i < NB1; ++i)
 #pragma unroll
-                for (int j = 0; j < NC1; ++j)
+                    for (int r = 0; r < 16; ++r) chk = __builtin_fmaf(aw1w[i][r], 0.f, chk);
+            } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) chk = __builtin_fmaf(aw1[i][j][r], 0.f, chk);
+                for (int i = 0; i < NOB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NC1; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) chk = __builtin_fmaf(aw1[i][j][r], 0.f, chk);
+            }
             redo_amax = wave_absmax_f32(amax);
-            bad = wave_any(chk != chk) ? 1 : 0;      // (every split of this kernel feeds the hidden_0 kernel sums: nothing else to test)
+            // (every split of this kernel feeds the hidden_0 kernel sums, except -- cached instance -- the planes of the mean's
+            //  cotangents, which feed the output kernel's sums only: their largest values at the scale; amax holds the larger of
+            //  |d| and 2^-CHAIN_Q_OVER_D |q|)
+            bad = (wave_any(chk != chk) || (CACHED && !(redo_amax * cs * (float)(1 << CHAIN_Q_OVER_D) <= 65504.f))) ? 1 : 0;
         }
         outs0 *= dist[CH_LMASK + q0] * us;
         outs1 *= dist[CH_LMASK + q1] * us;
         float* P = a.partials + (long long)sg * a.partial_stride;
-        const bool redo = chain_reduce_to_partial<NC1, NC2, NOB, NW, CACHED>(sm + 4, P, aw2, aw2w, aw1, aw3, ob1acc, ob2acc, gb2v, outs0, outs1, outb30 * us,
-                                                                             outb31 * us, 0.f, klsum, O, A, tid, us, bad);
+        const bool redo = chain_reduce_to_partial<NC1, NC2, NOB, NW, CACHED>(sm + 4, P, aw2, aw2w, aw1, aw1w, gb1v, aw3, ob1acc, ob2acc, gb2v, outs0, outs1,
+                                                                             outb30 * us, outb31 * us, 0.f, klsum, O, A, tid, us, bad, us * w1w);
         if (redo) {               // (the partial row just written is written again)
             if (tid == 0) atomic_add_agent(a.split_events + 1, 1);
             attempt += 1;

@@ -49,9 +49,7 @@ struct PassLds {                 // offsets in 4-byte words
     int wave0, wave_stride, xt, ta, tb, dm;
     int total;
 };
-#define PROMP_PASS_TPLANE 512    // words per plane of a [16 samples][64 units] bf16 tile
-#define PROMP_PASS_XPLANE 256    // [16][32 observation slots]
-#define PROMP_PASS_DPLANE 160    // [16][16 action slots], rows of 8 words, 32 words of padding between samples 7 and 8
+// (PROMP_PASS_TPLANE / XPLANE / DPLANE, PassTileAddr: promp_kernels_chain.h -- k_chain_hvp's cached instance uses the same tiles)
 
 PROMP_CX PassLds pass_layout(int NC1, int NC2, int nwaves, int NP) {
     PassLds L{};
@@ -390,11 +388,6 @@ struct PassWalk {
 #else
 #define PASS_STAMP(j) do { } while (0)
 #endif
-// per-lane addresses (in words) of the transposed tiles
-struct PassTileAddr {
-    int wr, xw0, xw1, rd32_0, rd32_1, rd16_0, rd16_1, dmw, dr0, dr1;
-};
-
 // this lane's eight observation entries of its sample in tile t: obs[row i16][8 kk .. 8 kk + 7] (zeros outside the tile / task)
 PROMP_DEV void pass_load_x(float (&xr)[8], const PassWalk& W, int t, int i16, int kk) {
     const int nv = (t < W.tend) ? (W.tnrows - 16 * t < 16 ? W.tnrows - 16 * t : 16) : 0;
@@ -777,25 +770,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
     const int ob1 = O * H1, oW2 = ob1 + H1, ob2 = oW2 + H1 * H2, oW3 = ob2 + H2, ob3 = oW3 + H2 * A, oS = ob3 + A, NP = oS + A;
     const float* dist = sm + L.dist;
     float* wreg = sm + L.wave0 + w * L.wave_stride;
-    PassTileAddr T;
-    {
-        const int p16 = lane & 15, g32 = (lane >> 4) & 1, kh = lane >> 5;
-        // where this lane writes (chain side: sample i16, chunk 4 c + kk) ...
-        T.wr = 2 * pass_slot(i16, kk);
-        T.xw0 = 2 * pass_slot(i16, 2 * kk);
-        T.xw1 = 2 * pass_slot(i16, 2 * kk + 1);
-        // ... and reads: 32-unit blocks (v_mfma_f32_32x32x16_bf16 operands): samples 8 kh + 4 t + p16 / 4, chunk 8 b + 4 g32 + p16 % 4
-        T.rd32_0 = 2 * pass_slot(8 * kh + (p16 >> 2), 4 * g32 + (p16 & 3));
-        T.rd32_1 = 2 * pass_slot(8 * kh + 4 + (p16 >> 2), 4 * g32 + (p16 & 3));
-        // 16-unit blocks (A operand of the output-kernel gradient on v_mfma_f32_16x16x32_bf16): samples 8 (kk & 1) + 4 t + p16 / 4
-        // (the k-slots of the lane groups kk >= 2 meet zeros on the B side; they read the same finite data as kk - 2)
-        T.rd16_0 = 2 * pass_slot(8 * (kk & 1) + (p16 >> 2), p16 & 3);
-        T.rd16_1 = 2 * pass_slot(8 * (kk & 1) + 4 + (p16 >> 2), p16 & 3);
-        // cotangent-of-the-mean tile [16 samples][16 action slots]: rows of 8 words, 32 words of padding after sample 7
-        T.dmw = 8 * i16 + 32 * (i16 >> 3) + kk;
-        T.dr0 = (kk < 2) ? 8 * (8 * kk + (p16 >> 2)) + 32 * kk + 2 * (p16 & 3) : 4;     // kk >= 2: a chunk of zeros (actions 8..11 of sample 0)
-        T.dr1 = (kk < 2) ? 8 * (8 * kk + 4 + (p16 >> 2)) + 32 * kk + 2 * (p16 & 3) : 4;
-    }
+    const PassTileAddr T = pass_tile_addr(lane);
     PassWalk W;
     W.obs = a.obs; W.act = a.act; W.adv = a.adv; W.old_mean = a.old_mean; W.old_log_std = a.old_log_std; W.hcache = a.hcache;
     W.ls_per_row = a.ls_per_row; W.O = O; W.A = A; W.loss_kind = a.loss_kind; W.clip_eps = a.clip_eps;
