@@ -185,12 +185,12 @@ PROMP_CX ChainLds chain_layout(int NC1, int NC2, int nwaves, bool hvp, int NP, b
     int q = 0;
     if (bwdp) {
         // round 6: every product of the cached instance runs on the split's planes (k_pass's tiles): two full plane tiles (tangent /
-        // primal hidden_1 activations for the output-kernel gradient, then the cotangents dZ2 / qZ2, then qZ1), the half tile of
-        // the hidden_1 kernel gradient's A operand, the observations, the two cotangents of the mean.  No float32 tile is left.
+        // primal hidden_1 activations for the output-kernel gradient; then the two operands of each stage of the hidden_1 kernel
+        // gradient; then qZ1), the observations, the two cotangents of the mean.  No float32 tile is left.
         L.tb0 = L.tb1 = L.db0 = L.db1 = 0;
         L.tp = q;  q += PROMP_NT * PROMP_CH_TPL;
         L.tq = q;  q += PROMP_NT * PROMP_CH_TPL;
-        L.tah = q; q += PROMP_NT * PROMP_CH_APL;
+        L.tah = 0;
         L.xt = q;  q += PROMP_NT * PROMP_PASS_XPLANE;
         L.dm0 = q; q += PROMP_NT * PROMP_PASS_DPLANE;
         L.dm1 = q; q += PROMP_NT * PROMP_PASS_DPLANE;
@@ -1017,7 +1017,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     // CACHED: the hidden_1 kernel gradient runs on v_mfma_f32_32x32x16_bf16 (round 4): its operands' BF16 planes go through
     // swizzled tiles over TB0 / TB1 and come back through the transpose read (pass_slot; word addresses of this lane)
     constexpr int NB1 = NC1 / 2, NB2 = NC2 / 2, TPL = PROMP_CH_TPL, APL = PROMP_CH_APL;
-    float *TBP = wreg + L.tp, *TAH = wreg + L.tah;
+    float *TBP = wreg + L.tp;
     // ... and (round 6) every other product of the cached instance too: k_pass's tiles and lane addresses
     constexpr int XPL = PROMP_PASS_XPLANE, DPL = PROMP_PASS_DPLANE, NP1 = NC1 / 2, NP2 = NC2 / 2;
     float *TQ = wreg + L.tq, *XT = wreg + L.xt, *DM0 = wreg + L.dm0, *DM1 = wreg + L.dm1;
@@ -1520,11 +1520,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
             // ---- out_W2 += R'H1^T dZ2 + H1^T qZ2 ; out_b2 += sum qZ2
             u32x4 dB[NB2][PROMP_NT], qB[NB2][PROMP_NT];     // CACHED: the planes of dZ2 / qZ2 (this product and qZ1 below)
             if (CACHED) {
-                // On v_mfma_f32_32x32x16_bf16 (K = 16 samples = one tile), float32-equivalent: 6 of the 9 term products.  Four
-                // stages (product, 32-unit block of the A operand): (R'H1, dZ2) x NB1, (H1, qZ2) x NB1.  The B planes of a product
-                // sit in the full tile TBP, the A planes of one stage in the half tile TAH; a stage writes and requests the NEXT
-                // stage's operands before it issues its own products (LDS executes a wave's instructions in order: the half tile
-                // is rewritten behind the reads that were issued from it).
+                // On v_mfma_f32_32x32x16 (K = 16 samples = one tile), float32-equivalent split products.  Two stages: (R'H1, dZ2),
+                // (H1, qZ2); the B planes of a stage sit in the full tile TBP, its A planes in TQ.  (Rounds 4-5 walked four stages
+                // through a half tile that aliased the float32 transpose tiles; measured equal, the two-stage form is the shorter.)
 #pragma unroll
                 for (int P = 0; P < NB2; ++P) {
                     pass_split8(dz2[2 * P], dz2[2 * P + 1], dB[P]);
@@ -1532,52 +1530,36 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
                 }
 #pragma unroll
                 for (int c = 0; c < NC2; ++c) gb2v[c] += qz2[c];
-                wave_fence();         // the output-kernel gradient's reads of TB0 / TB1 precede these writes
+                // (round 6) two stages, each with BOTH 32-unit blocks of its A operand at once: the A operand's planes go through
+                // the second full tile (free since the output-kernel gradient read H2 from it) instead of a half tile, block by
+                // block -- two LDS round trips per tile instead of four
 #pragma unroll
-                for (int P = 0; P < NB2; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, dB[P]);
-                u32x4 fa[PROMP_NT], fb[NB2][PROMP_NT];
-                {
-                    u32x4 aB[PROMP_NT];
-                    pass_split8(rh1[0], rh1[1], aB);
-                    pass_store_planes(TAH, APL, twr, aB);
-                }
-                wave_fence();
-                pass_read_tr(fa, TAH, APL, trd0, trd1);
+                for (int s = 0; s < 2; ++s) {
+                    u32x4 aB[NP1][PROMP_NT];
 #pragma unroll
-                for (int b = 0; b < NB2; ++b) pass_read_tr(fb[b], TBP, TPL, trd0 + 256 * b, trd1 + 256 * b);
-#pragma unroll
-                for (int s = 0; s < 2 * NB1; ++s) {
-                    const int hb = s % NB1;
-                    u32x4 fan[PROMP_NT];
-                    if (s + 1 < 2 * NB1) {
-                        const int pn = (s + 1) / NB1, hn = (s + 1) % NB1;
-                        u32x4 aB[PROMP_NT];
-                        if (pn == 0) pass_split8(rh1[2 * hn], rh1[2 * hn + 1], aB);
-                        else pass_split8(h1[2 * hn], h1[2 * hn + 1], aB);
-                        wave_fence();
-                        pass_store_planes(TAH, APL, twr, aB);
-                        if (hn == 0) {
-#pragma unroll
-                            for (int P = 0; P < NB2; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, qB[P]);
-                        }
-                        wave_fence();
-                        pass_read_tr(fan, TAH, APL, trd0, trd1);
+                    for (int P = 0; P < NP1; ++P) {
+                        if (s == 0) pass_split8(rh1[2 * P], rh1[2 * P + 1], aB[P]);
+                        else pass_split8(h1[2 * P], h1[2 * P + 1], aB[P]);
                     }
+                    wave_fence();         // the reads of both tiles issued so far (output-kernel gradient / stage 0) precede these writes
+#pragma unroll
+                    for (int P = 0; P < NB2; ++P) pass_store_planes(TBP, TPL, twr + 256 * P, s == 0 ? dB[P] : qB[P]);
+#pragma unroll
+                    for (int P = 0; P < NP1; ++P) pass_store_planes(TQ, TPL, twr + 256 * P, aB[P]);
+                    wave_fence();
+                    u32x4 fa[NB1][PROMP_NT], fb[NB2][PROMP_NT];
+#pragma unroll
+                    for (int b = 0; b < NB1; ++b) pass_read_tr(fa[b], TQ, TPL, trd0 + 256 * b, trd1 + 256 * b);
+#pragma unroll
+                    for (int b = 0; b < NB2; ++b) pass_read_tr(fb[b], TBP, TPL, trd0 + 256 * b, trd1 + 256 * b);
 #pragma unroll
                     for (int ta = PROMP_NT - 1; ta >= 0; --ta)
 #pragma unroll
                         for (int tb = PROMP_NT - 1 - ta; tb >= 0; --tb)
 #pragma unroll
-                            for (int bj = 0; bj < NB2; ++bj) aw2w[hb][bj] = mfma32_sw<PROMP_NT>(fa[ta], fb[bj][tb], aw2w[hb][bj]);
-                    if (s + 1 < 2 * NB1) {
+                            for (int bi = 0; bi < NB1; ++bi)
 #pragma unroll
-                        for (int tt = 0; tt < PROMP_NT; ++tt) fa[tt] = fan[tt];
-                        if ((s + 1) % NB1 == 0) {     // the second product's B planes: behind the first product's last instructions
-                            sched_fence();            // (their registers are the first product's; the planes were written above)
-#pragma unroll
-                            for (int b = 0; b < NB2; ++b) pass_read_tr(fb[b], TBP, TPL, trd0 + 256 * b, trd1 + 256 * b);
-                        }
-                    }
+                                for (int bj = 0; bj < NB2; ++bj) aw2w[bi][bj] = mfma32_sw<PROMP_NT>(fa[bi][ta], fb[bj][tb], aw2w[bi][bj]);
                     sched_fence();
                 }
                 wave_fence();
