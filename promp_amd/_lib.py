@@ -525,25 +525,39 @@ class Context:
         self._call('promp_process_samples', int(step), C.byref(o))
         self._last_kind = int(baseline_kind)
 
-    def download_processed(self, step, baseline_kind=None, want_returns32=True, want_advantages=True):
+    # The downloads in two halves: the destination arrays first (page-locked, recycled), the blocking copies into them later -- a
+    # caller with host work that needs the arrays but not yet their contents (views per path and per task: samplers/base.py)
+    # does it in between, while the device is still busy with the upload and the sample-processing kernels.
+    def alloc_processed(self, step, baseline_kind=None, want_returns32=True, want_advantages=True):
         R, P = self.step_rows[step], self.step_paths[step]
         kind = self._last_kind if baseline_kind is None else baseline_kind
         D = self.lib.cdll.promp_feature_dim(C.byref(self.dims), int(kind))
-        out = dict(returns=host_pool.get((R,), np.float32, self.lib) if want_returns32 else None,
-                   advantages=host_pool.get((R,), np.float32, self.lib) if want_advantages else None,
-                   coeffs=np.zeros((self.n_tasks, D), np.float64), path_returns0=np.empty(P, np.float64),
-                   path_undiscounted=np.empty(P, np.float64), path_reward_sumsq=np.empty(P, np.float64))
+        return dict(returns=host_pool.get((R,), np.float32, self.lib) if want_returns32 else None,
+                    advantages=host_pool.get((R,), np.float32, self.lib) if want_advantages else None,
+                    coeffs=np.zeros((self.n_tasks, D), np.float64), path_returns0=np.empty(P, np.float64),
+                    path_undiscounted=np.empty(P, np.float64), path_reward_sumsq=np.empty(P, np.float64))
+
+    def fetch_processed(self, step, out):
+        D = out['coeffs'].shape[1]
         self._call('promp_download_processed', int(step), _ptr(out['returns'], C.c_float),
                    _ptr(out['advantages'], C.c_float), _ptr(out['coeffs'], C.c_double) if D else None,
                    _ptr(out['path_returns0'], C.c_double), _ptr(out['path_undiscounted'], C.c_double),
                    _ptr(out['path_reward_sumsq'], C.c_double))
         return out
 
-    def download_raw(self, step):
+    def download_processed(self, step, baseline_kind=None, want_returns32=True, want_advantages=True):
+        return self.fetch_processed(step, self.alloc_processed(step, baseline_kind, want_returns32, want_advantages))
+
+    def alloc_raw(self, step):
         R = self.step_rows[step]
-        ret, adv = host_pool.get((R,), np.float64, self.lib), host_pool.get((R,), np.float64, self.lib)
+        return host_pool.get((R,), np.float64, self.lib), host_pool.get((R,), np.float64, self.lib)
+
+    def fetch_raw(self, step, ret, adv):
         self._call('promp_download_raw', int(step), _ptr(ret, C.c_double), _ptr(adv, C.c_double))
         return ret, adv
+
+    def download_raw(self, step):
+        return self.fetch_raw(step, *self.alloc_raw(step))
 
     def set_coeffs(self, step, baseline_kind, coeffs):
         coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)

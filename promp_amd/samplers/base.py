@@ -92,38 +92,51 @@ class SampleProcessor(object):
         path_lists = list(paths_meta_batch.raw_values() if hasattr(paths_meta_batch, 'raw_values') else paths_meta_batch.values())
         resident = ref is not None and sess is not None and sess.ctx is not None and ref[0] == sess.serial \
             and sess.upload_serial[ref[2]] == ref[1]
+        kind = getattr(self.baseline, 'kind', _lib.BASELINE_ZERO)
+        opts = dict(discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=self.normalize_adv,
+                    positive_adv=self.positive_adv, baseline_kind=kind, reg_coeff=getattr(self.baseline, '_reg_coeff', 1e-5))
         if resident:
             # a device rollout (samplers/device_point_sampler.py): the slab is already resident, nothing to upload
             fl, upload, slot = paths_meta_batch.flat, ref[1], ref[2]
+            sess.ctx.process_samples(slot, **opts)
         else:
-            fl = _lib.flatten_paths(paths_meta_batch, _lib.get_library())
-            O = fl['obs'].shape[1]
+            lib = _lib.get_library()
             first = path_lists[0][0]
             A = int(np.asarray(first['actions']).reshape(len(first['rewards']), -1).shape[1]) if 'actions' in first else 1
-            sess = self._session_for(M, O, A)
+            # samplers.meta_sampler.HostPaths: the sampler built the flat arrays while it collected, and they are what goes to the
+            # device as long as every path dict still holds the sampler's own arrays.  Checking that is 800 paths x 6 identities:
+            # the copies and the kernels are enqueued FIRST (page-locked sources: promp_upload_step returns at once) and the check
+            # runs while they are under way; a batch somebody edited since (rare) is flattened the general way and goes again.
+            verify, fl = getattr(paths_meta_batch, 'flat_if_intact', None), getattr(paths_meta_batch, 'flat', None)
+            optimistic = verify is not None and fl is not None and len(fl['task_path_offsets']) == M + 1 \
+                and int(fl['task_path_offsets'][-1]) == sum(len(pl) for pl in path_lists)
+            if not optimistic:
+                fl = _lib.flatten_paths(paths_meta_batch, lib)
+            sess = self._session_for(M, fl['obs'].shape[1], A)
             slot = sess.next_slot()
             upload = sess.upload_flat(slot, fl)
+            sess.ctx.process_samples(slot, **opts)
+            if optimistic and verify() is None:
+                fl = _lib.flatten_paths(paths_meta_batch, lib)
+                upload = sess.upload_flat(slot, fl)
+                sess.ctx.process_samples(slot, **opts)
         ctx = sess.ctx
-        kind = getattr(self.baseline, 'kind', _lib.BASELINE_ZERO)
-        ctx.process_samples(slot, discount=self.discount, gae_lambda=self.gae_lambda, normalize_adv=self.normalize_adv,
-                            positive_adv=self.positive_adv, baseline_kind=kind,
-                            reg_coeff=getattr(self.baseline, '_reg_coeff', 1e-5))
         lazy = bool(resident and self.lazy_host_arrays and hasattr(paths_meta_batch, 'settle'))
-        # coefficients and per-path sums always come back (small); the per-row arrays now or on first use
-        out = ctx.download_processed(slot, kind, want_returns32=False, want_advantages=not lazy)
+        # coefficients and per-path sums always come back (small); the per-row arrays now or on first use.  Their destination
+        # arrays exist from here on; their CONTENTS arrive with the blocking fetch at the end of this function -- everything in
+        # between (two views per path, seven per task) is host work done while the device is still busy with this call's upload
+        # and kernels.
+        out = ctx.alloc_processed(slot, kind, want_returns32=False, want_advantages=not lazy)
         pro, tpo = fl['path_row_offsets'], fl['task_path_offsets']
         n_rows = int(pro[-1])
         if lazy:
             res = ctx.lazy_results(slot)
             rows = lambda field, a, b: _lib.LazyRows(res, field, a, b)
             ret64, raw_adv64, adv32 = rows('returns', 0, n_rows), rows('raw_advantages', 0, n_rows), rows('advantages', 0, n_rows)
-            out['advantages'] = adv32
         else:
-            ret64, raw_adv64 = ctx.download_raw(slot)
+            ret64, raw_adv64 = ctx.alloc_raw(slot)
             adv32 = out['advantages']
             rows = lambda field, a, b: dict(returns=ret64, raw_advantages=raw_adv64, advantages=adv32)[field][a:b]
-        if kind != _lib.BASELINE_ZERO:
-            self.baseline._coeffs = out['coeffs'][-1].copy()      # the shared baseline ends on the last task's fit
         # side effect of samplers/base.py:104,159: two views and two dict stores per path (plain slices on Python ints: np.split
         # costs ten times as much per piece) -- now, or when somebody looks at the paths of a resident batch again
         flat_paths = [p for plist in path_lists for p in plist]
@@ -131,10 +144,16 @@ class SampleProcessor(object):
 
         def side_effect():
             a = ends[0]
-            for p, b in zip(flat_paths, ends[1:]):
-                p['returns'] = rows('returns', a, b)
-                p['advantages'] = rows('raw_advantages', a, b)
-                a = b
+            if lazy:
+                for p, b in zip(flat_paths, ends[1:]):
+                    p['returns'] = rows('returns', a, b)
+                    p['advantages'] = rows('raw_advantages', a, b)
+                    a = b
+            else:
+                for p, b in zip(flat_paths, ends[1:]):
+                    p['returns'] = ret64[a:b]
+                    p['advantages'] = raw_adv64[a:b]
+                    a = b
         if lazy:
             paths_meta_batch._pending = side_effect
         else:
@@ -166,6 +185,13 @@ class SampleProcessor(object):
             )
             sd.device_ref = (sess.serial, upload, slot, i)
             result.append(sd)
+        ctx.fetch_processed(slot, out)
+        if lazy:
+            out['advantages'] = adv32
+        else:
+            ctx.fetch_raw(slot, ret64, raw_adv64)
+        if kind != _lib.BASELINE_ZERO:
+            self.baseline._coeffs = out['coeffs'][-1].copy()      # the shared baseline ends on the last task's fit
         return result, out
 
     # -- reference API ---------------------------------------------------------------------------

@@ -774,3 +774,22 @@ def test_host_paths_give_process_samples_the_same_results_as_plain_dicts(emu):
             np.testing.assert_array_equal(p['advantages'], q['advantages'])
     np.testing.assert_array_equal(pa.baseline.get_param_values(), pb.baseline.get_param_values())
     assert np.shares_memory(out_fast[0]['observations'], fast.flat['obs'])       # the samples data are views of the same arrays
+    # The flat arrays go to the device BEFORE the identities of the path dicts are checked (the check runs under the copies): a batch
+    # somebody edited since the sampler built it -- a replaced rewards array, a dropped path -- must still be processed as the dicts
+    # stand, not as the stale flat arrays say.
+    for edit in ('replace', 'drop'):
+        rng2 = np.random.RandomState(8)
+        plain2 = synthetic.make_paths(rng2, theta, M, P, T, O, A, (8, 8))
+        fast2 = slab_backed(OrderedDict((i, [dict(p, agent_infos=dict(p['agent_infos'])) for p in pl]) for i, pl in plain2.items()))
+        assert fast2.flat_if_intact() is fast2.flat
+        for batch in (plain2, fast2):
+            if edit == 'replace':
+                batch[1][2]['rewards'] = batch[1][2]['rewards'] * 3.0 + 1.0
+            else:
+                batch[2].pop()
+        assert fast2.flat_if_intact() is None
+        pc, pd = MetaSampleProcessor(baseline=LinearFeatureBaseline(), **kw), MetaSampleProcessor(baseline=LinearFeatureBaseline(), **kw)
+        for a, b in zip(pc.process_samples(plain2), pd.process_samples(fast2)):
+            for key in ('observations', 'actions', 'rewards', 'returns', 'advantages', 'adj_avg_rewards'):
+                np.testing.assert_array_equal(np.asarray(a[key]), np.asarray(b[key]), err_msg='%s after %s' % (key, edit))
+        np.testing.assert_array_equal(pc.baseline.get_param_values(), pd.baseline.get_param_values())
