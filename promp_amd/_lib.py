@@ -201,9 +201,13 @@ class _HostPool(object):
     sampler's thread both draw from it)."""
     _MIN_CLASS = 1 << 16
 
-    def __init__(self, keep=64, max_bytes=1 << 30):
-        import threading
+    def __init__(self, keep=64, max_bytes=None):
+        import os, threading
+        if max_bytes is None:        # PROMP_HOST_POOL_MB: the cap per process (N ranks per node hold N pools of page-locked memory)
+            max_bytes = int(float(os.environ.get('PROMP_HOST_POOL_MB', '1024')) * (1 << 20))
         self._owners = {}            # (class bytes, pinned) -> [owner, ...], most recently used last
+        self._used = {}              # id(owner) -> tick of its last hand-out (eviction order over ALL classes)
+        self._tick = 0
         self._keep, self._max_bytes, self._bytes = keep, int(max_bytes), 0
         self._lock = threading.Lock()
 
@@ -243,6 +247,8 @@ class _HostPool(object):
                 owner = self._new_owner(cls_bytes, lib)
                 self._bytes += cls_bytes
             lst.append(owner)                    # most recently used last
+            self._tick += 1
+            self._used[id(owner)] = self._tick
             if len(lst) > self._keep:
                 self._drop_free(lst, cls_bytes, len(lst) - self._keep, skip=owner)
             if self._bytes > self._max_bytes:
@@ -253,6 +259,7 @@ class _HostPool(object):
         i = 0
         while n > 0 and i < len(lst):
             if lst[i] is not skip and self._free(lst, i):
+                self._used.pop(id(lst[i]), None)
                 del lst[i]
                 self._bytes -= cls_bytes
                 n -= 1
@@ -260,14 +267,28 @@ class _HostPool(object):
                 i += 1
 
     def _evict(self, skip):
-        # least recently used free owners first, over all classes (a list's front is its oldest entry)
-        for key in sorted(self._owners, key=lambda k: -k[0]):
+        # over the cap: the FREE owners go, least recently handed out first, whatever their size class (owners somebody still
+        # references stay -- their memory is the caller's until the last view dies)
+        order = sorted(((self._used.get(id(o), 0), key, o) for key, lst in self._owners.items() for o in lst), key=lambda e: e[0])
+        for _, key, owner in order:
             if self._bytes <= self._max_bytes:
                 break
             lst = self._owners[key]
-            self._drop_free(lst, key[0], len(lst), skip)
+            for i in range(len(lst)):
+                if lst[i] is owner:
+                    if owner is not skip and self._free_at(lst, i):
+                        self._used.pop(id(owner), None)
+                        del lst[i]
+                        self._bytes -= key[0]
+                    break
         for key in [k for k, v in self._owners.items() if not v]:
             del self._owners[key]
+
+    @staticmethod
+    def _free_at(lst, i):
+        import sys
+        # (the pool's list, _evict's `order` entry, its loop variable, getrefcount's argument: no view outside)
+        return sys.getrefcount(lst[i]) == 4
 
     @staticmethod
     def _new_owner(nbytes, lib):
@@ -421,7 +442,8 @@ class Context:
         self.n_tasks, self.K = int(n_tasks), int(num_inner_steps)
         self.step_rows = {}
         self._staged, self._live_refs = {}, {}
-        self._upload_refs = {}       # step -> sources of the last two promp_upload_step calls (copies possibly in flight)
+        self._upload_refs = {}       # step -> [(wait epoch, sources)] of promp_upload_step calls whose copies may be in flight
+        self._wait_epoch = 0
         self.step_ls_rows = {}
         self.step_paths = {}
         self._lazy = {}              # step -> WeakSet of LazyResults that have not fetched yet
@@ -452,8 +474,26 @@ class Context:
         except Exception:
             pass
 
+    # entry points that return only after the work enqueued before them has completed (the compute stream waits for every upload
+    # enqueued before it, so an upload's sources are free once one of these has returned)
+    _WAITS = frozenset(('promp_sync', 'promp_download_processed', 'promp_download_raw', 'promp_get_theta', 'promp_stage_wait'))
+
     def _call(self, name, *args):
-        return self.lib.check(getattr(self.lib.cdll, name)(self._h, *args))
+        rc = self.lib.check(getattr(self.lib.cdll, name)(self._h, *args))
+        if name in self._WAITS:
+            self._wait_epoch += 1
+        return rc
+
+    def _retain_upload(self, step, refs):
+        """Keep the sources of an enqueued upload referenced until its copies have completed: entries older than the last call that
+        waited for the device are dropped; a third upload of a step with no such call in between waits itself (enqueueing later
+        uploads proves nothing about earlier DMAs -- ADVICE r5)."""
+        lst = self._upload_refs.setdefault(int(step), [])
+        lst[:] = [e for e in lst if e[0] == self._wait_epoch]
+        if len(lst) >= 2:
+            self._call('promp_sync')
+            del lst[:]
+        lst.append((self._wait_epoch, refs))
 
     # ---- trajectories ----
     def upload_step(self, step, task_path_offsets, path_row_offsets, obs, rew, act=None, old_mean=None,
@@ -478,10 +518,9 @@ class Context:
                    _ptr(obs, C.c_float), _ptr(act, C.c_float), _ptr(rew, C.c_float), _ptr(old_mean, C.c_float),
                    _ptr(old_log_std, C.c_float), per_row)
         # promp_upload_step returns with its copies enqueued: page-locked sources (host_pool's buffers) must not be recycled while the
-        # DMA may still read them.  The context keeps them referenced -- the pool only reuses buffers nobody references -- until the
-        # upload AFTER the next one of this step (stream order: by then these copies have completed) or the next sync().
-        self._upload_refs.setdefault(int(step), []).append((tpo, pro, obs, act, rew, old_mean, old_log_std, rew64))
-        del self._upload_refs[int(step)][:-2]
+        # DMA may still read them.  The context keeps them referenced -- the pool only reuses buffers nobody references -- until a
+        # call that waited for the device has returned since (_retain_upload).
+        self._retain_upload(step, (tpo, pro, obs, act, rew, old_mean, old_log_std, rew64))
         self.step_rows[step] = int(pro[-1])
         self.step_paths[step] = int(n_paths)
         self.step_ls_rows[step] = int(pro[-1]) if per_row else self.n_tasks

@@ -96,15 +96,18 @@ class ExactDeviceHvp(object):
     samples were drawn with (there the constraint's gradient wrt the adapted parameters is zero, and with it every term
     that differentiates the adaptation Jacobians)."""
 
-    def __init__(self):
+    def __init__(self, allow_fallback=True, fallback_eps=1e-5, fallback_symmetric=True):
+        """allow_fallback: where the exact product does not exist (below) use a FiniteDifferenceHvp(fallback_eps,
+        fallback_symmetric) instead -- said once in the log --; False: raise there"""
         self.reg_coeff = None
         self._ev = None
         self._fresh = False
         self._fd = None
+        self._allow_fallback, self._fd_args, self._told = bool(allow_fallback), (fallback_eps, fallback_symmetric), False
 
     def build_graph(self, evaluator, reg_coeff):
         self._ev, self.reg_coeff = evaluator, reg_coeff
-        self._fd = FiniteDifferenceHvp()
+        self._fd = FiniteDifferenceHvp(base_eps=self._fd_args[0], symmetric=self._fd_args[1])
         self._fd.build_graph(evaluator, reg_coeff)
 
     def constraint_gradient(self):
@@ -115,6 +118,14 @@ class ExactDeviceHvp(object):
         if getattr(self._ev, 'exact_hvp_available', lambda: True)() is False:
             # ranks that exchange through the session's `collective` hold no communicator: the library refuses to present one
             # shard's product as the batch's.  The reference's own construction works there (its gradients cross the collective).
+            if not self._allow_fallback:
+                raise RuntimeError('ExactDeviceHvp: the exact constraint product needs the library\'s communicator; this session '
+                                   'exchanges through `collective` (allow_fallback=True takes finite differences there)')
+            if not self._told:
+                self._told = True
+                logger.log('ExactDeviceHvp: no exact constraint product on ranks that exchange through `collective`; using finite '
+                           'differences (eps %g, %s)'
+                           % (self._fd_args[0], 'symmetric: two gradient evaluations per product' if self._fd_args[1] else 'one-sided'))
             return self._fd.Hx(x)
         out = self._ev.constraint_hvp(x, refresh_chain=not self._fresh)   # the adapted parameters are computed once per theta
         self._fresh = True

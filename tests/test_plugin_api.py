@@ -715,6 +715,50 @@ def test_host_pool_reuses_size_classes_and_caps_what_it_keeps():
     assert pool.retained_bytes() <= 64 << 20
 
 
+def test_host_pool_evicts_the_least_recently_used_free_buffers_first(monkeypatch):
+    """over the cap the free owners go in the order they were last handed out, whatever their size class (the
+    eviction used to walk the classes largest first); owners somebody references never go; PROMP_HOST_POOL_MB sets the cap"""
+    from promp_amd._lib import _HostPool
+    pool = _HostPool(max_bytes=4 << 20)
+    old_big = pool.get((1 << 19,), np.float32)          # 2 MB class, handed out first
+    small = pool.get((1 << 18,), np.float32)            # 1 MB class
+    big_class = _HostPool.size_class(4 << 19)
+    del old_big, small                                  # both free; the big one is the older
+    again = pool.get((1 << 18,), np.float32)            # the 1 MB owner again: now the most recent
+    other = pool.get((300000,), np.float32)             # a third owner: over the cap -> the oldest free owner (the big one) goes
+    assert all(k[0] != big_class or not v for k, v in pool._owners.items()) and pool.retained_bytes() <= 4 << 20
+    held = [pool.get((1 << 19,), np.float32) for _ in range(3)]     # referenced owners stay, cap or not
+    assert pool.retained_owners() == 5 and pool.retained_bytes() > 4 << 20
+    del held, again, other
+    monkeypatch.setenv('PROMP_HOST_POOL_MB', '2')
+    assert _HostPool()._max_bytes == 2 << 20
+
+
+def test_upload_sources_stay_referenced_until_a_call_has_waited_for_the_device(emu):
+    """promp_upload_step returns with its copies enqueued; their page-locked sources may be recycled only after a
+    call that waited for the device -- a later upload proves nothing.  Three uploads of one step with no such call in between make
+    the third wait itself; a download in between releases the older sources."""
+    from promp_amd import synthetic
+    rng = np.random.RandomState(5)
+    M, P, T, O, A, hidden = 2, 2, 8, 4, 2, (8, 8)
+    theta = synthetic.init_theta(rng, O, hidden, A)
+    ctx = _lib.Context(M, O, A, hidden, 1, max_rows=M * P * T, max_paths=M * P)
+    fl = _lib.flatten_paths(synthetic.make_paths(rng, theta, M, P, T, O, A, hidden))
+    up = lambda: ctx.upload_step(0, fl['task_path_offsets'], fl['path_row_offsets'], fl['obs'], fl['rew'], fl['act'], fl['old_mean'], fl['old_log_std'])
+    calls = []
+    real = ctx._call
+    ctx._call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    up(); up()
+    assert len(ctx._upload_refs[0]) == 2 and 'promp_sync' not in calls
+    up()                                                # the third in a row: waits, then holds only its own sources
+    assert calls.count('promp_sync') == 1 and len(ctx._upload_refs[0]) == 1
+    ctx.process_samples(0)
+    ctx.download_processed(0)                           # waited for the device: what was enqueued before is done
+    up()
+    assert len(ctx._upload_refs[0]) == 1 and calls.count('promp_sync') == 1
+    ctx.close()
+
+
 def test_hidden_nonlinearity_argument_is_honoured_or_refused(emu):
     """policies/base.py:31 / networks/mlp.py:47: hidden_nonlinearity is tf.tanh by default, any TF function or None (linear hidden
     layers).  The plugin class maps 'tanh' / 'relu' / None (and callables of those names) onto the device kernels and refuses the

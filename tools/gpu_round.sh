@@ -22,7 +22,7 @@ done
 # BASELINE config 4 (Ant shapes, cooperative kernels): bench line + kernel trace
 timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 > $ROOT/$R/bench_config4.json 2> $ROOT/$R/bench_config4.err; echo "bench config4 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$R/trace4 -o trace4 -- python $ROOT/bench.py --config 4 --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-plugin-path > /dev/null 2> $ROOT/$R/trace4.err; echo "trace4 rc=$?"
-cd $ROOT; rm -f $R/trace4/*kernel_trace.csv
+cd $ROOT; TIMELINE_STEP=2 python tools/timeline.py $R/trace4 > $R/timeline_config4.txt 2>&1; rm -f $R/trace4/*kernel_trace.csv
 # config 4 with the exact-FP32 cooperative kernels (the A/B of the BF16-pipe kernels, same box), cycle stamps, PMC counters
 PROMP_WIDE_FP32=1 timeout 600 python $ROOT/bench.py --config 4 --steps 10 --warmup 2 --no-cpu-baseline --no-plugin-path > $ROOT/$R/bench_config4_fp32_kernels.json 2> /dev/null; echo "bench config4 fp32 rc=$?"
 bash tools/gpu_wb_stamps.sh 0,1 > $ROOT/$R/wb_stamps.txt 2>&1

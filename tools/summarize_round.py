@@ -16,7 +16,7 @@ for name, out in [('bench.json', '%s_bench.json'), ('pytest_gpu.log', '%s_pytest
                   ('device.txt', '%s_device.txt'), ('trace/trace_kernel_stats.csv', '%s_rocprofv3_kernel_stats.csv'),
                   ('trace/trace_domain_stats.csv', '%s_rocprofv3_domain_stats.csv'),
                   ('bench_config4.json', '%s_bench_config4.json'), ('bench_config5.json', '%s_bench_config5.json'),
-                  ('shard_timings.txt', '%s_shard_timings.txt'), ('shard_timings_config4.txt', '%s_shard_timings_config4.txt'), ('primal_cache_ab.txt', '%s_primal_cache_ab.txt'), ('h2d_overlap.txt', '%s_h2d_overlap.txt'), ('bench_staged.json', '%s_bench_staged_uploads.json'), ('timeline.txt', '%s_step_timeline.txt'), ('generic_shapes.txt', '%s_generic_shapes.txt'), ('stage_a.txt', '%s_stage_a.txt'),
+                  ('shard_timings.txt', '%s_shard_timings.txt'), ('shard_timings_config4.txt', '%s_shard_timings_config4.txt'), ('primal_cache_ab.txt', '%s_primal_cache_ab.txt'), ('h2d_overlap.txt', '%s_h2d_overlap.txt'), ('bench_staged.json', '%s_bench_staged_uploads.json'), ('timeline.txt', '%s_step_timeline.txt'), ('timeline_config4.txt', '%s_step_timeline_config4.txt'), ('generic_shapes.txt', '%s_generic_shapes.txt'), ('stage_a.txt', '%s_stage_a.txt'),
                   ('trace4/trace4_kernel_stats.csv', '%s_rocprofv3_kernel_stats_config4.csv'),
                   ('full_size_parity.txt', '%s_full_size_parity.txt'), ('split_accuracy.txt', '%s_split_accuracy.txt'),
                   ('bench_config4_fp32_kernels.json', '%s_bench_config4_fp32_kernels.json'), ('wb_stamps.txt', '%s_wb_kernels_phase_stamps.txt'),
