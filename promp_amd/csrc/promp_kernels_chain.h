@@ -42,6 +42,16 @@
 
 enum { LOSS_RATIO = 0, LOSS_CLIP = 1, LOSS_LOGLIK = 2, LOSS_KL = 3 };   // LOSS_KL: mean KL(old || new) itself (TRPO constraint)
 
+// Which entry of the workgroup -> segments table a workgroup of k_pass / k_chain_hvp takes.  The table is ordered by task, and the
+// dispatcher deals consecutive workgroups out over the eight XCDs: with the identity (0) the ~6 workgroups of a task sit on different
+// XCDs and each of the eight L2s fetches every task's parameters; with xcd_item (1) an XCD takes a contiguous eighth of the table --
+// five tasks at config 3 -- and a task's parameters, direction and partial rows stay in one L2.  Measured at config 3 (round 6, two
+// A/B pairs on one box): k_pass 50.0 -> 50.5 us, k_chain_hvp 71.8 -> 72.5 us, forward-only 27.3 -> 26.7 us, step 1.093 -> 1.091 ms:
+// nothing -- these kernels read their parameters once per segment (24 KB, 7 % of a segment with the loads of all lanes in flight),
+// unlike the cooperative kernels, which re-read them every round and do use the mapping.  The identity stays.
+#ifndef PROMP_PASS_XCD
+#define PROMP_PASS_XCD 0
+#endif
 struct WorkItem {
     int task, row_begin, row_end, pad;
 };
@@ -1026,7 +1036,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_chain_hvp(PassArgs a) {
     const int trd0 = 2 * pass_slot(8 * (lane >> 5) + (i16 >> 2), 4 * (kk & 1) + (i16 & 3));
     const int trd1 = 2 * pass_slot(8 * (lane >> 5) + 4 + (i16 >> 2), 4 * (kk & 1) + (i16 & 3));
 
-    const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
+    const int wgi = PROMP_PASS_XCD ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;     // (see PROMP_PASS_XCD)
+    const int sg0 = a.wg_seg_offsets[wgi], sg1 = a.wg_seg_offsets[wgi + 1];
     CH_WGSTAMP(0);
     int attempt = 0;              // FP16 split: how often the current segment has overflowed (see the end of the tile walk)
     float redo_amax = 0.f;        // ... and the largest cotangent this wave met on the way

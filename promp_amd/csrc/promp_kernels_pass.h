@@ -778,7 +778,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) k_pass(PassArgs a) {
     W.own0 = 2 * kk < A; W.own1 = 2 * kk + 1 < A;
     W.q0 = W.own0 ? 2 * kk : 0; W.q1 = W.own1 ? 2 * kk + 1 : 0;
 
-    const int sg0 = a.wg_seg_offsets[blockIdx.x], sg1 = a.wg_seg_offsets[blockIdx.x + 1];
+    const int wgi = PROMP_PASS_XCD ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;     // (see PROMP_PASS_XCD)
+    const int sg0 = a.wg_seg_offsets[wgi], sg1 = a.wg_seg_offsets[wgi + 1];
     CH_WGSTAMP(0);
     int attempt = 0;             // FP16 split: how often the current segment has overflowed (see the end of the tile walk)
     float redo_amax = 0.f;       // ... and the largest cotangent this wave met on the way
