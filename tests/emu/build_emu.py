@@ -14,9 +14,20 @@ def build(force=False):
     deps = [SRC, os.path.join(HERE, 'hip_emu.h')] + [os.path.join(ROOT, 'promp_amd', 'csrc', f)
                                                       for f in os.listdir(os.path.join(ROOT, 'promp_amd', 'csrc'))]
     deps.append(os.path.join(ROOT, 'include', 'promp_hip.h'))
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)
+    if not force and fresh():
         return OUT
-    tmp = '%s.%d.tmp' % (OUT, os.getpid())      # two processes may find the library stale at once: each links its own file
+    # the workers of a parallel test run find the library stale together: one builds (80 s of g++), the others wait for it
+    import fcntl
+    with open(OUT + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return OUT
+        return _compile()
+
+
+def _compile():
+    tmp = '%s.%d.tmp' % (OUT, os.getpid())
     cmd = ['g++', '-std=c++20', '-O1', '-g', '-DPROMP_EMU', '-fPIC', '-shared', '-x', 'c++', SRC,
            '-I', HERE, '-I', os.path.join(ROOT, 'promp_amd', 'csrc'), '-o', tmp, '-lpthread',
            '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-variable', '-Wno-unused-but-set-variable']
