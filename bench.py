@@ -61,7 +61,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-primal-cache', action='store_true',
-                    help='developer switch: promp_set_primal_cache(1) whatever the size of the shard (default: on from two rounds of tiles per compute unit)')
+                    help='developer switch: promp_set_primal_cache(1) (the default since round 6; through round 5 the default was on from two rounds of tiles per compute unit)')
     ap.add_argument('--no-primal-cache', action='store_true',
                     help='developer switch: the second-order pass recomputes the activations instead of reading the gradient '
                          'pass\'s copies back (promp_set_primal_cache)')

@@ -192,8 +192,9 @@ int promp_set_schedule(promp_ctx* ctx, int stage_overlap, int fuse_min_tasks);
  * parameters on the same slab; with the cache on, the former writes its hidden activations, means and first-layer
  * cotangents to HBM (4 (2 H1 + H2 + 8) bytes per row) and the latter reads them back instead of recomputing them.
  * Results agree with the recomputing path to float32 rounding (both evaluate the same tanh network; the two kernels
- * contract in different orders).  on = 1 always, 0 never, -1 (default) whenever a step holds at least two rounds of
- * 16-row tiles per compute unit -- below that the passes are all fixed cost and the stores do not pay. */
+ * contract in different orders).  on = 1 always, 0 never, -1 (default) = always too since round 6 (the cache-reading pass is
+ * less than half the recomputing one per tile and wins on 3-task shards as well; through round 5: from two rounds of 16-row
+ * tiles per compute unit on). */
 int promp_set_primal_cache(promp_ctx* ctx, int on);
 /* The inner step and the first epoch of the optimisation that follows it evaluate the same pass.  MAMLAlgo._adapt
  * (meta_algos/base.py:217-242) runs the inner gradient step of every task from the meta-parameters; the first thing

@@ -770,7 +770,7 @@ class Context:
 
     def set_primal_cache(self, on=True):
         """the second-order pass reads the inner gradient pass's activations back instead of recomputing them
-        (True / False; None = the default: on for steps with at least two rounds of tiles per compute unit)"""
+        (True / False; None = the default: on)"""
         self._call('promp_set_primal_cache', -1 if on is None else int(bool(on)))
 
     def set_reuse_adapt(self, on=True):

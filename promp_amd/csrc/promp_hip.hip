@@ -170,7 +170,7 @@ struct promp_ctx {
     const float* pass_adv = nullptr;     // launch_pass: per-row weights instead of the step's advantages (DiCE coupling pass)
     float* pass_row_tan = nullptr;       // launch_pass (R-operator pass): where the rows' log-likelihood tangents go
     int pass_cache = 0;                  // launch_pass: 1 = the gradient pass fills the step's primal cache, 2 = the R-operator pass reads it
-    int primal_cache = -1;               // promp_set_primal_cache: 1 on, 0 off, -1 on from two rounds of tiles per CU on
+    int primal_cache = -1;               // promp_set_primal_cache: 1 on, 0 off, -1 default (on: primal_cache_worth)
     // promp_inner_adapt(step 0) from the meta-parameters evaluates exactly what the first epoch of the following optimisation
     // evaluates first (the inner pass at theta on step 0's slab): it leaves theta', the inner scalars and the primal cache
     // where that epoch expects them, and the epoch skips its pass while nothing it depends on has changed (reuse_adapt).
@@ -463,6 +463,16 @@ int enqueue_obs_range(promp_ctx* c, StepData& S, hipStream_t st) {
     return 0;
 }
 
+// Does the gradient pass fill the primal cache for the R-operator pass behind it?  promp_set_primal_cache: 1 / 0; -1 (default) = yes at
+// every size.  Through round 5 the default was "from two rounds of tiles per compute unit" (a small shard's passes are all fixed cost
+// and the stores cost what the R-operator pass got back: 0.750 vs 0.737 ms per step at 5 tasks).  Since the cache-reading instance
+// runs every product on the FP16 pipe (round 6: 12.2 k cycles per tile against 26.3 k for the recomputing one) the cache pays on
+// small shards too: 0.516 vs 0.545 ms at 5 tasks, 0.475 vs 0.485 at 3 (two A/B pairs, one box).
+static bool primal_cache_worth(const promp_ctx* c, long long n_rows) {
+    (void)n_rows;
+    return c->primal_cache != 0;
+}
+
 // One policy pass over a step's slabs plus the per-task reduction that consumes it:
 //   red_mode RED_STEP / RED_OUTER / RED_HVP / RED_PLAIN / RED_SCAL (promp_kernels_chain.h).
 // k_chain_hvp can do both in one launch; k_pass and the cooperative kernels (hidden 128 / wide observations) are
@@ -666,9 +676,7 @@ int enqueue_meta(promp_ctx* c, float clip_eps, const float* eta_host, int inner_
         if (join_side(c, c->steps[k])) return -2;
         // the R-operator pass of this step (below) runs at these parameters on this slab: it reads the activations and means
         // back instead of recomputing them (primal cache, promp_kernels_chain.h)
-        // (a small shard's passes are all fixed cost -- staging, one round of tiles, end reduction: the stores then cost more
-        // than the second-order pass gets back: 0.750 vs 0.737 ms per step at 5 tasks, 0.937 vs 0.951 at 10, 1.789 vs 1.894 at 40)
-        const bool worth = c->primal_cache > 0 || (c->primal_cache < 0 && c->steps[k].n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
+        const bool worth = primal_cache_worth(c, c->steps[k].n_rows);
         const bool cached = want_grad && worth && !c->wide && policy_shape_chain(&c->d);
         if (cached && !c->steps[k].hcache &&
             dev_alloc(&c->steps[k].hcache, ((size_t)c->d.max_rows + 16 * (size_t)M) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
@@ -1838,7 +1846,7 @@ int promp_inner_adapt(promp_ctx* c, int step, int inner_kind) {
     bool cached = false;
     if (leave) {
         const size_t MNP = (size_t)c->d.n_tasks * c->NP;
-        const bool worth = c->primal_cache > 0 || (c->primal_cache < 0 && S.n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
+        const bool worth = primal_cache_worth(c, S.n_rows);
         cached = worth && !c->wide && policy_shape_chain(&c->d);      // (the cooperative kernels keep no primal cache: theta' and the scalars only)
         if (cached && !S.hcache &&
             dev_alloc(&S.hcache, ((size_t)c->d.max_rows + 16 * (size_t)c->d.n_tasks) * chain_cache_row(c->d.hidden1, c->d.hidden2))) return -2;
@@ -2162,7 +2170,7 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     // meta-objective's cache (enqueue_meta).
     bool use_cache = !c->wide && policy_shape_chain(&c->d);      // (the cooperative kernels keep no primal cache)
     for (int k = 0; k <= K && use_cache; ++k)
-        use_cache = c->primal_cache > 0 || (c->primal_cache < 0 && c->steps[k].n_rows >= 16 * 2 * CHAIN_NW_HVP * c->n_cus);
+        use_cache = primal_cache_worth(c, c->steps[k].n_rows);
     if (refresh_chain) {
         c->chvp.valid = false;
         for (int k = 0; k <= K && use_cache; ++k)

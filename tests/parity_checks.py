@@ -541,6 +541,7 @@ def check_exact_constraint_hvp(lib, seed, M, P, T, O, A, hidden, K=1, inner='log
     helpers.upload_slabs(ctx, all_paths, all_slabs)
     ctx.set_theta(theta)
     ctx.set_step_sizes(alpha)
+    ctx.set_primal_cache(False)        # the recomputing passes first (the default is on since round 6): the cached ones are compared with them below
     rng = np.random.RandomState(seed + 1)
     g, st = ctx.meta_grad(0.0, np.zeros(K, np.float32), inner_kind=kind, outer_kind=_lib.OUTER_KL)
     assert abs(st['outer_kl']) < 1e-6 and np.abs(g).max() < 1e-4      # on-policy: KL and its gradient vanish
@@ -561,7 +562,7 @@ def check_exact_constraint_hvp(lib, seed, M, P, T, O, A, hidden, K=1, inner='log
     if tuple(hidden) in ((32, 32), (64, 64), (32, 64), (64, 32)) and O <= 32:
         # primal caches: the chain-refreshing passes store, all 2K + 1 R-operator passes of every product read; equal to the
         # recomputing passes to rounding, and nothing stale survives new parameters / a refresh
-        assert ctx.constraint_hvp_cached_passes() == 0               # (these shapes are below the worth-it threshold)
+        assert ctx.constraint_hvp_cached_passes() == 0               # (switched off above)
         ctx.set_primal_cache(True)
         h1 = ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=True)
         h2 = ctx.constraint_hvp(x, inner_kind=kind, refresh_chain=False)
