@@ -205,7 +205,8 @@ class ConjugateGradientOptimizer(object):
         grad = self.gradient()
         curvature = self._hvp_approach.build_eval()
         direction = conjugate_gradients(curvature, grad, cg_iters=self._cg_iters)
-        length = np.sqrt(2.0 * self._max_constraint_val * (1. / (direction.dot(curvature(direction)) + 1e-8)))
+        with np.errstate(invalid='ignore'):       # negative curvature along the direction: NaN, rejected below (as the reference, :264-268)
+            length = np.sqrt(2.0 * self._max_constraint_val * (1. / (direction.dot(curvature(direction)) + 1e-8)))
         self.last = dict(loss_before=loss_before, gradient=grad, descent_direction=direction, initial_step_size=float(length),
                          n_backtracks=0, rejected=False)
         if np.isnan(length):
