@@ -141,6 +141,11 @@ struct promp_ctx {
                                          // 1..3 = the observation class (NKO, NXB) = (4,2) (7,4) (8,4): obs_dim <= 63 / 111 / 127
     size_t smem_wb_fwd = 0, smem_wb_bwd = 0, smem_wb_hvp = 0;
     unsigned *wb_planes = nullptr, *wb_vplanes = nullptr;   // [tasks][wb_planes_words]: k_wb_planes' output for theta / the direction
+    // The planes of the META-parameters (theta itself, stride 0) have their own block: an epoch passes over step 0 at theta twice --
+    // the inner gradient pass and, two passes later, the R-operator pass -- and the second finds the first one's planes (same
+    // parameters, same slab, same observation scales): one k_wb_planes launch less per epoch.
+    unsigned* wb_planes_meta = nullptr;
+    struct { bool valid = false; unsigned long long theta_version = 0, data_version = 0, sizes_version = 0; const void* step = nullptr; } wbp;
     unsigned* vdir_absmax = nullptr;     // [tasks]: k_vec_absmax's output for the direction (FP16 split)
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
     // cotangent buffers for the whole context (the passes of a context run one after another on its stream)
@@ -460,6 +465,7 @@ int enqueue_obs_range(promp_ctx* c, StepData& S, hipStream_t st) {
     PROMP_LAUNCH(k_obs_range, dim3(slices < 1 ? 1 : slices > 32 ? 32 : slices, c->d.n_tasks), 256, 16, st, r);
     HIPCHECK(hipGetLastError());
     S.obs_range_valid = true;
+    c->wbp.valid = false;          // (the hidden_0 planes carry the scales this launch rewrites)
     return 0;
 }
 
@@ -522,12 +528,19 @@ int launch_pass(promp_ctx* c, StepData& S, bool hvp, const float* theta, long lo
         // the parameters' (and the direction's) hidden kernels as BF16 planes in fragment order (one small launch each: 276 KB per task)
         const int nko = wb_nko(c->wbf);
         WbPlaneArgs pa;
-        pa.src = theta; pa.src_stride = theta_stride; pa.dst = c->wb_planes; pa.O = c->d.obs_dim; pa.A = c->d.act_dim; pa.NKO = nko; pa.row_sign = 1.f;
+        const bool at_meta = theta == c->theta && theta_stride == 0 && c->wb_planes_meta;
+        const bool standing = at_meta && c->wbp.valid && c->wbp.theta_version == c->theta_version && c->wbp.data_version == S.data_version &&
+                              c->wbp.sizes_version == c->sizes_version && c->wbp.step == (const void*)&S;
+        pa.src = theta; pa.src_stride = theta_stride; pa.dst = at_meta ? c->wb_planes_meta : c->wb_planes; pa.O = c->d.obs_dim; pa.A = c->d.act_dim; pa.NKO = nko; pa.row_sign = 1.f;
         pa.obs_absmax = a.obs_absmax; pa.vec_absmax = nullptr;       // FP16 split: the hidden_0 kernel takes the inverse of the observations' scale
         // (one copy per task even when the tasks share their parameters: the hidden_0 kernel's planes carry the task's observation scale)
         const bool per_task = theta_stride != 0 || PROMP_NT == 2;
-        PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, per_task ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
-        a.wb_theta_planes = c->wb_planes;
+        if (!standing) PROMP_LAUNCH(k_wb_planes, dim3((4 * (nko + 16) * 64 + 256 + 255) / 256, per_task ? c->d.n_tasks : 1), 256, 0, c->stream, pa);
+        if (at_meta) {
+            c->wbp.valid = true; c->wbp.theta_version = c->theta_version; c->wbp.data_version = S.data_version;
+            c->wbp.sizes_version = c->sizes_version; c->wbp.step = (const void*)&S;
+        }
+        a.wb_theta_planes = pa.dst;
         a.wb_plane_stride = per_task ? wb_planes_words(nko) : 0;
         if (hvp) {
             // the direction's planes carry its scale: its largest entry per task first (one small launch)
@@ -1059,7 +1072,7 @@ int promp_ctx_create(promp_ctx** out, int device_id, const promp_dims* user_dims
     rc |= dev_alloc(&c->lam, MNP); rc |= dev_alloc(&c->vbuf, MNP);
     if (c->wbf) {
         const size_t pw = (size_t)M * wb_planes_words(wb_nko(c->wbf));
-        rc |= dev_alloc(&c->wb_planes, pw); rc |= dev_alloc(&c->wb_vplanes, pw);
+        rc |= dev_alloc(&c->wb_planes, pw); rc |= dev_alloc(&c->wb_vplanes, pw); rc |= dev_alloc(&c->wb_planes_meta, pw);
         rc |= dev_alloc(&c->vdir_absmax, (size_t)M);
     }
     rc |= dev_alloc(&c->partials, (size_t)c->max_work * c->partial_stride);
@@ -1108,7 +1121,7 @@ void promp_ctx_destroy(promp_ctx* c) {
             if (S.ev_done) (void)hipEventDestroy(S.ev_done);
             if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
         }
-    void* ptrs[] = {c->vdir_absmax, c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    void* ptrs[] = {c->vdir_absmax, c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wb_planes_meta, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->split_events, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
