@@ -159,7 +159,8 @@ def main():
                                                            meta_eval=lambda *a, **k: ctx.meta_eval(*a, **k)), num_inner_grad_steps=K,
                                    inner_kind=_lib.INNER_LOGLIK, exploration=False, meta_batch_size=M)
             from promp_amd.optimizers.conjugate_gradient_optimizer import ExactDeviceHvp
-            cgs = dict(finite_difference=ConjugateGradientOptimizer(), exact=ConjugateGradientOptimizer(hvp_approach=ExactDeviceHvp()))
+            cgs = dict(finite_difference=ConjugateGradientOptimizer(), exact=ConjugateGradientOptimizer(hvp_approach=ExactDeviceHvp()),
+                       host_loop=ConjugateGradientOptimizer(device_solve=False))
             for o in cgs.values():
                 o.build_graph(_DeviceEvaluator(shim), 0.01)
             mode = dict(hvp='finite_difference')     # the reference's construction is the timed default (parity mode)
@@ -375,6 +376,16 @@ def main():
                             'loss_after': float(res_ex['loss_after']), 'kl_after': float(res_ex['kl_after']),
                             'note': 'same step with hvp_approach=exact: 3 R-operator passes per product instead of two '
                                     'displaced constraint gradients (6 passes)'}
+        # ... and with the optimizer looping over its products on the host (the reference's control flow: every displaced
+        # gradient crosses PCIe and back) instead of promp_cg_solve's back-to-back launches
+        iteration.mode['hvp'] = 'host_loop'
+        el_h, res_h = run_timed(ctx, iteration, 1, n_ex)
+        iteration.mode['hvp'] = 'finite_difference'
+        iteration.reset()
+        iteration()
+        out['host_cg_loop'] = {'ms_per_step': 1e3 * el_h / n_ex, 'value': M_global * N * (K + 1) * n_ex / el_h, 'steps': n_ex,
+                               'note': 'same step with ConjugateGradientOptimizer(device_solve=False): the conjugate-gradient loop on the '
+                                       'host, 22 constraint gradients fetched one at a time'}
 
     # ---- host -> device cost of the two slabs (never part of `value`: the timed region starts with the batch in HBM) ----
     if rank == 0 and world == 1 and not args.staged_only:

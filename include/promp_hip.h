@@ -311,6 +311,19 @@ int promp_meta_grad(promp_ctx* ctx, float clip_eps, const float* inner_kl_coeff,
  * Every supported policy shape (register-chained and cooperative kernels); the register-chained ones keep primal caches
  * over the products of one solve (promp_set_primal_cache, promp_constraint_hvp_cached_passes). */
 int promp_constraint_hvp(promp_ctx* ctx, int inner_kind, const float* v, int refresh_chain, float* out);
+/* ConjugateGradientOptimizer's whole solve on the device (optimizers/conjugate_gradient_optimizer.py:59-89 cg(); :107-148
+ * FiniteDifferenceHvp.build_eval -- the product x -> (H + reg_coeff I) x of the constraint; :258-262 the closing product that
+ * sizes the step): cg_iters conjugate-gradient iterations on (H + reg_coeff I) x = b from x = 0, then x . (H + reg_coeff I) x.
+ *   hvp_mode 0  H v = (grad c(theta + eps v) - grad c(theta - eps v)) / (2 eps)   (the reference's default: symmetric, eps 1e-5)
+ *            1  H v = (grad c(theta + eps v) - grad c(theta)) / eps
+ *            2  the exact product of promp_constraint_hvp (eps unused)
+ * with grad c the gradient of the mean outer KL through the adaptation (promp_meta_grad with PROMP_OUTER_KL).  Same arithmetic
+ * as the host loop over promp_set_theta / promp_meta_grad (float32 vectors; the dot products are summed in float64 in a fixed
+ * order), but nothing crosses to the host between the products: 2 cg_iters + 2 gradient evaluations enqueued back to back, one
+ * synchronisation at the end.  The iteration stops updating once r.r < residual_tol (1e-10 in the reference).  The parameters
+ * are back at theta when the call returns.  b [Theta] = the loss gradient; x_out [Theta]; *xhx_out = x . (H + reg_coeff I) x. */
+int promp_cg_solve(promp_ctx* ctx, int inner_kind, const float* b, int cg_iters, float reg_coeff, float eps, int hvp_mode,
+                   float residual_tol, float* x_out, double* xhx_out);
 /* tf.train.AdamOptimizer step on theta with the gradient left by promp_meta_grad
  * (optimizers/maml_first_order_optimizer.py:24,64; b1=.9 b2=.999 eps=1e-8, bias-corrected lr). */
 int promp_adam_step(promp_ctx* ctx, float learning_rate);

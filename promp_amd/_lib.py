@@ -87,6 +87,7 @@ SIGNATURES = {
     'promp_host_alloc': (C.c_void_p, [C.c_size_t]),
     'promp_host_free': (None, [C.c_void_p]),
     'promp_constraint_hvp': (C.c_int, [_P, C.c_int, _F, C.c_int, _F]),
+    'promp_cg_solve': (C.c_int, [_P, C.c_int, _F, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _F, C.POINTER(C.c_double)]),
     'promp_set_adam_state': (C.c_int, [_P, _F, _F, C.c_int64]),
     'promp_get_adam_state': (C.c_int, [_P, _F, _F, C.POINTER(C.c_int64)]),
     'promp_switch_to_pre_update': (C.c_int, [_P]),
@@ -834,6 +835,17 @@ class Context:
         out = np.empty_like(v)
         self._call('promp_constraint_hvp', int(inner_kind), _ptr(v, C.c_float), int(bool(refresh_chain)), _ptr(out, C.c_float))
         return out
+
+    def cg_solve(self, b, cg_iters=10, reg_coeff=0.0, eps=1e-5, hvp_mode=0, residual_tol=1e-10, inner_kind=INNER_LOGLIK):
+        """ConjugateGradientOptimizer's solve on the device (promp_cg_solve): -> (x, x . (H + reg I) x).
+        hvp_mode 0 symmetric finite differences of the constraint gradient, 1 one-sided, 2 the exact product"""
+        b = _f32(b)
+        assert b.shape == (self.n_params,)
+        x = np.empty_like(b)
+        xhx = C.c_double(0.0)
+        self._call('promp_cg_solve', int(inner_kind), _ptr(b, C.c_float), int(cg_iters), float(reg_coeff), float(eps), int(hvp_mode),
+                   float(residual_tol), _ptr(x, C.c_float), C.byref(xhx))
+        return x, float(xhx.value)
 
     def eval_hvp(self, step, v, inner_kind=INNER_RATIO, clip_log_std=False, kl_weight=0.0):
         v = _f32(v)

@@ -145,6 +145,8 @@ struct promp_ctx {
     // the inner gradient pass and, two passes later, the R-operator pass -- and the second finds the first one's planes (same
     // parameters, same slab, same observation scales): one k_wb_planes launch less per epoch.
     unsigned* wb_planes_meta = nullptr;
+    float* cg_buf = nullptr;             // promp_cg_solve: x, r, d, (H + reg I) d, the gradient ahead, theta0 [+ the gradient at theta0]
+    double* cg_scal = nullptr;           // [4] r.r, d.Hd, converged, x.Hx
     struct { bool valid = false; unsigned long long theta_version = 0, data_version = 0, sizes_version = 0; const void* step = nullptr; } wbp;
     unsigned* vdir_absmax = nullptr;     // [tasks]: k_vec_absmax's output for the direction (FP16 split)
     // layer-by-layer kernels (promp_kernels_generic.h) for every other shape: layer table, and one set of activation / tangent /
@@ -1121,7 +1123,7 @@ void promp_ctx_destroy(promp_ctx* c) {
             if (S.ev_done) (void)hipEventDestroy(S.ev_done);
             if (S.ev_ready) (void)hipEventDestroy(S.ev_ready);
         }
-    void* ptrs[] = {c->vdir_absmax, c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wb_planes_meta, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
+    void* ptrs[] = {c->cg_buf, c->cg_scal, c->vdir_absmax, c->gb_wplanes, c->gb_vplanes, c->wb_planes, c->wb_vplanes, c->wb_planes_meta, c->wbuf, c->gram_partials_side, c->fit_scratch_side, c->theta, c->step_sizes, c->adam_m, c->adam_v, c->theta_tasks, c->chain, c->lam, c->vbuf,
                     c->partials, c->scal_inner, c->scal_outer, c->scal_tmp, c->red, c->grad_mean, c->stats,
                     c->gram_partials, c->red64, c->fwd_buf, c->stage_rows, c->task_counters, c->split_events, c->dbg, c->fit_scratch, c->rollout_buf};
     for (void* p : ptrs)
@@ -2159,8 +2161,8 @@ int promp_meta_grad(promp_ctx* c, float clip_eps, const float* eta, int inner_ki
 //     H v = mean_i  J_0^T ... J_{K-1}^T  H_KL(theta_K)  J_{K-1} ... J_0  v .
 // The terms that differentiate the J_k are contracted with grad_{theta_K} KL, which is zero where TRPO builds the
 // product: at the parameters the samples were drawn with (old distribution == adapted policy).  2K + 1 R-operator passes.
-int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refresh_chain, float* out) {
-    if (!c || !v || !out) return fail(-1, "NULL argument");
+// (the direction is in c->grad_mean, the sums over the tasks -- all-reduced -- are left in c->red)
+static int enqueue_constraint_hvp(promp_ctx* c, int inner_kind, int refresh_chain) {
     if (sharded_without_comm(c))
         return fail(-3, "this context holds %d of %d tasks and has no communicator: the product would be this rank's share only "
                         "(promp_comm_init first)", c->d.n_tasks, c->d.n_tasks_global);
@@ -2220,7 +2222,6 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     auto cache_ok = [&](int k) {
         return rec_ok && c->steps[k].hcache && c->chvp.data_version[k] == c->steps[k].data_version && c->chvp.tag[k] == c->steps[k].cache_tag;
     };
-    if (params_in(c, c->grad_mean, v, 1)) return -2;
     PROMP_LAUNCH(k_replicate, dim3((NP + 255) / 256), 256, 0, c->stream, c->vbuf, c->grad_mean, NP, M);
     const dim3 eg((NP + 255) / 256, M);
     auto pass = [&](int k, int kind) -> int {
@@ -2249,10 +2250,99 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     PROMP_LAUNCH(k_reduce_final, dim3((NP + K + 2 + 63) / 64), 256, 0, c->stream, f);
     HIPCHECK(hipGetLastError());
     if (exchange_sums(c, c->red, (size_t)NP)) return -4;
+    for (int k = 0; k <= K; ++k) c->steps[k].dirty = true;
+    return 0;
+}
+
+int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refresh_chain, float* out) {
+    if (!c || !v || !out) return fail(-1, "NULL argument");
+    if (params_in(c, c->grad_mean, v, 1)) return -2;
+    const int rc = enqueue_constraint_hvp(c, inner_kind, refresh_chain);
+    if (rc) return rc;
     if (params_out(c, out, c->red, 1)) return -2;
     const float inv = 1.0f / (float)c->d.n_tasks_global;
     for (int j = 0; j < c->NPu; ++j) out[j] *= inv;
-    for (int k = 0; k <= K; ++k) c->steps[k].dirty = true;
+    return 0;
+}
+
+// ConjugateGradientOptimizer's solve with nothing crossing to the host between its products (conjugate_gradient_optimizer.py:59-89
+// cg(), :107-148 FiniteDifferenceHvp.build_eval, :258-262 the closing product): see include/promp_hip.h.
+int promp_cg_solve(promp_ctx* c, int inner_kind, const float* b, int cg_iters, float reg_coeff, float eps, int hvp_mode,
+                   float residual_tol, float* x_out, double* xhx_out) {
+    if (!c || !b || !x_out || !xhx_out) return fail(-1, "NULL argument");
+    if (cg_iters < 0) return fail(-1, "cg_iters must not be negative");
+    if (hvp_mode < 0 || hvp_mode > 2) return fail(-1, "hvp_mode %d unknown (0 symmetric differences, 1 one-sided, 2 exact)", hvp_mode);
+    if (hvp_mode != 2 && !(eps > 0.f)) return fail(-1, "the finite differences need eps > 0");
+    if (sharded_without_comm(c))
+        return fail(-3, "this context holds %d of %d tasks and has no communicator: the products would be this rank's share only "
+                        "(promp_comm_init first)", c->d.n_tasks, c->d.n_tasks_global);
+    const int NP = c->NP;
+    if (!c->cg_buf) {
+        if (dev_alloc(&c->cg_buf, (size_t)7 * NP)) return -2;
+        if (dev_alloc(&c->cg_scal, 4)) return -2;
+    }
+    float *x = c->cg_buf, *r = x + NP, *d = r + NP, *hd = d + NP, *ga = hd + NP, *th0 = ga + NP;
+    if (params_in(c, r, b, 1)) return -2;                       // (blocking: b is the caller's)
+    float eta[PROMP_ETA_MAX] = {};
+    if (upload_eta(c, eta)) return -2;
+    CgArgs a;
+    a.g_ahead = ga; a.g_behind = nullptr; a.div_h = 1.f; a.mul_s = 1.f; a.reg = reg_coeff;
+    a.x = x; a.r = r; a.d = d; a.hd = hd; a.scal = c->cg_scal; a.tol = residual_tol; a.n = NP; a.mode = 2;
+    PROMP_LAUNCH(k_cg_step, dim3(1), 1024, 0, c->stream, a);      // x = 0, d = r = b, scal = {b.b, 0, 0, 0}
+    HIPCHECK(hipGetLastError());
+    const bool exact = hvp_mode == 2;
+    const bool ls_known = c->ls_known;
+    auto gradient_at = [&](float s, const float* v) -> int {      // the constraint's gradient at theta0 + s v -> c->grad_mean
+        PROMP_LAUNCH(k_cg_displace, dim3((NP + 255) / 256), 256, 0, c->stream, c->theta, th0, v, s, NP);
+        c->theta_version = ++c->version_counter;
+        c->ls_known = false;
+        return enqueue_meta(c, 0.f, eta, inner_kind, PROMP_OUTER_KL, true, false, 0.f);
+    };
+    if (!exact) {
+        HIPCHECK(hipMemcpyAsync(th0, c->theta, sizeof(float) * NP, hipMemcpyDeviceToDevice, c->stream));
+        if (hvp_mode == 1) {                                      // one-sided: the gradient at theta0 itself, once
+            if (enqueue_meta(c, 0.f, eta, inner_kind, PROMP_OUTER_KL, true, false, 0.f)) return -2;
+            HIPCHECK(hipMemcpyAsync(th0 + NP, c->grad_mean, sizeof(float) * NP, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    bool fresh = false;
+    auto product = [&](const float* v, int mode) -> int {        // hd = (H + reg I) v and the vector updates of `mode`
+        if (exact) {
+            HIPCHECK(hipMemcpyAsync(c->grad_mean, v, sizeof(float) * NP, hipMemcpyDeviceToDevice, c->stream));
+            const int rc = enqueue_constraint_hvp(c, inner_kind, fresh ? 0 : 1);
+            if (rc) return rc;
+            fresh = true;
+            a.g_ahead = c->red; a.g_behind = nullptr; a.div_h = 1.f; a.mul_s = 1.0f / (float)c->d.n_tasks_global;
+        } else {
+            if (gradient_at(eps, v)) return -2;
+            HIPCHECK(hipMemcpyAsync(ga, c->grad_mean, sizeof(float) * NP, hipMemcpyDeviceToDevice, c->stream));
+            if (hvp_mode == 0) {
+                if (gradient_at(-eps, v)) return -2;
+                a.g_behind = c->grad_mean; a.div_h = 2.f * eps;
+            } else {
+                a.g_behind = th0 + NP; a.div_h = eps;
+            }
+            a.g_ahead = ga; a.mul_s = 1.f;
+        }
+        a.mode = mode;
+        PROMP_LAUNCH(k_cg_step, dim3(1), 1024, 0, c->stream, a);
+        HIPCHECK(hipGetLastError());
+        return 0;
+    };
+    int rc = 0;
+    for (int it = 0; it < cg_iters && !rc; ++it) rc = product(d, 0);
+    if (!rc) rc = product(x, 1);                                  // x . (H + reg I) x: the step length's denominator
+    if (!exact) {                                                 // the parameters are back at theta0 when the solve returns
+        HIPCHECK(hipMemcpyAsync(c->theta, th0, sizeof(float) * NP, hipMemcpyDeviceToDevice, c->stream));
+        c->theta_version = ++c->version_counter;
+        c->ls_known = ls_known;
+    }
+    if (rc) return rc;
+    if (params_out(c, x_out, x, 1)) return -2;
+    double sc[4];
+    HIPCHECK(hipMemcpyAsync(sc, c->cg_scal, sizeof sc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *xhx_out = sc[3];
     return 0;
 }
 

@@ -326,3 +326,89 @@ __global__ void __launch_bounds__(256) k_policy_forward(ForwardArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Conjugate gradients on the device (promp_cg_solve): the vector side of ConjugateGradientOptimizer's solve
+// (optimizers/conjugate_gradient_optimizer.py:59-89) between two products, in ONE launch of one workgroup -- the vectors are
+// Theta floats (6 k ... 70 k), the launch is a link in a chain of dependent launches and costs what any of them costs.
+// Sums in a fixed order (thread-strided, then a tree over the workgroup) in float64; the vectors stay float32 like the
+// NumPy arrays of the host form.
+// ---------------------------------------------------------------------------------------------
+// theta = theta0 + s x  (FiniteDifferenceHvp: the parameters the displaced constraint gradient is taken at; one rounding)
+__global__ void __launch_bounds__(256) k_cg_displace(float* theta, const float* theta0, const float* x, float s, int n) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) theta[j] = __builtin_fmaf(s, x[j], theta0[j]);
+}
+
+struct CgArgs {
+    const float* g_ahead;    // finite differences: the constraint gradient at theta0 + eps v; exact: the task sums of the product
+    const float* g_behind;   // ... at theta0 - eps v (symmetric) / at theta0 (one-sided); NULL: nothing is subtracted
+    float div_h, mul_s;      // H v = ((g_ahead - g_behind) / div_h) * mul_s   (2 eps or eps, 1; exact: 1, 1 / tasks)
+    float reg;               // + reg v
+    float *x, *r, *d, *hd;   // solution, residual, search direction, (H + reg I) v
+    double* scal;            // [0] r.r   [1] d.(H + reg I)d of the last iteration   [2] != 0: converged   [3] x.(H + reg I)x
+    float tol;               // residual_tol
+    int n;
+    int mode;                // 2: x = 0, d = r (= b), scal[0] = r.r;   0: one iteration along d;   1: the closing product on x
+};
+PROMP_DEV double cg_block_sum(double v, double* buf) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    buf[t] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (t < s) buf[t] += buf[t + s];
+        __syncthreads();
+    }
+    return buf[0];
+}
+// grid = 1, block = 1024
+__global__ void __launch_bounds__(1024) k_cg_step(CgArgs a) {
+    __shared__ double buf[1024];
+    const int t = threadIdx.x;
+    if (a.mode == 2) {
+        double s = 0.0;
+        for (int j = t; j < a.n; j += 1024) {
+            const float b = a.r[j];
+            a.x[j] = 0.f;
+            a.d[j] = b;
+            s += (double)b * (double)b;
+        }
+        s = cg_block_sum(s, buf);
+        if (t == 0) {
+            a.scal[0] = s; a.scal[1] = 0.0; a.scal[2] = 0.0; a.scal[3] = 0.0;
+        }
+        return;
+    }
+    const float* v = a.mode == 1 ? a.x : a.d;
+    double dot = 0.0;
+    for (int j = t; j < a.n; j += 1024) {
+        const float gb = a.g_behind ? a.g_behind[j] : 0.f;
+        const float h = __builtin_fmaf(a.reg, v[j], ((a.g_ahead[j] - gb) / a.div_h) * a.mul_s);
+        a.hd[j] = h;
+        dot += (double)v[j] * (double)h;
+    }
+    dot = cg_block_sum(dot, buf);
+    if (a.mode == 1) {
+        if (t == 0) a.scal[3] = dot;
+        return;
+    }
+    const double res = a.scal[0];
+    if (a.scal[2] != 0.0) return;          // converged in an earlier iteration: the host form has left its loop (uniform: no barrier is skipped by a part of the block)
+    const float step = (float)(res / dot);
+    double nres = 0.0;
+    for (int j = t; j < a.n; j += 1024) {
+        a.x[j] = __builtin_fmaf(step, a.d[j], a.x[j]);
+        const float rr = __builtin_fmaf(-step, a.hd[j], a.r[j]);
+        a.r[j] = rr;
+        nres += (double)rr * (double)rr;
+    }
+    nres = cg_block_sum(nres, buf);
+    const float beta = (float)(nres / res);
+    for (int j = t; j < a.n; j += 1024) a.d[j] = __builtin_fmaf(beta, a.d[j], a.r[j]);
+    if (t == 0) {
+        a.scal[0] = nres;
+        a.scal[1] = dot;
+        if (nres < (double)a.tol) a.scal[2] = 1.0;
+    }
+}

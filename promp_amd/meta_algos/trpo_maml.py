@@ -79,6 +79,14 @@ class _DeviceEvaluator(object):
     def constraint_hvp(self, x, refresh_chain=True):   # exact (d2 constraint / d theta2) x on the device
         return self.ctx.constraint_hvp(np.asarray(x, dtype=np.float32), self.algo.inner_kind, refresh_chain)
 
+    def cg_solve(self, b, cg_iters, reg_coeff, hvp_mode, eps=1e-5, residual_tol=1e-10):
+        """ConjugateGradientOptimizer's solve with its products enqueued back to back on the device (promp_cg_solve):
+        -> (direction, direction . (H + reg I) direction), or None where the library cannot run it (ranks that exchange through
+        session.collective hold no communicator) and the optimizer loops over its own products on the host"""
+        if self.algo.session.external():
+            return None
+        return self.ctx.cg_solve(np.asarray(b, dtype=np.float32), cg_iters, reg_coeff, eps, hvp_mode, residual_tol, self.algo.inner_kind)
+
     def get_theta(self):
         return self.ctx.get_theta()
 

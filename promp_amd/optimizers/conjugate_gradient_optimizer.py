@@ -147,7 +147,8 @@ class ConjugateGradientOptimizer(object):
     """
 
     def __init__(self, cg_iters=10, reg_coeff=0, subsample_factor=1., backtrack_ratio=0.8, max_backtracks=15,
-                 debug_nan=False, accept_violation=False, hvp_approach=None):
+                 debug_nan=False, accept_violation=False, hvp_approach=None, device_solve=True):
+        self._device_solve = bool(device_solve)
         self._cg_iters = cg_iters
         self._reg_coeff = reg_coeff
         self._subsample_factor = subsample_factor
@@ -176,6 +177,24 @@ class ConjugateGradientOptimizer(object):
     def gradient(self, *_):
         return self._ev.gradient()
 
+    # ---- the solve ----
+    def _solve_on_device(self, grad):
+        """The reference's loop -- cg_iters products, each two displaced constraint gradients, then the closing product -- asks the
+        device for 2 cg_iters + 2 gradients one at a time, and every one of them crosses to the host and back.  With the evaluator
+        of the device kernels and one of this module's own product constructions the library runs the same loop with the products
+        enqueued back to back (promp_cg_solve: same float32 vectors, dot products in float64).  None: not available, loop here."""
+        solve = getattr(self._ev, 'cg_solve', None)
+        hv = self._hvp_approach
+        if not self._device_solve or solve is None:
+            return None
+        if type(hv) is FiniteDifferenceHvp and hv.grad_clip is None:
+            mode, eps = (0 if hv.symmetric else 1), float(hv.base_eps)
+        elif type(hv) is ExactDeviceHvp and getattr(self._ev, 'exact_hvp_available', lambda: True)() is not False:
+            mode, eps = 2, 1e-5
+        else:
+            return None
+        return solve(grad, self._cg_iters, float(self._reg_coeff), mode, eps=eps)
+
     # ---- the step ----
     def _search(self, origin, full_step, loss_before):
         """backtracking over the scales ratio^k; returns (loss, constraint, k) of the last candidate tried"""
@@ -203,10 +222,15 @@ class ConjugateGradientOptimizer(object):
         logger.log('trust-region step: conjugate gradients')
         loss_before = self.loss()
         grad = self.gradient()
-        curvature = self._hvp_approach.build_eval()
-        direction = conjugate_gradients(curvature, grad, cg_iters=self._cg_iters)
+        solved = self._solve_on_device(grad)
+        if solved is not None:
+            direction, curved = solved
+        else:
+            curvature = self._hvp_approach.build_eval()
+            direction = conjugate_gradients(curvature, grad, cg_iters=self._cg_iters)
+            curved = direction.dot(curvature(direction))
         with np.errstate(invalid='ignore'):       # negative curvature along the direction: NaN, rejected below (as the reference, :264-268)
-            length = np.sqrt(2.0 * self._max_constraint_val * (1. / (direction.dot(curvature(direction)) + 1e-8)))
+            length = np.sqrt(2.0 * self._max_constraint_val * (1. / (curved + 1e-8)))
         self.last = dict(loss_before=loss_before, gradient=grad, descent_direction=direction, initial_step_size=float(length),
                          n_backtracks=0, rejected=False)
         if np.isnan(length):

@@ -528,6 +528,73 @@ def on_policy_case(seed, M, P, T, O, A, hidden, K, alpha, inner_kind, ragged=Tru
     return theta, all_slabs, all_paths
 
 
+def check_cg_solve_on_device(lib, seed, M, P, T, O, A, hidden, K=1, inner='loglik', cg_iters=4, fd=True):
+    """promp_cg_solve (ConjugateGradientOptimizer's loop with its products enqueued back to back on the device) against the same
+    loop on the host over the library's own products: conjugate_gradient_optimizer.py:59-89 with the exact product (no
+    finite-difference noise: the two differ by the rounding of their dot products only) and with the reference's symmetric
+    finite differences (one product and the closing quadratic form, where the directions are bitwise the same on both sides:
+    over several iterations the noise of eps = 1e-5 in float32 amplifies any rounding difference).  The parameters are back
+    where they were, the evaluation after the solve equals the one before it."""
+    from promp_amd.optimizers.conjugate_gradient_optimizer import conjugate_gradients
+    spec = op.PolicySpec(O, A, hidden)
+    alpha = np.full(spec.n_params, 0.05, np.float32)
+    kind = dict(loglik=_lib.INNER_LOGLIK, ratio=_lib.INNER_RATIO)[inner]
+    okind = dict(loglik=pm.INNER_LOGLIK, ratio=pm.INNER_RATIO)[inner]
+    theta, all_slabs, all_paths = on_policy_case(seed, M, P, T, O, A, hidden, K, alpha, okind)
+    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths)
+    helpers.upload_slabs(ctx, all_paths, all_slabs)
+    ctx.set_theta(theta)
+    ctx.set_step_sizes(alpha)
+    eta = np.zeros(K, np.float32)
+    b, st0 = ctx.meta_grad(0.0, eta, inner_kind=kind, outer_kind=_lib.OUTER_RATIO)      # the loss gradient: the right-hand side
+    # exact products
+    fresh = [False]
+
+    def hx_exact(x):
+        out = ctx.constraint_hvp(np.asarray(x, np.float32), inner_kind=kind, refresh_chain=not fresh[0])
+        fresh[0] = True
+        return out
+    ref = conjugate_gradients(hx_exact, b, cg_iters=cg_iters)
+    ref_q = float(ref.astype(np.float64).dot(hx_exact(ref).astype(np.float64)))
+    x, q = ctx.cg_solve(b, cg_iters=cg_iters, hvp_mode=2, inner_kind=kind)
+    assert rel_max(x, ref) < 2e-4, rel_max(x, ref)
+    assert q > 0 and abs(q - ref_q) <= 2e-4 * abs(ref_q), (q, ref_q)
+    assert np.array_equal(ctx.get_theta(), theta)
+    # with a Tikhonov term
+    x2, q2 = ctx.cg_solve(b, cg_iters=2, reg_coeff=0.5, hvp_mode=2, inner_kind=kind)
+    fresh[0] = False
+    ref2 = conjugate_gradients(lambda v: hx_exact(v) + np.float32(0.5) * v, b, cg_iters=2)
+    assert rel_max(x2, ref2) < 2e-4, rel_max(x2, ref2)
+    assert abs(q2 - float(ref2.astype(np.float64).dot((hx_exact(ref2) + np.float32(0.5) * ref2).astype(np.float64)))) <= 2e-4 * abs(q2)
+    # zero iterations: x = 0
+    x0, q0 = ctx.cg_solve(b, cg_iters=0, hvp_mode=2, inner_kind=kind)
+    assert not x0.any() and q0 == 0.0
+    if fd:
+        # the reference's finite differences: ONE iteration is step * b with step = b.b / b.(H b), and H b is taken at the same
+        # displaced parameters on both sides (theta + eps b in one rounding here, two in NumPy: compared loosely)
+        eps = np.float32(1e-5)
+
+        def grad_c(th):
+            ctx.set_theta(th.astype(np.float32))
+            return ctx.meta_grad(0.0, eta, inner_kind=kind, outer_kind=_lib.OUTER_KL)[0]
+        for mode in (0, 1):
+            x1, q1 = ctx.cg_solve(b, cg_iters=1, eps=float(eps), hvp_mode=mode, inner_kind=kind)
+            assert np.array_equal(ctx.get_theta(), theta)
+            t64 = theta.astype(np.float64)
+            ahead = grad_c(np.float32(1) * (theta + eps * b))
+            hb = (ahead - grad_c(theta - eps * b)) / (2 * eps) if mode == 0 else (ahead - grad_c(theta)) / eps
+            ctx.set_theta(theta)
+            step = float(b.astype(np.float64).dot(b)) / float(b.astype(np.float64).dot(hb))
+            # (the quotient of two noisy sums: the displaced parameters differ in their last bit between the two forms)
+            assert np.isfinite(x1).all() and rel_max(x1, step * b) < 0.2, rel_max(x1, step * b)
+            assert np.isfinite(q1)
+        del t64
+    # the solve leaves nothing behind: the same evaluation as before it
+    b2, st2 = ctx.meta_grad(0.0, eta, inner_kind=kind, outer_kind=_lib.OUTER_RATIO)
+    assert np.array_equal(b, b2) and st2['loss'] == st0['loss']
+    ctx.close()
+
+
 def check_exact_constraint_hvp(lib, seed, M, P, T, O, A, hidden, K=1, inner='loglik', tol=1e-4):
     """promp_constraint_hvp (2K+1 R-operator passes, Gauss-Newton form through the adaptation) against the float64 central
     difference of the oracle's constraint gradient, at the operating point of TRPO (old distribution = adapted policy)"""

@@ -283,6 +283,10 @@ def test_trpo_e_maml_exploration_term(lib, two_cus):
     pc.check_trpo(lib, 18, M=2, P=1, T=12, O=4, A=2, hidden=(32, 32), cg_iters=1, max_backtracks=1, exploration=True)
 
 
+def test_cg_solve_on_device(lib, two_cus):
+    pc.check_cg_solve_on_device(lib, 19, M=2, P=1, T=16, O=4, A=2, hidden=(32, 32), cg_iters=2)
+
+
 def test_trpo_maml_step(lib, two_cus):
     pc.check_trpo(lib, 17, M=2, P=1, T=16, O=4, A=2, hidden=(32, 32), cg_iters=1, max_backtracks=2)
 

@@ -471,6 +471,15 @@ def test_comm_info_and_exchange_timing_on_a_one_rank_communicator(lib):
     pc.check_comm_info_and_exchange_timing(lib)
 
 
+def test_cg_solve_on_device_equals_the_host_loop(lib):
+    """promp_cg_solve: ConjugateGradientOptimizer's products enqueued back to back (config 5's step: 22 gradient evaluations and
+    no host round trip between them) against the host loop over the same products"""
+    pc.check_cg_solve_on_device(lib, 71, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner='loglik', cg_iters=5)
+    pc.check_cg_solve_on_device(lib, 72, M=3, P=4, T=60, O=5, A=3, hidden=(32, 32), inner='ratio', cg_iters=3)
+    pc.check_cg_solve_on_device(lib, 73, M=3, P=4, T=80, O=111, A=8, hidden=(128, 128), inner='loglik', cg_iters=3)     # cooperative kernels
+    pc.check_cg_solve_on_device(lib, 74, M=3, P=4, T=60, O=20, A=6, hidden=(100, 100), inner='loglik', cg_iters=3, fd=False)  # zero-padded layout
+
+
 def test_trpo_maml_step_with_exact_constraint_hvp(lib):
     """the plugin with hvp_approach='exact': with the finite-difference noise gone, the float32 step tracks the float64 oracle"""
     pc.check_trpo(lib, 66, M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood', hvp_approach='exact', on_policy=True)
