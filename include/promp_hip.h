@@ -55,9 +55,13 @@ typedef struct promp_dims {
     int32_t hidden3, hidden4;   /* widths of the third / fourth hidden layer (n_hidden >= 3 / 4)    */
     int32_t hidden_act;         /* hidden nonlinearity (policies/networks/mlp.py:47, policies/base.py:31): PROMP_ACT_TANH (0, the
                                  * reference's default and every run script's), PROMP_ACT_RELU, PROMP_ACT_IDENTITY (the reference's
-                                 * hidden_nonlinearity=None: linear hidden layers).  Anything but tanh runs on the layer-by-layer kernels */
+                                 * hidden_nonlinearity=None: linear hidden layers).  Anything but tanh runs on the layer-by-layer kernels.
+                                 * Bits 8..15: output_nonlinearity (policies/networks/mlp.py:53-60, 114-117: applied to the mean network's
+                                 * last layer; None in every run script of the reference): PROMP_OUT_ACT_NONE (0), _TANH, _RELU, e.g.
+                                 * PROMP_ACT_TANH | (PROMP_OUT_ACT_TANH << PROMP_OUT_ACT_SHIFT); layer-by-layer kernels as well */
 } promp_dims;
 enum { PROMP_ACT_TANH = 0, PROMP_ACT_RELU = 1, PROMP_ACT_IDENTITY = 2 };
+enum { PROMP_OUT_ACT_NONE = 0, PROMP_OUT_ACT_TANH = 1, PROMP_OUT_ACT_RELU = 2, PROMP_OUT_ACT_SHIFT = 8 };
 
 enum { PROMP_BASELINE_ZERO = 0, PROMP_BASELINE_LINEAR_FEATURE = 1, PROMP_BASELINE_LINEAR_TIME = 2 };
 enum { PROMP_INNER_RATIO = 0,   /* -mean(ratio*adv)   meta_algos/pro_mp.py:59-65   */

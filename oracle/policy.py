@@ -21,9 +21,11 @@ LOG_2PI = float(np.log(2.0 * np.pi))
 
 
 class PolicySpec:
-    def __init__(self, obs_dim, action_dim, hidden_sizes=(64, 64), min_std=1e-6, hidden_act='tanh'):
+    def __init__(self, obs_dim, action_dim, hidden_sizes=(64, 64), min_std=1e-6, hidden_act='tanh', output_act='identity'):
         assert hidden_act in ('tanh', 'relu', 'identity')      # policies/networks/mlp.py:47 (None = identity)
+        assert output_act in ('tanh', 'relu', 'identity')      # policies/networks/mlp.py:53-60, 114-117: output_nonlinearity on the mean (None = identity)
         self.hidden_act = hidden_act
+        self.output_act = output_act
         self.obs_dim = int(obs_dim)
         self.action_dim = int(action_dim)
         self.hidden_sizes = tuple(int(h) for h in hidden_sizes)
@@ -93,7 +95,7 @@ def forward(spec, theta, obs, clip_log_std):
     nl = len(spec.layer_shapes)
     for li in range(nl):
         z = x @ parts[2 * li] + parts[2 * li + 1]
-        x = act_f(spec.hidden_act, z) if li < nl - 1 else z
+        x = act_f(spec.hidden_act, z) if li < nl - 1 else act_f(spec.output_act, z)      # mlp.py:114-117
         acts.append(x)
     s_raw = parts[-1].reshape(-1)
     if clip_log_std:

@@ -45,7 +45,7 @@ def _backprop(spec, cache, dmu, ds):
     acts, parts = cache['acts'], cache['parts']
     nl = len(spec.layer_shapes)
     grads = [None] * (2 * nl + 1)
-    dz = dmu
+    dz = dmu * act_d(spec.output_act, acts[nl])          # output_nonlinearity (mlp.py:114-117; identity: ones)
     for li in range(nl - 1, -1, -1):
         grads[2 * li] = acts[li].T @ dz
         grads[2 * li + 1] = dz.sum(axis=0)
@@ -126,7 +126,7 @@ def hvp(spec, theta, slab, v, kind, clip_log_std):
     Rx = Racts[0]
     for li in range(nl):
         Rz = Rx @ parts[2 * li] + acts[li] @ vparts[2 * li] + vparts[2 * li + 1]
-        Rx = act_d(spec.hidden_act, acts[li + 1]) * Rz if li < nl - 1 else Rz
+        Rx = act_d(spec.hidden_act if li < nl - 1 else spec.output_act, acts[li + 1]) * Rz
         Racts.append(Rx)
     Rmu = Racts[-1]
     Rs = vparts[-1].reshape(-1) * s_mask
@@ -151,7 +151,8 @@ def hvp(spec, theta, slab, v, kind, clip_log_std):
     Rds = np.sum(Rc[:, None] * (z ** 2 - 1.0) + c[:, None] * 2.0 * z * Rzn, axis=0)
     # ---- R-backward
     out = [None] * (2 * nl + 1)
-    dz, Rdz = dmu, Rdmu
+    d_out = act_d(spec.output_act, mu)                   # through the output nonlinearity (identity: ones, zero curvature)
+    dz, Rdz = dmu * d_out, Rdmu * d_out + dmu * act_dd_over_d(spec.output_act, mu) * Rmu
     for li in range(nl - 1, -1, -1):
         out[2 * li] = Racts[li].T @ dz + acts[li].T @ Rdz
         out[2 * li + 1] = Rdz.sum(axis=0)

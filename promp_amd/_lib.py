@@ -425,18 +425,35 @@ def hidden_act_id(act):
     return HIDDEN_ACTS[name]
 
 
+OUTPUT_ACTS = dict(identity=0, tanh=1, relu=2)      # PROMP_OUT_ACT_*: bits 8.. of promp_dims.hidden_act
+OUT_ACT_SHIFT = 8
+
+
+def output_act_id(act):
+    """the reference's output_nonlinearity argument (policies/networks/mlp.py:53-60, 114-117: a TF function applied to the mean
+    network's last layer, or None -- what every run script passes) -> PROMP_OUT_ACT_*; anything else is refused by name"""
+    if act is None:
+        return OUTPUT_ACTS['identity']
+    name = act if isinstance(act, str) else getattr(act, '__name__', '')
+    name = {'linear': 'identity'}.get(name, name)
+    if name not in OUTPUT_ACTS:
+        raise PrompError('output nonlinearity %r unsupported: None (linear), tanh or relu' % (act,))
+    return OUTPUT_ACTS[name]
+
+
 class Context:
     """One promp_ctx (one GPU).  Thin, NumPy-in / NumPy-out."""
 
     def __init__(self, n_tasks, obs_dim, act_dim, hidden_sizes, num_inner_steps=1, max_rows=0, max_paths=0,
-                 n_tasks_global=None, device_id=0, lib=None, hidden_act='tanh'):
+                 n_tasks_global=None, device_id=0, lib=None, hidden_act='tanh', output_act=None):
         self.lib = lib or get_library()
         hs = tuple(int(h) for h in hidden_sizes)
         if not 1 <= len(hs) <= 4:
             raise PrompError('hidden_sizes %r unsupported: 1 to 4 hidden layers' % (hidden_sizes,))
         h4 = hs + (0,) * (4 - len(hs))
         self.dims = Dims(int(n_tasks), int(n_tasks_global or n_tasks), int(obs_dim), int(act_dim), h4[0], h4[1],
-                         int(num_inner_steps), int(max_rows), int(max_paths), len(hs), h4[2], h4[3], hidden_act_id(hidden_act))
+                         int(num_inner_steps), int(max_rows), int(max_paths), len(hs), h4[2], h4[3],
+                         hidden_act_id(hidden_act) | (output_act_id(output_act) << OUT_ACT_SHIFT))
         self._h = _P()
         self.lib.check(self.lib.cdll.promp_ctx_create(C.byref(self._h), int(device_id), C.byref(self.dims)))
         self.n_params = self.lib.cdll.promp_param_count(C.byref(self.dims))

@@ -283,9 +283,16 @@ static HiddenList hidden_list(const promp_dims* d) {
 }
 // which family of pass kernels serves a network shape (sample processing alone works for any obs_dim <= 128)
 #define PROMP_LINFEAT_MAX_O 480     // LinearFeatureBaseline on the device: 2 obs_dim + 5 <= 965 columns (16 feature rows + their observations in LDS)
+// what the layer-by-layer kernels read as GenArgs.act_kind: the hidden nonlinearity's code in the low byte, the output
+// nonlinearity's (mlp.py:53-60, 114-117; none = identity) above it
+static int gen_act_kinds(const promp_dims* d) {
+    const int out = d->hidden_act >> PROMP_OUT_ACT_SHIFT;
+    const int ok = out == PROMP_OUT_ACT_TANH ? GEN_ACT_TANH : out == PROMP_OUT_ACT_RELU ? GEN_ACT_RELU : GEN_ACT_IDENTITY;
+    return (d->hidden_act & 0xff) | (ok << 8);
+}
 bool policy_shape_generic(const promp_dims* d) {   // layer-by-layer kernels (promp_kernels_generic.h): everything the fused ones do not cover
     const HiddenList L = hidden_list(d);
-    return L.n != 2 || d->obs_dim > 128 || d->act_dim > 8 || d->hidden1 > 128 || d->hidden2 > 128 || d->hidden_act != PROMP_ACT_TANH;
+    return L.n != 2 || d->obs_dim > 128 || d->act_dim > 8 || d->hidden1 > 128 || d->hidden2 > 128 || d->hidden_act != PROMP_ACT_TANH;      // (an output nonlinearity sits in the upper bits: != too)
 }
 bool policy_shape_chain(const promp_dims* d) {     // register-chained kernels: hidden widths from {32, 64}, obs_dim <= 32
     return !policy_shape_generic(d) && d->obs_dim <= 32 && (d->hidden1 == 32 || d->hidden1 == 64) && (d->hidden2 == 32 || d->hidden2 == 64);
@@ -307,8 +314,10 @@ int check_dims(const promp_dims* d) {
             return fail(-1, "hidden size %d (layer %d) unsupported: tanh layers of 1..%d units.  Two layers of up to 128 units run on the fused "
                         "kernels (narrower ones zero-padded on the instantiated widths: every combination of {32, 64} for obs_dim <= 32, "
                         "(64,64) / (128,128) otherwise); wider layers and other depths on the layer-by-layer kernels", L.h[l], l, GEN_MAX_N);
-    if (d->hidden_act < PROMP_ACT_TANH || d->hidden_act > PROMP_ACT_IDENTITY)
-        return fail(-1, "hidden_act %d unknown (0 tanh, 1 relu, 2 identity)", d->hidden_act);
+    if ((d->hidden_act & 0xff) > PROMP_ACT_IDENTITY || d->hidden_act < 0)
+        return fail(-1, "hidden_act %d unknown (0 tanh, 1 relu, 2 identity)", d->hidden_act & 0xff);
+    if ((d->hidden_act >> PROMP_OUT_ACT_SHIFT) > PROMP_OUT_ACT_RELU)
+        return fail(-1, "output nonlinearity %d unknown (0 none, 1 tanh, 2 relu)", d->hidden_act >> PROMP_OUT_ACT_SHIFT);
     if (d->num_inner_steps < 1 || d->num_inner_steps > PROMP_ETA_MAX) return fail(-1, "num_inner_steps must be in [1, %d]", PROMP_ETA_MAX);
     if (d->max_rows < 1 || d->max_paths < 1) return fail(-1, "max_rows / max_paths must be positive");
     return 0;
@@ -380,7 +389,7 @@ int launch_pass_generic(promp_ctx* c, StepData& S, const PassArgs& a, bool hvp, 
     g.work = a.work; g.task_row_offsets = a.task_row_offsets;
     g.n_lin = c->n_lin;
     for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
-    g.O = a.O; g.A = a.A; g.NP = c->NP; g.act_kind = c->d.hidden_act;
+    g.O = a.O; g.A = a.A; g.NP = c->NP; g.act_kind = gen_act_kinds(&c->d);
     g.theta = a.theta; g.theta_task_stride = a.theta_task_stride; g.vdir = a.vdir;
     g.act[0] = a.obs;
     for (int l = 1; l < c->n_lin; ++l) { g.act[l] = c->g_act[l]; g.out_act[l] = c->g_act[l]; g.ract[l] = c->g_ract[l]; }
@@ -1903,7 +1912,7 @@ int promp_policy_forward(promp_ctx* c, const float* obs, int batch, float* mean_
     if (c->generic) {
         GenForwardArgs gf;
         gf.obs = d_obs; gf.theta_tasks = c->theta_tasks; gf.mean = d_out; gf.scratch = d_out + n_out;
-        gf.B = batch; gf.NP = c->NP; gf.n_lin = c->n_lin; gf.maxw = c->g_maxw; gf.act_kind = c->d.hidden_act;
+        gf.B = batch; gf.NP = c->NP; gf.n_lin = c->n_lin; gf.maxw = c->g_maxw; gf.act_kind = gen_act_kinds(&c->d);
         for (int l = 0; l < c->n_lin; ++l) gf.lin[l] = c->lin[l];
         PROMP_LAUNCH(k_gen_policy_forward, dim3(M), 256, 0, c->stream, gf);
     } else
@@ -1976,7 +1985,7 @@ int promp_rollout_point_env(promp_ctx* c, int step, int envs_per_task, int path_
     a.normalization_scale = o->normalization_scale; a.max_step = o->max_step; a.reward_type = o->reward_type; a.sparse_radius = o->sparse_radius;
     if (c->generic) {          // any layer table: one workgroup per environment (promp_kernels_generic.h)
         GenPointRolloutArgs g;
-        g.p = a; g.n_lin = c->n_lin; g.act_kind = c->d.hidden_act;
+        g.p = a; g.n_lin = c->n_lin; g.act_kind = gen_act_kinds(&c->d);
         for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
         PROMP_LAUNCH(k_gen_point_rollout, dim3(B, M), 256, gen_rollout_smem(2), st, g);
     } else
@@ -2082,7 +2091,7 @@ int promp_policy_step(promp_ctx* c, int step, int t, const float* obs, uint64_t 
     a.seed = seed; a.stream = (unsigned)step;
     if (c->generic) {          // any layer table: one workgroup per environment (promp_kernels_generic.h)
         GenPolicyStepArgs g;
-        g.p = a; g.n_lin = c->n_lin; g.act_kind = c->d.hidden_act;
+        g.p = a; g.n_lin = c->n_lin; g.act_kind = gen_act_kinds(&c->d);
         for (int l = 0; l < c->n_lin; ++l) g.lin[l] = c->lin[l];
         PROMP_LAUNCH(k_gen_policy_step, dim3(B, M), 256, gen_rollout_smem(O), st, g);
     } else

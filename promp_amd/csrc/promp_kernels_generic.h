@@ -60,7 +60,8 @@ struct GenArgs {
     float min_log_std;
     float kl_weight;
     float* row_tan;
-    int act_kind;                      // hidden nonlinearity: GEN_ACT_TANH / _RELU / _IDENTITY (policies/networks/mlp.py:47 takes any)
+    int act_kind;                      // low byte: hidden nonlinearity, GEN_ACT_TANH / _RELU / _IDENTITY (policies/networks/mlp.py:47 takes any);
+                                       // bits 8..: the same code for output_nonlinearity (mlp.py:53-60, 114-117; none = GEN_ACT_IDENTITY): gen_hidden / gen_out
     // the BF16 plane copies of the parameters / of minus the direction (promp_kernels_generic_bf16.h: k_gb_planes), 16-bit elements
     const unsigned short *wplanes, *vplanes;
     long long wplane_stride, vplane_stride;        // per task (0: one copy for all tasks)
@@ -71,6 +72,8 @@ enum { GEN_FWD = 0, GEN_FWD_T = 1, GEN_BWD = 2, GEN_BWD_T = 3 };
 // Hidden nonlinearities.  The derivative is a function of the OUTPUT for all three (tanh: 1 - h^2; relu: h > 0, TF's relu'(0) = 0;
 // identity: 1), so the backward kernels need no pre-activations; only tanh has a second derivative (-2 h (1 - h^2)).
 enum { GEN_ACT_TANH = 0, GEN_ACT_RELU = 1, GEN_ACT_IDENTITY = 2 };
+PROMP_DEV int gen_hidden(int packed) { return packed & 0xff; }
+PROMP_DEV int gen_out(int packed) { return packed >> 8; }
 PROMP_DEV float gen_act(int kind, float z) { return kind == GEN_ACT_TANH ? fast_tanh(z) : kind == GEN_ACT_RELU ? fmaxf(z, 0.f) : z; }
 PROMP_DEV float gen_act_d(int kind, float h) { return kind == GEN_ACT_TANH ? 1.f - h * h : kind == GEN_ACT_RELU ? (h > 0.f ? 1.f : 0.f) : 1.f; }
 PROMP_HD int gen_wgrad_ld(int N) { return 64 * ((N + 63) / 64) + 16; }
@@ -209,11 +212,12 @@ __global__ void __launch_bounds__(256) k_gen_linear(GenArgs a, int li, int pp) {
                             const int row = 16 * rb + 4 * kk + r;
                             if (row < nrows) {
                                 const float z = acc[rb][c][r] + b;
-                                const float h = last ? z : gen_act(a.act_kind, z);
+                                const int kind = last ? gen_out(a.act_kind) : gen_hidden(a.act_kind);
+                                const float h = gen_act(kind, z);
                                 Hout[(long long)(row0 + row) * Nc + col] = h;
                                 if (TAN) {
                                     const float rz = racc[rb][c][r] + ub;
-                                    RHout[(long long)(row0 + row) * Nc + col] = last ? rz : gen_act_d(a.act_kind, h) * rz;
+                                    RHout[(long long)(row0 + row) * Nc + col] = gen_act_d(kind, h) * rz;
                                 }
                             }
                         }
@@ -234,10 +238,10 @@ __global__ void __launch_bounds__(256) k_gen_linear(GenArgs a, int li, int pp) {
                         for (int r = 0; r < 4; ++r) {
                             const int row = 16 * rb + 4 * kk + r;
                             const long long o = (long long)(row0 + (row < nrows ? row : nrows - 1)) * Nc + col;
-                            const float h = Hp[o], rh = TAN ? RHp[o] : 0.f, d1 = gen_act_d(a.act_kind, h), dx = acc[rb][c][r];
+                            const float h = Hp[o], rh = TAN ? RHp[o] : 0.f, d1 = gen_act_d(gen_hidden(a.act_kind), h), dx = acc[rb][c][r];
                             if (row < nrows) {
                                 DZo[o] = dx * d1;
-                                if (TAN) QZo[o] = racc[rb][c][r] * d1 - (a.act_kind == GEN_ACT_TANH ? 2.f * dx * h * rh : 0.f);
+                                if (TAN) QZo[o] = racc[rb][c][r] * d1 - (gen_hidden(a.act_kind) == GEN_ACT_TANH ? 2.f * dx * h * rh : 0.f);
                             }
                         }
                 }
@@ -418,6 +422,7 @@ __global__ void __launch_bounds__(256) k_gen_loss(GenArgs a, int pp) {
     float ssum = 0.f;          // sum of the log standard deviations (log-likelihood objective)
     for (int j = 0; j < A; ++j) ssum += cst[j];
     const bool is_kl = a.loss_kind == LOSS_KL, is_ratio = a.loss_kind == LOSS_RATIO, is_clip = a.loss_kind == LOSS_CLIP;
+    const int out_kind = gen_out(a.act_kind);
     const int cj = tid & 63, cq = tid >> 6;
     float gacc = 0.f;          // this thread's share of the log_std gradient of action cj
     for (int base = wk.row_begin; base < wk.row_end; base += 256) {
@@ -489,6 +494,11 @@ __global__ void __launch_bounds__(256) k_gen_loss(GenArgs a, int pp) {
                     os = Rds + a.kl_weight * dkls;
                 }
             }
+            if (out_kind != GEN_ACT_IDENTITY) {      // output_nonlinearity (mlp.py:114-117): mu = f(z), d / dz = f'(z) d / dmu, and its R-operator
+                const float d1 = gen_act_d(out_kind, mu);
+                if (HVP) q = q * d1 - (out_kind == GEN_ACT_TANH ? 2.f * d * mu * g_rmu[(long long)n * A + j] : 0.f);
+                d *= d1;
+            }
             if (rv) {
                 g_dz[(long long)n * A + j] = d;
                 if (HVP) g_qz[(long long)n * A + j] = q;
@@ -539,7 +549,7 @@ __global__ void __launch_bounds__(256) k_gen_policy_forward(GenForwardArgs a) {
             for (int j = 0; j < Ly.N; ++j) {
                 float z = th[Ly.b_off + j];
                 for (int k = 0; k < Ly.K; ++k) z = fmaf(x[k], th[Ly.w_off + k * Ly.N + j], z);
-                y[j] = last ? z : gen_act(a.act_kind, z);
+                y[j] = gen_act(last ? gen_out(a.act_kind) : gen_hidden(a.act_kind), z);
             }
             x = y;
         }
@@ -564,7 +574,7 @@ PROMP_DEV const float* gen_mlp_block(const float* th, const GenLin* lin, int n_l
         if (tid < Ly.N) {
             float z = th[Ly.b_off + tid];
             for (int k = 0; k < Ly.K; ++k) z = fmaf(in[k], th[Ly.w_off + k * Ly.N + tid], z);
-            out[tid] = l == n_lin - 1 ? z : gen_act(act_kind, z);
+            out[tid] = gen_act(l == n_lin - 1 ? gen_out(act_kind) : gen_hidden(act_kind), z);
         }
         __syncthreads();
         in = out;

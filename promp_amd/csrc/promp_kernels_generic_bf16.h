@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_gb_linear(GenArgs a, int li, int pp) {
         // loads over this block's stores, 128 more live registers --: load / store pairs in one loop ran one memory round trip after
         // the other, 90 us per launch at 256 x 256).  The nonlinearity is a compile-time constant inside the loops.
         GB_PHASE(4);
-        const int kind = (FWD && last) ? GEN_ACT_IDENTITY : a.act_kind;
+        const int kind = (FWD && last) ? gen_out(a.act_kind) : gen_hidden(a.act_kind);
         auto epilogue = [&](auto kind_c) {
             constexpr int KIND = decltype(kind_c)::value;
             const int hz = hi + opaque_zero();      // (per round: keeps the block offsets below from being hoisted out of the row loop and spilled)

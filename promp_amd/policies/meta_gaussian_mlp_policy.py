@@ -26,12 +26,14 @@ class MetaGaussianMLPPolicy(object):
         """meta_batch_size is the number of tasks THIS process holds.  In a task-sharded run (one process per GPU under
         torchrun) rank / world / device default to RANK / WORLD_SIZE / LOCAL_RANK and n_tasks_global to
         meta_batch_size * world: the meta-gradient is then the mean over all ranks' tasks (one RCCL all-reduce per epoch)."""
-        assert output_nonlinearity is None, 'only a linear output layer is implemented'
         # policies/base.py:31, networks/mlp.py:47: tanh (the default), relu, or None = LINEAR hidden layers (what
         # tf.layers.dense(activation=None) builds) -- anything else is refused by name, nothing is silently replaced
-        from .._lib import hidden_act_id, HIDDEN_ACTS
+        from .._lib import hidden_act_id, HIDDEN_ACTS, output_act_id, OUTPUT_ACTS
         act_id = hidden_act_id(hidden_nonlinearity)
         self.hidden_nonlinearity = [k for k, v in HIDDEN_ACTS.items() if v == act_id][0]
+        # output_nonlinearity (mlp.py:53-60, 114-117): applied to the mean network's last layer; None (every run script), tanh or relu
+        out_id = output_act_id(output_nonlinearity)
+        self.output_nonlinearity = [k for k, v in OUTPUT_ACTS.items() if v == out_id][0]
         self.meta_batch_size = int(meta_batch_size)
         self.obs_dim, self.action_dim = int(np.prod(obs_dim)), int(np.prod(action_dim))
         self.name = name
@@ -64,7 +66,8 @@ class MetaGaussianMLPPolicy(object):
         device_id = (env_local if world > 1 else 0) if device_id is None else int(device_id)
         self.session = session_mod.DeviceSession(self.meta_batch_size, self.obs_dim, self.action_dim, self.hidden_sizes,
                                                  n_tasks_global=n_tasks_global or self.meta_batch_size * world,
-                                                 device_id=device_id, rank=rank, world=world, hidden_act=self.hidden_nonlinearity)
+                                                 device_id=device_id, rank=rank, world=world, hidden_act=self.hidden_nonlinearity,
+                                                 output_act=self.output_nonlinearity)
         self.session.min_std = float(min_std)
         self.session.learn_std = bool(learn_std)      # False: log_std is neither adapted nor trained (gaussian_mlp_policy.py:63-69)
         self.session.set_theta(self._flatten(parts))

@@ -26,13 +26,14 @@ class SamplesData(dict):
 
 class DeviceSession:
     def __init__(self, meta_batch_size, obs_dim, action_dim, hidden_sizes, num_inner_grad_steps=1,
-                 n_tasks_global=None, device_id=0, rank=0, world=1, hidden_act='tanh'):
+                 n_tasks_global=None, device_id=0, rank=0, world=1, hidden_act='tanh', output_act=None):
         global _current, _serial
         _serial += 1
         self.serial = _serial
         self.M, self.O, self.A = int(meta_batch_size), int(obs_dim), int(action_dim)
         self.hidden = tuple(int(h) for h in hidden_sizes)
         self.hidden_act = hidden_act
+        self.output_act = output_act
         self.K = int(num_inner_grad_steps)
         self.M_global = int(n_tasks_global or meta_batch_size)
         self.device_id, self.rank, self.world = device_id, rank, world
@@ -133,7 +134,8 @@ class DeviceSession:
             if old is not None:
                 self.pull_state()
             self.ctx = _lib.Context(self.M, self.O, self.A, self.hidden, self.K, max_rows=cap[0], max_paths=cap[1],
-                                    n_tasks_global=self.M_global, device_id=self.device_id, hidden_act=self.hidden_act)
+                                    n_tasks_global=self.M_global, device_id=self.device_id, hidden_act=self.hidden_act,
+                                    output_act=self.output_act)
             if old is not None:
                 # ranks with ragged batches regrow at different times: the communicator moves to the new context instead
                 # of a fresh rendezvous (which would wait for peers that are not regrowing)

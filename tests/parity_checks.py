@@ -177,21 +177,22 @@ def check_fit_phases_equal_one_launch(lib, seed, M=3, P=6, T=100, O=376):
     assert np.array_equal(outs[0]['advantages'], outs[1]['advantages'])
 
 
-def make_ctx(lib, M, O, A, hidden, K, all_paths, n_tasks_global=None, hidden_act='tanh'):
+def make_ctx(lib, M, O, A, hidden, K, all_paths, n_tasks_global=None, hidden_act='tanh', output_act=None):
     R = max(sum(len(p['rewards']) for pl in paths.values() for p in pl) for paths in all_paths)
     NPaths = max(sum(len(pl) for pl in paths.values()) for paths in all_paths)
-    return _lib.Context(M, O, A, hidden, K, max_rows=R, max_paths=NPaths, lib=lib, n_tasks_global=n_tasks_global, hidden_act=hidden_act)
+    return _lib.Context(M, O, A, hidden, K, max_rows=R, max_paths=NPaths, lib=lib, n_tasks_global=n_tasks_global, hidden_act=hidden_act,
+                        output_act=output_act)
 
 
 def check_loss_grad(lib, seed, M, P, T, O, A, hidden, ragged=False, compact_log_std=False, low_log_std=False, min_std=1e-6,
-                    hidden_act='tanh'):
+                    hidden_act='tanh', output_act=None):
     """low_log_std: some log_std entries below log(min_std), i.e. the tf.maximum clip is active.  At the default min_std = 1e-6
     values are not comparable in float32 (see below); with a benign min_std (0.5) they are, and are compared."""
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=ragged,
                                                           low_log_std=low_log_std, min_std=min_std)
-    spec = op.PolicySpec(O, A, hidden, min_std=min_std, hidden_act=hidden_act)
+    spec = op.PolicySpec(O, A, hidden, min_std=min_std, hidden_act=hidden_act, output_act=output_act or 'identity')
     comparable = not low_log_std or min_std > 1e-3
-    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths, hidden_act=hidden_act)
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths, hidden_act=hidden_act, output_act=output_act)
     ctx.set_min_std(min_std)
     helpers.upload_slabs(ctx, all_paths, all_slabs, compact_log_std=compact_log_std)
     rng = np.random.RandomState(seed + 1)
@@ -217,10 +218,10 @@ def check_loss_grad(lib, seed, M, P, T, O, A, hidden, ragged=False, compact_log_
     ctx.close()
 
 
-def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False, hidden_act='tanh'):
+def check_hvp(lib, seed, M, P, T, O, A, hidden, ragged=False, hidden_act='tanh', output_act=None):
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, 1, ragged=ragged)
-    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act)
-    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths, hidden_act=hidden_act)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act, output_act=output_act or 'identity')
+    ctx = make_ctx(lib, M, O, A, hidden, 1, all_paths, hidden_act=hidden_act, output_act=output_act)
     helpers.upload_slabs(ctx, all_paths, all_slabs)
     rng = np.random.RandomState(seed + 2)
     th = (theta + 0.02 * rng.randn(M, theta.size)).astype(np.float32)
@@ -405,11 +406,11 @@ def check_adam_golden(lib, name):
     return worst, excluded
 
 
-def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, compact_log_std=False, hidden_act='tanh'):
+def check_meta(lib, seed, M, P, T, O, A, hidden, K, ragged=False, epochs=2, compact_log_std=False, hidden_act='tanh', output_act=None):
     """meta-objective + exact gradient, _adapt, and E Adam epochs + compute_stats."""
     theta, all_slabs, all_paths = helpers.make_promp_case(seed, M, P, T, O, A, hidden, K, ragged=ragged)
-    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act)
-    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths, hidden_act=hidden_act)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act, output_act=output_act or 'identity')
+    ctx = make_ctx(lib, M, O, A, hidden, K, all_paths, hidden_act=hidden_act, output_act=output_act)
     helpers.upload_slabs(ctx, all_paths, all_slabs, compact_log_std=compact_log_std)
     alpha = np.full(spec.n_params, 0.1, np.float32)
     eta = np.array([5e-4, 1e-3, 2e-3][:K], np.float32)

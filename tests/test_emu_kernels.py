@@ -116,6 +116,15 @@ def test_hidden_nonlinearities_other_than_tanh(lib, two_cus, act):
     pc.check_meta(lib, 43, M=2, P=1, T=30, O=6, A=3, hidden=(32, 32), K=1, epochs=1, hidden_act=act)
 
 
+@pytest.mark.parametrize('act,out', [('tanh', 'tanh'), ('relu', 'relu')])
+def test_output_nonlinearity(lib, two_cus, act, out):
+    # policies/networks/mlp.py:53-60, 114-117: output_nonlinearity on the mean network's last layer (None in every run script of the
+    # reference); any policy that has one runs on the layer-by-layer kernels: objective, gradient, R-operator product, Adam epochs
+    pc.check_loss_grad(lib, 44, M=2, P=1, T=33, O=6, A=3, hidden=(32, 32), hidden_act=act, output_act=out)
+    pc.check_hvp(lib, 45, M=1, P=1, T=40, O=6, A=3, hidden=(32, 32), hidden_act=act, output_act=out)
+    pc.check_meta(lib, 46, M=2, P=1, T=30, O=6, A=3, hidden=(32, 32), K=1, epochs=1, hidden_act=act, output_act=out)
+
+
 def test_hvp_segments_straddling_tasks(lib, monkeypatch):
     # 3 tasks x ~12 tiles on 2 emulated CUs: the round list is cut into two shares, so a workgroup of k_chain_hvp walks
     # segments of two (or all three) tasks one after the other and is the last arriver for some of them

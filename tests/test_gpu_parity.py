@@ -128,6 +128,17 @@ def test_hidden_nonlinearities_other_than_tanh(lib, act, hidden, O, A):
     pc.check_meta(lib, 83, M=3, P=2, T=50, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2, hidden_act=act)
 
 
+@pytest.mark.parametrize('act,out,hidden,O,A', [('tanh', 'tanh', (64, 64), 20, 6), ('relu', 'tanh', (128, 128), 111, 8),
+                                                ('tanh', 'relu', (64, 64, 64), 20, 6), ('tanh', 'tanh', (256, 256), 20, 6)])
+def test_output_nonlinearity(lib, act, out, hidden, O, A):
+    """policies/networks/mlp.py:53-60, 114-117: output_nonlinearity is an argument of the mean network (None in the reference's run
+    scripts).  tanh / relu on the last layer run on the layer-by-layer kernels at any shape: objective, gradient, Hessian-vector
+    product, _adapt, Adam epochs against the float64 oracle (itself pinned by torch.autograd: tests/test_oracle_policy.py)"""
+    pc.check_loss_grad(lib, 84, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True, hidden_act=act, output_act=out)
+    pc.check_hvp(lib, 85, M=2, P=2, T=45, O=O, A=A, hidden=hidden, ragged=True, hidden_act=act, output_act=out)
+    pc.check_meta(lib, 86, M=3, P=2, T=50, O=O, A=A, hidden=hidden, K=1, ragged=True, epochs=2, hidden_act=act, output_act=out)
+
+
 def test_generic_policy_shapes_two_inner_steps_and_trpo_constraint(lib):
     pc.check_meta(lib, 75, M=3, P=2, T=50, O=20, A=6, hidden=(64, 64, 64), K=2, ragged=True, epochs=2)
     pc.check_exact_constraint_hvp(lib, 76, M=2, P=2, T=40, O=20, A=6, hidden=(64, 64, 64), K=1)

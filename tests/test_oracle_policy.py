@@ -170,22 +170,24 @@ def test_sharded_partial_sums_add_up():
     np.testing.assert_allclose(p0['inner_kl'] + p1['inner_kl'], full['inner_kl'], rtol=1e-12)
 
 
-@pytest.mark.parametrize('act', ['relu', 'identity', 'tanh'])
-def test_hidden_nonlinearities_gradient_and_hvp_match_torch_autograd(act):
+@pytest.mark.parametrize('act,out_act', [('relu', 'identity'), ('identity', 'identity'), ('tanh', 'identity'), ('tanh', 'tanh'),
+                                         ('relu', 'tanh'), ('tanh', 'relu')])
+def test_hidden_nonlinearities_gradient_and_hvp_match_torch_autograd(act, out_act):
     """policies/networks/mlp.py:47 takes any hidden_nonlinearity (policies/base.py:31 defaults to tanh; None builds linear hidden
     layers).  The oracle's hand-derived gradient and R-operator product for relu / identity, against torch.autograd on a
     transcription of the forward arithmetic (double backward for the Hessian-vector product; relu'' = 0, relu'(0) = 0 as in TF)."""
     torch = pytest.importorskip('torch')
     O, A, hidden = 7, 3, (12, 10)
     theta, all_slabs, _ = helpers.make_promp_case(5, 1, 2, 25, O, A, hidden, 1)
-    spec = op.PolicySpec(O, A, hidden, hidden_act=act)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=act, output_act=out_act)     # (output_nonlinearity: mlp.py:53-60, 114-117)
     slab = all_slabs[0][0]
     t64 = theta.astype(np.float64)
     obs, acts = torch.tensor(slab['observations'], dtype=torch.float64), torch.tensor(slab['actions'], dtype=torch.float64)
     adv = torch.tensor(slab['advantages'], dtype=torch.float64)
     om = torch.tensor(slab['agent_infos']['mean'], dtype=torch.float64)
     ols = torch.tensor(slab['agent_infos']['log_std'], dtype=torch.float64)
-    f = dict(tanh=torch.tanh, relu=torch.relu, identity=lambda x: x)[act]
+    fs = dict(tanh=torch.tanh, relu=torch.relu, identity=lambda x: x)
+    f, f_out = fs[act], fs[out_act]
 
     def loss_fn(th, kind):
         x, off = obs, 0
@@ -196,8 +198,7 @@ def test_hidden_nonlinearities_gradient_and_hvp_match_torch_autograd(act):
             b = th[off:off + sizes[i + 1]]
             off += sizes[i + 1]
             x = x @ W + b
-            if i < len(sizes) - 2:
-                x = f(x)
+            x = f(x) if i < len(sizes) - 2 else f_out(x)
         s = th[off:off + A]
         lp = -s.sum() - 0.5 * (((acts - x) * torch.exp(-s)) ** 2).sum(1)
         lp_old = -ols.sum(1) - 0.5 * (((acts - om) * torch.exp(-ols)) ** 2).sum(1)

@@ -246,7 +246,7 @@ def test_device_rollout_point_env(emu):
     run_device_rollout_scenario(M=2, B=3, T=9, reward_type='dense_squared')
 
 
-def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32), hidden_act='tanh'):
+def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32), hidden_act='tanh', output_act=None):
     """DeviceSlabSampler: every environment step is one promp_policy_step; the slab rows equal the oracle's forward pass plus
     the oracle's Philox noise; rewards arrive once; process_samples uploads nothing; an early `done` falls back to the host."""
     from oracle import philox, policy as op
@@ -271,7 +271,7 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32), hidden_ac
 
     np.random.seed(5)
     policy = MetaGaussianMLPPolicy(name='p', obs_dim=O, action_dim=A, meta_batch_size=M, hidden_sizes=hidden,
-                                   hidden_nonlinearity=None if hidden_act == 'identity' else hidden_act)
+                                   hidden_nonlinearity=None if hidden_act == 'identity' else hidden_act, output_nonlinearity=output_act)
     sampler = DeviceSlabSampler(env=DriftEnv(), policy=policy, rollouts_per_meta_task=B, meta_batch_size=M, max_path_length=T)
     sampler.update_tasks()
     policy.switch_to_pre_update()
@@ -279,7 +279,7 @@ def run_policy_step_scenario(M=2, B=3, T=5, O=4, A=3, hidden=(32, 32), hidden_ac
     paths = sampler.obtain_samples()
     np.random.set_state(state)
     seed = int(np.random.randint(0, 2 ** 31 - 1))
-    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act)
+    spec = op.PolicySpec(O, A, hidden, hidden_act=hidden_act, output_act=output_act or 'identity')
     theta = spec.from_ordered_dict(policy.get_param_values()).astype(np.float64)
     assert sampler.host_fallbacks == 0 and all(len(paths[i]) == B for i in range(M))
     cat = lambda key, sub=None: np.concatenate([(p[key] if sub is None else p[key][sub]) for i in range(M) for p in paths[i]])
@@ -578,6 +578,7 @@ def test_rollout_kernels_on_any_layer_table(emu):
     one workgroup per environment walks the layer table (k_gen_policy_step / k_gen_point_rollout)."""
     run_policy_step_scenario(M=2, B=3, T=5, O=9, A=11, hidden=(48, 40, 24))
     run_policy_step_scenario(M=2, B=2, T=4, O=5, A=3, hidden=(20,), hidden_act='relu')
+    run_policy_step_scenario(M=2, B=2, T=4, O=5, A=3, hidden=(32, 32), output_act='tanh')        # output_nonlinearity (mlp.py:114-117)
     run_device_rollout_scenario(M=2, B=3, T=9, hidden=(32, 16, 24), reward_type='sparse')
     run_device_rollout_scenario(M=2, B=2, T=6, hidden=(24, 24), reward_type='dense', hidden_act='identity')
 
