@@ -315,9 +315,9 @@ int promp_meta_grad(promp_ctx* ctx, float clip_eps, const float* inner_kl_coeff,
  * Every supported policy shape (register-chained and cooperative kernels); the register-chained ones keep primal caches
  * over the products of one solve (promp_set_primal_cache, promp_constraint_hvp_cached_passes). */
 int promp_constraint_hvp(promp_ctx* ctx, int inner_kind, const float* v, int refresh_chain, float* out);
-/* ConjugateGradientOptimizer's whole solve on the device (optimizers/conjugate_gradient_optimizer.py:59-89 cg(); :107-148
- * FiniteDifferenceHvp.build_eval -- the product x -> (H + reg_coeff I) x of the constraint; :258-262 the closing product that
- * sizes the step): cg_iters conjugate-gradient iterations on (H + reg_coeff I) x = b from x = 0, then x . (H + reg_coeff I) x.
+/* ConjugateGradientOptimizer's whole solve on the device (optimizers/conjugate_gradient_optimizer.py:325-354 conjugate_gradients();
+ * :59-104 FiniteDifferenceHvp.Hx / build_eval -- the product x -> (H + reg_coeff I) x of the constraint; :259-264 the solve inside
+ * optimize() and the closing product that sizes the step): cg_iters conjugate-gradient iterations on (H + reg_coeff I) x = b from x = 0, then x . (H + reg_coeff I) x.
  *   hvp_mode 0  H v = (grad c(theta + eps v) - grad c(theta - eps v)) / (2 eps)   (the reference's default: symmetric, eps 1e-5)
  *            1  H v = (grad c(theta + eps v) - grad c(theta)) / eps
  *            2  the exact product of promp_constraint_hvp (eps unused)

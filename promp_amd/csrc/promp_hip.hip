@@ -2274,8 +2274,8 @@ int promp_constraint_hvp(promp_ctx* c, int inner_kind, const float* v, int refre
     return 0;
 }
 
-// ConjugateGradientOptimizer's solve with nothing crossing to the host between its products (conjugate_gradient_optimizer.py:59-89
-// cg(), :107-148 FiniteDifferenceHvp.build_eval, :258-262 the closing product): see include/promp_hip.h.
+// ConjugateGradientOptimizer's solve with nothing crossing to the host between its products (conjugate_gradient_optimizer.py:325-354
+// conjugate_gradients(), :59-104 FiniteDifferenceHvp.Hx / build_eval, :259-264 the solve and the closing product): see include/promp_hip.h.
 int promp_cg_solve(promp_ctx* c, int inner_kind, const float* b, int cg_iters, float reg_coeff, float eps, int hvp_mode,
                    float residual_tol, float* x_out, double* xhx_out) {
     if (!c || !b || !x_out || !xhx_out) return fail(-1, "NULL argument");

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) k_policy_forward(ForwardArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // Conjugate gradients on the device (promp_cg_solve): the vector side of ConjugateGradientOptimizer's solve
-// (optimizers/conjugate_gradient_optimizer.py:59-89) between two products, in ONE launch of one workgroup -- the vectors are
+// (optimizers/conjugate_gradient_optimizer.py:325-354, conjugate_gradients) between two products, in ONE launch of one workgroup -- the vectors are
 // Theta floats (6 k ... 70 k), the launch is a link in a chain of dependent launches and costs what any of them costs.
 // Sums in a fixed order (thread-strided, then a tree over the workgroup) in float64; the vectors stay float32 like the
 // NumPy arrays of the host form.

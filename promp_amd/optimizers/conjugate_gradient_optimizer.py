@@ -1,7 +1,8 @@
 """Trust-region step for TRPO-MAML: ConjugateGradientOptimizer + FiniteDifferenceHvp.
 
 Behaviour contract (what meta_algos/trpo_maml.py and the parity tests rely on; the reference implements the same
-contract in meta_policy_search/optimizers/conjugate_gradient_optimizer.py:59-89, 107-148, 239-354):
+contract in meta_policy_search/optimizers/conjugate_gradient_optimizer.py:8-104 (FiniteDifferenceHvp), 107-307 (ConjugateGradientOptimizer),
+325-354 (conjugate_gradients)):
 
   * the search direction d solves  (H + reg I) d = g  approximately: `cg_iters` conjugate-gradient iterations on products
     H x only, H = Hessian of the constraint (mean KL), g = gradient of the loss;

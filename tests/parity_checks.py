@@ -531,7 +531,7 @@ def on_policy_case(seed, M, P, T, O, A, hidden, K, alpha, inner_kind, ragged=Tru
 
 def check_cg_solve_on_device(lib, seed, M, P, T, O, A, hidden, K=1, inner='loglik', cg_iters=4, fd=True):
     """promp_cg_solve (ConjugateGradientOptimizer's loop with its products enqueued back to back on the device) against the same
-    loop on the host over the library's own products: conjugate_gradient_optimizer.py:59-89 with the exact product (no
+    loop on the host over the library's own products: conjugate_gradient_optimizer.py:325-354 with the exact product (no
     finite-difference noise: the two differ by the rounding of their dot products only) and with the reference's symmetric
     finite differences (one product and the closing quadratic form, where the directions are bitwise the same on both sides:
     over several iterations the noise of eps = 1e-5 in float32 amplifies any rounding difference).  The parameters are back
