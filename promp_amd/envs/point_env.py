@@ -12,6 +12,8 @@ class are the golden vectors tests/golden/point_env_*.npz.
 """
 import numpy as np
 
+from .base import MetaEnv
+
 
 class ActionBox(object):
     """just the attributes the normalize wrapper and the run scripts read from a gym.spaces.Box"""
@@ -22,7 +24,7 @@ class ActionBox(object):
         self.shape = tuple(shape)
 
 
-class MetaPointEnvCorner(object):
+class MetaPointEnvCorner(MetaEnv):
     CORNERS = np.array([[-2.0, -2.0], [2.0, -2.0], [-2.0, 2.0], [2.0, 2.0]])
 
     def __init__(self, reward_type='sparse', sparse_reward_radius=0.5):
