@@ -94,6 +94,29 @@ def test_promp_learns_on_point_env(tmp_path, device_rollouts):
     logger.configure(quiet=True)
 
 
+@pytest.mark.parametrize('exploration', [False, True], ids=['trpo_maml', 'e_maml'])
+def test_trpo_maml_run_script_on_point_env(tmp_path, exploration):
+    """run_scripts/maml_run_point_mass.py (the reference's maml_run_mujoco.py / e-maml_run_mujoco.py on its MuJoCo-free environment):
+    every iteration's trust-region step goes through promp_cg_solve, lowers the surrogate and keeps the mean KL inside the region"""
+    import csv
+    import importlib.util
+    import os
+    from promp_amd.utils import logger
+    spec = importlib.util.spec_from_file_location('run_maml', os.path.join(scen.__file__.rsplit('/tests/', 1)[0], 'run_scripts', 'maml_run_point_mass.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = dict(mod.DEFAULT, n_itr=6, meta_batch_size=4, rollouts_per_meta_task=8, max_path_length=25, seed=5, exploration=exploration)
+    logger.configure(dir=str(tmp_path), quiet=True)
+    mod.main(cfg)
+    rows = list(csv.DictReader(open(os.path.join(str(tmp_path), 'progress.csv'))))
+    assert len(rows) == 6
+    for r in rows:
+        assert float(r['MeanKL']) <= 0.01 * 1.001, r['MeanKL']                      # trpo_maml.py:158: the trust region
+        assert float(r['LossAfter']) <= float(r['LossBefore']) + 1e-9                # a rejected step restores the parameters
+    assert any(float(r['LossAfter']) < float(r['LossBefore']) for r in rows)
+    logger.configure(quiet=True)
+
+
 def test_vpg_maml_on_device():
     scen.run_vpg_scenario(M=4, P=5, T=100, O=20, A=6, hidden=(64, 64), inner_type='log_likelihood')
     scen.run_vpg_scenario(M=3, P=3, T=40, O=5, A=3, hidden=(32, 32), inner_type='likelihood_ratio', exploration=True)
