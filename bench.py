@@ -172,6 +172,8 @@ def main():
             ctx.process_samples(1, **opts)                   # :105  (step 1)
             if trpo:
                 cg = cgs[mode['hvp']]
+                if cg._ev.objectives_ride_on_gradient():      # as TRPOMAML.optimize_policy: the loss gradient's pass yields both values
+                    cg.gradient()
                 kl0, l0 = cg.constraint_val(), cg.loss()
                 cg.optimize()
                 return dict(loss_before=l0, loss_after=cg.loss(), kl_before=kl0, kl_after=cg.constraint_val(),

@@ -14,6 +14,18 @@ class _DeviceEvaluator(object):
     def __init__(self, algo):
         self.algo = algo
         self._memo = None
+        self._gmemo = None       # (key, loss gradient): gradient() twice at one state is one device evaluation
+
+    def _key(self):
+        ctx = self.ctx
+        return (id(ctx), ctx.state_version(), self.algo.inner_kind)
+
+    def objectives_ride_on_gradient(self):
+        """the loss gradient's pass computes the surrogate loss and the mean KL on its way (promp_meta_grad returns them): where that
+        holds for the whole batch -- one process, or ranks under the library's communicator -- and nothing re-enters between the two
+        (the E-MAML term rewrites step 0's advantages for a moment), asking for the gradient FIRST answers the optimizer's 'KL before' /
+        'loss before' queries without a forward pass of their own"""
+        return not self.algo.exploration and not self.algo.session.external()
 
     @property
     def ctx(self):
@@ -65,6 +77,14 @@ class _DeviceEvaluator(object):
         return self._objectives()['outer_kl']
 
     def gradient(self):
+        if self.objectives_ride_on_gradient():
+            if self._gmemo is None or self._gmemo[0] != self._key():
+                g, st = self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)
+                key = self._key()
+                self._gmemo = (key, g)
+                if self._memo is None or self._memo[0] != key:
+                    self._memo = (key, dict(loss=st['loss'], inner_kl=st['inner_kl'], outer_kl=st['outer_kl']))
+            return self._gmemo[1]
         g = self._whole_batch(self.ctx.meta_grad(0.0, self._eta(), self.algo.inner_kind, _lib.OUTER_RATIO)[0])
         return (g + self._exploration(True)[1]).astype(np.float32) if self.algo.exploration else g
 
@@ -128,6 +148,8 @@ class TRPOMAML(MAMLAlgo):
             last = all_samples_data[self.num_inner_grad_steps]
             self._explore_coeffs = np.array([np.mean(np.asarray(d['adj_avg_rewards'], dtype=np.float32)) for d in last], np.float64)
             self._explore_adv0 = np.concatenate([np.asarray(d['advantages'], dtype=np.float32) for d in all_samples_data[0]])
+        if self.optimizer._ev.objectives_ride_on_gradient():
+            self.optimizer.gradient()          # one pass: the gradient optimize() will ask for, and the two values asked for next
         logger.log('Computing KL before')
         mean_kl_before = self.optimizer.constraint_val()
         logger.log('Computing loss before')
