@@ -277,6 +277,14 @@ def main():
     if not np.isfinite(res['loss_after']):
         raise SystemExit('bench: non-finite loss')
     split_events = dict(ctx.split_events(), steps=args.warmup + args.steps * len(loops))      # over the warm-up and every timed loop
+    trpo_last = None
+    if trpo and res is not None:       # what the last timed step's trust-region step did (the same resident batch every step: see the note)
+        trpo_last = {'n_backtracks': int(res.get('n_backtracks', -1)), 'rejected': bool(res.get('rejected', False)),
+                     'kl_before': float(res['kl_before']), 'kl_after': float(res['kl_after']),
+                     'note': 'the resident batch is the same every step: after the first accepted steps the policy sits at the edge of the '
+                             'trust region around the distribution that sampled it, and a timed step then runs the line search to its '
+                             'last candidate (max_backtracks = 15 evaluations) -- the search at its most expensive, in the host-loop '
+                             'figure alike'}
     env_steps = M_global * N * (K + 1) * args.steps
     value = env_steps / elapsed
 
@@ -286,6 +294,7 @@ def main():
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'timed_loops_ms_per_step': [1e3 * e / args.steps for e in loops],
         'fp16_split_events': split_events,
+        **({'trpo_last_step': trpo_last} if trpo_last else {}),
         'config': {'workload': 'BASELINE config %d: %d-task %s shapes (obs=%d, act=%d, 2x%d tanh MLP, H=%d, '
                                'P=%d paths/task, K=1 inner step, %s); process_samples x2 + _adapt + '
                                'optimize_policy per step' % (args.config, M_global, ENV_NAMES[args.config], O, A, hidden[0], T, P,
